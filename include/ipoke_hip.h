@@ -1,0 +1,243 @@
+/*
+ * libipoke_hip -- C ABI of the MI355X (gfx950) implementation of the iPOKE hot path.
+ *
+ * The reference (CompVis/ipoke) is pure Python on PyTorch and has no FFI of its own; every entry
+ * point below replaces the PyTorch op sequence of one reference function (cited per group).  The
+ * reference-side binding a maintainer would add is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all buffers are device memory owned by the caller;
+ *   - every function returns 0 (IPOKE_OK) or a negative ipoke_status, never throws; the message of
+ *     the last failure on the calling thread is available from ipoke_last_error();
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises the host, so every call is
+ *     capturable in a hipGraph;
+ *   - `dtype` selects the arithmetic type of the matrix-core contractions:
+ *         IPOKE_F32  exact-f32 MFMA (v_mfma_f32_16x16x4_f32), parity mode
+ *         IPOKE_BF16 bf16 MFMA inputs, fp32 accumulate (v_mfma_f32_16x16x32_bf16), throughput mode
+ *     Flow state, affine transforms, log-determinants, normalisation statistics, gradients of
+ *     parameters and optimizer state are always fp32.
+ *   - flow state tensors are "positions-major" [B, 64, ld] fp32 (NHWC of the 8x8 latent) inside the
+ *     library; ipoke_nchw_to_state / ipoke_state_to_nchw convert at the boundary.
+ */
+#ifndef IPOKE_HIP_H
+#define IPOKE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  IPOKE_OK = 0,
+  IPOKE_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  IPOKE_ERR_HIP = -2,       /* a HIP runtime call failed        */
+  IPOKE_ERR_STATE = -3      /* call sequence error (e.g. backward without forward) */
+} ipoke_status;
+
+enum { IPOKE_F32 = 0, IPOKE_BF16 = 1 };
+enum { IPOKE_ACT_NONE = 0, IPOKE_ACT_ELU = 1, IPOKE_ACT_RELU = 2, IPOKE_ACT_LRELU02 = 3, IPOKE_ACT_TANH = 4,
+       IPOKE_ACT_SIGMOID = 5 };
+
+const char* ipoke_last_error(void);
+int ipoke_version(void);
+/* size in bytes of one element of `dtype` */
+int ipoke_dtype_size(int dtype);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the matrix cores.
+ * Replaces F.conv2d / nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d call sites of the reference:
+ *   models/modules/INN/macow_utils.py:270-281 (NICE nets), :492-499 (shifted conv),
+ *   models/modules/motion_models/motion_encoder.py:161-241 (Conv3d ResNet),
+ *   models/modules/motion_models/rnn.py:16-18 (ConvGRU gates),
+ *   models/modules/autoencoders/util.py:52-55,252-255 (Conv2d / ConvTranspose2d blocks).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  /* geometry: rows of the GEMM are output positions (n, od, oh, ow); Do, Ho, Wo must be powers of two */
+  int32_t NB, Di, Hi, Wi, Do, Ho, Wo;
+  int32_t kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int32_t transposed;      /* 0: in = out*s - p + k (conv);  1: in = (out + p - k)/s when divisible
+                              (ConvTranspose forward, or data-gradient of a strided conv)          */
+  /* A operand (activations) */
+  const void* A;           /* a_f32 ? float : dtype */
+  int32_t a_f32;           /* 1: A is fp32 and is converted on load (flow state, input images)     */
+  int64_t a_sn, a_sd, a_sh, a_sw, a_sc;  /* element strides of n, d, h, w, channel                 */
+  int32_t a_coff;          /* first channel used                                                   */
+  int32_t Kc_real;         /* channels per tap actually present                                    */
+  int32_t Kc;              /* channels per tap in the K index (>= Kc_real, multiple of 16B/elt)    */
+  /* B operand (weights), dtype, [Nout][ldw] with k = tap*Kc + c, zero padded                      */
+  const void* W;
+  int32_t ldw;
+  int32_t Nout;
+  /* epilogue */
+  const float* bias;       /* [Nout] or NULL                                                       */
+  int32_t act;             /* IPOKE_ACT_* applied after bias                                        */
+  const void* dact;        /* optional [M][ld_dact] dtype: multiply by act'(saved output) (dgrad)  */
+  int32_t ld_dact, dact_act;
+  void* C;                 /* output                                                                */
+  int32_t c_f32;           /* 1: C is fp32, 0: dtype                                                */
+  int32_t c_accumulate;    /* 1: C += result (fp32 only)                                            */
+  int64_t ldc;             /* row stride of C in elements                                           */
+  int32_t c_coff, c_cstride; /* column n is stored at c_coff + n*c_cstride                          */
+  int32_t splitk;          /* >1: fp32 partials C[z][M][ldc], epilogue skipped (bias/act by consumer) */
+} ipoke_conv_desc;
+
+int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
+
+/* Weight gradient: dW[n][tap*Kc + c] (+)= sum_m dY[m][n] * A[src(m,tap)][c].
+ * dY is dtype [M][ldy]; A as in ipoke_conv_desc (fp32 or dtype).  Output fp32, written through a
+ * (n, c, tap) stride triple so PyTorch's [out][in][k...] layout is produced directly. */
+typedef struct {
+  int32_t NB, Di, Hi, Wi, Do, Ho, Wo, kd, kh, kw, sd, sh, sw, pd, ph, pw, transposed;
+  const void* A; int32_t a_f32; int64_t a_sn, a_sd, a_sh, a_sw, a_sc; int32_t a_coff, Kc_real, Kc;
+  const void* dY; int32_t ldy; int32_t y_coff; int32_t Nout;
+  float* dW; int64_t w_sn, w_sc, w_st;   /* strides of out-channel n, in-channel c, tap */
+  int32_t accumulate;                    /* 1: dW += */
+  int32_t splitm;                        /* >1: reduction split over gridDim.z with fp32 atomics (dW must be pre-zeroed or accumulate) */
+} ipoke_wgrad_desc;
+
+int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Flow-state element-wise layers (fp32).  State = [B*P][ld], P = 64 positions of the 8x8 latent.
+ * ------------------------------------------------------------------------------------------- */
+int ipoke_nchw_to_state(const float* x_nchw, float* state, int B, int C, int P, int ld, void* stream);
+int ipoke_state_to_nchw(const float* state, float* x_nchw, int B, int C, int P, int ld, void* stream);
+/* act(cond) in dtype, channels-last: shared input of all MCF 1x1 convs (macow_utils.py:429-431) */
+int ipoke_cond_prepare(const float* cond_nchw, void* out, int B, int Cc, int P, int act, int dtype, void* stream);
+
+/* ActNorm2dFlow (macow2.py:476-540) optionally fused with the Shuffle that follows it
+ * (flow_blocks.py:314-326): out[:, c0+j] = in[:, c0+idx[j]] * exp(ls[idx[j]]) + bias[idx[j]].
+ * log_scale == bias == NULL gives the bare permutation; idx == NULL the bare ActNorm.
+ * The batch-independent log-det H*W*sum(log_scale) is accounted for by ipoke_actnorm_logdet. */
+int ipoke_actnorm_fwd(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
+                      const float* bias, const int32_t* idx, void* stream);
+/* inverse: undo the permutation with inv_idx (= backward_shuffle_idx), then (x - bias)/(exp(ls)+1e-8) */
+int ipoke_actnorm_inv(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
+                      const float* bias, const int32_t* inv_idx, void* stream);
+int ipoke_actnorm_bwd(const float* dy, const float* x, float* dx, int M, int ld, int c0, int C,
+                      const float* log_scale, const int32_t* idx, const float* dld, int B, int P,
+                      float* d_log_scale, float* d_bias, void* stream);
+/* data-dependent init (macow2.py:526-539): overwrites log_scale / bias in place */
+int ipoke_actnorm_init(const float* x, int M, int ld, int c0, int C, float* log_scale, float* bias, void* stream);
+
+/* Affine coupling transform (macow_utils.py:42-66) on the channels t_off + i*t_stride, i < Cp.
+ * raw = [mu | s] is given as nsplit fp32 partial sums (the split-K output of the coupling net's
+ * last conv) plus an optional bias; scale = tanh(s/2) + 1. */
+typedef struct {
+  const float* raw; int32_t nsplit; int64_t split_stride; int32_t ldraw;
+  const float* bias;
+  int32_t Cp, t_off, t_stride;
+  int32_t P, ld;
+} ipoke_affine_desc;
+int ipoke_affine_fwd(const ipoke_affine_desc* d, const float* in, float* out, float* scale_out /* [M][Cp] or NULL */,
+                     float* logdet_slot /* [B*slot_stride] or NULL */, int slot_stride, int B, void* stream);
+int ipoke_affine_inv(const ipoke_affine_desc* d, const float* in, float* out, int B, void* stream);
+int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, const float* dy, const float* x,
+                     const float* scale, const float* dld, float* dx, void* dparams /* dtype [M][ldp] */, int ldp,
+                     float* dbias_part /* [B][2Cp] or NULL */, int B, int dtype, void* stream);
+int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream);
+
+int ipoke_logdet_finalize(const float* slots, int nslots, int B, int slot_w, float const_term, const float* const_dev,
+                          float* logdet, void* stream);
+int ipoke_actnorm_logdet(const float* params, const void* refs_dev, int n, int P, float* out_scalar, void* stream);
+/* FlowLoss (loss.py:6-31,75-79): scalars3 = (loss, nll, nlogdet); optional gradients in state layout */
+int ipoke_flow_nll(const float* z_state, const float* logdet, int B, int P, int C, int ld, float logdet_weight,
+                   float* scalars3, float* d_out_state, float* dld, void* stream);
+/* torch.optim.Adam(amsgrad=True) step over a flat fp32 buffer (second_stage_video.py:648-650) */
+int ipoke_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused masked convolutional flow (macow2.py:25-288, macow_utils.py:407-499).
+ * Weight operands are the shadows produced by ipoke_flow_prepare_weights (dims: ipoke_mcf_shadow_dims).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x; float* y;       /* state in / out (distinct buffers), fwd: x->y, inv: y_in -> x_out */
+  int32_t ld, C, B;
+  const void* cond; int32_t Cc;   /* act(cond), dtype [B*64][Cc] */
+  const void* W1; const void* W2; const float* bias2;
+  int32_t order;                  /* 0..3 = A..D */
+  int32_t rows_per_block;         /* fwd only: 16/32/64, 0 = default */
+  void* a2_save; float* scale_save; float* logdet_slot;   /* fwd saves (may be NULL) */
+  /* backward */
+  const void* W2T; const void* W1T;
+  const float* dy; const float* dld; float* dx;
+  void* dparams_save; void* dc_save; float* dbias_part;
+} ipoke_mcf_desc;
+int ipoke_mcf_shadow_dims(int C, int Cc, int dtype, int32_t* dims8);
+int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream);
+int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream);
+int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream);
+
+/* multi-tensor weight preparation (job tables are built by the flow engine) */
+int ipoke_relayout_job_size(void);
+int ipoke_wn_job_size(void);
+int ipoke_relayout_multi(const float* params, void* shadow, const float* wn_scale, const void* jobs_dev, int njobs,
+                         int total_blocks, int dtype, void* stream);
+int ipoke_wn_scale_multi(const float* params, float* scale, float* inv_norm, const void* jobs_dev, int njobs,
+                         int total_rows, void* stream);
+int ipoke_wn_bwd_multi(const float* params, float* grads, const float* inv_norm, const void* jobs_dev, int njobs,
+                       int total_rows, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Flow engine: the whole SupervisedMacowTransformer (INN.py:446-481; MultiScaleInternal macow2.py:821-920,
+ * MaCowStep :999-1117, MaCowUnit :925-995, MultiScalePrior :543-593) as one native layer program.
+ *
+ * The engine defines the flat fp32 parameter layout (state-dict order of the reference, every tensor
+ * starting on a 16-byte boundary) and reports the reference's state-dict names so the host can expose
+ * named views.  Caller-owned buffers:
+ *     params  float [param_count]          master weights (also: grads, Adam state of the same layout)
+ *     perm    int32 [index_count]          forward/backward shuffle indices
+ *     shadow  bytes [shadow_bytes]         matrix-core weight operands, refreshed by prepare_weights
+ *     workspace bytes [workspace_bytes(B, training)]
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ipoke_flow ipoke_flow;
+typedef struct {
+  int32_t z_channels;       /* flow_in_channels                               */
+  int32_t hidden;           /* flow_mid_channels                              */
+  int32_t cond_channels;    /* h_channels                                     */
+  int32_t factor;
+  int32_t n_levels;
+  int32_t num_steps[32];
+  int32_t kernel_h, kernel_w;
+  int32_t dtype;            /* IPOKE_F32 / IPOKE_BF16                         */
+  int32_t max_batch;
+} ipoke_flow_config;
+
+int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out);
+void ipoke_flow_destroy(ipoke_flow* f);
+int64_t ipoke_flow_param_count(const ipoke_flow* f);
+int64_t ipoke_flow_index_count(const ipoke_flow* f);
+int32_t ipoke_flow_tensor_count(const ipoke_flow* f);
+int32_t ipoke_flow_op_count(const ipoke_flow* f);
+/* kind: 0 float parameter (offset in floats), 1 forward_shuffle_idx, 2 backward_shuffle_idx (offset in
+ * int32 entries of perm), 3 uint8 `initialized` flag (host-side state only, offset -1) */
+int ipoke_flow_tensor_info(const ipoke_flow* f, int i, char* name, int name_cap, int64_t* offset, int32_t* ndim,
+                           int64_t* shape4, int32_t* kind);
+int64_t ipoke_flow_shadow_bytes(const ipoke_flow* f);
+int64_t ipoke_flow_workspace_bytes(ipoke_flow* f, int B, int training);
+/* fold weight norm and lay the weights out for the matrix cores; call after every parameter update */
+int ipoke_flow_prepare_weights(ipoke_flow* f, const float* params, void* shadow, void* stream);
+/* out, logdet = flow(x, cond)   (INN.py:469-473) */
+int ipoke_flow_forward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow, const float* x_nchw,
+                       const float* cond_nchw, int B, float* out_nchw, float* logdet, void* workspace,
+                       int save_for_backward, void* stream);
+/* first forward with initialized == 0 everywhere: data-dependent ActNorm init, zero-init couplings
+ * (macow2.py:503-505,526-539; macow_utils.py:231-250).  Overwrites ActNorm/weight-norm parameters. */
+int ipoke_flow_init_forward(ipoke_flow* f, float* params, const int32_t* perm, const float* x_nchw, int B,
+                            float* out_nchw, float* logdet, void* workspace, void* stream);
+/* x = flow(z, cond, reverse=True)   (INN.py:475-476, macow2.py:901-920) */
+int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow, const float* z_nchw,
+                       const float* cond_nchw, int B, float* x_nchw, void* workspace, void* stream);
+/* parameter gradients (written, not accumulated) and optionally d/dx, given d/d_out and d/d_logdet */
+int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                        const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
+                        void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPOKE_HIP_H */

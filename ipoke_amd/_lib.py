@@ -1,0 +1,156 @@
+"""ctypes binding of ``libipoke_hip.so`` (the C ABI declared in ``include/ipoke_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing or a call
+fails, a ``RuntimeError`` is raised.  Build the library with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C ipoke_amd/csrc``.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libipoke_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_ELU, ACT_RELU, ACT_LRELU02, ACT_TANH, ACT_SIGMOID = range(6)
+
+DTYPES = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("NB", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "kd", "kh", "kw", "sd", "sh", "sw",
+                                       "pd", "ph", "pw", "transposed")] + [
+        ("A", c_void_p), ("a_f32", c_int32),
+        ("a_sn", c_int64), ("a_sd", c_int64), ("a_sh", c_int64), ("a_sw", c_int64), ("a_sc", c_int64),
+        ("a_coff", c_int32), ("Kc_real", c_int32), ("Kc", c_int32),
+        ("W", c_void_p), ("ldw", c_int32), ("Nout", c_int32),
+        ("bias", c_void_p), ("act", c_int32), ("dact", c_void_p), ("ld_dact", c_int32), ("dact_act", c_int32),
+        ("C", c_void_p), ("c_f32", c_int32), ("c_accumulate", c_int32), ("ldc", c_int64),
+        ("c_coff", c_int32), ("c_cstride", c_int32), ("splitk", c_int32)]
+
+
+class WgradDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("NB", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "kd", "kh", "kw", "sd", "sh", "sw",
+                                       "pd", "ph", "pw", "transposed")] + [
+        ("A", c_void_p), ("a_f32", c_int32),
+        ("a_sn", c_int64), ("a_sd", c_int64), ("a_sh", c_int64), ("a_sw", c_int64), ("a_sc", c_int64),
+        ("a_coff", c_int32), ("Kc_real", c_int32), ("Kc", c_int32),
+        ("dY", c_void_p), ("ldy", c_int32), ("y_coff", c_int32), ("Nout", c_int32),
+        ("dW", c_void_p), ("w_sn", c_int64), ("w_sc", c_int64), ("w_st", c_int64),
+        ("accumulate", c_int32), ("splitm", c_int32)]
+
+
+class AffineDesc(Structure):
+    _fields_ = [("raw", c_void_p), ("nsplit", c_int32), ("split_stride", c_int64), ("ldraw", c_int32),
+                ("bias", c_void_p), ("Cp", c_int32), ("t_off", c_int32), ("t_stride", c_int32),
+                ("P", c_int32), ("ld", c_int32)]
+
+
+class McfDesc(Structure):
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("ld", c_int32), ("C", c_int32), ("B", c_int32),
+                ("cond", c_void_p), ("Cc", c_int32),
+                ("W1", c_void_p), ("W2", c_void_p), ("bias2", c_void_p), ("order", c_int32),
+                ("rows_per_block", c_int32),
+                ("a2_save", c_void_p), ("scale_save", c_void_p), ("logdet_slot", c_void_p),
+                ("W2T", c_void_p), ("W1T", c_void_p), ("dy", c_void_p), ("dld", c_void_p), ("dx", c_void_p),
+                ("dparams_save", c_void_p), ("dc_save", c_void_p), ("dbias_part", c_void_p)]
+
+
+class FlowConfig(Structure):
+    _fields_ = [("z_channels", c_int32), ("hidden", c_int32), ("cond_channels", c_int32), ("factor", c_int32),
+                ("n_levels", c_int32), ("num_steps", c_int32 * 32), ("kernel_h", c_int32), ("kernel_w", c_int32),
+                ("dtype", c_int32), ("max_batch", c_int32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/ipoke_hip.h
+_P = c_void_p
+SIGNATURES = {
+    "ipoke_last_error": (c_char_p, []),
+    "ipoke_version": (c_int, []),
+    "ipoke_dtype_size": (c_int, [c_int]),
+    "ipoke_conv_forward": (c_int, [POINTER(ConvDesc), c_int, _P]),
+    "ipoke_conv_wgrad": (c_int, [POINTER(WgradDesc), c_int, _P]),
+    "ipoke_nchw_to_state": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_state_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_cond_prepare": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_actnorm_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "ipoke_actnorm_inv": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "ipoke_actnorm_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    "ipoke_actnorm_init": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "ipoke_affine_fwd": (c_int, [POINTER(AffineDesc), _P, _P, _P, _P, c_int, c_int, _P]),
+    "ipoke_affine_inv": (c_int, [POINTER(AffineDesc), _P, _P, c_int, _P]),
+    "ipoke_affine_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P]),
+    "ipoke_reduce_rows": (c_int, [_P, _P, c_int, c_int, _P]),
+    "ipoke_logdet_finalize": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    "ipoke_actnorm_logdet": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "ipoke_flow_nll": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "ipoke_adam_amsgrad_step": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
+                                        c_float, _P]),
+    "ipoke_mcf_shadow_dims": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
+    "ipoke_mcf_fwd": (c_int, [POINTER(McfDesc), c_int, _P]),
+    "ipoke_mcf_inv": (c_int, [POINTER(McfDesc), c_int, _P]),
+    "ipoke_mcf_bwd": (c_int, [POINTER(McfDesc), c_int, _P]),
+    "ipoke_relayout_job_size": (c_int, []),
+    "ipoke_wn_job_size": (c_int, []),
+    "ipoke_relayout_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ipoke_wn_scale_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "ipoke_wn_bwd_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),
+    "ipoke_flow_destroy": (None, [_P]),
+    "ipoke_flow_param_count": (c_int64, [_P]),
+    "ipoke_flow_index_count": (c_int64, [_P]),
+    "ipoke_flow_tensor_count": (c_int32, [_P]),
+    "ipoke_flow_op_count": (c_int32, [_P]),
+    "ipoke_flow_tensor_info": (c_int, [_P, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64),
+                                       POINTER(c_int32)]),
+    "ipoke_flow_shadow_bytes": (c_int64, [_P]),
+    "ipoke_flow_workspace_bytes": (c_int64, [_P, c_int, c_int]),
+    "ipoke_flow_prepare_weights": (c_int, [_P, _P, _P, _P]),
+    "ipoke_flow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P]),
+    "ipoke_flow_init_forward": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "ipoke_flow_reverse": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "ipoke_flow_backward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. ipoke_amd has no CPU fallback; "
+                "run `make -C ipoke_amd/csrc` (or __graft_entry__.build()) first.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().ipoke_last_error()
+        raise RuntimeError(f"libipoke_hip call failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor as c_void_p; None -> NULL."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("ipoke_amd needs an MI355X (gfx950) GPU: no HIP device is visible and there is no CPU path")

@@ -1,0 +1,126 @@
+// Shared device/host helpers for libipoke_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/ipoke_hip.h"
+
+namespace ipoke {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// ---- error plumbing (never throws across the C ABI) -----------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define IPK_HIP(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return ::ipoke::fail(IPOKE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+#define IPK_REQUIRE(cond, msg)                                              \
+  do {                                                                      \
+    if (!(cond)) return ::ipoke::fail(IPOKE_ERR_INVALID, std::string(msg) + " [" #cond "]"); \
+  } while (0)
+
+#define IPK_LAUNCH_CHECK() IPK_HIP(hipGetLastError())
+
+// ---- element traits --------------------------------------------------------
+template <typename T> struct ET;
+template <> struct ET<bf16_t> {
+  static constexpr int E16 = 8;           // elements per 16-byte chunk
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ bf16_t from_f32(float x) { return (bf16_t)x; }
+  static __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+};
+template <> struct ET<float> {
+  static constexpr int E16 = 4;
+  typedef f32x4 frag;
+  static __device__ __forceinline__ float from_f32(float x) { return x; }
+  static __device__ __forceinline__ float to_f32(float x) { return x; }
+};
+
+// One 64-byte K "super-step" of a 16x16 output fragment.
+//   bf16: one v_mfma_f32_16x16x32_bf16 (lane group g = lane>>4 holds k = 8g..8g+7)
+//   f32 : four v_mfma_f32_16x16x4_f32; lane group g holds the 4 contiguous floats k = 4g..4g+3 and
+//         instruction c uses component c -- a K permutation applied identically to both operands.
+// Operand order (b, a) yields D[n][m]: the lane owning column m = lane&15 holds 4 consecutive n
+// (n = 4*(lane>>4)+r), i.e. row-major C gets 4 contiguous outputs per lane.
+__device__ __forceinline__ void mma64(const bf16x8& a, const bf16x8& b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma64(const f32x4& a, const f32x4& b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[0], a[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[1], a[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[2], a[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[3], a[3], acc, 0, 0, 0);
+}
+
+// ---- activations -----------------------------------------------------------
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case IPOKE_ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case IPOKE_ACT_RELU: return x > 0.f ? x : 0.f;
+    case IPOKE_ACT_LRELU02: return x > 0.f ? x : 0.2f * x;
+    case IPOKE_ACT_TANH: return tanhf(x);
+    case IPOKE_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    default: return x;
+  }
+}
+// derivative expressed through the activation OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(int act, float y) {
+  switch (act) {
+    case IPOKE_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+    case IPOKE_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case IPOKE_ACT_LRELU02: return y > 0.f ? 1.f : 0.2f;
+    case IPOKE_ACT_TANH: return 1.f - y * y;
+    case IPOKE_ACT_SIGMOID: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
+// ---- reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// block-wide sum; `red` is >= (blockDim.x/64) floats of LDS. All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+struct McfGeom { int kh, kw, oy, ox; };
+__host__ __device__ inline McfGeom mcf_geom(int order) {
+  // input(y + ky + oy, x + kx + ox) feeds output (y, x): strictly above / below / left / right
+  switch (order) {
+    case 0: return {2, 3, -2, -1};   // A
+    case 1: return {2, 3, +1, -1};   // B
+    case 2: return {3, 2, -1, -2};   // C
+    default: return {3, 2, -1, +1};  // D
+  }
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+static inline int ilog2_exact(int v) {   // -1 when v is not a power of two
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+}  // namespace ipoke

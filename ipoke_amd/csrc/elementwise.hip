@@ -1,0 +1,496 @@
+// Element-wise / reduction kernels of the flow: ActNorm (+fused channel permutation), affine coupling
+// transform with log-det, NLL loss, layout conversion, fused Adam-amsgrad.  All arithmetic fp32.
+//
+// Flow state layout: S[B*64][ld] fp32, row = (sample, position), columns = channels ("positions
+// major").  A layer acting on the first C channels leaves columns >= C untouched (they are the
+// channels the multi-scale architecture has already split off, reference macow2.py:888-899).
+#include "common.h"
+
+namespace ipoke {
+
+// ------------------------------------------------------------------ layout conversion
+// NCHW [B][C][P] <-> state [B][P][ld]; one block per sample.
+__global__ void nchw_to_state_kernel(const float* __restrict__ x, float* __restrict__ s, int C, int P, int ld) {
+  const int b = blockIdx.x;
+  const float* xb = x + (long)b * C * P;
+  float* sb = s + (long)b * P * ld;
+  for (int i = threadIdx.x; i < C * P; i += blockDim.x) {
+    const int c = i / P, p = i - c * P;        // read coalesced along p
+    sb[(long)p * ld + c] = xb[i];
+  }
+}
+__global__ void state_to_nchw_kernel(const float* __restrict__ s, float* __restrict__ x, int C, int P, int ld) {
+  const int b = blockIdx.x;
+  float* xb = x + (long)b * C * P;
+  const float* sb = s + (long)b * P * ld;
+  for (int i = threadIdx.x; i < C * P; i += blockDim.x) {
+    const int c = i / P, p = i - c * P;
+    xb[i] = sb[(long)p * ld + c];
+  }
+}
+// cond [B][Cc][P] fp32 -> ELU -> T [B][P][Cc]   (the MCF blocks concatenate h before their ELU,
+// macow_utils.py:429-431, so ELU(h) is shared by all 800 blocks and computed once)
+template <typename T>
+__global__ void cond_prepare_kernel(const float* __restrict__ h, T* __restrict__ out, int Cc, int P, int act) {
+  const int b = blockIdx.x;
+  const float* hb = h + (long)b * Cc * P;
+  T* ob = out + (long)b * P * Cc;
+  for (int i = threadIdx.x; i < Cc * P; i += blockDim.x) {
+    const int c = i / P, p = i - c * P;
+    ob[(long)p * Cc + c] = ET<T>::from_f32(act_apply(act, hb[i]));
+  }
+}
+
+// ------------------------------------------------------------------ ActNorm (+ Shuffle)
+// out[m][c0 + j] = in[m][c0 + idx[j]] * exp(ls[idx[j]]) + bias[idx[j]]   (idx == NULL: identity)
+// ls/bias == NULL: pure permutation.  Columns outside [c0, c0+C) are copied.
+__global__ void actnorm_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int ld, int c0, int C,
+                                   const float* __restrict__ ls, const float* __restrict__ bias,
+                                   const int* __restrict__ idx) {
+  const long total = (long)M * ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ld);
+    const long row = i / ld;
+    const int j = col - c0;
+    float v;
+    if (j >= 0 && j < C) {
+      const int src = idx ? idx[j] : j;
+      v = in[row * ld + c0 + src];
+      if (ls) v = v * expf(ls[src]) + bias[src];
+    } else {
+      v = in[i];
+    }
+    out[i] = v;
+  }
+}
+// inverse: first undo the permutation (x'[idx[j]] = y[j]), then x = (x' - bias) / (exp(ls) + 1e-8)
+__global__ void actnorm_inv_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int ld, int c0, int C,
+                                   const float* __restrict__ ls, const float* __restrict__ bias,
+                                   const int* __restrict__ inv_idx) {
+  const long total = (long)M * ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ld);
+    const long row = i / ld;
+    const int c = col - c0;
+    float v;
+    if (c >= 0 && c < C) {
+      const int src = inv_idx ? inv_idx[c] : c;     // out channel c came from shuffled position src
+      v = in[row * ld + c0 + src];
+      if (ls) v = (v - bias[c]) / (expf(ls[c]) + 1e-8f);
+    } else {
+      v = in[i];
+    }
+    out[i] = v;
+  }
+}
+// backward.  x = saved input of the layer.  Single block (M*C is tiny); grads are written (not accumulated).
+//   dx[m][c0+idx[j]] = dy[m][c0+j] * exp(ls[idx[j]])
+//   dls[c] = sum_m dy'[m][c] * x[m][c] * exp(ls[c]) + P * sum_b dld[b] ;  dbias[c] = sum_m dy'[m][c]
+__global__ void actnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                   int M, int ld, int c0, int C, const float* __restrict__ ls,
+                                   const int* __restrict__ idx, const float* __restrict__ dld, int B, int P,
+                                   float* __restrict__ dls, float* __restrict__ dbias) {
+  extern __shared__ float sm[];   // [2][rows_par][C]
+  const int tid = threadIdx.x;
+  const int rows_par = blockDim.x / C;      // host guarantees >= 1
+  const int j = tid % C, r0 = tid / C;
+  float a_ls = 0.f, a_b = 0.f;
+  int src = 0;
+  float e = 1.f;
+  if (r0 < rows_par) {
+    src = idx ? idx[j] : j;
+    e = ls ? expf(ls[src]) : 1.f;
+    for (int m = r0; m < M; m += rows_par) {
+      const float g = dy[(long)m * ld + c0 + j];
+      const float xv = ls ? x[(long)m * ld + c0 + src] : 0.f;
+      dx[(long)m * ld + c0 + src] = g * e;
+      a_ls += g * xv * e;
+      a_b += g;
+    }
+  }
+  // pass-through columns
+  for (long i = tid; i < (long)M * ld; i += blockDim.x) {
+    const int col = (int)(i % ld);
+    if (col < c0 || col >= c0 + C) dx[i] = dy[i];
+  }
+  if (!ls) return;
+  if (r0 < rows_par) { sm[r0 * C + j] = a_ls; sm[(rows_par + r0) * C + j] = a_b; }
+  __syncthreads();
+  if (tid < C) {
+    const int s = idx ? idx[tid] : tid;     // thread tid accumulated channel s
+    float t_ls = 0.f, t_b = 0.f;
+    for (int r = 0; r < rows_par; ++r) { t_ls += sm[r * C + tid]; t_b += sm[(rows_par + r) * C + tid]; }
+    float sum_dld = 0.f;
+    for (int b = 0; b < B; ++b) sum_dld += dld[b];
+    dls[s] = t_ls + (float)P * sum_dld;
+    dbias[s] = t_b;
+  }
+}
+// data-dependent init (reference macow2.py:526-539): statistics of y0 = x*exp(ls0)+b0 over all rows,
+// unbiased std, then ls <- log(1/(std+1e-6)), bias <- -mean/(std+1e-6).  One block per channel.
+__global__ void actnorm_init_kernel(const float* __restrict__ x, int M, int ld, int c0, float* __restrict__ ls,
+                                    float* __restrict__ bias) {
+  __shared__ float red[8];
+  const int c = blockIdx.x;
+  const float e = expf(ls[c]), b0 = bias[c];
+  float s = 0.f;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) s += x[(long)m * ld + c0 + c] * e + b0;
+  const float mean = block_sum(s, red) / (float)M;
+  float v = 0.f;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) {
+    const float d = x[(long)m * ld + c0 + c] * e + b0 - mean;
+    v += d * d;
+  }
+  const float var = block_sum(v, red) / (float)(M - 1);
+  if (threadIdx.x == 0) {
+    const float inv = 1.f / (sqrtf(var) + 1e-6f);
+    ls[c] = logf(inv);
+    bias[c] = -mean * inv;
+  }
+}
+
+// ------------------------------------------------------------------ affine coupling transform
+// raw[m][0:Cp] = mu, raw[m][Cp:2Cp] = s, given as `nsplit` fp32 partial sums (split-K conv output)
+// plus bias.  scale = tanh(s/2)+1 (macow_utils.py:49-52);  transformed channel i lives in state
+// column t_off + i*t_stride.  One block per sample: the per-sample log-det is a block reduction.
+struct AffineArgs {
+  const float* raw; int nsplit; long split_stride; int ldraw;     // raw + s*split_stride + m*ldraw + col
+  const float* bias;                                              // [2*Cp] or NULL
+  int Cp, t_off, t_stride;
+  int P, ld;
+};
+__device__ __forceinline__ void affine_params_at(const AffineArgs& a, long m, int i, float& mu, float& sc) {
+  float vm = 0.f, vs = 0.f;
+  for (int s = 0; s < a.nsplit; ++s) {
+    const float* r = a.raw + s * a.split_stride + m * a.ldraw;
+    vm += r[i]; vs += r[a.Cp + i];
+  }
+  if (a.bias) { vm += a.bias[i]; vs += a.bias[a.Cp + i]; }
+  mu = vm; sc = tanhf(0.5f * vs) + 1.f;
+}
+__global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out,
+                                  float* __restrict__ scale_out, float* __restrict__ logdet_slot, int slot_stride) {
+  __shared__ float red[8];
+  const int b = blockIdx.x;
+  const long row0 = (long)b * a.P;
+  // copy the whole sample, then overwrite the transformed channels (disjoint elements, same thread order)
+  for (int i = threadIdx.x; i < a.P * a.ld; i += blockDim.x) {
+    const int col = i % a.ld, p = i / a.ld;
+    const int rel = col - a.t_off;
+    const bool transformed = rel >= 0 && rel % a.t_stride == 0 && rel / a.t_stride < a.Cp;
+    if (!transformed) out[(row0 + p) * a.ld + col] = in[(row0 + p) * a.ld + col];
+  }
+  float ld_acc = 0.f;
+  for (int e = threadIdx.x; e < a.P * a.Cp; e += blockDim.x) {
+    const int p = e / a.Cp, i = e - p * a.Cp;
+    float mu, sc;
+    affine_params_at(a, row0 + p, i, mu, sc);
+    const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
+    out[off] = sc * in[off] + mu;
+    if (scale_out) scale_out[(row0 + p) * a.Cp + i] = sc;
+    ld_acc += logf(sc);
+  }
+  const float tot = block_sum(ld_acc, red);
+  if (threadIdx.x == 0 && logdet_slot) logdet_slot[(long)b * slot_stride] = tot;
+}
+__global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  const long row0 = (long)b * a.P;
+  for (int i = threadIdx.x; i < a.P * a.ld; i += blockDim.x) {
+    const int col = i % a.ld, p = i / a.ld;
+    const int rel = col - a.t_off;
+    const bool transformed = rel >= 0 && rel % a.t_stride == 0 && rel / a.t_stride < a.Cp;
+    if (!transformed) out[(row0 + p) * a.ld + col] = in[(row0 + p) * a.ld + col];
+  }
+  for (int e = threadIdx.x; e < a.P * a.Cp; e += blockDim.x) {
+    const int p = e / a.Cp, i = e - p * a.Cp;
+    float mu, sc;
+    affine_params_at(a, row0 + p, i, mu, sc);
+    const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
+    out[off] = (in[off] - mu) / (sc + 1e-12f);      // macow_utils.py:64
+  }
+}
+// backward.  x = saved layer input, scale = saved scales.  Produces
+//   dx (zp channels: dy*scale, others: dy copied),  dparams T [m][ldp] = [dmu | ds | 0 pad],
+//   per-sample column sums of dparams (for the conv bias gradient) into dbias_part[b][2Cp].
+template <typename T>
+__global__ void affine_bwd_kernel(int Cp, int t_off, int t_stride, int P, int ld, const float* __restrict__ dy,
+                                  const float* __restrict__ x, const float* __restrict__ scale,
+                                  const float* __restrict__ dld, float* __restrict__ dx, T* __restrict__ dparams,
+                                  int ldp, float* __restrict__ dbias_part) {
+  extern __shared__ float sm[];      // [2*Cp] column sums
+  const int b = blockIdx.x;
+  const long row0 = (long)b * P;
+  for (int i = threadIdx.x; i < 2 * Cp; i += blockDim.x) sm[i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < P * ld; i += blockDim.x) {
+    const int col = i % ld, p = i / ld;
+    const int rel = col - t_off;
+    const bool transformed = rel >= 0 && rel % t_stride == 0 && rel / t_stride < Cp;
+    if (!transformed) dx[(row0 + p) * ld + col] = dy[(row0 + p) * ld + col];
+  }
+  const float g_ld = dld[b];
+  for (int e = threadIdx.x; e < P * ldp; e += blockDim.x) {
+    const int p = e / ldp, j = e - p * ldp;
+    float v = 0.f;
+    if (j < 2 * Cp) {
+      const int i = j < Cp ? j : j - Cp;
+      const long off = (row0 + p) * ld + t_off + (long)i * t_stride;
+      const float g = dy[off];
+      if (j < Cp) {
+        v = g;                                               // d mu
+        dx[off] = g * scale[(row0 + p) * Cp + i];
+      } else {
+        const float sc = scale[(row0 + p) * Cp + i];
+        const float t = sc - 1.f;                            // tanh(s/2)
+        v = (g * x[off] + g_ld / sc) * 0.5f * (1.f - t * t);  // d s
+      }
+      atomicAdd(&sm[j], v);
+    }
+    dparams[(row0 + p) * ldp + j] = ET<T>::from_f32(v);
+  }
+  __syncthreads();
+  if (dbias_part)
+    for (int i = threadIdx.x; i < 2 * Cp; i += blockDim.x) dbias_part[(long)b * 2 * Cp + i] = sm[i];
+}
+// dst[c] = sum_r src[r][c]
+__global__ void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int ncols) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int r = 0; r < R; ++r) t += src[(long)r * ncols + c];
+    dst[c] = t;
+  }
+}
+
+// ------------------------------------------------------------------ log-det bookkeeping and the loss
+// logdet[b] = const_term + sum_l slots[l][b*slot_w .. +slot_w)
+__global__ void logdet_finalize_kernel(const float* __restrict__ slots, int nslots, int B, int slot_w, float const_term,
+                                       const float* __restrict__ const_dev, float* __restrict__ logdet) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float t = const_term + (const_dev ? const_dev[0] : 0.f);
+  for (int l = 0; l < nslots; ++l)
+    for (int w = 0; w < slot_w; ++w) t += slots[((long)l * B + b) * slot_w + w];
+  logdet[b] = t;
+}
+// out_scalar[0] = P * sum over `n` ActNorm layers of sum_c log_scale  (batch independent, macow2.py:512)
+struct LsRef { long off; int C; };
+__global__ void actnorm_logdet_kernel(const float* __restrict__ params, const LsRef* __restrict__ refs, int n, int P,
+                                      float* __restrict__ out_scalar) {
+  __shared__ float red[8];
+  float t = 0.f;
+  for (int l = 0; l < n; ++l) {
+    const float* ls = params + refs[l].off;
+    for (int c = threadIdx.x; c < refs[l].C; c += blockDim.x) t += ls[c];
+  }
+  const float tot = block_sum(t, red);
+  if (threadIdx.x == 0) out_scalar[0] = tot * (float)P;
+}
+// FlowLoss (loss.py:13-31,75-79): loss = mean_b 0.5*sum z^2 - w * mean_b logdet.
+// Writes scalars[0..2] = (loss, nll, nlogdet) and the gradients d_out = z/B (state layout), dld[b] = -w/B.
+__global__ void flow_nll_kernel(const float* __restrict__ z, const float* __restrict__ logdet, int B, int P, int C, int ld,
+                                float w, float* __restrict__ scalars, float* __restrict__ d_out, float* __restrict__ dld) {
+  __shared__ float red[8];
+  float t = 0.f;
+  const long total = (long)B * P * ld;
+  const float invB = 1.f / (float)B;
+  for (long i = threadIdx.x; i < total; i += blockDim.x) {
+    const int col = (int)(i % ld);
+    const float v = col < C ? z[i] : 0.f;
+    t += v * v;
+    if (d_out) d_out[i] = v * invB;
+  }
+  const float ss = block_sum(t, red);
+  float l = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    l += logdet[b];
+    if (dld) dld[b] = -w * invB;
+  }
+  const float lsum = block_sum(l, red);
+  if (threadIdx.x == 0) {
+    const float nll = 0.5f * ss * invB, nld = -lsum * invB;
+    scalars[0] = nll + w * nld; scalars[1] = nll; scalars[2] = nld;
+  }
+}
+
+// ------------------------------------------------------------------ Adam with amsgrad (torch.optim.Adam semantics)
+__global__ void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, float* __restrict__ vmax, long n, float lr, float beta1,
+                                    float beta2, float eps, float wd, float bc1, float bc2_sqrt, float grad_scale) {
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+      f32x4 vx = *reinterpret_cast<f32x4*>(vmax + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gr = gg[k] * grad_scale + wd * pp[k];
+        mm[k] = beta1 * mm[k] + (1.f - beta1) * gr;
+        vv[k] = beta2 * vv[k] + (1.f - beta2) * gr * gr;
+        vx[k] = fmaxf(vx[k], vv[k]);
+        const float denom = sqrtf(vx[k]) / bc2_sqrt + eps;
+        pp[k] -= (lr / bc1) * (mm[k] / denom);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm;
+      *reinterpret_cast<f32x4*>(v + i) = vv; *reinterpret_cast<f32x4*>(vmax + i) = vx;
+    } else {
+      for (long k = i; k < n; ++k) {
+        const float gr = g[k] * grad_scale + wd * p[k];
+        m[k] = beta1 * m[k] + (1.f - beta1) * gr;
+        v[k] = beta2 * v[k] + (1.f - beta2) * gr * gr;
+        vmax[k] = fmaxf(vmax[k], v[k]);
+        p[k] -= (lr / bc1) * (m[k] / (sqrtf(vmax[k]) / bc2_sqrt + eps));
+      }
+    }
+  }
+}
+
+static inline int grid_for(long n, int block, int cap = 2048) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace ipoke
+
+using namespace ipoke;
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int ipoke_nchw_to_state(const float* x, float* state, int B, int C, int P, int ld, void* stream) {
+  IPK_REQUIRE(x && state && C <= ld, "bad arguments");
+  hipLaunchKernelGGL(nchw_to_state_kernel, dim3(B), dim3(256), 0, STREAM(stream), x, state, C, P, ld);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_state_to_nchw(const float* state, float* x, int B, int C, int P, int ld, void* stream) {
+  IPK_REQUIRE(x && state && C <= ld, "bad arguments");
+  hipLaunchKernelGGL(state_to_nchw_kernel, dim3(B), dim3(256), 0, STREAM(stream), state, x, C, P, ld);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_cond_prepare(const float* cond, void* out, int B, int Cc, int P, int act, int dtype, void* stream) {
+  IPK_REQUIRE(cond && out, "null tensor");
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(cond_prepare_kernel<bf16_t>, dim3(B), dim3(256), 0, STREAM(stream), cond, (bf16_t*)out, Cc, P, act);
+  else
+    hipLaunchKernelGGL(cond_prepare_kernel<float>, dim3(B), dim3(256), 0, STREAM(stream), cond, (float*)out, Cc, P, act);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_actnorm_fwd(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
+                                 const float* bias, const int32_t* idx, void* stream) {
+  IPK_REQUIRE(in && out && c0 >= 0 && c0 + C <= ld, "bad arguments");
+  IPK_REQUIRE((log_scale == nullptr) == (bias == nullptr), "log_scale and bias come together");
+  hipLaunchKernelGGL(actnorm_fwd_kernel, dim3(grid_for((long)M * ld, 256)), dim3(256), 0, STREAM(stream), in, out, M, ld,
+                     c0, C, log_scale, bias, idx);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_actnorm_inv(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
+                                 const float* bias, const int32_t* inv_idx, void* stream) {
+  IPK_REQUIRE(in && out && c0 >= 0 && c0 + C <= ld, "bad arguments");
+  hipLaunchKernelGGL(actnorm_inv_kernel, dim3(grid_for((long)M * ld, 256)), dim3(256), 0, STREAM(stream), in, out, M, ld,
+                     c0, C, log_scale, bias, inv_idx);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_actnorm_bwd(const float* dy, const float* x, float* dx, int M, int ld, int c0, int C,
+                                 const float* log_scale, const int32_t* idx, const float* dld, int B, int P,
+                                 float* d_log_scale, float* d_bias, void* stream) {
+  IPK_REQUIRE(dy && x && dx && C >= 1 && C <= 256 && c0 + C <= ld, "bad arguments");
+  IPK_REQUIRE(!log_scale || (dld && d_log_scale && d_bias), "parameter gradients need dld and outputs");
+  const int block = C <= 64 ? 256 : (C <= 128 ? 512 : 1024);
+  const int rows_par = block / C;
+  hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(1), dim3(block), 2 * rows_par * C * sizeof(float), STREAM(stream), dy, x, dx,
+                     M, ld, c0, C, log_scale, idx, dld, B, P, d_log_scale, d_bias);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_actnorm_init(const float* x, int M, int ld, int c0, int C, float* log_scale, float* bias, void* stream) {
+  IPK_REQUIRE(x && log_scale && bias && M >= 2, "bad arguments");
+  hipLaunchKernelGGL(actnorm_init_kernel, dim3(C), dim3(256), 0, STREAM(stream), x, M, ld, c0, log_scale, bias);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+static int check_affine(const ipoke_affine_desc* d) {
+  IPK_REQUIRE(d && d->raw && d->Cp >= 1 && d->nsplit >= 1 && d->t_stride >= 1, "bad affine descriptor");
+  IPK_REQUIRE(d->t_off + (d->Cp - 1) * d->t_stride < d->ld, "transformed channels exceed the state width");
+  return IPOKE_OK;
+}
+static AffineArgs to_args(const ipoke_affine_desc* d) {
+  AffineArgs a;
+  a.raw = d->raw; a.nsplit = d->nsplit; a.split_stride = d->split_stride; a.ldraw = d->ldraw; a.bias = d->bias;
+  a.Cp = d->Cp; a.t_off = d->t_off; a.t_stride = d->t_stride; a.P = d->P; a.ld = d->ld;
+  return a;
+}
+extern "C" int ipoke_affine_fwd(const ipoke_affine_desc* d, const float* in, float* out, float* scale_out,
+                                float* logdet_slot, int slot_stride, int B, void* stream) {
+  int rc = check_affine(d); if (rc) return rc;
+  IPK_REQUIRE(in && out, "null state");
+  hipLaunchKernelGGL(affine_fwd_kernel, dim3(B), dim3(256), 0, STREAM(stream), to_args(d), in, out, scale_out, logdet_slot, slot_stride < 1 ? 1 : slot_stride);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_affine_inv(const ipoke_affine_desc* d, const float* in, float* out, int B, void* stream) {
+  int rc = check_affine(d); if (rc) return rc;
+  IPK_REQUIRE(in && out, "null state");
+  hipLaunchKernelGGL(affine_inv_kernel, dim3(B), dim3(256), 0, STREAM(stream), to_args(d), in, out);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, const float* dy, const float* x,
+                                const float* scale, const float* dld, float* dx, void* dparams, int ldp,
+                                float* dbias_part, int B, int dtype, void* stream) {
+  IPK_REQUIRE(dy && x && scale && dld && dx && dparams && ldp >= 2 * Cp, "bad arguments");
+  const size_t sm = 2 * Cp * sizeof(float);
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(affine_bwd_kernel<bf16_t>, dim3(B), dim3(256), sm, STREAM(stream), Cp, t_off, t_stride, P, ld, dy, x,
+                       scale, dld, dx, (bf16_t*)dparams, ldp, dbias_part);
+  else
+    hipLaunchKernelGGL(affine_bwd_kernel<float>, dim3(B), dim3(256), sm, STREAM(stream), Cp, t_off, t_stride, P, ld, dy, x,
+                       scale, dld, dx, (float*)dparams, ldp, dbias_part);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream) {
+  IPK_REQUIRE(src && dst, "null tensor");
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(grid_for(ncols, 128)), dim3(128), 0, STREAM(stream), src, dst, R, ncols);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_logdet_finalize(const float* slots, int nslots, int B, int slot_w, float const_term,
+                                     const float* const_dev, float* logdet, void* stream) {
+  IPK_REQUIRE(logdet && (nslots == 0 || slots), "bad arguments");
+  hipLaunchKernelGGL(logdet_finalize_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, STREAM(stream), slots, nslots, B, slot_w,
+                     const_term, const_dev, logdet);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_actnorm_logdet(const float* params, const void* refs_dev, int n, int P, float* out_scalar, void* stream) {
+  IPK_REQUIRE(params && refs_dev && out_scalar, "null tensor");
+  hipLaunchKernelGGL(actnorm_logdet_kernel, dim3(1), dim3(256), 0, STREAM(stream), params, (const LsRef*)refs_dev, n, P,
+                     out_scalar);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_flow_nll(const float* z_state, const float* logdet, int B, int P, int C, int ld, float logdet_weight,
+                              float* scalars3, float* d_out_state, float* dld, void* stream) {
+  IPK_REQUIRE(z_state && logdet && scalars3, "null tensor");
+  hipLaunchKernelGGL(flow_nll_kernel, dim3(1), dim3(512), 0, STREAM(stream), z_state, logdet, B, P, C, ld, logdet_weight,
+                     scalars3, d_out_state, dld);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
+                                       float beta1, float beta2, float eps, float weight_decay, int step,
+                                       float grad_scale, void* stream) {
+  IPK_REQUIRE(p && g && m && v && vmax && n > 0 && step >= 1, "bad arguments");
+  IPK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) == 0, "16-byte alignment");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, STREAM(stream), p, g, m, v,
+                     vmax, (long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}

@@ -1,0 +1,724 @@
+// Native executor of the conditional MaCow flow (reference models/modules/INN/INN.py:446-481,
+// macow2.py:821-1117).  The engine owns the *topology* -- the ordered layer program, the reference's
+// state-dict names, the flat fp32 parameter layout, the matrix-core weight shadows and the workspace
+// plan -- and issues the per-layer kernels of elementwise.hip / mcf.hip / gemm.hip back to back on
+// the caller's stream: no host synchronisation, no allocation, capturable in a hipGraph.  Weight
+// gradient GEMMs are forked onto a side stream so that they overlap the serial data-gradient chain.
+//
+// Host code only (compiled by hipcc together with the kernels).
+#include <memory>
+#include <vector>
+#include <string>
+#include <cstring>
+
+#include "common.h"
+
+namespace ipoke {
+
+enum OpType { OP_ACTNORM = 0, OP_MCF = 1, OP_NICE = 2 };
+enum TensorKind { TK_PARAM = 0, TK_IDX_FWD = 1, TK_IDX_BWD = 2, TK_FLAG = 3 };
+
+struct TensorInfo {
+  std::string name;
+  int64_t offset;            // floats (params) or int32 entries (perm); -1 for flags
+  std::vector<int64_t> shape;
+  int kind;
+};
+
+struct Op {
+  int type = 0;
+  int C = 0;                                   // active channels
+  // actnorm / shuffle
+  int c0 = 0, Cn = 0;
+  int64_t p_ls = -1, p_bias = -1, idx_fwd = -1, idx_bwd = -1;
+  // mcf
+  int order = 0;
+  int64_t p_w1 = -1, p_b = -1, p_g = -1, p_v = -1;
+  int Cp = 0, K1p = 0, K2p = 0, K3p = 0, Hq = 0, H = 0;
+  int64_t sh_w1 = -1, sh_w1t = -1, sh_w2 = -1, sh_w2t = -1;
+  int64_t wn_off = -1;
+  // nice
+  int cin = 0, cout = 0, z_off = 0, z_stride = 1, t_off = 0, t_stride = 1;
+  int64_t p_c1 = -1, p_c2 = -1;               // conv1.weight, conv2.weight (conv3: p_b, p_g, p_v)
+  int Kc1 = 0, Kc3 = 0;
+  int64_t sh_c1 = -1, sh_c1t = -1, sh_c2 = -1, sh_c2t = -1, sh_c3 = -1, sh_c3t = -1;
+  // workspace (elements resolved per call)
+  int64_t ws_a = -1, ws_b = -1, ws_c = -1, ws_d = -1, ws_e = -1, ws_f = -1, ws_g = -1;
+  int slot = -1;                               // log-det slot index
+};
+
+struct RelayoutJobH {
+  long src_off, dst_off, scale_off; int rows_pad, rows_real, taps, inner_pad, inner_real, ld;
+  long s_row, s_inner, s_tap; int scale_on_row, block_start;
+};
+struct WnJobH { long v_off, g_off, out_off; int rows, K, row_start; };
+struct LsRefH { long off; int C; };
+
+}  // namespace ipoke
+
+using namespace ipoke;
+
+struct ipoke_flow {
+  ipoke_flow_config cfg;
+  int esz = 2, e16 = 8, ks = 32;
+  std::vector<TensorInfo> tensors;
+  std::vector<Op> ops;
+  int64_t n_params = 0, n_perm = 0;
+  int64_t shadow_elems = 0;           // T elements
+  int64_t wn_rows = 0;
+  int nslots = 0;
+  std::vector<RelayoutJobH> rjobs; int rblocks = 0;
+  std::vector<WnJobH> wjobs;
+  std::vector<LsRefH> lsrefs;
+  void* d_rjobs = nullptr; void* d_wjobs = nullptr; void* d_lsrefs = nullptr;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events; size_t ev_next = 0;
+  bool use_side = true;
+  int last_fwd_B = 0; bool have_saved = false;
+  int P = 64;
+};
+
+namespace {
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct Builder {
+  ipoke_flow& f;
+  explicit Builder(ipoke_flow& fl) : f(fl) {}
+  int64_t add_param(const std::string& name, std::vector<int64_t> shape) {
+    int64_t n = 1; for (auto s : shape) n *= s;
+    const int64_t off = f.n_params;
+    f.tensors.push_back({name, off, shape, TK_PARAM});
+    f.n_params = align_up(off + n, 4);
+    return off;
+  }
+  int64_t add_idx(const std::string& name, int C, int kind) {
+    const int64_t off = f.n_perm;
+    f.tensors.push_back({name, off, {C}, kind});
+    f.n_perm += C;
+    return off;
+  }
+  void add_flag(const std::string& name) { f.tensors.push_back({name, -1, {}, TK_FLAG}); }
+  int64_t add_shadow(int64_t elems) {
+    const int64_t off = f.shadow_elems;
+    f.shadow_elems = align_up(off + elems, 64);
+    return off;
+  }
+  void relayout(long src, long dst, long scale, int rows_pad, int rows_real, int taps, int inner_pad, int inner_real, int ld,
+                long s_row, long s_inner, long s_tap, int scale_on_row) {
+    RelayoutJobH j{src, dst, scale, rows_pad, rows_real, taps, inner_pad, inner_real, ld, s_row, s_inner, s_tap, scale_on_row, f.rblocks};
+    f.rjobs.push_back(j);
+    const long total = (long)rows_pad * ld;
+    f.rblocks += (int)((total + 2047) / 2048);
+  }
+
+  void actnorm(const std::string& pfx, int C_active, int c0, int Cn, const std::string* shuffle_pfx) {
+    Op op; op.type = OP_ACTNORM; op.C = C_active; op.c0 = c0; op.Cn = Cn;
+    if (!pfx.empty()) {
+      op.p_ls = add_param(pfx + ".log_scale", {Cn, 1, 1});
+      op.p_bias = add_param(pfx + ".bias", {Cn, 1, 1});
+      add_flag(pfx + ".initialized");
+      f.lsrefs.push_back({(long)op.p_ls, Cn});
+    }
+    if (shuffle_pfx) {
+      op.idx_fwd = add_idx(*shuffle_pfx + ".forward_shuffle_idx", Cn, TK_IDX_FWD);
+      op.idx_bwd = add_idx(*shuffle_pfx + ".backward_shuffle_idx", Cn, TK_IDX_BWD);
+    }
+    f.ops.push_back(op);
+  }
+
+  void mcf(const std::string& pfx, int C, int order) {
+    const int Cc = f.cfg.cond_channels;
+    Op op; op.type = OP_MCF; op.C = C; op.order = order;
+    const int kh = order < 2 ? f.cfg.kernel_h : f.cfg.kernel_w, kw = order < 2 ? f.cfg.kernel_w : f.cfg.kernel_h;
+    op.H = 4 * C;
+    op.Cp = round_up(C, f.e16);
+    op.K1p = round_up(6 * op.Cp, f.ks);
+    op.K2p = round_up(op.H + Cc, f.ks);
+    op.K3p = round_up(2 * C, f.ks);
+    op.Hq = round_up(op.H, f.ks);
+    const int K2 = op.H + Cc;
+    op.p_w1 = add_param(pfx + ".net.shift_conv.weight", {op.H, C, kh, kw});
+    add_flag(pfx + ".net.conv1x1.initialized");
+    op.p_b = add_param(pfx + ".net.conv1x1.conv.bias", {2 * C});
+    op.p_g = add_param(pfx + ".net.conv1x1.conv.weight_g", {2 * C, 1, 1, 1});
+    op.p_v = add_param(pfx + ".net.conv1x1.conv.weight_v", {2 * C, K2, 1, 1});
+    op.wn_off = f.wn_rows;
+    f.wjobs.push_back({(long)op.p_v, (long)op.p_g, (long)op.wn_off, 2 * C, K2, (int)f.wn_rows});
+    f.wn_rows += 2 * C;
+    const int Hr = round_up(op.H, 16), N2r = round_up(2 * C, 16), Cr = round_up(C, 16);
+    op.sh_w1 = add_shadow((int64_t)Hr * op.K1p);
+    op.sh_w1t = add_shadow((int64_t)Cr * 6 * op.Hq);
+    op.sh_w2 = add_shadow((int64_t)N2r * op.K2p);
+    op.sh_w2t = add_shadow((int64_t)Hr * op.K3p);
+    relayout(op.p_w1, op.sh_w1, -1, Hr, op.H, 6, op.Cp, C, op.K1p, (long)C * 6, 6, 1, 0);
+    relayout(op.p_w1, op.sh_w1t, -1, Cr, C, 6, op.Hq, op.H, 6 * op.Hq, 6, (long)C * 6, 1, 0);
+    relayout(op.p_v, op.sh_w2, op.wn_off, N2r, 2 * C, 1, op.K2p, K2, op.K2p, K2, 1, 0, 1);
+    relayout(op.p_v, op.sh_w2t, op.wn_off, Hr, op.H, 1, op.K3p, 2 * C, op.K3p, 1, K2, 0, 0);
+    op.slot = f.nslots++;
+    f.ops.push_back(op);
+  }
+
+  void nice(const std::string& pfx, int C, bool skip, bool up, int factor) {
+    const int hid = f.cfg.hidden;
+    Op op; op.type = OP_NICE; op.C = C;
+    op.cout = C / factor; op.cin = C - op.cout;
+    if (skip && (C % 2 == 1)) skip = false;
+    if (!skip) {
+      const int z1 = up ? op.cin : op.cout;
+      if (up) { op.z_off = 0; op.t_off = z1; } else { op.z_off = z1; op.t_off = 0; }
+      op.z_stride = op.t_stride = 1;
+    } else {
+      op.z_stride = op.t_stride = 2;
+      if (up) { op.z_off = 0; op.t_off = 1; } else { op.z_off = 1; op.t_off = 0; }
+    }
+    op.Kc1 = round_up(op.cin, f.e16);
+    op.Kc3 = round_up(2 * op.cout, f.e16);
+    op.p_c1 = add_param(pfx + ".net.conv1.weight", {hid, op.cin, 3, 3});
+    op.p_c2 = add_param(pfx + ".net.conv2.weight", {hid, hid, 1, 1});
+    add_flag(pfx + ".net.conv3.initialized");
+    op.p_b = add_param(pfx + ".net.conv3.conv.bias", {2 * op.cout});
+    op.p_g = add_param(pfx + ".net.conv3.conv.weight_g", {2 * op.cout, 1, 1, 1});
+    op.p_v = add_param(pfx + ".net.conv3.conv.weight_v", {2 * op.cout, hid, 3, 3});
+    op.wn_off = f.wn_rows;
+    f.wjobs.push_back({(long)op.p_v, (long)op.p_g, (long)op.wn_off, 2 * op.cout, hid * 9, (int)f.wn_rows});
+    f.wn_rows += 2 * op.cout;
+    const int N3 = 2 * op.cout;
+    op.sh_c1 = add_shadow((int64_t)hid * 9 * op.Kc1);
+    op.sh_c1t = add_shadow((int64_t)op.cin * 9 * hid);
+    op.sh_c2 = add_shadow((int64_t)hid * hid);
+    op.sh_c2t = add_shadow((int64_t)hid * hid);
+    op.sh_c3 = add_shadow((int64_t)N3 * 9 * hid);
+    op.sh_c3t = add_shadow((int64_t)hid * 9 * op.Kc3);
+    // conv1.weight [hid][cin][3][3]
+    relayout(op.p_c1, op.sh_c1, -1, hid, hid, 9, op.Kc1, op.cin, 9 * op.Kc1, (long)op.cin * 9, 9, 1, 0);
+    relayout(op.p_c1, op.sh_c1t, -1, op.cin, op.cin, 9, hid, hid, 9 * hid, 9, (long)op.cin * 9, 1, 0);
+    // conv2.weight [hid][hid]
+    relayout(op.p_c2, op.sh_c2, -1, hid, hid, 1, hid, hid, hid, hid, 1, 0, 0);
+    relayout(op.p_c2, op.sh_c2t, -1, hid, hid, 1, hid, hid, hid, 1, hid, 0, 0);
+    // conv3 weight_v [N3][hid][3][3] with weight-norm scale
+    relayout(op.p_v, op.sh_c3, op.wn_off, N3, N3, 9, hid, hid, 9 * hid, (long)hid * 9, 9, 1, 1);
+    relayout(op.p_v, op.sh_c3t, op.wn_off, hid, hid, 9, op.Kc3, N3, 9 * op.Kc3, 9, (long)hid * 9, 1, 0);
+    op.slot = f.nslots++;
+    f.ops.push_back(op);
+  }
+
+  void unit(const std::string& pfx, int C) {
+    mcf(pfx + ".conv1", C, 0);
+    mcf(pfx + ".conv2", C, 1);
+    actnorm(pfx + ".actnorm1", C, 0, C, nullptr);
+    mcf(pfx + ".conv3", C, 2);
+    mcf(pfx + ".conv4", C, 3);
+    actnorm(pfx + ".actnorm2", C, 0, C, nullptr);
+  }
+  void step(const std::string& pfx, int C) {
+    const std::string sh = pfx + ".conv1x1";
+    actnorm(pfx + ".actnorm1", C, 0, C, &sh);
+    unit(pfx + ".units1.0", C); unit(pfx + ".units1.1", C);
+    nice(pfx + ".coupling1_up", C, false, true, 2);
+    nice(pfx + ".coupling1_dn", C, false, false, 2);
+    actnorm(pfx + ".actnorm2", C, 0, C, nullptr);
+    unit(pfx + ".units2.0", C); unit(pfx + ".units2.1", C);
+    nice(pfx + ".coupling2_up", C, true, true, 2);
+    nice(pfx + ".coupling2_dn", C, true, false, 2);
+  }
+};
+
+// The reference registers layers.*, then priors.*, then shuffle_layers.* (macow2.py:835-863); the
+// state-dict (and hence the flat parameter) order follows registration, the execution order does not.
+int build(ipoke_flow& f) {
+  const ipoke_flow_config& c = f.cfg;
+  Builder b(f);
+  const int L = c.n_levels;
+  std::vector<std::vector<Op>> level_ops(L), prior_ops(L), shuf_ops(L);
+  int C = c.z_channels, factor = c.factor;
+  const int cstep = c.z_channels / c.factor;
+  std::vector<int> Cs(L), fs(L);
+  for (int l = 0; l < L; ++l) { Cs[l] = C; fs[l] = factor; C -= cstep; --factor; }
+  for (int l = 0; l < L; ++l) {
+    f.ops.clear();
+    for (int s = 0; s < c.num_steps[l]; ++s)
+      b.step("flow.layers." + std::to_string(l) + "." + std::to_string(s), Cs[l]);
+    level_ops[l] = f.ops;
+  }
+  for (int l = 0; l < L; ++l) {
+    f.ops.clear();
+    const std::string pfx = "flow.priors." + std::to_string(l);
+    const std::string sh = pfx + ".conv1x1";
+    b.actnorm("", Cs[l], 0, Cs[l], &sh);                         // bare shuffle
+    b.nice(pfx + ".coupling", Cs[l], false, true, fs[l]);
+    const int cout = Cs[l] / fs[l];
+    b.actnorm(pfx + ".actnorm", Cs[l], Cs[l] - cout, cout, nullptr);
+    prior_ops[l] = f.ops;
+  }
+  for (int l = 0; l < L; ++l) {
+    f.ops.clear();
+    const std::string sh = "flow.shuffle_layers." + std::to_string(l);
+    b.actnorm("", Cs[l], 0, Cs[l], &sh);
+    shuf_ops[l] = f.ops;
+  }
+  f.ops.clear();
+  for (int l = 0; l < L; ++l) {
+    for (auto& o : level_ops[l]) f.ops.push_back(o);
+    for (auto& o : prior_ops[l]) f.ops.push_back(o);
+    for (auto& o : shuf_ops[l]) f.ops.push_back(o);
+  }
+  return IPOKE_OK;
+}
+
+// ---- workspace plan ---------------------------------------------------------------------------
+struct Plan {
+  int64_t bytes = 0;
+  int64_t cond_act = 0, slots = 0, ls_const = 0, partials = 0, dld = 0, dbias_part = 0;
+  int64_t state0 = 0, state_stride = 0;     // saved states S[0..nops]
+  int64_t g0 = 0, g1 = 0;                   // gradient ping-pong
+  int64_t tmp_h1 = 0, tmp_h2 = 0;           // shared hidden buffers when nothing is saved
+};
+int64_t take(int64_t& cur, int64_t bytes) { const int64_t o = cur; cur = align_up(cur + bytes, 256); return o; }
+
+int max_splitk(const ipoke_flow& f, int B) {
+  const int M = B * f.P;
+  const int tiles = ceil_div(M, 64);
+  const int nkb = ceil_div(9 * f.cfg.hidden, 128 / f.esz);
+  int s = (384 + tiles - 1) / tiles;
+  if (s < 1) s = 1;
+  if (s > nkb) s = nkb;
+  if (s > 32) s = 32;
+  return s;
+}
+
+// mode 0: inference (forward without saves / reverse / init); 1: training forward+backward
+Plan make_plan(ipoke_flow& f, int B, int mode) {
+  Plan p;
+  const int64_t M = (int64_t)B * f.P, ld = f.cfg.z_channels, hid = f.cfg.hidden;
+  int64_t cur = 0;
+  p.cond_act = take(cur, M * f.cfg.cond_channels * f.esz);
+  p.slots = take(cur, (int64_t)f.nslots * B * 4 * 4);
+  p.ls_const = take(cur, 256);
+  p.dld = take(cur, (int64_t)B * 4);
+  p.partials = take(cur, (int64_t)max_splitk(f, B) * M * 64 * 4);
+  p.state_stride = align_up(M * ld * 4, 256);
+  if (mode == 0) {
+    p.state0 = take(cur, 2 * p.state_stride);
+    p.tmp_h1 = take(cur, M * hid * f.esz);
+    p.tmp_h2 = take(cur, M * hid * f.esz);
+    p.bytes = cur;
+    return p;
+  }
+  p.state0 = take(cur, (int64_t)(f.ops.size() + 1) * p.state_stride);
+  p.g0 = take(cur, p.state_stride);
+  p.g1 = take(cur, p.state_stride);
+  p.dbias_part = take(cur, (int64_t)f.ops.size() * B * 128 * 4);
+  for (auto& op : f.ops) {
+    if (op.type == OP_MCF) {
+      op.ws_a = take(cur, M * op.K2p * f.esz);        // a2 (ELU(cat[c, h]))
+      op.ws_b = take(cur, M * op.C * 4);              // scale
+      op.ws_c = take(cur, M * op.K3p * f.esz);        // dparams
+      op.ws_d = take(cur, M * op.Hq * f.esz);         // dc
+    } else if (op.type == OP_NICE) {
+      op.ws_a = take(cur, M * hid * f.esz);           // h1
+      op.ws_b = take(cur, M * hid * f.esz);           // h2
+      op.ws_c = take(cur, M * op.cout * 4);           // scale
+      op.ws_d = take(cur, M * op.Kc3 * f.esz);        // dparams
+      op.ws_e = take(cur, M * hid * f.esz);           // dp2
+      op.ws_f = take(cur, M * hid * f.esz);           // dp1
+    }
+  }
+  p.bytes = cur;
+  return p;
+}
+
+struct Ctx {
+  ipoke_flow* f; int B; int64_t M; int ld; int dtype; hipStream_t s;
+  const float* params; const int32_t* perm; const unsigned char* shadow; unsigned char* ws; Plan plan;
+  const float* wn_scale() const { return reinterpret_cast<const float*>(shadow); }
+  const float* wn_inv() const { return reinterpret_cast<const float*>(shadow) + align_up(f->wn_rows, 64); }
+  const unsigned char* sh(int64_t elem_off) const { return shadow + shadow_base() + elem_off * f->esz; }
+  int64_t shadow_base() const { return 2 * align_up(f->wn_rows, 64) * 4; }
+  float* state(int i) const { return reinterpret_cast<float*>(ws + plan.state0 + (int64_t)i * plan.state_stride); }
+  template <typename T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
+};
+
+void set_conv8(ipoke_conv_desc& d, int B, int k, int pad) {
+  std::memset(&d, 0, sizeof(d));
+  d.NB = B; d.Di = 1; d.Hi = 8; d.Wi = 8; d.Do = 1; d.Ho = 8; d.Wo = 8;
+  d.kd = 1; d.kh = k; d.kw = k; d.sd = d.sh = d.sw = 1; d.pd = 0; d.ph = pad; d.pw = pad;
+  d.c_cstride = 1; d.splitk = 1;
+}
+void set_a_state(ipoke_conv_desc& d, const float* state, int ld, int off, int stride, int creal, int kc) {
+  d.A = state; d.a_f32 = 1; d.a_sn = 64L * ld; d.a_sd = 0; d.a_sh = 8L * ld; d.a_sw = ld; d.a_sc = stride;
+  d.a_coff = off; d.Kc_real = creal; d.Kc = kc;
+}
+void set_a_dense(ipoke_conv_desc& d, const void* act, int ld, int kc) {
+  d.A = act; d.a_f32 = 0; d.a_sn = 64L * ld; d.a_sd = 0; d.a_sh = 8L * ld; d.a_sw = ld; d.a_sc = 1;
+  d.a_coff = 0; d.Kc_real = kc; d.Kc = kc;
+}
+
+int nice_splitk(const Ctx& c) { return max_splitk(*c.f, c.B); }
+
+// coupling net forward: conv1 -> ELU -> conv2 -> ELU -> conv3 (split-K partials)
+int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2) {
+  const int hid = c.f->cfg.hidden;
+  ipoke_conv_desc d;
+  set_conv8(d, c.B, 3, 1);
+  set_a_state(d, in, c.ld, op.z_off, op.z_stride, op.cin, op.Kc1);
+  d.W = c.sh(op.sh_c1); d.ldw = 9 * op.Kc1; d.Nout = hid; d.act = IPOKE_ACT_ELU; d.C = h1; d.ldc = hid;
+  int rc = ipoke_conv_forward(&d, c.dtype, c.s); if (rc) return rc;
+  set_conv8(d, c.B, 1, 0);
+  set_a_dense(d, h1, hid, hid);
+  d.W = c.sh(op.sh_c2); d.ldw = hid; d.Nout = hid; d.act = IPOKE_ACT_ELU; d.C = h2; d.ldc = hid;
+  rc = ipoke_conv_forward(&d, c.dtype, c.s); if (rc) return rc;
+  set_conv8(d, c.B, 3, 1);
+  set_a_dense(d, h2, hid, hid);
+  d.W = c.sh(op.sh_c3); d.ldw = 9 * hid; d.Nout = 2 * op.cout; d.C = c.at<float>(c.plan.partials); d.c_f32 = 1; d.ldc = 64;
+  d.splitk = nice_splitk(c);
+  return ipoke_conv_forward(&d, c.dtype, c.s);
+}
+void nice_affine_desc(const Ctx& c, const Op& op, ipoke_affine_desc& a) {
+  a.raw = c.at<float>(c.plan.partials); a.nsplit = nice_splitk(c); a.split_stride = c.M * 64; a.ldraw = 64;
+  a.bias = c.params + op.p_b; a.Cp = op.cout; a.t_off = op.t_off; a.t_stride = op.t_stride; a.P = c.f->P; a.ld = c.ld;
+}
+void mcf_desc(const Ctx& c, const Op& op, ipoke_mcf_desc& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.ld = c.ld; d.C = op.C; d.B = c.B; d.cond = c.at<void>(c.plan.cond_act); d.Cc = c.f->cfg.cond_channels;
+  d.W1 = c.sh(op.sh_w1); d.W2 = c.sh(op.sh_w2); d.bias2 = c.params + op.p_b; d.order = op.order;
+  d.W1T = c.sh(op.sh_w1t); d.W2T = c.sh(op.sh_w2t);
+}
+
+int common_checks(ipoke_flow* f, int B) {
+  IPK_REQUIRE(f != nullptr, "null flow handle");
+  IPK_REQUIRE(B >= 1 && B <= f->cfg.max_batch, "batch exceeds max_batch of the flow handle");
+  return IPOKE_OK;
+}
+
+hipEvent_t next_event(ipoke_flow* f) {
+  hipEvent_t e = f->events[f->ev_next];
+  f->ev_next = (f->ev_next + 1) % f->events.size();
+  return e;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out) {
+  IPK_REQUIRE(cfg && out, "null argument");
+  IPK_REQUIRE(cfg->dtype == IPOKE_F32 || cfg->dtype == IPOKE_BF16, "bad dtype");
+  IPK_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= 32 && cfg->n_levels < cfg->factor, "num_steps must be shorter than factor");
+  IPK_REQUIRE(cfg->z_channels % cfg->factor == 0 && cfg->z_channels <= 64, "flow_in_channels must be a multiple of factor, <= 64");
+  IPK_REQUIRE((cfg->z_channels / cfg->factor) % 2 == 0, "channel step must be even (skip split)");
+  IPK_REQUIRE(cfg->kernel_h == 2 && cfg->kernel_w == 3, "kernel_size must be [2,3] (shipped configs)");
+  IPK_REQUIRE(cfg->hidden % 32 == 0 && cfg->cond_channels % 32 == 0, "hidden / cond widths must be multiples of 32");
+  std::unique_ptr<ipoke_flow> f(new ipoke_flow());
+  f->cfg = *cfg;
+  f->esz = cfg->dtype == IPOKE_BF16 ? 2 : 4; f->e16 = 16 / f->esz; f->ks = 64 / f->esz;
+  int rc = build(*f); if (rc) return rc;
+  const char* env = getenv("IPOKE_NO_SIDE_STREAM");
+  f->use_side = !(env && env[0] == '1');
+  *out = f.release();
+  return IPOKE_OK;
+}
+
+// Device-side tables, the side stream and its events are created on first use so that the topology
+// (names, shapes, offsets) can be inspected on a host without a GPU.
+static int ensure_device(ipoke_flow* f) {
+  if (f->d_rjobs) return IPOKE_OK;
+  IPK_REQUIRE((int)sizeof(RelayoutJobH) == ipoke_relayout_job_size() && (int)sizeof(WnJobH) == ipoke_wn_job_size(),
+              "job table layout mismatch");
+  IPK_HIP(hipMalloc(&f->d_rjobs, f->rjobs.size() * sizeof(RelayoutJobH)));
+  IPK_HIP(hipMemcpy(f->d_rjobs, f->rjobs.data(), f->rjobs.size() * sizeof(RelayoutJobH), hipMemcpyHostToDevice));
+  IPK_HIP(hipMalloc(&f->d_wjobs, f->wjobs.size() * sizeof(WnJobH)));
+  IPK_HIP(hipMemcpy(f->d_wjobs, f->wjobs.data(), f->wjobs.size() * sizeof(WnJobH), hipMemcpyHostToDevice));
+  IPK_HIP(hipMalloc(&f->d_lsrefs, f->lsrefs.size() * sizeof(LsRefH)));
+  IPK_HIP(hipMemcpy(f->d_lsrefs, f->lsrefs.data(), f->lsrefs.size() * sizeof(LsRefH), hipMemcpyHostToDevice));
+  IPK_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+  f->events.resize(64);
+  for (auto& e : f->events) IPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return IPOKE_OK;
+}
+
+extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
+  if (!f) return;
+  if (f->d_rjobs) (void)hipFree(f->d_rjobs);
+  if (f->d_wjobs) (void)hipFree(f->d_wjobs);
+  if (f->d_lsrefs) (void)hipFree(f->d_lsrefs);
+  for (auto e : f->events) (void)hipEventDestroy(e);
+  if (f->side) (void)hipStreamDestroy(f->side);
+  delete f;
+}
+
+extern "C" int64_t ipoke_flow_param_count(const ipoke_flow* f) { return f ? f->n_params : -1; }
+extern "C" int64_t ipoke_flow_index_count(const ipoke_flow* f) { return f ? f->n_perm : -1; }
+extern "C" int32_t ipoke_flow_tensor_count(const ipoke_flow* f) { return f ? (int32_t)f->tensors.size() : -1; }
+extern "C" int32_t ipoke_flow_op_count(const ipoke_flow* f) { return f ? (int32_t)f->ops.size() : -1; }
+extern "C" int ipoke_flow_tensor_info(const ipoke_flow* f, int i, char* name, int name_cap, int64_t* offset, int32_t* ndim,
+                                      int64_t* shape4, int32_t* kind) {
+  IPK_REQUIRE(f && i >= 0 && i < (int)f->tensors.size() && name && offset && ndim && shape4 && kind, "bad arguments");
+  const TensorInfo& t = f->tensors[i];
+  IPK_REQUIRE((int)t.name.size() + 1 <= name_cap, "name buffer too small");
+  std::memcpy(name, t.name.c_str(), t.name.size() + 1);
+  *offset = t.offset; *ndim = (int32_t)t.shape.size(); *kind = t.kind;
+  for (int k = 0; k < 4; ++k) shape4[k] = k < (int)t.shape.size() ? t.shape[k] : 1;
+  return IPOKE_OK;
+}
+extern "C" int64_t ipoke_flow_shadow_bytes(const ipoke_flow* f) {
+  if (!f) return -1;
+  return 2 * align_up(f->wn_rows, 64) * 4 + f->shadow_elems * f->esz;
+}
+extern "C" int64_t ipoke_flow_workspace_bytes(ipoke_flow* f, int B, int training) {
+  if (!f || B < 1) return -1;
+  return make_plan(*f, B, training ? 1 : 0).bytes;
+}
+
+extern "C" int ipoke_flow_prepare_weights(ipoke_flow* f, const float* params, void* shadow, void* stream) {
+  IPK_REQUIRE(f && params && shadow, "null argument");
+  { int rc0 = ensure_device(f); if (rc0) return rc0; }
+  float* wn_scale = reinterpret_cast<float*>(shadow);
+  float* wn_inv = wn_scale + align_up(f->wn_rows, 64);
+  int rc = ipoke_wn_scale_multi(params, wn_scale, wn_inv, f->d_wjobs, (int)f->wjobs.size(), (int)f->wn_rows, stream);
+  if (rc) return rc;
+  void* sh = reinterpret_cast<unsigned char*>(shadow) + 2 * align_up(f->wn_rows, 64) * 4;
+  return ipoke_relayout_multi(params, sh, wn_scale, f->d_rjobs, (int)f->rjobs.size(), f->rblocks, f->cfg.dtype, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow, const float* x_nchw,
+                       const float* cond_nchw, int B, float* out_nchw, float* logdet, void* workspace, int save, int init,
+                       float* params_mut, void* stream) {
+  int rc = common_checks(f, B); if (rc) return rc;
+  rc = ensure_device(f); if (rc) return rc;
+  IPK_REQUIRE(params && perm && x_nchw && out_nchw && workspace, "null argument");
+  IPK_REQUIRE(init || (shadow && cond_nchw), "shadow weights and cond are required");
+  Ctx c{f, B, (int64_t)B * f->P, f->cfg.z_channels, f->cfg.dtype, reinterpret_cast<hipStream_t>(stream),
+        params, perm, reinterpret_cast<const unsigned char*>(shadow), reinterpret_cast<unsigned char*>(workspace),
+        make_plan(*f, B, save ? 1 : 0)};
+  const int z = f->cfg.z_channels;
+  rc = ipoke_nchw_to_state(x_nchw, c.state(0), B, z, f->P, c.ld, stream); if (rc) return rc;
+  if (!init) {
+    rc = ipoke_cond_prepare(cond_nchw, c.at<void>(c.plan.cond_act), B, f->cfg.cond_channels, f->P, IPOKE_ACT_ELU, c.dtype, stream);
+    if (rc) return rc;
+  }
+  IPK_HIP(hipMemsetAsync(c.at<void>(c.plan.slots), 0, (size_t)f->nslots * B * 4 * sizeof(float), c.s));
+  int cur = 0;
+  for (size_t i = 0; i < f->ops.size(); ++i) {
+    const Op& op = f->ops[i];
+    const int nxt = save ? (int)i + 1 : (cur ^ 1);
+    const float* in = c.state(cur); float* out = c.state(nxt);
+    if (op.type == OP_ACTNORM) {
+      const float* ls = op.p_ls >= 0 ? params + op.p_ls : nullptr;
+      const float* bs = op.p_bias >= 0 ? params + op.p_bias : nullptr;
+      const int32_t* idx = op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr;
+      if (init && op.p_ls >= 0) {
+        rc = ipoke_actnorm_init(in, (int)c.M, c.ld, op.c0, op.Cn, params_mut + op.p_ls, params_mut + op.p_bias, stream);
+        if (rc) return rc;
+      }
+      rc = ipoke_actnorm_fwd(in, out, (int)c.M, c.ld, op.c0, op.Cn, ls, bs, idx, stream);
+    } else if (init) {
+      // zero-initialised couplings are the identity (macow_utils.py:231-250 with init_scale = 0)
+      continue;
+    } else if (op.type == OP_MCF) {
+      ipoke_mcf_desc d; mcf_desc(c, op, d);
+      d.x = in; d.y = out;
+      d.logdet_slot = c.at<float>(c.plan.slots) + (int64_t)op.slot * B * 4;
+      d.rows_per_block = 16;    // 4 slices per sample -> slot width 4
+      if (save) { d.a2_save = c.at<void>(op.ws_a); d.scale_save = c.at<float>(op.ws_b); }
+      rc = ipoke_mcf_fwd(&d, c.dtype, stream);
+    } else {
+      void* h1 = save ? c.at<void>(op.ws_a) : c.at<void>(c.plan.tmp_h1);
+      void* h2 = save ? c.at<void>(op.ws_b) : c.at<void>(c.plan.tmp_h2);
+      rc = nice_net(c, op, in, h1, h2); if (rc) return rc;
+      ipoke_affine_desc a; nice_affine_desc(c, op, a);
+      rc = ipoke_affine_fwd(&a, in, out, save ? c.at<float>(op.ws_c) : nullptr,
+                            c.at<float>(c.plan.slots) + (int64_t)op.slot * B * 4, 4, B, stream);
+    }
+    if (rc) return rc;
+    cur = nxt;
+  }
+  rc = ipoke_state_to_nchw(c.state(cur), out_nchw, B, z, f->P, c.ld, stream); if (rc) return rc;
+  if (logdet) {
+    rc = ipoke_actnorm_logdet(params, f->d_lsrefs, (int)f->lsrefs.size(), f->P, c.at<float>(c.plan.ls_const), stream);
+    if (rc) return rc;
+    rc = ipoke_logdet_finalize(c.at<float>(c.plan.slots), init ? 0 : f->nslots, B, 4, 0.f, c.at<float>(c.plan.ls_const), logdet, stream);
+    if (rc) return rc;
+  }
+  f->last_fwd_B = B; f->have_saved = save != 0;
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_flow_forward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                                  const float* x_nchw, const float* cond_nchw, int B, float* out_nchw, float* logdet,
+                                  void* workspace, int save_for_backward, void* stream) {
+  return run_forward(f, params, perm, shadow, x_nchw, cond_nchw, B, out_nchw, logdet, workspace, save_for_backward, 0, nullptr, stream);
+}
+
+extern "C" int ipoke_flow_init_forward(ipoke_flow* f, float* params, const int32_t* perm, const float* x_nchw, int B,
+                                       float* out_nchw, float* logdet, void* workspace, void* stream) {
+  IPK_REQUIRE(f && params, "null argument");
+  // weight-norm layers with zero_init: g <- 0/(std+1e-6) = 0, bias <- -mean*0 = 0 (macow_utils.py:231-250)
+  for (const Op& op : f->ops) {
+    if (op.type == OP_ACTNORM) continue;
+    const int n = op.type == OP_MCF ? 2 * op.C : 2 * op.cout;
+    IPK_HIP(hipMemsetAsync(params + op.p_g, 0, n * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
+    IPK_HIP(hipMemsetAsync(params + op.p_b, 0, n * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
+  }
+  return run_forward(f, params, perm, nullptr, x_nchw, nullptr, B, out_nchw, logdet, workspace, 0, 1, params, stream);
+}
+
+extern "C" int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                                  const float* z_nchw, const float* cond_nchw, int B, float* x_nchw, void* workspace,
+                                  void* stream) {
+  int rc = common_checks(f, B); if (rc) return rc;
+  rc = ensure_device(f); if (rc) return rc;
+  IPK_REQUIRE(params && perm && shadow && z_nchw && cond_nchw && x_nchw && workspace, "null argument");
+  Ctx c{f, B, (int64_t)B * f->P, f->cfg.z_channels, f->cfg.dtype, reinterpret_cast<hipStream_t>(stream),
+        params, perm, reinterpret_cast<const unsigned char*>(shadow), reinterpret_cast<unsigned char*>(workspace),
+        make_plan(*f, B, 0)};
+  const int z = f->cfg.z_channels;
+  rc = ipoke_nchw_to_state(z_nchw, c.state(0), B, z, f->P, c.ld, stream); if (rc) return rc;
+  rc = ipoke_cond_prepare(cond_nchw, c.at<void>(c.plan.cond_act), B, f->cfg.cond_channels, f->P, IPOKE_ACT_ELU, c.dtype, stream);
+  if (rc) return rc;
+  int cur = 0;
+  for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
+    const Op& op = f->ops[i];
+    const float* in = c.state(cur); float* out = c.state(cur ^ 1);
+    if (op.type == OP_ACTNORM) {
+      rc = ipoke_actnorm_inv(in, out, (int)c.M, c.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
+                             op.p_bias >= 0 ? params + op.p_bias : nullptr, op.idx_bwd >= 0 ? perm + op.idx_bwd : nullptr, stream);
+    } else if (op.type == OP_MCF) {
+      ipoke_mcf_desc d; mcf_desc(c, op, d);
+      d.x = in; d.y = out;
+      rc = ipoke_mcf_inv(&d, c.dtype, stream);
+    } else {
+      // the conditioning channels are untouched by the coupling, so the net sees the same input as in forward
+      rc = nice_net(c, op, in, c.at<void>(c.plan.tmp_h1), c.at<void>(c.plan.tmp_h2)); if (rc) return rc;
+      ipoke_affine_desc a; nice_affine_desc(c, op, a);
+      rc = ipoke_affine_inv(&a, in, out, B, stream);
+    }
+    if (rc) return rc;
+    cur ^= 1;
+  }
+  return ipoke_state_to_nchw(c.state(cur), x_nchw, B, z, f->P, c.ld, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                                   const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
+                                   void* workspace, void* stream) {
+  int rc = common_checks(f, B); if (rc) return rc;
+  IPK_REQUIRE(params && perm && shadow && d_out_nchw && d_logdet && grads && workspace, "null argument");
+  if (!f->have_saved || f->last_fwd_B != B)
+    return fail(IPOKE_ERR_STATE, "ipoke_flow_backward needs a preceding ipoke_flow_forward(save_for_backward=1) with the same batch");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Ctx c{f, B, (int64_t)B * f->P, f->cfg.z_channels, f->cfg.dtype, s, params, perm,
+        reinterpret_cast<const unsigned char*>(shadow), reinterpret_cast<unsigned char*>(workspace), make_plan(*f, B, 1)};
+  const int z = f->cfg.z_channels, hid = f->cfg.hidden, M = (int)c.M;
+  float* G[2] = {c.at<float>(c.plan.g0), c.at<float>(c.plan.g1)};
+  float* dld = c.at<float>(c.plan.dld);
+  rc = ipoke_nchw_to_state(d_out_nchw, G[0], B, z, f->P, c.ld, stream); if (rc) return rc;
+  IPK_HIP(hipMemcpyAsync(dld, d_logdet, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  hipStream_t ws_stream = f->use_side ? f->side : s;
+  void* wstream = reinterpret_cast<void*>(ws_stream);
+  if (f->use_side) {   // the side stream joins after everything already queued on the main stream
+    hipEvent_t e = next_event(f);
+    IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0));
+  }
+  int cur = 0;
+  for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
+    const Op& op = f->ops[i];
+    const float* gin = G[cur]; float* gout = G[cur ^ 1];
+    const float* xin = c.state(i);                 // saved input of op i
+    float* dbp = c.at<float>(c.plan.dbias_part) + (int64_t)i * B * 128;
+    if (op.type == OP_ACTNORM) {
+      rc = ipoke_actnorm_bwd(gin, xin, gout, M, c.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
+                             op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr, dld, B, f->P,
+                             op.p_ls >= 0 ? grads + op.p_ls : nullptr, op.p_bias >= 0 ? grads + op.p_bias : nullptr, stream);
+      if (rc) return rc;
+    } else if (op.type == OP_MCF) {
+      ipoke_mcf_desc d; mcf_desc(c, op, d);
+      d.x = xin; d.dy = gin; d.dx = gout; d.dld = dld;
+      d.a2_save = c.at<void>(op.ws_a); d.scale_save = c.at<float>(op.ws_b);
+      d.dparams_save = c.at<void>(op.ws_c); d.dc_save = c.at<void>(op.ws_d); d.dbias_part = dbp;
+      d.y = gout;   // unused by the backward kernel, must be non-null for the shared validator
+      rc = ipoke_mcf_bwd(&d, c.dtype, stream); if (rc) return rc;
+      if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
+      // weight gradients (side stream)
+      rc = ipoke_reduce_rows(dbp, grads + op.p_b, B, 2 * op.C, wstream); if (rc) return rc;
+      ipoke_wgrad_desc w; std::memset(&w, 0, sizeof(w));
+      w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = w.kh = w.kw = 1; w.sd = w.sh = w.sw = 1;
+      const int K2 = op.H + f->cfg.cond_channels;
+      w.A = c.at<void>(op.ws_a); w.a_f32 = 0; w.a_sn = 64L * op.K2p; w.a_sh = 8L * op.K2p; w.a_sw = op.K2p; w.a_sc = 1;
+      w.Kc_real = K2; w.Kc = op.K2p;
+      w.dY = c.at<void>(op.ws_c); w.ldy = op.K3p; w.Nout = 2 * op.C;
+      w.dW = grads + op.p_v; w.w_sn = K2; w.w_sc = 1; w.w_st = 0;
+      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+      const McfGeom g = mcf_geom(op.order);
+      std::memset(&w, 0, sizeof(w));
+      w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = g.kh; w.kw = g.kw;
+      w.sd = w.sh = w.sw = 1; w.ph = -g.oy; w.pw = -g.ox;
+      w.A = xin; w.a_f32 = 1; w.a_sn = 64L * c.ld; w.a_sh = 8L * c.ld; w.a_sw = c.ld; w.a_sc = 1; w.Kc_real = op.C; w.Kc = op.Cp;
+      w.dY = c.at<void>(op.ws_d); w.ldy = op.Hq; w.Nout = op.H;
+      w.dW = grads + op.p_w1; w.w_sn = (int64_t)op.C * 6; w.w_sc = 6; w.w_st = 1;
+      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+    } else {
+      const void* h1 = c.at<void>(op.ws_a); const void* h2 = c.at<void>(op.ws_b);
+      void* dprm = c.at<void>(op.ws_d); void* dp2 = c.at<void>(op.ws_e); void* dp1 = c.at<void>(op.ws_f);
+      rc = ipoke_affine_bwd(op.cout, op.t_off, op.t_stride, f->P, c.ld, gin, xin, c.at<float>(op.ws_c), dld, gout, dprm,
+                            op.Kc3, dbp, B, c.dtype, stream);
+      if (rc) return rc;
+      ipoke_conv_desc d;
+      // conv3 data gradient, times ELU'(h2)
+      set_conv8(d, B, 3, 1); d.transposed = 1;
+      set_a_dense(d, dprm, op.Kc3, op.Kc3);
+      d.W = c.sh(op.sh_c3t); d.ldw = 9 * op.Kc3; d.Nout = hid; d.dact = h2; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
+      d.C = dp2; d.ldc = hid;
+      rc = ipoke_conv_forward(&d, c.dtype, stream); if (rc) return rc;
+      // conv2 data gradient, times ELU'(h1)
+      set_conv8(d, B, 1, 0);
+      set_a_dense(d, dp2, hid, hid);
+      d.W = c.sh(op.sh_c2t); d.ldw = hid; d.Nout = hid; d.dact = h1; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
+      d.C = dp1; d.ldc = hid;
+      rc = ipoke_conv_forward(&d, c.dtype, stream); if (rc) return rc;
+      // conv1 data gradient accumulated into the conditioning channels
+      set_conv8(d, B, 3, 1); d.transposed = 1;
+      set_a_dense(d, dp1, hid, hid);
+      d.W = c.sh(op.sh_c1t); d.ldw = 9 * hid; d.Nout = op.cin; d.C = gout; d.c_f32 = 1; d.c_accumulate = 1; d.ldc = c.ld;
+      d.c_coff = op.z_off; d.c_cstride = op.z_stride;
+      rc = ipoke_conv_forward(&d, c.dtype, stream); if (rc) return rc;
+      if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
+      rc = ipoke_reduce_rows(dbp, grads + op.p_b, B, 2 * op.cout, wstream); if (rc) return rc;
+      ipoke_wgrad_desc w;
+      auto base8 = [&](int k, int pad) {
+        std::memset(&w, 0, sizeof(w));
+        w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = w.kw = k;
+        w.sd = w.sh = w.sw = 1; w.ph = w.pw = pad;
+      };
+      // conv3 (effective weight; weight-norm backward runs at the end)
+      base8(3, 1);
+      w.A = h2; w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
+      w.dY = dprm; w.ldy = op.Kc3; w.Nout = 2 * op.cout;
+      w.dW = grads + op.p_v; w.w_sn = (int64_t)hid * 9; w.w_sc = 9; w.w_st = 1;
+      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+      // conv2
+      base8(1, 0);
+      w.A = h1; w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
+      w.dY = dp2; w.ldy = hid; w.Nout = hid;
+      w.dW = grads + op.p_c2; w.w_sn = hid; w.w_sc = 1; w.w_st = 0;
+      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+      // conv1 (input = conditioning channels of the saved state)
+      base8(3, 1);
+      w.A = xin; w.a_f32 = 1; w.a_sn = 64L * c.ld; w.a_sh = 8L * c.ld; w.a_sw = c.ld; w.a_sc = op.z_stride; w.a_coff = op.z_off;
+      w.Kc_real = op.cin; w.Kc = op.Kc1;
+      w.dY = dp1; w.ldy = hid; w.Nout = hid;
+      w.dW = grads + op.p_c1; w.w_sn = (int64_t)op.cin * 9; w.w_sc = 9; w.w_st = 1;
+      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+    }
+    cur ^= 1;
+  }
+  if (f->use_side) {
+    hipEvent_t e = next_event(f);
+    IPK_HIP(hipEventRecord(e, f->side)); IPK_HIP(hipStreamWaitEvent(s, e, 0));
+  }
+  rc = ipoke_wn_bwd_multi(params, grads, c.wn_inv(), f->d_wjobs, (int)f->wjobs.size(), (int)f->wn_rows, stream);
+  if (rc) return rc;
+  if (dx_nchw) { rc = ipoke_state_to_nchw(G[cur], dx_nchw, B, z, f->P, c.ld, stream); if (rc) return rc; }
+  return IPOKE_OK;
+}

@@ -1,0 +1,622 @@
+// Implicit-GEMM convolution kernels on the CDNA4 matrix cores (gfx950).
+//
+//   igemm_nt : C[m][n] = sum_k A[m][k] * W[n][k]      (forward conv, transposed conv, data gradients)
+//   igemm_tn : dW[n][k] = sum_m dY[m][n] * A[m][k]    (weight gradients)
+//
+// A[m][k] is never materialised: row m is an output position (n, od, oh, ow), k = tap*Kc + c, and
+// the loader gathers channel runs of the tap's input position from a channels-last (or arbitrarily
+// strided fp32) tensor, zero-filling out-of-range taps.  Tiles are staged global -> VGPR -> LDS
+// (double buffered, one barrier per K-block) so that fp32 sources are converted on the fly and, in
+// the TN kernel, 8x8 (bf16) / 4x4 (f32) blocks are transposed in registers before they reach LDS.
+// 256 threads = 4 wave64; each wave owns MREP x NREP 16x16 accumulator fragments.
+#include "common.h"
+
+namespace ipoke {
+
+static constexpr int kPitch = 144;   // 128 B of K per LDS row + 16 B pad
+
+struct GeomDev {
+  int M;
+  int lDo, lHo, lWo;         // log2 of output dims
+  int Di, Hi, Wi;
+  int khw, kw, taps;         // kh*kw, kw, kd*kh*kw
+  int sd, sh, sw, pd, ph, pw;
+  int lsd, lsh, lsw;         // log2 strides (transposed mode)
+  int transposed;
+};
+
+struct NtParams {
+  GeomDev g;
+  const void* A; int a_f32; long a_sn, a_sd, a_sh, a_sw, a_sc; int a_coff, Kc_real, Kc;
+  const void* W; int ldw; int Nout; int Ktot;
+  const float* bias; int act; const void* dact; int ld_dact, dact_act;
+  void* C; int c_f32, c_acc; long ldc; int c_coff, c_cstride;
+  int splitk, kb_per_split, n_pad;
+  int tiles_m, tiles_n, xa, xb;
+};
+
+struct TnParams {
+  GeomDev g;
+  const void* A; int a_f32; long a_sn, a_sd, a_sh, a_sw, a_sc; int a_coff, Kc_real, Kc;
+  const void* dY; int ldy, y_coff; int Nout; int Ktot;
+  float* dW; long w_sn, w_sc, w_st; int accumulate;
+  int splitm, mb_per_split;
+  int tiles_n, tiles_k;
+};
+
+// decode output row m -> input base coordinates
+struct RowPos { long nb; int d0, h0, w0; int ok; };
+
+__device__ __forceinline__ RowPos decode_row(const GeomDev& g, int m, long a_sn) {
+  RowPos r;
+  r.ok = m < g.M;
+  const int ow = m & ((1 << g.lWo) - 1);
+  const int t1 = m >> g.lWo;
+  const int oh = t1 & ((1 << g.lHo) - 1);
+  const int t2 = t1 >> g.lHo;
+  const int od = t2 & ((1 << g.lDo) - 1);
+  const int n = t2 >> g.lDo;
+  r.nb = (long)n * a_sn;
+  if (!g.transposed) {
+    r.d0 = od * g.sd - g.pd; r.h0 = oh * g.sh - g.ph; r.w0 = ow * g.sw - g.pw;
+  } else {
+    r.d0 = od + g.pd; r.h0 = oh + g.ph; r.w0 = ow + g.pw;
+  }
+  return r;
+}
+
+// input coordinates of (row, tap); returns validity
+__device__ __forceinline__ bool tap_coords(const GeomDev& g, const RowPos& r, int tapcode, int& id, int& ih, int& iw) {
+  const int td = tapcode & 0xff, th = (tapcode >> 8) & 0xff, tw = (tapcode >> 16) & 0xff;
+  if (!g.transposed) {
+    id = r.d0 + td; ih = r.h0 + th; iw = r.w0 + tw;
+  } else {
+    const int nd = r.d0 - td, nh = r.h0 - th, nw = r.w0 - tw;
+    if ((nd | nh | nw) < 0) return false;
+    if ((nd & (g.sd - 1)) | (nh & (g.sh - 1)) | (nw & (g.sw - 1))) return false;
+    id = nd >> g.lsd; ih = nh >> g.lsh; iw = nw >> g.lsw;
+  }
+  return (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
+}
+
+template <typename T> struct Chunk;      // 16 bytes of T
+template <> struct Chunk<bf16_t> { typedef bf16x8 type; };
+template <> struct Chunk<float> { typedef f32x4 type; };
+
+// gather one 16-byte chunk of A: channels [c, c+E16) of the tap's input position
+template <typename T>
+__device__ __forceinline__ u32x4 load_a_chunk(const void* A, int a_f32, long off, long a_sc, int a_coff, int c, int Kc_real) {
+  constexpr int E16 = ET<T>::E16;
+  u32x4 out = {0u, 0u, 0u, 0u};
+  if (!a_f32) {
+    if (c < Kc_real) out = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(A) + off + a_coff + c);
+  } else {
+    const float* src = reinterpret_cast<const float*>(A) + off;
+    typename Chunk<T>::type v;
+#pragma unroll
+    for (int e = 0; e < E16; ++e) {
+      const int ch = c + e;
+      const float f = ch < Kc_real ? src[(long)(a_coff + ch) * a_sc] : 0.f;
+      v[e] = ET<T>::from_f32(f);
+    }
+    out = *reinterpret_cast<u32x4*>(&v);
+  }
+  return out;
+}
+
+__device__ __forceinline__ void fill_taptab(int* tab, const GeomDev& g) {
+  for (int t = threadIdx.x; t < g.taps; t += blockDim.x) {
+    const int td = t / g.khw, rem = t - td * g.khw;
+    const int th = rem / g.kw, tw = rem - th * g.kw;
+    tab[t] = td | (th << 8) | (tw << 16);
+  }
+}
+
+// =============================================================================================
+template <typename T, int WM, int WN, int MREP, int NREP>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
+  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
+  constexpr int E16 = ET<T>::E16;
+  constexpr int BK = 128 / (int)sizeof(T);
+  constexpr int A_IT = (BM * 8 + 255) / 256, B_IT = (BN * 8 + 255) / 256;
+  typedef typename ET<T>::frag frag_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * BM * kPitch;
+  int* taptab = reinterpret_cast<int*>(smem + 2 * (BM + BN) * kPitch);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const GeomDev& g = p.g;
+
+  int tm, tn;
+  {
+    const int bid = blockIdx.x;
+    if (p.xa > 0) {
+      const int xcd = bid & 7, q = bid >> 3;
+      const int sub_m = p.tiles_m / p.xa, sub_n = p.tiles_n / p.xb;
+      (void)sub_n;
+      tm = (xcd % p.xa) * sub_m + q % sub_m;
+      tn = (xcd / p.xa) * sub_n + q / sub_m;
+    } else {
+      tm = bid % p.tiles_m; tn = bid / p.tiles_m;
+    }
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int nkb_total = (p.Ktot + BK - 1) / BK;
+  const int kb_begin = z * p.kb_per_split;
+  const int kb_end = min(nkb_total, kb_begin + p.kb_per_split);
+
+  fill_taptab(taptab, g);
+
+  // per-thread chunk bookkeeping
+  RowPos arow[A_IT]; int a_tap[A_IT], a_c[A_IT]; int a_lds[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int ch = tid + 256 * i;
+    const int row = ch >> 3, kc = ch & 7;
+    const bool in_tile = row < BM;
+    arow[i] = decode_row(g, m0 + row, p.a_sn);
+    arow[i].ok = arow[i].ok && in_tile;
+    const int kglob = kb_begin * BK + kc * E16;
+    a_tap[i] = kglob / p.Kc;
+    a_c[i] = kglob - a_tap[i] * p.Kc;
+    a_lds[i] = in_tile ? row * kPitch + kc * 16 : -1;
+  }
+  int b_row[B_IT], b_k[B_IT], b_lds[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int ch = tid + 256 * i;
+    const int row = ch >> 3, kc = ch & 7;
+    b_row[i] = (row < BN && n0 + row < p.Nout) ? n0 + row : -1;
+    b_k[i] = kb_begin * BK + kc * E16;
+    b_lds[i] = row < BN ? row * kPitch + kc * 16 : -1;
+  }
+  __syncthreads();   // taptab ready
+
+  u32x4 ra[A_IT], rb[B_IT];
+  auto load_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (arow[i].ok && a_tap[i] < g.taps) {
+        int id, ih, iw;
+        if (tap_coords(g, arow[i], taptab[a_tap[i]], id, ih, iw)) {
+          const long off = arow[i].nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw;
+          v = load_a_chunk<T>(p.A, p.a_f32, off, p.a_sc, p.a_coff, a_c[i], p.Kc_real);
+        }
+      }
+      ra[i] = v;
+      a_c[i] += BK;
+      while (a_c[i] >= p.Kc) { a_c[i] -= p.Kc; ++a_tap[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (b_row[i] >= 0 && b_k[i] < p.ldw)
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.W) + (long)b_row[i] * p.ldw + b_k[i]);
+      rb[i] = v;
+      b_k[i] += BK;
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      if (a_lds[i] >= 0) *reinterpret_cast<u32x4*>(sA + buf * BM * kPitch + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      if (b_lds[i] >= 0) *reinterpret_cast<u32x4*>(sB + buf * BN * kPitch + b_lds[i]) = rb[i];
+  };
+
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kb_begin < kb_end) {
+    load_stage();
+    store_stage(0);
+    __syncthreads();
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      const int buf = (kb - kb_begin) & 1;
+      const bool more = kb + 1 < kb_end;
+      if (more) load_stage();
+      const unsigned char* a_base = sA + buf * BM * kPitch + (wm * MREP * 16 + (lane & 15)) * kPitch + (lane >> 4) * 16;
+      const unsigned char* b_base = sB + buf * BN * kPitch + (wn * NREP * 16 + (lane & 15)) * kPitch + (lane >> 4) * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        frag_t fa[MREP], fb[NREP];
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) fa[i] = *reinterpret_cast<const frag_t*>(a_base + i * 16 * kPitch + s * 64);
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(b_base + j * 16 * kPitch + s * 64);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) mma64(fa[i], fb[j], acc[i][j]);
+      }
+      if (more) store_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  const int mrow = m0 + wm * MREP * 16 + (lane & 15);
+  const int ncol = n0 + wn * NREP * 16 + (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    const int m = mrow + i * 16;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int n = ncol + j * 16;
+      if (n >= p.n_pad) continue;
+      f32x4 v = acc[i][j];
+      if (p.splitk > 1) {
+        float* P = reinterpret_cast<float*>(p.C) + ((long)z * g.M + m) * p.ldc + n;
+        if (n + 3 < p.ldc) *reinterpret_cast<f32x4*>(P) = v;    // ldc is padded to a multiple of 4
+        else for (int r = 0; r < 4; ++r) if (n + r < p.ldc) P[r] = v[r];
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = v[r];
+        if (n + r < p.Nout) {
+          if (p.bias) x += p.bias[n + r];
+          x = act_apply(p.act, x);
+          if (p.dact) {
+            const float y = ET<T>::to_f32(reinterpret_cast<const T*>(p.dact)[(long)m * p.ld_dact + n + r]);
+            x *= act_grad_from_out(p.dact_act, y);
+          }
+        } else {
+          x = 0.f;
+        }
+        v[r] = x;
+      }
+      if (p.c_f32) {
+        float* Cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + p.c_coff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.Nout) {
+            float* q = Cp + (long)(n + r) * p.c_cstride;
+            *q = p.c_acc ? *q + v[r] : v[r];
+          }
+        }
+      } else {
+        T* Cp = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + p.c_coff + n;
+        // columns up to n_pad are written (zero beyond Nout) so that consumers can read a padded K
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.n_pad) Cp[r] = ET<T>::from_f32(v[r]);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// weight gradient
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
+  constexpr int TN_ = 128, TK_ = 128;          // output tile: 128 out-channels x 128 k
+  constexpr int E16 = ET<T>::E16;
+  constexpr int RM = 128 / (int)sizeof(T);     // reduction rows per stage
+  constexpr int LOGE = E16 == 8 ? 3 : 2;
+  constexpr int NBLK = (RM / E16) * (128 / E16);   // ExE blocks per operand tile (bf16: 128, f32: 256)
+  constexpr int PER_OP = NBLK / 256 == 0 ? 1 : NBLK / 256;   // blocks per thread per operand (f32: 1)
+  typedef typename ET<T>::frag frag_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sY = smem;                         // [2][128][kPitch]  rows = out-channel n, 128 B of m
+  unsigned char* sX = smem + 2 * TN_ * kPitch;      // [2][128][kPitch]  rows = k
+  int* taptab = reinterpret_cast<int*>(smem + 4 * 128 * kPitch);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const GeomDev& g = p.g;
+  const int tn = blockIdx.x % p.tiles_n, tk = blockIdx.x / p.tiles_n;
+  const int n0 = tn * TN_, k0 = tk * TK_;
+  const int z = blockIdx.y;
+  const int nmb_total = (g.M + RM - 1) / RM;
+  const int mb_begin = z * p.mb_per_split, mb_end = min(nmb_total, mb_begin + p.mb_per_split);
+
+  fill_taptab(taptab, g);
+
+  // Work split.  bf16: threads 0..127 stage dY blocks, 128..255 stage A blocks (one 8x8 block each).
+  //              f32 : every thread stages one 4x4 block of dY and one of A.
+  // block id -> (mb, cb): cb fastest so that a wave's loads run along the contiguous dimension.
+  constexpr int CB = 128 / E16;                 // column blocks per tile row (16 / 32)
+  const bool do_y = (E16 == 8) ? (tid < 128) : true;
+  const bool do_x = (E16 == 8) ? (tid >= 128) : true;
+  const int blk = (E16 == 8) ? (tid & 127) : tid;
+  const int cb = blk % CB, mbk = blk / CB;      // mbk in [0, RM/E16) = [0,8)
+  (void)PER_OP;
+
+  // A-operand column bookkeeping (fixed for the whole reduction)
+  const int kcol = k0 + cb * E16;
+  const int x_tap = kcol / p.Kc, x_c = kcol - x_tap * p.Kc;
+  const bool x_col_ok = do_x && kcol < p.Ktot;
+  const int ncol = n0 + cb * E16;
+  const bool y_col_ok = do_y && ncol < ((p.Nout + E16 - 1) / E16) * E16;
+  __syncthreads();
+  const int x_tapcode = x_col_ok ? taptab[x_tap] : 0;
+
+  u32x4 ry[E16], rx[E16];
+  auto load_stage = [&](int mb) {
+    const int mbase = mb * RM + mbk * E16;
+    if (do_y) {
+#pragma unroll
+      for (int i = 0; i < E16; ++i) {
+        const int m = mbase + i;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (y_col_ok && m < g.M)
+          v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dY) + (long)m * p.ldy + p.y_coff + ncol);
+        ry[i] = v;
+      }
+    }
+    if (do_x) {
+#pragma unroll
+      for (int i = 0; i < E16; ++i) {
+        const int m = mbase + i;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (x_col_ok && m < g.M) {
+          const RowPos r = decode_row(g, m, p.a_sn);
+          int id, ih, iw;
+          if (tap_coords(g, r, x_tapcode, id, ih, iw)) {
+            const long off = r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw;
+            v = load_a_chunk<T>(p.A, p.a_f32, off, p.a_sc, p.a_coff, x_c, p.Kc_real);
+          }
+        }
+        rx[i] = v;
+      }
+    }
+  };
+  // transpose an ExE block held as E16 row-chunks and store its E16 columns as rows of the LDS tile
+  auto store_block = [&](unsigned char* tile, const u32x4* r) {
+    const int key = cb & 7;                                   // == ((row / E16) & 7) for row = cb*E16 + j
+    const int chunk = (mbk ^ key) * 16;
+    if constexpr (E16 == 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        u32x4 o;
+        const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_perm(r[2 * d + 1][j >> 1], r[2 * d][j >> 1], sel);
+        *reinterpret_cast<u32x4*>(tile + (cb * 8 + j) * kPitch + chunk) = o;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x4 o = {r[0][j], r[1][j], r[2][j], r[3][j]};
+        *reinterpret_cast<u32x4*>(tile + (cb * 4 + j) * kPitch + chunk) = o;
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+    if (do_y) store_block(sY + buf * 128 * kPitch, ry);
+    if (do_x) store_block(sX + buf * 128 * kPitch, rx);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (mb_begin < mb_end) {
+    load_stage(mb_begin);
+    store_stage(0);
+    __syncthreads();
+    for (int mb = mb_begin; mb < mb_end; ++mb) {
+      const int buf = (mb - mb_begin) & 1;
+      const bool more = mb + 1 < mb_end;
+      if (more) load_stage(mb + 1);
+      const int yrow = wm * 64 + (lane & 15), xrow = wn * 64 + (lane & 15);
+      const unsigned char* y_base = sY + buf * 128 * kPitch;
+      const unsigned char* x_base = sX + buf * 128 * kPitch;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int q = s * 4 + (lane >> 4);
+        frag_t fy[4], fx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = yrow + i * 16;
+          fy[i] = *reinterpret_cast<const frag_t*>(y_base + row * kPitch + ((q ^ ((row >> LOGE) & 7)) * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = xrow + j * 16;
+          fx[j] = *reinterpret_cast<const frag_t*>(x_base + row * kPitch + ((q ^ ((row >> LOGE) & 7)) * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mma64(fy[i], fx[j], acc[i][j]);
+      }
+      if (more) store_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: acc[i][j][r] = dW[n = n0 + wm*64 + 16i + (lane&15)][k = k0 + wn*64 + 16j + 4*(lane>>4) + r]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wm * 64 + i * 16 + (lane & 15);
+    if (n >= p.Nout) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (k >= p.Ktot) continue;
+      const int tap = k / p.Kc, c = k - tap * p.Kc;     // 4 consecutive k share the tap (Kc % 4 == 0)
+      float* base = p.dW + (long)n * p.w_sn + (long)tap * p.w_st;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (c + r < p.Kc_real) {
+          float* q = base + (long)(c + r) * p.w_sc;
+          if (p.splitm > 1) atomicAdd(q, acc[i][j][r]);
+          else *q = p.accumulate ? *q + acc[i][j][r] : acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// host side
+static int make_geom(GeomDev& g, int NB, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kd, int kh, int kw,
+                     int sd, int sh, int sw, int pd, int ph, int pw, int transposed) {
+  g.lDo = ilog2_exact(Do); g.lHo = ilog2_exact(Ho); g.lWo = ilog2_exact(Wo);
+  IPK_REQUIRE(g.lDo >= 0 && g.lHo >= 0 && g.lWo >= 0, "output extents must be powers of two");
+  g.lsd = ilog2_exact(sd); g.lsh = ilog2_exact(sh); g.lsw = ilog2_exact(sw);
+  IPK_REQUIRE(g.lsd >= 0 && g.lsh >= 0 && g.lsw >= 0, "strides must be powers of two");
+  IPK_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1 && kd * kh * kw <= 256, "unsupported kernel extent");
+  g.M = NB * Do * Ho * Wo;
+  g.Di = Di; g.Hi = Hi; g.Wi = Wi;
+  g.khw = kh * kw; g.kw = kw; g.taps = kd * kh * kw;
+  g.sd = sd; g.sh = sh; g.sw = sw; g.pd = pd; g.ph = ph; g.pw = pw;
+  g.transposed = transposed;
+  return IPOKE_OK;
+}
+
+template <typename KernelT>
+static int set_lds(KernelT k, size_t bytes) {
+  IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return IPOKE_OK;
+}
+
+template <typename T, int WM, int WN, int MREP, int NREP>
+static int launch_nt(NtParams& p, hipStream_t s) {
+  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
+  constexpr int BK = 128 / (int)sizeof(T);
+  p.tiles_m = ceil_div(p.g.M, BM);
+  p.tiles_n = ceil_div(p.Nout, BN);
+  const int nkb = ceil_div(p.Ktot, BK);
+  if (p.splitk < 1) p.splitk = 1;
+  p.kb_per_split = ceil_div(nkb, p.splitk);
+  // XCD-aware tile -> block mapping: XCD x (= blockIdx % 8) owns a (tiles_m/xa) x (tiles_n/xb) sub-grid so
+  // that its private L2 holds one slab of A rows and one slab of W rows; (xa, xb) minimises L2 fill bytes.
+  p.xa = 0; p.xb = 0;
+  const long nt = (long)p.tiles_m * p.tiles_n;
+  if (nt % 8 == 0) {
+    double best = -1;
+    const double bytesA = (double)p.g.M * p.Ktot, bytesW = (double)p.Nout * p.Ktot;
+    for (int xa = 1; xa <= 8; xa *= 2) {
+      const int xb = 8 / xa;
+      if (p.tiles_m % xa || p.tiles_n % xb) continue;
+      const double cost = bytesA / xa + bytesW / xb;
+      if (best < 0 || cost < best) { best = cost; p.xa = xa; p.xb = xb; }
+    }
+  }
+  const size_t lds = 2 * (BM + BN) * kPitch + 256 * sizeof(int);
+  auto kern = igemm_nt_kernel<T, WM, WN, MREP, NREP>;
+  static bool attr_done = false;     // one flag per template instantiation
+  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  dim3 grid((unsigned)nt, (unsigned)p.splitk);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+template <typename T>
+static int dispatch_nt(NtParams& p, hipStream_t s) {
+  // Tile choice: fill the 256 CUs with one wave of tiles when the problem allows it.
+  const int M = p.g.M, N = p.Nout;
+  if (N <= 64) return launch_nt<T, 4, 1, 1, 4>(p, s);                  // 64 x 64 tiles, skinny N (split-K upstream)
+  const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+  if (M % 80 == 0 && M % 128 != 0 && (long)(M / 80) * ceil_div(N, 128) <= 256 && t128 < 256)
+    return launch_nt<T, 1, 4, 5, 2>(p, s);                            // 80 x 128 (e.g. M = 1280 -> 256 tiles)
+  if (M % 160 == 0 && M % 128 != 0 && (long)(M / 160) * ceil_div(N, 128) >= 128)
+    return launch_nt<T, 2, 2, 5, 4>(p, s);                            // 160 x 128 (e.g. M = 2560 -> 256 tiles)
+  if (t128 < 128) return launch_nt<T, 2, 2, 2, 4>(p, s);              // 64 x 128: more tiles for small problems
+  return launch_nt<T, 2, 2, 4, 4>(p, s);                              // 128 x 128
+}
+
+template <typename T>
+static int launch_tn(TnParams& p, hipStream_t s) {
+  constexpr int RM = 128 / (int)sizeof(T);
+  p.tiles_n = ceil_div(p.Nout, 128);
+  p.tiles_k = ceil_div(p.Ktot, 128);
+  const int nmb = ceil_div(p.g.M, RM);
+  if (p.splitm < 1) p.splitm = 1;
+  if (p.splitm > nmb) p.splitm = nmb;
+  p.mb_per_split = ceil_div(nmb, p.splitm);
+  const size_t lds = 4 * 128 * kPitch + 256 * sizeof(int);
+  auto kern = igemm_tn_kernel<T>;
+  static bool attr_done = false;
+  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+}  // namespace ipoke
+
+using namespace ipoke;
+
+extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream) {
+  IPK_REQUIRE(d != nullptr, "null descriptor");
+  IPK_REQUIRE(dtype == IPOKE_F32 || dtype == IPOKE_BF16, "bad dtype");
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4, e16 = 16 / esz;
+  NtParams p;
+  int rc = make_geom(p.g, d->NB, d->Di, d->Hi, d->Wi, d->Do, d->Ho, d->Wo, d->kd, d->kh, d->kw, d->sd, d->sh, d->sw,
+                     d->pd, d->ph, d->pw, d->transposed);
+  if (rc) return rc;
+  IPK_REQUIRE(d->A && d->W && d->C, "null tensor");
+  IPK_REQUIRE(d->Kc % e16 == 0 && d->Kc >= d->Kc_real && d->Kc_real > 0, "Kc must be a padded multiple of 16 bytes");
+  if (!d->a_f32) {
+    IPK_REQUIRE(d->a_sc == 1, "dtype activations must be channels-last");
+    IPK_REQUIRE(d->Kc_real % e16 == 0 && d->a_coff % e16 == 0, "dtype activations need 16-byte aligned channel runs");
+    IPK_REQUIRE(d->a_sn % e16 == 0 && d->a_sd % e16 == 0 && d->a_sh % e16 == 0 && d->a_sw % e16 == 0,
+                "dtype activations need 16-byte aligned rows");
+    IPK_REQUIRE(((uintptr_t)d->A & 15) == 0, "A must be 16-byte aligned");
+  }
+  IPK_REQUIRE(d->ldw % e16 == 0 && ((uintptr_t)d->W & 15) == 0, "weights need 16-byte aligned rows");
+  IPK_REQUIRE(d->ldw >= round_up(p.g.taps * d->Kc, e16) || d->ldw >= p.g.taps * d->Kc, "ldw too small");
+  p.A = d->A; p.a_f32 = d->a_f32; p.a_sn = d->a_sn; p.a_sd = d->a_sd; p.a_sh = d->a_sh; p.a_sw = d->a_sw; p.a_sc = d->a_sc;
+  p.a_coff = d->a_coff; p.Kc_real = d->Kc_real; p.Kc = d->Kc;
+  p.W = d->W; p.ldw = d->ldw; p.Nout = d->Nout; p.Ktot = p.g.taps * d->Kc;
+  p.bias = d->bias; p.act = d->act; p.dact = d->dact; p.ld_dact = d->ld_dact; p.dact_act = d->dact_act;
+  p.C = d->C; p.c_f32 = d->c_f32; p.c_acc = d->c_accumulate; p.ldc = d->ldc; p.c_coff = d->c_coff;
+  p.c_cstride = d->c_cstride <= 0 ? 1 : d->c_cstride;
+  p.splitk = d->splitk < 1 ? 1 : d->splitk;
+  p.n_pad = d->Nout;
+  if (!d->c_f32 && p.splitk == 1) {
+    const long lim = d->ldc - d->c_coff;
+    p.n_pad = (int)(round_up(d->Nout, e16) < lim ? round_up(d->Nout, e16) : lim);
+  }
+  if (p.splitk > 1) {
+    IPK_REQUIRE(d->ldc % 4 == 0 && d->ldc >= d->Nout, "split-K partials need ldc >= Nout, multiple of 4");
+  } else if (!d->c_f32) {
+    IPK_REQUIRE(p.c_cstride == 1 && !d->c_accumulate, "dtype outputs are dense, non-accumulating");
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
+}
+
+extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream) {
+  IPK_REQUIRE(d != nullptr, "null descriptor");
+  IPK_REQUIRE(dtype == IPOKE_F32 || dtype == IPOKE_BF16, "bad dtype");
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4, e16 = 16 / esz;
+  TnParams p;
+  int rc = make_geom(p.g, d->NB, d->Di, d->Hi, d->Wi, d->Do, d->Ho, d->Wo, d->kd, d->kh, d->kw, d->sd, d->sh, d->sw,
+                     d->pd, d->ph, d->pw, d->transposed);
+  if (rc) return rc;
+  IPK_REQUIRE(d->A && d->dY && d->dW, "null tensor");
+  IPK_REQUIRE(d->Kc % e16 == 0 && d->Kc >= d->Kc_real && d->Kc_real > 0, "Kc must be a padded multiple of 16 bytes");
+  if (!d->a_f32) {
+    IPK_REQUIRE(d->a_sc == 1 && d->Kc_real % e16 == 0 && d->a_coff % e16 == 0, "dtype activations: aligned channels-last");
+    IPK_REQUIRE(d->a_sn % e16 == 0 && d->a_sd % e16 == 0 && d->a_sh % e16 == 0 && d->a_sw % e16 == 0, "aligned rows");
+  }
+  IPK_REQUIRE(d->ldy % e16 == 0 && d->y_coff % e16 == 0 && ((uintptr_t)d->dY & 15) == 0, "dY rows must be 16-byte aligned");
+  IPK_REQUIRE(d->y_coff + round_up(d->Nout, e16) <= d->ldy, "dY pitch must cover the padded channel count");
+  p.A = d->A; p.a_f32 = d->a_f32; p.a_sn = d->a_sn; p.a_sd = d->a_sd; p.a_sh = d->a_sh; p.a_sw = d->a_sw; p.a_sc = d->a_sc;
+  p.a_coff = d->a_coff; p.Kc_real = d->Kc_real; p.Kc = d->Kc;
+  p.dY = d->dY; p.ldy = d->ldy; p.y_coff = d->y_coff; p.Nout = d->Nout; p.Ktot = p.g.taps * d->Kc;
+  p.dW = d->dW; p.w_sn = d->w_sn; p.w_sc = d->w_sc; p.w_st = d->w_st; p.accumulate = d->accumulate;
+  p.splitm = d->splitm < 1 ? 1 : d->splitm;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s) : launch_tn<float>(p, s);
+}

@@ -1,0 +1,559 @@
+// Fused Masked-Convolutional-Flow kernels (reference models/modules/INN/macow2.py:25-288 and
+// macow_utils.py:407-499).  One MCF layer is
+//     c = shiftconv_{2x3|3x2}(x)  ->  ELU(cat[c, h])  ->  weight-normed 1x1  ->  (mu, s)
+//     y = (tanh(s/2)+1) * x + mu ,  logdet = sum log scale
+// and all of it runs inside one workgroup per sample (or per slice of a sample): the 8x8xC latent,
+// the hidden activations and the coupling parameters never leave LDS; only weights stream in (from L2)
+// as matrix-core B fragments.  The analytic inverse walks the 8 rows/columns inside a single launch.
+//
+// Matrix-core tiling: 4 wave64 split the output channels; each wave owns MF x NFW 16x16 fragments.
+// A fragments come from LDS (gathered with the autoregressive tap offsets), B fragments are 16-byte
+// global loads of the K-contiguous weight shadows prepared by ipoke_flow_prepare_weights.
+#include "common.h"
+
+namespace ipoke {
+
+template <typename T> struct K64 { static constexpr int value = 64 / (int)sizeof(T); };   // K per super-step
+
+// 16-byte chunk of the (virtual) im2col row of position p: channels [c, c+E16) of tap `tap`
+template <typename T>
+__device__ __forceinline__ typename ET<T>::frag gather_fwd(const unsigned char* tile, int pitch, const McfGeom& g, int p,
+                                                           int tap, int c, int ntaps) {
+  typedef typename ET<T>::frag frag_t;
+  frag_t z;
+#pragma unroll
+  for (int e = 0; e < ET<T>::E16; ++e) z[e] = (T)0.f;
+  if (tap >= ntaps) return z;
+  const int ky = g.kw == 3 ? (tap >= 3) : (tap >> 1);
+  const int kx = tap - ky * g.kw;
+  const int yy = (p >> 3) + ky + g.oy, xx = (p & 7) + kx + g.ox;
+  if ((unsigned)yy >= 8u || (unsigned)xx >= 8u) return z;
+  return *reinterpret_cast<const frag_t*>(tile + (yy * 8 + xx) * pitch + c * (int)sizeof(T));
+}
+// adjoint gather: positions q whose receptive field contains p through tap `tap`
+template <typename T>
+__device__ __forceinline__ typename ET<T>::frag gather_adj(const unsigned char* tile, int pitch, const McfGeom& g, int p,
+                                                           int tap, int c) {
+  typedef typename ET<T>::frag frag_t;
+  frag_t z;
+#pragma unroll
+  for (int e = 0; e < ET<T>::E16; ++e) z[e] = (T)0.f;
+  const int ky = g.kw == 3 ? (tap >= 3) : (tap >> 1);
+  const int kx = tap - ky * g.kw;
+  const int yy = (p >> 3) - ky - g.oy, xx = (p & 7) - kx - g.ox;
+  if ((unsigned)yy >= 8u || (unsigned)xx >= 8u) return z;
+  return *reinterpret_cast<const frag_t*>(tile + (yy * 8 + xx) * pitch + c * (int)sizeof(T));
+}
+
+template <typename T>
+__device__ __forceinline__ typename ET<T>::frag load_wfrag(const T* W, int ldw, int row, int k) {
+  return *reinterpret_cast<const typename ET<T>::frag*>(W + (long)row * ldw + k);
+}
+
+struct McfParams {
+  const float* x; float* y; int ld; int C; int B;
+  const void* cond; int Cc;          // T [B][64][Cc] = act(cond)
+  const void* W1; int K1p; int H;    // [round16(H)][K1p], k = tap*Cp + c
+  const void* W2; int K2p;           // [round16(2C)][K2p], k over [hidden | cond]
+  const float* bias2;                // [2C]
+  int Cp, order;
+  void* a2_save;                     // T [M][K2p] or NULL
+  float* scale_save;                 // [M][C] or NULL
+  float* ld_slot;                    // [B][RS] or NULL
+  // backward only
+  const void* W2T; int K3p;          // [round16(H)][K3p] : W2T[n][j] = W2[j][n]
+  const void* W1T; int Hq;           // [round16(C)][6*Hq]: W1T[c][tap*Hq + n] = W1[n][tap*Cp + c]
+  const float* dy; const float* dld; float* dx;
+  void* dparams_save;                // T [M][K3p]
+  void* dc_save;                     // T [M][Hq]
+  float* dbias_part;                 // [B][2C]
+};
+
+// ------------------------------------------------------------------------------------------
+// stage the sample's latent (fp32, channels-last with pitch ld) into LDS as T [64][Cp] (zero padded)
+template <typename T>
+__device__ __forceinline__ void stage_x(const float* xb, int ld, int C, int Cp, unsigned char* xs, int pitch) {
+  for (int i = threadIdx.x; i < 64 * Cp; i += blockDim.x) {
+    const int p = i / Cp, c = i - p * Cp;
+    const float v = c < C ? xb[(long)p * ld + c] : 0.f;
+    *reinterpret_cast<T*>(xs + p * pitch + c * (int)sizeof(T)) = ET<T>::from_f32(v);
+  }
+}
+
+// hidden = ELU(A1 x W1^T) for MF*16 rows starting at local row 0 (global position pos0 + row) -> a2[row][0:H]
+// rowpos(r) maps a local row to (tile index, position) -- supplied by the caller through lambdas.
+template <typename T, int MF, typename RowFn>
+__device__ __forceinline__ void mcf_gemm1(const McfParams& P, const McfGeom& g, RowFn rowfn, unsigned char* a2, int a2_pitch) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, gq = lane >> 4;
+  const int NF1 = (P.H + 15) >> 4;
+  const int ntaps = g.kh * g.kw;
+  f32x4 acc[MF][4];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned char* tile[MF]; int pos[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) rowfn(i * 16 + r, tile[i], pos[i]);
+  int tap = (E16 * gq) / P.Cp, c = E16 * gq - tap * P.Cp;
+  const T* W1 = reinterpret_cast<const T*>(P.W1);
+  for (int k = 0; k < P.K1p; k += KS) {
+    frag_t fa[MF], fb[4];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) fa[i] = gather_fwd<T>(tile[i], P.Cp * (int)sizeof(T) + 16, g, pos[i], tap, c, ntaps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nf = wave + 4 * j;
+      if (nf < NF1) fb[j] = load_wfrag<T>(W1, P.K1p, nf * 16 + r, k + E16 * gq);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nf = wave + 4 * j;
+      if (nf < NF1) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) mma64(fa[i], fb[j], acc[i][j]);
+      }
+    }
+    c += KS;
+    while (c >= P.Cp) { c -= P.Cp; ++tap; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = (wave + 4 * j) * 16 + 4 * gq;
+    if (n < P.H) {     // H is a multiple of 4: the 4 columns of a lane are all valid or all invalid
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        T* dst = reinterpret_cast<T*>(a2 + (i * 16 + r) * a2_pitch) + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = ET<T>::from_f32(act_apply(IPOKE_ACT_ELU, acc[i][j][q]));
+      }
+    }
+  }
+}
+
+// params[row][0:2C] = A2 x W2^T + bias2  (rows MF*16)
+template <typename T, int MF>
+__device__ __forceinline__ void mcf_gemm2(const McfParams& P, const unsigned char* a2, int a2_pitch, float* prm, int prm_ld) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, gq = lane >> 4;
+  const int N2 = 2 * P.C, NF2 = (N2 + 15) >> 4;
+  f32x4 acc[MF][2];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+  const T* W2 = reinterpret_cast<const T*>(P.W2);
+  for (int k = 0; k < P.K2p; k += KS) {
+    frag_t fa[MF], fb[2];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+      fa[i] = *reinterpret_cast<const frag_t*>(a2 + (i * 16 + r) * a2_pitch + (k + E16 * gq) * (int)sizeof(T));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nf = wave + 4 * j;
+      if (nf < NF2) fb[j] = load_wfrag<T>(W2, P.K2p, nf * 16 + r, k + E16 * gq);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (wave + 4 * j < NF2) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) mma64(fa[i], fb[j], acc[i][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = (wave + 4 * j) * 16 + 4 * gq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (n + q < N2) {
+        const float b = P.bias2 ? P.bias2[n + q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) prm[(i * 16 + r) * prm_ld + n + q] = acc[i][j][q] + b;
+      }
+    }
+  }
+}
+
+// copy act(cond) rows and zero the K padding of the 1x1 conv's input tile
+template <typename T, typename RowFn>
+__device__ __forceinline__ void fill_cond(const McfParams& P, int rows, RowFn grow /* local row -> global row or -1 */,
+                                          unsigned char* a2, int a2_pitch) {
+  constexpr int E16 = ET<T>::E16;
+  const int chunks = (P.K2p - P.H) / E16;              // cond columns + zero padding, in 16-byte chunks
+  const T* cond = reinterpret_cast<const T*>(P.cond);
+  for (int i = threadIdx.x; i < rows * chunks; i += blockDim.x) {
+    const int row = i / chunks, ch = i - row * chunks;
+    const long gr = grow(row);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (gr >= 0 && ch * E16 < P.Cc) v = *reinterpret_cast<const u32x4*>(cond + gr * P.Cc + ch * E16);
+    *reinterpret_cast<u32x4*>(a2 + row * a2_pitch + (P.H + ch * E16) * (int)sizeof(T)) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename T, int MF>
+__global__ __launch_bounds__(256) void mcf_fwd_kernel(const McfParams P) {
+  constexpr int MT = MF * 16, RS = 64 / MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[8];
+  const int b = blockIdx.x / RS, rs = blockIdx.x % RS;
+  const int pos0 = rs * MT;
+  const McfGeom g = mcf_geom(P.order);
+  const int xs_pitch = P.Cp * (int)sizeof(T) + 16;
+  const int a2_pitch = P.K2p * (int)sizeof(T) + 16;
+  const int N2 = 2 * P.C;
+  unsigned char* xs = smem;
+  unsigned char* a2 = xs + 64 * xs_pitch;
+  float* prm = reinterpret_cast<float*>(a2 + MT * a2_pitch);
+
+  const float* xb = P.x + (long)b * 64 * P.ld;
+  stage_x<T>(xb, P.ld, P.C, P.Cp, xs, xs_pitch);
+  fill_cond<T>(P, MT, [&](int row) { return (long)b * 64 + pos0 + row; }, a2, a2_pitch);
+  __syncthreads();
+  mcf_gemm1<T, MF>(P, g, [&](int row, const unsigned char*& tile, int& pos) { tile = xs; pos = pos0 + row; }, a2, a2_pitch);
+  __syncthreads();
+  if (P.a2_save) {
+    constexpr int E16 = ET<T>::E16;
+    const int chunks = P.K2p / E16;
+    T* dst = reinterpret_cast<T*>(P.a2_save) + ((long)b * 64 + pos0) * P.K2p;
+    for (int i = threadIdx.x; i < MT * chunks; i += blockDim.x) {
+      const int row = i / chunks, ch = i - row * chunks;
+      *reinterpret_cast<u32x4*>(dst + (long)row * P.K2p + ch * E16) =
+          *reinterpret_cast<const u32x4*>(a2 + row * a2_pitch + ch * 16);
+    }
+  }
+  mcf_gemm2<T, MF>(P, a2, a2_pitch, prm, N2);
+  __syncthreads();
+  float ld_acc = 0.f;
+  const long row0 = (long)b * 64 + pos0;
+  for (int e = threadIdx.x; e < MT * P.C; e += blockDim.x) {
+    const int p = e / P.C, c = e - p * P.C;
+    const float mu = prm[p * N2 + c], s = prm[p * N2 + P.C + c];
+    const float sc = tanhf(0.5f * s) + 1.f;
+    const long off = (row0 + p) * P.ld + c;
+    P.y[off] = sc * P.x[off] + mu;
+    if (P.scale_save) P.scale_save[(row0 + p) * P.C + c] = sc;
+    ld_acc += logf(sc);
+  }
+  const int rest = P.ld - P.C;
+  for (int e = threadIdx.x; e < MT * rest; e += blockDim.x) {
+    const int p = e / rest, c = P.C + e - p * rest;
+    P.y[(row0 + p) * P.ld + c] = P.x[(row0 + p) * P.ld + c];
+  }
+  const float tot = block_sum(ld_acc, red);
+  if (threadIdx.x == 0 && P.ld_slot) P.ld_slot[(long)b * RS + rs] = tot;
+}
+
+// ------------------------------------------------------------------------------------------ inverse
+// Two samples per workgroup: a strip of 8 positions per sample fills one 16-row matrix-core tile.
+template <typename T>
+__global__ __launch_bounds__(256) void mcf_inv_kernel(const McfParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b0 = blockIdx.x * 2;
+  const int nb = min(2, P.B - b0);
+  const McfGeom g = mcf_geom(P.order);
+  const int xs_pitch = P.Cp * (int)sizeof(T) + 16;
+  const int a2_pitch = P.K2p * (int)sizeof(T) + 16;
+  const int N2 = 2 * P.C;
+  unsigned char* xs = smem;                                   // [2][64] rows of T
+  unsigned char* a2 = xs + 2 * 64 * xs_pitch;                 // [16] rows
+  float* prm = reinterpret_cast<float*>(a2 + 16 * a2_pitch);  // [16][2C]
+  float* xf = prm + 16 * N2;                                  // [2][64][C] exact reconstruction
+
+  for (int i = threadIdx.x; i < 2 * 64 * xs_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(xs)[i] = 0u;
+  __syncthreads();
+  const bool rows_first = P.order < 2, backwards = (P.order & 1);
+  for (int step = 0; step < 8; ++step) {
+    const int i = backwards ? 7 - step : step;
+    auto strip_pos = [&](int j) { return rows_first ? i * 8 + j : j * 8 + i; };
+    fill_cond<T>(P, 16, [&](int row) -> long {
+      const int s = row >> 3;
+      return s < nb ? (long)(b0 + s) * 64 + strip_pos(row & 7) : -1L;
+    }, a2, a2_pitch);
+    mcf_gemm1<T, 1>(P, g, [&](int row, const unsigned char*& tile, int& pos) {
+      tile = xs + (row >> 3) * 64 * xs_pitch; pos = strip_pos(row & 7);
+    }, a2, a2_pitch);
+    __syncthreads();
+    mcf_gemm2<T, 1>(P, a2, a2_pitch, prm, N2);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * P.C; e += blockDim.x) {
+      const int row = e / P.C, c = e - row * P.C;
+      const int s = row >> 3;
+      if (s < nb) {
+        const int p = strip_pos(row & 7);
+        const float mu = prm[row * N2 + c], sv = prm[row * N2 + P.C + c];
+        const float sc = tanhf(0.5f * sv) + 1.f;
+        const float yv = P.x[((long)(b0 + s) * 64 + p) * P.ld + c];
+        const float xv = (yv - mu) / (sc + 1e-12f);
+        xf[(s * 64 + p) * P.C + c] = xv;
+        *reinterpret_cast<T*>(xs + (s * 64 + p) * xs_pitch + c * (int)sizeof(T)) = ET<T>::from_f32(xv);
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < nb * 64 * P.ld; e += blockDim.x) {
+    const int c = e % P.ld, sp = e / P.ld;        // sp = s*64 + p
+    const long off = ((long)b0 * 64 + sp) * P.ld + c;
+    P.y[off] = c < P.C ? xf[sp * P.C + c] : P.x[off];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward (data path)
+template <typename T>
+__global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const McfGeom g = mcf_geom(P.order);
+  const int N2 = 2 * P.C;
+  const int dp_pitch = P.K3p * (int)sizeof(T) + 16;
+  const int dc_pitch = P.Hq * (int)sizeof(T) + 16;
+  unsigned char* dp = smem;                                       // [64][K3p] T
+  unsigned char* dc = dp + 64 * dp_pitch;                         // [64][Hq]  T
+  float* dxd = reinterpret_cast<float*>(dc + 64 * dc_pitch);      // [64][C]   dy*scale
+  float* colsum = dxd + 64 * P.C;                                 // [2C]
+  const long row0 = (long)b * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
+
+  for (int i = threadIdx.x; i < N2; i += blockDim.x) colsum[i] = 0.f;
+  for (int i = threadIdx.x; i < 64 * dc_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(dc)[i] = 0u;
+  __syncthreads();
+  // (a) gradients of the coupling parameters
+  const float g_ld = P.dld[b];
+  T* dps = reinterpret_cast<T*>(P.dparams_save);
+  for (int e = threadIdx.x; e < 64 * P.K3p; e += blockDim.x) {
+    const int p = e / P.K3p, j = e - p * P.K3p;
+    float v = 0.f;
+    if (j < N2) {
+      const int c = j < P.C ? j : j - P.C;
+      const float gy = P.dy[(row0 + p) * P.ld + c];
+      const float sc = P.scale_save[(row0 + p) * P.C + c];
+      if (j < P.C) {
+        v = gy;
+        dxd[p * P.C + c] = gy * sc;
+      } else {
+        const float t = sc - 1.f;
+        v = (gy * P.x[(row0 + p) * P.ld + c] + g_ld / sc) * 0.5f * (1.f - t * t);
+      }
+      atomicAdd(&colsum[j], v);
+    }
+    const T tv = ET<T>::from_f32(v);
+    *reinterpret_cast<T*>(dp + p * dp_pitch + j * (int)sizeof(T)) = tv;
+    if (dps) dps[(row0 + p) * P.K3p + j] = tv;
+  }
+  __syncthreads();
+  if (P.dbias_part)
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) P.dbias_part[(long)b * N2 + i] = colsum[i];
+
+  // (b) dA2[:, :H] = dparams x W2[:, :H]  , times ELU'(c) -> dc
+  {
+    const int NF = (P.H + 15) >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* W2T = reinterpret_cast<const T*>(P.W2T);
+    for (int k = 0; k < P.K3p; k += KS) {
+      frag_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = *reinterpret_cast<const frag_t*>(dp + (i * 16 + r) * dp_pitch + (k + E16 * gq) * (int)sizeof(T));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (wave + 4 * j < NF) fb[j] = load_wfrag<T>(W2T, P.K3p, (wave + 4 * j) * 16 + r, k + E16 * gq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (wave + 4 * j < NF) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mma64(fa[i], fb[j], acc[i][j]);
+        }
+    }
+    const T* a2s = reinterpret_cast<const T*>(P.a2_save);
+    T* dcs = reinterpret_cast<T*>(P.dc_save);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = (wave + 4 * j) * 16 + 4 * gq;
+      if (n < P.H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = i * 16 + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float cact = ET<T>::to_f32(a2s[(row0 + p) * P.K2p + n + q]);
+            const T tv = ET<T>::from_f32(acc[i][j][q] * act_grad_from_out(IPOKE_ACT_ELU, cact));
+            *reinterpret_cast<T*>(dc + p * dc_pitch + (n + q) * (int)sizeof(T)) = tv;
+            if (dcs) dcs[(row0 + p) * P.Hq + n + q] = tv;
+          }
+        }
+      }
+    }
+    if (dcs) {   // zero the K padding of the saved tensor (read by the weight-gradient GEMM)
+      const int padc = P.Hq - P.H;
+      for (int e = threadIdx.x; e < 64 * padc; e += blockDim.x) {
+        const int p = e / padc, c = P.H + e - p * padc;
+        dcs[(row0 + p) * P.Hq + c] = (T)0.f;
+      }
+    }
+  }
+  __syncthreads();
+
+  // (c) dx = dy*scale + sum_tap dc[p - off(tap)] x W1[:, tap, :]
+  {
+    const int NF = (P.C + 15) >> 4;       // <= 4: one fragment column per wave
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntaps = g.kh * g.kw;
+    const int Ktot = ntaps * P.Hq;
+    const T* W1T = reinterpret_cast<const T*>(P.W1T);
+    if (wave < NF) {
+      int tap = 0, c = E16 * gq;           // Hq is a multiple of KS: a super-step never straddles taps
+      for (int k = 0; k < Ktot; k += KS) {
+        frag_t fa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = gather_adj<T>(dc, dc_pitch, g, i * 16 + r, tap, c);
+        const frag_t fb = load_wfrag<T>(W1T, Ktot, wave * 16 + r, k + E16 * gq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma64(fa[i], fb, acc[i]);
+        c += KS;
+        if (c >= P.Hq) { c -= P.Hq; ++tap; }
+      }
+      const int n = wave * 16 + 4 * gq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = i * 16 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (n + q < P.C) P.dx[(row0 + p) * P.ld + n + q] = dxd[p * P.C + n + q] + acc[i][q];
+      }
+    }
+  }
+  const int rest = P.ld - P.C;
+  for (int e = threadIdx.x; e < 64 * rest; e += blockDim.x) {
+    const int p = e / rest, c = P.C + e - p * rest;
+    P.dx[(row0 + p) * P.ld + c] = P.dy[(row0 + p) * P.ld + c];
+  }
+}
+
+template <auto Kern>
+static int set_lds_attr_once() {
+  static bool done = false;
+  if (!done) {
+    IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  return IPOKE_OK;
+}
+
+static int fill_params(McfParams& P, const ipoke_mcf_desc* d, int dtype) {
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4, e16 = 16 / esz, ks = 64 / esz;
+  IPK_REQUIRE(d->C >= 2 && d->C <= 64 && d->C % 2 == 0, "MCF supports even channel counts up to 64");
+  IPK_REQUIRE(d->order >= 0 && d->order <= 3, "order is 0..3 (A..D)");
+  IPK_REQUIRE(d->ld >= d->C, "state pitch smaller than channel count");
+  P.x = d->x; P.y = d->y; P.ld = d->ld; P.C = d->C; P.B = d->B;
+  P.cond = d->cond; P.Cc = d->Cc;
+  P.H = 4 * d->C;
+  P.Cp = round_up(d->C, e16);
+  P.K1p = round_up(6 * P.Cp, ks);
+  P.K2p = round_up(P.H + d->Cc, ks);
+  P.K3p = round_up(2 * d->C, ks);
+  P.Hq = round_up(P.H, ks);
+  IPK_REQUIRE(d->Cc % e16 == 0 && (P.H % e16) == 0, "hidden/cond widths must be multiples of 16 bytes");
+  P.W1 = d->W1; P.W2 = d->W2; P.bias2 = d->bias2; P.order = d->order;
+  P.a2_save = d->a2_save; P.scale_save = d->scale_save; P.ld_slot = d->logdet_slot;
+  P.W2T = d->W2T; P.W1T = d->W1T; P.dy = d->dy; P.dld = d->dld; P.dx = d->dx;
+  P.dparams_save = d->dparams_save; P.dc_save = d->dc_save; P.dbias_part = d->dbias_part;
+  return IPOKE_OK;
+}
+
+}  // namespace ipoke
+
+using namespace ipoke;
+
+extern "C" int ipoke_mcf_shadow_dims(int C, int Cc, int dtype, int32_t* dims8) {
+  IPK_REQUIRE(dims8 && (dtype == IPOKE_BF16 || dtype == IPOKE_F32), "bad arguments");
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4, e16 = 16 / esz, ks = 64 / esz;
+  const int H = 4 * C, Cp = round_up(C, e16);
+  dims8[0] = Cp;                       // channels per tap in K1
+  dims8[1] = round_up(6 * Cp, ks);     // K1p
+  dims8[2] = round_up(H + Cc, ks);     // K2p
+  dims8[3] = round_up(2 * C, ks);      // K3p
+  dims8[4] = round_up(H, ks);          // Hq
+  dims8[5] = round_up(H, 16);          // rows of W1 / W2T
+  dims8[6] = round_up(2 * C, 16);      // rows of W2
+  dims8[7] = round_up(C, 16);          // rows of W1T
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
+  IPK_REQUIRE(d && d->x && d->y && d->cond && d->W1 && d->W2, "null tensor");
+  McfParams P;
+  int rc = fill_params(P, d, dtype); if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4;
+  // rows per workgroup: a full sample when LDS allows it, else half
+  auto lds_bytes = [&](int MT) { return (size_t)64 * (P.Cp * esz + 16) + (size_t)MT * (P.K2p * esz + 16) + (size_t)MT * 2 * P.C * 4; };
+  int MT = d->rows_per_block > 0 ? d->rows_per_block : (dtype == IPOKE_BF16 ? 32 : 16);
+  IPK_REQUIRE(MT == 16 || MT == 32 || MT == 64, "rows_per_block must be 16, 32 or 64");
+  const size_t lds = lds_bytes(MT);
+  IPK_REQUIRE(lds <= 160 * 1024, "MCF tile does not fit LDS");
+  const int RS = 64 / MT;
+#define LAUNCH_FWD(TT, MF)                                                                      \
+  do {                                                                                          \
+    rc = set_lds_attr_once<mcf_fwd_kernel<TT, MF>>(); if (rc) return rc;                        \
+    hipLaunchKernelGGL((mcf_fwd_kernel<TT, MF>), dim3(d->B * RS), dim3(256), lds, s, P);        \
+  } while (0)
+  if (dtype == IPOKE_BF16) {
+    if (MT == 64) LAUNCH_FWD(bf16_t, 4); else if (MT == 32) LAUNCH_FWD(bf16_t, 2); else LAUNCH_FWD(bf16_t, 1);
+  } else {
+    if (MT == 64) LAUNCH_FWD(float, 4); else if (MT == 32) LAUNCH_FWD(float, 2); else LAUNCH_FWD(float, 1);
+  }
+#undef LAUNCH_FWD
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream) {
+  IPK_REQUIRE(d && d->x && d->y && d->cond && d->W1 && d->W2, "null tensor");
+  McfParams P;
+  int rc = fill_params(P, d, dtype); if (rc) return rc;
+  P.a2_save = nullptr; P.scale_save = nullptr; P.ld_slot = nullptr;
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4;
+  const size_t lds = (size_t)128 * (P.Cp * esz + 16) + (size_t)16 * (P.K2p * esz + 16) + (size_t)16 * 2 * P.C * 4 +
+                     (size_t)128 * P.C * 4;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == IPOKE_BF16) {
+    rc = set_lds_attr_once<mcf_inv_kernel<bf16_t>>(); if (rc) return rc;
+    hipLaunchKernelGGL(mcf_inv_kernel<bf16_t>, dim3((d->B + 1) / 2), dim3(256), lds, s, P);
+  } else {
+    rc = set_lds_attr_once<mcf_inv_kernel<float>>(); if (rc) return rc;
+    hipLaunchKernelGGL(mcf_inv_kernel<float>, dim3((d->B + 1) / 2), dim3(256), lds, s, P);
+  }
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
+  IPK_REQUIRE(d && d->x && d->dy && d->dx && d->dld && d->W2T && d->W1T && d->a2_save && d->scale_save, "null tensor");
+  McfParams P;
+  int rc = fill_params(P, d, dtype); if (rc) return rc;
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4;
+  const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)64 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4;
+  IPK_REQUIRE(lds <= 160 * 1024, "MCF backward tile does not fit LDS");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == IPOKE_BF16) {
+    rc = set_lds_attr_once<mcf_bwd_kernel<bf16_t>>(); if (rc) return rc;
+    hipLaunchKernelGGL(mcf_bwd_kernel<bf16_t>, dim3(d->B), dim3(256), lds, s, P);
+  } else {
+    rc = set_lds_attr_once<mcf_bwd_kernel<float>>(); if (rc) return rc;
+    hipLaunchKernelGGL(mcf_bwd_kernel<float>, dim3(d->B), dim3(256), lds, s, P);
+  }
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}

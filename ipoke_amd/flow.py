@@ -1,0 +1,367 @@
+"""Host-side mirror of the reference's conditional flow, backed by the native HIP flow engine.
+
+``SupervisedMacowTransformer(config)`` has the call surface of
+``models/modules/INN/INN.py:446-481``:
+
+    out, logdet = flow(x, cond)                 # density direction
+    x = flow(z, cond, reverse=True)             # sampling direction
+    flow.flow.reshape == 'none'                 # read by PokeMotionModel.make_flow_input
+
+and the state-dict keys of the reference (``flow.layers.{L}.{s}.actnorm1.log_scale`` ...), so that
+reference checkpoints load unchanged.  All parameters are views of ONE flat fp32 device buffer whose
+layout the native engine defines; gradients are written by the engine into a second flat buffer of
+the same layout (``p.grad`` of every named parameter is a view of it), which is what the fused Adam
+step and the data-parallel all-reduce operate on.
+
+There is no CPU path: forward/reverse raise if the HIP library or a GPU is missing.
+"""
+import ctypes
+from ctypes import byref, c_char_p, c_int32, c_int64, c_void_p, create_string_buffer
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, ptr
+
+TK_PARAM, TK_IDX_FWD, TK_IDX_BWD, TK_FLAG = 0, 1, 2, 3
+
+
+class FlowEngine:
+    """Owner of the native handle and of the flat device buffers."""
+
+    def __init__(self, arch, dtype="bf16", max_batch=64, device=None):
+        for key in ("attention", "condition_nice", "cond_conv", "use1x1", "multistack", "augmented_input"):
+            if arch.get(key, False):
+                raise NotImplementedError(f"architecture option {key}=True is outside the shipped iPOKE configs")
+        if arch.get("transform", "affine") != "affine" or arch.get("prior_transform", "affine") != "affine":
+            raise NotImplementedError("only the affine transform is implemented (shipped configs)")
+        if arch.get("activation", "elu") != "elu" or arch.get("coupling_type", "conv") != "conv":
+            raise NotImplementedError("only activation='elu', coupling_type='conv' are implemented (shipped configs)")
+        self.lib = _lib.lib()
+        self.dtype = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        self.dtype_name = "bf16" if self.dtype == _lib.BF16 else "f32"
+        cfg = _lib.FlowConfig()
+        cfg.z_channels = int(arch["flow_in_channels"])
+        cfg.hidden = int(arch["flow_mid_channels"])
+        cfg.cond_channels = int(arch["h_channels"])
+        cfg.factor = int(arch["factor"])
+        steps = list(arch["num_steps"])
+        cfg.n_levels = len(steps)
+        for i, s in enumerate(steps):
+            cfg.num_steps[i] = int(s)
+        cfg.kernel_h, cfg.kernel_w = int(arch["kernel_size"][0]), int(arch["kernel_size"][1])
+        cfg.dtype = self.dtype
+        cfg.max_batch = int(max_batch)
+        self.cfg = cfg
+        self.z, self.cond_channels, self.max_batch = cfg.z_channels, cfg.cond_channels, cfg.max_batch
+        h = c_void_p()
+        check(self.lib.ipoke_flow_create(byref(cfg), byref(h)))
+        self.handle = h
+        self.n_params = self.lib.ipoke_flow_param_count(h)
+        self.n_perm = self.lib.ipoke_flow_index_count(h)
+        self.n_ops = self.lib.ipoke_flow_op_count(h)
+        self.tensors = self._tensor_table()
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.grads = None
+        self.perm = torch.zeros(max(self.n_perm, 1), dtype=torch.int32, device=self.device)
+        self.shadow = None
+        self._ws = {}
+        self.shadow_stale = True
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ipoke_flow_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _tensor_table(self):
+        out = []
+        name = create_string_buffer(256)
+        off, ndim, kind = c_int64(), c_int32(), c_int32()
+        shape = (c_int64 * 4)()
+        for i in range(self.lib.ipoke_flow_tensor_count(self.handle)):
+            check(self.lib.ipoke_flow_tensor_info(self.handle, i, name, 256, byref(off), byref(ndim), shape, byref(kind)))
+            out.append((name.value.decode(), off.value, tuple(shape[k] for k in range(ndim.value)), kind.value))
+        return out
+
+    # ---- buffers -------------------------------------------------------------------------
+    def _need_gpu(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("the iPOKE flow engine runs on an MI355X only (no CPU path); construct it on a cuda device")
+
+    def ensure_grads(self):
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+        return self.grads
+
+    def workspace(self, B, training):
+        key = (int(B), bool(training))
+        if key not in self._ws:
+            n = self.lib.ipoke_flow_workspace_bytes(self.handle, int(B), int(training))
+            if n < 0:
+                raise RuntimeError("workspace query failed")
+            # keep at most one buffer per mode
+            for k in [k for k in self._ws if k[1] == key[1]]:
+                del self._ws[k]
+            self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self._ws[key]
+
+    def prepare_weights(self):
+        """Refresh the matrix-core weight shadows from the master weights (after every update)."""
+        self._need_gpu()
+        if self.shadow is None:
+            self.shadow = torch.empty(self.lib.ipoke_flow_shadow_bytes(self.handle), dtype=torch.uint8, device=self.device)
+        check(self.lib.ipoke_flow_prepare_weights(self.handle, ptr(self.params), ptr(self.shadow), _lib.current_stream()))
+        self.shadow_stale = False
+
+    # ---- compute -------------------------------------------------------------------------
+    def _prep_inputs(self, x, cond):
+        self._need_gpu()
+        B = x.shape[0]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch={self.max_batch} of this flow")
+        if tuple(x.shape[1:]) != (self.z, 8, 8):
+            raise ValueError(f"flow input must be [B,{self.z},8,8], got {tuple(x.shape)}")
+        x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        if cond is not None:
+            if tuple(cond.shape) != (B, self.cond_channels, 8, 8):
+                raise ValueError(f"cond must be [B,{self.cond_channels},8,8], got {tuple(cond.shape)}")
+            cond = cond.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        if self.shadow_stale:
+            self.prepare_weights()
+        return x, cond, B
+
+    def forward(self, x, cond, save_for_backward=False):
+        x, cond, B = self._prep_inputs(x, cond)
+        out = torch.empty_like(x)
+        logdet = torch.empty(B, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, save_for_backward)
+        check(self.lib.ipoke_flow_forward(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(x), ptr(cond),
+                                          B, ptr(out), ptr(logdet), ptr(ws), int(save_for_backward), _lib.current_stream()))
+        return out, logdet
+
+    def init_forward(self, x):
+        """Data-dependent initialisation pass (first forward of an uninitialised reference flow)."""
+        self._need_gpu()
+        x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        B = x.shape[0]
+        out = torch.empty_like(x)
+        logdet = torch.empty(B, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, False)
+        check(self.lib.ipoke_flow_init_forward(self.handle, ptr(self.params), ptr(self.perm), ptr(x), B, ptr(out), ptr(logdet),
+                                               ptr(ws), _lib.current_stream()))
+        self.shadow_stale = True
+        return out, logdet
+
+    def reverse(self, z, cond):
+        z, cond, B = self._prep_inputs(z, cond)
+        x = torch.empty_like(z)
+        ws = self.workspace(B, False)
+        check(self.lib.ipoke_flow_reverse(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(z), ptr(cond), B,
+                                          ptr(x), ptr(ws), _lib.current_stream()))
+        return x
+
+    def backward(self, d_out, d_logdet, need_dx=False):
+        self._need_gpu()
+        B = d_out.shape[0]
+        d_out = d_out.to(dtype=torch.float32).contiguous()
+        d_logdet = d_logdet.to(dtype=torch.float32).contiguous()
+        grads = self.ensure_grads()
+        dx = torch.empty_like(d_out) if need_dx else None
+        ws = self.workspace(B, True)
+        check(self.lib.ipoke_flow_backward(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(d_out),
+                                           ptr(d_logdet), B, ptr(grads), ptr(dx), ptr(ws), _lib.current_stream()))
+        return dx
+
+
+class _FlowFunction(torch.autograd.Function):
+    """out, logdet = flow(x, cond).  Parameter gradients are written by the engine straight into the
+    flat gradient buffer (every named parameter's ``.grad`` is a view of it); autograd only carries the
+    gradient with respect to x."""
+
+    @staticmethod
+    def forward(ctx, x, cond, anchor, engine):
+        train = torch.is_grad_enabled() and (anchor.requires_grad or x.requires_grad)
+        out, logdet = engine.forward(x, cond, save_for_backward=train)
+        ctx.engine = engine
+        ctx.need_dx = x.requires_grad
+        return out, logdet
+
+    @staticmethod
+    def backward(ctx, d_out, d_logdet):
+        dx = ctx.engine.backward(d_out, d_logdet, need_dx=ctx.need_dx)
+        return dx, None, None, None
+
+
+class _Node(nn.Module):
+    """Generic container reproducing the reference's module nesting (and ModuleList integer indexing)."""
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+    def __len__(self):
+        return sum(1 for k in self._modules if k.isdigit())
+
+    def __iter__(self):
+        return (self._modules[str(i)] for i in range(len(self)))
+
+
+class SupervisedMacowTransformer(nn.Module):
+    """Drop-in for the reference class of the same name (INN.py:446-481)."""
+
+    def __init__(self, config, dtype="bf16", max_batch=64, device=None, init="reference"):
+        super().__init__()
+        self.config = config
+        self.engine = FlowEngine(config, dtype=dtype, max_batch=max_batch, device=device)
+        self.flow = _Node()
+        self.flow.reshape = "none"                        # macow2.py:831, read at second_stage_video.py:290
+        self.flow.z_channels = None
+        self._views = {}          # name -> (kind, offset, shape)
+        self._idx_names = []
+        self._flag_names = []
+        eng = self.engine
+        self._anchor = eng.params.requires_grad_(True)
+        for name, off, shape, kind in eng.tensors:
+            assert name.startswith("flow.")
+            parent, leaf = self._descend(name)
+            if kind == TK_PARAM:
+                n = 1
+                for s in shape:
+                    n *= s
+                view = eng.params.detach()[off:off + n].view(shape)
+                parent.register_parameter(leaf, nn.Parameter(view, requires_grad=True))
+            elif kind in (TK_IDX_FWD, TK_IDX_BWD):
+                parent.register_buffer(leaf, torch.arange(shape[0], dtype=torch.int64, device=eng.device))
+                self._idx_names.append((name, off, shape[0]))
+            else:
+                parent.register_buffer(leaf, torch.tensor(0, dtype=torch.uint8, device=eng.device))
+                self._flag_names.append(name)
+            self._views[name] = (kind, off, shape)
+        self._initialized = False
+        if init == "reference":
+            self.reset_parameters()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.sync_buffers())
+
+    # ---- structure ---------------------------------------------------------------------------
+    def _descend(self, name):
+        parts = name.split(".")
+        node = self
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Node())
+            node = node._modules[p]
+        return node, parts[-1]
+
+    def named_tensor(self, name):
+        node, leaf = self._descend(name)
+        return getattr(node, leaf)
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, device=self.engine.device))
+        if probe.device != self.engine.device or probe.dtype != torch.float32:
+            raise RuntimeError("the flow's parameters are views of one flat device buffer; construct the module on its "
+                               "final device (device=...) instead of calling .to()/.cuda()/.half()")
+        return self
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        """Distribution-equivalent re-statement of the reference constructors' initialisers
+        (macow2.py:485-487, macow_utils.py:225-229, nn.Conv2d default, flow_blocks.py:318)."""
+        for name, (kind, off, shape) in self._views.items():
+            t = self.named_tensor(name)
+            leaf = name.rsplit(".", 1)[-1]
+            if kind == TK_PARAM:
+                if leaf == "log_scale":
+                    t.normal_(0.0, 0.05)
+                elif leaf == "bias":
+                    t.zero_()
+                elif leaf == "weight_v":
+                    t.normal_(0.0, 0.05)
+                elif leaf == "weight_g":
+                    pass                                   # set from ||v|| below
+                else:                                      # plain conv weights: kaiming_uniform(a=sqrt(5))
+                    fan_in = shape[1] * shape[2] * shape[3]
+                    bound = 1.0 / fan_in ** 0.5
+                    t.uniform_(-bound, bound)
+            elif kind == TK_IDX_FWD:
+                t.copy_(torch.randperm(shape[0]).to(t.device))
+            elif kind == TK_FLAG:
+                t.zero_()
+        for name, (kind, off, shape) in self._views.items():
+            if kind == TK_PARAM and name.endswith("weight_g"):
+                v = self.named_tensor(name[:-1] + "v")
+                self.named_tensor(name).copy_(v.flatten(1).norm(dim=1).view(shape))
+            if kind == TK_IDX_BWD:
+                fwd = self.named_tensor(name.replace("backward_shuffle_idx", "forward_shuffle_idx"))
+                self.named_tensor(name).copy_(torch.argsort(fwd))
+        self.sync_buffers()
+
+    def sync_buffers(self):
+        """Mirror the int64 shuffle buffers / uint8 flags of the state dict into the engine (after loading)."""
+        perm = torch.empty(max(self.engine.n_perm, 1), dtype=torch.int32)
+        for name, off, n in self._idx_names:
+            perm[off:off + n] = self.named_tensor(name).to("cpu", torch.int32)
+        self.engine.perm.copy_(perm)
+        flags = [int(self.named_tensor(n)) for n in self._flag_names]
+        if all(f == 1 for f in flags):
+            self._initialized = True
+        elif all(f == 0 for f in flags):
+            self._initialized = False
+        else:
+            raise NotImplementedError("partially initialised flows (mixed `initialized` flags) are not supported")
+        self.engine.shadow_stale = True
+
+    def mark_weights_updated(self):
+        """Call after changing parameters outside of the fused optimizer (e.g. manual edits)."""
+        self.engine.shadow_stale = True
+
+    @property
+    def flat_params(self):
+        return self.engine.params
+
+    @property
+    def flat_grads(self):
+        return self.engine.ensure_grads()
+
+    def bind_grads(self):
+        """Make ``p.grad`` of every named parameter a view of the flat gradient buffer."""
+        g = self.engine.ensure_grads()
+        for name, (kind, off, shape) in self._views.items():
+            if kind == TK_PARAM:
+                n = 1
+                for s in shape:
+                    n *= s
+                self.named_tensor(name).grad = g[off:off + n].view(shape)
+        return g
+
+    # ---- compute -----------------------------------------------------------------------------
+    def _maybe_init(self, x):
+        if not self._initialized:
+            self.engine.init_forward(x)
+            for n in self._flag_names:
+                self.named_tensor(n).fill_(1)
+            self._initialized = True
+
+    def forward(self, input, cond, reverse=False):
+        if reverse:
+            return self.reverse(input, cond)
+        self._maybe_init(input)
+        train = torch.is_grad_enabled() and self.training
+        if train and self.engine.grads is None:
+            self.bind_grads()
+        anchor = self._anchor if train else self._anchor.detach()
+        out, logdet = _FlowFunction.apply(input, cond, anchor, self.engine)
+        return out, logdet
+
+    def reverse(self, out, cond):
+        with torch.no_grad():
+            return self.engine.reverse(out, cond)
+
+    def sample(self, shape, cond, device="cpu"):
+        z = torch.randn(shape).to(self.engine.device)
+        return self.reverse(z, cond)

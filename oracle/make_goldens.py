@@ -1,0 +1,533 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own modules.
+
+Run inside the build container only (needs the read-only checkout at
+/root/reference):
+
+    python -m oracle.make_goldens            # writes tests/golden/*.npz
+
+Each fixture holds inputs and the outputs the reference produced for them.
+Weights are NOT stored: every parameter/buffer is overwritten with the
+name-keyed deterministic fill of ``ipoke_amd.utils.detfill`` (SURVEY.md §7
+step 0), which any implementation sharing the state-dict keys regenerates.
+Exceptions are stored explicitly (pre-init ActNorm draws, data-initialised
+ActNorm parameters of the full-size flow).
+
+While generating, the CPU oracle (oracle/flow_ref.py, oracle/vae_ref.py) is run
+on the same inputs and asserted against the reference -- this is what pins it.
+"""
+import copy
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ipoke_amd import configs                                    # noqa: E402
+from ipoke_amd.utils.detfill import deterministic_fill_          # noqa: E402
+from oracle import flow_ref, ref_import, vae_ref                 # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rn(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=gen(seed)) * scale
+
+
+def npz(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def close(a, b, atol, what):
+    err = (a.double() - b.double()).abs().max().item()
+    assert err <= atol, f"oracle != reference for {what}: {err} > {atol}"
+    return err
+
+
+def checksum(t, key):
+    """sum, abs-sum and three name-keyed sampled elements of a tensor."""
+    t = t.detach().double().flatten()
+    g = gen(zlib.crc32(key.encode()))
+    idx = torch.randint(0, t.numel(), (3,), generator=g)
+    return np.array([t.sum().item(), t.abs().sum().item(), *t[idx].tolist()])
+
+
+# ---------------------------------------------------------------------------
+def g1_units():
+    """G1: per-layer goldens of the flow's building blocks."""
+    m2 = ref_import.ref("models.modules.INN.macow2")
+    mu_ = ref_import.ref("models.modules.INN.macow_utils")
+    fb = ref_import.ref("models.modules.INN.flow_blocks")
+    out = {}
+    for C in (8, 32):
+        x = rn((2, C, 8, 8), 100 + C)
+        h = rn((2, 128, 8, 8), 200 + C)
+        out[f"x_{C}"], out[f"h_{C}"] = x, h
+
+        # ActNorm: init path then fwd / inverse
+        torch.manual_seed(7 + C)
+        an = m2.ActNorm2dFlow(C)
+        pre = an.log_scale.detach().clone()
+        xi = rn((4, C, 8, 8), 300 + C, 2.0) + 0.5
+        y, ld = an(xi)
+        out[f"actnorm_{C}_pre_log_scale"], out[f"actnorm_{C}_init_x"] = pre, xi
+        out[f"actnorm_{C}_post_log_scale"], out[f"actnorm_{C}_post_bias"] = an.log_scale, an.bias
+        out[f"actnorm_{C}_y"], out[f"actnorm_{C}_logdet"] = y, ld
+        out[f"actnorm_{C}_inv"] = an(y, reverse=True)
+        o = flow_ref.ActNorm2dFlow(C)
+        with torch.no_grad():
+            o.log_scale.copy_(pre)
+        yo, ldo = o(xi)
+        close(yo, y, 1e-6, "actnorm init fwd"); close(ldo, ld, 1e-4, "actnorm logdet")
+        close(o(yo, reverse=True), an(y, reverse=True), 1e-6, "actnorm inv")
+
+        # Shuffle (bit exact)
+        sh = fb.Shuffle(C)
+        deterministic_fill_(sh, prefix=f"shuffle{C}.")
+        ys, zero = sh(x)
+        assert zero == 0
+        out[f"shuffle_{C}_fwd_idx"], out[f"shuffle_{C}_bwd_idx"] = sh.forward_shuffle_idx, sh.backward_shuffle_idx
+        out[f"shuffle_{C}_y"], out[f"shuffle_{C}_inv"] = ys, sh(ys, reverse=True)
+        assert torch.equal(sh(ys, reverse=True), x)
+        o = flow_ref.Shuffle(C); deterministic_fill_(o, prefix=f"shuffle{C}.")
+        assert torch.equal(o(x)[0], ys) and torch.equal(o(ys, reverse=True), x)
+
+        # Affine transform
+        raw = rn((2, 2 * C, 8, 8), 400 + C)
+        aff = mu_.Affine(dim=1, alpha=1.0)
+        p = aff.calc_params(raw)
+        ya, lda = aff.fwd(x, p)
+        xa, ldb = aff.bwd(ya, p)
+        out[f"affine_{C}_raw"], out[f"affine_{C}_y"], out[f"affine_{C}_logdet"] = raw, ya, lda
+        out[f"affine_{C}_inv"] = xa
+        mo, so = flow_ref.affine_params(raw)
+        close(flow_ref.affine_fwd(x, mo, so)[0], ya, 1e-6, "affine fwd")
+        close(flow_ref.affine_inv(ya, mo, so), xa, 1e-6, "affine inv")
+
+        # shifted convs + MCF for the four orders
+        for order, ks in (("A", (2, 3)), ("B", (2, 3)), ("C", (3, 2)), ("D", (3, 2))):
+            sc = mu_.ShiftedConv2d(C, 4 * C, ks, order=order, bias=False)
+            deterministic_fill_(sc, prefix=f"sc{C}{order}.")
+            out[f"shiftconv_{C}_{order}"] = sc(x)
+            o = flow_ref.ShiftedConv2d(C, 4 * C, ks, order); deterministic_fill_(o, prefix=f"sc{C}{order}.")
+            close(o(x), sc(x), 1e-5, "shiftconv")
+
+            mcf = m2.MaskedConvFlow(C, ks, h_channels=128, order=order, activation="elu", transform="affine", alpha=1.0)
+            deterministic_fill_(mcf, prefix=f"mcf{C}{order}.")
+            ym, ldm = mcf(x, h=h)
+            xm = mcf(ym, h=h, reverse=True)
+            out[f"mcf_{C}_{order}_y"], out[f"mcf_{C}_{order}_logdet"], out[f"mcf_{C}_{order}_inv"] = ym, ldm, xm
+            # gradients of a scalar objective wrt input and the two weights
+            xg = x.clone().requires_grad_(True)
+            yg, lg = mcf(xg, h=h)
+            (0.5 * (yg ** 2).sum() - lg.sum()).backward()
+            out[f"mcf_{C}_{order}_dx"] = xg.grad
+            out[f"mcf_{C}_{order}_dshift"] = mcf.net.shift_conv.weight.grad
+            out[f"mcf_{C}_{order}_dv"] = mcf.net.conv1x1.conv.weight_v.grad
+            out[f"mcf_{C}_{order}_dg"] = mcf.net.conv1x1.conv.weight_g.grad
+            out[f"mcf_{C}_{order}_db"] = mcf.net.conv1x1.conv.bias.grad
+            o = flow_ref.MaskedConvFlow(C, ks, order, 128); deterministic_fill_(o, prefix=f"mcf{C}{order}.")
+            yo, lo = o(x, h=h)
+            close(yo, ym, 1e-5, "mcf fwd"); close(lo, ldm, 1e-4, "mcf logdet")
+            close(o(yo, h=h, reverse=True), xm, 1e-5, "mcf inverse")
+
+        # NICE couplings
+        for split in ("continuous", "skip"):
+            for order in ("up", "down"):
+                nice = m2.NICE2d(C, hidden_channels=64, h_channels=0, split_type=split, order=order, factor=2,
+                                 transform="affine", alpha=1.0, type="conv", activation="elu")
+                tag = f"nice_{C}_{split}_{order}"
+                deterministic_fill_(nice, prefix=tag + ".")
+                yn, ldn = nice(x)
+                out[tag + "_y"], out[tag + "_logdet"], out[tag + "_inv"] = yn, ldn, nice(yn, reverse=True)
+                o = flow_ref.NICE2d(C, 64, split, order); deterministic_fill_(o, prefix=tag + ".")
+                yo, lo = o(x)
+                close(yo, yn, 1e-5, tag); close(lo, ldn, 1e-4, tag + " logdet")
+                close(o(yo, reverse=True), nice(yn, reverse=True), 1e-5, tag + " inv")
+
+        # prior
+        f = 4
+        pr = m2.MultiScalePrior(C, hidden_channels=64, h_channels=128, factor=f, transform="affine", alpha=1.0,
+                                coupling_type="conv", h_type=None, activation="elu", normalize=None, num_groups=None)
+        deterministic_fill_(pr, prefix=f"prior{C}.")
+        yp, ldp = pr(x, h=h)
+        out[f"prior_{C}_y"], out[f"prior_{C}_logdet"], out[f"prior_{C}_inv"] = yp, ldp, pr(yp, h=h, reverse=True)
+        o = flow_ref.MultiScalePrior(C, 64, f); deterministic_fill_(o, prefix=f"prior{C}.")
+        yo, lo = o(x, h=h)
+        close(yo, yp, 1e-5, "prior"); close(lo, ldp, 1e-4, "prior logdet")
+
+    # LU-parametrised invertible 1x1 conv (optional path: use1x1)
+    np.random.seed(3)
+    lu = m2.InvertibleConvLU1d(8)
+    x = out["x_8"]
+    ylu, ldlu = lu(x)
+    out["lu_8_permutated"], out["lu_8_sign_s"] = lu.permutated, lu.sign_s
+    out["lu_8_l"], out["lu_8_u"], out["lu_8_log_s"] = lu.l, lu.u, lu.log_s
+    out["lu_8_y"], out["lu_8_logdet"], out["lu_8_inv"] = ylu, ldlu, lu(ylu, reverse=True)
+    npz("g1_flow_units", **out)
+
+
+# ---------------------------------------------------------------------------
+def _loss_and_grads(model, loss_mod, x, cond, seed):
+    model.zero_grad()
+    out, logdet = model(x, cond)
+    torch.manual_seed(seed)
+    loss, log = loss_mod(out, logdet)
+    loss.backward()
+    return out, logdet, loss, log
+
+
+def g2_reduced_flow():
+    """G2: reduced full-topology flow -- activations, reverse, loss dict, every parameter gradient,
+    plus the data-dependent init path (G3-iii of SURVEY.md §7)."""
+    INN = ref_import.ref("models.modules.INN.INN")
+    loss_m = ref_import.ref("models.modules.INN.loss")
+    arch = configs.reduced_flow_arch()
+    R = INN.SupervisedMacowTransformer(copy.deepcopy(arch))
+    O = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch))
+    assert list(R.state_dict()) == list(O.state_dict()), "state-dict keys/order differ from the reference"
+    deterministic_fill_(R, prefix="flow."); deterministic_fill_(O, prefix="flow.")
+    x, cond = rn((3, 16, 8, 8), 11), rn((3, 128, 8, 8), 12)
+    out, logdet, loss, log = _loss_and_grads(R, loss_m.FlowLoss(), x, cond, 1234)
+    oo, ol, oloss, olog = _loss_and_grads(O, flow_ref.FlowLoss(), x, cond, 1234)
+    close(oo, out, 2e-5, "G2 out"); close(ol, logdet, 1e-3, "G2 logdet"); close(oloss, loss, 1e-3, "G2 loss")
+    close(olog["reference_nll_loss"], log["reference_nll_loss"], 1e-4, "G2 reference nll (RNG)")
+    rev = R(out.detach(), cond, reverse=True)
+    close(O(oo.detach(), cond, reverse=True), rev, 5e-5, "G2 reverse")
+    arrs = dict(x=x, cond=cond, out=out, logdet=logdet, loss=loss, reverse=rev,
+                reference_nll_loss=log["reference_nll_loss"], nll_loss=log["nll_loss"],
+                nlogdet_loss=log["nlogdet_loss"], roundtrip_err=(rev - x).abs().max())
+    worst = 0.0
+    for (k, p), (k2, q) in zip(R.named_parameters(), O.named_parameters()):
+        assert k == k2
+        arrs["grad." + k] = p.grad
+        worst = max(worst, (p.grad - q.grad).abs().max().item() / (p.grad.abs().max().item() + 1e-12))
+    assert worst < 1e-4, worst
+    print(f"  G2 oracle-vs-reference worst relative grad error {worst:.2e}")
+    npz("g2_reduced_flow", **arrs)
+
+    # init path: construction-order RNG of the reference is NOT reproduced; instead the
+    # freshly constructed (uninitialised) parameters are captured and stored.
+    torch.manual_seed(5)
+    R2 = INN.SupervisedMacowTransformer(copy.deepcopy(arch))
+    pre = {k: v.clone() for k, v in R2.state_dict().items()}
+    O2 = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch)); O2.load_state_dict(pre)
+    xi, ci = rn((4, 16, 8, 8), 21, 2.0) + 0.5, rn((4, 128, 8, 8), 22)
+    with torch.no_grad():
+        yi, li = R2(xi, ci)
+        yo, lo = O2(xi, ci)
+    close(yo, yi, 1e-5, "init out"); close(lo, li, 1e-3, "init logdet")
+    arrs = dict(x=xi, cond=ci, out=yi, logdet=li)
+    for k, v in pre.items():
+        if v.dtype.is_floating_point and v.numel() <= 4096 or not v.dtype.is_floating_point:
+            arrs["pre." + k] = v          # small tensors verbatim (ActNorm draws, flags, shuffle idx, g, biases)
+    for k, v in R2.state_dict().items():
+        if k.endswith(("log_scale", "bias", "weight_g", "initialized")):
+            arrs["post." + k] = v
+            close(O2.state_dict()[k].float(), v.float(), 1e-5, "post-init " + k)
+    # big tensors of the pre-init state are regenerated by name-keyed fill instead of being stored
+    big = [k for k, v in pre.items() if v.dtype.is_floating_point and v.numel() > 4096]
+    R3 = INN.SupervisedMacowTransformer(copy.deepcopy(arch)); R3.load_state_dict(pre)
+    sd3 = R3.state_dict()
+    from ipoke_amd.utils.detfill import fill_value
+    with torch.no_grad():
+        for k in big:
+            sd3[k].copy_(fill_value("flow." + k, sd3[k]))
+        y3, l3 = R3(xi, ci)
+    arrs["big_keys"] = np.array(big)
+    arrs["out_filled"], arrs["logdet_filled"] = y3, l3
+    for k, v in R3.state_dict().items():
+        if k.endswith(("log_scale", "bias", "weight_g")):
+            arrs["postfilled." + k] = v
+    npz("g2_reduced_flow_init", **arrs)
+
+
+# ---------------------------------------------------------------------------
+def g3_full_flow(z_dim=32):
+    """G3: full-size flow (1.05 B parameters): activations, log-det, loss, per-parameter gradient checksums."""
+    INN = ref_import.ref("models.modules.INN.INN")
+    loss_m = ref_import.ref("models.modules.INN.loss")
+    arch = configs.flow_arch(z_dim)
+    t = time.time()
+    R = INN.SupervisedMacowTransformer(copy.deepcopy(arch))
+    deterministic_fill_(R, prefix="flow.")
+    # The analytic inverse of 800 chained autoregressive flows amplifies round-off by the coupling
+    # gain; scaling the weight-norm gains keeps the random-weight flow well conditioned so that the
+    # reverse pass can be compared value by value (recorded in the fixture as g_scale).
+    g_scale = 0.3
+    with torch.no_grad():
+        for k, v in R.state_dict().items():
+            if k.endswith("weight_g"):
+                v.mul_(g_scale)
+    print(f"  built+filled reference flow z={z_dim} in {time.time() - t:.0f}s")
+    # ActNorm parameters come from the reference's own data-dependent init on a seeded batch
+    for k, v in R.state_dict().items():
+        if "actnorm" in k and k.endswith("initialized"):
+            v.fill_(0)
+    xi, ci = rn((8, z_dim, 8, 8), 31), rn((8, 128, 8, 8), 32)
+    with torch.no_grad():
+        R(xi, ci)
+    actn = {k: v.clone() for k, v in R.state_dict().items() if "actnorm" in k and not k.endswith("initialized")}
+    x, cond = rn((2, z_dim, 8, 8), 33), rn((2, 128, 8, 8), 34)
+    out, logdet, loss, log = _loss_and_grads(R, loss_m.FlowLoss(), x, cond, 1234)
+    with torch.no_grad():
+        rev = R(out.detach(), cond, reverse=True)
+    arrs = dict(x=x, cond=cond, out=out, logdet=logdet, loss=loss, reverse=rev, init_x=xi, init_cond=ci, g_scale=g_scale)
+    names, sums = [], []
+    for k, p in R.named_parameters():
+        names.append(k); sums.append(checksum(p.grad, k))
+    arrs["grad_names"], arrs["grad_checksums"] = np.array(names), np.stack(sums)
+    for k, v in actn.items():
+        arrs["actnorm." + k] = v
+    # pin the oracle at full size too
+    O = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch))
+    O.load_state_dict(R.state_dict())
+    oo, ol, oloss, _ = _loss_and_grads(O, flow_ref.FlowLoss(), x, cond, 1234)
+    e1 = close(oo, out, 5e-4, "G3 out"); e2 = close(ol, logdet, 5e-2, "G3 logdet")
+    print(f"  G3 oracle-vs-reference: out {e1:.2e}, logdet {e2:.2e}, roundtrip {(rev - x).abs().max().item():.2e}")
+    npz(f"g3_full_flow_z{z_dim}", **arrs)
+
+
+# ---------------------------------------------------------------------------
+def _ref_first_stage(size, z_dim, n_frames):
+    fsm = ref_import.ref("models.first_stage_motion_model")
+    cfg = configs.first_stage_config(size, z_dim, n_frames)
+    m = fsm.SpadeCondMotionModel(copy.deepcopy(cfg), dirs={}, train=False)
+    deterministic_fill_(m, prefix="first_stage.")
+    return m.eval(), cfg
+
+
+def g4_g5_first_stage():
+    """G4 (3-D encoder) and G5 (ConvGRU + SPADE decoder), 64x64, T=16, z=32."""
+    m, cfg = _ref_first_stage(64, 32, 16)
+    o = vae_ref.SpadeCondMotionModel(copy.deepcopy(cfg)).eval()
+    missing = set(m.state_dict()) ^ set(o.state_dict())
+    assert not missing, missing
+    o.load_state_dict(m.state_dict())
+    X = torch.rand(2, 16, 3, 64, 64, generator=gen(41)) * 2 - 1
+    eps = rn((2, 32, 8, 8), 42)
+    with torch.no_grad():
+        emb = m.enc_motion.conv1(X.transpose(1, 2))
+        x = torch.relu(m.enc_motion.bn1(emb))
+        shapes = [tuple(x.shape)]
+        for name in ("layer1", "layer2", "layer3"):
+            x = getattr(m.enc_motion, name)(x); shapes.append(tuple(x.shape))
+        mu, logvar = m.enc_motion.conv_mu(x.squeeze(2)), m.enc_motion.conv_var(x.squeeze(2))
+        z = eps * (0.5 * logvar).exp() + mu
+        zo, muo, lvo = o.enc_motion(X.transpose(1, 2), eps=eps)
+    close(muo, mu, 2e-5, "G4 mu"); close(lvo, logvar, 2e-5, "G4 logvar"); close(zo, z, 2e-5, "G4 z")
+    npz("g4_encoder_64", X=X, eps=eps, mu=mu, logvar=logvar, z=z, stage_shapes=np.array(shapes))
+
+    # G5: decode 3 frames from a fixed latent
+    zin, x0 = rn((2, 32, 8, 8), 43), X[:, 0]
+    with torch.no_grad():
+        hidden = [zin] * m.n_layers
+        in_rnn = torch.cat([m.motion_bias] * 2, dim=0)
+        frames, hids = [], []
+        for _ in range(3):
+            hidden = m.rnn(in_rnn, hidden)
+            hids.append(hidden[-1])
+            frames.append(m.gen([hidden[-1]], x0, del_shape=True))
+        frames = torch.stack(frames, 1)
+        fo = o.decode(zin, x0, 3)
+    close(fo, frames, 5e-5, "G5 frames")
+    arrs = dict(z=zin, x0=x0, frames=frames, hidden_last=torch.stack(hids, 1))
+    # unit goldens of the decoder's parts
+    with torch.no_grad():
+        t0 = m.gen.in_block(hids[0]); arrs["in_block"] = t0
+        t1 = m.gen.blocks[0](t0); arrs["block0"] = t1
+        arrs["block0_conv1"] = m.gen.blocks[0].conv1(t0)          # ConvTranspose + ("elu" -> ReLU)
+        arrs["spade0"] = m.gen.spade_blocks[0](t1, x0)
+        close(o.gen.in_block(hids[0]), t0, 2e-5, "in_block"); close(o.gen.blocks[0](t0), t1, 2e-5, "block0")
+        close(o.gen.spade_blocks[0](t1, x0), arrs["spade0"], 2e-5, "spade0")
+    npz("g5_decoder_64", **arrs)
+
+    # train-mode spectral-norm power iteration (one forward of one transposed block)
+    blk = m.gen.blocks[0].conv1
+    u0, v0 = blk.conv.weight_u.clone(), blk.conv.weight_v.clone()
+    blk.train()
+    with torch.no_grad():
+        yt = blk(t0)
+    blk.eval()
+    ob = o.gen.blocks[0].conv1
+    ob.conv.spectral_power_iter()
+    with torch.no_grad():
+        close(ob(t0), yt, 2e-5, "train-mode spectral norm fwd")
+    npz("g5_spectral_train", x=t0, u0=u0, v0=v0, u1=blk.conv.weight_u, v1=blk.conv.weight_v, y=yt)
+
+    # full first-stage forward + L1/KL loss + two sampled grads (c4 path, small shape)
+    Xs = X[:, :4]
+    cfg4 = configs.first_stage_config(64, 32, 4)
+    fsm = ref_import.ref("models.first_stage_motion_model")
+    m4 = fsm.SpadeCondMotionModel(copy.deepcopy(cfg4), dirs={}, train=False)
+    deterministic_fill_(m4, prefix="first_stage.")
+    m4.eval()     # frozen spectral-norm u,v (train-mode iteration is pinned separately above)
+    torch.manual_seed(77)
+    eps4 = torch.FloatTensor(2, 32, 8, 8).normal_()
+    torch.manual_seed(77)
+    Xh, mu4, lv4 = m4(Xs)
+    losses = ref_import.ref("utils.losses")
+    loss = 10 * (Xs[:, 1:] - Xh).abs().mean() + 1e-7 * losses.KL(mu4, lv4)
+    loss.backward()
+    o4 = vae_ref.SpadeCondMotionModel(copy.deepcopy(cfg4)).eval(); o4.load_state_dict(m4.state_dict())
+    Xo, muo, lvo = o4(Xs, eps=eps4)
+    lo = vae_ref.first_stage_loss(Xs, Xo, muo, lvo)
+    close(Xo, Xh, 5e-5, "first-stage X_hat"); close(lo, loss, 1e-4, "first-stage loss")
+    lo.backward()
+    arrs = dict(X=Xs, eps=eps4, X_hat=Xh, mu=mu4, logvar=lv4, loss=loss)
+    names, sums = [], []
+    for (k, p), (k2, q) in zip(m4.named_parameters(), o4.named_parameters()):
+        if p.grad is None:
+            continue
+        names.append(k); sums.append(checksum(p.grad, k))
+        assert (p.grad - q.grad).abs().max().item() <= 1e-4 * (p.grad.abs().max().item() + 1e-6) + 1e-7, k
+    arrs["grad_names"], arrs["grad_checksums"] = np.array(names), np.stack(sums)
+    npz("g5_first_stage_train_64", **arrs)
+
+
+def g4_encoder_128():
+    m, cfg = _ref_first_stage(128, 32, 16)
+    o = vae_ref.SpadeCondMotionModel(copy.deepcopy(cfg)).eval(); o.load_state_dict(m.state_dict())
+    X = torch.rand(1, 16, 3, 128, 128, generator=gen(45)) * 2 - 1
+    with torch.no_grad():
+        feats = m.enc_motion.conv1(X.transpose(1, 2))
+        x = torch.relu(m.enc_motion.bn1(feats)); shapes = [tuple(x.shape)]
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            x = getattr(m.enc_motion, name)(x); shapes.append(tuple(x.shape))
+        mu, logvar = m.enc_motion.conv_mu(x.squeeze(2)), m.enc_motion.conv_var(x.squeeze(2))
+        _, muo, lvo = o.enc_motion(X.transpose(1, 2), eps=torch.zeros(1, 32, 8, 8))
+    close(muo, mu, 5e-5, "G4-128 mu"); close(lvo, logvar, 5e-5, "G4-128 logvar")
+    npz("g4_encoder_128", X_seed=45, mu=mu, logvar=logvar, stage_shapes=np.array(shapes))
+
+
+# ---------------------------------------------------------------------------
+def build_reference_poke_model(size, z_dim, n_frames, arch):
+    """PokeMotionModel via __new__ (its __init__ needs checkpoints that are not in the container)."""
+    ssv = ref_import.ref("models.second_stage_video")
+    fsm = ref_import.ref("models.first_stage_motion_model")
+    fcm = ref_import.ref("models.modules.autoencoders.fully_conv_models")
+    INN = ref_import.ref("models.modules.INN.INN")
+    loss_m = ref_import.ref("models.modules.INN.loss")
+    cfg = configs.second_stage_config(size, z_dim, n_frames, arch=arch)
+    M = ssv.PokeMotionModel.__new__(ssv.PokeMotionModel)
+    torch.nn.Module.__init__(M)
+    M.config = cfg
+    M.first_stage_config = copy.deepcopy(cfg["first_stage"])
+    M.first_stage_model = fsm.SpadeCondMotionModel(copy.deepcopy(cfg["first_stage"]), dirs={}, train=False)
+    M.poke_embedder = fcm.FirstStageWrapper(copy.deepcopy(cfg["poke_embedder"]))
+    M.conditioner = fcm.FirstStageWrapper(copy.deepcopy(cfg["conditioner_model"]))
+    M.flow = INN.SupervisedMacowTransformer(copy.deepcopy(cfg["architecture"]))
+    M.loss_func = loss_m.FlowLoss()
+    M.use_cond, M.embed_poke_and_image, M.poke_key = True, False, "flow"
+    M.adapt_poke_emb_ssize = M.adapt_cond_ssize = False
+    M.augment_input, M.full_seq = False, True
+    deterministic_fill_(M.first_stage_model, prefix="first_stage.")
+    deterministic_fill_(M.poke_embedder, prefix="poke_embedder.")
+    deterministic_fill_(M.conditioner, prefix="conditioner.")
+    deterministic_fill_(M.flow, prefix="flow.")
+    return M, cfg
+
+
+def synthetic_batch(B, T, size, seed=1):
+    g = gen(seed)
+    images = torch.rand(B, T, 3, size, size, generator=g) * 2 - 1
+    flow = torch.randn(B, 2, size, size, generator=g)
+    mask = (torch.rand(B, 1, size, size, generator=g) < 0.05).float()
+    poke = [torch.randn(B, 2, size, size, generator=g) * mask, torch.zeros(B, 5, 2, dtype=torch.int64)]
+    return {"images": images, "flow": flow, "poke": poke, "sample_ids": torch.zeros(B, T, dtype=torch.int64)}
+
+
+def g6_g7_glue():
+    """G6 (make_flow_input, training step, Adam-amsgrad, LR rule) and G7 (forward_sample with injected z)."""
+    arch = configs.reduced_flow_arch(); arch.update(flow_in_channels=32, factor=4)
+    arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+    M, cfg = build_reference_poke_model(64, 32, 16, arch)
+    batch = synthetic_batch(2, 16, 64)
+    torch.manual_seed(99)
+    eps = torch.FloatTensor(2, 32, 8, 8).normal_()      # what reparameterize will draw
+    torch.manual_seed(99)
+    flow_input, cond = M.make_flow_input(batch)
+    arrs = dict(images_seed=1, eps=eps, flow_input=flow_input, cond=cond)
+
+    opt = torch.optim.Adam(M.flow.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5, amsgrad=True)
+    losses = []
+    names = [k for k, _ in M.flow.named_parameters()]
+    for step in range(2):
+        opt.zero_grad()
+        out, logdet = M.flow(flow_input.detach(), cond)
+        torch.manual_seed(1234)
+        loss, log = M.loss_func(out, logdet)
+        loss.backward()
+        if step == 0:
+            arrs["out"], arrs["logdet"] = out, logdet
+        opt.step()
+        losses.append(loss.item())
+        arrs[f"param_checksums_step{step + 1}"] = np.stack([checksum(p, k) for k, p in M.flow.named_parameters()])
+    arrs["losses"], arrs["param_names"] = np.array(losses), np.array(names)
+    gen_mod = ref_import.ref("utils.general")
+    its = [0, 1, 250, 499, 500, 501, 100000, 199999, 200000]
+    lrs = []
+    for it in its:
+        if it < 500:
+            lrs.append(float(gen_mod.linear_var(it, start_it=0, end_it=500, start_val=0., end_val=1e-3, clip_min=0., clip_max=1e-3)))
+        else:
+            lrs.append(float(gen_mod.linear_var(it, start_it=500, end_it=200000, start_val=1e-3, end_val=0., clip_min=0., clip_max=1e-3)))
+        assert abs(lrs[-1] - flow_ref.lr_at(it)) < 1e-12
+    arrs["lr_its"], arrs["lr_vals"] = np.array(its), np.array(lrs)
+
+    # oracle pin: the same two steps on the CPU restatement
+    O = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch)); deterministic_fill_(O, prefix="flow.")
+    oopt = torch.optim.Adam(O.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5, amsgrad=True)
+    for step in range(2):
+        oopt.zero_grad()
+        oo, ol = O(flow_input.detach(), cond)
+        torch.manual_seed(1234)
+        l, _ = flow_ref.FlowLoss()(oo, ol)
+        l.backward(); oopt.step()
+        assert abs(l.item() - losses[step]) < 1e-3 * max(1.0, abs(losses[step])), (l.item(), losses[step])
+    npz("g6_glue_64", **arrs)
+
+    # G7: sampling with an injected latent
+    zs = rn((2, 32, 8, 8), 55)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: zs.clone()
+    try:
+        vids = M.forward_sample(batch, n_samples=1, n_logged_vids=2)
+    finally:
+        torch.randn = real_randn
+    with torch.no_grad():
+        motion = M.flow(zs, cond, reverse=True)
+    npz("g7_sample_64", z=zs, motion=motion, video=vids[0][:, :4], video_checksum=checksum(vids[0], "video"),
+        video_shape=np.array(vids[0].shape))
+
+
+def main(which):
+    torch.set_num_threads(os.cpu_count())
+    torch.manual_seed(0)
+    jobs = {"g1": g1_units, "g2": g2_reduced_flow, "g3": g3_full_flow, "g45": g4_g5_first_stage,
+            "g4_128": g4_encoder_128, "g67": g6_g7_glue}
+    for name in (which or list(jobs)):
+        print(f"[{name}]")
+        t = time.time()
+        jobs[name]()
+        print(f"  done in {time.time() - t:.1f}s")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
