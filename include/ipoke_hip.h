@@ -62,7 +62,7 @@ typedef struct {
   const void* A;           /* a_f32 ? float : dtype */
   int32_t a_f32;           /* 1: A is fp32 and is converted on load (flow state, input images)     */
   int64_t a_sn, a_sd, a_sh, a_sw, a_sc;  /* element strides of n, d, h, w, channel                 */
-  int32_t a_coff;          /* first channel used                                                   */
+  int32_t a_coff;          /* element offset of the first channel used; channel c is at a_coff + c*a_sc */
   int32_t Kc_real;         /* channels per tap actually present                                    */
   int32_t Kc;              /* channels per tap in the K index (>= Kc_real, multiple of 16B/elt)    */
   /* B operand (weights), dtype, [Nout][ldw] with k = tap*Kc + c, zero padded                      */
@@ -218,6 +218,11 @@ int32_t ipoke_flow_op_count(const ipoke_flow* f);
 int ipoke_flow_tensor_info(const ipoke_flow* f, int i, char* name, int name_cap, int64_t* offset, int32_t* ndim,
                            int64_t* shape4, int32_t* kind);
 int64_t ipoke_flow_shadow_bytes(const ipoke_flow* f);
+/* introspection: fields of op i = {type, C, c0, Cn, p_ls, p_bias, idx_fwd, idx_bwd, order, p_w1, p_b, p_g, p_v, sh_w1,
+ * sh_w1t, sh_w2, sh_w2t, wn_off, cin, cout, z_off, z_stride, t_off, t_stride, p_c1, p_c2, sh_c1, sh_c1t, sh_c2, sh_c2t,
+ * sh_c3, sh_c3t}; shadow offsets are in dtype elements past ipoke_flow_shadow_base() bytes */
+int ipoke_flow_op_info(const ipoke_flow* f, int i, int64_t* out32);
+int64_t ipoke_flow_shadow_base(const ipoke_flow* f);
 int64_t ipoke_flow_workspace_bytes(ipoke_flow* f, int B, int training);
 /* fold weight norm and lay the weights out for the matrix cores; call after every parameter update */
 int ipoke_flow_prepare_weights(ipoke_flow* f, const float* params, void* shadow, void* stream);

@@ -104,6 +104,8 @@ SIGNATURES = {
     "ipoke_flow_tensor_info": (c_int, [_P, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32)]),
     "ipoke_flow_shadow_bytes": (c_int64, [_P]),
+    "ipoke_flow_op_info": (c_int, [_P, c_int, POINTER(c_int64)]),
+    "ipoke_flow_shadow_base": (c_int64, [_P]),
     "ipoke_flow_workspace_bytes": (c_int64, [_P, c_int, c_int]),
     "ipoke_flow_prepare_weights": (c_int, [_P, _P, _P, _P]),
     "ipoke_flow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P]),

@@ -460,6 +460,19 @@ extern "C" int ipoke_flow_tensor_info(const ipoke_flow* f, int i, char* name, in
   for (int k = 0; k < 4; ++k) shape4[k] = k < (int)t.shape.size() ? t.shape[k] : 1;
   return IPOKE_OK;
 }
+// Introspection for tests / documentation: 32 int64 fields describing op i of the layer program.
+extern "C" int ipoke_flow_op_info(const ipoke_flow* f, int i, int64_t* out32) {
+  IPK_REQUIRE(f && out32 && i >= 0 && i < (int)f->ops.size(), "bad arguments");
+  const Op& o = f->ops[i];
+  const int64_t v[32] = {o.type, o.C, o.c0, o.Cn, o.p_ls, o.p_bias, o.idx_fwd, o.idx_bwd, o.order, o.p_w1, o.p_b, o.p_g, o.p_v,
+                         o.sh_w1, o.sh_w1t, o.sh_w2, o.sh_w2t, o.wn_off, o.cin, o.cout, o.z_off, o.z_stride, o.t_off, o.t_stride,
+                         o.p_c1, o.p_c2, o.sh_c1, o.sh_c1t, o.sh_c2, o.sh_c2t, o.sh_c3, o.sh_c3t};
+  for (int k = 0; k < 32; ++k) out32[k] = v[k];
+  return IPOKE_OK;
+}
+/* byte offset of the first weight shadow inside the shadow buffer (after the weight-norm row tables) */
+extern "C" int64_t ipoke_flow_shadow_base(const ipoke_flow* f) { return f ? 2 * align_up(f->wn_rows, 64) * 4 : -1; }
+
 extern "C" int64_t ipoke_flow_shadow_bytes(const ipoke_flow* f) {
   if (!f) return -1;
   return 2 * align_up(f->wn_rows, 64) * 4 + f->shadow_elems * f->esz;

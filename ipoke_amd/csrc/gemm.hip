@@ -96,7 +96,7 @@ __device__ __forceinline__ u32x4 load_a_chunk(const void* A, int a_f32, long off
 #pragma unroll
     for (int e = 0; e < E16; ++e) {
       const int ch = c + e;
-      const float f = ch < Kc_real ? src[(long)(a_coff + ch) * a_sc] : 0.f;
+      const float f = ch < Kc_real ? src[a_coff + (long)ch * a_sc] : 0.f;
       v[e] = ET<T>::from_f32(f);
     }
     out = *reinterpret_cast<u32x4*>(&v);

@@ -442,11 +442,11 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
 }
 
 template <auto Kern>
-static int set_lds_attr_once() {
-  static bool done = false;
-  if (!done) {
-    IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
+static int ensure_lds(size_t bytes) {
+  static size_t granted = 0;          // per kernel instantiation; grows monotonically
+  if (bytes > granted) {
+    IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    granted = bytes;
   }
   return IPOKE_OK;
 }
@@ -502,11 +502,11 @@ extern "C" int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   int MT = d->rows_per_block > 0 ? d->rows_per_block : (dtype == IPOKE_BF16 ? 32 : 16);
   IPK_REQUIRE(MT == 16 || MT == 32 || MT == 64, "rows_per_block must be 16, 32 or 64");
   const size_t lds = lds_bytes(MT);
-  IPK_REQUIRE(lds <= 160 * 1024, "MCF tile does not fit LDS");
+  IPK_REQUIRE(lds <= 158 * 1024, "MCF tile does not fit LDS");
   const int RS = 64 / MT;
 #define LAUNCH_FWD(TT, MF)                                                                      \
   do {                                                                                          \
-    rc = set_lds_attr_once<mcf_fwd_kernel<TT, MF>>(); if (rc) return rc;                        \
+    rc = ensure_lds<mcf_fwd_kernel<TT, MF>>(lds); if (rc) return rc;                              \
     hipLaunchKernelGGL((mcf_fwd_kernel<TT, MF>), dim3(d->B * RS), dim3(256), lds, s, P);        \
   } while (0)
   if (dtype == IPOKE_BF16) {
@@ -529,10 +529,10 @@ extern "C" int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream) {
                      (size_t)128 * P.C * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16) {
-    rc = set_lds_attr_once<mcf_inv_kernel<bf16_t>>(); if (rc) return rc;
+    rc = ensure_lds<mcf_inv_kernel<bf16_t>>(lds); if (rc) return rc;
     hipLaunchKernelGGL(mcf_inv_kernel<bf16_t>, dim3((d->B + 1) / 2), dim3(256), lds, s, P);
   } else {
-    rc = set_lds_attr_once<mcf_inv_kernel<float>>(); if (rc) return rc;
+    rc = ensure_lds<mcf_inv_kernel<float>>(lds); if (rc) return rc;
     hipLaunchKernelGGL(mcf_inv_kernel<float>, dim3((d->B + 1) / 2), dim3(256), lds, s, P);
   }
   IPK_LAUNCH_CHECK();
@@ -545,13 +545,13 @@ extern "C" int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   int rc = fill_params(P, d, dtype); if (rc) return rc;
   const int esz = dtype == IPOKE_BF16 ? 2 : 4;
   const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)64 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4;
-  IPK_REQUIRE(lds <= 160 * 1024, "MCF backward tile does not fit LDS");
+  IPK_REQUIRE(lds <= 158 * 1024, "MCF backward tile does not fit LDS");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16) {
-    rc = set_lds_attr_once<mcf_bwd_kernel<bf16_t>>(); if (rc) return rc;
+    rc = ensure_lds<mcf_bwd_kernel<bf16_t>>(lds); if (rc) return rc;
     hipLaunchKernelGGL(mcf_bwd_kernel<bf16_t>, dim3(d->B), dim3(256), lds, s, P);
   } else {
-    rc = set_lds_attr_once<mcf_bwd_kernel<float>>(); if (rc) return rc;
+    rc = ensure_lds<mcf_bwd_kernel<float>>(lds); if (rc) return rc;
     hipLaunchKernelGGL(mcf_bwd_kernel<float>, dim3(d->B), dim3(256), lds, s, P);
   }
   IPK_LAUNCH_CHECK();

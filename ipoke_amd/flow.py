@@ -185,8 +185,7 @@ class _FlowFunction(torch.autograd.Function):
     gradient with respect to x."""
 
     @staticmethod
-    def forward(ctx, x, cond, anchor, engine):
-        train = torch.is_grad_enabled() and (anchor.requires_grad or x.requires_grad)
+    def forward(ctx, x, cond, anchor, engine, train):
         out, logdet = engine.forward(x, cond, save_for_backward=train)
         ctx.engine = engine
         ctx.need_dx = x.requires_grad
@@ -195,7 +194,7 @@ class _FlowFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_logdet):
         dx = ctx.engine.backward(d_out, d_logdet, need_dx=ctx.need_dx)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class _Node(nn.Module):
@@ -351,11 +350,11 @@ class SupervisedMacowTransformer(nn.Module):
         if reverse:
             return self.reverse(input, cond)
         self._maybe_init(input)
-        train = torch.is_grad_enabled() and self.training
+        train = torch.is_grad_enabled() and (self.training or input.requires_grad)
         if train and self.engine.grads is None:
             self.bind_grads()
         anchor = self._anchor if train else self._anchor.detach()
-        out, logdet = _FlowFunction.apply(input, cond, anchor, self.engine)
+        out, logdet = _FlowFunction.apply(input, cond, anchor, self.engine, train)
         return out, logdet
 
     def reverse(self, out, cond):

@@ -1,0 +1,61 @@
+"""Test-side helpers: torch re-statements of the weight "shadow" layouts and small wrappers."""
+import torch
+
+from ipoke_amd import ops
+
+
+def tdt(dtype):
+    return ops.torch_dtype(dtype)
+
+
+def shadow_nt(w, kc_pad, rows_pad=None, ld=None, dtype="f32", row_scale=None):
+    """Conv weight [N][Cin][*k] -> [rows_pad][ld], k = tap*kc_pad + c (zero padded)."""
+    N, Cin = w.shape[:2]
+    taps = w[0, 0].numel()
+    rows_pad = N if rows_pad is None else rows_pad
+    ld = taps * kc_pad if ld is None else ld
+    w3 = w.reshape(N, Cin, taps).permute(0, 2, 1).float()
+    if row_scale is not None:
+        w3 = w3 * row_scale.view(N, 1, 1)
+    buf = torch.zeros(rows_pad, ld, dtype=torch.float32, device=w.device)
+    tmp = torch.zeros(N, taps, kc_pad, device=w.device)
+    tmp[:, :, :Cin] = w3
+    buf[:N, :taps * kc_pad] = tmp.reshape(N, taps * kc_pad)
+    return buf.to(tdt(dtype)).contiguous()
+
+
+def shadow_t(w, n_pad, rows_pad=None, dtype="f32", col_scale=None):
+    """Transposed operand: [rows_pad (c_in)][taps*n_pad], entry [c][tap*n_pad + n] = w[n][c][tap]."""
+    N, Cin = w.shape[:2]
+    taps = w[0, 0].numel()
+    rows_pad = Cin if rows_pad is None else rows_pad
+    w3 = w.reshape(N, Cin, taps).float()
+    if col_scale is not None:
+        w3 = w3 * col_scale.view(N, 1, 1)
+    tmp = torch.zeros(Cin, taps, n_pad, device=w.device)
+    tmp[:, :, :N] = w3.permute(1, 2, 0)
+    buf = torch.zeros(rows_pad, taps * n_pad, device=w.device)
+    buf[:Cin] = tmp.reshape(Cin, taps * n_pad)
+    return buf.to(tdt(dtype)).contiguous()
+
+
+def wn_scale(g, v):
+    return g.flatten() / v.flatten(1).norm(dim=1)
+
+
+def mcf_shadows(sd, prefix, C, Cc, dtype):
+    """Shadows of one MaskedConvFlow from its (reference-keyed) state dict."""
+    d = ops.mcf_dims(C, Cc, dtype)
+    w1 = sd[prefix + "net.shift_conv.weight"]
+    v = sd[prefix + "net.conv1x1.conv.weight_v"]
+    g = sd[prefix + "net.conv1x1.conv.weight_g"]
+    b = sd[prefix + "net.conv1x1.conv.bias"].float().contiguous()
+    H, K2 = 4 * C, 4 * C + Cc
+    sc = wn_scale(g, v)
+    W1 = shadow_nt(w1, d["Cp"], d["Hr"], d["K1p"], dtype)
+    W1T = shadow_t(w1, d["Hq"], d["Cr"], dtype)
+    W2 = shadow_nt(v, d["K2p"], d["N2r"], d["K2p"], dtype, row_scale=sc)
+    weff = (v.flatten(1) * sc.view(-1, 1))[:, :H]                 # [2C][H]
+    W2T = torch.zeros(d["Hr"], d["K3p"], device=v.device)
+    W2T[:H, :2 * C] = weff.t()
+    return dict(W1=W1, W1T=W1T, W2=W2, W2T=W2T.to(tdt(dtype)).contiguous(), bias=b, dims=d)

@@ -12,8 +12,11 @@ from tests.conftest import t
 pytestmark = pytest.mark.gpu
 
 # tolerances: f32 MFMA mode vs reference fp32 CPU; bf16 mode looser
+# f32: exact-f32 MFMA vs the reference's fp32 CPU run (4x the oracle's own 2e-5 / 1e-3 bounds).
+# bf16: nets take bf16 inputs (8-bit mantissa, ~4e-3 relative per contraction), transforms stay fp32; the
+# golden outputs reach |out| ~ 8, so 6e-2 absolute is < 1 % of range; logdet within 0.5 % of |logdet| ~ 65-75.
 TOL = {"f32": dict(out=8e-5, logdet=4e-3, grad=2e-3, rev=2e-4),
-       "bf16": dict(out=2e-2, logdet=0.5, grad=6e-2, rev=2e-2)}
+       "bf16": dict(out=6e-2, logdet=0.35, grad=6e-2, rev=6e-2)}
 
 
 def build(arch, dtype):

@@ -1,0 +1,336 @@
+"""Per-kernel GPU parity against the reference's unit goldens (G1) and torch CPU ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ipoke_amd import _lib, ops
+from ipoke_amd.utils.detfill import deterministic_fill_
+from oracle import flow_ref
+from tests.conftest import t
+from tests.helpers import mcf_shadows, shadow_nt, shadow_t, tdt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOLS = {"f32": 3e-5, "bf16": 3e-2}
+
+
+@pytest.mark.parametrize("C", [8, 32])
+def test_actnorm_and_shuffle(golden, C):
+    g = golden("g1_flow_units")
+    x = t(g[f"actnorm_{C}_init_x"], DEV)
+    ls, b = t(g[f"actnorm_{C}_post_log_scale"], DEV).flatten(), t(g[f"actnorm_{C}_post_bias"], DEV).flatten()
+    B = x.shape[0]
+    s = ops.to_state(x)
+    y = ops.from_state(ops.actnorm_fwd(s, 0, C, ls, b), B, C)
+    assert (y.cpu() - t(g[f"actnorm_{C}_y"])).abs().max() <= 2e-6
+    xi = ops.from_state(ops.actnorm_inv(ops.to_state(y), 0, C, ls, b), B, C)
+    assert (xi.cpu() - t(g[f"actnorm_{C}_inv"])).abs().max() <= 2e-6
+    # data-dependent init reproduces the reference's post-init parameters from its pre-init draw
+    ls0 = t(g[f"actnorm_{C}_pre_log_scale"], DEV).flatten().clone()
+    b0 = torch.zeros(C, device=DEV)
+    ops.actnorm_init_(s, 0, C, ls0, b0)
+    assert (ls0.cpu() - ls.cpu()).abs().max() <= 2e-6 and (b0.cpu() - b.cpu()).abs().max() <= 2e-6
+    # permutation: bit exact
+    xs = t(g[f"x_{C}"], DEV)
+    fi, bi = t(g[f"shuffle_{C}_fwd_idx"], DEV), t(g[f"shuffle_{C}_bwd_idx"], DEV)
+    ys = ops.from_state(ops.actnorm_fwd(ops.to_state(xs), 0, C, None, None, fi), 2, C)
+    assert torch.equal(ys.cpu(), t(g[f"shuffle_{C}_y"]))
+    xr = ops.from_state(ops.actnorm_inv(ops.to_state(ys), 0, C, None, None, bi), 2, C)
+    assert torch.equal(xr.cpu(), xs.cpu())
+
+
+@pytest.mark.parametrize("C", [8, 32])
+def test_affine(golden, C):
+    g = golden("g1_flow_units")
+    x, raw = t(g[f"x_{C}"], DEV), t(g[f"affine_{C}_raw"], DEV)
+    s = ops.to_state(x)
+    raw_s = ops.to_state(raw)                       # [M][2C]: [mu | s]
+    y, ld, scale = ops.affine_fwd(s, raw_s, None, C, 0, 1, 2)
+    assert (ops.from_state(y, 2, C).cpu() - t(g[f"affine_{C}_y"])).abs().max() <= 2e-6
+    assert (ld.cpu() - t(g[f"affine_{C}_logdet"])).abs().max() <= 1e-4
+    xi = ops.affine_inv(y, raw_s, None, C, 0, 1, 2)
+    assert (ops.from_state(xi, 2, C).cpu() - t(g[f"affine_{C}_inv"])).abs().max() <= 2e-6
+
+
+def _run_conv(x, w, dtype, stride, pad, bias=None, act=_lib.ACT_NONE, transposed=False, out_pad=0, a_f32=False, splitk=1):
+    """x [N,Cin,D,H,W] fp32 (cuda), w torch-layout weight; returns [N,Cout,Do,Ho,Wo] fp32."""
+    N, Cin, Di, Hi, Wi = x.shape
+    if transposed:
+        Cout = w.shape[1]
+        k = tuple(w.shape[2:])
+        Do, Ho, Wo = [(i - 1) * s - 2 * p + kk + out_pad * (1 if kk > 1 else 0) for i, s, p, kk in zip((Di, Hi, Wi), stride, pad, k)]
+        wt = w.transpose(0, 1)                     # -> [Cout][Cin][k]
+    else:
+        Cout = w.shape[0]
+        k = tuple(w.shape[2:])
+        Do, Ho, Wo = [(i + 2 * p - kk) // s + 1 for i, s, p, kk in zip((Di, Hi, Wi), stride, pad, k)]
+        wt = w
+    e16 = 8 if dtype == "bf16" else 4
+    kc = -(-Cin // e16) * e16
+    d = ops.conv_desc(N, (Di, Hi, Wi), (Do, Ho, Wo), k, stride, pad, transposed)
+    if a_f32:
+        xa = x.permute(0, 2, 3, 4, 1).contiguous()            # channels-last fp32
+        d.a_f32 = 1
+    else:
+        xa = torch.zeros(N, Di, Hi, Wi, kc, device=DEV, dtype=tdt(dtype))
+        xa[..., :Cin] = x.permute(0, 2, 3, 4, 1).to(tdt(dtype))
+    ldx = xa.shape[-1]
+    d.A = xa.data_ptr(); d.a_sn = Di * Hi * Wi * ldx; d.a_sd = Hi * Wi * ldx; d.a_sh = Wi * ldx; d.a_sw = ldx; d.a_sc = 1
+    d.Kc_real = Cin if a_f32 else kc; d.Kc = kc
+    ws = shadow_nt(wt.contiguous(), kc, dtype=dtype)
+    d.W = ws.data_ptr(); d.ldw = ws.shape[1]; d.Nout = Cout
+    M = N * Do * Ho * Wo
+    if splitk > 1:
+        ldc = -(-Cout // 4) * 4
+        out = torch.zeros(splitk, M, ldc, device=DEV)
+        d.C = out.data_ptr(); d.c_f32 = 1; d.ldc = ldc; d.splitk = splitk
+        ops.conv_forward(d, dtype)
+        res = out.sum(0)[:, :Cout]
+        if bias is not None:
+            res = res + bias
+    else:
+        out = torch.zeros(M, Cout, device=DEV)
+        d.C = out.data_ptr(); d.c_f32 = 1; d.ldc = Cout
+        d.bias = 0 if bias is None else bias.data_ptr(); d.act = act
+        ops.conv_forward(d, dtype)
+        res = out
+    torch.cuda.synchronize()
+    return res.view(N, Do, Ho, Wo, Cout).permute(0, 4, 1, 2, 3).contiguous()
+
+
+CONV_CASES = [
+    # name, N, Cin, (D,H,W), Cout, k, stride, pad, transposed
+    ("nice_conv1", 3, 8, (1, 8, 8), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    ("conv1x1", 3, 64, (1, 8, 8), 96, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),
+    ("nice_conv3", 5, 64, (1, 8, 8), 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    ("conv3d_s2", 2, 16, (4, 16, 16), 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), False),
+    ("conv3d_first", 1, 3, (4, 16, 16), 16, (3, 7, 7), (2, 2, 2), (1, 3, 3), False),
+    ("conv3d_t211", 2, 16, (4, 8, 8), 32, (3, 3, 3), (2, 1, 1), (1, 1, 1), False),
+    ("convT2d", 2, 32, (1, 8, 8), 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), True),
+    ("big_m", 20, 64, (1, 8, 8), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_forward_vs_torch(case, dtype):
+    name, N, Cin, dhw, Cout, k, s, p, tr = case
+    gen = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(N, Cin, *dhw, generator=gen)
+    bias = torch.randn(Cout, generator=gen)
+    if tr:
+        w = torch.randn(Cin, Cout, *k, generator=gen) / (Cin * 9) ** 0.5
+        ref = F.conv_transpose3d(x, w, bias, stride=s, padding=p, output_padding=(0, p[1], p[2]))
+        got = _run_conv(x.to(DEV), w.to(DEV), dtype, s, p, bias.to(DEV), transposed=True, out_pad=1)
+    else:
+        w = torch.randn(Cout, Cin, *k, generator=gen) / (Cin * k[0] * k[1] * k[2]) ** 0.5
+        ref = F.conv3d(x, w, bias, stride=s, padding=p)
+        got = _run_conv(x.to(DEV), w.to(DEV), dtype, s, p, bias.to(DEV))
+    err = (got.cpu() - ref).abs().max().item()
+    print(f"{name}[{dtype}] max err {err:.3e} (ref max {ref.abs().max():.2f})")
+    assert got.shape == ref.shape and err <= TOLS[dtype] * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_forward_state_input_and_splitk(dtype):
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 12, 1, 8, 8, generator=gen)
+    w = torch.randn(40, 12, 1, 3, 3, generator=gen) / 10
+    ref = F.conv3d(x, w, None, padding=(0, 1, 1))
+    got = _run_conv(x.to(DEV), w.to(DEV), dtype, (1, 1, 1), (0, 1, 1), a_f32=True)
+    assert (got.cpu() - ref).abs().max() <= TOLS[dtype] * 3
+    x2 = torch.randn(4, 256, 1, 8, 8, generator=gen)
+    w2 = torch.randn(24, 256, 1, 3, 3, generator=gen) / 48
+    ref2 = F.conv3d(x2, w2, None, padding=(0, 1, 1))
+    got2 = _run_conv(x2.to(DEV), w2.to(DEV), dtype, (1, 1, 1), (0, 1, 1), splitk=5)
+    assert (got2.cpu() - ref2).abs().max() <= TOLS[dtype] * 3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES[:6], ids=[c[0] for c in CONV_CASES[:6]])
+def test_conv_wgrad_vs_torch(case, dtype):
+    name, N, Cin, dhw, Cout, k, s, p, tr = case
+    gen = torch.Generator().manual_seed(hash(name) % 1000 + 1)
+    x = torch.randn(N, Cin, *dhw, generator=gen)
+    w = (torch.randn(Cout, Cin, *k, generator=gen) / 10).requires_grad_(True)
+    y = F.conv3d(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    Do, Ho, Wo = y.shape[2:]
+    e16 = 8 if dtype == "bf16" else 4
+    kc, ncp = -(-Cin // e16) * e16, -(-Cout // e16) * e16
+    a_f32 = Cin % e16 != 0            # e.g. the RGB input of the first encoder conv: read as fp32, converted on load
+    if a_f32:
+        xa = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+        ldx = Cin
+    else:
+        xa = torch.zeros(N, *dhw, kc, device=DEV, dtype=tdt(dtype))
+        xa[..., :Cin] = x.permute(0, 2, 3, 4, 1).to(DEV).to(tdt(dtype))
+        ldx = kc
+    dya = torch.zeros(N * Do * Ho * Wo, ncp, device=DEV, dtype=tdt(dtype))
+    dya[:, :Cout] = dy.permute(0, 2, 3, 4, 1).reshape(-1, Cout).to(DEV).to(tdt(dtype))
+    d = _lib.WgradDesc()
+    d.NB = N; d.Di, d.Hi, d.Wi = dhw; d.Do, d.Ho, d.Wo = Do, Ho, Wo
+    d.kd, d.kh, d.kw = k; d.sd, d.sh, d.sw = s; d.pd, d.ph, d.pw = p
+    d.A = xa.data_ptr(); d.a_f32 = int(a_f32)
+    d.a_sn = dhw[0] * dhw[1] * dhw[2] * ldx; d.a_sd = dhw[1] * dhw[2] * ldx; d.a_sh = dhw[2] * ldx; d.a_sw = ldx; d.a_sc = 1
+    d.Kc_real = Cin if a_f32 else kc; d.Kc = kc
+    d.dY = dya.data_ptr(); d.ldy = ncp; d.Nout = Cout
+    taps = k[0] * k[1] * k[2]
+    dW = torch.zeros(Cout, Cin, taps, device=DEV)
+    d.dW = dW.data_ptr(); d.w_sn = Cin * taps; d.w_sc = taps; d.w_st = 1
+    ops.conv_wgrad(d, dtype)
+    torch.cuda.synchronize()
+    ref = w.grad.reshape(Cout, Cin, taps)
+    err = (dW.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"wgrad {name}[{dtype}] rel err {err:.3e}")
+    assert err <= (2e-5 if dtype == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("order", ["A", "B", "C", "D"])
+@pytest.mark.parametrize("C", [8, 32])
+def test_mcf_forward_inverse(golden, C, order, dtype):
+    g = golden("g1_flow_units")
+    ks = (2, 3) if order in "AB" else (3, 2)
+    o = flow_ref.MaskedConvFlow(C, ks, order, 128)
+    deterministic_fill_(o, prefix=f"mcf{C}{order}.")
+    sd = {k: v.to(DEV) for k, v in o.state_dict().items()}
+    sh = mcf_shadows(sd, "", C, 128, dtype)
+    x, h = t(g[f"x_{C}"], DEV), t(g[f"h_{C}"], DEV)
+    B = x.shape[0]
+    xs, cond = ops.to_state(x), ops.cond_prepare(h, dtype)
+    y = torch.empty_like(xs)
+    ld = torch.zeros(B, 4, device=DEV)
+    d = ops.mcf_desc(xs, C, B, cond, sh["W1"], sh["W2"], sh["bias"], "ABCD".index(order))
+    d.y = y.data_ptr(); d.logdet_slot = ld.data_ptr(); d.rows_per_block = 16
+    _lib.check(_lib.lib().ipoke_mcf_fwd(d, _lib.DTYPES[dtype], _lib.current_stream()))
+    torch.cuda.synchronize()
+    tol = TOLS[dtype]
+    e_y = (ops.from_state(y, B, C).cpu() - t(g[f"mcf_{C}_{order}_y"])).abs().max().item()
+    e_ld = (ld.sum(1).cpu() - t(g[f"mcf_{C}_{order}_logdet"])).abs().max().item()
+    print(f"mcf {C}{order}[{dtype}] y err {e_y:.3e} logdet err {e_ld:.3e}")
+    assert e_y <= tol * 4 and e_ld <= tol * 200
+    # inverse of the golden output
+    yin = ops.to_state(t(g[f"mcf_{C}_{order}_y"], DEV))
+    xr = torch.empty_like(yin)
+    d2 = ops.mcf_desc(yin, C, B, cond, sh["W1"], sh["W2"], sh["bias"], "ABCD".index(order))
+    d2.y = xr.data_ptr()
+    _lib.check(_lib.lib().ipoke_mcf_inv(d2, _lib.DTYPES[dtype], _lib.current_stream()))
+    torch.cuda.synchronize()
+    e_x = (ops.from_state(xr, B, C).cpu() - t(g[f"mcf_{C}_{order}_inv"])).abs().max().item()
+    print(f"mcf {C}{order}[{dtype}] inverse err {e_x:.3e}")
+    assert e_x <= tol * 10
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_engine_weight_shadows_match_torch_layouts(dtype):
+    """ipoke_flow_prepare_weights (multi-tensor relayout + weight norm) against torch re-statements."""
+    from ctypes import c_int64
+    from ipoke_amd import configs
+    from ipoke_amd.flow import SupervisedMacowTransformer
+    from tests.helpers import wn_scale
+    m = SupervisedMacowTransformer(configs.reduced_flow_arch(), dtype=dtype, device=DEV, init="none")
+    deterministic_fill_(m, prefix="flow.")
+    m.sync_buffers()
+    eng = m.engine
+    eng.prepare_weights()
+    torch.cuda.synchronize()
+    base = eng.lib.ipoke_flow_shadow_base(eng.handle)
+    esz = 2 if dtype == "bf16" else 4
+    flat = eng.shadow[base:].view(tdt(dtype))
+    P = eng.params.detach()
+    hid, Cc = 64, 128
+    info = (c_int64 * 32)()
+    seen = set()
+    for i in range(eng.n_ops):
+        _lib.check(eng.lib.ipoke_flow_op_info(eng.handle, i, info))
+        v = list(info)
+        typ, C = v[0], v[1]
+        if typ == 1 and ("mcf", C) not in seen:
+            seen.add(("mcf", C))
+            d = ops.mcf_dims(C, Cc, dtype)
+            H, K2 = 4 * C, 4 * C + Cc
+            kh, kw = (2, 3) if v[8] < 2 else (3, 2)
+            w1 = P[v[9]:v[9] + H * C * 6].view(H, C, kh, kw)
+            g = P[v[11]:v[11] + 2 * C]; vv = P[v[12]:v[12] + 2 * C * K2].view(2 * C, K2, 1, 1)
+            sd = {"net.shift_conv.weight": w1, "net.conv1x1.conv.weight_v": vv, "net.conv1x1.conv.weight_g": g,
+                  "net.conv1x1.conv.bias": P[v[10]:v[10] + 2 * C]}
+            sh = mcf_shadows(sd, "", C, Cc, dtype)
+            for key, off in (("W1", v[13]), ("W1T", v[14]), ("W2", v[15]), ("W2T", v[16])):
+                ref = sh[key]
+                got = flat[off:off + ref.numel()].view_as(ref)
+                err = (got.float() - ref.float()).abs().max().item()
+                assert err <= (0 if dtype == "f32" else 1e-2) + 1e-6, (i, key, err)
+        if typ == 2 and ("nice", C, v[18]) not in seen:
+            seen.add(("nice", C, v[18]))
+            cin, cout = v[18], v[19]
+            e16 = 8 if dtype == "bf16" else 4
+            kc1, kc3 = -(-cin // e16) * e16, -(-2 * cout // e16) * e16
+            c1 = P[v[24]:v[24] + hid * cin * 9].view(hid, cin, 3, 3)
+            c2 = P[v[25]:v[25] + hid * hid].view(hid, hid, 1, 1)
+            g = P[v[11]:v[11] + 2 * cout]; vv = P[v[12]:v[12] + 2 * cout * hid * 9].view(2 * cout, hid, 3, 3)
+            sc = wn_scale(g, vv)
+            refs = {26: shadow_nt(c1, kc1, dtype=dtype), 27: shadow_t(c1, hid, dtype=dtype),
+                    28: shadow_nt(c2, hid, dtype=dtype), 29: shadow_t(c2, hid, dtype=dtype),
+                    30: shadow_nt(vv, hid, dtype=dtype, row_scale=sc), 31: shadow_t(vv, kc3, dtype=dtype, col_scale=sc)}
+            for fld, ref in refs.items():
+                got = flat[v[fld]:v[fld] + ref.numel()].view_as(ref)
+                err = (got.float() - ref.float()).abs().max().item()
+                assert err <= (0 if dtype == "f32" else 1e-2) + 1e-6, (i, fld, err)
+    assert len(seen) > 4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", ["continuous_up", "continuous_down", "skip_up", "skip_down"])
+@pytest.mark.parametrize("C", [8, 32])
+def test_nice_coupling_composed(golden, C, variant, dtype):
+    """conv3x3 -> ELU -> conv1x1 -> ELU -> weight-normed conv3x3 (split-K) -> affine, as the engine chains them."""
+    g = golden("g1_flow_units")
+    split, order = variant.split("_")
+    tag = f"nice_{C}_{split}_{order}"
+    o = flow_ref.NICE2d(C, 64, split, order)
+    deterministic_fill_(o, prefix=tag + ".")
+    sd = {k: v.detach().to(DEV) for k, v in o.state_dict().items()}
+    hid, cout = 64, C // 2
+    cin = C - cout
+    up = order == "up"
+    if split == "continuous":
+        z1 = cin if up else cout
+        z_off, t_off, stride = (0, z1, 1) if up else (z1, 0, 1)
+    else:
+        z_off, t_off, stride = (0, 1, 2) if up else (1, 0, 2)
+    e16 = 8 if dtype == "bf16" else 4
+    kc1 = -(-cin // e16) * e16
+    x = t(g[f"x_{C}"], DEV); B = x.shape[0]; M = B * 64
+    xs = ops.to_state(x)
+    from tests.helpers import wn_scale
+    w1 = shadow_nt(sd["net.conv1.weight"], kc1, dtype=dtype)
+    w2 = shadow_nt(sd["net.conv2.weight"], hid, dtype=dtype)
+    sc = wn_scale(sd["net.conv3.conv.weight_g"], sd["net.conv3.conv.weight_v"])
+    w3 = shadow_nt(sd["net.conv3.conv.weight_v"], hid, dtype=dtype, row_scale=sc)
+    h1 = torch.empty(M, hid, device=DEV, dtype=tdt(dtype)); h2 = torch.empty_like(h1)
+    d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    d.A = xs.data_ptr(); d.a_f32 = 1; d.a_sn = 64 * C; d.a_sh = 8 * C; d.a_sw = C; d.a_sc = stride; d.a_coff = z_off
+    d.Kc_real = cin; d.Kc = kc1; d.W = w1.data_ptr(); d.ldw = 9 * kc1; d.Nout = hid; d.act = _lib.ACT_ELU
+    d.C = h1.data_ptr(); d.ldc = hid
+    ops.conv_forward(d, dtype)
+    d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    d.A = h1.data_ptr(); d.a_sn = 64 * hid; d.a_sh = 8 * hid; d.a_sw = hid; d.a_sc = 1; d.Kc_real = hid; d.Kc = hid
+    d.W = w2.data_ptr(); d.ldw = hid; d.Nout = hid; d.act = _lib.ACT_ELU; d.C = h2.data_ptr(); d.ldc = hid
+    ops.conv_forward(d, dtype)
+    nsplit = 3
+    part = torch.zeros(nsplit, M, 64, device=DEV)
+    d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    d.A = h2.data_ptr(); d.a_sn = 64 * hid; d.a_sh = 8 * hid; d.a_sw = hid; d.a_sc = 1; d.Kc_real = hid; d.Kc = hid
+    d.W = w3.data_ptr(); d.ldw = 9 * hid; d.Nout = 2 * cout; d.C = part.data_ptr(); d.c_f32 = 1; d.ldc = 64; d.splitk = nsplit
+    ops.conv_forward(d, dtype)
+    y, ld, scale = ops.affine_fwd(xs, part, sd["net.conv3.conv.bias"].float().contiguous(), cout, t_off, stride, B)
+    torch.cuda.synchronize()
+    e_y = (ops.from_state(y, B, C).cpu() - t(g[tag + "_y"])).abs().max().item()
+    e_ld = (ld.cpu() - t(g[tag + "_logdet"])).abs().max().item()
+    print(f"{tag}[{dtype}] y err {e_y:.3e} logdet err {e_ld:.3e}")
+    assert e_y <= TOLS[dtype] * 4 and e_ld <= TOLS[dtype] * 200
+    xi = ops.affine_inv(y, part, sd["net.conv3.conv.bias"].float().contiguous(), cout, t_off, stride, B)
+    assert (ops.from_state(xi, B, C).cpu() - x.cpu()).abs().max() <= 1e-5
