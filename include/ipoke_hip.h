@@ -79,7 +79,8 @@ typedef struct {
   int32_t c_accumulate;    /* 1: C += result (fp32 only)                                            */
   int64_t ldc;             /* row stride of C in elements                                           */
   int32_t c_coff, c_cstride; /* column n is stored at c_coff + n*c_cstride                          */
-  int32_t splitk;          /* >1: fp32 partials C[z][M][ldc], epilogue skipped (bias/act by consumer) */
+  int32_t splitk;          /* >1: fp32 partials C[z][M][ldc], epilogue skipped (bias/act by consumer);
+                              with c_accumulate: the K slices are atomically added into C instead      */
 } ipoke_conv_desc;
 
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
@@ -116,9 +117,10 @@ int ipoke_actnorm_fwd(const float* in, float* out, int M, int ld, int c0, int C,
 /* inverse: undo the permutation with inv_idx (= backward_shuffle_idx), then (x - bias)/(exp(ls)+1e-8) */
 int ipoke_actnorm_inv(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
                       const float* bias, const int32_t* inv_idx, void* stream);
+/* per-sample partial sums part[b] = [d_log_scale(C) | d_bias(C)]; reduce over b with ipoke_reduce_rows */
 int ipoke_actnorm_bwd(const float* dy, const float* x, float* dx, int M, int ld, int c0, int C,
                       const float* log_scale, const int32_t* idx, const float* dld, int B, int P,
-                      float* d_log_scale, float* d_bias, void* stream);
+                      float* part, void* stream);
 /* data-dependent init (macow2.py:526-539): overwrites log_scale / bias in place */
 int ipoke_actnorm_init(const float* x, int M, int ld, int c0, int C, float* log_scale, float* bias, void* stream);
 

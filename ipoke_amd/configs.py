@@ -17,8 +17,11 @@ SHIPPED_NUM_STEPS = [10, 5, 5, 4, 4, 4, 3, 3, 3, 2, 2, 2, 1, 1, 1]
 def flow_arch(z_dim, hidden=None, num_steps=None, factor=16, h_channels=128):
     """`architecture` section consumed by SupervisedMacowTransformer (reference INN.py:451-467).
 
-    ``flow_mid_channels = flow_mid_channels_factor(64) * z_dim`` (second_stage_video.py:107-108).
+    ``flow_mid_channels = flow_mid_channels_factor * z_dim`` (second_stage_video.py:107-108); the shipped
+    factor is 64 for the z_dim=32 models and 32 for the z_dim=64 models (config/pretrained_models/*.yaml:15),
+    i.e. 2048 hidden channels in every shipped flow.
     """
+    mid_factor = 64 if z_dim <= 32 else 32
     return {
         "attention": False,
         "flow_attn_heads": 4,
@@ -36,9 +39,9 @@ def flow_arch(z_dim, hidden=None, num_steps=None, factor=16, h_channels=128):
         "cond_conv_hidden_channels": 256,
         "reshape": "none",
         "p_dropout": 0.0,
-        "flow_mid_channels_factor": 64,
+        "flow_mid_channels_factor": mid_factor,
         "flow_in_channels": z_dim,
-        "flow_mid_channels": 64 * z_dim if hidden is None else hidden,
+        "flow_mid_channels": mid_factor * z_dim if hidden is None else hidden,
         "h_channels": h_channels,
     }
 

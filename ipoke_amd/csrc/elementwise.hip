@@ -83,35 +83,34 @@ __global__ void actnorm_inv_kernel(const float* __restrict__ in, float* __restri
     out[i] = v;
   }
 }
-// backward.  x = saved input of the layer.  Single block (M*C is tiny); grads are written (not accumulated).
+// backward.  x = saved input of the layer.  One block per sample; per-sample partial sums of the
+// parameter gradients go to part[b][2C] (reduced over b by ipoke_reduce_rows):
 //   dx[m][c0+idx[j]] = dy[m][c0+j] * exp(ls[idx[j]])
 //   dls[c] = sum_m dy'[m][c] * x[m][c] * exp(ls[c]) + P * sum_b dld[b] ;  dbias[c] = sum_m dy'[m][c]
 __global__ void actnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
-                                   int M, int ld, int c0, int C, const float* __restrict__ ls,
-                                   const int* __restrict__ idx, const float* __restrict__ dld, int B, int P,
-                                   float* __restrict__ dls, float* __restrict__ dbias) {
+                                   int P, int ld, int c0, int C, const float* __restrict__ ls,
+                                   const int* __restrict__ idx, const float* __restrict__ dld,
+                                   float* __restrict__ part) {
   extern __shared__ float sm[];   // [2][rows_par][C]
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const long row0 = (long)b * P;
   const int rows_par = blockDim.x / C;      // host guarantees >= 1
   const int j = tid % C, r0 = tid / C;
   float a_ls = 0.f, a_b = 0.f;
-  int src = 0;
-  float e = 1.f;
   if (r0 < rows_par) {
-    src = idx ? idx[j] : j;
-    e = ls ? expf(ls[src]) : 1.f;
-    for (int m = r0; m < M; m += rows_par) {
-      const float g = dy[(long)m * ld + c0 + j];
-      const float xv = ls ? x[(long)m * ld + c0 + src] : 0.f;
-      dx[(long)m * ld + c0 + src] = g * e;
+    const int src = idx ? idx[j] : j;
+    const float e = ls ? expf(ls[src]) : 1.f;
+    for (int m = r0; m < P; m += rows_par) {
+      const float g = dy[(row0 + m) * ld + c0 + j];
+      const float xv = ls ? x[(row0 + m) * ld + c0 + src] : 0.f;
+      dx[(row0 + m) * ld + c0 + src] = g * e;
       a_ls += g * xv * e;
       a_b += g;
     }
   }
-  // pass-through columns
-  for (long i = tid; i < (long)M * ld; i += blockDim.x) {
-    const int col = (int)(i % ld);
-    if (col < c0 || col >= c0 + C) dx[i] = dy[i];
+  for (int i = tid; i < P * ld; i += blockDim.x) {       // pass-through columns
+    const int col = i % ld;
+    if (col < c0 || col >= c0 + C) dx[row0 * ld + i] = dy[row0 * ld + i];
   }
   if (!ls) return;
   if (r0 < rows_par) { sm[r0 * C + j] = a_ls; sm[(rows_par + r0) * C + j] = a_b; }
@@ -120,10 +119,8 @@ __global__ void actnorm_bwd_kernel(const float* __restrict__ dy, const float* __
     const int s = idx ? idx[tid] : tid;     // thread tid accumulated channel s
     float t_ls = 0.f, t_b = 0.f;
     for (int r = 0; r < rows_par; ++r) { t_ls += sm[r * C + tid]; t_b += sm[(rows_par + r) * C + tid]; }
-    float sum_dld = 0.f;
-    for (int b = 0; b < B; ++b) sum_dld += dld[b];
-    dls[s] = t_ls + (float)P * sum_dld;
-    dbias[s] = t_b;
+    part[(long)b * 2 * C + s] = t_ls + (float)P * dld[b];
+    part[(long)b * 2 * C + C + s] = t_b;
   }
 }
 // data-dependent init (reference macow2.py:526-539): statistics of y0 = x*exp(ls0)+b0 over all rows,
@@ -159,21 +156,32 @@ struct AffineArgs {
   int Cp, t_off, t_stride;
   int P, ld;
 };
-__device__ __forceinline__ void affine_params_at(const AffineArgs& a, long m, int i, float& mu, float& sc) {
-  float vm = 0.f, vs = 0.f;
-  for (int s = 0; s < a.nsplit; ++s) {
-    const float* r = a.raw + s * a.split_stride + m * a.ldraw;
-    vm += r[i]; vs += r[a.Cp + i];
+// sum the split-K partials (+bias) of one sample into LDS: raw_s[p][0:2Cp]
+__device__ __forceinline__ void affine_stage_raw(const AffineArgs& a, long row0, float* raw_s) {
+  const int n2 = 2 * a.Cp;
+  for (int e = threadIdx.x; e < a.P * n2; e += blockDim.x) {
+    const int p = e / n2, j = e - p * n2;
+    const float* r = a.raw + (row0 + p) * a.ldraw + j;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 3 < a.nsplit; s += 4) {
+      v0 += r[(long)s * a.split_stride]; v1 += r[(long)(s + 1) * a.split_stride];
+      v2 += r[(long)(s + 2) * a.split_stride]; v3 += r[(long)(s + 3) * a.split_stride];
+    }
+    for (; s < a.nsplit; ++s) v0 += r[(long)s * a.split_stride];
+    float v = (v0 + v1) + (v2 + v3);
+    if (a.bias) v += a.bias[j];
+    raw_s[e] = v;
   }
-  if (a.bias) { vm += a.bias[i]; vs += a.bias[a.Cp + i]; }
-  mu = vm; sc = tanhf(0.5f * vs) + 1.f;
+  __syncthreads();
 }
 __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out,
                                   float* __restrict__ scale_out, float* __restrict__ logdet_slot, int slot_stride) {
+  extern __shared__ float raw_s[];
   __shared__ float red[8];
   const int b = blockIdx.x;
   const long row0 = (long)b * a.P;
-  // copy the whole sample, then overwrite the transformed channels (disjoint elements, same thread order)
+  affine_stage_raw(a, row0, raw_s);
   for (int i = threadIdx.x; i < a.P * a.ld; i += blockDim.x) {
     const int col = i % a.ld, p = i / a.ld;
     const int rel = col - a.t_off;
@@ -183,8 +191,8 @@ __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, fl
   float ld_acc = 0.f;
   for (int e = threadIdx.x; e < a.P * a.Cp; e += blockDim.x) {
     const int p = e / a.Cp, i = e - p * a.Cp;
-    float mu, sc;
-    affine_params_at(a, row0 + p, i, mu, sc);
+    const float mu = raw_s[p * 2 * a.Cp + i];
+    const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
     out[off] = sc * in[off] + mu;
     if (scale_out) scale_out[(row0 + p) * a.Cp + i] = sc;
@@ -194,8 +202,10 @@ __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, fl
   if (threadIdx.x == 0 && logdet_slot) logdet_slot[(long)b * slot_stride] = tot;
 }
 __global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out) {
+  extern __shared__ float raw_s[];
   const int b = blockIdx.x;
   const long row0 = (long)b * a.P;
+  affine_stage_raw(a, row0, raw_s);
   for (int i = threadIdx.x; i < a.P * a.ld; i += blockDim.x) {
     const int col = i % a.ld, p = i / a.ld;
     const int rel = col - a.t_off;
@@ -204,8 +214,8 @@ __global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, fl
   }
   for (int e = threadIdx.x; e < a.P * a.Cp; e += blockDim.x) {
     const int p = e / a.Cp, i = e - p * a.Cp;
-    float mu, sc;
-    affine_params_at(a, row0 + p, i, mu, sc);
+    const float mu = raw_s[p * 2 * a.Cp + i];
+    const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
     out[off] = (in[off] - mu) / (sc + 1e-12f);      // macow_utils.py:64
   }
@@ -397,13 +407,13 @@ extern "C" int ipoke_actnorm_inv(const float* in, float* out, int M, int ld, int
 }
 extern "C" int ipoke_actnorm_bwd(const float* dy, const float* x, float* dx, int M, int ld, int c0, int C,
                                  const float* log_scale, const int32_t* idx, const float* dld, int B, int P,
-                                 float* d_log_scale, float* d_bias, void* stream) {
-  IPK_REQUIRE(dy && x && dx && C >= 1 && C <= 256 && c0 + C <= ld, "bad arguments");
-  IPK_REQUIRE(!log_scale || (dld && d_log_scale && d_bias), "parameter gradients need dld and outputs");
+                                 float* part, void* stream) {
+  IPK_REQUIRE(dy && dx && C >= 1 && C <= 256 && c0 + C <= ld && M == B * P, "bad arguments");
+  IPK_REQUIRE(!log_scale || (x && dld && part), "parameter gradients need x, dld and the partial-sum buffer");
   const int block = C <= 64 ? 256 : (C <= 128 ? 512 : 1024);
   const int rows_par = block / C;
-  hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(1), dim3(block), 2 * rows_par * C * sizeof(float), STREAM(stream), dy, x, dx,
-                     M, ld, c0, C, log_scale, idx, dld, B, P, d_log_scale, d_bias);
+  hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(B), dim3(block), 2 * rows_par * C * sizeof(float), STREAM(stream), dy, x, dx,
+                     P, ld, c0, C, log_scale, idx, dld, part);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
@@ -429,14 +439,15 @@ extern "C" int ipoke_affine_fwd(const ipoke_affine_desc* d, const float* in, flo
                                 float* logdet_slot, int slot_stride, int B, void* stream) {
   int rc = check_affine(d); if (rc) return rc;
   IPK_REQUIRE(in && out, "null state");
-  hipLaunchKernelGGL(affine_fwd_kernel, dim3(B), dim3(256), 0, STREAM(stream), to_args(d), in, out, scale_out, logdet_slot, slot_stride < 1 ? 1 : slot_stride);
+  hipLaunchKernelGGL(affine_fwd_kernel, dim3(B), dim3(512), (size_t)d->P * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d), in, out, scale_out,
+                     logdet_slot, slot_stride < 1 ? 1 : slot_stride);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
 extern "C" int ipoke_affine_inv(const ipoke_affine_desc* d, const float* in, float* out, int B, void* stream) {
   int rc = check_affine(d); if (rc) return rc;
   IPK_REQUIRE(in && out, "null state");
-  hipLaunchKernelGGL(affine_inv_kernel, dim3(B), dim3(256), 0, STREAM(stream), to_args(d), in, out);
+  hipLaunchKernelGGL(affine_inv_kernel, dim3(B), dim3(512), (size_t)d->P * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d), in, out);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -308,7 +308,7 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
   p.state0 = take(cur, (int64_t)(f.ops.size() + 1) * p.state_stride);
   p.g0 = take(cur, p.state_stride);
   p.g1 = take(cur, p.state_stride);
-  p.dbias_part = take(cur, (int64_t)f.ops.size() * B * 128 * 4);
+  p.dbias_part = take(cur, (int64_t)f.ops.size() * (B + 1) * 128 * 4);
   for (auto& op : f.ops) {
     if (op.type == OP_MCF) {
       op.ws_a = take(cur, M * op.K2p * f.esz);        // a2 (ELU(cat[c, h]))
@@ -630,6 +630,10 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
   IPK_HIP(hipMemcpyAsync(dld, d_logdet, B * sizeof(float), hipMemcpyDeviceToDevice, s));
   hipStream_t ws_stream = f->use_side ? f->side : s;
   void* wstream = reinterpret_cast<void*>(ws_stream);
+  // The small MCF weight-gradient GEMMs (a handful of output tiles) split their reduction over the batch
+  // across workgroups and add atomically, so the gradient buffer starts from zero.
+  const int small_splitm = B >= 4 ? (B + 1) / 2 : 1;
+  IPK_HIP(hipMemsetAsync(grads, 0, (size_t)f->n_params * sizeof(float), s));
   if (f->use_side) {   // the side stream joins after everything already queued on the main stream
     hipEvent_t e = next_event(f);
     IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0));
@@ -639,12 +643,19 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
     const Op& op = f->ops[i];
     const float* gin = G[cur]; float* gout = G[cur ^ 1];
     const float* xin = c.state(i);                 // saved input of op i
-    float* dbp = c.at<float>(c.plan.dbias_part) + (int64_t)i * B * 128;
+    float* dbp = c.at<float>(c.plan.dbias_part) + (int64_t)i * (B + 1) * 128;
     if (op.type == OP_ACTNORM) {
       rc = ipoke_actnorm_bwd(gin, xin, gout, M, c.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
-                             op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr, dld, B, f->P,
-                             op.p_ls >= 0 ? grads + op.p_ls : nullptr, op.p_bias >= 0 ? grads + op.p_bias : nullptr, stream);
+                             op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr, dld, B, f->P, dbp, stream);
       if (rc) return rc;
+      if (op.p_ls >= 0) {
+        if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
+        // ActNorm parameters are laid out [log_scale | bias] back to back only when Cn % 4 == 0; reduce them separately
+        float* tmp = dbp + (int64_t)B * 2 * op.Cn;            // [2*Cn] scratch behind the partials
+        rc = ipoke_reduce_rows(dbp, tmp, B, 2 * op.Cn, wstream); if (rc) return rc;
+        IPK_HIP(hipMemcpyAsync(grads + op.p_ls, tmp, op.Cn * sizeof(float), hipMemcpyDeviceToDevice, ws_stream));
+        IPK_HIP(hipMemcpyAsync(grads + op.p_bias, tmp + op.Cn, op.Cn * sizeof(float), hipMemcpyDeviceToDevice, ws_stream));
+      }
     } else if (op.type == OP_MCF) {
       ipoke_mcf_desc d; mcf_desc(c, op, d);
       d.x = xin; d.dy = gin; d.dx = gout; d.dld = dld;
@@ -661,7 +672,7 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
       w.A = c.at<void>(op.ws_a); w.a_f32 = 0; w.a_sn = 64L * op.K2p; w.a_sh = 8L * op.K2p; w.a_sw = op.K2p; w.a_sc = 1;
       w.Kc_real = K2; w.Kc = op.K2p;
       w.dY = c.at<void>(op.ws_c); w.ldy = op.K3p; w.Nout = 2 * op.C;
-      w.dW = grads + op.p_v; w.w_sn = K2; w.w_sc = 1; w.w_st = 0;
+      w.dW = grads + op.p_v; w.w_sn = K2; w.w_sc = 1; w.w_st = 0; w.splitm = small_splitm; w.accumulate = 1;
       rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
       const McfGeom g = mcf_geom(op.order);
       std::memset(&w, 0, sizeof(w));
@@ -669,7 +680,7 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
       w.sd = w.sh = w.sw = 1; w.ph = -g.oy; w.pw = -g.ox;
       w.A = xin; w.a_f32 = 1; w.a_sn = 64L * c.ld; w.a_sh = 8L * c.ld; w.a_sw = c.ld; w.a_sc = 1; w.Kc_real = op.C; w.Kc = op.Cp;
       w.dY = c.at<void>(op.ws_d); w.ldy = op.Hq; w.Nout = op.H;
-      w.dW = grads + op.p_w1; w.w_sn = (int64_t)op.C * 6; w.w_sc = 6; w.w_st = 1;
+      w.dW = grads + op.p_w1; w.w_sn = (int64_t)op.C * 6; w.w_sc = 6; w.w_st = 1; w.splitm = small_splitm; w.accumulate = 1;
       rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
     } else {
       const void* h1 = c.at<void>(op.ws_a); const void* h2 = c.at<void>(op.ws_b);
@@ -694,7 +705,7 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
       set_conv8(d, B, 3, 1); d.transposed = 1;
       set_a_dense(d, dp1, hid, hid);
       d.W = c.sh(op.sh_c1t); d.ldw = 9 * hid; d.Nout = op.cin; d.C = gout; d.c_f32 = 1; d.c_accumulate = 1; d.ldc = c.ld;
-      d.c_coff = op.z_off; d.c_cstride = op.z_stride;
+      d.c_coff = op.z_off; d.c_cstride = op.z_stride; d.splitk = nice_splitk(c);
       rc = ipoke_conv_forward(&d, c.dtype, stream); if (rc) return rc;
       if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
       rc = ipoke_reduce_rows(dbp, grads + op.p_b, B, 2 * op.cout, wstream); if (rc) return rc;

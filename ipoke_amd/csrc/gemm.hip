@@ -255,6 +255,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
       const int n = ncol + j * 16;
       if (n >= p.n_pad) continue;
       f32x4 v = acc[i][j];
+      if (p.splitk > 1 && p.c_acc) {       // K slices added atomically into an fp32 tensor that already holds a value
+        float* Cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + p.c_coff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.Nout) atomicAdd(Cp + (long)(n + r) * p.c_cstride, v[r]);
+        continue;
+      }
       if (p.splitk > 1) {
         float* P = reinterpret_cast<float*>(p.C) + ((long)z * g.M + m) * p.ldc + n;
         if (n + 3 < p.ldc) *reinterpret_cast<f32x4*>(P) = v;    // ldc is padded to a multiple of 4
@@ -587,7 +594,9 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
     const long lim = d->ldc - d->c_coff;
     p.n_pad = (int)(round_up(d->Nout, e16) < lim ? round_up(d->Nout, e16) : lim);
   }
-  if (p.splitk > 1) {
+  if (p.splitk > 1 && d->c_accumulate) {
+    IPK_REQUIRE(d->c_f32 && !d->bias && d->act == IPOKE_ACT_NONE && !d->dact, "atomic split-K accumulates raw fp32 sums only");
+  } else if (p.splitk > 1) {
     IPK_REQUIRE(d->ldc % 4 == 0 && d->ldc >= d->Nout, "split-K partials need ldc >= Nout, multiple of 4");
   } else if (!d->c_f32) {
     IPK_REQUIRE(p.c_cstride == 1 && !d->c_accumulate, "dtype outputs are dense, non-accumulating");

@@ -75,13 +75,15 @@ def actnorm_inv(state, c0, C, log_scale=None, bias=None, inv_idx=None):
 
 def actnorm_bwd(dy, x, c0, C, log_scale, idx, dld, B):
     dx = torch.empty_like(dy)
-    dls = torch.zeros(C, device=dy.device) if log_scale is not None else None
-    db = torch.zeros(C, device=dy.device) if log_scale is not None else None
+    part = torch.zeros(B, 2 * C, device=dy.device) if log_scale is not None else None
     i = _i32(idx)
     check(_lib.lib().ipoke_actnorm_bwd(ptr(dy), ptr(x), ptr(dx), dy.shape[0], dy.shape[1], c0, C,
                                        ptr(None if log_scale is None else log_scale.contiguous()), ptr(i), ptr(dld), B, P8,
-                                       ptr(dls), ptr(db), _s()))
-    return dx, dls, db
+                                       ptr(part), _s()))
+    if part is None:
+        return dx, None, None
+    tot = part.sum(0)
+    return dx, tot[:C], tot[C:]
 
 
 def actnorm_init_(state, c0, C, log_scale, bias):
