@@ -244,6 +244,40 @@ int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm,
                         const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
                         void* workspace, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * First-stage VAE helpers on channels-last activations [N][S][ld] of dtype.
+ * ------------------------------------------------------------------------------------------- */
+/* GroupNorm (InstanceNorm: G = C, no affine) fused with affine / SPADE modulation / residual / activation:
+ *   y = act( xhat * gamma + beta  [ * (1 + mod_gamma) + mod_beta ]  [ + res ] )
+ * Replaces nn.GroupNorm / nn.InstanceNorm2d call sites: motion_encoder.py:49-72, autoencoders/util.py:26-36,
+ * 223-233 and Spade.forward util.py:494-500. */
+typedef struct {
+  const void* x; int32_t ldx; void* y; int32_t ldy; int32_t y_f32;
+  int32_t N, S, C, G; float eps;
+  const float* gamma; const float* beta;                 /* [C] or NULL */
+  const void* mod_gamma; const void* mod_beta; int32_t ld_mod;
+  const void* res; int32_t ld_res;
+  int32_t act;
+  float* workspace;                                      /* ipoke_groupnorm_workspace_floats(N, S, G) floats */
+} ipoke_norm_desc;
+int64_t ipoke_groupnorm_workspace_floats(int N, int S, int G);
+int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream);
+int ipoke_add_act(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C, int act, int dtype,
+                  void* stream);
+/* ConvGRU cell element-wise stages (rnn.py:48-56) */
+int ipoke_gru_gates(const void* ur_pre, const void* h, int ldh, void* hr_out, int ld_hr, void* u_out, int64_t M, int Ch,
+                    int dtype, void* stream);
+int ipoke_gru_update(const void* o_pre, const void* u, const void* h, int ldh, void* h_new, int ld_new, int64_t M, int Ch,
+                     int dtype, void* stream);
+/* z = mu + eps*exp(logvar/2) (motion_encoder.py:218-222); mulv = [mu | logvar] per row */
+int ipoke_reparameterize(const void* mulv, int ld, const float* eps, float* z, float* mu, float* logvar, int64_t M, int Z,
+                         int dtype, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=True) (util.py:495): NCHW fp32 -> channels-last fp32 */
+int ipoke_bilinear_cl(const float* x_nchw, float* y_cl, int N, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+int ipoke_cl_to_nchw(const void* x_cl, int ld, float* y, int N, int C, int S, int dtype, void* stream);
+int ipoke_nchw_to_cl(const float* x, void* y_cl, int ld, int N, int C, int S, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

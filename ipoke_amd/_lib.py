@@ -56,6 +56,14 @@ class McfDesc(Structure):
                 ("dparams_save", c_void_p), ("dc_save", c_void_p), ("dbias_part", c_void_p)]
 
 
+class NormDesc(Structure):
+    _fields_ = [("x", c_void_p), ("ldx", c_int32), ("y", c_void_p), ("ldy", c_int32), ("y_f32", c_int32),
+                ("N", c_int32), ("S", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
+                ("gamma", c_void_p), ("beta", c_void_p),
+                ("mod_gamma", c_void_p), ("mod_beta", c_void_p), ("ld_mod", c_int32),
+                ("res", c_void_p), ("ld_res", c_int32), ("act", c_int32), ("workspace", c_void_p)]
+
+
 class FlowConfig(Structure):
     _fields_ = [("z_channels", c_int32), ("hidden", c_int32), ("cond_channels", c_int32), ("factor", c_int32),
                 ("n_levels", c_int32), ("num_steps", c_int32 * 32), ("kernel_h", c_int32), ("kernel_w", c_int32),
@@ -95,6 +103,15 @@ SIGNATURES = {
     "ipoke_relayout_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "ipoke_wn_scale_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "ipoke_wn_bwd_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "ipoke_groupnorm_workspace_floats": (c_int64, [c_int, c_int, c_int]),
+    "ipoke_groupnorm": (c_int, [POINTER(NormDesc), c_int, _P]),
+    "ipoke_add_act": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, _P]),
+    "ipoke_gru_gates": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int64, c_int, c_int, _P]),
+    "ipoke_gru_update": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int64, c_int, c_int, _P]),
+    "ipoke_reparameterize": (c_int, [_P, c_int, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "ipoke_bilinear_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_cl_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_nchw_to_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),
     "ipoke_flow_destroy": (None, [_P]),
     "ipoke_flow_param_count": (c_int64, [_P]),

@@ -1,0 +1,316 @@
+// GroupNorm / InstanceNorm / SPADE modulation on channels-last activations, plus small element-wise
+// helpers of the first-stage VAE (ConvGRU gate math, reparameterisation, bilinear resize).
+// Reference call sites: motion_encoder.py:45-74 (GroupNorm(16)+ReLU+residual), autoencoders/util.py:26-36,
+// 223-233 (GroupNorm / InstanceNorm in conv blocks), :473-500 (Spade), motion_models/rnn.py:32-56 (ConvGRU).
+//
+// Statistics are fp32 and numerically robust: every block reduces a chunk of positions to
+// (count, mean, M2) per group and a finalize kernel merges chunks with Chan's parallel update.
+#include "common.h"
+
+namespace ipoke {
+
+// x: [N][S][ldx] of T, channels [0, C) normalised in G groups of cpg = C/G consecutive channels.
+// part: [N][nchunks][G][3] = (count, mean, M2)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int S, int ldx, int C, int G, int pos_per_block,
+                                                       float* __restrict__ part) {
+  extern __shared__ float sm[];     // [2][C]
+  const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  const int p0 = chunk * pos_per_block, p1 = min(S, p0 + pos_per_block);
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sm[i] = 0.f;
+  __syncthreads();
+  constexpr int E16 = ET<T>::E16;
+  const int cvec = C / E16;                          // host guarantees C % E16 == 0
+  const int lanes_c = min(cvec, (int)blockDim.x);
+  const int cv = threadIdx.x % lanes_c, prow = threadIdx.x / lanes_c, prows = blockDim.x / lanes_c;
+  const T* xb = x + ((long)n * S) * ldx;
+  for (int cc = cv; cc < cvec; cc += lanes_c) {
+    float s[E16], q[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (prow < prows) {
+      for (int p = p0 + prow; p < p1; p += prows) {
+        const typename ET<T>::frag v = *reinterpret_cast<const typename ET<T>::frag*>(xb + (long)p * ldx + cc * E16);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) { const float f = ET<T>::to_f32(v[e]); s[e] += f; q[e] += f * f; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E16; ++e) { atomicAdd(&sm[cc * E16 + e], s[e]); atomicAdd(&sm[C + cc * E16 + e], q[e]); }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int c = 0; c < cpg; ++c) { s += sm[g * cpg + c]; q += sm[C + g * cpg + c]; }
+    const float cnt = (float)(p1 - p0) * cpg;
+    const float mean = cnt > 0 ? s / cnt : 0.f;
+    float m2 = q - s * mean;
+    if (m2 < 0.f) m2 = 0.f;
+    float* o = part + (((long)n * nchunks + chunk) * G + g) * 3;
+    o[0] = cnt; o[1] = mean; o[2] = m2;
+  }
+}
+// stats[n][g] = (mean, rstd)
+__global__ void gn_finalize_kernel(const float* __restrict__ part, int nchunks, int G, float eps, float* __restrict__ stats) {
+  const int n = blockIdx.x;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      const float* o = part + (((long)n * nchunks + c) * G + g) * 3;
+      const float cb = o[0];
+      if (cb <= 0.f) continue;
+      const float delta = o[1] - mean, tot = cnt + cb;
+      mean += delta * cb / tot;
+      m2 += o[2] + delta * delta * cnt * cb / tot;
+      cnt = tot;
+    }
+    stats[((long)n * G + g) * 2] = mean;
+    stats[((long)n * G + g) * 2 + 1] = rsqrtf(m2 / cnt + eps);     // biased variance, as torch group_norm
+  }
+}
+struct NormApply {
+  const void* x; int ldx; void* y; int ldy; int y_f32;
+  int N, S, C, G;
+  const float* stats;              // [N][G][2]
+  const float* gamma; const float* beta;      // [C] affine or NULL
+  const void* mod_gamma; const void* mod_beta; int ld_mod;   // SPADE: T [N*S][ld_mod]; y = xhat*(1+mg)+mb
+  const void* res; int ld_res;     // optional residual added before the activation
+  int act;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  const int cvec = a.C / E16;
+  const long total = (long)a.N * a.S * cvec;
+  const int cpg = a.C / a.G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cvec);
+    const long m = i / cvec;
+    const int n = (int)(m / a.S);
+    const frag_t v = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cc * E16);
+    frag_t r, mg, mb;
+    if (a.res) r = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.res) + m * a.ld_res + cc * E16);
+    if (a.mod_gamma) {
+      mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + m * a.ld_mod + cc * E16);
+      mb = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_beta) + m * a.ld_mod + cc * E16);
+    }
+    float o[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) {
+      const int c = cc * E16 + e, g = c / cpg;
+      const float mean = a.stats[((long)n * a.G + g) * 2], rstd = a.stats[((long)n * a.G + g) * 2 + 1];
+      float f = (ET<T>::to_f32(v[e]) - mean) * rstd;
+      if (a.gamma) f = f * a.gamma[c] + a.beta[c];
+      if (a.mod_gamma) f = f * (1.f + ET<T>::to_f32(mg[e])) + ET<T>::to_f32(mb[e]);
+      if (a.res) f += ET<T>::to_f32(r[e]);
+      o[e] = act_apply(a.act, f);
+    }
+    if (a.y_f32) {
+      float* yp = reinterpret_cast<float*>(a.y) + m * a.ldy + cc * E16;
+#pragma unroll
+      for (int e = 0; e < E16; ++e) yp[e] = o[e];
+    } else {
+      frag_t w;
+#pragma unroll
+      for (int e = 0; e < E16; ++e) w[e] = ET<T>::from_f32(o[e]);
+      *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.y) + m * a.ldy + cc * E16) = w;
+    }
+  }
+}
+
+// generic element-wise: y = act(a (+ b)) on dense T rows of C channels with pitches
+template <typename T>
+__global__ void ew_add_act_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb, T* __restrict__ y, int ldy,
+                                  long M, int C, int act) {
+  const long total = M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C; const int c = (int)(i - m * C);
+    float f = ET<T>::to_f32(a[m * lda + c]);
+    if (b) f += ET<T>::to_f32(b[m * ldb + c]);
+    y[m * ldy + c] = ET<T>::from_f32(act_apply(act, f));
+  }
+}
+
+// ConvGRU (rnn.py:48-56).  Phase 1: xh_r[:, Cx:Cx+Ch] = h * sigmoid(r_pre);  u = sigmoid(u_pre) (in place)
+template <typename T>
+__global__ void gru_gates_kernel(const T* __restrict__ ur_pre /* [M][2Ch]: u | r */, const T* __restrict__ h, int ldh,
+                                 T* __restrict__ hr_out, int ld_hr, T* __restrict__ u_out, long M, int Ch) {
+  const long total = M * Ch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / Ch; const int c = (int)(i - m * Ch);
+    const float u = act_apply(IPOKE_ACT_SIGMOID, ET<T>::to_f32(ur_pre[m * 2 * Ch + c]));
+    const float r = act_apply(IPOKE_ACT_SIGMOID, ET<T>::to_f32(ur_pre[m * 2 * Ch + Ch + c]));
+    hr_out[m * ld_hr + c] = ET<T>::from_f32(ET<T>::to_f32(h[m * ldh + c]) * r);
+    u_out[m * Ch + c] = ET<T>::from_f32(u);
+  }
+}
+// Phase 2: h' = h*(1-u) + tanh(o_pre)*u
+template <typename T>
+__global__ void gru_update_kernel(const T* __restrict__ o_pre, const T* __restrict__ u, const T* __restrict__ h, int ldh,
+                                  T* __restrict__ h_new, int ld_new, long M, int Ch) {
+  const long total = M * Ch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / Ch; const int c = (int)(i - m * Ch);
+    const float uu = ET<T>::to_f32(u[m * Ch + c]);
+    const float o = tanhf(ET<T>::to_f32(o_pre[m * Ch + c]));
+    h_new[m * ld_new + c] = ET<T>::from_f32(ET<T>::to_f32(h[m * ldh + c]) * (1.f - uu) + o * uu);
+  }
+}
+// z = mu + eps * exp(0.5*logvar)   (motion_encoder.py:218-222); mulv: T [M][2z] = mu | logvar; out fp32 NCHW-free [M][z]
+template <typename T>
+__global__ void reparam_kernel(const T* __restrict__ mulv, int ld, const float* __restrict__ eps, float* __restrict__ z,
+                               float* __restrict__ mu_out, float* __restrict__ lv_out, long M, int Z) {
+  const long total = M * Z;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / Z; const int c = (int)(i - m * Z);
+    const float mu = ET<T>::to_f32(mulv[m * ld + c]), lv = ET<T>::to_f32(mulv[m * ld + Z + c]);
+    z[i] = eps ? mu + eps[i] * expf(0.5f * lv) : mu;
+    if (mu_out) mu_out[i] = mu;
+    if (lv_out) lv_out[i] = lv;
+  }
+}
+// bilinear resize, align_corners=True (util.py:495), NCHW fp32 [N][C][Hi][Wi] -> channels-last fp32 [N][Ho][Wo][C]
+__global__ void bilinear_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int Hi, int Wi, int Ho, int Wo) {
+  const long total = (long)N * Ho * Wo * C;
+  const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long t = i / C;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho); const int n = (int)(t / Ho);
+    const float fy = oy * sy, fx = ox * sx;
+    const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
+    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const float* p = x + ((long)n * C + c) * Hi * Wi;
+    const float v = (1.f - wy) * ((1.f - wx) * p[y0 * Wi + x0] + wx * p[y0 * Wi + x1]) +
+                    wy * ((1.f - wx) * p[y1 * Wi + x0] + wx * p[y1 * Wi + x1]);
+    y[i] = v;
+  }
+}
+// channels-last T [M][ld] (first C channels) -> fp32 NCHW-like [N][C][S]
+template <typename T>
+__global__ void cl_to_nchw_kernel(const T* __restrict__ x, int ld, float* __restrict__ y, int N, int C, int S) {
+  const long total = (long)N * C * S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int s = (int)(i % S); long t = i / S;
+    const int c = (int)(t % C); const int n = (int)(t / C);
+    y[i] = ET<T>::to_f32(x[((long)n * S + s) * ld + c]);
+  }
+}
+// fp32 NCHW-like [N][C][S] -> channels-last T [N*S][ld] (zero padded to ld)
+template <typename T>
+__global__ void nchw_to_cl_kernel(const float* __restrict__ x, T* __restrict__ y, int ld, int N, int C, int S) {
+  const long total = (long)N * S * ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld); long t = i / ld;
+    const int s = (int)(t % S); const int n = (int)(t / S);
+    y[i] = ET<T>::from_f32(c < C ? x[((long)n * C + c) * S + s] : 0.f);
+  }
+}
+
+static inline int grid1d(long n, int block = 256, int cap = 4096) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace ipoke
+
+using namespace ipoke;
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+#define DISPATCH_T(dtype, CALL_BF, CALL_F32) do { if ((dtype) == IPOKE_BF16) { CALL_BF; } else { CALL_F32; } } while (0)
+
+extern "C" int64_t ipoke_groupnorm_workspace_floats(int N, int S, int G) {
+  const int ppb = 128;
+  const int nchunks = (S + ppb - 1) / ppb;
+  return (int64_t)N * nchunks * G * 3 + (int64_t)N * G * 2;
+}
+
+extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream) {
+  IPK_REQUIRE(d && d->x && d->y && d->workspace, "null tensor");
+  const int e16 = dtype == IPOKE_BF16 ? 8 : 4;
+  IPK_REQUIRE(d->C % e16 == 0 && d->C % d->G == 0 && d->C <= 4096, "channels must be a multiple of 16 bytes and of the group count");
+  IPK_REQUIRE(d->ldx % e16 == 0 && d->ldy % (d->y_f32 ? 1 : e16) == 0, "pitches must keep 16-byte alignment");
+  IPK_REQUIRE((d->gamma == nullptr) == (d->beta == nullptr) && (d->mod_gamma == nullptr) == (d->mod_beta == nullptr), "affine pairs");
+  const int ppb = 128;
+  const int nchunks = (d->S + ppb - 1) / ppb;
+  float* part = d->workspace;
+  float* stats = part + (int64_t)d->N * nchunks * d->G * 3;
+  hipStream_t s = STREAM(stream);
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, d->N), dim3(256), 2 * d->C * sizeof(float), s, (const bf16_t*)d->x, d->S, d->ldx, d->C, d->G, ppb, part),
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, d->N), dim3(256), 2 * d->C * sizeof(float), s, (const float*)d->x, d->S, d->ldx, d->C, d->G, ppb, part));
+  IPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->N), dim3(64), 0, s, part, nchunks, d->G, d->eps, stats);
+  IPK_LAUNCH_CHECK();
+  NormApply a;
+  a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.y_f32 = d->y_f32; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
+  a.stats = stats; a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = d->mod_gamma; a.mod_beta = d->mod_beta; a.ld_mod = d->ld_mod;
+  a.res = d->res; a.ld_res = d->ld_res; a.act = d->act;
+  const long total = (long)d->N * d->S * (d->C / e16);
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid1d(total)), dim3(256), 0, s, a),
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid1d(total)), dim3(256), 0, s, a));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_add_act(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C, int act,
+                             int dtype, void* stream) {
+  IPK_REQUIRE(a && y, "null tensor");
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(ew_add_act_kernel<bf16_t>, dim3(grid1d(M * C)), dim3(256), 0, STREAM(stream), (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)y, ldy, (long)M, C, act),
+    hipLaunchKernelGGL(ew_add_act_kernel<float>, dim3(grid1d(M * C)), dim3(256), 0, STREAM(stream), (const float*)a, lda, (const float*)b, ldb, (float*)y, ldy, (long)M, C, act));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_gru_gates(const void* ur_pre, const void* h, int ldh, void* hr_out, int ld_hr, void* u_out, int64_t M, int Ch,
+                               int dtype, void* stream) {
+  IPK_REQUIRE(ur_pre && h && hr_out && u_out, "null tensor");
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gru_gates_kernel<bf16_t>, dim3(grid1d(M * Ch)), dim3(256), 0, STREAM(stream), (const bf16_t*)ur_pre, (const bf16_t*)h, ldh, (bf16_t*)hr_out, ld_hr, (bf16_t*)u_out, (long)M, Ch),
+    hipLaunchKernelGGL(gru_gates_kernel<float>, dim3(grid1d(M * Ch)), dim3(256), 0, STREAM(stream), (const float*)ur_pre, (const float*)h, ldh, (float*)hr_out, ld_hr, (float*)u_out, (long)M, Ch));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_gru_update(const void* o_pre, const void* u, const void* h, int ldh, void* h_new, int ld_new, int64_t M, int Ch,
+                                int dtype, void* stream) {
+  IPK_REQUIRE(o_pre && u && h && h_new, "null tensor");
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gru_update_kernel<bf16_t>, dim3(grid1d(M * Ch)), dim3(256), 0, STREAM(stream), (const bf16_t*)o_pre, (const bf16_t*)u, (const bf16_t*)h, ldh, (bf16_t*)h_new, ld_new, (long)M, Ch),
+    hipLaunchKernelGGL(gru_update_kernel<float>, dim3(grid1d(M * Ch)), dim3(256), 0, STREAM(stream), (const float*)o_pre, (const float*)u, (const float*)h, ldh, (float*)h_new, ld_new, (long)M, Ch));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_reparameterize(const void* mulv, int ld, const float* eps, float* z, float* mu, float* logvar, int64_t M, int Z,
+                                    int dtype, void* stream) {
+  IPK_REQUIRE(mulv && z, "null tensor");
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(reparam_kernel<bf16_t>, dim3(grid1d(M * Z)), dim3(256), 0, STREAM(stream), (const bf16_t*)mulv, ld, eps, z, mu, logvar, (long)M, Z),
+    hipLaunchKernelGGL(reparam_kernel<float>, dim3(grid1d(M * Z)), dim3(256), 0, STREAM(stream), (const float*)mulv, ld, eps, z, mu, logvar, (long)M, Z));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_bilinear_cl(const float* x_nchw, float* y_cl, int N, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  IPK_REQUIRE(x_nchw && y_cl, "null tensor");
+  hipLaunchKernelGGL(bilinear_cl_kernel, dim3(grid1d((long)N * Ho * Wo * C)), dim3(256), 0, STREAM(stream), x_nchw, y_cl, N, C, Hi, Wi, Ho, Wo);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_cl_to_nchw(const void* x_cl, int ld, float* y, int N, int C, int S, int dtype, void* stream) {
+  IPK_REQUIRE(x_cl && y, "null tensor");
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(cl_to_nchw_kernel<bf16_t>, dim3(grid1d((long)N * C * S)), dim3(256), 0, STREAM(stream), (const bf16_t*)x_cl, ld, y, N, C, S),
+    hipLaunchKernelGGL(cl_to_nchw_kernel<float>, dim3(grid1d((long)N * C * S)), dim3(256), 0, STREAM(stream), (const float*)x_cl, ld, y, N, C, S));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_nchw_to_cl(const float* x, void* y_cl, int ld, int N, int C, int S, int dtype, void* stream) {
+  IPK_REQUIRE(x && y_cl && ld >= C, "bad arguments");
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(nchw_to_cl_kernel<bf16_t>, dim3(grid1d((long)N * S * ld)), dim3(256), 0, STREAM(stream), x, (bf16_t*)y_cl, ld, N, C, S),
+    hipLaunchKernelGGL(nchw_to_cl_kernel<float>, dim3(grid1d((long)N * S * ld)), dim3(256), 0, STREAM(stream), x, (float*)y_cl, ld, N, C, S));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}

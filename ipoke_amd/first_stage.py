@@ -1,0 +1,475 @@
+"""First-stage video VAE of iPOKE on the HIP kernels: 3-D ResNet-18 motion encoder, ConvGRU, SPADE decoder and
+the small 2-D poke / image encoders.  Class names, constructor arguments, attributes and state-dict keys follow
+the reference (models/first_stage_motion_model.py:469-522, modules/motion_models/{motion_encoder,rnn}.py,
+modules/autoencoders/{fully_conv_models,util}.py) so that reference checkpoints load with ``strict=False``
+exactly as ``PokeMotionModel.__initialize_first_stage`` does.
+
+This round implements the *inference* direction (what the second stage and sampling need: everything runs under
+``torch.no_grad`` there, second_stage_video.py:269-303).  Spectral-normalised convolutions are evaluated in eval
+mode (frozen u, v), i.e. ``W / sigma`` is folded into the cached weight operand.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F   # noqa: F401  (normalize() for buffer init only)
+
+from . import _lib, nn as K, ops
+from ._lib import check, ptr
+
+ACT = {"none": _lib.ACT_NONE, "elu": _lib.ACT_ELU, "relu": _lib.ACT_RELU, "tanh": _lib.ACT_TANH}
+
+
+class _Cached(nn.Module):
+    """Mixin: cache of weight operands, dropped whenever the state dict is (re)loaded."""
+
+    def _cache(self):
+        if "_opcache" not in self.__dict__:
+            self.__dict__["_opcache"] = {}
+        return self.__dict__["_opcache"]
+
+    def invalidate(self):
+        for m in self.modules():
+            m.__dict__.pop("_opcache", None)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.__dict__.pop("_opcache", None)
+        return super()._load_from_state_dict(*a, **k)
+
+
+class _Conv(_Cached):
+    """Parameter holder + executor of one convolution (nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d naming)."""
+
+    def __init__(self, cin, cout, k, stride, pad, bias=True, transposed=False, snorm=False, dims=2):
+        super().__init__()
+        k3 = (1, k, k) if (dims == 2 and isinstance(k, int)) else ((k, k, k) if isinstance(k, int) else tuple(k))
+        st = (1, stride, stride) if (dims == 2 and isinstance(stride, int)) else (
+            (stride,) * 3 if isinstance(stride, int) else tuple(stride))
+        pd = (0, pad, pad) if (dims == 2 and isinstance(pad, int)) else ((pad,) * 3 if isinstance(pad, int) else tuple(pad))
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k3, st, pd
+        self.transposed, self.snorm, self.dims = transposed, snorm, dims
+        kshape = k3[1:] if dims == 2 else k3
+        wshape = (cin, cout, *kshape) if transposed else (cout, cin, *kshape)
+        fan_in = cin * int(np.prod(kshape))
+        w = torch.empty(wshape).uniform_(-1, 1) / math.sqrt(fan_in)
+        if snorm:
+            self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+            self.weight_orig = nn.Parameter(w)
+            rows = cout
+            self.register_buffer("weight_u", F.normalize(torch.randn(rows), dim=0))
+            self.register_buffer("weight_v", F.normalize(torch.randn(w.numel() // rows), dim=0))
+        else:
+            self.weight = nn.Parameter(w)
+            self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+    def operand(self, dtype):
+        c = self._cache()
+        if dtype not in c:
+            with torch.no_grad():
+                if self.snorm:
+                    w = self.weight_orig / K.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.transposed)
+                else:
+                    w = self.weight
+                if self.dims == 2:
+                    w = w.unsqueeze(2)
+                wop, kc = K.weight_operand(w, dtype, self.transposed)
+                c[dtype] = (wop, kc, None if self.bias is None else self.bias.detach().float().contiguous())
+        return c[dtype]
+
+    def run(self, x, dtype, act=_lib.ACT_NONE, out_f32=False, src_f32=None):
+        wop, kc, b = self.operand(dtype)
+        out_pad = (0, self.pad[1], self.pad[2]) if self.transposed else (0, 0, 0)     # util.py:52 output_padding=padding
+        return K.conv(x, wop, kc, self.cout, self.k, self.stride, self.pad, dtype, bias=b, act=act, transposed=self.transposed,
+                      out_pad=out_pad, out_f32=out_f32, src_f32=src_f32)
+
+
+class _Norm(nn.Module):
+    """GroupNorm / InstanceNorm parameter holder."""
+
+    def __init__(self, kind, ch):
+        super().__init__()
+        self.kind, self.ch = kind, ch
+        if kind == "group":
+            self.weight = nn.Parameter(torch.ones(ch))
+            self.bias = nn.Parameter(torch.zeros(ch))
+            self.groups = 16
+        else:                      # "in": InstanceNorm2d(affine=False)
+            self.groups = ch
+
+    def run(self, x, dtype, act=_lib.ACT_NONE, res=None):
+        if self.kind == "group":
+            return K.group_norm(x, self.groups, dtype, self.weight.detach(), self.bias.detach(), act=act, res=res)
+        return K.group_norm(x, self.groups, dtype, act=act, res=res)
+
+
+# ---------------------------------------------------------------------------------------------- 3-D encoder
+class BasicBlock(nn.Module):
+    """motion_encoder.py:45-74."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv1 = _Conv(cin, cout, 3, stride, 1, bias=False, dims=3)
+        self.bn1 = _Norm("group", cout)
+        self.conv2 = _Conv(cout, cout, 3, 1, 1, bias=False, dims=3)
+        self.bn2 = _Norm("group", cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(_Conv(cin, cout, 1, stride, 0, bias=False, dims=3), _Norm("group", cout))
+
+    def run(self, x, dtype):
+        out = self.bn1.run(self.conv1.run(x, dtype), dtype, act=_lib.ACT_RELU)
+        res = x if self.downsample is None else self.downsample[1].run(self.downsample[0].run(x, dtype), dtype)
+        return self.bn2.run(self.conv2.run(out, dtype), dtype, act=_lib.ACT_RELU, res=res)
+
+
+class ResNetMotionEncoder(nn.Module):
+    """motion_encoder.py:150-241 (resnet18_alternative).  ``forward(x[B,3,T,H,W]) -> (z, mu, logvar)``."""
+
+    def __init__(self, dic, dtype="bf16"):
+        super().__init__()
+        ch = list(dic["ENC_M_channels"])
+        self.dtype = dtype
+        self.be_determinstic = bool(dic.get("deterministic", False))      # [sic]
+        self.spatial_size = dic["img_size"]
+        max_frames = dic["max_frames"]
+        self.min_ssize = dic.get("min_spatial_size", 8)
+        self.z_dim = dic["z_dim"]
+        self.conv1 = _Conv(3, ch[0], (3, 7, 7), 2, (1, 3, 3), bias=False, dims=3)
+        self.bn1 = _Norm("group", ch[0])
+        first_down = (len(ch) - 1 < int(np.ceil(np.log2(max_frames)))) or dic["full_seq"]
+        self.layer1 = self._make(ch[0], ch[1], (2, 1, 1) if first_down else 1)
+        self.layer2 = self._make(ch[1], ch[2], 2)
+        self.layer3 = self._make(ch[2], ch[3], 2)
+        last = ch[3]
+        self.stride4 = (2, 1, 1) if dic["full_seq"] and max_frames >= 16 else None
+        if self.spatial_size // 8 > self.min_ssize:
+            self.stride4 = 2
+        if self.stride4 is not None:
+            if len(ch) < 5:
+                ch.append(ch[-1])
+            self.layer4 = self._make(ch[3], ch[4], self.stride4)
+            last = ch[4]
+        self.has5 = self.spatial_size // 16 > self.min_ssize
+        if self.has5:
+            self.layer5 = self._make(last, ch[5], 2)
+            last = ch[5]
+        self.conv_mu = _Conv(last, self.z_dim, 3, 1, 1)
+        self.conv_var = _Conv(last, self.z_dim, 3, 1, 1)
+
+    @staticmethod
+    def _make(cin, cout, stride):
+        return nn.Sequential(BasicBlock(cin, cout, stride), BasicBlock(cout, cout, 1))
+
+    def _head_operand(self):
+        """conv_mu and conv_var share their input: one GEMM with 2*z output channels."""
+        c = self.conv_mu._cache()
+        key = ("head", self.dtype)
+        if key not in c:
+            with torch.no_grad():
+                w = torch.cat([self.conv_mu.weight, self.conv_var.weight], 0).unsqueeze(2)
+                wop, kc = K.weight_operand(w, self.dtype)
+                b = torch.cat([self.conv_mu.bias, self.conv_var.bias]).detach().float().contiguous()
+            c[key] = (wop, kc, b)
+        return c[key]
+
+    @torch.no_grad()
+    def forward(self, x, eps=None):
+        _lib.require_gpu()
+        dt = self.dtype
+        B, C, T, H, W = x.shape
+        x = x.float()
+        st = (x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4))
+        h = self.conv1.run(None, dt, src_f32=(x, B, C, (T, H, W), st))
+        h = self.bn1.run(h, dt, act=_lib.ACT_RELU)
+        layers = [self.layer1, self.layer2, self.layer3] + ([self.layer4] if self.stride4 is not None else []) + (
+            [self.layer5] if self.has5 else [])
+        for layer in layers:
+            for blk in layer:
+                h = blk.run(h, dt)
+        if h.dhw[0] != 1:
+            raise ValueError(f"temporal extent after the encoder is {h.dhw[0]}, expected 1 (x.squeeze(2) in the reference)")
+        wop, kc, b = self._head_operand()
+        mulv = K.conv(h, wop, kc, 2 * self.z_dim, (1, 3, 3), (1, 1, 1), (0, 1, 1), dt, bias=b)
+        M, Z = mulv.M, self.z_dim
+        if not self.be_determinstic and eps is None:
+            # the reference draws on the CPU generator: torch.FloatTensor(size).normal_() (motion_encoder.py:220)
+            eps = torch.FloatTensor(B, Z, h.dhw[1], h.dhw[2]).normal_().to(x.device)
+        eps_s = None if self.be_determinstic else ops.to_state(eps)
+        z = torch.empty(M, Z, device=x.device); mu = torch.empty_like(z); lv = torch.empty_like(z)
+        check(_lib.lib().ipoke_reparameterize(ptr(mulv.t), mulv.t.shape[1], ptr(eps_s), ptr(z), ptr(mu), ptr(lv), M, Z,
+                                              ops._dt(dt), _lib.current_stream()))
+        z, mu, lv = (ops.from_state(t_, B, Z) for t_ in (z, mu, lv))
+        if self.be_determinstic:
+            return mu, mu, mu
+        return z, mu, lv
+
+
+# ---------------------------------------------------------------------------------------------- ConvGRU
+class ConvGRUCell(_Cached):
+    """rnn.py:4-56."""
+
+    def __init__(self, cin, hidden, k=3):
+        super().__init__()
+        self.cin, self.hidden = cin, hidden
+        self.reset_gate = _Conv(cin + hidden, hidden, k, 1, k // 2)
+        self.update_gate = _Conv(cin + hidden, hidden, k, 1, k // 2)
+        self.out_gate = _Conv(cin + hidden, hidden, k, 1, k // 2)
+
+    def _ur_operand(self, dtype):
+        c = self._cache()
+        if dtype not in c:
+            with torch.no_grad():
+                w = torch.cat([self.update_gate.weight, self.reset_gate.weight], 0).unsqueeze(2)
+                wop, kc = K.weight_operand(w, dtype)
+                b = torch.cat([self.update_gate.bias, self.reset_gate.bias]).detach().float().contiguous()
+            c[dtype] = (wop, kc, b)
+        return c[dtype]
+
+    def run(self, x, h, dtype):
+        """x, h: CL with C = cin / hidden.  Returns the new hidden state (CL)."""
+        Ch = self.hidden
+        xh = torch.cat([x.t[:, :x.C], h.t[:, :Ch]], dim=1).contiguous()          # [M][cin+hidden]  (torch.cat in rnn.py:48)
+        xh_cl = K.CL(xh, x.N, x.dhw, x.C + Ch)
+        wop, kc, b = self._ur_operand(dtype)
+        ur = K.conv(xh_cl, wop, kc, 2 * Ch, (1, 3, 3), (1, 1, 1), (0, 1, 1), dtype, bias=b)
+        xhr = xh.clone()
+        u = torch.empty(x.M, Ch, dtype=xh.dtype, device=xh.device)
+        check(_lib.lib().ipoke_gru_gates(ptr(ur.t), ptr(h.t), h.t.shape[1], ptr(xhr[:, x.C:]), xhr.shape[1], ptr(u), x.M, Ch,
+                                         ops._dt(dtype), _lib.current_stream()))
+        o = self.out_gate.run(K.CL(xhr, x.N, x.dhw, x.C + Ch), dtype)
+        hn = torch.empty(x.M, Ch, dtype=xh.dtype, device=xh.device)
+        check(_lib.lib().ipoke_gru_update(ptr(o.t), ptr(u), ptr(h.t), h.t.shape[1], ptr(hn), Ch, x.M, Ch, ops._dt(dtype),
+                                          _lib.current_stream()))
+        return K.CL(hn, x.N, x.dhw, Ch)
+
+
+class ConvGRU(nn.Module):
+    """rnn.py:59-133: ``forward(x, hidden) -> list of new hidden states`` (NCHW fp32 at the API)."""
+
+    def __init__(self, input_size, hidden_sizes, kernel_sizes, n_layers, upsampling=None, dtype="bf16"):
+        super().__init__()
+        self.n_layers, self.dtype = n_layers, dtype
+        self.cells = nn.Sequential(*[ConvGRUCell(input_size if i == 0 else hidden_sizes, hidden_sizes, kernel_sizes)
+                                     for i in range(n_layers)])
+
+    def run(self, x, hidden):
+        out = []
+        for cell, h in zip(self.cells, hidden):
+            x = cell.run(x, h, self.dtype)
+            out.append(x)
+        return out
+
+    @torch.no_grad()
+    def forward(self, x, hidden):
+        xs = K.from_nchw(x, self.dtype)
+        hs = [K.from_nchw(h, self.dtype) for h in hidden]
+        return [K.to_nchw(h, self.dtype) for h in self.run(xs, hs)]
+
+
+# ---------------------------------------------------------------------------------------------- 2-D conv blocks
+class Conv2dBlock(nn.Module):
+    """util.py:195-273 (zero pad -> conv -> norm -> activation)."""
+
+    def __init__(self, cin, cout, ks, st, padding=0, norm="none", activation="elu", snorm=False):
+        super().__init__()
+        self.activation = activation
+        self.norm = None if norm == "none" else _Norm(norm, cout)
+        self.conv = _Conv(cin, cout, ks, st, padding, snorm=snorm)
+
+    def run(self, x, dtype, res=None, out_f32=False):
+        if self.norm is None:
+            y = self.conv.run(x, dtype, act=ACT[self.activation] if res is None else _lib.ACT_NONE, out_f32=out_f32)
+            return y if res is None else K.add_act(y, res, dtype, ACT[self.activation])
+        return self.norm.run(self.conv.run(x, dtype), dtype, act=ACT[self.activation], res=res)
+
+
+class Conv2dTransposeBlock(nn.Module):
+    """util.py:7-73.  NB the key "elu" selects nn.ReLU in this block (util.py:41-42)."""
+
+    def __init__(self, cin, cout, ks, st, padding=0, norm="none", activation="elu", snorm=False):
+        super().__init__()
+        self.act = _lib.ACT_RELU if activation == "elu" else ACT[activation]
+        self.norm = None if norm == "none" else _Norm(norm, cout)
+        self.conv = _Conv(cin, cout, ks, st, padding, transposed=True, snorm=snorm)
+
+    def run(self, x, dtype):
+        if self.norm is None:
+            return self.conv.run(x, dtype, act=self.act)
+        return self.norm.run(self.conv.run(x, dtype), dtype, act=self.act)
+
+
+class ResBlock(nn.Module):
+    """util.py:106-192: out = conv2(conv1(x)) + res_conv(x) (skip conv with InstanceNorm + activation)."""
+
+    def __init__(self, cin, cout, norm="in", activation="elu", upsampling=False, stride=1, snorm=False):
+        super().__init__()
+        if upsampling:
+            self.conv1 = Conv2dTransposeBlock(cin, cout, 3, 2, 1, norm=norm, activation=activation, snorm=snorm)
+        else:
+            self.conv1 = Conv2dBlock(cin, cout, 3, stride, 1, norm=norm, activation=activation, snorm=snorm)
+        self.conv2 = Conv2dBlock(cout, cout, 3, 1, 1, norm=norm, activation="none", snorm=snorm)
+        self.convolve_res = cin != cout or upsampling or stride != 1
+        if self.convolve_res:
+            if upsampling:
+                self.res_conv = Conv2dTransposeBlock(cin, cout, 3, 2, 1, norm="in", activation=activation, snorm=snorm)
+            else:
+                self.res_conv = Conv2dBlock(cin, cout, 3, stride, 1, norm="in", activation=activation, snorm=snorm)
+
+    def run(self, x, dtype):
+        res = self.res_conv.run(x, dtype) if self.convolve_res else x
+        return self.conv2.run(self.conv1.run(x, dtype), dtype, res=res)
+
+
+class Spade(_Cached):
+    """util.py:473-500.  gamma/beta depend on the start frame only: ``modulation`` is computed once per clip and
+    reused for every generated frame (the reference recomputes it T-1 times)."""
+
+    def __init__(self, ch, groups=16):
+        super().__init__()
+        while ch % groups != 0:
+            groups -= 1
+        self.groups, self.ch = groups, ch
+        self.conv = _Conv(3, 128, 3, 1, 1)
+        self.conv_gamma = _Conv(128, ch, 3, 1, 1)
+        self.conv_beta = _Conv(128, ch, 3, 1, 1)
+
+    def modulation(self, y_nchw, size, dtype):
+        N = y_nchw.shape[0]
+        ycl = K.bilinear_cl(y_nchw, size)                                     # fp32 [N*H*W, 3]
+        st = (size[0] * size[1] * 3, 1, 0, size[1] * 3, 3)
+        h = self.conv.run(None, dtype, act=_lib.ACT_LRELU02, src_f32=(ycl, N, 3, (1, size[0], size[1]), st))
+        return self.conv_gamma.run(h, dtype), self.conv_beta.run(h, dtype)
+
+    def run(self, x, mod, dtype):
+        return K.group_norm(x, self.groups, dtype, mod=mod)
+
+
+class SpadeCondConvDecoder(nn.Module):
+    """fully_conv_models.py:135-177: ``forward([h], start_frame) -> frame [B,3,H,W]``."""
+
+    def __init__(self, config, stacked_input=False, dtype="bf16"):
+        super().__init__()
+        ch = config["dec_channels"]
+        sn = config["spectral_norm"]
+        self.dtype = dtype
+        self.n_stages = len(ch) - 1
+        self.blocks = nn.ModuleList()
+        self.spade_blocks = nn.ModuleList()
+        self.in_block = ResBlock(2 * config["z_dim"] if stacked_input else config["z_dim"], ch[0], snorm=sn, norm=config["norm"])
+        for i, nf in enumerate(ch[1:]):
+            self.blocks.append(ResBlock(ch[i], nf, norm="none", upsampling=True, snorm=sn))
+            self.spade_blocks.append(Spade(nf))
+        self.out_conv = Conv2dBlock(ch[-1], config.get("out_channels", 3), 3, 1, 1, norm="none", activation="tanh")
+
+    def modulations(self, start_frame):
+        size = 8
+        mods = []
+        for sp in self.spade_blocks:
+            size *= 2
+            mods.append(sp.modulation(start_frame, (size, size), self.dtype))
+        return mods
+
+    def run(self, h, mods):
+        x = self.in_block.run(h, self.dtype)
+        for blk, sp, mod in zip(self.blocks, self.spade_blocks, mods):
+            x = sp.run(blk.run(x, self.dtype), mod, self.dtype)
+        y = self.out_conv.run(x, self.dtype, out_f32=True)                     # [M][3] fp32, tanh applied
+        return y.t.view(y.N, y.dhw[1], y.dhw[2], 3).permute(0, 3, 1, 2).contiguous()
+
+    @torch.no_grad()
+    def forward(self, actual_frame, start_frame, del_shape=True):
+        h = actual_frame.pop() if del_shape else actual_frame[-1]
+        return self.run(K.from_nchw(h, self.dtype), self.modulations(start_frame.float()))
+
+
+class ConvEncoder(nn.Module):
+    """fully_conv_models.py:28-94, deterministic variant: returns (bottleneck(out), out, None)."""
+
+    def __init__(self, nf_in, nf_max, n_stages, dtype="bf16"):
+        super().__init__()
+        self.dtype = dtype
+        nf = 32
+        blocks = [Conv2dBlock(nf_in, nf, 3, 2, 1, norm="group", activation="elu", snorm=True)]
+        for _ in range(n_stages - 1):
+            nxt = min(2 * nf, nf_max)
+            blocks.append(ResBlock(nf, nxt, stride=2, norm="group", activation="elu", snorm=True))
+            nf = nxt
+        self.model = nn.Sequential(*blocks)
+        self.bottleneck = nn.Sequential(ResBlock(nf, nf_max, activation="elu", norm="group"))
+        self.variational = False
+
+    @torch.no_grad()
+    def forward(self, x, sample_prior=False):
+        _lib.require_gpu()
+        x = x.float()
+        N, C, H, W = x.shape
+        first = self.model[0]
+        st = (x.stride(0), x.stride(1), 0, x.stride(2), x.stride(3))
+        h = first.norm.run(first.conv.run(None, self.dtype, src_f32=(x, N, C, (1, H, W), st)), self.dtype, act=_lib.ACT_ELU)
+        for blk in list(self.model)[1:]:
+            h = blk.run(h, self.dtype)
+        mean = h
+        out = self.bottleneck[0].run(h, self.dtype)
+        return K.to_nchw(out, self.dtype), K.to_nchw(mean, self.dtype), None
+
+
+class FirstStageWrapper(nn.Module):
+    """fully_conv_models.py:9-26.  Only the encoder half is on the hot path; decoder checkpoint keys are
+    accepted and ignored (``load_state_dict(strict=False)``)."""
+
+    def __init__(self, config, dtype="bf16"):
+        super().__init__()
+        self.config = config
+        arch = config["architecture"]
+        self.be_deterministic = arch["deterministic"]
+        if not self.be_deterministic:
+            raise NotImplementedError("the shipped poke / image encoders are deterministic")
+        n_stages = int(np.log2(config["data"]["spatial_size"][0] // arch["min_spatial_size"]))
+        nf_in = arch["nf_in"] + (3 if arch.get("poke_and_image", False) else 0)
+        self.encoder = ConvEncoder(nf_in, arch["nf_max"], n_stages, dtype=dtype)
+
+
+class SpadeCondMotionModel(nn.Module):
+    """first_stage_motion_model.py:469-522 (inference).  ``forward(X[B,T,3,H,W]) -> (X_hat, mu, logvar)``."""
+
+    def __init__(self, config, dirs=None, train=False, dtype="bf16"):
+        super().__init__()
+        if train:
+            raise NotImplementedError("first-stage *training* (GAN/VGG losses, backward of the VAE) is not part of this round")
+        self.config, self.dirs, self.dtype = config, dirs, dtype
+        arch = dict(config["architecture"])
+        self.full_sequence = bool(config["training"].get("full_sequence", False))
+        arch.update(img_size=config["data"]["spatial_size"][0], max_frames=config["data"]["max_frames"], full_seq=self.full_sequence)
+        self.use_motion_bias = bool(arch.get("motion_bias", False))
+        self.enc_motion = ResNetMotionEncoder(arch, dtype=dtype)
+        self.n_layers = arch["n_gru_layers"]
+        self.rnn = ConvGRU(arch["z_dim"], arch["z_dim"], 3, self.n_layers, dtype=dtype)
+        if self.use_motion_bias:
+            s = arch["min_spatial_size"]
+            self.motion_bias = nn.Parameter(torch.randn(1, arch["z_dim"], s, s))
+        self.gen = SpadeCondConvDecoder(arch, dtype=dtype)
+
+    @torch.no_grad()
+    def decode(self, motion, start_frame, length):
+        """GRU unroll + per-frame SPADE decoding (first_stage_motion_model.py:503-520, second_stage_video.py:361-382)."""
+        B = start_frame.shape[0]
+        dt = self.dtype
+        m = K.from_nchw(motion.float(), dt)
+        hidden = [m] * self.n_layers
+        if self.use_motion_bias:
+            in_rnn = K.from_nchw(self.motion_bias.detach().float().expand(B, -1, -1, -1).contiguous(), dt)
+        else:
+            in_rnn = m
+        mods = self.gen.modulations(start_frame.float())
+        frames = []
+        for _ in range(length):
+            hidden = self.rnn.run(in_rnn, hidden)
+            frames.append(self.gen.run(hidden[-1], mods))
+        return torch.stack(frames, dim=1)
+
+    @torch.no_grad()
+    def forward(self, X, eps=None):
+        X_in = X if self.full_sequence else X[:, 1:]
+        motion, mu, logvar = self.enc_motion(X_in.transpose(1, 2), eps=eps)
+        return self.decode(motion, X[:, 0], X.shape[1] - 1), mu, logvar

@@ -59,3 +59,14 @@ def mcf_shadows(sd, prefix, C, Cc, dtype):
     W2T = torch.zeros(d["Hr"], d["K3p"], device=v.device)
     W2T[:H, :2 * C] = weff.t()
     return dict(W1=W1, W1T=W1T, W2=W2, W2T=W2T.to(tdt(dtype)).contiguous(), bias=b, dims=d)
+
+
+def synthetic_batch(B, T, size, seed=1, device="cpu"):
+    """Same synthetic batch as oracle/make_goldens.py:synthetic_batch (SURVEY.md §8d inputs)."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(B, T, 3, size, size, generator=g) * 2 - 1
+    flow = torch.randn(B, 2, size, size, generator=g)
+    mask = (torch.rand(B, 1, size, size, generator=g) < 0.05).float()
+    poke = [torch.randn(B, 2, size, size, generator=g) * mask, torch.zeros(B, 5, 2, dtype=torch.int64)]
+    batch = {"images": images, "flow": flow, "poke": poke, "sample_ids": torch.zeros(B, T, dtype=torch.int64)}
+    return {k: ([p.to(device) for p in v] if isinstance(v, list) else v.to(device)) for k, v in batch.items()}

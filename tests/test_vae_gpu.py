@@ -1,0 +1,96 @@
+"""GPU parity of the first-stage VAE (encoder, ConvGRU, SPADE decoder, 2-D encoders) against the reference goldens."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from ipoke_amd import configs
+from ipoke_amd.utils.detfill import deterministic_fill_
+from tests.conftest import t
+
+pytestmark = pytest.mark.gpu
+# f32: exact-f32 matrix cores vs the reference's fp32 CPU run; bf16: 8-bit mantissa activations through ~20 conv+norm layers
+TOL = {"f32": 2e-4, "bf16": 6e-2}
+
+
+def first_stage(size, z, T, dtype):
+    from ipoke_amd.first_stage import SpadeCondMotionModel
+    m = SpadeCondMotionModel(configs.first_stage_config(size, z, T), dirs={}, train=False, dtype=dtype)
+    deterministic_fill_(m, prefix="first_stage.")
+    return m.to("cuda").eval()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_motion_encoder_64(golden, dtype):
+    g = golden("g4_encoder_64")
+    m = first_stage(64, 32, 16, dtype)
+    X, eps = t(g["X"], "cuda"), t(g["eps"], "cuda")
+    z, mu, lv = m.enc_motion(X.transpose(1, 2), eps=eps)
+    for name, got in (("mu", mu), ("logvar", lv), ("z", z)):
+        err = (got.cpu() - t(g[name])).abs().max().item()
+        print(f"encoder64[{dtype}] {name} err {err:.3e} (max |ref| {np.abs(g[name]).max():.2f})")
+        assert err <= TOL[dtype]
+
+
+def test_motion_encoder_128_f32(golden):
+    g = golden("g4_encoder_128")
+    m = first_stage(128, 32, 16, "f32")
+    X = torch.rand(1, 16, 3, 128, 128, generator=torch.Generator().manual_seed(int(g["X_seed"]))) * 2 - 1
+    z, mu, lv = m.enc_motion(X.cuda().transpose(1, 2), eps=torch.zeros(1, 32, 8, 8, device="cuda"))
+    assert (mu.cpu() - t(g["mu"])).abs().max().item() <= TOL["f32"]
+    assert (lv.cpu() - t(g["logvar"])).abs().max().item() <= TOL["f32"]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gru_and_spade_decoder_64(golden, dtype):
+    g = golden("g5_decoder_64")
+    m = first_stage(64, 32, 16, dtype)
+    z, x0 = t(g["z"], "cuda"), t(g["x0"], "cuda")
+    frames = m.decode(z, x0, 3)
+    diff = (frames.cpu() - t(g["frames"])).abs()
+    print(f"decoder64[{dtype}] frames max err {diff.max().item():.3e} mean err {diff.mean().item():.3e}")
+    assert frames.shape == (2, 3, 3, 64, 64)
+    # frames are tanh outputs in [-1, 1]; bf16: max error over 73k pixels after 12 GRU cells + 20 conv/norm layers
+    assert diff.max().item() <= (TOL["f32"] if dtype == "f32" else 0.12) and diff.mean().item() <= (1e-5 if dtype == "f32" else 1.2e-2)
+    # unit pieces
+    from ipoke_amd import nn as K
+    errs = {}
+    h0 = t(g["hidden_last"], "cuda")[:, 0]
+    ib = m.gen.in_block.run(K.from_nchw(h0, dtype), dtype)
+    def rel(got, key):        # the un-normalised upsampling blocks reach |x| ~ 1e5 with random weights: compare relative to range
+        ref = t(g[key])
+        return (K.to_nchw(got, dtype).cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    errs["in_block"] = rel(ib, "in_block")
+    tin = K.from_nchw(t(g["in_block"], "cuda"), dtype)
+    b0 = m.gen.blocks[0].run(tin, dtype)
+    errs["block0"] = rel(b0, "block0")
+    c1 = m.gen.blocks[0].conv1.run(tin, dtype)                                   # ConvTranspose + ("elu" -> ReLU)
+    errs["block0_conv1"] = rel(c1, "block0_conv1")
+    mods = m.gen.modulations(x0)
+    sp = m.gen.spade_blocks[0].run(K.from_nchw(t(g["block0"], "cuda"), dtype), mods[0], dtype)
+    errs["spade0"] = rel(sp, "spade0")
+    print(f"decoder64[{dtype}] unit errors {errs}")
+    assert all(v <= TOL[dtype] for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_glue_make_flow_input(golden, dtype):
+    """poke / image encoders + motion encoder as PokeMotionModel.make_flow_input chains them (G6)."""
+    from tests.helpers import synthetic_batch
+    g = golden("g6_glue_64")
+    from ipoke_amd.first_stage import FirstStageWrapper
+    pe = FirstStageWrapper(configs.encoder2d_config(64, 2), dtype=dtype)
+    ce = FirstStageWrapper(configs.encoder2d_config(64, 3), dtype=dtype)
+    deterministic_fill_(pe, prefix="poke_embedder."); deterministic_fill_(ce, prefix="conditioner.")
+    pe, ce = pe.cuda().eval(), ce.cuda().eval()
+    m = first_stage(64, 32, 16, dtype)
+    batch = synthetic_batch(2, 16, 64, device="cuda")
+    poke_emb, *_ = pe.encoder(batch["flow"])
+    cond, *_ = ce.encoder(batch["images"][:, 0])
+    z, mu, lv = m.enc_motion(batch["images"].transpose(1, 2), eps=t(g["eps"], "cuda"))
+    cond = torch.cat([cond, poke_emb], 1)
+    e1 = (cond.cpu() - t(g["cond"])).abs().max().item()
+    e2 = (z.cpu() - t(g["flow_input"])).abs().max().item()
+    print(f"glue[{dtype}] cond err {e1:.3e} flow_input err {e2:.3e}")
+    assert e1 <= TOL[dtype] * 2 and e2 <= TOL[dtype]
