@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Benchmark of the iPOKE second-stage train step on MI355X (BASELINE.json metric: video-frames/sec).
+
+    python bench.py --gpus 1 --steps K --warmup W            # one GPU
+    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...   # data parallel, one rank per GPU
+
+One *step* = the reference's second-stage optimisation step on one synthetic batch that is
+already resident in HBM: frozen poke/image/motion encoders (no grad) -> flow forward -> FlowLoss -> flow backward ->
+gradient all-reduce over RCCL (N > 1) -> fused Adam-amsgrad + weight-operand refresh.  Workload at N = 1 is
+BASELINE.json configs[1]: plants_128 (z = 64, 16 x 3 x 128 x 128 clips, per-GPU batch 20, bf16 matrix-core inputs).
+Rank 0 prints ONE JSON line; `value` is the whole-job frames/s (weak scaling: per-GPU batch fixed).
+
+Extra objects in the line:
+  roofline     -- the flow's dominant contraction (NICE 1x1 conv, a [B*64, 2048] x [2048, 2048] implicit GEMM) timed with
+                  HIP events on its own launches; algorithmic FLOPs / launch over the dense bf16 MFMA peak.
+  cpu_baseline -- the CPU oracle (oracle/, plain PyTorch fp32 restatement pinned to the reference's goldens) doing
+                  the same step on a bounded sample of the same workload, on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ipoke_amd import _lib, configs, dist as D, ops                      # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+FLOW_GFLOP = {32: 134.95304192, 64: 158.35070464}      # per sample forward
+ENC_GFLOP = {128: 82.96, 64: 20.52}
+
+
+def synthetic_batch(B, T, size, seed, device):
+    """SURVEY.md §8d synthetic inputs, generated on the host generator then moved to HBM before the timed region."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(B, T, 3, size, size, generator=g) * 2 - 1
+    flow = torch.randn(B, 2, size, size, generator=g)
+    mask = (torch.rand(B, 1, size, size, generator=g) < 0.05).float()
+    poke = [torch.randn(B, 2, size, size, generator=g) * mask, torch.zeros(B, 5, 2, dtype=torch.int64)]
+    batch = {"images": images, "flow": flow, "poke": poke, "sample_ids": torch.zeros(B, T, dtype=torch.int64)}
+    return {k: ([p.to(device) for p in v] if isinstance(v, list) else v.to(device)) for k, v in batch.items()}
+
+
+def build_model(cfg, dtype, device, seed=0):
+    from ipoke_amd.second_stage import PokeMotionModel
+    torch.manual_seed(seed)
+    conf = configs.second_stage_config(cfg["spatial_size"], cfg["z_dim"], cfg["n_frames"], cfg["batch_size"])
+    model = PokeMotionModel(conf, dirs={}, dtype=dtype, device=device, max_batch=cfg["batch_size"])
+    return model
+
+
+def randomise_couplings(model, seed=0):
+    """After the data-dependent init every coupling is the identity (zero-init weight norm).  Give the weight-norm
+    gains small non-zero values so that gradients, optimizer state and clocks are those of a model in training."""
+    g = torch.Generator(device=model.flow.flat_params.device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.flow.named_parameters():
+            if name.endswith("weight_g"):
+                p.copy_(0.02 + 0.01 * torch.rand(p.shape, device=p.device, generator=g))
+    model.flow.mark_weights_updated()
+
+
+def kernel_roofline(B, dtype, iters=50):
+    """Time the dominant GEMM ([B*64,2048] x [2048,2048]^T, 1x1 conv + ELU) on its own launches with HIP events."""
+    dev = "cuda"
+    hid, M = 2048, B * 64
+    td = ops.torch_dtype(dtype)
+    a = torch.randn(M, hid, device=dev).to(td)
+    w = (torch.randn(hid, hid, device=dev) / hid ** 0.5).to(td)
+    c = torch.empty(M, hid, device=dev, dtype=td)
+    d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    d.A = a.data_ptr(); d.a_sn = 64 * hid; d.a_sh = 8 * hid; d.a_sw = hid; d.a_sc = 1; d.Kc_real = hid; d.Kc = hid
+    d.W = w.data_ptr(); d.ldw = hid; d.Nout = hid; d.act = _lib.ACT_ELU; d.C = c.data_ptr(); d.ldc = hid
+    for _ in range(5):
+        ops.conv_forward(d, dtype)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                       # recorded on the current stream == the stream the kernel is launched on
+    for _ in range(iters):
+        ops.conv_forward(d, dtype)
+    e1.record()
+    torch.cuda.synchronize()
+    avg_s = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = 2.0 * M * hid * hid
+    achieved = flops / avg_s / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "igemm_nt (NICE conv2 1x1, M=%d N=K=2048, %s)" % (M, dtype), "avg_launch_us": round(avg_s * 1e6, 2),
+            "algorithmic_gflop_per_launch": round(flops / 1e9, 3)}
+
+
+def cpu_baseline(cfg, clips=1, seed=1):
+    """The CPU oracle doing the same optimisation step on `clips` clips of the same workload (bounded sample)."""
+    from oracle import flow_ref, vae_ref
+    from ipoke_amd.utils.detfill import deterministic_fill_
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    size, z, T = cfg["spatial_size"], cfg["z_dim"], cfg["n_frames"]
+    t_build = time.time()
+    fs = vae_ref.SpadeCondMotionModel(configs.first_stage_config(size, z, T)).eval()
+    pe = vae_ref.FirstStageWrapper(configs.encoder2d_config(size, 2)).eval()
+    ce = vae_ref.FirstStageWrapper(configs.encoder2d_config(size, 3)).eval()
+    flow = flow_ref.SupervisedMacowTransformer(configs.flow_arch(z))
+    for m, pfx in ((fs, "first_stage."), (pe, "poke_embedder."), (ce, "conditioner.")):
+        deterministic_fill_(m, prefix=pfx)
+    with torch.no_grad():
+        for k, v in flow.state_dict().items():      # cheap stable init: identity couplings, initialised flags
+            if k.endswith("initialized"):
+                v.fill_(1)
+            elif k.endswith(("weight_g", "bias")):
+                v.zero_()
+            elif k.endswith("log_scale"):
+                v.zero_()
+    opt = torch.optim.Adam(flow.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5, amsgrad=True)
+    loss_fn = flow_ref.FlowLoss()
+    batch = synthetic_batch(clips, T, size, seed, "cpu")
+    t_build = time.time() - t_build
+    t0 = time.time()
+    with torch.no_grad():
+        poke_emb, *_ = pe.encoder(batch["flow"])
+        cond, *_ = ce.encoder(batch["images"][:, 0])
+        motion, mu, _ = fs.enc_motion(batch["images"].transpose(1, 2))
+    opt.zero_grad()
+    out, logdet = flow(motion.detach(), torch.cat([cond, poke_emb], 1))
+    loss, _ = loss_fn(out, logdet)
+    loss.backward()
+    opt.step()
+    dt = time.time() - t0
+    return {"value": round(clips * T / dt, 4), "unit": "video-frames/sec", "cores": ncores, "kind": "port",
+            "sample": f"{clips} clip(s) of the same workload (16x3x{size}x{size}, z={z}): encoders + flow fwd + FlowLoss + bwd + "
+                      f"Adam-amsgrad, oracle/ PyTorch fp32 CPU, one step = {dt:.1f}s (model build {t_build:.0f}s untimed)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=1)
+    args = ap.parse_args()
+
+    _lib.require_gpu()
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    cfg = dict(configs.BENCH_CONFIGS[args.config])
+    if args.batch:
+        cfg["batch_size"] = args.batch
+    B, T, size, z = cfg["batch_size"], cfg["n_frames"], cfg["spatial_size"], cfg["z_dim"]
+
+    from ipoke_amd.trainer import SecondStageTrainer
+    model = build_model(cfg, args.dtype, device)
+    trainer = SecondStageTrainer(model)
+    batch = synthetic_batch(B, T, size, seed=1 + rank, device=device)
+    trainer.sync_initial_state(batch)                 # data-dependent init on rank 0's statistics, then broadcast
+    randomise_couplings(model)
+    for i in range(args.warmup):
+        trainer.train_step(batch, i)
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.train_step(batch, args.warmup + i)
+    torch.cuda.synchronize(); D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    loss_val = float(loss.item())
+    ms = elapsed / args.steps * 1e3
+    frames = world * B * T
+    value = frames / (elapsed / args.steps)
+
+    if rank == 0:
+        roof = kernel_roofline(B, args.dtype)
+        P_bytes = model.flow.engine.n_params * 4
+        step_tflop = B * (3 * FLOW_GFLOP[z] + ENC_GFLOP[size] + 0.47) / 1e3
+        line = {
+            "metric": "video-frames/sec (second-stage train step)", "value": round(value, 2), "unit": "video-frames/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{cfg['name']} second_stage train, {T}x3x{size}x{size} clips, z={z}, flow 2048 hidden "
+                                   f"({model.flow.engine.n_params / 1e9:.3f} B params), per-GPU batch {B}",
+                       "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
+                       "weights": "random init of the named architecture (no checkpoints offline)"},
+            "loss": round(loss_val, 3),
+            "algorithmic_tflop_per_step_per_gpu": round(step_tflop, 2),
+            "step_mfma_frac": round(step_tflop / (ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4),
+            "step_hbm_frac_12P": round(12 * P_bytes / (ms * 1e-3) / 8e12, 4),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, clips=args.cpu_clips)
+        print(json.dumps(line), flush=True)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

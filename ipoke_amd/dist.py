@@ -1,0 +1,63 @@
+"""Data-parallel helpers: one process per GPU, torch.distributed over RCCL ("nccl" backend on ROCm) / gloo on CPU.
+
+The flow's gradients live in ONE flat fp32 buffer, so the gradient exchange of a step (N1 in SURVEY.md: 4.2-4.95 GB)
+is a handful of large all-reduces over contiguous slices instead of DDP's ~200 25-MB buckets; xGMI is
+point-to-point, large messages keep every link busy.  The mean is folded into the fused Adam step (grad_scale).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def allreduce_flat_(flat, n_buckets=8):
+    """Sum ``flat`` (1-D tensor) over all ranks in ``n_buckets`` large, 16-byte aligned slices issued back to back."""
+    if world_size() == 1:
+        return flat
+    n = flat.numel()
+    step = -(-n // n_buckets)
+    step = -(-step // 4) * 4
+    works = []
+    for lo in range(0, n, step):
+        works.append(dist.all_reduce(flat[lo:min(n, lo + step)], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+    return flat
+
+
+def broadcast_(t, src=0):
+    if world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

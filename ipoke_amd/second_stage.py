@@ -1,0 +1,218 @@
+"""``PokeMotionModel``: the second-stage module of iPOKE with the reference's call surface
+(models/second_stage_video.py:31-452, 632-662) on the HIP flow engine and the HIP first-stage VAE.
+
+The reference class is a LightningModule whose ``__init__(config, dirs)`` loads three checkpoints from
+``logs/...``; Lightning and those files do not exist here, so this is a plain ``nn.Module`` that keeps the
+Lightning method names (``training_step``, ``configure_optimizers``, ``on_train_batch_start`` ...) and takes
+the three sub-model configurations from ``config['first_stage']``, ``config['poke_embedder']`` and
+``config['conditioner_model']`` (dictionaries with the reference's YAML keys).  Checkpoints are loaded with
+``load_first_stage / load_poke_embedder / load_conditioner`` which mirror ``__initialize_*`` (:182-236).
+``ipoke_amd.trainer.SecondStageTrainer`` is the loop that drives it (the counterpart of pl.Trainer.fit).
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .first_stage import FirstStageWrapper, SpadeCondMotionModel
+from .flow import SupervisedMacowTransformer
+from .loss import FlowLoss
+from .optim import FusedAdamAmsgrad
+
+
+def linear_var(act_it, start_it, end_it, start_val, end_val, clip_min, clip_max):
+    """utils/general.py:221-228."""
+    act_val = float(end_val - start_val) / (end_it - start_it) * (act_it - start_it) + start_val
+    return float(np.clip(act_val, a_min=clip_min, a_max=clip_max))
+
+
+class PokeMotionModel(nn.Module):
+    def __init__(self, config, dirs=None, dtype="bf16", device=None, max_batch=None):
+        super().__init__()
+        self.config = config
+        self.dirs = dirs or {}
+        self.dtype = dtype
+        self.embed_poke = True
+        self.test_mode = config["general"].get("test", "none")
+        tr = config["training"]
+        self.spatial_mean_for_loss = bool(tr.get("spatial_mean", False))
+        logdet_weight = config["logdet_weight"] if "logdet_weight" in config else 1.0      # looked up at top level (:41)
+        if tr.get("adabelief", False):
+            raise NotImplementedError("AdaBelief can never be selected by shipped configs (key mismatch, SURVEY §2 row 4b)")
+        self.n_test_samples = config["testing"]["n_samples_per_data_point"]
+        self.global_step = 0
+        self.current_epoch = 0
+        self._optimizer = None
+        self.device_ = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+        lr = tr["lr"]
+        self.apply_lr_scaling = bool(tr.get("lr_scaling", False))
+        if self.apply_lr_scaling:
+            self.lr_scaling = partial(linear_var, start_it=0, end_it=tr["lr_scaling_max_it"], start_val=0.0, end_val=lr,
+                                      clip_min=0.0, clip_max=lr)
+        self.custom_lr_decrease = tr["custom_lr_decrease"]
+        if self.custom_lr_decrease:
+            self.lr_adaptation = partial(linear_var, start_it=tr["lr_scaling_max_it"], start_val=lr, end_val=0.0, clip_min=0.0,
+                                         clip_max=lr)
+            # on_train_epoch_start (:317-323): end_it = n_epochs * num_training_batches (capped at max_batches_per_epoch)
+            self._lr_end_it = tr["n_epochs"] * tr.get("max_batches_per_epoch", 2000)
+
+        # frozen first-stage model, poke embedder, conditioner
+        self.first_stage_config = config["first_stage"]
+        self.first_stage_model = SpadeCondMotionModel(self.first_stage_config, dirs=self.dirs, train=False, dtype=dtype)
+        self.full_seq = bool(tr.get("full_seq", False))
+        self.use_cond = config["conditioner"].get("use", True)
+        self.poke_emb_config = config["poke_embedder"]
+        self.poke_embedder = FirstStageWrapper(self.poke_emb_config, dtype=dtype)
+        if self.use_cond:
+            self.conditioner_config = config["conditioner_model"]
+            self.conditioner = FirstStageWrapper(self.conditioner_config, dtype=dtype)
+        arch = config["architecture"]
+        self.augment_input = bool(arch.get("augmented_input", False))
+        if self.augment_input:
+            raise NotImplementedError("augmented_input is off in every shipped config")
+        arch["flow_in_channels"] = self.first_stage_config["architecture"]["z_dim"]
+        pe_arch = self.poke_emb_config["architecture"]
+        self.embed_poke_and_image = bool(pe_arch.get("poke_and_image", False))
+        self.poke_key = "flow" if pe_arch.get("flow_ae", False) else "poke"
+        assert not (self.poke_key == "flow" and self.embed_poke_and_image)
+        arch["h_channels"] = pe_arch["nf_max"] + (self.conditioner_config["architecture"]["nf_max"] if self.use_cond else 0)
+        arch["flow_mid_channels"] = int(arch["flow_mid_channels_factor"] * arch["flow_in_channels"])
+        arch["ssize"] = pe_arch["min_spatial_size"]
+        fs_min = self.first_stage_config["architecture"]["min_spatial_size"]
+        self.adapt_poke_emb_ssize = pe_arch["min_spatial_size"] != fs_min
+        self.adapt_cond_ssize = self.use_cond and self.conditioner_config["architecture"]["min_spatial_size"] != fs_min
+        if self.adapt_poke_emb_ssize or self.adapt_cond_ssize:
+            raise NotImplementedError("adapt_*_ssize convolutions are off in every shipped config (all latents are 8x8)")
+        if arch.get("multistack", False):
+            raise NotImplementedError("multistack flows are outside the shipped configs")
+        mb = max_batch if max_batch is not None else max(config["data"]["batch_size"], 1)
+        self.first_stage_model.to(self.device_); self.poke_embedder.to(self.device_)
+        if self.use_cond:
+            self.conditioner.to(self.device_)
+        self.flow = SupervisedMacowTransformer(arch, dtype=dtype, max_batch=mb, device=self.device_)
+        self.loss_func = FlowLoss(spatial_mean=self.spatial_mean_for_loss, logdet_weight=logdet_weight)
+        self.logged = {}
+
+    # ---- Lightning-compatible no-ops ---------------------------------------------------------------
+    def log(self, name, value, **kw):
+        self.logged[name] = value
+
+    def log_dict(self, d, **kw):
+        self.logged.update(d)
+
+    def optimizers(self):
+        return self._optimizer
+
+    # ---- checkpoints (second_stage_video.py:182-236) -----------------------------------------------
+    @staticmethod
+    def _sd(path_or_sd):
+        sd = torch.load(path_or_sd, map_location="cpu") if isinstance(path_or_sd, str) else path_or_sd
+        return sd["state_dict"] if "state_dict" in sd else sd
+
+    def load_first_stage(self, ckpt):
+        self.first_stage_model.load_state_dict(self._sd(ckpt), strict=False)
+        self.first_stage_model.enc_motion.conv1.invalidate()
+
+    def load_poke_embedder(self, ckpt):
+        sd = self._sd(ckpt)
+        sd = {".".join(k.split(".")[1:]): v for k, v in sd.items() if "encoder" in k or "decoder" in k}
+        self.poke_embedder.load_state_dict(sd, strict=False)
+
+    def load_conditioner(self, ckpt):
+        sd = {k: v for k, v in self._sd(ckpt).items() if "encoder" in k or "decoder" in k}
+        self.conditioner.load_state_dict(sd, strict=False)
+
+    # ---- LR rule (:238-253) ---------------------------------------------------------------------------
+    def on_train_epoch_start(self, num_training_batches=None):
+        if self.custom_lr_decrease and num_training_batches is not None:
+            self._lr_end_it = self.config["training"]["n_epochs"] * num_training_batches
+
+    def on_train_batch_start(self, batch, batch_idx, dataloader_idx=0):
+        max_it = self.config["training"]["lr_scaling_max_it"]
+        opt = self.optimizers()
+        if self.apply_lr_scaling and self.global_step < max_it:
+            lr = self.lr_scaling(self.global_step)
+            self.log("learning_rate", lr)
+            for pg in opt.param_groups:
+                pg["lr"] = lr
+        if self.custom_lr_decrease and self.global_step >= max_it:
+            lr = self.lr_adaptation(self.global_step, end_it=self._lr_end_it)
+            for pg in opt.param_groups:
+                pg["lr"] = lr
+
+    # ---- hot path ---------------------------------------------------------------------------------------
+    def make_flow_input(self, batch, reverse=False, use_kp_poke=False):
+        X = batch["images"]
+        if use_kp_poke:
+            poke, *_ = batch["keypoint_poke"]
+            poke = poke.to(torch.float)
+        else:
+            poke = batch[self.poke_key]
+            poke = poke[0] if isinstance(poke, list) else poke
+        if self.embed_poke_and_image:
+            poke = torch.cat([poke, X[:, 0]], dim=1)
+        self.first_stage_model.eval(); self.poke_embedder.eval()
+        with torch.no_grad():
+            poke_emb, *_ = self.poke_embedder.encoder(poke)
+            if self.use_cond:
+                cond, *_ = self.conditioner.encoder(X[:, 0])
+        if reverse:
+            spatial = self.first_stage_config["architecture"]["min_spatial_size"]
+            # CPU generator, then moved: torch.randn(...).type_as(X) (:296-300)
+            flow_input = torch.randn((X.size(0), self.config["architecture"]["flow_in_channels"], spatial, spatial)).type_as(X).detach()
+        else:
+            with torch.no_grad():
+                flow_input, *_ = self.encode_first_stage(X)
+        cond = torch.cat([cond, poke_emb], dim=1) if self.use_cond else poke_emb
+        return flow_input, cond
+
+    def encode_first_stage(self, X):
+        with torch.no_grad():
+            if self.full_seq:
+                X_in = X if self.first_stage_model.full_sequence or self.config["data"]["max_frames"] < 16 else X[:, :-1]
+            else:
+                X_in = X if self.first_stage_model.full_sequence else X[:, 1:]
+            motion, mu, cov = self.first_stage_model.enc_motion(X_in.transpose(1, 2))
+        return motion, mu
+
+    def decode_first_stage(self, motion, X, length=None):
+        if length is None:
+            length = X.size(1) - 1
+        return self.first_stage_model.decode(motion, X[:, 0], length)
+
+    def forward_density(self, batch):
+        flow_input, cond = self.make_flow_input(batch)
+        out, logdet = self.flow(flow_input.detach(), cond, reverse=False)
+        return out, logdet
+
+    def forward_sample(self, batch, n_samples=1, n_logged_vids=1, show_progress=False, add_first_frame=False,
+                       use_keypoint_pokes=False):
+        video_samples = []
+        with torch.no_grad():
+            X = batch["images"]
+            for _ in range(n_samples):
+                flow_input, cond = self.make_flow_input(batch, reverse=True, use_kp_poke=use_keypoint_pokes)
+                out_motion = self.flow(flow_input, cond, reverse=True)
+                out_video = self.decode_first_stage(out_motion, X)
+                if add_first_frame:
+                    out_video = torch.cat([X[:, 0].unsqueeze(1), out_video], dim=1)
+                video_samples.append(out_video[:n_logged_vids].cpu())
+        return video_samples
+
+    def training_step(self, batch, batch_idx):
+        out, logdet = self.forward_density(batch)
+        loss, loss_dict = self.loss_func(out, logdet)
+        self.log_dict(loss_dict)
+        self.log("global_step", self.global_step)
+        if self._optimizer is not None:
+            self.log("learning_rate", self._optimizer.param_groups[0]["lr"])
+        return loss
+
+    def configure_optimizers(self):
+        tr = self.config["training"]
+        self._optimizer = FusedAdamAmsgrad(self.flow, lr=tr["lr"], betas=(0.9, 0.999), weight_decay=tr["weight_decay"], amsgrad=True)
+        if not self.custom_lr_decrease:
+            raise NotImplementedError("the shipped configs use custom_lr_decrease=True (no scheduler object)")
+        return [self._optimizer]
