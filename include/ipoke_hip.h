@@ -84,6 +84,8 @@ typedef struct {
 } ipoke_conv_desc;
 
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
+/* n back-to-back native launches of the same convolution (kernel timing without host round trips) */
+int ipoke_conv_forward_repeat(const ipoke_conv_desc* d, int dtype, int n, void* stream);
 
 /* Weight gradient: dW[n][tap*Kc + c] (+)= sum_m dY[m][n] * A[src(m,tap)][c].
  * dY is dtype [M][ldy]; A as in ipoke_conv_desc (fp32 or dtype).  Output fp32, written through a

@@ -77,6 +77,7 @@ SIGNATURES = {
     "ipoke_version": (c_int, []),
     "ipoke_dtype_size": (c_int, [c_int]),
     "ipoke_conv_forward": (c_int, [POINTER(ConvDesc), c_int, _P]),
+    "ipoke_conv_forward_repeat": (c_int, [POINTER(ConvDesc), c_int, c_int, _P]),
     "ipoke_conv_wgrad": (c_int, [POINTER(WgradDesc), c_int, _P]),
     "ipoke_nchw_to_state": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_state_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

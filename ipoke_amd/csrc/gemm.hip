@@ -31,7 +31,7 @@ struct NtParams {
   const void* W; int ldw; int Nout; int Ktot;
   const float* bias; int act; const void* dact; int ld_dact, dact_act;
   void* C; int c_f32, c_acc; long ldc; int c_coff, c_cstride;
-  int splitk, kb_per_split, n_pad;
+  int splitk, kb_per_split, n_pad, ablate;
   int tiles_m, tiles_n, xa, xb;
 };
 
@@ -112,6 +112,111 @@ __device__ __forceinline__ void fill_taptab(int* tab, const GeomDev& g) {
   }
 }
 
+template <typename T> struct Pack4;     // 4 consecutive outputs of the compute dtype
+template <> struct Pack4<bf16_t> { typedef __attribute__((ext_vector_type(4))) __bf16 type; };
+template <> struct Pack4<float> { typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ float fast_act(int act, float x) {
+  // bf16 outputs carry 8 mantissa bits: the hardware exp is more than accurate enough for ELU there
+  if (sizeof(T) == 2 && act == IPOKE_ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;
+  return act_apply(act, x);
+}
+
+// Epilogue.  The accumulator tile is first parked in LDS (the operand ring is dead by now) and then swept by a
+// compact, non-unrolled loop in which consecutive lanes own consecutive 4-column groups of a row: bias /
+// activation / derivative-mask are applied once per group and the stores are full-width, row-contiguous.
+// (An epilogue unrolled over the 16 register fragments costs more in instruction-cache misses than the whole
+// K loop of the small GEMMs of the flow.)
+// acc[i][j][r] = C[m0 + wm*MREP*16 + 16i + (lane&15)][n0 + wn*NREP*16 + 16j + 4*(lane>>4) + r]
+template <typename T, int WM, int WN, int MREP, int NREP>
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP][NREP], unsigned char* smem, int m0, int n0,
+                                            int wm, int wn, int z) {
+  typedef typename Pack4<T>::type pack_t;
+  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
+  constexpr int EP = BN * 4 + 16;                      // staging pitch in bytes
+  const GeomDev& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  __syncthreads();
+  {
+    unsigned char* base = smem + (wm * MREP * 16 + (lane & 15)) * EP + (wn * NREP * 16 + (lane >> 4) * 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(base + i * 16 * EP + j * 64) = acc[i][j];
+  }
+  __syncthreads();
+  const bool vec_ok = (p.Nout & 3) == 0;                 // 4-wide groups never straddle Nout
+  constexpr int G4 = BN / 4;
+  for (int idx = tid; idx < BM * G4; idx += blockDim.x) {
+    const int row = idx / G4, c4 = idx - row * G4;
+    const int m = m0 + row, n = n0 + 4 * c4;
+    if (m >= g.M || n >= p.n_pad) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * EP + c4 * 16);
+    if (p.splitk > 1) {
+      if (p.c_acc) {          // K slices added atomically into an fp32 tensor that already holds a value
+        float* Cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + p.c_coff;
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.Nout) atomicAdd(Cp + (long)(n + r) * p.c_cstride, v[r]);
+      } else {
+        float* P = reinterpret_cast<float*>(p.C) + ((long)z * g.M + m) * p.ldc + n;
+        if (n + 3 < p.ldc) *reinterpret_cast<f32x4*>(P) = v;    // ldc is padded to a multiple of 4
+        else for (int r = 0; r < 4; ++r) if (n + r < p.ldc) P[r] = v[r];
+      }
+      continue;
+    }
+    const bool full = vec_ok && n + 3 < p.Nout;
+    if (p.bias) {
+      if (full) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      else for (int r = 0; r < 4; ++r) if (n + r < p.Nout) v[r] += p.bias[n + r];
+    }
+    if (p.act != IPOKE_ACT_NONE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fast_act<T>(p.act, v[r]);
+    }
+    if (p.dact) {
+      const T* dp = reinterpret_cast<const T*>(p.dact) + (long)m * p.ld_dact + n;
+      if (full && (p.ld_dact & 3) == 0) {
+        const pack_t y = *reinterpret_cast<const pack_t*>(dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(p.dact_act, ET<T>::to_f32(y[r]));
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.Nout) v[r] *= act_grad_from_out(p.dact_act, ET<T>::to_f32(dp[r]));
+      }
+    }
+    if (!full) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n + r >= p.Nout) v[r] = 0.f;
+    }
+    if (p.c_f32) {
+      float* Cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + p.c_coff;
+      if (full && p.c_cstride == 1 && !p.c_acc && ((p.ldc | p.c_coff) & 3) == 0) {
+        *reinterpret_cast<f32x4*>(Cp + n) = v;
+      } else {
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.Nout) {
+            float* q = Cp + (long)(n + r) * p.c_cstride;
+            *q = p.c_acc ? *q + v[r] : v[r];
+          }
+        }
+      }
+    } else {
+      T* Cp = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + p.c_coff + n;
+      // columns up to n_pad are written (zero beyond Nout) so that consumers can read a padded K
+      if (n + 3 < p.n_pad && ((p.ldc | p.c_coff) & 3) == 0) {
+        pack_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = ET<T>::from_f32(v[r]);
+        *reinterpret_cast<pack_t*>(Cp) = o;
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.n_pad) Cp[r] = ET<T>::from_f32(v[r]);
+      }
+    }
+  }
+}
+
 // =============================================================================================
 template <typename T, int WM, int WN, int MREP, int NREP>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
@@ -124,7 +229,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
   unsigned char* sB = smem + 2 * BM * kPitch;
-  int* taptab = reinterpret_cast<int*>(smem + 2 * (BM + BN) * kPitch);
+  constexpr int kRing = 2 * (BM + BN) * kPitch > BM * (BN * 4 + 16) ? 2 * (BM + BN) * kPitch : BM * (BN * 4 + 16);
+  int* taptab = reinterpret_cast<int*>(smem + kRing);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -243,64 +349,207 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     }
   }
 
-  // ---------------- epilogue ----------------
-  const int mrow = m0 + wm * MREP * 16 + (lane & 15);
-  const int ncol = n0 + wn * NREP * 16 + (lane >> 4) * 4;
+  nt_epilogue<T, WM, WN, MREP, NREP>(p, acc, smem, m0, n0, wm, wn, z);
+}
+
+// =============================================================================================
+// Multi-stage LDS-DMA variant of igemm_nt for activations already in the compute dtype.
+// Tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging) into an NSTAGE-deep ring, so
+// (NSTAGE-1) K-blocks of loads are in flight while one is consumed: the small-M GEMMs of the flow give
+// each CU a single workgroup, and this depth is what hides the L2/HBM latency.  The DMA destination is
+// lane-linear (8 lanes = one 128-byte row), so bank conflicts are avoided by permuting the SOURCE
+// chunk: LDS position p of row r holds K-chunk p ^ ((r >> 1) & 7); fragment reads apply the same XOR.
+// Waits are counted (s_waitcnt vmcnt(N)) and barriers are raw s_barrier so that loads survive them.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE>
+__global__ __launch_bounds__(256) void igemm_nt_glds_kernel(const NtParams p) {
+  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
+  constexpr int E16 = ET<T>::E16;
+  constexpr int BK = 128 / (int)sizeof(T);
+  constexpr int A_IT = (BM * 8 + 255) / 256, B_IT = (BN * 8 + 255) / 256, L = A_IT + B_IT;
+  constexpr int SUB = (BM + BN) * 128;            // one K-block of both operands
+  constexpr int STAGE = KPB * SUB;                // ring slot: KPB K-blocks are consumed per barrier
+  static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must fill whole DMA instructions");
+  static_assert((NSTAGE - 2) * L * KPB <= 63, "vmcnt field");
+  typedef typename ET<T>::frag frag_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* dummy = smem + NSTAGE * STAGE;                         // 4 KB: landing zone of padding DMAs
+  int* taptab = reinterpret_cast<int*>(smem + NSTAGE * STAGE + 4096);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const GeomDev& g = p.g;
+  int tm, tn;
+  {
+    const int bid = blockIdx.x;
+    if (p.xa > 0) {
+      const int xcd = bid & 7, q = bid >> 3;
+      const int sub_m = p.tiles_m / p.xa, sub_n = p.tiles_n / p.xb;
+      tm = (xcd % p.xa) * sub_m + q % sub_m;
+      tn = (xcd / p.xa) * sub_n + q / sub_m;
+    } else {
+      tm = bid % p.tiles_m; tn = bid / p.tiles_m;
+    }
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int nkb_total = (p.Ktot + BK - 1) / BK;
+  const int kb_begin = z * p.kb_per_split;
+  const int kb_end = min(nkb_total, kb_begin + p.kb_per_split);
+
+  fill_taptab(taptab, g);
+
+  // Per-chunk source bookkeeping.  SIMPLE (Kc a multiple of the K-block, no channel padding): a K-block lies in
+  // ONE tap for every chunk, so the loop only adds BK to 32-bit element offsets and re-derives input positions on
+  // the (wave-uniform, rare) tap change.  General: per-chunk tap tracking.  Host guarantees offsets < 2^31.
+  constexpr unsigned kInvalid = 0xffffffffu;
+  RowPos arow[A_IT]; int a_tap[A_IT], a_c[A_IT]; unsigned a_off[A_IT]; bool a_in[A_IT];
+  auto a_resolve = [&](int i) {
+    unsigned off = kInvalid;
+    if (arow[i].ok && a_tap[i] < g.taps && a_c[i] < p.Kc_real) {
+      int id, ih, iw;
+      if (tap_coords(g, arow[i], taptab[a_tap[i]], id, ih, iw))
+        off = (unsigned)(arow[i].nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw + p.a_coff + a_c[i]);
+    }
+    a_off[i] = off;
+  };
 #pragma unroll
-  for (int i = 0; i < MREP; ++i) {
-    const int m = mrow + i * 16;
-    if (m >= g.M) continue;
+  for (int i = 0; i < A_IT; ++i) {
+    const int ch = tid + 256 * i;
+    const int row = ch >> 3, pos = ch & 7;
+    a_in[i] = row < BM;
+    arow[i] = decode_row(g, m0 + row, p.a_sn);
+    arow[i].ok = arow[i].ok && a_in[i];
+    const int kglob = kb_begin * BK + (pos ^ ((row >> 1) & 7)) * E16;
+    a_tap[i] = kglob / p.Kc;
+    a_c[i] = kglob - a_tap[i] * p.Kc;
+  }
+  unsigned b_off[B_IT]; int b_k[B_IT]; bool b_in[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int ch = tid + 256 * i;
+    const int row = ch >> 3, pos = ch & 7;
+    b_in[i] = row < BN;
+    b_k[i] = kb_begin * BK + (pos ^ ((row >> 1) & 7)) * E16;
+    b_off[i] = (row < BN && n0 + row < p.Nout) ? (unsigned)((long)(n0 + row) * p.ldw + b_k[i]) : kInvalid;
+  }
+  __syncthreads();   // taptab ready (nothing in flight yet)
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) a_resolve(i);
+
+  const T* Abase = reinterpret_cast<const T*>(p.A);
+  const T* Wbase = reinterpret_cast<const T*>(p.W);
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+  int c_uni = (kb_begin * BK) % p.Kc;             // SIMPLE: channel offset of the K-block inside its tap (uniform)
+  auto issue = [&](int slot_bytes, bool real) {
+    unsigned char* sa = smem + slot_bytes;
+    if (!real) {                                   // keep the vmcnt bookkeeping uniform past the last K-block
+#pragma unroll
+      for (int i = 0; i < L; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void*)zero, (lds_void*)(dummy + wave * 1024), 16, 0, 0);
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const T* src = a_off[i] != kInvalid ? Abase + a_off[i] : zero;
+      unsigned char* dst = (wave * 64 + 256 * i) < BM * 8 ? sa + (wave * 64 + 256 * i) * 16 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const T* src = (b_off[i] != kInvalid && (SIMPLE || b_k[i] < p.ldw)) ? Wbase + b_off[i] : zero;
+      unsigned char* dst = (wave * 64 + 256 * i) < BN * 8 ? sa + BM * 128 + (wave * 64 + 256 * i) * 16 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+      if (!SIMPLE) b_k[i] += BK;
+      if (b_off[i] != kInvalid) b_off[i] += BK;
+    }
+    if (SIMPLE) {
+      c_uni += BK;
+      if (c_uni >= p.Kc) {                          // uniform: every chunk enters the next tap together
+        c_uni = 0;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) { ++a_tap[i]; a_c[i] -= p.Kc - BK; a_resolve(i); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) { a_c[i] += BK; if (a_off[i] != kInvalid) a_off[i] += BK; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        a_c[i] += BK;
+        while (a_c[i] >= p.Kc) { a_c[i] -= p.Kc; ++a_tap[i]; }
+        a_resolve(i);
+      }
+    }
+  };
+
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // loop-invariant LDS offsets of this lane's fragments (XOR swizzle folded in)
+  int a_rd[MREP][2], b_rd[NREP][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int q = s * 4 + (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+      const int row = wm * MREP * 16 + i * 16 + (lane & 15);
+      a_rd[i][s] = row * 128 + ((q ^ ((row >> 1) & 7)) * 16);
+    }
 #pragma unroll
     for (int j = 0; j < NREP; ++j) {
-      const int n = ncol + j * 16;
-      if (n >= p.n_pad) continue;
-      f32x4 v = acc[i][j];
-      if (p.splitk > 1 && p.c_acc) {       // K slices added atomically into an fp32 tensor that already holds a value
-        float* Cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + p.c_coff;
+      const int row = wn * NREP * 16 + j * 16 + (lane & 15);
+      b_rd[j][s] = BM * 128 + row * 128 + ((q ^ ((row >> 1) & 7)) * 16);
+    }
+  }
+  int kb_issue = kb_begin;                        // next K-block to be requested
+  auto issue_slot = [&](int slot) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.Nout) atomicAdd(Cp + (long)(n + r) * p.c_cstride, v[r]);
-        continue;
-      }
-      if (p.splitk > 1) {
-        float* P = reinterpret_cast<float*>(p.C) + ((long)z * g.M + m) * p.ldc + n;
-        if (n + 3 < p.ldc) *reinterpret_cast<f32x4*>(P) = v;    // ldc is padded to a multiple of 4
-        else for (int r = 0; r < 4; ++r) if (n + r < p.ldc) P[r] = v[r];
-        continue;
-      }
+    for (int u = 0; u < KPB; ++u) { issue(slot * STAGE + u * SUB, kb_issue < kb_end); ++kb_issue; }
+  };
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = v[r];
-        if (n + r < p.Nout) {
-          if (p.bias) x += p.bias[n + r];
-          x = act_apply(p.act, x);
-          if (p.dact) {
-            const float y = ET<T>::to_f32(reinterpret_cast<const T*>(p.dact)[(long)m * p.ld_dact + n + r]);
-            x *= act_grad_from_out(p.dact_act, y);
-          }
-        } else {
-          x = 0.f;
-        }
-        v[r] = x;
-      }
-      if (p.c_f32) {
-        float* Cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + p.c_coff;
+  for (int s = 0; s < NSTAGE - 1; ++s) issue_slot(s);
+
+  auto load_frags = [&](const unsigned char* sub, int hs, frag_t* fa, frag_t* fb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r < p.Nout) {
-            float* q = Cp + (long)(n + r) * p.c_cstride;
-            *q = p.c_acc ? *q + v[r] : v[r];
-          }
-        }
-      } else {
-        T* Cp = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + p.c_coff + n;
-        // columns up to n_pad are written (zero beyond Nout) so that consumers can read a padded K
+    for (int i = 0; i < MREP; ++i) fa[i] = *reinterpret_cast<const frag_t*>(sub + a_rd[i][hs]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.n_pad) Cp[r] = ET<T>::from_f32(v[r]);
+    for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(sub + b_rd[j][hs]);
+  };
+  int slot = 0;
+  for (int kb = kb_begin; kb < kb_end; kb += KPB) {
+    wait_vmcnt<(NSTAGE - 2) * L * KPB>();      // this wave's share of the oldest slot has landed
+    if (p.ablate < 3) __builtin_amdgcn_s_barrier();   // ... and everybody else's; all reads of the slot refilled below are done
+    if (p.ablate == 0 || p.ablate == 1) issue_slot((slot + NSTAGE - 1) % NSTAGE);
+    const unsigned char* base = smem + slot * STAGE;
+    slot = (slot + 1) % NSTAGE;
+    if (p.ablate == 1) continue;
+    const int nsub = min(KPB, kb_end - kb);
+    // 2*nsub half-steps; fragments of half-step h+1 are fetched while the matrix cores work on h
+    frag_t fa[2][MREP], fb[2][NREP];
+    load_frags(base, 0, fa[0], fb[0]);
+#pragma unroll
+    for (int h = 0; h < 2 * KPB; ++h) {
+      if (h < 2 * nsub) {
+        if (h + 1 < 2 * nsub && p.ablate != 4) load_frags(base + ((h + 1) >> 1) * SUB, (h + 1) & 1, fa[(h + 1) & 1], fb[(h + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) mma64(fa[h & 1][i], fb[h & 1][j], acc[i][j]);
       }
     }
   }
+  wait_vmcnt<0>();                         // only padding DMAs (to the dummy zone) can still be in flight
+  nt_epilogue<T, WM, WN, MREP, NREP>(p, acc, smem, m0, n0, wm, wn, z);
 }
 
 // =============================================================================================
@@ -493,17 +742,9 @@ static int set_lds(KernelT k, size_t bytes) {
   return IPOKE_OK;
 }
 
-template <typename T, int WM, int WN, int MREP, int NREP>
-static int launch_nt(NtParams& p, hipStream_t s) {
-  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
-  constexpr int BK = 128 / (int)sizeof(T);
-  p.tiles_m = ceil_div(p.g.M, BM);
-  p.tiles_n = ceil_div(p.Nout, BN);
-  const int nkb = ceil_div(p.Ktot, BK);
-  if (p.splitk < 1) p.splitk = 1;
-  p.kb_per_split = ceil_div(nkb, p.splitk);
-  // XCD-aware tile -> block mapping: XCD x (= blockIdx % 8) owns a (tiles_m/xa) x (tiles_n/xb) sub-grid so
-  // that its private L2 holds one slab of A rows and one slab of W rows; (xa, xb) minimises L2 fill bytes.
+// XCD-aware tile -> block mapping: XCD x (= blockIdx % 8) owns a (tiles_m/xa) x (tiles_n/xb) sub-grid so
+// that its private L2 holds one slab of A rows and one slab of W rows; (xa, xb) minimises L2 fill bytes.
+static void pick_xcd_map(NtParams& p) {
   p.xa = 0; p.xb = 0;
   const long nt = (long)p.tiles_m * p.tiles_n;
   if (nt % 8 == 0) {
@@ -516,7 +757,50 @@ static int launch_nt(NtParams& p, hipStream_t s) {
       if (best < 0 || cost < best) { best = cost; p.xa = xa; p.xb = xb; }
     }
   }
-  const size_t lds = 2 * (BM + BN) * kPitch + 256 * sizeof(int);
+}
+
+template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE>
+static int launch_nt_glds_impl(NtParams& p, hipStream_t s) {
+  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
+  constexpr int BK = 128 / (int)sizeof(T);
+  p.tiles_m = ceil_div(p.g.M, BM);
+  p.tiles_n = ceil_div(p.Nout, BN);
+  const int nkb = ceil_div(p.Ktot, BK);
+  if (p.splitk < 1) p.splitk = 1;
+  p.kb_per_split = ceil_div(nkb, p.splitk);
+  pick_xcd_map(p);
+  const size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * 128 + 4096 + 256 * sizeof(int);
+  auto kern = igemm_nt_glds_kernel<T, WM, WN, MREP, NREP, NSTAGE, KPB, SIMPLE>;
+  static bool attr_done = false;
+  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  dim3 grid((unsigned)((long)p.tiles_m * p.tiles_n), (unsigned)p.splitk);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB = 1>
+static int launch_nt_glds(NtParams& p, hipStream_t s) {
+  constexpr int BK = 128 / (int)sizeof(T);
+  const bool simple = p.Kc % BK == 0 && p.Kc_real == p.Kc && p.ldw >= p.Ktot;
+  return simple ? launch_nt_glds_impl<T, WM, WN, MREP, NREP, NSTAGE, KPB, true>(p, s)
+                : launch_nt_glds_impl<T, WM, WN, MREP, NREP, NSTAGE, KPB, false>(p, s);
+}
+
+template <typename T, int WM, int WN, int MREP, int NREP>
+static int launch_nt(NtParams& p, hipStream_t s) {
+  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
+  constexpr int BK = 128 / (int)sizeof(T);
+  p.tiles_m = ceil_div(p.g.M, BM);
+  p.tiles_n = ceil_div(p.Nout, BN);
+  const int nkb = ceil_div(p.Ktot, BK);
+  if (p.splitk < 1) p.splitk = 1;
+  p.kb_per_split = ceil_div(nkb, p.splitk);
+  pick_xcd_map(p);
+  const long nt = (long)p.tiles_m * p.tiles_n;
+  size_t lds = 2 * (BM + BN) * kPitch;
+  if (lds < (size_t)BM * (BN * 4 + 16)) lds = (size_t)BM * (BN * 4 + 16);
+  lds += 256 * sizeof(int);
   auto kern = igemm_nt_kernel<T, WM, WN, MREP, NREP>;
   static bool attr_done = false;     // one flag per template instantiation
   if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
@@ -530,6 +814,29 @@ template <typename T>
 static int dispatch_nt(NtParams& p, hipStream_t s) {
   // Tile choice: fill the 256 CUs with one wave of tiles when the problem allows it.
   const int M = p.g.M, N = p.Nout;
+  static const int forced = getenv("IPOKE_NT_TILE") ? atoi(getenv("IPOKE_NT_TILE")) : 0;     // developer override
+  switch (forced) {
+    case 1: return launch_nt<T, 4, 1, 1, 4>(p, s);
+    case 2: return launch_nt<T, 2, 2, 2, 4>(p, s);
+    case 3: return launch_nt<T, 2, 2, 4, 4>(p, s);
+    case 4: return launch_nt<T, 1, 4, 5, 2>(p, s);
+    case 5: return launch_nt<T, 2, 2, 5, 4>(p, s);
+    case 6: return launch_nt<T, 2, 2, 2, 2>(p, s);
+    default: break;
+  }
+  static const int glds_mode = getenv("IPOKE_NT_GLDS") ? atoi(getenv("IPOKE_NT_GLDS")) : 1;
+  if (glds_mode && !p.a_f32 && forced == 0) {
+    if (N <= 64) return launch_nt_glds<T, 4, 1, 1, 4, 4>(p, s);                     // 64 x 64, skinny N
+    if (glds_mode == 2) return launch_nt_glds<T, 2, 2, 4, 4, 4>(p, s);             // 128 x 128, 4 stages (128 KB LDS)
+    if (glds_mode == 3) return launch_nt_glds<T, 2, 2, 2, 4, 4>(p, s);             // 64 x 128
+    if (glds_mode == 4) return launch_nt_glds<T, 2, 2, 2, 2, 4>(p, s);             // 64 x 64
+    if (glds_mode == 5) return launch_nt_glds<T, 2, 2, 4, 4, 2, 2>(p, s);          // 128 x 128, 2 slots x 2 K-blocks
+    if (glds_mode == 6) return launch_nt_glds<T, 2, 2, 2, 4, 3, 2>(p, s);          // 64 x 128, 3 slots x 2 K-blocks
+    if (glds_mode == 7) return launch_nt_glds<T, 2, 2, 2, 2, 3, 4>(p, s);          // 64 x 64, 3 slots x 4 K-blocks
+    if (glds_mode == 8) return launch_nt_glds<T, 2, 2, 2, 2, 4, 2>(p, s);          // 64 x 64, 4 slots x 2 K-blocks
+    if ((long)ceil_div(M, 128) * ceil_div(N, 128) >= 100) return launch_nt_glds<T, 2, 2, 4, 4, 2, 2>(p, s);
+    return launch_nt_glds<T, 2, 2, 2, 2, 4>(p, s);
+  }
   if (N <= 64) return launch_nt<T, 4, 1, 1, 4>(p, s);                  // 64 x 64 tiles, skinny N (split-K upstream)
   const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
   if (M % 80 == 0 && M % 128 != 0 && (long)(M / 80) * ceil_div(N, 128) <= 256 && t128 < 256)
@@ -589,6 +896,7 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   p.C = d->C; p.c_f32 = d->c_f32; p.c_acc = d->c_accumulate; p.ldc = d->ldc; p.c_coff = d->c_coff;
   p.c_cstride = d->c_cstride <= 0 ? 1 : d->c_cstride;
   p.splitk = d->splitk < 1 ? 1 : d->splitk;
+  p.ablate = getenv("IPOKE_ABLATE") ? atoi(getenv("IPOKE_ABLATE")) : 0;      // developer experiment: 1 = loads only, 2 = math only
   p.n_pad = d->Nout;
   if (!d->c_f32 && p.splitk == 1) {
     const long lim = d->ldc - d->c_coff;
@@ -628,4 +936,14 @@ extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stre
   p.splitm = d->splitm < 1 ? 1 : d->splitm;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s) : launch_tn<float>(p, s);
+}
+
+/* Benchmark helper: `n` back-to-back launches of the same convolution issued natively (no host round trips in between),
+ * so that HIP events placed around the call measure kernel time rather than the caller's launch rate. */
+extern "C" int ipoke_conv_forward_repeat(const ipoke_conv_desc* d, int dtype, int n, void* stream) {
+  for (int i = 0; i < n; ++i) {
+    const int rc = ipoke_conv_forward(d, dtype, stream);
+    if (rc) return rc;
+  }
+  return IPOKE_OK;
 }
