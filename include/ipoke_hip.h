@@ -100,6 +100,11 @@ typedef struct {
 } ipoke_wgrad_desc;
 
 int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream);
+/* nbatch same-shape problems in one launch; entries_dev[i] = {int64 a_off bytes, int64 y_off bytes, int64 w_off floats,
+ * int32 kh, kw, ph, pw} relative to a_base / y_base / w_base (the descriptor's A, dY, dW and kh/kw/ph/pw are ignored) */
+int ipoke_wgrad_batch_entry_size(void);
+int ipoke_conv_wgrad_batched(const ipoke_wgrad_desc* d, const void* entries_dev, int nbatch, const void* a_base,
+                             const void* y_base, float* w_base, int dtype, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -142,6 +147,9 @@ int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, const float
                      const float* scale, const float* dld, float* dx, void* dparams /* dtype [M][ldp] */, int ldp,
                      float* dbias_part /* [B][2Cp] or NULL */, int B, int dtype, void* stream);
 int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream);
+/* multi-tensor form: entries_dev[i] = {int64 src, int64 dst (float offsets), int32 ld, int32 ncols}; R rows each */
+int ipoke_reduce_entry_size(void);
+int ipoke_reduce_rows_multi(const float* src, float* dst, const void* entries_dev, int nentries, int R, void* stream);
 
 int ipoke_logdet_finalize(const float* slots, int nslots, int B, int slot_w, float const_term, const float* const_dev,
                           float* logdet, void* stream);

@@ -79,6 +79,10 @@ SIGNATURES = {
     "ipoke_conv_forward": (c_int, [POINTER(ConvDesc), c_int, _P]),
     "ipoke_conv_forward_repeat": (c_int, [POINTER(ConvDesc), c_int, c_int, _P]),
     "ipoke_conv_wgrad": (c_int, [POINTER(WgradDesc), c_int, _P]),
+    "ipoke_wgrad_batch_entry_size": (c_int, []),
+    "ipoke_conv_wgrad_batched": (c_int, [POINTER(WgradDesc), _P, c_int, _P, _P, _P, c_int, _P]),
+    "ipoke_reduce_entry_size": (c_int, []),
+    "ipoke_reduce_rows_multi": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "ipoke_nchw_to_state": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_state_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_cond_prepare": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -356,6 +356,18 @@ __global__ void adam_amsgrad_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
+// dst[e.dst + c] = sum_r src[e.src + r*e.ld + c], c < e.ncols -- one block per entry (multi-tensor reduction)
+struct ReduceEntry { long src, dst; int ld, ncols; };
+__global__ void reduce_rows_multi_kernel(const float* __restrict__ src, float* __restrict__ dst, const ReduceEntry* __restrict__ ent,
+                                         int R) {
+  const ReduceEntry e = ent[blockIdx.x];
+  for (int c = threadIdx.x; c < e.ncols; c += blockDim.x) {
+    float t = 0.f;
+    for (int r = 0; r < R; ++r) t += src[e.src + (long)r * e.ld + c];
+    dst[e.dst + c] = t;
+  }
+}
+
 static inline int grid_for(long n, int block, int cap = 2048) {
   long g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -468,6 +480,14 @@ extern "C" int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, 
 extern "C" int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream) {
   IPK_REQUIRE(src && dst, "null tensor");
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(grid_for(ncols, 128)), dim3(128), 0, STREAM(stream), src, dst, R, ncols);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_reduce_entry_size(void) { return (int)sizeof(ReduceEntry); }
+extern "C" int ipoke_reduce_rows_multi(const float* src, float* dst, const void* entries_dev, int nentries, int R, void* stream) {
+  IPK_REQUIRE(src && dst && entries_dev && nentries >= 1 && R >= 1, "bad arguments");
+  hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3(nentries), dim3(128), 0, STREAM(stream), src, dst,
+                     (const ReduceEntry*)entries_dev, R);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

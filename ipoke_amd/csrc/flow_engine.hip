@@ -45,6 +45,7 @@ struct Op {
   // workspace (elements resolved per call)
   int64_t ws_a = -1, ws_b = -1, ws_c = -1, ws_d = -1, ws_e = -1, ws_f = -1, ws_g = -1;
   int slot = -1;                               // log-det slot index
+  int mcf_idx = -1;                            // running index among the MCF ops (batched weight gradients)
 };
 
 struct RelayoutJobH {
@@ -67,6 +68,9 @@ struct ipoke_flow {
   int64_t shadow_elems = 0;           // T elements
   int64_t wn_rows = 0;
   int nslots = 0;
+  int n_mcf = 0;
+  // per-batch-size device tables of the batched weight-gradient / reduction launches
+  int tab_B = 0; void* d_w1tab = nullptr; void* d_w2tab = nullptr; void* d_redtab = nullptr; int n_red = 0;
   std::vector<RelayoutJobH> rjobs; int rblocks = 0;
   std::vector<WnJobH> wjobs;
   std::vector<LsRefH> lsrefs;
@@ -156,6 +160,7 @@ struct Builder {
     relayout(op.p_v, op.sh_w2, op.wn_off, N2r, 2 * C, 1, op.K2p, K2, op.K2p, K2, 1, 0, 1);
     relayout(op.p_v, op.sh_w2t, op.wn_off, Hr, op.H, 1, op.K3p, 2 * C, op.K3p, 1, K2, 0, 0);
     op.slot = f.nslots++;
+    op.mcf_idx = f.n_mcf++;
     f.ops.push_back(op);
   }
 
@@ -263,6 +268,8 @@ int build(ipoke_flow& f) {
     for (auto& o : prior_ops[l]) f.ops.push_back(o);
     for (auto& o : shuf_ops[l]) f.ops.push_back(o);
   }
+  int k = 0;
+  for (auto& o : f.ops) if (o.type == OP_MCF) o.mcf_idx = k++;     // execution order
   return IPOKE_OK;
 }
 
@@ -391,6 +398,45 @@ int common_checks(ipoke_flow* f, int B) {
   return IPOKE_OK;
 }
 
+struct WgEntryH { long a_off, y_off, w_off; int kh, kw, ph, pw; };
+struct RedEntryH { long src, dst; int ld, ncols; };
+
+// (Re)build the device tables for batch size B.  Offsets are relative to the workspace base (bytes) / the
+// gradient buffer (floats), so the tables stay valid as long as B does.  Not called under graph capture
+// after the first (warm-up) step.
+int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
+  if (f->tab_B == B && f->d_w1tab) return IPOKE_OK;
+  IPK_REQUIRE((int)sizeof(WgEntryH) == ipoke_wgrad_batch_entry_size() && (int)sizeof(RedEntryH) == ipoke_reduce_entry_size(),
+              "batch table layout mismatch");
+  std::vector<WgEntryH> w1(f->n_mcf), w2(f->n_mcf);
+  std::vector<RedEntryH> red;
+  for (size_t i = 0; i < f->ops.size(); ++i) {
+    const Op& op = f->ops[i];
+    const long dbp = (long)(plan.dbias_part / 4) + (long)i * (B + 1) * 128;
+    if (op.type == OP_MCF) {
+      const McfGeom g = mcf_geom(op.order);
+      w1[op.mcf_idx] = {(long)(plan.state0 + (int64_t)i * plan.state_stride), (long)op.ws_d, (long)op.p_w1, g.kh, g.kw, -g.oy, -g.ox};
+      w2[op.mcf_idx] = {(long)op.ws_a, (long)op.ws_c, (long)op.p_v, 1, 1, 0, 0};
+      red.push_back({dbp, (long)op.p_b, 2 * op.C, 2 * op.C});
+    } else if (op.type == OP_NICE) {
+      red.push_back({dbp, (long)op.p_b, 2 * op.cout, 2 * op.cout});
+    } else if (op.p_ls >= 0) {
+      red.push_back({dbp, (long)op.p_ls, 2 * op.Cn, op.Cn});
+      red.push_back({dbp + op.Cn, (long)op.p_bias, 2 * op.Cn, op.Cn});
+    }
+  }
+  if (f->d_w1tab) { (void)hipFree(f->d_w1tab); (void)hipFree(f->d_w2tab); (void)hipFree(f->d_redtab); }
+  IPK_HIP(hipMalloc(&f->d_w1tab, w1.size() * sizeof(WgEntryH)));
+  IPK_HIP(hipMalloc(&f->d_w2tab, w2.size() * sizeof(WgEntryH)));
+  IPK_HIP(hipMalloc(&f->d_redtab, red.size() * sizeof(RedEntryH)));
+  IPK_HIP(hipMemcpy(f->d_w1tab, w1.data(), w1.size() * sizeof(WgEntryH), hipMemcpyHostToDevice));
+  IPK_HIP(hipMemcpy(f->d_w2tab, w2.data(), w2.size() * sizeof(WgEntryH), hipMemcpyHostToDevice));
+  IPK_HIP(hipMemcpy(f->d_redtab, red.data(), red.size() * sizeof(RedEntryH), hipMemcpyHostToDevice));
+  f->n_red = (int)red.size();
+  f->tab_B = B;
+  return IPOKE_OK;
+}
+
 hipEvent_t next_event(ipoke_flow* f) {
   hipEvent_t e = f->events[f->ev_next];
   f->ev_next = (f->ev_next + 1) % f->events.size();
@@ -441,6 +487,9 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   if (f->d_rjobs) (void)hipFree(f->d_rjobs);
   if (f->d_wjobs) (void)hipFree(f->d_wjobs);
   if (f->d_lsrefs) (void)hipFree(f->d_lsrefs);
+  if (f->d_w1tab) (void)hipFree(f->d_w1tab);
+  if (f->d_w2tab) (void)hipFree(f->d_w2tab);
+  if (f->d_redtab) (void)hipFree(f->d_redtab);
   for (auto e : f->events) (void)hipEventDestroy(e);
   if (f->side) (void)hipStreamDestroy(f->side);
   delete f;
@@ -630,10 +679,33 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
   IPK_HIP(hipMemcpyAsync(dld, d_logdet, B * sizeof(float), hipMemcpyDeviceToDevice, s));
   hipStream_t ws_stream = f->use_side ? f->side : s;
   void* wstream = reinterpret_cast<void*>(ws_stream);
-  // The small MCF weight-gradient GEMMs (a handful of output tiles) split their reduction over the batch
-  // across workgroups and add atomically, so the gradient buffer starts from zero.
-  const int small_splitm = B >= 4 ? (B + 1) / 2 : 1;
-  IPK_HIP(hipMemsetAsync(grads, 0, (size_t)f->n_params * sizeof(float), s));
+  // Every parameter gradient is written exactly once per backward (no accumulation, no memset).  The weight gradients
+  // of the MCF layers are tiny GEMMs (a handful of output tiles): they are deferred and issued as batched launches,
+  // one per run of same-shape layers (= one level), using the per-layer saved operands that stay in the workspace.
+  rc = ensure_tables(f, B, c.plan); if (rc) return rc;
+  int pend_lo = -1, pend_hi = -1, pend_op = -1;      // pending MCF index range [lo, hi] and a representative op
+  auto flush_mcf = [&]() -> int {
+    if (pend_lo < 0) return IPOKE_OK;
+    const Op& op = f->ops[pend_op];
+    const int nb = pend_hi - pend_lo + 1;
+    if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
+    ipoke_wgrad_desc w; std::memset(&w, 0, sizeof(w));
+    w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = w.kh = w.kw = 1; w.sd = w.sh = w.sw = 1;
+    const int K2 = op.H + f->cfg.cond_channels;
+    w.a_f32 = 0; w.a_sn = 64L * op.K2p; w.a_sh = 8L * op.K2p; w.a_sw = op.K2p; w.a_sc = 1; w.Kc_real = K2; w.Kc = op.K2p;
+    w.ldy = op.K3p; w.Nout = 2 * op.C; w.w_sn = K2; w.w_sc = 1; w.w_st = 0;
+    int r = ipoke_conv_wgrad_batched(&w, reinterpret_cast<const unsigned char*>(f->d_w2tab) + (size_t)pend_lo * ipoke_wgrad_batch_entry_size(),
+                                     nb, c.ws, c.ws, grads, c.dtype, wstream);
+    if (r) return r;
+    std::memset(&w, 0, sizeof(w));
+    w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = 2; w.kw = 3; w.sd = w.sh = w.sw = 1;
+    w.a_f32 = 1; w.a_sn = 64L * c.ld; w.a_sh = 8L * c.ld; w.a_sw = c.ld; w.a_sc = 1; w.Kc_real = op.C; w.Kc = op.Cp;
+    w.ldy = op.Hq; w.Nout = op.H; w.w_sn = (int64_t)op.C * 6; w.w_sc = 6; w.w_st = 1;
+    r = ipoke_conv_wgrad_batched(&w, reinterpret_cast<const unsigned char*>(f->d_w1tab) + (size_t)pend_lo * ipoke_wgrad_batch_entry_size(),
+                                 nb, c.ws, c.ws, grads, c.dtype, wstream);
+    pend_lo = pend_hi = pend_op = -1;
+    return r;
+  };
   if (f->use_side) {   // the side stream joins after everything already queued on the main stream
     hipEvent_t e = next_event(f);
     IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0));
@@ -648,14 +720,6 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
       rc = ipoke_actnorm_bwd(gin, xin, gout, M, c.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
                              op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr, dld, B, f->P, dbp, stream);
       if (rc) return rc;
-      if (op.p_ls >= 0) {
-        if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
-        // ActNorm parameters are laid out [log_scale | bias] back to back only when Cn % 4 == 0; reduce them separately
-        float* tmp = dbp + (int64_t)B * 2 * op.Cn;            // [2*Cn] scratch behind the partials
-        rc = ipoke_reduce_rows(dbp, tmp, B, 2 * op.Cn, wstream); if (rc) return rc;
-        IPK_HIP(hipMemcpyAsync(grads + op.p_ls, tmp, op.Cn * sizeof(float), hipMemcpyDeviceToDevice, ws_stream));
-        IPK_HIP(hipMemcpyAsync(grads + op.p_bias, tmp + op.Cn, op.Cn * sizeof(float), hipMemcpyDeviceToDevice, ws_stream));
-      }
     } else if (op.type == OP_MCF) {
       ipoke_mcf_desc d; mcf_desc(c, op, d);
       d.x = xin; d.dy = gin; d.dx = gout; d.dld = dld;
@@ -663,25 +727,10 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
       d.dparams_save = c.at<void>(op.ws_c); d.dc_save = c.at<void>(op.ws_d); d.dbias_part = dbp;
       d.y = gout;   // unused by the backward kernel, must be non-null for the shared validator
       rc = ipoke_mcf_bwd(&d, c.dtype, stream); if (rc) return rc;
-      if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
-      // weight gradients (side stream)
-      rc = ipoke_reduce_rows(dbp, grads + op.p_b, B, 2 * op.C, wstream); if (rc) return rc;
-      ipoke_wgrad_desc w; std::memset(&w, 0, sizeof(w));
-      w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = w.kh = w.kw = 1; w.sd = w.sh = w.sw = 1;
-      const int K2 = op.H + f->cfg.cond_channels;
-      w.A = c.at<void>(op.ws_a); w.a_f32 = 0; w.a_sn = 64L * op.K2p; w.a_sh = 8L * op.K2p; w.a_sw = op.K2p; w.a_sc = 1;
-      w.Kc_real = K2; w.Kc = op.K2p;
-      w.dY = c.at<void>(op.ws_c); w.ldy = op.K3p; w.Nout = 2 * op.C;
-      w.dW = grads + op.p_v; w.w_sn = K2; w.w_sc = 1; w.w_st = 0; w.splitm = small_splitm; w.accumulate = 1;
-      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
-      const McfGeom g = mcf_geom(op.order);
-      std::memset(&w, 0, sizeof(w));
-      w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = g.kh; w.kw = g.kw;
-      w.sd = w.sh = w.sw = 1; w.ph = -g.oy; w.pw = -g.ox;
-      w.A = xin; w.a_f32 = 1; w.a_sn = 64L * c.ld; w.a_sh = 8L * c.ld; w.a_sw = c.ld; w.a_sc = 1; w.Kc_real = op.C; w.Kc = op.Cp;
-      w.dY = c.at<void>(op.ws_d); w.ldy = op.Hq; w.Nout = op.H;
-      w.dW = grads + op.p_w1; w.w_sn = (int64_t)op.C * 6; w.w_sc = 6; w.w_st = 1; w.splitm = small_splitm; w.accumulate = 1;
-      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+      // weight gradients: deferred, batched per run of same-width layers
+      if (pend_lo >= 0 && (f->ops[pend_op].C != op.C || pend_hi - pend_lo + 1 >= 256)) { rc = flush_mcf(); if (rc) return rc; }
+      if (pend_lo < 0) { pend_hi = op.mcf_idx; pend_op = i; }
+      pend_lo = op.mcf_idx;
     } else {
       const void* h1 = c.at<void>(op.ws_a); const void* h2 = c.at<void>(op.ws_b);
       void* dprm = c.at<void>(op.ws_d); void* dp2 = c.at<void>(op.ws_e); void* dp1 = c.at<void>(op.ws_f);
@@ -708,7 +757,6 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
       d.c_coff = op.z_off; d.c_cstride = op.z_stride; d.splitk = nice_splitk(c);
       rc = ipoke_conv_forward(&d, c.dtype, stream); if (rc) return rc;
       if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
-      rc = ipoke_reduce_rows(dbp, grads + op.p_b, B, 2 * op.cout, wstream); if (rc) return rc;
       ipoke_wgrad_desc w;
       auto base8 = [&](int k, int pad) {
         std::memset(&w, 0, sizeof(w));
@@ -737,6 +785,9 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
     }
     cur ^= 1;
   }
+  rc = flush_mcf(); if (rc) return rc;
+  // bias / ActNorm parameter gradients: one multi-tensor reduction over the per-sample partial sums of every layer
+  rc = ipoke_reduce_rows_multi(reinterpret_cast<const float*>(c.ws), grads, f->d_redtab, f->n_red, B, stream); if (rc) return rc;
   if (f->use_side) {
     hipEvent_t e = next_event(f);
     IPK_HIP(hipEventRecord(e, f->side)); IPK_HIP(hipStreamWaitEvent(s, e, 0));

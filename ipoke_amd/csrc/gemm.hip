@@ -35,12 +35,16 @@ struct NtParams {
   int tiles_m, tiles_n, xa, xb;
 };
 
+// one problem of a batched weight-gradient launch (blockIdx.z): byte/float offsets against the launch's bases
+struct TnBatchEntry { long a_off, y_off, w_off; int kh, kw, ph, pw; };
+
 struct TnParams {
   GeomDev g;
+  const TnBatchEntry* batch; const unsigned char* a_base; const unsigned char* y_base; float* w_base;
   const void* A; int a_f32; long a_sn, a_sd, a_sh, a_sw, a_sc; int a_coff, Kc_real, Kc;
   const void* dY; int ldy, y_coff; int Nout; int Ktot;
   float* dW; long w_sn, w_sc, w_st; int accumulate;
-  int splitm, mb_per_split;
+  int splitm, mb_per_split, rows_fixed;
   int tiles_n, tiles_k;
 };
 
@@ -555,7 +559,13 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(const NtParams p) {
 // =============================================================================================
 // weight gradient
 template <typename T>
-__global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
+__global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
+  TnParams p = pin;
+  if (pin.batch) {                       // batched launch: blockIdx.z selects operands and the 2-D tap geometry
+    const TnBatchEntry e = pin.batch[blockIdx.z];
+    p.A = pin.a_base + e.a_off; p.dY = pin.y_base + e.y_off; p.dW = pin.w_base + e.w_off;
+    p.g.khw = e.kh * e.kw; p.g.kw = e.kw; p.g.taps = e.kh * e.kw; p.g.ph = e.ph; p.g.pw = e.pw;
+  }
   constexpr int TN_ = 128, TK_ = 128;          // output tile: 128 out-channels x 128 k
   constexpr int E16 = ET<T>::E16;
   constexpr int RM = 128 / (int)sizeof(T);     // reduction rows per stage
@@ -599,33 +609,77 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
   __syncthreads();
   const int x_tapcode = x_col_ok ? taptab[x_tap] : 0;
 
+  // Fast path (p.rows_fixed: a reduction block of RM rows covers whole samples, e.g. the 8x8 latent with bf16):
+  // the spatial position -- hence tap validity and the in-sample offset -- of each of this thread's rows is
+  // loop invariant; only the sample index advances.  Offsets are 32-bit element offsets (host-checked).
+  constexpr unsigned kBad = 0xffffffffu;
+  unsigned x_fix[E16];
+  const int S = 1 << (g.lDo + g.lHo + g.lWo);
+  if (p.rows_fixed && do_x) {
+#pragma unroll
+    for (int i = 0; i < E16; ++i) {
+      x_fix[i] = kBad;
+      if (x_col_ok) {
+        const RowPos r = decode_row(g, mbk * E16 + i, p.a_sn);        // row inside the reduction block
+        int id, ih, iw;
+        if (tap_coords(g, r, x_tapcode, id, ih, iw))
+          x_fix[i] = (unsigned)(r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw);
+      }
+    }
+  }
+  const bool vec_f32 = p.a_f32 && p.a_sc == 1 && ((p.a_coff + x_c) & 3) == 0 && x_c + E16 <= p.Kc_real &&
+                       ((p.a_sn | p.a_sd | p.a_sh | p.a_sw) & 3) == 0;
+  auto load_x = [&](long off) -> u32x4 {
+    if (vec_f32) {      // contiguous fp32 channels: two (bf16) / one (f32) 16-byte loads, converted in registers
+      const float* src = reinterpret_cast<const float*>(p.A) + off + p.a_coff + x_c;
+      typename Chunk<T>::type v;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ET<T>::from_f32(lo[e]);
+      if constexpr (E16 == 8) {
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 + e] = ET<T>::from_f32(hi[e]);
+      }
+      return *reinterpret_cast<u32x4*>(&v);
+    }
+    return load_a_chunk<T>(p.A, p.a_f32, off, p.a_sc, p.a_coff, x_c, p.Kc_real);
+  };
+
   u32x4 ry[E16], rx[E16];
   auto load_stage = [&](int mb) {
     const int mbase = mb * RM + mbk * E16;
     if (do_y) {
+      const T* yp = reinterpret_cast<const T*>(p.dY) + (long)mbase * p.ldy + p.y_coff + ncol;
 #pragma unroll
       for (int i = 0; i < E16; ++i) {
-        const int m = mbase + i;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (y_col_ok && m < g.M)
-          v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dY) + (long)m * p.ldy + p.y_coff + ncol);
+        if (y_col_ok && mbase + i < g.M) v = *reinterpret_cast<const u32x4*>(yp + (long)i * p.ldy);
         ry[i] = v;
       }
     }
     if (do_x) {
+      if (p.rows_fixed) {
+        const long nb = (long)(mb * (RM / S)) * p.a_sn;
 #pragma unroll
-      for (int i = 0; i < E16; ++i) {
-        const int m = mbase + i;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (x_col_ok && m < g.M) {
-          const RowPos r = decode_row(g, m, p.a_sn);
-          int id, ih, iw;
-          if (tap_coords(g, r, x_tapcode, id, ih, iw)) {
-            const long off = r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw;
-            v = load_a_chunk<T>(p.A, p.a_f32, off, p.a_sc, p.a_coff, x_c, p.Kc_real);
-          }
+        for (int i = 0; i < E16; ++i) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (x_fix[i] != kBad && mbase + i < g.M) v = load_x(nb + x_fix[i]);
+          rx[i] = v;
         }
-        rx[i] = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < E16; ++i) {
+          const int m = mbase + i;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (x_col_ok && m < g.M) {
+            const RowPos r = decode_row(g, m, p.a_sn);
+            int id, ih, iw;
+            if (tap_coords(g, r, x_tapcode, id, ih, iw))
+              v = load_x(r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw);
+          }
+          rx[i] = v;
+        }
       }
     }
   };
@@ -848,11 +902,15 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
 }
 
 template <typename T>
-static int launch_tn(TnParams& p, hipStream_t s) {
+static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   constexpr int RM = 128 / (int)sizeof(T);
   p.tiles_n = ceil_div(p.Nout, 128);
   p.tiles_k = ceil_div(p.Ktot, 128);
   const int nmb = ceil_div(p.g.M, RM);
+  {
+    const int S = 1 << (p.g.lDo + p.g.lHo + p.g.lWo);
+    p.rows_fixed = (RM % S == 0) ? 1 : 0;
+  }
   if (p.splitm < 1) p.splitm = 1;
   if (p.splitm > nmb) p.splitm = nmb;
   p.mb_per_split = ceil_div(nmb, p.splitm);
@@ -860,7 +918,7 @@ static int launch_tn(TnParams& p, hipStream_t s) {
   auto kern = igemm_tn_kernel<T>;
   static bool attr_done = false;
   if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
-  dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm);
+  dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, (unsigned)nbatch);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
@@ -913,15 +971,14 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   return dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
 }
 
-extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream) {
+static int fill_tn(TnParams& p, const ipoke_wgrad_desc* d, int dtype, bool batched) {
   IPK_REQUIRE(d != nullptr, "null descriptor");
   IPK_REQUIRE(dtype == IPOKE_F32 || dtype == IPOKE_BF16, "bad dtype");
   const int esz = dtype == IPOKE_BF16 ? 2 : 4, e16 = 16 / esz;
-  TnParams p;
   int rc = make_geom(p.g, d->NB, d->Di, d->Hi, d->Wi, d->Do, d->Ho, d->Wo, d->kd, d->kh, d->kw, d->sd, d->sh, d->sw,
                      d->pd, d->ph, d->pw, d->transposed);
   if (rc) return rc;
-  IPK_REQUIRE(d->A && d->dY && d->dW, "null tensor");
+  IPK_REQUIRE(batched || (d->A && d->dY && d->dW), "null tensor");
   IPK_REQUIRE(d->Kc % e16 == 0 && d->Kc >= d->Kc_real && d->Kc_real > 0, "Kc must be a padded multiple of 16 bytes");
   if (!d->a_f32) {
     IPK_REQUIRE(d->a_sc == 1 && d->Kc_real % e16 == 0 && d->a_coff % e16 == 0, "dtype activations: aligned channels-last");
@@ -929,13 +986,36 @@ extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stre
   }
   IPK_REQUIRE(d->ldy % e16 == 0 && d->y_coff % e16 == 0 && ((uintptr_t)d->dY & 15) == 0, "dY rows must be 16-byte aligned");
   IPK_REQUIRE(d->y_coff + round_up(d->Nout, e16) <= d->ldy, "dY pitch must cover the padded channel count");
+  p.batch = nullptr; p.a_base = nullptr; p.y_base = nullptr; p.w_base = nullptr;
   p.A = d->A; p.a_f32 = d->a_f32; p.a_sn = d->a_sn; p.a_sd = d->a_sd; p.a_sh = d->a_sh; p.a_sw = d->a_sw; p.a_sc = d->a_sc;
   p.a_coff = d->a_coff; p.Kc_real = d->Kc_real; p.Kc = d->Kc;
   p.dY = d->dY; p.ldy = d->ldy; p.y_coff = d->y_coff; p.Nout = d->Nout; p.Ktot = p.g.taps * d->Kc;
   p.dW = d->dW; p.w_sn = d->w_sn; p.w_sc = d->w_sc; p.w_st = d->w_st; p.accumulate = d->accumulate;
   p.splitm = d->splitm < 1 ? 1 : d->splitm;
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream) {
+  TnParams p;
+  int rc = fill_tn(p, d, dtype, false); if (rc) return rc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s) : launch_tn<float>(p, s);
+}
+
+extern "C" int ipoke_wgrad_batch_entry_size(void) { return (int)sizeof(TnBatchEntry); }
+
+/* Batched weight gradients: `nbatch` problems of identical shape (all but the 2-D kernel extent / padding, which come
+ * from the entry) in one launch.  entries_dev[i] = {a_off bytes, y_off bytes, w_off floats, kh, kw, ph, pw}. */
+extern "C" int ipoke_conv_wgrad_batched(const ipoke_wgrad_desc* d, const void* entries_dev, int nbatch, const void* a_base,
+                                        const void* y_base, float* w_base, int dtype, void* stream) {
+  IPK_REQUIRE(entries_dev && nbatch >= 1 && a_base && y_base && w_base, "bad batch arguments");
+  TnParams p;
+  int rc = fill_tn(p, d, dtype, true); if (rc) return rc;
+  p.batch = reinterpret_cast<const TnBatchEntry*>(entries_dev);
+  p.a_base = reinterpret_cast<const unsigned char*>(a_base); p.y_base = reinterpret_cast<const unsigned char*>(y_base);
+  p.w_base = w_base;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s, nbatch) : launch_tn<float>(p, s, nbatch);
 }
 
 /* Benchmark helper: `n` back-to-back launches of the same convolution issued natively (no host round trips in between),
