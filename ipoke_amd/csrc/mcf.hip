@@ -101,33 +101,37 @@ __device__ __forceinline__ void mcf_gemm1(const McfParams& P, const McfGeom& g, 
   int tap = (E16 * gq) / P.Cp, c = E16 * gq - tap * P.Cp;
   const T* W1 = reinterpret_cast<const T*>(P.W1);
   const int xpitch = P.Cp * (int)sizeof(T) + 16;
-  // fragments of step k+1 are fetched before the matrix-core work of step k (weights stream from L2)
-  frag_t fa[MF], fb[4], na[MF], nb[4];
-  auto fetch = [&](int k, frag_t* a, frag_t* b) {
-#pragma unroll
-    for (int i = 0; i < MF; ++i) a[i] = gather_fwd<T>(tile[i], xpitch, g, pos[i], tap, c, ntaps);
+  // Weight fragments stream from L2/HBM with ~1 us latency and nothing else to hide it (one workgroup per slice of a
+  // sample): keep a ring of PF K-steps of B fragments in flight.
+  constexpr int PF = 3;
+  const int nsteps = P.K1p / KS;
+  frag_t ring[PF][4];
+  auto load_b = [&](int st, frag_t* b) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (wave + 4 * j < NF1) b[j] = load_wfrag<T>(W1, P.K1p, (wave + 4 * j) * 16 + r, k + E16 * gq);
-    c += KS;
-    while (c >= P.Cp) { c -= P.Cp; ++tap; }
+      if (wave + 4 * j < NF1) b[j] = load_wfrag<T>(W1, P.K1p, (wave + 4 * j) * 16 + r, st * KS + E16 * gq);
   };
-  fetch(0, fa, fb);
-  for (int k = 0; k < P.K1p; k += KS) {
-    const bool more = k + KS < P.K1p;
-    if (more) fetch(k + KS, na, nb);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (wave + 4 * j < NF1) {
+  for (int d = 0; d < PF; ++d) if (d < nsteps) load_b(d, ring[d]);
+  for (int k0 = 0; k0 < nsteps; k0 += PF) {
 #pragma unroll
-        for (int i = 0; i < MF; ++i) mma64(fa[i], fb[j], acc[i][j]);
+    for (int d = 0; d < PF; ++d) {
+      const int st = k0 + d;
+      if (st < nsteps) {
+        frag_t fa[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) fa[i] = gather_fwd<T>(tile[i], xpitch, g, pos[i], tap, c, ntaps);
+        c += KS;
+        while (c >= P.Cp) { c -= P.Cp; ++tap; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (wave + 4 * j < NF1) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) mma64(fa[i], ring[d][j], acc[i][j]);
+          }
+        }
+        if (st + PF < nsteps) load_b(st + PF, ring[d]);
       }
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < MF; ++i) fa[i] = na[i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = nb[j];
     }
   }
 #pragma unroll
@@ -156,30 +160,34 @@ __device__ __forceinline__ void mcf_gemm2(const McfParams& P, const unsigned cha
 #pragma unroll
   for (int i = 0; i < MF; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
   const T* W2 = reinterpret_cast<const T*>(P.W2);
-  frag_t fa[MF], fb[2], na[MF], nb[2];
-  auto fetch = [&](int k, frag_t* a, frag_t* b) {
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-      a[i] = *reinterpret_cast<const frag_t*>(a2 + (i * 16 + r) * a2_pitch + (k + E16 * gq) * (int)sizeof(T));
+  constexpr int PF = 4;
+  const int nsteps = P.K2p / KS;
+  frag_t ring[PF][2];
+  auto load_b = [&](int st, frag_t* b) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      if (wave + 4 * j < NF2) b[j] = load_wfrag<T>(W2, P.K2p, (wave + 4 * j) * 16 + r, k + E16 * gq);
+      if (wave + 4 * j < NF2) b[j] = load_wfrag<T>(W2, P.K2p, (wave + 4 * j) * 16 + r, st * KS + E16 * gq);
   };
-  fetch(0, fa, fb);
-  for (int k = 0; k < P.K2p; k += KS) {
-    const bool more = k + KS < P.K2p;
-    if (more) fetch(k + KS, na, nb);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (wave + 4 * j < NF2) {
+  for (int d = 0; d < PF; ++d) if (d < nsteps) load_b(d, ring[d]);
+  for (int k0 = 0; k0 < nsteps; k0 += PF) {
 #pragma unroll
-        for (int i = 0; i < MF; ++i) mma64(fa[i], fb[j], acc[i][j]);
+    for (int d = 0; d < PF; ++d) {
+      const int st = k0 + d;
+      if (st < nsteps) {
+        frag_t fa[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+          fa[i] = *reinterpret_cast<const frag_t*>(a2 + (i * 16 + r) * a2_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (wave + 4 * j < NF2) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) mma64(fa[i], ring[d][j], acc[i][j]);
+          }
+        }
+        if (st + PF < nsteps) load_b(st + PF, ring[d]);
       }
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < MF; ++i) fa[i] = na[i];
-      fb[0] = nb[0]; fb[1] = nb[1];
     }
   }
 #pragma unroll
@@ -377,28 +385,33 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* W2T = reinterpret_cast<const T*>(P.W2T);
-    frag_t fa[4], fb[4], na[4], nb[4];
-    auto fetch = [&](int k, frag_t* a, frag_t* b) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        a[i] = *reinterpret_cast<const frag_t*>(dp + (i * 16 + r) * dp_pitch + (k + E16 * gq) * (int)sizeof(T));
+    constexpr int PF = 4;
+    const int nsteps = P.K3p / KS;
+    frag_t ring[PF][4];
+    auto load_b = [&](int st, frag_t* b) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (wave + 4 * j < NF) b[j] = load_wfrag<T>(W2T, P.K3p, (wave + 4 * j) * 16 + r, k + E16 * gq);
+        if (wave + 4 * j < NF) b[j] = load_wfrag<T>(W2T, P.K3p, (wave + 4 * j) * 16 + r, st * KS + E16 * gq);
     };
-    fetch(0, fa, fb);
-    for (int k = 0; k < P.K3p; k += KS) {
-      const bool more = k + KS < P.K3p;
-      if (more) fetch(k + KS, na, nb);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (wave + 4 * j < NF) {
+    for (int d = 0; d < PF; ++d) if (d < nsteps) load_b(d, ring[d]);
+    for (int k0 = 0; k0 < nsteps; k0 += PF) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) mma64(fa[i], fb[j], acc[i][j]);
+      for (int d = 0; d < PF; ++d) {
+        const int st = k0 + d;
+        if (st < nsteps) {
+          frag_t fa[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            fa[i] = *reinterpret_cast<const frag_t*>(dp + (i * 16 + r) * dp_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (wave + 4 * j < NF) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) mma64(fa[i], ring[d][j], acc[i][j]);
+            }
+          if (st + PF < nsteps) load_b(st + PF, ring[d]);
         }
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
       }
     }
     const T* a2s = reinterpret_cast<const T*>(P.a2_save);
@@ -441,24 +454,25 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
     const T* W1T = reinterpret_cast<const T*>(P.W1T);
     if (wave < NF) {
       int tap = 0, c = E16 * gq;           // Hq is a multiple of KS: a super-step never straddles taps
-      frag_t fa[4], na[4], fb, nb;
-      auto fetch = [&](int k, frag_t* a, frag_t& b) {
+      constexpr int PF = 8;
+      const int nsteps = Ktot / KS;
+      frag_t ring[PF];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = gather_adj<T>(dc, dc_pitch, g, i * 16 + r, tap, c);
-        b = load_wfrag<T>(W1T, Ktot, wave * 16 + r, k + E16 * gq);
-        c += KS;
-        if (c >= P.Hq) { c -= P.Hq; ++tap; }
-      };
-      fetch(0, fa, fb);
-      for (int k = 0; k < Ktot; k += KS) {
-        const bool more = k + KS < Ktot;
-        if (more) fetch(k + KS, na, nb);
+      for (int d = 0; d < PF; ++d) if (d < nsteps) ring[d] = load_wfrag<T>(W1T, Ktot, wave * 16 + r, d * KS + E16 * gq);
+      for (int k0 = 0; k0 < nsteps; k0 += PF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mma64(fa[i], fb, acc[i]);
-        if (more) {
+        for (int d = 0; d < PF; ++d) {
+          const int st = k0 + d;
+          if (st < nsteps) {
+            frag_t fa[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) fa[i] = na[i];
-          fb = nb;
+            for (int i = 0; i < 4; ++i) fa[i] = gather_adj<T>(dc, dc_pitch, g, i * 16 + r, tap, c);
+            c += KS;
+            if (c >= P.Hq) { c -= P.Hq; ++tap; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma64(fa[i], ring[d], acc[i]);
+            if (st + PF < nsteps) ring[d] = load_wfrag<T>(W1T, Ktot, wave * 16 + r, (st + PF) * KS + E16 * gq);
+          }
         }
       }
       const int n = wave * 16 + 4 * gq;
