@@ -136,8 +136,8 @@ struct Builder {
     Op op; op.type = OP_MCF; op.C = C; op.order = order;
     const int kh = order < 2 ? f.cfg.kernel_h : f.cfg.kernel_w, kw = order < 2 ? f.cfg.kernel_w : f.cfg.kernel_h;
     op.H = 4 * C;
-    op.Cp = round_up(C, f.e16);
-    op.K1p = round_up(6 * op.Cp, f.ks);
+    op.Cp = round_up(C, f.ks);
+    op.K1p = 6 * op.Cp;
     op.K2p = round_up(op.H + Cc, f.ks);
     op.K3p = round_up(2 * C, f.ks);
     op.Hq = round_up(op.H, f.ks);

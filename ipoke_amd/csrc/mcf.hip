@@ -13,6 +13,10 @@
 
 namespace ipoke {
 
+template <typename T> struct Pack4;     // 4 consecutive values of the compute dtype
+template <> struct Pack4<bf16_t> { typedef __attribute__((ext_vector_type(4))) __bf16 type; };
+template <> struct Pack4<float> { typedef f32x4 type; };
+
 template <typename T> struct K64 { static constexpr int value = 64 / (int)sizeof(T); };   // K per super-step
 
 // 16-byte chunk of the (virtual) im2col row of position p: channels [c, c+E16) of tap `tap`
@@ -45,6 +49,22 @@ __device__ __forceinline__ typename ET<T>::frag gather_adj(const unsigned char* 
   return *reinterpret_cast<const frag_t*>(tile + (yy * 8 + xx) * pitch + c * (int)sizeof(T));
 }
 
+// LDS address of the row feeding position p through tap (compile-time) `tap`, or the all-zero row when out of range
+__device__ __forceinline__ const unsigned char* tap_src_fwd(const unsigned char* tile, const unsigned char* zrow, int pitch,
+                                                            const McfGeom& g, int p, int tap) {
+  const int ky = g.kw == 3 ? (tap >= 3) : (tap >> 1);
+  const int kx = tap - ky * g.kw;
+  const int yy = (p >> 3) + ky + g.oy, xx = (p & 7) + kx + g.ox;
+  return ((unsigned)yy < 8u && (unsigned)xx < 8u) ? tile + (yy * 8 + xx) * pitch : zrow;
+}
+__device__ __forceinline__ const unsigned char* tap_src_adj(const unsigned char* tile, const unsigned char* zrow, int pitch,
+                                                            const McfGeom& g, int p, int tap) {
+  const int ky = g.kw == 3 ? (tap >= 3) : (tap >> 1);
+  const int kx = tap - ky * g.kw;
+  const int yy = (p >> 3) - ky - g.oy, xx = (p & 7) - kx - g.ox;
+  return ((unsigned)yy < 8u && (unsigned)xx < 8u) ? tile + (yy * 8 + xx) * pitch : zrow;
+}
+
 template <typename T>
 __device__ __forceinline__ typename ET<T>::frag load_wfrag(const T* W, int ldw, int row, int k) {
   return *reinterpret_cast<const typename ET<T>::frag*>(W + (long)row * ldw + k);
@@ -67,6 +87,7 @@ struct McfParams {
   void* dparams_save;                // T [M][K3p]
   void* dc_save;                     // T [M][Hq]
   float* dbias_part;                 // [B][2C]
+  int dbg;                           // developer ablation switch (IPOKE_MCF_ABLATE)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -83,13 +104,13 @@ __device__ __forceinline__ void stage_x(const float* xb, int ld, int C, int Cp, 
 // hidden = ELU(A1 x W1^T) for MF*16 rows starting at local row 0 (global position pos0 + row) -> a2[row][0:H]
 // rowpos(r) maps a local row to (tile index, position) -- supplied by the caller through lambdas.
 template <typename T, int MF, typename RowFn>
-__device__ __forceinline__ void mcf_gemm1(const McfParams& P, const McfGeom& g, RowFn rowfn, unsigned char* a2, int a2_pitch) {
+__device__ __forceinline__ void mcf_gemm1(const McfParams& P, const McfGeom& g, RowFn rowfn, const unsigned char* zrow,
+                                          unsigned char* a2, int a2_pitch) {
   constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, gq = lane >> 4;
   const int NF1 = (P.H + 15) >> 4;
-  const int ntaps = g.kh * g.kw;
   f32x4 acc[MF][4];
 #pragma unroll
   for (int i = 0; i < MF; ++i)
@@ -98,39 +119,29 @@ __device__ __forceinline__ void mcf_gemm1(const McfParams& P, const McfGeom& g, 
   const unsigned char* tile[MF]; int pos[MF];
 #pragma unroll
   for (int i = 0; i < MF; ++i) rowfn(i * 16 + r, tile[i], pos[i]);
-  int tap = (E16 * gq) / P.Cp, c = E16 * gq - tap * P.Cp;
   const T* W1 = reinterpret_cast<const T*>(P.W1);
   const int xpitch = P.Cp * (int)sizeof(T) + 16;
-  // Weight fragments stream from L2/HBM with ~1 us latency and nothing else to hide it (one workgroup per slice of a
-  // sample): keep a ring of PF K-steps of B fragments in flight.
-  constexpr int PF = 3;
-  const int nsteps = P.K1p / KS;
-  frag_t ring[PF][4];
-  auto load_b = [&](int st, frag_t* b) {
+  // K index = tap*Cp + c with Cp a multiple of the 64-byte K step: a step never straddles taps, so the six taps are
+  // unrolled statically (per-tap source rows resolved once: valid neighbour or the all-zero row) and only the
+  // channel loop is dynamic.  Keeps the per-step instruction count -- the real limiter with one wave per SIMD -- small.
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (wave + 4 * j < NF1) b[j] = load_wfrag<T>(W1, P.K1p, (wave + 4 * j) * 16 + r, st * KS + E16 * gq);
-  };
+  for (int tap = 0; tap < 6; ++tap) {
+    const unsigned char* src[MF];
 #pragma unroll
-  for (int d = 0; d < PF; ++d) if (d < nsteps) load_b(d, ring[d]);
-  for (int k0 = 0; k0 < nsteps; k0 += PF) {
+    for (int i = 0; i < MF; ++i) src[i] = tap_src_fwd(tile[i], zrow, xpitch, g, pos[i], tap) + E16 * gq * (int)sizeof(T);
+    for (int c = 0; c < P.Cp; c += KS) {
+      frag_t fa[MF], fb[4];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {
-      const int st = k0 + d;
-      if (st < nsteps) {
-        frag_t fa[MF];
+      for (int j = 0; j < 4; ++j)
+        if (wave + 4 * j < NF1) fb[j] = load_wfrag<T>(W1, P.K1p, (wave + 4 * j) * 16 + r, tap * P.Cp + c + E16 * gq);
 #pragma unroll
-        for (int i = 0; i < MF; ++i) fa[i] = gather_fwd<T>(tile[i], xpitch, g, pos[i], tap, c, ntaps);
-        c += KS;
-        while (c >= P.Cp) { c -= P.Cp; ++tap; }
+      for (int i = 0; i < MF; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + c * (int)sizeof(T));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (wave + 4 * j < NF1) {
+      for (int j = 0; j < 4; ++j) {
+        if (wave + 4 * j < NF1) {
 #pragma unroll
-            for (int i = 0; i < MF; ++i) mma64(fa[i], ring[d][j], acc[i][j]);
-          }
+          for (int i = 0; i < MF; ++i) mma64(fa[i], fb[j], acc[i][j]);
         }
-        if (st + PF < nsteps) load_b(st + PF, ring[d]);
       }
     }
   }
@@ -232,15 +243,17 @@ __global__ __launch_bounds__(256) void mcf_fwd_kernel(const McfParams P) {
   const int xs_pitch = P.Cp * (int)sizeof(T) + 16;
   const int a2_pitch = P.K2p * (int)sizeof(T) + 16;
   const int N2 = 2 * P.C;
-  unsigned char* xs = smem;
-  unsigned char* a2 = xs + 64 * xs_pitch;
+  unsigned char* xs = smem;                                    // 64 rows + one all-zero row
+  unsigned char* a2 = xs + 65 * xs_pitch;
   float* prm = reinterpret_cast<float*>(a2 + MT * a2_pitch);
 
   const float* xb = P.x + (long)b * 64 * P.ld;
   stage_x<T>(xb, P.ld, P.C, P.Cp, xs, xs_pitch);
+  for (int i = threadIdx.x; i < xs_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(xs + 64 * xs_pitch)[i] = 0u;
   fill_cond<T>(P, MT, [&](int row) { return (long)b * 64 + pos0 + row; }, a2, a2_pitch);
   __syncthreads();
-  mcf_gemm1<T, MF>(P, g, [&](int row, const unsigned char*& tile, int& pos) { tile = xs; pos = pos0 + row; }, a2, a2_pitch);
+  mcf_gemm1<T, MF>(P, g, [&](int row, const unsigned char*& tile, int& pos) { tile = xs; pos = pos0 + row; }, xs + 64 * xs_pitch,
+                   a2, a2_pitch);
   __syncthreads();
   if (P.a2_save) {
     constexpr int E16 = ET<T>::E16;
@@ -285,12 +298,12 @@ __global__ __launch_bounds__(256) void mcf_inv_kernel(const McfParams P) {
   const int xs_pitch = P.Cp * (int)sizeof(T) + 16;
   const int a2_pitch = P.K2p * (int)sizeof(T) + 16;
   const int N2 = 2 * P.C;
-  unsigned char* xs = smem;                                   // [2][64] rows of T
-  unsigned char* a2 = xs + 2 * 64 * xs_pitch;                 // [16] rows
+  unsigned char* xs = smem;                                   // [2][64] rows of T + one all-zero row
+  unsigned char* a2 = xs + 129 * xs_pitch;                    // [16] rows
   float* prm = reinterpret_cast<float*>(a2 + 16 * a2_pitch);  // [16][2C]
   float* xf = prm + 16 * N2;                                  // [2][64][C] exact reconstruction
 
-  for (int i = threadIdx.x; i < 2 * 64 * xs_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(xs)[i] = 0u;
+  for (int i = threadIdx.x; i < 129 * xs_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(xs)[i] = 0u;
   __syncthreads();
   const bool rows_first = P.order < 2, backwards = (P.order & 1);
   for (int step = 0; step < 8; ++step) {
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(256) void mcf_inv_kernel(const McfParams P) {
     }, a2, a2_pitch);
     mcf_gemm1<T, 1>(P, g, [&](int row, const unsigned char*& tile, int& pos) {
       tile = xs + (row >> 3) * 64 * xs_pitch; pos = strip_pos(row & 7);
-    }, a2, a2_pitch);
+    }, xs + 128 * xs_pitch, a2, a2_pitch);
     __syncthreads();
     mcf_gemm2<T, 1>(P, a2, a2_pitch, prm, N2);
     __syncthreads();
@@ -340,44 +353,80 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
   const int dp_pitch = P.K3p * (int)sizeof(T) + 16;
   const int dc_pitch = P.Hq * (int)sizeof(T) + 16;
   unsigned char* dp = smem;                                       // [64][K3p] T
-  unsigned char* dc = dp + 64 * dp_pitch;                         // [64][Hq]  T
-  float* dxd = reinterpret_cast<float*>(dc + 64 * dc_pitch);      // [64][C]   dy*scale
+  unsigned char* dc = dp + 64 * dp_pitch;                         // [64][Hq]  T + one all-zero row
+  float* dxd = reinterpret_cast<float*>(dc + 65 * dc_pitch);      // [64][C]   dy*scale
   float* colsum = dxd + 64 * P.C;                                 // [2C]
   const long row0 = (long)b * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
 
   for (int i = threadIdx.x; i < N2; i += blockDim.x) colsum[i] = 0.f;
-  for (int i = threadIdx.x; i < 64 * dc_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(dc)[i] = 0u;
+  for (int i = threadIdx.x; i < 65 * dc_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(dc)[i] = 0u;
   __syncthreads();
-  // (a) gradients of the coupling parameters
+  // (a) gradients of the coupling parameters.  Vector path: every thread owns 4-channel groups of one row, so dy / x /
+  // scale arrive as independent 16-byte loads and the column sums need one LDS atomic per channel and thread.
   const float g_ld = P.dld[b];
   T* dps = reinterpret_cast<T*>(P.dparams_save);
-  for (int e = threadIdx.x; e < 64 * P.K3p; e += blockDim.x) {
-    const int p = e / P.K3p, j = e - p * P.K3p;
-    float v = 0.f;
-    if (j < N2) {
-      const int c = j < P.C ? j : j - P.C;
-      const float gy = P.dy[(row0 + p) * P.ld + c];
-      const float sc = P.scale_save[(row0 + p) * P.C + c];
-      if (j < P.C) {
-        v = gy;
-        dxd[p * P.C + c] = gy * sc;
-      } else {
-        const float t = sc - 1.f;
-        v = (gy * P.x[(row0 + p) * P.ld + c] + g_ld / sc) * 0.5f * (1.f - t * t);
+  typedef typename Pack4<T>::type pack_t;
+  if ((P.C & 3) == 0 && (P.ld & 3) == 0) {
+    const int G4 = P.C >> 2;                                   // 4-channel groups per row
+    for (int e = threadIdx.x; e < 64 * G4; e += blockDim.x) {
+      const int p = e / G4, c = (e - p * G4) * 4;
+      const f32x4 gy = *reinterpret_cast<const f32x4*>(P.dy + (row0 + p) * P.ld + c);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(P.x + (row0 + p) * P.ld + c);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(P.scale_save + (row0 + p) * P.C + c);
+      f32x4 ds, dxv;
+      pack_t tm, ts;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float t = sc[q] - 1.f;
+        ds[q] = (gy[q] * xv[q] + g_ld / sc[q]) * 0.5f * (1.f - t * t);
+        dxv[q] = gy[q] * sc[q];
+        tm[q] = ET<T>::from_f32(gy[q]); ts[q] = ET<T>::from_f32(ds[q]);
+        atomicAdd(&colsum[c + q], gy[q]);
+        atomicAdd(&colsum[P.C + c + q], ds[q]);
       }
-      atomicAdd(&colsum[j], v);
+      *reinterpret_cast<f32x4*>(dxd + p * P.C + c) = dxv;
+      *reinterpret_cast<pack_t*>(dp + p * dp_pitch + c * (int)sizeof(T)) = tm;
+      *reinterpret_cast<pack_t*>(dp + p * dp_pitch + (P.C + c) * (int)sizeof(T)) = ts;
+      if (dps) {
+        *reinterpret_cast<pack_t*>(dps + (row0 + p) * P.K3p + c) = tm;
+        *reinterpret_cast<pack_t*>(dps + (row0 + p) * P.K3p + P.C + c) = ts;
+      }
     }
-    const T tv = ET<T>::from_f32(v);
-    *reinterpret_cast<T*>(dp + p * dp_pitch + j * (int)sizeof(T)) = tv;
-    if (dps) dps[(row0 + p) * P.K3p + j] = tv;
+    const int padc = P.K3p - N2;                               // zero the K padding (LDS tile and saved tensor)
+    for (int e = threadIdx.x; e < 64 * padc; e += blockDim.x) {
+      const int p = e / padc, j = N2 + e - p * padc;
+      *reinterpret_cast<T*>(dp + p * dp_pitch + j * (int)sizeof(T)) = (T)0.f;
+      if (dps) dps[(row0 + p) * P.K3p + j] = (T)0.f;
+    }
+  } else {
+    for (int e = threadIdx.x; e < 64 * P.K3p; e += blockDim.x) {
+      const int p = e / P.K3p, j = e - p * P.K3p;
+      float v = 0.f;
+      if (j < N2) {
+        const int c = j < P.C ? j : j - P.C;
+        const float gy = P.dy[(row0 + p) * P.ld + c];
+        const float sc = P.scale_save[(row0 + p) * P.C + c];
+        if (j < P.C) {
+          v = gy;
+          dxd[p * P.C + c] = gy * sc;
+        } else {
+          const float t = sc - 1.f;
+          v = (gy * P.x[(row0 + p) * P.ld + c] + g_ld / sc) * 0.5f * (1.f - t * t);
+        }
+        atomicAdd(&colsum[j], v);
+      }
+      const T tv = ET<T>::from_f32(v);
+      *reinterpret_cast<T*>(dp + p * dp_pitch + j * (int)sizeof(T)) = tv;
+      if (dps) dps[(row0 + p) * P.K3p + j] = tv;
+    }
   }
   __syncthreads();
   if (P.dbias_part)
     for (int i = threadIdx.x; i < N2; i += blockDim.x) P.dbias_part[(long)b * N2 + i] = colsum[i];
 
   // (b) dA2[:, :H] = dparams x W2[:, :H]  , times ELU'(c) -> dc
-  {
+  if (P.dbg != 2 && P.dbg != 4) {
     const int NF = (P.H + 15) >> 4;
     f32x4 acc[4][4];
 #pragma unroll
@@ -423,13 +472,13 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int p = i * 16 + r;
+          const pack_t cact = *reinterpret_cast<const pack_t*>(a2s + (row0 + p) * P.K2p + n);    // K2p, n multiples of 4
+          pack_t tv;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float cact = ET<T>::to_f32(a2s[(row0 + p) * P.K2p + n + q]);
-            const T tv = ET<T>::from_f32(acc[i][j][q] * act_grad_from_out(IPOKE_ACT_ELU, cact));
-            *reinterpret_cast<T*>(dc + p * dc_pitch + (n + q) * (int)sizeof(T)) = tv;
-            if (dcs) dcs[(row0 + p) * P.Hq + n + q] = tv;
-          }
+          for (int q = 0; q < 4; ++q)
+            tv[q] = ET<T>::from_f32(acc[i][j][q] * act_grad_from_out(IPOKE_ACT_ELU, ET<T>::to_f32(cact[q])));
+          *reinterpret_cast<pack_t*>(dc + p * dc_pitch + n * (int)sizeof(T)) = tv;
+          if (dcs) *reinterpret_cast<pack_t*>(dcs + (row0 + p) * P.Hq + n) = tv;
         }
       }
     }
@@ -444,7 +493,7 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
   __syncthreads();
 
   // (c) dx = dy*scale + sum_tap dc[p - off(tap)] x W1[:, tap, :]
-  {
+  if (P.dbg != 3 && P.dbg != 4) {
     const int NF = (P.C + 15) >> 4;       // <= 4: one fragment column per wave
     f32x4 acc[4];
 #pragma unroll
@@ -453,26 +502,20 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
     const int Ktot = ntaps * P.Hq;
     const T* W1T = reinterpret_cast<const T*>(P.W1T);
     if (wave < NF) {
-      int tap = 0, c = E16 * gq;           // Hq is a multiple of KS: a super-step never straddles taps
-      constexpr int PF = 8;
-      const int nsteps = Ktot / KS;
-      frag_t ring[PF];
+      // Hq is a multiple of the K step: taps unrolled statically, source rows (or the zero row) resolved once per tap
+      const unsigned char* zrow = dc + 64 * dc_pitch;
 #pragma unroll
-      for (int d = 0; d < PF; ++d) if (d < nsteps) ring[d] = load_wfrag<T>(W1T, Ktot, wave * 16 + r, d * KS + E16 * gq);
-      for (int k0 = 0; k0 < nsteps; k0 += PF) {
+      for (int tap = 0; tap < 6; ++tap) {
+        const unsigned char* src[4];
 #pragma unroll
-        for (int d = 0; d < PF; ++d) {
-          const int st = k0 + d;
-          if (st < nsteps) {
-            frag_t fa[4];
+        for (int i = 0; i < 4; ++i) src[i] = tap_src_adj(dc, zrow, dc_pitch, g, i * 16 + r, tap) + E16 * gq * (int)sizeof(T);
+        for (int c = 0; c < P.Hq; c += KS) {
+          const frag_t fb = load_wfrag<T>(W1T, Ktot, wave * 16 + r, tap * P.Hq + c + E16 * gq);
+          frag_t fa[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = gather_adj<T>(dc, dc_pitch, g, i * 16 + r, tap, c);
-            c += KS;
-            if (c >= P.Hq) { c -= P.Hq; ++tap; }
+          for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + c * (int)sizeof(T));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mma64(fa[i], ring[d], acc[i]);
-            if (st + PF < nsteps) ring[d] = load_wfrag<T>(W1T, Ktot, wave * 16 + r, (st + PF) * KS + E16 * gq);
-          }
+          for (int i = 0; i < 4; ++i) mma64(fa[i], fb, acc[i]);
         }
       }
       const int n = wave * 16 + 4 * gq;
@@ -510,8 +553,8 @@ static int fill_params(McfParams& P, const ipoke_mcf_desc* d, int dtype) {
   P.x = d->x; P.y = d->y; P.ld = d->ld; P.C = d->C; P.B = d->B;
   P.cond = d->cond; P.Cc = d->Cc;
   P.H = 4 * d->C;
-  P.Cp = round_up(d->C, e16);
-  P.K1p = round_up(6 * P.Cp, ks);
+  P.Cp = round_up(d->C, ks);          // channels per tap padded to the 64-byte K step
+  P.K1p = 6 * P.Cp;
   P.K2p = round_up(P.H + d->Cc, ks);
   P.K3p = round_up(2 * d->C, ks);
   P.Hq = round_up(P.H, ks);
@@ -520,6 +563,7 @@ static int fill_params(McfParams& P, const ipoke_mcf_desc* d, int dtype) {
   P.a2_save = d->a2_save; P.scale_save = d->scale_save; P.ld_slot = d->logdet_slot;
   P.W2T = d->W2T; P.W1T = d->W1T; P.dy = d->dy; P.dld = d->dld; P.dx = d->dx;
   P.dparams_save = d->dparams_save; P.dc_save = d->dc_save; P.dbias_part = d->dbias_part;
+  { static const int dbg = getenv("IPOKE_MCF_ABLATE") ? atoi(getenv("IPOKE_MCF_ABLATE")) : 0; P.dbg = dbg; }
   return IPOKE_OK;
 }
 
@@ -530,9 +574,9 @@ using namespace ipoke;
 extern "C" int ipoke_mcf_shadow_dims(int C, int Cc, int dtype, int32_t* dims8) {
   IPK_REQUIRE(dims8 && (dtype == IPOKE_BF16 || dtype == IPOKE_F32), "bad arguments");
   const int esz = dtype == IPOKE_BF16 ? 2 : 4, e16 = 16 / esz, ks = 64 / esz;
-  const int H = 4 * C, Cp = round_up(C, e16);
-  dims8[0] = Cp;                       // channels per tap in K1
-  dims8[1] = round_up(6 * Cp, ks);     // K1p
+  const int H = 4 * C, Cp = round_up(C, ks);
+  dims8[0] = Cp;                       // channels per tap in K1 (padded to the 64-byte K step)
+  dims8[1] = 6 * Cp;                   // K1p
   dims8[2] = round_up(H + Cc, ks);     // K2p
   dims8[3] = round_up(2 * C, ks);      // K3p
   dims8[4] = round_up(H, ks);          // Hq
@@ -549,7 +593,7 @@ extern "C" int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int esz = dtype == IPOKE_BF16 ? 2 : 4;
   // rows per workgroup: a full sample when LDS allows it, else half
-  auto lds_bytes = [&](int MT) { return (size_t)64 * (P.Cp * esz + 16) + (size_t)MT * (P.K2p * esz + 16) + (size_t)MT * 2 * P.C * 4; };
+  auto lds_bytes = [&](int MT) { return (size_t)65 * (P.Cp * esz + 16) + (size_t)MT * (P.K2p * esz + 16) + (size_t)MT * 2 * P.C * 4; };
   int MT = d->rows_per_block > 0 ? d->rows_per_block : (dtype == IPOKE_BF16 ? 32 : 16);
   IPK_REQUIRE(MT == 16 || MT == 32 || MT == 64, "rows_per_block must be 16, 32 or 64");
   const size_t lds = lds_bytes(MT);
@@ -576,7 +620,7 @@ extern "C" int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream) {
   int rc = fill_params(P, d, dtype); if (rc) return rc;
   P.a2_save = nullptr; P.scale_save = nullptr; P.ld_slot = nullptr;
   const int esz = dtype == IPOKE_BF16 ? 2 : 4;
-  const size_t lds = (size_t)128 * (P.Cp * esz + 16) + (size_t)16 * (P.K2p * esz + 16) + (size_t)16 * 2 * P.C * 4 +
+  const size_t lds = (size_t)129 * (P.Cp * esz + 16) + (size_t)16 * (P.K2p * esz + 16) + (size_t)16 * 2 * P.C * 4 +
                      (size_t)128 * P.C * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16) {
@@ -595,7 +639,7 @@ extern "C" int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   McfParams P;
   int rc = fill_params(P, d, dtype); if (rc) return rc;
   const int esz = dtype == IPOKE_BF16 ? 2 : 4;
-  const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)64 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4;
+  const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)65 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4;
   IPK_REQUIRE(lds <= 158 * 1024, "MCF backward tile does not fit LDS");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16) {
