@@ -503,7 +503,15 @@ def g6_g7_glue():
         assert abs(l.item() - losses[step]) < 1e-3 * max(1.0, abs(losses[step])), (l.item(), losses[step])
     npz("g6_glue_64", **arrs)
 
-    # G7: sampling with an injected latent
+    # G7: sampling with an injected latent.  Fresh name-keyed weights; the weight-norm gains are scaled down so that the
+    # analytic inverse of the randomly filled flow stays well conditioned (a reverse pass from z ~ N(0,1) through random,
+    # unscaled couplings overflows in the reference itself).
+    g_scale = 0.3
+    deterministic_fill_(M.flow, prefix="flow.")
+    with torch.no_grad():
+        for k, v in M.flow.state_dict().items():
+            if k.endswith("weight_g"):
+                v.mul_(g_scale)
     zs = rn((2, 32, 8, 8), 55)
     real_randn = torch.randn
     torch.randn = lambda *a, **k: zs.clone()
@@ -513,8 +521,13 @@ def g6_g7_glue():
         torch.randn = real_randn
     with torch.no_grad():
         motion = M.flow(zs, cond, reverse=True)
+    assert torch.isfinite(motion).all() and torch.isfinite(vids[0]).all()
+    O7 = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch)); O7.load_state_dict(M.flow.state_dict())
+    with torch.no_grad():
+        close(O7(zs, cond, reverse=True), motion, 1e-4, "G7 reverse")
+    print(f"  G7 motion max {motion.abs().max().item():.2f}")
     npz("g7_sample_64", z=zs, motion=motion, video=vids[0][:, :4], video_checksum=checksum(vids[0], "video"),
-        video_shape=np.array(vids[0].shape))
+        video_shape=np.array(vids[0].shape), g_scale=g_scale)
 
 
 def main(which):

@@ -1,0 +1,135 @@
+"""GPU parity at full size (1.05 B-parameter flow, G3) and of the glue: Adam-amsgrad steps (G6) and sampling (G7)."""
+import copy
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from ipoke_amd import configs
+from ipoke_amd.utils.detfill import deterministic_fill_
+from tests.conftest import t
+
+pytestmark = pytest.mark.gpu
+
+
+def checksum(x, key):
+    x = x.detach().double().flatten().cpu()
+    g = torch.Generator().manual_seed(zlib.crc32(key.encode()))
+    idx = torch.randint(0, x.numel(), (3,), generator=g)
+    return np.array([x.sum().item(), x.abs().sum().item(), *x[idx].tolist()])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_size_flow_z32(golden, dtype):
+    """Full shipped topology (iper_128 / plants_64 flow: z = 32, 2048 hidden, 1 054 426 620 parameters)."""
+    from ipoke_amd.flow import SupervisedMacowTransformer
+    g = golden("g3_full_flow_z32")
+    m = SupervisedMacowTransformer(configs.flow_arch(32), dtype=dtype, device="cuda", init="none", max_batch=8)
+    deterministic_fill_(m, prefix="flow.")
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("weight_g"):
+                p.mul_(float(g["g_scale"]))
+        sd = m.state_dict()
+        for k in g:
+            if k.startswith("actnorm."):
+                sd[k[len("actnorm."):]].copy_(t(g[k], "cuda"))
+    m.sync_buffers()
+    x, cond = t(g["x"], "cuda"), t(g["cond"], "cuda")
+    m.train()
+    out, logdet = m(x, cond)
+    e_out = (out.detach().cpu() - t(g["out"])).abs().max().item()
+    e_ld = ((logdet.detach().cpu() - t(g["logdet"])).abs() / t(g["logdet"]).abs()).max().item()
+    print(f"[{dtype}] full flow: out err {e_out:.3e} (|out| max {np.abs(g['out']).max():.2f}), logdet rel err {e_ld:.3e}")
+    # 1 530 chained layers; SURVEY.md: f32 <= 4x(1e-5 abs, 1e-3 abs on logdet ~ 1e4); bf16 nets: 2e-2 / 0.5 %
+    assert e_out <= (2e-4 if dtype == "f32" else 6e-2) and e_ld <= (2e-6 if dtype == "f32" else 5e-3)
+    loss = (0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()
+    assert abs(loss.item() - float(g["loss"])) <= (2e-2 if dtype == "f32" else 0.005 * abs(float(g["loss"])))
+    loss.backward()
+    names = g["grad_names"].tolist()
+    ref = g["grad_checksums"]
+    grads = dict(m.named_parameters())
+    worst = 0.0
+    for i in range(0, len(names), 7):                    # every 7th tensor (~430 of 3 000): sums and sampled elements
+        k = names[i]
+        cs = checksum(grads[k].grad, k)
+        scale = max(ref[i][1] / grads[k].numel(), 1e-9)       # mean |grad|
+        err = max(abs(cs[0] - ref[i][0]) / max(ref[i][1], 1e-9), np.abs(cs[2:] - ref[i][2:]).max() / (scale * 50))
+        worst = max(worst, err)
+    print(f"[{dtype}] full flow: worst gradient checksum error {worst:.3e}")
+    assert worst <= (2e-3 if dtype == "f32" else 8e-2)
+    with torch.no_grad():
+        rev = m(t(g["out"], "cuda"), cond, reverse=True)
+    e_rev = (rev.cpu() - t(g["reverse"])).abs().max().item()
+    print(f"[{dtype}] full flow: reverse err {e_rev:.3e}")
+    assert e_rev <= (2e-3 if dtype == "f32" else 0.15)
+
+
+def _glue_model(dtype):
+    from ipoke_amd.second_stage import PokeMotionModel
+    arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+    arch["flow_mid_channels_factor"] = 2
+    conf = configs.second_stage_config(64, 32, 16, batch_size=2, arch=arch)
+    m = PokeMotionModel(conf, dirs={}, dtype=dtype, device="cuda", max_batch=2)
+    deterministic_fill_(m.first_stage_model, prefix="first_stage.")
+    deterministic_fill_(m.poke_embedder, prefix="poke_embedder.")
+    deterministic_fill_(m.conditioner, prefix="conditioner.")
+    deterministic_fill_(m.flow, prefix="flow.")
+    m.flow.sync_buffers()
+    return m
+
+
+def test_training_steps_adam_amsgrad(golden):
+    """Two optimisation steps (flow fwd, FlowLoss, bwd, fused Adam-amsgrad with weight decay) vs torch.optim.Adam on the
+    reference: losses and per-tensor parameter checksums after each step."""
+    from ipoke_amd.optim import FusedAdamAmsgrad
+    g = golden("g6_glue_64")
+    m = _glue_model("f32")
+    flow_input, cond = t(g["flow_input"], "cuda"), t(g["cond"], "cuda")
+    opt = FusedAdamAmsgrad(m.flow, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5, amsgrad=True)
+    m.flow.train()
+    names = g["param_names"].tolist()
+    for step in range(2):
+        out, logdet = m.flow(flow_input, cond)
+        if step == 0:
+            assert (out.detach().cpu() - t(g["out"])).abs().max() <= 1e-4
+        loss, log = m.loss_func(out, logdet)
+        assert abs(loss.item() - float(g["losses"][step])) <= 2e-3 * max(1.0, abs(float(g["losses"][step])))
+        loss.backward()
+        opt.step()
+        ref = g[f"param_checksums_step{step + 1}"]
+        params = dict(m.flow.named_parameters())
+        for i, k in enumerate(names):
+            cs = checksum(params[k], k)
+            assert abs(cs[0] - ref[i][0]) <= 2e-4 * max(ref[i][1], 1e-3), (step, k, cs, ref[i])
+            assert np.abs(cs[2:] - ref[i][2:]).max() <= 2e-4 * max(np.abs(ref[i][2:]).max(), 1e-2), (step, k)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_forward_sample_with_injected_latent(golden, dtype):
+    """forward_sample: reverse flow + GRU/SPADE decode of an injected z (the reference's torch.randn is patched)."""
+    from tests.helpers import synthetic_batch
+    g6, g7 = golden("g6_glue_64"), golden("g7_sample_64")
+    m = _glue_model(dtype)
+    with torch.no_grad():
+        for k, p in m.flow.named_parameters():
+            if k.endswith("weight_g"):
+                p.mul_(float(g7["g_scale"]))
+    m.flow.mark_weights_updated()
+    batch = synthetic_batch(2, 16, 64, device="cuda")
+    z = t(g7["z"])
+    real = torch.randn
+    torch.randn = lambda *a, **k: z.clone()
+    try:
+        vids = m.forward_sample(batch, n_samples=1, n_logged_vids=2)
+    finally:
+        torch.randn = real
+    assert tuple(vids[0].shape) == tuple(g7["video_shape"]) and vids[0].device.type == "cpu"
+    with torch.no_grad():
+        motion = m.flow(z.cuda(), t(g6["cond"], "cuda"), reverse=True)
+    e_m = (motion.cpu() - t(g7["motion"])).abs().max().item()
+    e_v = (vids[0][:, :4] - t(g7["video"])).abs()
+    print(f"[{dtype}] sample: motion err {e_m:.3e}, video max err {e_v.max().item():.3e} mean {e_v.mean().item():.3e}")
+    assert e_m <= (1e-4 if dtype == "f32" else 0.1)
+    assert e_v.max().item() <= (5e-4 if dtype == "f32" else 0.2) and e_v.mean().item() <= (2e-5 if dtype == "f32" else 2e-2)

@@ -1,0 +1,164 @@
+"""CPU: the oracle (oracle/flow_ref.py, oracle/vae_ref.py) against the golden vectors generated from the REFERENCE's own
+modules (oracle/make_goldens.py).  This is what pins the oracle; tolerances are those of SURVEY.md §8c."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from ipoke_amd import configs
+from ipoke_amd.utils.detfill import deterministic_fill_, fill_value
+from oracle import flow_ref, vae_ref
+from tests.conftest import t
+
+
+@pytest.mark.parametrize("C", [8, 32])
+def test_unit_layers(golden, C):
+    g = golden("g1_flow_units")
+    x, h = t(g[f"x_{C}"]), t(g[f"h_{C}"])
+    # ActNorm: data-dependent init from the reference's pre-init draw, forward, inverse
+    an = flow_ref.ActNorm2dFlow(C)
+    with torch.no_grad():
+        an.log_scale.copy_(t(g[f"actnorm_{C}_pre_log_scale"]))
+    y, ld = an(t(g[f"actnorm_{C}_init_x"]))
+    assert (an.log_scale - t(g[f"actnorm_{C}_post_log_scale"])).abs().max() < 1e-6
+    assert (y - t(g[f"actnorm_{C}_y"])).abs().max() < 1e-6 and (ld - t(g[f"actnorm_{C}_logdet"])).abs().max() < 1e-4
+    assert (an(y, reverse=True) - t(g[f"actnorm_{C}_inv"])).abs().max() < 1e-6
+    # Shuffle: bit exact, indices are int64 buffers, argsort relation
+    sh = flow_ref.Shuffle(C)
+    deterministic_fill_(sh, prefix=f"shuffle{C}.")
+    assert sh.forward_shuffle_idx.dtype == torch.int64
+    assert torch.equal(sh.forward_shuffle_idx, t(g[f"shuffle_{C}_fwd_idx"]))
+    assert torch.equal(sh.backward_shuffle_idx, torch.argsort(sh.forward_shuffle_idx))
+    ys, zero = sh(x)
+    assert zero == 0 and torch.equal(ys, t(g[f"shuffle_{C}_y"])) and torch.equal(sh(ys, reverse=True), x)
+    # affine transform
+    mu, sc = flow_ref.affine_params(t(g[f"affine_{C}_raw"]))
+    ya, la = flow_ref.affine_fwd(x, mu, sc)
+    assert (ya - t(g[f"affine_{C}_y"])).abs().max() < 1e-6 and (la - t(g[f"affine_{C}_logdet"])).abs().max() < 1e-4
+    assert (flow_ref.affine_inv(ya, mu, sc) - t(g[f"affine_{C}_inv"])).abs().max() < 1e-6
+    for order, ks in (("A", (2, 3)), ("B", (2, 3)), ("C", (3, 2)), ("D", (3, 2))):
+        sconv = flow_ref.ShiftedConv2d(C, 4 * C, ks, order)
+        deterministic_fill_(sconv, prefix=f"sc{C}{order}.")
+        assert (sconv(x) - t(g[f"shiftconv_{C}_{order}"])).abs().max() < 1e-5
+        m = flow_ref.MaskedConvFlow(C, ks, order, 128)
+        deterministic_fill_(m, prefix=f"mcf{C}{order}.")
+        xg = x.clone().requires_grad_(True)
+        ym, lm = m(xg, h=h)
+        assert (ym - t(g[f"mcf_{C}_{order}_y"])).abs().max() < 1e-5
+        assert (lm - t(g[f"mcf_{C}_{order}_logdet"])).abs().max() < 1e-4
+        assert (m(ym.detach(), h=h, reverse=True) - t(g[f"mcf_{C}_{order}_inv"])).abs().max() < 1e-5
+        (0.5 * (ym ** 2).sum() - lm.sum()).backward()
+        for name, grad in (("dx", xg.grad), ("dshift", m.net.shift_conv.weight.grad), ("dv", m.net.conv1x1.conv.weight_v.grad),
+                           ("dg", m.net.conv1x1.conv.weight_g.grad), ("db", m.net.conv1x1.conv.bias.grad)):
+            ref = t(g[f"mcf_{C}_{order}_{name}"])
+            assert (grad - ref).abs().max() <= 1e-4 * (1 + ref.abs().max()), (order, name)
+        # autoregressive property: output row i of order A does not depend on input rows >= i
+        if order == "A":
+            x2 = x.clone(); x2[:, :, 4:] += 1.0
+            y2, _ = m(x2, h=h)
+            # the affine transform multiplies x itself, so compare the *parameters* through rows above the change
+            assert torch.allclose((y2 - ym)[:, :, :4], torch.zeros_like(ym[:, :, :4]), atol=1e-6)
+    for split in ("continuous", "skip"):
+        for order in ("up", "down"):
+            tag = f"nice_{C}_{split}_{order}"
+            n = flow_ref.NICE2d(C, 64, split, order)
+            deterministic_fill_(n, prefix=tag + ".")
+            yn, ln = n(x)
+            assert (yn - t(g[tag + "_y"])).abs().max() < 1e-5 and (ln - t(g[tag + "_logdet"])).abs().max() < 1e-4
+            assert (n(yn, reverse=True) - t(g[tag + "_inv"])).abs().max() < 1e-5
+    pr = flow_ref.MultiScalePrior(C, 64, 4)
+    deterministic_fill_(pr, prefix=f"prior{C}.")
+    yp, lp = pr(x, h=h)
+    assert (yp - t(g[f"prior_{C}_y"])).abs().max() < 1e-5 and (lp - t(g[f"prior_{C}_logdet"])).abs().max() < 1e-4
+    assert (pr(yp, h=h, reverse=True) - t(g[f"prior_{C}_inv"])).abs().max() < 1e-5
+
+
+def test_reduced_flow_full_topology(golden):
+    g = golden("g2_reduced_flow")
+    o = flow_ref.SupervisedMacowTransformer(configs.reduced_flow_arch())
+    deterministic_fill_(o, prefix="flow.")
+    x, cond = t(g["x"]), t(g["cond"])
+    out, logdet = o(x, cond)
+    assert (out - t(g["out"])).abs().max() <= 2e-5 and (logdet - t(g["logdet"])).abs().max() <= 1e-3
+    assert (o(out.detach(), cond, reverse=True) - t(g["reverse"])).abs().max() <= 5e-5
+    torch.manual_seed(1234)
+    loss, log = flow_ref.FlowLoss()(out, logdet)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-3
+    assert abs(log["reference_nll_loss"].item() - float(g["reference_nll_loss"])) <= 1e-4      # same RNG consumption
+    loss.backward()
+    for k, p in o.named_parameters():
+        ref = t(g["grad." + k])
+        assert (p.grad - ref).abs().max() <= 1e-4 * (ref.abs().max() + 1e-6), k
+
+
+def test_identity_at_init_and_data_init(golden):
+    """Known answers: after the initialising forward every coupling is the identity; logdet = 64 * sum log_scale."""
+    g = golden("g2_reduced_flow_init")
+    o = flow_ref.SupervisedMacowTransformer(configs.reduced_flow_arch())
+    sd = o.state_dict()
+    big = set(g["big_keys"].tolist())
+    with torch.no_grad():
+        for k, v in sd.items():
+            v.copy_(fill_value("flow." + k, v) if k in big else t(g["pre." + k]))
+    with torch.no_grad():
+        out, logdet = o(t(g["x"]), t(g["cond"]))
+    assert (out - t(g["out_filled"])).abs().max() <= 1e-5 and (logdet - t(g["logdet_filled"])).abs().max() <= 1e-3
+    assert (logdet - logdet[0]).abs().max() < 1e-4                       # batch independent
+    ls_sum = sum(v.sum() for k, v in o.state_dict().items() if k.endswith("log_scale"))
+    assert abs(float(ls_sum) * 64 - float(logdet[0])) <= 1e-2
+    for k, v in o.state_dict().items():
+        if k.endswith("weight_g"):
+            assert float(v.abs().max()) == 0.0
+        if k.endswith("initialized"):
+            assert int(v) == 1
+
+
+def test_flow_loss_known_answers():
+    fl = flow_ref.FlowLoss()
+    z = torch.zeros(3, 4, 8, 8)
+    assert fl(z, torch.zeros(3))[0].item() == 0.0
+    assert abs(fl(torch.ones(3, 4, 8, 8), torch.zeros(3))[0].item() - 0.5 * 4 * 64) < 1e-4
+    with pytest.raises(AssertionError):
+        fl(z, torch.zeros(3, 1))                       # reference asserts len(logdet.shape) == 1 (loss.py:15)
+
+
+def test_lr_schedule(golden):
+    g = golden("g6_glue_64")
+    for it, lr in zip(g["lr_its"], g["lr_vals"]):
+        assert abs(flow_ref.lr_at(int(it)) - float(lr)) < 1e-12
+
+
+def test_motion_encoder_and_decoder(golden):
+    g4, g5 = golden("g4_encoder_64"), golden("g5_decoder_64")
+    m = vae_ref.SpadeCondMotionModel(configs.first_stage_config(64, 32, 16)).eval()
+    deterministic_fill_(m, prefix="first_stage.")
+    with torch.no_grad():
+        z, mu, lv = m.enc_motion(t(g4["X"]).transpose(1, 2), eps=t(g4["eps"]))
+        frames = m.decode(t(g5["z"]), t(g5["x0"]), 3)
+    assert (mu - t(g4["mu"])).abs().max() <= 2e-5 and (lv - t(g4["logvar"])).abs().max() <= 2e-5
+    assert (z - t(g4["z"])).abs().max() <= 2e-5
+    assert (frames - t(g5["frames"])).abs().max() <= 5e-5
+
+
+def test_spectral_norm_train_mode_power_iteration(golden):
+    g = golden("g5_spectral_train")
+    m = vae_ref.SpadeCondMotionModel(configs.first_stage_config(64, 32, 16)).eval()
+    deterministic_fill_(m, prefix="first_stage.")
+    blk = m.gen.blocks[0].conv1
+    assert torch.allclose(blk.conv.weight_u, t(g["u0"]))
+    blk.conv.spectral_power_iter()
+    assert (blk.conv.weight_u - t(g["u1"])).abs().max() < 1e-5 and (blk.conv.weight_v - t(g["v1"])).abs().max() < 1e-5
+    with torch.no_grad():
+        y = blk(t(g["x"]))
+    assert (y - t(g["y"])).abs().max() <= 2e-5 * max(1.0, float(np.abs(g["y"]).max()))
+
+
+def test_first_stage_l1_kl_training_slice(golden):
+    g = golden("g5_first_stage_train_64")
+    m = vae_ref.SpadeCondMotionModel(configs.first_stage_config(64, 32, 4)).eval()
+    deterministic_fill_(m, prefix="first_stage.")
+    X = t(g["X"])
+    Xh, mu, lv = m(X, eps=t(g["eps"]))
+    loss = vae_ref.first_stage_loss(X, Xh, mu, lv)
+    assert (Xh - t(g["X_hat"])).abs().max() <= 5e-5 and abs(loss.item() - float(g["loss"])) <= 1e-4
