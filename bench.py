@@ -93,11 +93,28 @@ def kernel_roofline(B, dtype, iters=50):
             "algorithmic_gflop_per_launch": round(flops / 1e9, 3)}
 
 
+def usable_cores():
+    """Host cores this process may actually use: CPU affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(cfg, clips=1, seed=1):
     """The CPU oracle doing the same optimisation step on `clips` clips of the same workload (bounded sample)."""
     from oracle import flow_ref, vae_ref
     from ipoke_amd.utils.detfill import deterministic_fill_
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     # identity-initialised couplings produce exact zeros / subnormals in the backward pass; without flush-to-zero the
     # x86 microcode path makes the same arithmetic ~25x slower (measured: 725 s vs 29 s per step on 8 cores)
@@ -153,7 +170,7 @@ def cpu_baseline_subprocess(config, clips, timeout_s):
         return {"value": None, "unit": "video-frames/sec", "cores": None, "kind": "port",
                 "sample": "cpu leg failed: " + (out.stderr.strip().splitlines() or ["?"])[-1][:200]}
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "video-frames/sec", "cores": os.cpu_count(), "kind": "port",
+        return {"value": None, "unit": "video-frames/sec", "cores": usable_cores(), "kind": "port",
                 "sample": f"cpu leg exceeded {timeout_s}s for {clips} clip(s); lower bound {clips * 16 / timeout_s:.4f} frames/s not reached"}
 
 
