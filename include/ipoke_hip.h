@@ -96,7 +96,8 @@ typedef struct {
   const void* dY; int32_t ldy; int32_t y_coff; int32_t Nout;
   float* dW; int64_t w_sn, w_sc, w_st;   /* strides of out-channel n, in-channel c, tap */
   int32_t accumulate;                    /* 1: dW += */
-  int32_t splitm;                        /* >1: reduction split over gridDim.z with fp32 atomics (dW must be pre-zeroed or accumulate) */
+  int32_t splitm;                        /* >1: reduction split over gridDim.y with fp32 atomics (dW must be pre-zeroed or accumulate) */
+  int32_t Kc_store;                      /* channels per tap written to dW (0: Kc_real); < Kc_real when A carries zero padding */
 } ipoke_wgrad_desc;
 
 int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream);
@@ -113,6 +114,9 @@ int ipoke_conv_wgrad_batched(const ipoke_wgrad_desc* d, const void* entries_dev,
 int ipoke_nchw_to_state(const float* x_nchw, float* state, int B, int C, int P, int ld, void* stream);
 int ipoke_state_to_nchw(const float* state, float* x_nchw, int B, int C, int P, int ld, void* stream);
 /* act(cond) in dtype, channels-last: shared input of all MCF 1x1 convs (macow_utils.py:429-431) */
+/* dense, zero-padded dtype copy of `C` state channels starting at `off` with stride `stride` (NICE split, macow2.py:364-375) */
+int ipoke_extract_cols(const float* state, int ld, int off, int stride, int C, void* out, int ldo, int64_t M, int dtype,
+                       void* stream);
 int ipoke_cond_prepare(const float* cond_nchw, void* out, int B, int Cc, int P, int act, int dtype, void* stream);
 
 /* ActNorm2dFlow (macow2.py:476-540) optionally fused with the Shuffle that follows it

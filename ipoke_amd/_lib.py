@@ -37,7 +37,7 @@ class WgradDesc(Structure):
         ("a_coff", c_int32), ("Kc_real", c_int32), ("Kc", c_int32),
         ("dY", c_void_p), ("ldy", c_int32), ("y_coff", c_int32), ("Nout", c_int32),
         ("dW", c_void_p), ("w_sn", c_int64), ("w_sc", c_int64), ("w_st", c_int64),
-        ("accumulate", c_int32), ("splitm", c_int32)]
+        ("accumulate", c_int32), ("splitm", c_int32), ("Kc_store", c_int32)]
 
 
 class AffineDesc(Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "ipoke_reduce_rows_multi": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "ipoke_nchw_to_state": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_state_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_extract_cols": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int64, c_int, _P]),
     "ipoke_cond_prepare": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_actnorm_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "ipoke_actnorm_inv": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -41,6 +41,18 @@ __global__ void cond_prepare_kernel(const float* __restrict__ h, T* __restrict__
   }
 }
 
+// out[m][j] = T(state[m][off + j*stride]) for j < C, zero for C <= j < ldo  (conditioning channels of a NICE coupling,
+// continuous or even/odd "skip" split: macow2.py:364-375) -- gives the coupling net a dense, padded operand.
+template <typename T>
+__global__ void extract_cols_kernel(const float* __restrict__ s, int ld, int off, int stride, int C, T* __restrict__ out, int ldo,
+                                    long M) {
+  const long total = M * ldo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / ldo; const int j = (int)(i - m * ldo);
+    out[i] = ET<T>::from_f32(j < C ? s[m * ld + off + (long)j * stride] : 0.f);
+  }
+}
+
 // ------------------------------------------------------------------ ActNorm (+ Shuffle)
 // out[m][c0 + j] = in[m][c0 + idx[j]] * exp(ls[idx[j]]) + bias[idx[j]]   (idx == NULL: identity)
 // ls/bias == NULL: pure permutation.  Columns outside [c0, c0+C) are copied.
@@ -400,6 +412,18 @@ extern "C" int ipoke_cond_prepare(const float* cond, void* out, int B, int Cc, i
   return IPOKE_OK;
 }
 
+extern "C" int ipoke_extract_cols(const float* state, int ld, int off, int stride, int C, void* out, int ldo, int64_t M, int dtype,
+                                  void* stream) {
+  IPK_REQUIRE(state && out && C >= 1 && ldo >= C && off + (C - 1) * stride < ld, "bad arguments");
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(extract_cols_kernel<bf16_t>, dim3(grid_for(M * ldo, 256)), dim3(256), 0, STREAM(stream), state, ld, off, stride,
+                       C, (bf16_t*)out, ldo, (long)M);
+  else
+    hipLaunchKernelGGL(extract_cols_kernel<float>, dim3(grid_for(M * ldo, 256)), dim3(256), 0, STREAM(stream), state, ld, off, stride,
+                       C, (float*)out, ldo, (long)M);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
 extern "C" int ipoke_actnorm_fwd(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
                                  const float* bias, const int32_t* idx, void* stream) {
   IPK_REQUIRE(in && out && c0 >= 0 && c0 + C <= ld, "bad arguments");

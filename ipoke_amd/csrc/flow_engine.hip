@@ -279,7 +279,7 @@ struct Plan {
   int64_t cond_act = 0, slots = 0, ls_const = 0, partials = 0, dld = 0, dbias_part = 0;
   int64_t state0 = 0, state_stride = 0;     // saved states S[0..nops]
   int64_t g0 = 0, g1 = 0;                   // gradient ping-pong
-  int64_t tmp_h1 = 0, tmp_h2 = 0;           // shared hidden buffers when nothing is saved
+  int64_t tmp_h1 = 0, tmp_h2 = 0, tmp_zc = 0;   // shared hidden buffers when nothing is saved
 };
 int64_t take(int64_t& cur, int64_t bytes) { const int64_t o = cur; cur = align_up(cur + bytes, 256); return o; }
 
@@ -309,6 +309,7 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
     p.state0 = take(cur, 2 * p.state_stride);
     p.tmp_h1 = take(cur, M * hid * f.esz);
     p.tmp_h2 = take(cur, M * hid * f.esz);
+    p.tmp_zc = take(cur, M * 64 * f.esz);
     p.bytes = cur;
     return p;
   }
@@ -329,6 +330,7 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
       op.ws_d = take(cur, M * op.Kc3 * f.esz);        // dparams
       op.ws_e = take(cur, M * hid * f.esz);           // dp2
       op.ws_f = take(cur, M * hid * f.esz);           // dp1
+      op.ws_g = take(cur, M * op.Kc1 * f.esz);        // zc: conditioning channels, dense dtype copy
     }
   }
   p.bytes = cur;
@@ -364,11 +366,13 @@ void set_a_dense(ipoke_conv_desc& d, const void* act, int ld, int kc) {
 int nice_splitk(const Ctx& c) { return max_splitk(*c.f, c.B); }
 
 // coupling net forward: conv1 -> ELU -> conv2 -> ELU -> conv3 (split-K partials)
-int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2) {
+int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2, void* zc) {
   const int hid = c.f->cfg.hidden;
   ipoke_conv_desc d;
+  int rc0 = ipoke_extract_cols(in, c.ld, op.z_off, op.z_stride, op.cin, zc, op.Kc1, c.M, c.dtype, c.s);
+  if (rc0) return rc0;
   set_conv8(d, c.B, 3, 1);
-  set_a_state(d, in, c.ld, op.z_off, op.z_stride, op.cin, op.Kc1);
+  set_a_dense(d, zc, op.Kc1, op.Kc1);
   d.W = c.sh(op.sh_c1); d.ldw = 9 * op.Kc1; d.Nout = hid; d.act = IPOKE_ACT_ELU; d.C = h1; d.ldc = hid;
   int rc = ipoke_conv_forward(&d, c.dtype, c.s); if (rc) return rc;
   set_conv8(d, c.B, 1, 0);
@@ -587,7 +591,7 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
     } else {
       void* h1 = save ? c.at<void>(op.ws_a) : c.at<void>(c.plan.tmp_h1);
       void* h2 = save ? c.at<void>(op.ws_b) : c.at<void>(c.plan.tmp_h2);
-      rc = nice_net(c, op, in, h1, h2); if (rc) return rc;
+      rc = nice_net(c, op, in, h1, h2, save ? c.at<void>(op.ws_g) : c.at<void>(c.plan.tmp_zc)); if (rc) return rc;
       ipoke_affine_desc a; nice_affine_desc(c, op, a);
       rc = ipoke_affine_fwd(&a, in, out, save ? c.at<float>(op.ws_c) : nullptr,
                             c.at<float>(c.plan.slots) + (int64_t)op.slot * B * 4, 4, B, stream);
@@ -651,7 +655,7 @@ extern "C" int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int3
       rc = ipoke_mcf_inv(&d, c.dtype, stream);
     } else {
       // the conditioning channels are untouched by the coupling, so the net sees the same input as in forward
-      rc = nice_net(c, op, in, c.at<void>(c.plan.tmp_h1), c.at<void>(c.plan.tmp_h2)); if (rc) return rc;
+      rc = nice_net(c, op, in, c.at<void>(c.plan.tmp_h1), c.at<void>(c.plan.tmp_h2), c.at<void>(c.plan.tmp_zc)); if (rc) return rc;
       ipoke_affine_desc a; nice_affine_desc(c, op, a);
       rc = ipoke_affine_inv(&a, in, out, B, stream);
     }
@@ -777,10 +781,10 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
       rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
       // conv1 (input = conditioning channels of the saved state)
       base8(3, 1);
-      w.A = xin; w.a_f32 = 1; w.a_sn = 64L * c.ld; w.a_sh = 8L * c.ld; w.a_sw = c.ld; w.a_sc = op.z_stride; w.a_coff = op.z_off;
-      w.Kc_real = op.cin; w.Kc = op.Kc1;
+      w.A = c.at<void>(op.ws_g); w.a_f32 = 0; w.a_sn = 64L * op.Kc1; w.a_sh = 8L * op.Kc1; w.a_sw = op.Kc1; w.a_sc = 1;
+      w.Kc_real = op.Kc1; w.Kc = op.Kc1;
       w.dY = dp1; w.ldy = hid; w.Nout = hid;
-      w.dW = grads + op.p_c1; w.w_sn = (int64_t)op.cin * 9; w.w_sc = 9; w.w_st = 1;
+      w.dW = grads + op.p_c1; w.w_sn = (int64_t)op.cin * 9; w.w_sc = 9; w.w_st = 1; w.Kc_store = op.cin;
       rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
     }
     cur ^= 1;

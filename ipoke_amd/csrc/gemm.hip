@@ -44,7 +44,7 @@ struct TnParams {
   const void* A; int a_f32; long a_sn, a_sd, a_sh, a_sw, a_sc; int a_coff, Kc_real, Kc;
   const void* dY; int ldy, y_coff; int Nout; int Ktot;
   float* dW; long w_sn, w_sc, w_st; int accumulate;
-  int splitm, mb_per_split, rows_fixed;
+  int splitm, mb_per_split, rows_fixed, Kc_store;
   int tiles_n, tiles_k;
 };
 
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
       float* base = p.dW + (long)n * p.w_sn + (long)tap * p.w_st;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (c + r < p.Kc_real) {
+        if (c + r < p.Kc_store) {
           float* q = base + (long)(c + r) * p.w_sc;
           if (p.splitm > 1) atomicAdd(q, acc[i][j][r]);
           else *q = p.accumulate ? *q + acc[i][j][r] : acc[i][j][r];
@@ -992,6 +992,8 @@ static int fill_tn(TnParams& p, const ipoke_wgrad_desc* d, int dtype, bool batch
   p.dY = d->dY; p.ldy = d->ldy; p.y_coff = d->y_coff; p.Nout = d->Nout; p.Ktot = p.g.taps * d->Kc;
   p.dW = d->dW; p.w_sn = d->w_sn; p.w_sc = d->w_sc; p.w_st = d->w_st; p.accumulate = d->accumulate;
   p.splitm = d->splitm < 1 ? 1 : d->splitm;
+  p.Kc_store = d->Kc_store > 0 ? d->Kc_store : d->Kc_real;
+  IPK_REQUIRE(p.Kc_store <= d->Kc_real, "Kc_store exceeds Kc_real");
   return IPOKE_OK;
 }
 
