@@ -369,11 +369,12 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE>
-__global__ __launch_bounds__(256) void igemm_nt_glds_kernel(const NtParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtParams p) {
+  constexpr int NTHR = WM * WN * 64;               // 4 or 8 wave64 (8 waves = two per SIMD: one's LDS reads hide under the other's MFMAs)
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr int E16 = ET<T>::E16;
   constexpr int BK = 128 / (int)sizeof(T);
-  constexpr int A_IT = (BM * 8 + 255) / 256, B_IT = (BN * 8 + 255) / 256, L = A_IT + B_IT;
+  constexpr int A_IT = (BM * 8 + NTHR - 1) / NTHR, B_IT = (BN * 8 + NTHR - 1) / NTHR, L = A_IT + B_IT;
   constexpr int SUB = (BM + BN) * 128;            // one K-block of both operands
   constexpr int STAGE = KPB * SUB;                // ring slot: KPB K-blocks are consumed per barrier
   static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must fill whole DMA instructions");
@@ -383,8 +384,8 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(const NtParams p) {
   typedef const __attribute__((address_space(1))) void glb_void;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* dummy = smem + NSTAGE * STAGE;                         // 4 KB: landing zone of padding DMAs
-  int* taptab = reinterpret_cast<int*>(smem + NSTAGE * STAGE + 4096);
+  unsigned char* dummy = smem + NSTAGE * STAGE;                         // 1 KB per wave: landing zone of padding DMAs
+  int* taptab = reinterpret_cast<int*>(smem + NSTAGE * STAGE + NTHR * 16);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(const NtParams p) {
   };
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int ch = tid + 256 * i;
+    const int ch = tid + NTHR * i;
     const int row = ch >> 3, pos = ch & 7;
     a_in[i] = row < BM;
     arow[i] = decode_row(g, m0 + row, p.a_sn);
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(const NtParams p) {
   unsigned b_off[B_IT]; int b_k[B_IT]; bool b_in[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int ch = tid + 256 * i;
+    const int ch = tid + NTHR * i;
     const int row = ch >> 3, pos = ch & 7;
     b_in[i] = row < BN;
     b_k[i] = kb_begin * BK + (pos ^ ((row >> 1) & 7)) * E16;
@@ -462,13 +463,13 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(const NtParams p) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const T* src = a_off[i] != kInvalid ? Abase + a_off[i] : zero;
-      unsigned char* dst = (wave * 64 + 256 * i) < BM * 8 ? sa + (wave * 64 + 256 * i) * 16 : dummy + wave * 1024;
+      unsigned char* dst = (wave * 64 + NTHR * i) < BM * 8 ? sa + (wave * 64 + NTHR * i) * 16 : dummy + wave * 1024;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const T* src = (b_off[i] != kInvalid && (SIMPLE || b_k[i] < p.ldw)) ? Wbase + b_off[i] : zero;
-      unsigned char* dst = (wave * 64 + 256 * i) < BN * 8 ? sa + BM * 128 + (wave * 64 + 256 * i) * 16 : dummy + wave * 1024;
+      unsigned char* dst = (wave * 64 + NTHR * i) < BN * 8 ? sa + BM * 128 + (wave * 64 + NTHR * i) * 16 : dummy + wave * 1024;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
       if (!SIMPLE) b_k[i] += BK;
       if (b_off[i] != kInvalid) b_off[i] += BK;
@@ -823,12 +824,12 @@ static int launch_nt_glds_impl(NtParams& p, hipStream_t s) {
   if (p.splitk < 1) p.splitk = 1;
   p.kb_per_split = ceil_div(nkb, p.splitk);
   pick_xcd_map(p);
-  const size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * 128 + 4096 + 256 * sizeof(int);
+  const size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * 128 + WM * WN * 64 * 16 + 256 * sizeof(int);
   auto kern = igemm_nt_glds_kernel<T, WM, WN, MREP, NREP, NSTAGE, KPB, SIMPLE>;
   static bool attr_done = false;
   if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
   dim3 grid((unsigned)((long)p.tiles_m * p.tiles_n), (unsigned)p.splitk);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, p);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
@@ -888,7 +889,11 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
     if (glds_mode == 6) return launch_nt_glds<T, 2, 2, 2, 4, 3, 2>(p, s);          // 64 x 128, 3 slots x 2 K-blocks
     if (glds_mode == 7) return launch_nt_glds<T, 2, 2, 2, 2, 3, 4>(p, s);          // 64 x 64, 3 slots x 4 K-blocks
     if (glds_mode == 8) return launch_nt_glds<T, 2, 2, 2, 2, 4, 2>(p, s);          // 64 x 64, 4 slots x 2 K-blocks
-    if ((long)ceil_div(M, 128) * ceil_div(N, 128) >= 100) return launch_nt_glds<T, 2, 2, 4, 4, 2, 2>(p, s);
+    if (glds_mode == 9) return launch_nt_glds<T, 2, 4, 4, 2, 2, 2>(p, s);          // 128 x 128, 8 waves, 2 slots x 2 K-blocks
+    if (glds_mode == 10) return launch_nt_glds<T, 2, 4, 4, 2, 4, 1>(p, s);         // 128 x 128, 8 waves, 4 slots
+    if (glds_mode == 11) return launch_nt_glds<T, 4, 2, 2, 4, 2, 2>(p, s);         // 128 x 128, 8 waves (4x2)
+    if (glds_mode == 12) return launch_nt_glds<T, 2, 4, 2, 2, 4, 1>(p, s);         // 64 x 128, 8 waves
+    if ((long)ceil_div(M, 128) * ceil_div(N, 128) >= 100) return launch_nt_glds<T, 2, 4, 4, 2, 2, 2>(p, s);   // 8 waves
     return launch_nt_glds<T, 2, 2, 2, 2, 4>(p, s);
   }
   if (N <= 64) return launch_nt<T, 4, 1, 1, 4>(p, s);                  // 64 x 64 tiles, skinny N (split-K upstream)
