@@ -585,7 +585,8 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
       ipoke_mcf_desc d; mcf_desc(c, op, d);
       d.x = in; d.y = out;
       d.logdet_slot = c.at<float>(c.plan.slots) + (int64_t)op.slot * B * 4;
-      d.rows_per_block = 16;    // 4 slices per sample -> slot width 4
+      static const int rpb = getenv("IPOKE_MCF_ROWS") ? atoi(getenv("IPOKE_MCF_ROWS")) : 16;
+      d.rows_per_block = rpb;   // 16: 4 slices per sample -> slot width 4
       if (save) { d.a2_save = c.at<void>(op.ws_a); d.scale_save = c.at<float>(op.ws_b); }
       rc = ipoke_mcf_fwd(&d, c.dtype, stream);
     } else {

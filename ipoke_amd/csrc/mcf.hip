@@ -17,6 +17,13 @@ template <typename T> struct Pack4;     // 4 consecutive values of the compute d
 template <> struct Pack4<bf16_t> { typedef __attribute__((ext_vector_type(4))) __bf16 type; };
 template <> struct Pack4<float> { typedef f32x4 type; };
 
+// MCF workgroups run 8 wave64 (two per SIMD): the kernels are chains of short dependent phases, a second wave per SIMD
+// overlaps one wave's LDS/global latency with the other's matrix-core work.
+static constexpr int kMcfWaves = 8;
+static constexpr int kMcfThreads = kMcfWaves * 64;
+static constexpr int kJ16 = 16 / kMcfWaves;      // fragment columns per wave when N <= 256
+static constexpr int kJ8 = (8 + kMcfWaves - 1) / kMcfWaves;   // ... when N <= 128
+
 template <typename T> struct K64 { static constexpr int value = 64 / (int)sizeof(T); };   // K per super-step
 
 // 16-byte chunk of the (virtual) im2col row of position p: channels [c, c+E16) of tap `tap`
@@ -111,11 +118,11 @@ __device__ __forceinline__ void mcf_gemm1(const McfParams& P, const McfGeom& g, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, gq = lane >> 4;
   const int NF1 = (P.H + 15) >> 4;
-  f32x4 acc[MF][4];
+  f32x4 acc[MF][kJ16];
 #pragma unroll
   for (int i = 0; i < MF; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < kJ16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const unsigned char* tile[MF]; int pos[MF];
 #pragma unroll
   for (int i = 0; i < MF; ++i) rowfn(i * 16 + r, tile[i], pos[i]);
@@ -130,15 +137,15 @@ __device__ __forceinline__ void mcf_gemm1(const McfParams& P, const McfGeom& g, 
 #pragma unroll
     for (int i = 0; i < MF; ++i) src[i] = tap_src_fwd(tile[i], zrow, xpitch, g, pos[i], tap) + E16 * gq * (int)sizeof(T);
     for (int c = 0; c < P.Cp; c += KS) {
-      frag_t fa[MF], fb[4];
+      frag_t fa[MF], fb[kJ16];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (wave + 4 * j < NF1) fb[j] = load_wfrag<T>(W1, P.K1p, (wave + 4 * j) * 16 + r, tap * P.Cp + c + E16 * gq);
+      for (int j = 0; j < kJ16; ++j)
+        if (wave + kMcfWaves * j < NF1) fb[j] = load_wfrag<T>(W1, P.K1p, (wave + kMcfWaves * j) * 16 + r, tap * P.Cp + c + E16 * gq);
 #pragma unroll
       for (int i = 0; i < MF; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + c * (int)sizeof(T));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (wave + 4 * j < NF1) {
+      for (int j = 0; j < kJ16; ++j) {
+        if (wave + kMcfWaves * j < NF1) {
 #pragma unroll
           for (int i = 0; i < MF; ++i) mma64(fa[i], fb[j], acc[i][j]);
         }
@@ -146,8 +153,8 @@ __device__ __forceinline__ void mcf_gemm1(const McfParams& P, const McfGeom& g, 
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = (wave + 4 * j) * 16 + 4 * gq;
+  for (int j = 0; j < kJ16; ++j) {
+    const int n = (wave + kMcfWaves * j) * 16 + 4 * gq;
     if (n < P.H) {     // H is a multiple of 4: the 4 columns of a lane are all valid or all invalid
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
@@ -167,17 +174,20 @@ __device__ __forceinline__ void mcf_gemm2(const McfParams& P, const unsigned cha
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, gq = lane >> 4;
   const int N2 = 2 * P.C, NF2 = (N2 + 15) >> 4;
-  f32x4 acc[MF][2];
+  f32x4 acc[MF][kJ8];
 #pragma unroll
-  for (int i = 0; i < MF; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+  for (int i = 0; i < MF; ++i) {
+#pragma unroll
+    for (int j = 0; j < kJ8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const T* W2 = reinterpret_cast<const T*>(P.W2);
   constexpr int PF = 4;
   const int nsteps = P.K2p / KS;
-  frag_t ring[PF][2];
+  frag_t ring[PF][kJ8];
   auto load_b = [&](int st, frag_t* b) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (wave + 4 * j < NF2) b[j] = load_wfrag<T>(W2, P.K2p, (wave + 4 * j) * 16 + r, st * KS + E16 * gq);
+    for (int j = 0; j < kJ8; ++j)
+      if (wave + kMcfWaves * j < NF2) b[j] = load_wfrag<T>(W2, P.K2p, (wave + kMcfWaves * j) * 16 + r, st * KS + E16 * gq);
   };
 #pragma unroll
   for (int d = 0; d < PF; ++d) if (d < nsteps) load_b(d, ring[d]);
@@ -191,8 +201,8 @@ __device__ __forceinline__ void mcf_gemm2(const McfParams& P, const unsigned cha
         for (int i = 0; i < MF; ++i)
           fa[i] = *reinterpret_cast<const frag_t*>(a2 + (i * 16 + r) * a2_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (wave + 4 * j < NF2) {
+        for (int j = 0; j < kJ8; ++j) {
+          if (wave + kMcfWaves * j < NF2) {
 #pragma unroll
             for (int i = 0; i < MF; ++i) mma64(fa[i], ring[d][j], acc[i][j]);
           }
@@ -202,8 +212,8 @@ __device__ __forceinline__ void mcf_gemm2(const McfParams& P, const unsigned cha
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = (wave + 4 * j) * 16 + 4 * gq;
+  for (int j = 0; j < kJ8; ++j) {
+    const int n = (wave + kMcfWaves * j) * 16 + 4 * gq;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (n + q < N2) {
@@ -233,7 +243,7 @@ __device__ __forceinline__ void fill_cond(const McfParams& P, int rows, RowFn gr
 
 // ------------------------------------------------------------------------------------------ forward
 template <typename T, int MF>
-__global__ __launch_bounds__(256) void mcf_fwd_kernel(const McfParams P) {
+__global__ __launch_bounds__(kMcfThreads) void mcf_fwd_kernel(const McfParams P) {
   constexpr int MT = MF * 16, RS = 64 / MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float red[8];
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256) void mcf_fwd_kernel(const McfParams P) {
 // ------------------------------------------------------------------------------------------ inverse
 // Two samples per workgroup: a strip of 8 positions per sample fills one 16-row matrix-core tile.
 template <typename T>
-__global__ __launch_bounds__(256) void mcf_inv_kernel(const McfParams P) {
+__global__ __launch_bounds__(kMcfThreads) void mcf_inv_kernel(const McfParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b0 = blockIdx.x * 2;
   const int nb = min(2, P.B - b0);
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256) void mcf_inv_kernel(const McfParams P) {
 
 // ------------------------------------------------------------------------------------------ backward (data path)
 template <typename T>
-__global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
+__global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P) {
   constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -428,19 +438,19 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
   // (b) dA2[:, :H] = dparams x W2[:, :H]  , times ELU'(c) -> dc
   if (P.dbg != 2 && P.dbg != 4) {
     const int NF = (P.H + 15) >> 4;
-    f32x4 acc[4][4];
+    f32x4 acc[4][kJ16];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < kJ16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const T* W2T = reinterpret_cast<const T*>(P.W2T);
     constexpr int PF = 4;
     const int nsteps = P.K3p / KS;
-    frag_t ring[PF][4];
+    frag_t ring[PF][kJ16];
     auto load_b = [&](int st, frag_t* b) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (wave + 4 * j < NF) b[j] = load_wfrag<T>(W2T, P.K3p, (wave + 4 * j) * 16 + r, st * KS + E16 * gq);
+      for (int j = 0; j < kJ16; ++j)
+        if (wave + kMcfWaves * j < NF) b[j] = load_wfrag<T>(W2T, P.K3p, (wave + kMcfWaves * j) * 16 + r, st * KS + E16 * gq);
     };
 #pragma unroll
     for (int d = 0; d < PF; ++d) if (d < nsteps) load_b(d, ring[d]);
@@ -454,8 +464,8 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
           for (int i = 0; i < 4; ++i)
             fa[i] = *reinterpret_cast<const frag_t*>(dp + (i * 16 + r) * dp_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (wave + 4 * j < NF) {
+          for (int j = 0; j < kJ16; ++j)
+            if (wave + kMcfWaves * j < NF) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) mma64(fa[i], ring[d][j], acc[i][j]);
             }
@@ -466,8 +476,8 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
     const T* a2s = reinterpret_cast<const T*>(P.a2_save);
     T* dcs = reinterpret_cast<T*>(P.dc_save);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = (wave + 4 * j) * 16 + 4 * gq;
+    for (int j = 0; j < kJ16; ++j) {
+      const int n = (wave + kMcfWaves * j) * 16 + 4 * gq;
       if (n < P.H) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -493,35 +503,37 @@ __global__ __launch_bounds__(256) void mcf_bwd_kernel(const McfParams P) {
   __syncthreads();
 
   // (c) dx = dy*scale + sum_tap dc[p - off(tap)] x W1[:, tap, :]
+  //     16 (row-fragment, channel-fragment) pairs over the 8 waves: wave w owns channel fragment w & 3 and the two
+  //     row fragments 2*(w >> 2), 2*(w >> 2) + 1.
   if (P.dbg != 3 && P.dbg != 4) {
-    const int NF = (P.C + 15) >> 4;       // <= 4: one fragment column per wave
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int NF = (P.C + 15) >> 4;       // <= 4 channel fragments
+    const int nfrag = wave & 3, mbase = (wave >> 2) * 2;
+    f32x4 acc[2];
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
     const int ntaps = g.kh * g.kw;
     const int Ktot = ntaps * P.Hq;
     const T* W1T = reinterpret_cast<const T*>(P.W1T);
-    if (wave < NF) {
+    if (nfrag < NF) {
       // Hq is a multiple of the K step: taps unrolled statically, source rows (or the zero row) resolved once per tap
       const unsigned char* zrow = dc + 64 * dc_pitch;
 #pragma unroll
       for (int tap = 0; tap < 6; ++tap) {
-        const unsigned char* src[4];
+        const unsigned char* src[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) src[i] = tap_src_adj(dc, zrow, dc_pitch, g, i * 16 + r, tap) + E16 * gq * (int)sizeof(T);
+        for (int i = 0; i < 2; ++i) src[i] = tap_src_adj(dc, zrow, dc_pitch, g, (mbase + i) * 16 + r, tap) + E16 * gq * (int)sizeof(T);
         for (int c = 0; c < P.Hq; c += KS) {
-          const frag_t fb = load_wfrag<T>(W1T, Ktot, wave * 16 + r, tap * P.Hq + c + E16 * gq);
-          frag_t fa[4];
+          const frag_t fb = load_wfrag<T>(W1T, Ktot, nfrag * 16 + r, tap * P.Hq + c + E16 * gq);
+          frag_t fa[2];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + c * (int)sizeof(T));
+          for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + c * (int)sizeof(T));
 #pragma unroll
-          for (int i = 0; i < 4; ++i) mma64(fa[i], fb, acc[i]);
+          for (int i = 0; i < 2; ++i) mma64(fa[i], fb, acc[i]);
         }
       }
-      const int n = wave * 16 + 4 * gq;
+      const int n = nfrag * 16 + 4 * gq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = i * 16 + r;
+      for (int i = 0; i < 2; ++i) {
+        const int p = (mbase + i) * 16 + r;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (n + q < P.C) P.dx[(row0 + p) * P.ld + n + q] = dxd[p * P.C + n + q] + acc[i][q];
@@ -602,7 +614,7 @@ extern "C" int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
 #define LAUNCH_FWD(TT, MF)                                                                      \
   do {                                                                                          \
     rc = ensure_lds<mcf_fwd_kernel<TT, MF>>(lds); if (rc) return rc;                              \
-    hipLaunchKernelGGL((mcf_fwd_kernel<TT, MF>), dim3(d->B * RS), dim3(256), lds, s, P);        \
+    hipLaunchKernelGGL((mcf_fwd_kernel<TT, MF>), dim3(d->B * RS), dim3(kMcfThreads), lds, s, P);        \
   } while (0)
   if (dtype == IPOKE_BF16) {
     if (MT == 64) LAUNCH_FWD(bf16_t, 4); else if (MT == 32) LAUNCH_FWD(bf16_t, 2); else LAUNCH_FWD(bf16_t, 1);
@@ -625,10 +637,10 @@ extern "C" int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16) {
     rc = ensure_lds<mcf_inv_kernel<bf16_t>>(lds); if (rc) return rc;
-    hipLaunchKernelGGL(mcf_inv_kernel<bf16_t>, dim3((d->B + 1) / 2), dim3(256), lds, s, P);
+    hipLaunchKernelGGL(mcf_inv_kernel<bf16_t>, dim3((d->B + 1) / 2), dim3(kMcfThreads), lds, s, P);
   } else {
     rc = ensure_lds<mcf_inv_kernel<float>>(lds); if (rc) return rc;
-    hipLaunchKernelGGL(mcf_inv_kernel<float>, dim3((d->B + 1) / 2), dim3(256), lds, s, P);
+    hipLaunchKernelGGL(mcf_inv_kernel<float>, dim3((d->B + 1) / 2), dim3(kMcfThreads), lds, s, P);
   }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
@@ -644,10 +656,10 @@ extern "C" int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16) {
     rc = ensure_lds<mcf_bwd_kernel<bf16_t>>(lds); if (rc) return rc;
-    hipLaunchKernelGGL(mcf_bwd_kernel<bf16_t>, dim3(d->B), dim3(256), lds, s, P);
+    hipLaunchKernelGGL(mcf_bwd_kernel<bf16_t>, dim3(d->B), dim3(kMcfThreads), lds, s, P);
   } else {
     rc = ensure_lds<mcf_bwd_kernel<float>>(lds); if (rc) return rc;
-    hipLaunchKernelGGL(mcf_bwd_kernel<float>, dim3(d->B), dim3(256), lds, s, P);
+    hipLaunchKernelGGL(mcf_bwd_kernel<float>, dim3(d->B), dim3(kMcfThreads), lds, s, P);
   }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
