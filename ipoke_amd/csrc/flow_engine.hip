@@ -76,8 +76,13 @@ struct ipoke_flow {
   std::vector<LsRefH> lsrefs;
   void* d_rjobs = nullptr; void* d_wjobs = nullptr; void* d_lsrefs = nullptr;
   hipStream_t side = nullptr;
+  std::vector<hipStream_t> lanes;     // extra streams for sub-batch lanes 1..kMaxLanes-1 (lane 0 = caller's stream)
+  int n_lanes = 1;
   std::vector<hipEvent_t> events; size_t ev_next = 0;
   bool use_side = true;
+  // hipGraph replay of the ~5000-launch layer programs: keyed by every pointer argument + batch + mode
+  struct GraphEntry { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int state = 0; uint64_t used = 0; };
+  std::vector<GraphEntry> graphs; hipStream_t cap = nullptr; bool use_graph = false; uint64_t tick = 0;
   int last_fwd_B = 0; bool have_saved = false;
   int P = 64;
 };
@@ -276,11 +281,12 @@ int build(ipoke_flow& f) {
 // ---- workspace plan ---------------------------------------------------------------------------
 struct Plan {
   int64_t bytes = 0;
-  int64_t cond_act = 0, slots = 0, ls_const = 0, partials = 0, dld = 0, dbias_part = 0;
+  int64_t cond_act = 0, slots = 0, ls_const = 0, partials = 0, partials_lane = 0, dld = 0, dbias_part = 0;
   int64_t state0 = 0, state_stride = 0;     // saved states S[0..nops]
   int64_t g0 = 0, g1 = 0;                   // gradient ping-pong
   int64_t tmp_h1 = 0, tmp_h2 = 0, tmp_zc = 0;   // shared hidden buffers when nothing is saved
 };
+constexpr int kMaxLanes = 4;
 int64_t take(int64_t& cur, int64_t bytes) { const int64_t o = cur; cur = align_up(cur + bytes, 256); return o; }
 
 int max_splitk(const ipoke_flow& f, int B) {
@@ -303,7 +309,8 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
   p.slots = take(cur, (int64_t)f.nslots * B * 4 * 4);
   p.ls_const = take(cur, 256);
   p.dld = take(cur, (int64_t)B * 4);
-  p.partials = take(cur, (int64_t)max_splitk(f, B) * M * 64 * 4);
+  p.partials_lane = align_up((int64_t)32 * M * 64 * 4, 256);   // upper bound of splitk * M_lane * 64 floats
+  p.partials = take(cur, kMaxLanes * p.partials_lane);
   p.state_stride = align_up(M * ld * 4, 256);
   if (mode == 0) {
     p.state0 = take(cur, 2 * p.state_stride);
@@ -337,15 +344,30 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
   return p;
 }
 
+// Execution context of one *lane*: a contiguous range of samples [b0, b0 + B) of the batch, processed on its own stream.
+// The flow is strictly sequential per sample, and at the shipped batch sizes every kernel on the chain is bound by its
+// fixed launch/prologue/epilogue latency rather than by throughput; independent lanes on separate streams overlap those
+// latencies.  All row-indexed workspace buffers are laid out for the full batch, a lane addresses its row range.
 struct Ctx {
   ipoke_flow* f; int B; int64_t M; int ld; int dtype; hipStream_t s;
   const float* params; const int32_t* perm; const unsigned char* shadow; unsigned char* ws; Plan plan;
+  int b0 = 0, Bfull = 0, lane = 0;
   const float* wn_scale() const { return reinterpret_cast<const float*>(shadow); }
   const float* wn_inv() const { return reinterpret_cast<const float*>(shadow) + align_up(f->wn_rows, 64); }
   const unsigned char* sh(int64_t elem_off) const { return shadow + shadow_base() + elem_off * f->esz; }
   int64_t shadow_base() const { return 2 * align_up(f->wn_rows, 64) * 4; }
-  float* state(int i) const { return reinterpret_cast<float*>(ws + plan.state0 + (int64_t)i * plan.state_stride); }
+  int64_t row0() const { return (int64_t)b0 * f->P; }
+  float* state(int i) const { return reinterpret_cast<float*>(ws + plan.state0 + (int64_t)i * plan.state_stride) + row0() * ld; }
   template <typename T> T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
+  // row-indexed buffer at byte offset `off` with `row_bytes` per position
+  void* rows(int64_t off, int64_t row_bytes) const { return ws + off + row0() * row_bytes; }
+  float* rowsf(int64_t off, int64_t row_floats) const { return reinterpret_cast<float*>(ws + off) + row0() * row_floats; }
+  void* stream() const { return reinterpret_cast<void*>(s); }
+  float* slot(int k) const { return at<float>(plan.slots) + ((int64_t)k * Bfull + b0) * 4; }
+  float* partials() const { return reinterpret_cast<float*>(ws + plan.partials + (int64_t)lane * plan.partials_lane); }
+  void* cond() const { return rows(plan.cond_act, (int64_t)f->cfg.cond_channels * f->esz); }
+  float* dld() const { return at<float>(plan.dld) + b0; }
+  float* dbp(int op_index, int ldp) const { return at<float>(plan.dbias_part) + (int64_t)op_index * (Bfull + 1) * 128 + (int64_t)b0 * ldp; }
 };
 
 void set_conv8(ipoke_conv_desc& d, int B, int k, int pad) {
@@ -369,29 +391,29 @@ int nice_splitk(const Ctx& c) { return max_splitk(*c.f, c.B); }
 int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2, void* zc) {
   const int hid = c.f->cfg.hidden;
   ipoke_conv_desc d;
-  int rc0 = ipoke_extract_cols(in, c.ld, op.z_off, op.z_stride, op.cin, zc, op.Kc1, c.M, c.dtype, c.s);
+  int rc0 = ipoke_extract_cols(in, c.ld, op.z_off, op.z_stride, op.cin, zc, op.Kc1, c.M, c.dtype, c.stream());
   if (rc0) return rc0;
   set_conv8(d, c.B, 3, 1);
   set_a_dense(d, zc, op.Kc1, op.Kc1);
   d.W = c.sh(op.sh_c1); d.ldw = 9 * op.Kc1; d.Nout = hid; d.act = IPOKE_ACT_ELU; d.C = h1; d.ldc = hid;
-  int rc = ipoke_conv_forward(&d, c.dtype, c.s); if (rc) return rc;
+  int rc = ipoke_conv_forward(&d, c.dtype, c.stream()); if (rc) return rc;
   set_conv8(d, c.B, 1, 0);
   set_a_dense(d, h1, hid, hid);
   d.W = c.sh(op.sh_c2); d.ldw = hid; d.Nout = hid; d.act = IPOKE_ACT_ELU; d.C = h2; d.ldc = hid;
-  rc = ipoke_conv_forward(&d, c.dtype, c.s); if (rc) return rc;
+  rc = ipoke_conv_forward(&d, c.dtype, c.stream()); if (rc) return rc;
   set_conv8(d, c.B, 3, 1);
   set_a_dense(d, h2, hid, hid);
-  d.W = c.sh(op.sh_c3); d.ldw = 9 * hid; d.Nout = 2 * op.cout; d.C = c.at<float>(c.plan.partials); d.c_f32 = 1; d.ldc = 64;
+  d.W = c.sh(op.sh_c3); d.ldw = 9 * hid; d.Nout = 2 * op.cout; d.C = c.partials(); d.c_f32 = 1; d.ldc = 64;
   d.splitk = nice_splitk(c);
-  return ipoke_conv_forward(&d, c.dtype, c.s);
+  return ipoke_conv_forward(&d, c.dtype, c.stream());
 }
 void nice_affine_desc(const Ctx& c, const Op& op, ipoke_affine_desc& a) {
-  a.raw = c.at<float>(c.plan.partials); a.nsplit = nice_splitk(c); a.split_stride = c.M * 64; a.ldraw = 64;
+  a.raw = c.partials(); a.nsplit = nice_splitk(c); a.split_stride = c.M * 64; a.ldraw = 64;
   a.bias = c.params + op.p_b; a.Cp = op.cout; a.t_off = op.t_off; a.t_stride = op.t_stride; a.P = c.f->P; a.ld = c.ld;
 }
 void mcf_desc(const Ctx& c, const Op& op, ipoke_mcf_desc& d) {
   std::memset(&d, 0, sizeof(d));
-  d.ld = c.ld; d.C = op.C; d.B = c.B; d.cond = c.at<void>(c.plan.cond_act); d.Cc = c.f->cfg.cond_channels;
+  d.ld = c.ld; d.C = op.C; d.B = c.B; d.cond = c.cond(); d.Cc = c.f->cfg.cond_channels;
   d.W1 = c.sh(op.sh_w1); d.W2 = c.sh(op.sh_w2); d.bias2 = c.params + op.p_b; d.order = op.order;
   d.W1T = c.sh(op.sh_w1t); d.W2T = c.sh(op.sh_w2t);
 }
@@ -404,6 +426,14 @@ int common_checks(ipoke_flow* f, int B) {
 
 struct WgEntryH { long a_off, y_off, w_off; int kh, kw, ph, pw; };
 struct RedEntryH { long src, dst; int ld, ncols; };
+
+void drop_graphs(ipoke_flow* f) {
+  for (auto& g : f->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  f->graphs.clear();
+}
 
 // (Re)build the device tables for batch size B.  Offsets are relative to the workspace base (bytes) / the
 // gradient buffer (floats), so the tables stay valid as long as B does.  Not called under graph capture
@@ -429,6 +459,7 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
       red.push_back({dbp + op.Cn, (long)op.p_bias, 2 * op.Cn, op.Cn});
     }
   }
+  drop_graphs(f);    // captured launches hold the old table addresses
   if (f->d_w1tab) { (void)hipFree(f->d_w1tab); (void)hipFree(f->d_w2tab); (void)hipFree(f->d_redtab); }
   IPK_HIP(hipMalloc(&f->d_w1tab, w1.size() * sizeof(WgEntryH)));
   IPK_HIP(hipMalloc(&f->d_w2tab, w2.size() * sizeof(WgEntryH)));
@@ -464,6 +495,12 @@ extern "C" int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out)
   int rc = build(*f); if (rc) return rc;
   const char* env = getenv("IPOKE_NO_SIDE_STREAM");
   f->use_side = !(env && env[0] == '1');
+  const char* gr = getenv("IPOKE_GRAPH");
+  f->use_graph = gr && gr[0] == '1';     // opt-in: see DESIGN.md (replay is slower than eager launches on ROCm 7.2)
+  const char* ln = getenv("IPOKE_LANES");
+  f->n_lanes = ln ? atoi(ln) : 1;
+  if (f->n_lanes < 1) f->n_lanes = 1;
+  if (f->n_lanes > kMaxLanes) f->n_lanes = kMaxLanes;
   *out = f.release();
   return IPOKE_OK;
 }
@@ -481,7 +518,10 @@ static int ensure_device(ipoke_flow* f) {
   IPK_HIP(hipMalloc(&f->d_lsrefs, f->lsrefs.size() * sizeof(LsRefH)));
   IPK_HIP(hipMemcpy(f->d_lsrefs, f->lsrefs.data(), f->lsrefs.size() * sizeof(LsRefH), hipMemcpyHostToDevice));
   IPK_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-  f->events.resize(64);
+  IPK_HIP(hipStreamCreateWithFlags(&f->cap, hipStreamNonBlocking));
+  f->lanes.resize(kMaxLanes - 1);
+  for (auto& l : f->lanes) IPK_HIP(hipStreamCreateWithFlags(&l, hipStreamNonBlocking));
+  f->events.resize(256);
   for (auto& e : f->events) IPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return IPOKE_OK;
 }
@@ -495,7 +535,10 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   if (f->d_w2tab) (void)hipFree(f->d_w2tab);
   if (f->d_redtab) (void)hipFree(f->d_redtab);
   for (auto e : f->events) (void)hipEventDestroy(e);
+  drop_graphs(f);
   if (f->side) (void)hipStreamDestroy(f->side);
+  if (f->cap) (void)hipStreamDestroy(f->cap);
+  for (auto l : f->lanes) if (l) (void)hipStreamDestroy(l);
   delete f;
 }
 
@@ -547,9 +590,95 @@ extern "C" int ipoke_flow_prepare_weights(ipoke_flow* f, const float* params, vo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lanes: split the batch into up to n_lanes contiguous sample ranges, lane 0 on the caller's stream.
+static int make_lanes(const Ctx& full, int want, std::vector<Ctx>& lanes) {
+  ipoke_flow* f = full.f;
+  int n = want < 1 ? 1 : want;
+  if (n > kMaxLanes) n = kMaxLanes;
+  if (n > full.B) n = full.B;
+  lanes.clear();
+  int b0 = 0;
+  for (int k = 0; k < n; ++k) {
+    const int nb = (full.B - b0 + (n - k) - 1) / (n - k);
+    Ctx c = full;
+    c.b0 = b0; c.B = nb; c.M = (int64_t)nb * f->P; c.Bfull = full.B; c.lane = k;
+    c.s = k == 0 ? full.s : f->lanes[k - 1];
+    lanes.push_back(c);
+    b0 += nb;
+  }
+  return IPOKE_OK;
+}
+// lanes 1.. wait for everything queued so far on the caller's stream
+static int fork_lanes(ipoke_flow* f, hipStream_t from, const std::vector<Ctx>& lanes) {
+  if (lanes.size() < 2) return IPOKE_OK;
+  hipEvent_t e = next_event(f);
+  IPK_HIP(hipEventRecord(e, from));
+  for (size_t k = 1; k < lanes.size(); ++k) IPK_HIP(hipStreamWaitEvent(lanes[k].s, e, 0));
+  return IPOKE_OK;
+}
+// `to` waits for the work queued so far on every lane (lanes that already run on `to` are skipped)
+static int join_lanes(ipoke_flow* f, const std::vector<Ctx>& lanes, hipStream_t to) {
+  for (size_t k = 0; k < lanes.size(); ++k) {
+    if (lanes[k].s == to) continue;
+    hipEvent_t e = next_event(f);
+    IPK_HIP(hipEventRecord(e, lanes[k].s));
+    IPK_HIP(hipStreamWaitEvent(to, e, 0));
+  }
+  return IPOKE_OK;
+}
+
+// Run `enqueue(stream)` either eagerly on the caller's stream (first call with a given argument set: it also performs
+// the one-time allocations / attribute calls that are illegal under capture) or as a replay of the hipGraph captured on
+// the second call.  The graph runs on the engine's own stream, ordered after / before the caller's stream by events.
+template <typename Fn>
+static int with_graph(ipoke_flow* f, std::vector<uintptr_t> key, hipStream_t caller, Fn enqueue) {
+  if (!f->use_graph) return enqueue(caller);
+  int rc0 = ensure_device(f); if (rc0) return rc0;
+  ipoke_flow::GraphEntry* e = nullptr;
+  for (auto& g : f->graphs) if (g.key == key) { e = &g; break; }
+  if (!e) {
+    if (f->graphs.size() >= 12) {
+      size_t old = 0;
+      for (size_t i = 1; i < f->graphs.size(); ++i) if (f->graphs[i].used < f->graphs[old].used) old = i;
+      if (f->graphs[old].exec) (void)hipGraphExecDestroy(f->graphs[old].exec);
+      if (f->graphs[old].graph) (void)hipGraphDestroy(f->graphs[old].graph);
+      f->graphs.erase(f->graphs.begin() + old);
+    }
+    ipoke_flow::GraphEntry ne; ne.key = std::move(key); ne.used = ++f->tick;
+    f->graphs.push_back(std::move(ne));
+    return enqueue(caller);
+  }
+  e->used = ++f->tick;
+  if (e->state < 0) return enqueue(caller);          // capture failed before: stay eager
+  if (!e->exec) {
+    const std::vector<uintptr_t> k = e->key;
+    IPK_HIP(hipStreamBeginCapture(f->cap, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue(f->cap);
+    hipGraph_t g = nullptr;
+    const hipError_t er = hipStreamEndCapture(f->cap, &g);
+    // enqueue() may have rebuilt tables and dropped every entry: look the entry up again
+    e = nullptr;
+    for (auto& ge : f->graphs) if (ge.key == k) { e = &ge; break; }
+    if (rc != IPOKE_OK) { if (g) (void)hipGraphDestroy(g); if (e) e->state = -1; return rc; }
+    if (er != hipSuccess || !g || !e) { (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g); if (e) e->state = -1; return enqueue(caller); }
+    hipGraphExec_t ex = nullptr;
+    if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError(); (void)hipGraphDestroy(g); e->state = -1; return enqueue(caller);
+    }
+    e->graph = g; e->exec = ex; e->state = 1;
+  }
+  hipEvent_t a = next_event(f);
+  IPK_HIP(hipEventRecord(a, caller)); IPK_HIP(hipStreamWaitEvent(f->cap, a, 0));
+  IPK_HIP(hipGraphLaunch(e->exec, f->cap));
+  hipEvent_t b = next_event(f);
+  IPK_HIP(hipEventRecord(b, f->cap)); IPK_HIP(hipStreamWaitEvent(caller, b, 0));
+  return IPOKE_OK;
+}
+
 static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow, const float* x_nchw,
                        const float* cond_nchw, int B, float* out_nchw, float* logdet, void* workspace, int save, int init,
-                       float* params_mut, void* stream) {
+                       float* params_mut, hipStream_t stream_h) {
+  void* stream = reinterpret_cast<void*>(stream_h);
   int rc = common_checks(f, B); if (rc) return rc;
   rc = ensure_device(f); if (rc) return rc;
   IPK_REQUIRE(params && perm && x_nchw && out_nchw && workspace, "null argument");
@@ -557,49 +686,56 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
   Ctx c{f, B, (int64_t)B * f->P, f->cfg.z_channels, f->cfg.dtype, reinterpret_cast<hipStream_t>(stream),
         params, perm, reinterpret_cast<const unsigned char*>(shadow), reinterpret_cast<unsigned char*>(workspace),
         make_plan(*f, B, save ? 1 : 0)};
+  c.Bfull = B;
   const int z = f->cfg.z_channels;
   rc = ipoke_nchw_to_state(x_nchw, c.state(0), B, z, f->P, c.ld, stream); if (rc) return rc;
   if (!init) {
-    rc = ipoke_cond_prepare(cond_nchw, c.at<void>(c.plan.cond_act), B, f->cfg.cond_channels, f->P, IPOKE_ACT_ELU, c.dtype, stream);
+    rc = ipoke_cond_prepare(cond_nchw, c.cond(), B, f->cfg.cond_channels, f->P, IPOKE_ACT_ELU, c.dtype, stream);
     if (rc) return rc;
   }
   IPK_HIP(hipMemsetAsync(c.at<void>(c.plan.slots), 0, (size_t)f->nslots * B * 4 * sizeof(float), c.s));
+  // the data-dependent ActNorm init needs whole-batch statistics: one lane
+  std::vector<Ctx> lanes;
+  rc = make_lanes(c, init ? 1 : f->n_lanes, lanes); if (rc) return rc;
+  rc = fork_lanes(f, c.s, lanes); if (rc) return rc;
+  static const int rpb = getenv("IPOKE_MCF_ROWS") ? atoi(getenv("IPOKE_MCF_ROWS")) : 16;
   int cur = 0;
   for (size_t i = 0; i < f->ops.size(); ++i) {
     const Op& op = f->ops[i];
+    if (init && op.type != OP_ACTNORM) continue;   // zero-initialised couplings are the identity (macow_utils.py:231-250)
     const int nxt = save ? (int)i + 1 : (cur ^ 1);
-    const float* in = c.state(cur); float* out = c.state(nxt);
-    if (op.type == OP_ACTNORM) {
-      const float* ls = op.p_ls >= 0 ? params + op.p_ls : nullptr;
-      const float* bs = op.p_bias >= 0 ? params + op.p_bias : nullptr;
-      const int32_t* idx = op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr;
-      if (init && op.p_ls >= 0) {
-        rc = ipoke_actnorm_init(in, (int)c.M, c.ld, op.c0, op.Cn, params_mut + op.p_ls, params_mut + op.p_bias, stream);
-        if (rc) return rc;
+    for (const Ctx& l : lanes) {
+      const float* in = l.state(cur); float* out = l.state(nxt);
+      if (op.type == OP_ACTNORM) {
+        const float* ls = op.p_ls >= 0 ? params + op.p_ls : nullptr;
+        const float* bs = op.p_bias >= 0 ? params + op.p_bias : nullptr;
+        const int32_t* idx = op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr;
+        if (init && op.p_ls >= 0) {
+          rc = ipoke_actnorm_init(in, (int)l.M, l.ld, op.c0, op.Cn, params_mut + op.p_ls, params_mut + op.p_bias, l.stream());
+          if (rc) return rc;
+        }
+        rc = ipoke_actnorm_fwd(in, out, (int)l.M, l.ld, op.c0, op.Cn, ls, bs, idx, l.stream());
+      } else if (op.type == OP_MCF) {
+        ipoke_mcf_desc d; mcf_desc(l, op, d);
+        d.x = in; d.y = out;
+        d.logdet_slot = l.slot(op.slot);
+        d.rows_per_block = rpb;   // 16: 4 slices per sample -> slot width 4
+        if (save) { d.a2_save = l.rows(op.ws_a, (int64_t)op.K2p * f->esz); d.scale_save = l.rowsf(op.ws_b, op.C); }
+        rc = ipoke_mcf_fwd(&d, l.dtype, l.stream());
+      } else {
+        const int64_t hb = (int64_t)f->cfg.hidden * f->esz;
+        void* h1 = l.rows(save ? op.ws_a : l.plan.tmp_h1, hb);
+        void* h2 = l.rows(save ? op.ws_b : l.plan.tmp_h2, hb);
+        void* zc = save ? l.rows(op.ws_g, (int64_t)op.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
+        rc = nice_net(l, op, in, h1, h2, zc); if (rc) return rc;
+        ipoke_affine_desc a; nice_affine_desc(l, op, a);
+        rc = ipoke_affine_fwd(&a, in, out, save ? l.rowsf(op.ws_c, op.cout) : nullptr, l.slot(op.slot), 4, l.B, l.stream());
       }
-      rc = ipoke_actnorm_fwd(in, out, (int)c.M, c.ld, op.c0, op.Cn, ls, bs, idx, stream);
-    } else if (init) {
-      // zero-initialised couplings are the identity (macow_utils.py:231-250 with init_scale = 0)
-      continue;
-    } else if (op.type == OP_MCF) {
-      ipoke_mcf_desc d; mcf_desc(c, op, d);
-      d.x = in; d.y = out;
-      d.logdet_slot = c.at<float>(c.plan.slots) + (int64_t)op.slot * B * 4;
-      static const int rpb = getenv("IPOKE_MCF_ROWS") ? atoi(getenv("IPOKE_MCF_ROWS")) : 16;
-      d.rows_per_block = rpb;   // 16: 4 slices per sample -> slot width 4
-      if (save) { d.a2_save = c.at<void>(op.ws_a); d.scale_save = c.at<float>(op.ws_b); }
-      rc = ipoke_mcf_fwd(&d, c.dtype, stream);
-    } else {
-      void* h1 = save ? c.at<void>(op.ws_a) : c.at<void>(c.plan.tmp_h1);
-      void* h2 = save ? c.at<void>(op.ws_b) : c.at<void>(c.plan.tmp_h2);
-      rc = nice_net(c, op, in, h1, h2, save ? c.at<void>(op.ws_g) : c.at<void>(c.plan.tmp_zc)); if (rc) return rc;
-      ipoke_affine_desc a; nice_affine_desc(c, op, a);
-      rc = ipoke_affine_fwd(&a, in, out, save ? c.at<float>(op.ws_c) : nullptr,
-                            c.at<float>(c.plan.slots) + (int64_t)op.slot * B * 4, 4, B, stream);
+      if (rc) return rc;
     }
-    if (rc) return rc;
     cur = nxt;
   }
+  rc = join_lanes(f, lanes, c.s); if (rc) return rc;
   rc = ipoke_state_to_nchw(c.state(cur), out_nchw, B, z, f->P, c.ld, stream); if (rc) return rc;
   if (logdet) {
     rc = ipoke_actnorm_logdet(params, f->d_lsrefs, (int)f->lsrefs.size(), f->P, c.at<float>(c.plan.ls_const), stream);
@@ -607,14 +743,20 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
     rc = ipoke_logdet_finalize(c.at<float>(c.plan.slots), init ? 0 : f->nslots, B, 4, 0.f, c.at<float>(c.plan.ls_const), logdet, stream);
     if (rc) return rc;
   }
-  f->last_fwd_B = B; f->have_saved = save != 0;
   return IPOKE_OK;
 }
 
 extern "C" int ipoke_flow_forward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
                                   const float* x_nchw, const float* cond_nchw, int B, float* out_nchw, float* logdet,
                                   void* workspace, int save_for_backward, void* stream) {
-  return run_forward(f, params, perm, shadow, x_nchw, cond_nchw, B, out_nchw, logdet, workspace, save_for_backward, 0, nullptr, stream);
+  IPK_REQUIRE(f != nullptr, "null flow handle");
+  std::vector<uintptr_t> key = {1, (uintptr_t)params, (uintptr_t)perm, (uintptr_t)shadow, (uintptr_t)x_nchw, (uintptr_t)cond_nchw,
+                                (uintptr_t)B, (uintptr_t)out_nchw, (uintptr_t)logdet, (uintptr_t)workspace, (uintptr_t)save_for_backward};
+  int rc = with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
+    return run_forward(f, params, perm, shadow, x_nchw, cond_nchw, B, out_nchw, logdet, workspace, save_for_backward, 0, nullptr, s);
+  });
+  if (rc == IPOKE_OK) { f->last_fwd_B = B; f->have_saved = save_for_backward != 0; }
+  return rc;
 }
 
 extern "C" int ipoke_flow_init_forward(ipoke_flow* f, float* params, const int32_t* perm, const float* x_nchw, int B,
@@ -627,63 +769,91 @@ extern "C" int ipoke_flow_init_forward(ipoke_flow* f, float* params, const int32
     IPK_HIP(hipMemsetAsync(params + op.p_g, 0, n * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
     IPK_HIP(hipMemsetAsync(params + op.p_b, 0, n * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
   }
-  return run_forward(f, params, perm, nullptr, x_nchw, nullptr, B, out_nchw, logdet, workspace, 0, 1, params, stream);
+  f->have_saved = false;
+  return run_forward(f, params, perm, nullptr, x_nchw, nullptr, B, out_nchw, logdet, workspace, 0, 1, params, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
-                                  const float* z_nchw, const float* cond_nchw, int B, float* x_nchw, void* workspace,
-                                  void* stream) {
+static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                       const float* z_nchw, const float* cond_nchw, int B, float* x_nchw, void* workspace, hipStream_t stream_h) {
+  void* stream = reinterpret_cast<void*>(stream_h);
   int rc = common_checks(f, B); if (rc) return rc;
   rc = ensure_device(f); if (rc) return rc;
   IPK_REQUIRE(params && perm && shadow && z_nchw && cond_nchw && x_nchw && workspace, "null argument");
   Ctx c{f, B, (int64_t)B * f->P, f->cfg.z_channels, f->cfg.dtype, reinterpret_cast<hipStream_t>(stream),
         params, perm, reinterpret_cast<const unsigned char*>(shadow), reinterpret_cast<unsigned char*>(workspace),
         make_plan(*f, B, 0)};
+  c.Bfull = B;
   const int z = f->cfg.z_channels;
   rc = ipoke_nchw_to_state(z_nchw, c.state(0), B, z, f->P, c.ld, stream); if (rc) return rc;
-  rc = ipoke_cond_prepare(cond_nchw, c.at<void>(c.plan.cond_act), B, f->cfg.cond_channels, f->P, IPOKE_ACT_ELU, c.dtype, stream);
+  rc = ipoke_cond_prepare(cond_nchw, c.cond(), B, f->cfg.cond_channels, f->P, IPOKE_ACT_ELU, c.dtype, stream);
   if (rc) return rc;
+  std::vector<Ctx> lanes;
+  rc = make_lanes(c, f->n_lanes, lanes); if (rc) return rc;
+  rc = fork_lanes(f, c.s, lanes); if (rc) return rc;
+  const int64_t hb = (int64_t)f->cfg.hidden * f->esz;
   int cur = 0;
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
     const Op& op = f->ops[i];
-    const float* in = c.state(cur); float* out = c.state(cur ^ 1);
-    if (op.type == OP_ACTNORM) {
-      rc = ipoke_actnorm_inv(in, out, (int)c.M, c.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
-                             op.p_bias >= 0 ? params + op.p_bias : nullptr, op.idx_bwd >= 0 ? perm + op.idx_bwd : nullptr, stream);
-    } else if (op.type == OP_MCF) {
-      ipoke_mcf_desc d; mcf_desc(c, op, d);
-      d.x = in; d.y = out;
-      rc = ipoke_mcf_inv(&d, c.dtype, stream);
-    } else {
-      // the conditioning channels are untouched by the coupling, so the net sees the same input as in forward
-      rc = nice_net(c, op, in, c.at<void>(c.plan.tmp_h1), c.at<void>(c.plan.tmp_h2), c.at<void>(c.plan.tmp_zc)); if (rc) return rc;
-      ipoke_affine_desc a; nice_affine_desc(c, op, a);
-      rc = ipoke_affine_inv(&a, in, out, B, stream);
+    for (const Ctx& l : lanes) {
+      const float* in = l.state(cur); float* out = l.state(cur ^ 1);
+      if (op.type == OP_ACTNORM) {
+        rc = ipoke_actnorm_inv(in, out, (int)l.M, l.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
+                               op.p_bias >= 0 ? params + op.p_bias : nullptr, op.idx_bwd >= 0 ? perm + op.idx_bwd : nullptr,
+                               l.stream());
+      } else if (op.type == OP_MCF) {
+        ipoke_mcf_desc d; mcf_desc(l, op, d);
+        d.x = in; d.y = out;
+        rc = ipoke_mcf_inv(&d, l.dtype, l.stream());
+      } else {
+        // the conditioning channels are untouched by the coupling, so the net sees the same input as in forward
+        rc = nice_net(l, op, in, l.rows(l.plan.tmp_h1, hb), l.rows(l.plan.tmp_h2, hb), l.rows(l.plan.tmp_zc, 64L * f->esz));
+        if (rc) return rc;
+        ipoke_affine_desc a; nice_affine_desc(l, op, a);
+        rc = ipoke_affine_inv(&a, in, out, l.B, l.stream());
+      }
+      if (rc) return rc;
     }
-    if (rc) return rc;
     cur ^= 1;
   }
+  rc = join_lanes(f, lanes, c.s); if (rc) return rc;
   return ipoke_state_to_nchw(c.state(cur), x_nchw, B, z, f->P, c.ld, stream);
 }
 
+extern "C" int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                                  const float* z_nchw, const float* cond_nchw, int B, float* x_nchw, void* workspace,
+                                  void* stream) {
+  IPK_REQUIRE(f != nullptr, "null flow handle");
+  std::vector<uintptr_t> key = {2, (uintptr_t)params, (uintptr_t)perm, (uintptr_t)shadow, (uintptr_t)z_nchw, (uintptr_t)cond_nchw,
+                                (uintptr_t)B, (uintptr_t)x_nchw, (uintptr_t)workspace};
+  return with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
+    return run_reverse(f, params, perm, shadow, z_nchw, cond_nchw, B, x_nchw, workspace, s);
+  });
+}
+
 // ------------------------------------------------------------------------------------------------
-extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
-                                   const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
-                                   void* workspace, void* stream) {
+static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                        const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
+                        void* workspace, hipStream_t stream_h) {
+  void* stream = reinterpret_cast<void*>(stream_h);
   int rc = common_checks(f, B); if (rc) return rc;
+  rc = ensure_device(f); if (rc) return rc;
   IPK_REQUIRE(params && perm && shadow && d_out_nchw && d_logdet && grads && workspace, "null argument");
-  if (!f->have_saved || f->last_fwd_B != B)
-    return fail(IPOKE_ERR_STATE, "ipoke_flow_backward needs a preceding ipoke_flow_forward(save_for_backward=1) with the same batch");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Ctx c{f, B, (int64_t)B * f->P, f->cfg.z_channels, f->cfg.dtype, s, params, perm,
         reinterpret_cast<const unsigned char*>(shadow), reinterpret_cast<unsigned char*>(workspace), make_plan(*f, B, 1)};
-  const int z = f->cfg.z_channels, hid = f->cfg.hidden, M = (int)c.M;
-  float* G[2] = {c.at<float>(c.plan.g0), c.at<float>(c.plan.g1)};
-  float* dld = c.at<float>(c.plan.dld);
-  rc = ipoke_nchw_to_state(d_out_nchw, G[0], B, z, f->P, c.ld, stream); if (rc) return rc;
-  IPK_HIP(hipMemcpyAsync(dld, d_logdet, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  c.Bfull = B;
+  const int z = f->cfg.z_channels, hid = f->cfg.hidden;
+  const int64_t hb = (int64_t)hid * f->esz;
+  rc = ipoke_nchw_to_state(d_out_nchw, c.at<float>(c.plan.g0), B, z, f->P, c.ld, stream); if (rc) return rc;
+  IPK_HIP(hipMemcpyAsync(c.dld(), d_logdet, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  std::vector<Ctx> lanes;
+  rc = make_lanes(c, f->n_lanes, lanes); if (rc) return rc;
+  rc = fork_lanes(f, s, lanes); if (rc) return rc;
+  // Weight gradients reduce over the whole batch: they run on the side stream (or on lane 0 when it is disabled)
+  // after every lane has produced the operands of that layer.
   hipStream_t ws_stream = f->use_side ? f->side : s;
   void* wstream = reinterpret_cast<void*>(ws_stream);
+  auto wgrads_wait_lanes = [&]() -> int { return join_lanes(f, lanes, ws_stream); };
   // Every parameter gradient is written exactly once per backward (no accumulation, no memset).  The weight gradients
   // of the MCF layers are tiny GEMMs (a handful of output tiles): they are deferred and issued as batched launches,
   // one per run of same-shape layers (= one level), using the per-layer saved operands that stay in the workspace.
@@ -693,14 +863,14 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
     if (pend_lo < 0) return IPOKE_OK;
     const Op& op = f->ops[pend_op];
     const int nb = pend_hi - pend_lo + 1;
-    if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
+    int r = wgrads_wait_lanes(); if (r) return r;
     ipoke_wgrad_desc w; std::memset(&w, 0, sizeof(w));
     w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = w.kh = w.kw = 1; w.sd = w.sh = w.sw = 1;
     const int K2 = op.H + f->cfg.cond_channels;
     w.a_f32 = 0; w.a_sn = 64L * op.K2p; w.a_sh = 8L * op.K2p; w.a_sw = op.K2p; w.a_sc = 1; w.Kc_real = K2; w.Kc = op.K2p;
     w.ldy = op.K3p; w.Nout = 2 * op.C; w.w_sn = K2; w.w_sc = 1; w.w_st = 0;
-    int r = ipoke_conv_wgrad_batched(&w, reinterpret_cast<const unsigned char*>(f->d_w2tab) + (size_t)pend_lo * ipoke_wgrad_batch_entry_size(),
-                                     nb, c.ws, c.ws, grads, c.dtype, wstream);
+    r = ipoke_conv_wgrad_batched(&w, reinterpret_cast<const unsigned char*>(f->d_w2tab) + (size_t)pend_lo * ipoke_wgrad_batch_entry_size(),
+                                 nb, c.ws, c.ws, grads, c.dtype, wstream);
     if (r) return r;
     std::memset(&w, 0, sizeof(w));
     w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = 2; w.kw = 3; w.sd = w.sh = w.sw = 1;
@@ -716,52 +886,60 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
     IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0));
   }
   int cur = 0;
+  const int64_t goff[2] = {c.plan.g0, c.plan.g1};
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
     const Op& op = f->ops[i];
-    const float* gin = G[cur]; float* gout = G[cur ^ 1];
-    const float* xin = c.state(i);                 // saved input of op i
-    float* dbp = c.at<float>(c.plan.dbias_part) + (int64_t)i * (B + 1) * 128;
-    if (op.type == OP_ACTNORM) {
-      rc = ipoke_actnorm_bwd(gin, xin, gout, M, c.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
-                             op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr, dld, B, f->P, dbp, stream);
-      if (rc) return rc;
-    } else if (op.type == OP_MCF) {
-      ipoke_mcf_desc d; mcf_desc(c, op, d);
-      d.x = xin; d.dy = gin; d.dx = gout; d.dld = dld;
-      d.a2_save = c.at<void>(op.ws_a); d.scale_save = c.at<float>(op.ws_b);
-      d.dparams_save = c.at<void>(op.ws_c); d.dc_save = c.at<void>(op.ws_d); d.dbias_part = dbp;
-      d.y = gout;   // unused by the backward kernel, must be non-null for the shared validator
-      rc = ipoke_mcf_bwd(&d, c.dtype, stream); if (rc) return rc;
+    for (const Ctx& l : lanes) {
+      const float* gin = l.rowsf(goff[cur], l.ld); float* gout = l.rowsf(goff[cur ^ 1], l.ld);
+      const float* xin = l.state(i);                 // saved input of op i
+      if (op.type == OP_ACTNORM) {
+        rc = ipoke_actnorm_bwd(gin, xin, gout, (int)l.M, l.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
+                               op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr, l.dld(), l.B, f->P, l.dbp(i, 2 * op.Cn), l.stream());
+        if (rc) return rc;
+      } else if (op.type == OP_MCF) {
+        ipoke_mcf_desc d; mcf_desc(l, op, d);
+        d.x = xin; d.dy = gin; d.dx = gout; d.dld = l.dld();
+        d.a2_save = l.rows(op.ws_a, (int64_t)op.K2p * f->esz); d.scale_save = l.rowsf(op.ws_b, op.C);
+        d.dparams_save = l.rows(op.ws_c, (int64_t)op.K3p * f->esz); d.dc_save = l.rows(op.ws_d, (int64_t)op.Hq * f->esz);
+        d.dbias_part = l.dbp(i, 2 * op.C);
+        d.y = gout;   // unused by the backward kernel, must be non-null for the shared validator
+        rc = ipoke_mcf_bwd(&d, l.dtype, l.stream()); if (rc) return rc;
+      } else {
+        const void* h1 = l.rows(op.ws_a, hb); const void* h2 = l.rows(op.ws_b, hb);
+        void* dprm = l.rows(op.ws_d, (int64_t)op.Kc3 * f->esz); void* dp2 = l.rows(op.ws_e, hb); void* dp1 = l.rows(op.ws_f, hb);
+        rc = ipoke_affine_bwd(op.cout, op.t_off, op.t_stride, f->P, l.ld, gin, xin, l.rowsf(op.ws_c, op.cout), l.dld(), gout, dprm,
+                              op.Kc3, l.dbp(i, 2 * op.cout), l.B, l.dtype, l.stream());
+        if (rc) return rc;
+        ipoke_conv_desc d;
+        // conv3 data gradient, times ELU'(h2)
+        set_conv8(d, l.B, 3, 1); d.transposed = 1;
+        set_a_dense(d, dprm, op.Kc3, op.Kc3);
+        d.W = l.sh(op.sh_c3t); d.ldw = 9 * op.Kc3; d.Nout = hid; d.dact = h2; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
+        d.C = dp2; d.ldc = hid;
+        rc = ipoke_conv_forward(&d, l.dtype, l.stream()); if (rc) return rc;
+        // conv2 data gradient, times ELU'(h1)
+        set_conv8(d, l.B, 1, 0);
+        set_a_dense(d, dp2, hid, hid);
+        d.W = l.sh(op.sh_c2t); d.ldw = hid; d.Nout = hid; d.dact = h1; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
+        d.C = dp1; d.ldc = hid;
+        rc = ipoke_conv_forward(&d, l.dtype, l.stream()); if (rc) return rc;
+        // conv1 data gradient accumulated into the conditioning channels
+        set_conv8(d, l.B, 3, 1); d.transposed = 1;
+        set_a_dense(d, dp1, hid, hid);
+        d.W = l.sh(op.sh_c1t); d.ldw = 9 * hid; d.Nout = op.cin; d.C = gout; d.c_f32 = 1; d.c_accumulate = 1; d.ldc = l.ld;
+        d.c_coff = op.z_off; d.c_cstride = op.z_stride; d.splitk = nice_splitk(l);
+        rc = ipoke_conv_forward(&d, l.dtype, l.stream()); if (rc) return rc;
+      }
+    }
+    if (op.type == OP_MCF) {
       // weight gradients: deferred, batched per run of same-width layers
       if (pend_lo >= 0 && (f->ops[pend_op].C != op.C || pend_hi - pend_lo + 1 >= 256)) { rc = flush_mcf(); if (rc) return rc; }
       if (pend_lo < 0) { pend_hi = op.mcf_idx; pend_op = i; }
       pend_lo = op.mcf_idx;
-    } else {
+    } else if (op.type == OP_NICE) {
+      rc = wgrads_wait_lanes(); if (rc) return rc;
       const void* h1 = c.at<void>(op.ws_a); const void* h2 = c.at<void>(op.ws_b);
-      void* dprm = c.at<void>(op.ws_d); void* dp2 = c.at<void>(op.ws_e); void* dp1 = c.at<void>(op.ws_f);
-      rc = ipoke_affine_bwd(op.cout, op.t_off, op.t_stride, f->P, c.ld, gin, xin, c.at<float>(op.ws_c), dld, gout, dprm,
-                            op.Kc3, dbp, B, c.dtype, stream);
-      if (rc) return rc;
-      ipoke_conv_desc d;
-      // conv3 data gradient, times ELU'(h2)
-      set_conv8(d, B, 3, 1); d.transposed = 1;
-      set_a_dense(d, dprm, op.Kc3, op.Kc3);
-      d.W = c.sh(op.sh_c3t); d.ldw = 9 * op.Kc3; d.Nout = hid; d.dact = h2; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
-      d.C = dp2; d.ldc = hid;
-      rc = ipoke_conv_forward(&d, c.dtype, stream); if (rc) return rc;
-      // conv2 data gradient, times ELU'(h1)
-      set_conv8(d, B, 1, 0);
-      set_a_dense(d, dp2, hid, hid);
-      d.W = c.sh(op.sh_c2t); d.ldw = hid; d.Nout = hid; d.dact = h1; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
-      d.C = dp1; d.ldc = hid;
-      rc = ipoke_conv_forward(&d, c.dtype, stream); if (rc) return rc;
-      // conv1 data gradient accumulated into the conditioning channels
-      set_conv8(d, B, 3, 1); d.transposed = 1;
-      set_a_dense(d, dp1, hid, hid);
-      d.W = c.sh(op.sh_c1t); d.ldw = 9 * hid; d.Nout = op.cin; d.C = gout; d.c_f32 = 1; d.c_accumulate = 1; d.ldc = c.ld;
-      d.c_coff = op.z_off; d.c_cstride = op.z_stride; d.splitk = nice_splitk(c);
-      rc = ipoke_conv_forward(&d, c.dtype, stream); if (rc) return rc;
-      if (f->use_side) { hipEvent_t e = next_event(f); IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0)); }
+      const void* dprm = c.at<void>(op.ws_d); const void* dp2 = c.at<void>(op.ws_e); const void* dp1 = c.at<void>(op.ws_f);
       ipoke_wgrad_desc w;
       auto base8 = [&](int k, int pad) {
         std::memset(&w, 0, sizeof(w));
@@ -791,6 +969,7 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
     cur ^= 1;
   }
   rc = flush_mcf(); if (rc) return rc;
+  rc = join_lanes(f, lanes, s); if (rc) return rc;
   // bias / ActNorm parameter gradients: one multi-tensor reduction over the per-sample partial sums of every layer
   rc = ipoke_reduce_rows_multi(reinterpret_cast<const float*>(c.ws), grads, f->d_redtab, f->n_red, B, stream); if (rc) return rc;
   if (f->use_side) {
@@ -799,6 +978,19 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
   }
   rc = ipoke_wn_bwd_multi(params, grads, c.wn_inv(), f->d_wjobs, (int)f->wjobs.size(), (int)f->wn_rows, stream);
   if (rc) return rc;
-  if (dx_nchw) { rc = ipoke_state_to_nchw(G[cur], dx_nchw, B, z, f->P, c.ld, stream); if (rc) return rc; }
+  if (dx_nchw) { rc = ipoke_state_to_nchw(c.rowsf(goff[cur], c.ld), dx_nchw, B, z, f->P, c.ld, stream); if (rc) return rc; }
   return IPOKE_OK;
+}
+
+extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                                   const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
+                                   void* workspace, void* stream) {
+  IPK_REQUIRE(f != nullptr, "null flow handle");
+  if (!f->have_saved || f->last_fwd_B != B)
+    return fail(IPOKE_ERR_STATE, "ipoke_flow_backward needs a preceding ipoke_flow_forward(save_for_backward=1) with the same batch");
+  std::vector<uintptr_t> key = {3, (uintptr_t)params, (uintptr_t)perm, (uintptr_t)shadow, (uintptr_t)d_out_nchw, (uintptr_t)d_logdet,
+                                (uintptr_t)B, (uintptr_t)grads, (uintptr_t)dx_nchw, (uintptr_t)workspace};
+  return with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
+    return run_backward(f, params, perm, shadow, d_out_nchw, d_logdet, B, grads, dx_nchw, workspace, s);
+  });
 }

@@ -101,10 +101,48 @@ struct McfParams {
 // stage the sample's latent (fp32, channels-last with pitch ld) into LDS as T [64][Cp] (zero padded)
 template <typename T>
 __device__ __forceinline__ void stage_x(const float* xb, int ld, int C, int Cp, unsigned char* xs, int pitch) {
+  typedef typename Pack4<T>::type pack_t;
+  if (((C | ld | Cp) & 3) == 0) {
+    // 16-byte loads, two per thread in flight (a sample is at most 64 x 64 floats = 1024 groups)
+    const int G = Cp >> 2, n = 64 * G;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 2 * blockDim.x) {
+      const int i1 = i0 + blockDim.x;
+      const bool has1 = i1 < n;
+      const int j1 = has1 ? i1 : i0;
+      const int p0 = i0 / G, c0 = (i0 - p0 * G) * 4, p1 = j1 / G, c1 = (j1 - p1 * G) * 4;
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (c0 < C) v0 = *reinterpret_cast<const f32x4*>(xb + (long)p0 * ld + c0);
+      if (c1 < C) v1 = *reinterpret_cast<const f32x4*>(xb + (long)p1 * ld + c1);
+      pack_t t0, t1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { t0[q] = ET<T>::from_f32(v0[q]); t1[q] = ET<T>::from_f32(v1[q]); }
+      *reinterpret_cast<pack_t*>(xs + p0 * pitch + c0 * (int)sizeof(T)) = t0;
+      if (has1) *reinterpret_cast<pack_t*>(xs + p1 * pitch + c1 * (int)sizeof(T)) = t1;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < 64 * Cp; i += blockDim.x) {
     const int p = i / Cp, c = i - p * Cp;
     const float v = c < C ? xb[(long)p * ld + c] : 0.f;
     *reinterpret_cast<T*>(xs + p * pitch + c * (int)sizeof(T)) = ET<T>::from_f32(v);
+  }
+}
+
+// y[:, C:ld] = x[:, C:ld] for `rows` positions: independent of the coupling, issued first
+__device__ __forceinline__ void copy_rest(const float* x, float* y, long row0, int rows, int C, int ld) {
+  const int rest = ld - C;
+  if (rest <= 0) return;
+  if (((C | ld) & 3) == 0) {
+    const int R4 = rest >> 2;
+    for (int e = threadIdx.x; e < rows * R4; e += blockDim.x) {
+      const int p = e / R4, c = C + (e - p * R4) * 4;
+      *reinterpret_cast<f32x4*>(y + (row0 + p) * ld + c) = *reinterpret_cast<const f32x4*>(x + (row0 + p) * ld + c);
+    }
+    return;
+  }
+  for (int e = threadIdx.x; e < rows * rest; e += blockDim.x) {
+    const int p = e / rest, c = C + e - p * rest;
+    y[(row0 + p) * ld + c] = x[(row0 + p) * ld + c];
   }
 }
 
@@ -225,6 +263,136 @@ __device__ __forceinline__ void mcf_gemm2(const McfParams& P, const unsigned cha
   }
 }
 
+// ---- register-resident weights (bf16 fast path) ---------------------------------------------------
+// A layer's weights are used once per launch and come from HBM/L2 with ~1 us latency.  Fetching them fragment by
+// fragment inside the K loops serialises 12 (forward) to 48 (backward) such latencies per workgroup, which is what
+// these kernels used to spend their time on.  With two waves per SIMD a wave owns 256 VGPRs: enough to issue *every*
+// B-fragment load of the layer up front (forward: 144 VGPRs) and let the matrix-core loops consume them as they land.
+static constexpr int kW1Steps = 2;      // Cp / KS   (C <= 64, bf16)
+static constexpr int kW2Steps = 12;     // K2p / KS  (4C + Cc <= 384, bf16)
+template <typename T> struct McfW {
+  typename ET<T>::frag w1[6][kW1Steps][kJ16];
+  typename ET<T>::frag w2[kW2Steps][kJ8];
+};
+template <typename T>
+__device__ __forceinline__ void mcf_preload(const McfParams& P, McfW<T>& w) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
+  const int NF1 = (P.H + 15) >> 4, NF2 = (2 * P.C + 15) >> 4, cs = P.Cp / KS, n2 = P.K2p / KS;
+  const T* W1 = reinterpret_cast<const T*>(P.W1);
+  const T* W2 = reinterpret_cast<const T*>(P.W2);
+#pragma unroll
+  for (int tap = 0; tap < 6; ++tap)
+#pragma unroll
+    for (int st = 0; st < kW1Steps; ++st)
+#pragma unroll
+      for (int j = 0; j < kJ16; ++j)
+        if (st < cs && wave + kMcfWaves * j < NF1)
+          w.w1[tap][st][j] = load_wfrag<T>(W1, P.K1p, (wave + kMcfWaves * j) * 16 + r, tap * P.Cp + st * KS + E16 * gq);
+#pragma unroll
+  for (int st = 0; st < kW2Steps; ++st)
+#pragma unroll
+    for (int j = 0; j < kJ8; ++j)
+      if (st < n2 && wave + kMcfWaves * j < NF2)
+        w.w2[st][j] = load_wfrag<T>(W2, P.K2p, (wave + kMcfWaves * j) * 16 + r, st * KS + E16 * gq);
+}
+
+template <typename T, int MF, typename RowFn>
+__device__ __forceinline__ void mcf_gemm1_pre(const McfParams& P, const McfGeom& g, RowFn rowfn, const unsigned char* zrow,
+                                              unsigned char* a2, int a2_pitch, const McfW<T>& w) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, gq = lane >> 4;
+  const int NF1 = (P.H + 15) >> 4, cs = P.Cp / KS;
+  f32x4 acc[MF][kJ16];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < kJ16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned char* tile[MF]; int pos[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) rowfn(i * 16 + r, tile[i], pos[i]);
+  const int xpitch = P.Cp * (int)sizeof(T) + 16;
+#pragma unroll
+  for (int tap = 0; tap < 6; ++tap) {
+    const unsigned char* src[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) src[i] = tap_src_fwd(tile[i], zrow, xpitch, g, pos[i], tap) + E16 * gq * (int)sizeof(T);
+#pragma unroll
+    for (int st = 0; st < kW1Steps; ++st) {
+      if (st < cs) {
+        frag_t fa[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + st * KS * (int)sizeof(T));
+#pragma unroll
+        for (int j = 0; j < kJ16; ++j) {
+          if (wave + kMcfWaves * j < NF1) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) mma64(fa[i], w.w1[tap][st][j], acc[i][j]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kJ16; ++j) {
+    const int n = (wave + kMcfWaves * j) * 16 + 4 * gq;
+    if (n < P.H) {
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        typename Pack4<T>::type tv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tv[q] = ET<T>::from_f32(act_apply(IPOKE_ACT_ELU, acc[i][j][q]));
+        *reinterpret_cast<typename Pack4<T>::type*>(a2 + (i * 16 + r) * a2_pitch + n * (int)sizeof(T)) = tv;
+      }
+    }
+  }
+}
+
+template <typename T, int MF>
+__device__ __forceinline__ void mcf_gemm2_pre(const McfParams& P, const unsigned char* a2, int a2_pitch, float* prm, int prm_ld,
+                                              const McfW<T>& w) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, gq = lane >> 4;
+  const int N2 = 2 * P.C, NF2 = (N2 + 15) >> 4, n2 = P.K2p / KS;
+  f32x4 acc[MF][kJ8];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < kJ8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < kW2Steps; ++st) {
+    if (st < n2) {
+      frag_t fa[MF];
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+        fa[i] = *reinterpret_cast<const frag_t*>(a2 + (i * 16 + r) * a2_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
+#pragma unroll
+      for (int j = 0; j < kJ8; ++j) {
+        if (wave + kMcfWaves * j < NF2) {
+#pragma unroll
+          for (int i = 0; i < MF; ++i) mma64(fa[i], w.w2[st][j], acc[i][j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kJ8; ++j) {
+    const int n = (wave + kMcfWaves * j) * 16 + 4 * gq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (n + q < N2) {
+        const float b = P.bias2 ? P.bias2[n + q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) prm[(i * 16 + r) * prm_ld + n + q] = acc[i][j][q] + b;
+      }
+    }
+  }
+}
+
 // copy act(cond) rows and zero the K padding of the 1x1 conv's input tile
 template <typename T, typename RowFn>
 __device__ __forceinline__ void fill_cond(const McfParams& P, int rows, RowFn grow /* local row -> global row or -1 */,
@@ -242,11 +410,13 @@ __device__ __forceinline__ void fill_cond(const McfParams& P, int rows, RowFn gr
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <typename T, int MF>
+template <typename T, int MF, bool FAST>
 __global__ __launch_bounds__(kMcfThreads) void mcf_fwd_kernel(const McfParams P) {
   constexpr int MT = MF * 16, RS = 64 / MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float red[8];
+  McfW<T> wr;
+  if constexpr (FAST) mcf_preload<T>(P, wr);
   const int b = blockIdx.x / RS, rs = blockIdx.x % RS;
   const int pos0 = rs * MT;
   const McfGeom g = mcf_geom(P.order);
@@ -258,12 +428,28 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_fwd_kernel(const McfParams P)
   float* prm = reinterpret_cast<float*>(a2 + MT * a2_pitch);
 
   const float* xb = P.x + (long)b * 64 * P.ld;
+  const long row0 = (long)b * 64 + pos0;
+  // everything that only depends on the input is requested up front: the pass-through channels, the fp32 x of this
+  // slice for the affine epilogue, the latent tile and the conditioning rows
+  const bool vec = ((P.C | P.ld) & 3) == 0;
+  const int G4 = P.C >> 2;
+  constexpr int NE = (MF + 1) / 2;                 // epilogue items (row, 4-channel group) per thread
+  f32x4 xe[NE];
+  if (vec) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = threadIdx.x + k * kMcfThreads;
+      if (e < MT * G4) { const int p = e / G4, c = (e - p * G4) * 4; xe[k] = *reinterpret_cast<const f32x4*>(P.x + (row0 + p) * P.ld + c); }
+    }
+  }
+  copy_rest(P.x, P.y, row0, MT, P.C, P.ld);
   stage_x<T>(xb, P.ld, P.C, P.Cp, xs, xs_pitch);
   for (int i = threadIdx.x; i < xs_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(xs + 64 * xs_pitch)[i] = 0u;
   fill_cond<T>(P, MT, [&](int row) { return (long)b * 64 + pos0 + row; }, a2, a2_pitch);
   __syncthreads();
-  mcf_gemm1<T, MF>(P, g, [&](int row, const unsigned char*& tile, int& pos) { tile = xs; pos = pos0 + row; }, xs + 64 * xs_pitch,
-                   a2, a2_pitch);
+  auto rowfn = [&](int row, const unsigned char*& tile, int& pos) { tile = xs; pos = pos0 + row; };
+  if constexpr (FAST) mcf_gemm1_pre<T, MF>(P, g, rowfn, xs + 64 * xs_pitch, a2, a2_pitch, wr);
+  else mcf_gemm1<T, MF>(P, g, rowfn, xs + 64 * xs_pitch, a2, a2_pitch);
   __syncthreads();
   if (P.a2_save) {
     constexpr int E16 = ET<T>::E16;
@@ -275,23 +461,39 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_fwd_kernel(const McfParams P)
           *reinterpret_cast<const u32x4*>(a2 + row * a2_pitch + ch * 16);
     }
   }
-  mcf_gemm2<T, MF>(P, a2, a2_pitch, prm, N2);
+  if constexpr (FAST) mcf_gemm2_pre<T, MF>(P, a2, a2_pitch, prm, N2, wr);
+  else mcf_gemm2<T, MF>(P, a2, a2_pitch, prm, N2);
   __syncthreads();
   float ld_acc = 0.f;
-  const long row0 = (long)b * 64 + pos0;
-  for (int e = threadIdx.x; e < MT * P.C; e += blockDim.x) {
-    const int p = e / P.C, c = e - p * P.C;
-    const float mu = prm[p * N2 + c], s = prm[p * N2 + P.C + c];
-    const float sc = tanhf(0.5f * s) + 1.f;
-    const long off = (row0 + p) * P.ld + c;
-    P.y[off] = sc * P.x[off] + mu;
-    if (P.scale_save) P.scale_save[(row0 + p) * P.C + c] = sc;
-    ld_acc += logf(sc);
-  }
-  const int rest = P.ld - P.C;
-  for (int e = threadIdx.x; e < MT * rest; e += blockDim.x) {
-    const int p = e / rest, c = P.C + e - p * rest;
-    P.y[(row0 + p) * P.ld + c] = P.x[(row0 + p) * P.ld + c];
+  if (vec) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = threadIdx.x + k * kMcfThreads;
+      if (e < MT * G4) {
+        const int p = e / G4, c = (e - p * G4) * 4;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(prm + p * N2 + c);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(prm + p * N2 + P.C + c);
+        f32x4 sc, yv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sc[q] = tanhf(0.5f * sv[q]) + 1.f;
+          yv[q] = sc[q] * xe[k][q] + mu[q];
+          ld_acc += logf(sc[q]);
+        }
+        *reinterpret_cast<f32x4*>(P.y + (row0 + p) * P.ld + c) = yv;
+        if (P.scale_save) *reinterpret_cast<f32x4*>(P.scale_save + (row0 + p) * P.C + c) = sc;
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < MT * P.C; e += blockDim.x) {
+      const int p = e / P.C, c = e - p * P.C;
+      const float mu = prm[p * N2 + c], sv = prm[p * N2 + P.C + c];
+      const float sc = tanhf(0.5f * sv) + 1.f;
+      const long off = (row0 + p) * P.ld + c;
+      P.y[off] = sc * P.x[off] + mu;
+      if (P.scale_save) P.scale_save[(row0 + p) * P.C + c] = sc;
+      ld_acc += logf(sc);
+    }
   }
   const float tot = block_sum(ld_acc, red);
   if (threadIdx.x == 0 && P.ld_slot) P.ld_slot[(long)b * RS + rs] = tot;
@@ -299,9 +501,11 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_fwd_kernel(const McfParams P)
 
 // ------------------------------------------------------------------------------------------ inverse
 // Two samples per workgroup: a strip of 8 positions per sample fills one 16-row matrix-core tile.
-template <typename T>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(kMcfThreads) void mcf_inv_kernel(const McfParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  McfW<T> wr;                                 // the 8 strips reuse the same weights: fetched once
+  if constexpr (FAST) mcf_preload<T>(P, wr);
   const int b0 = blockIdx.x * 2;
   const int nb = min(2, P.B - b0);
   const McfGeom g = mcf_geom(P.order);
@@ -323,11 +527,14 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_inv_kernel(const McfParams P)
       const int s = row >> 3;
       return s < nb ? (long)(b0 + s) * 64 + strip_pos(row & 7) : -1L;
     }, a2, a2_pitch);
-    mcf_gemm1<T, 1>(P, g, [&](int row, const unsigned char*& tile, int& pos) {
+    auto rowfn = [&](int row, const unsigned char*& tile, int& pos) {
       tile = xs + (row >> 3) * 64 * xs_pitch; pos = strip_pos(row & 7);
-    }, xs + 128 * xs_pitch, a2, a2_pitch);
+    };
+    if constexpr (FAST) mcf_gemm1_pre<T, 1>(P, g, rowfn, xs + 128 * xs_pitch, a2, a2_pitch, wr);
+    else mcf_gemm1<T, 1>(P, g, rowfn, xs + 128 * xs_pitch, a2, a2_pitch);
     __syncthreads();
-    mcf_gemm2<T, 1>(P, a2, a2_pitch, prm, N2);
+    if constexpr (FAST) mcf_gemm2_pre<T, 1>(P, a2, a2_pitch, prm, N2, wr);
+    else mcf_gemm2<T, 1>(P, a2, a2_pitch, prm, N2);
     __syncthreads();
     for (int e = threadIdx.x; e < 16 * P.C; e += blockDim.x) {
       const int row = e / P.C, c = e - row * P.C;
@@ -352,12 +559,48 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_inv_kernel(const McfParams P)
 }
 
 // ------------------------------------------------------------------------------------------ backward (data path)
-template <typename T>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P) {
   constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
+  // FAST: every weight fragment of the layer and the saved ELU outputs are requested before anything else (see McfW).
+  // Phase (c) splits K over the two wave groups: wave w owns channel fragment w & 3 and taps 3*(w >> 2) .. +2.
+  typedef typename Pack4<T>::type pack_t;
+  frag_t w2t[4][kJ16];
+  frag_t w1t[3][8];
+  pack_t cact[4][kJ16];
+  if constexpr (FAST) {
+    const int lane0 = threadIdx.x & 63, wave0 = threadIdx.x >> 6, r0 = lane0 & 15, gq0 = lane0 >> 4;
+    const int NFh = (P.H + 15) >> 4, n3 = P.K3p / KS, hs = P.Hq / KS;
+    const T* W2T = reinterpret_cast<const T*>(P.W2T);
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < kJ16; ++j)
+        if (st < n3 && wave0 + kMcfWaves * j < NFh)
+          w2t[st][j] = load_wfrag<T>(W2T, P.K3p, (wave0 + kMcfWaves * j) * 16 + r0, st * KS + E16 * gq0);
+    const T* a2s0 = reinterpret_cast<const T*>(P.a2_save);
+#pragma unroll
+    for (int j = 0; j < kJ16; ++j) {
+      const int n = (wave0 + kMcfWaves * j) * 16 + 4 * gq0;
+      if (n < P.H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cact[i][j] = *reinterpret_cast<const pack_t*>(a2s0 + ((long)b * 64 + i * 16 + r0) * P.K2p + n);
+      }
+    }
+    const int nfrag0 = wave0 & 3, kh0 = wave0 >> 2;
+    if (nfrag0 < ((P.C + 15) >> 4)) {
+      const T* W1T = reinterpret_cast<const T*>(P.W1T);
+      const int Ktot = 6 * P.Hq;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+          if (st < hs) w1t[t][st] = load_wfrag<T>(W1T, Ktot, nfrag0 * 16 + r0, (kh0 * 3 + t) * P.Hq + st * KS + E16 * gq0);
+    }
+  }
   const McfGeom g = mcf_geom(P.order);
   const int N2 = 2 * P.C;
   const int dp_pitch = P.K3p * (int)sizeof(T) + 16;
@@ -369,38 +612,55 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
   const long row0 = (long)b * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
 
+  copy_rest(P.dy, P.dx, row0, 64, P.C, P.ld);      // pass-through channels: independent of everything below
   for (int i = threadIdx.x; i < N2; i += blockDim.x) colsum[i] = 0.f;
-  for (int i = threadIdx.x; i < 65 * dc_pitch / 4; i += blockDim.x) reinterpret_cast<unsigned*>(dc)[i] = 0u;
+  for (int i = threadIdx.x; i < 65 * dc_pitch / 16; i += blockDim.x) reinterpret_cast<u32x4*>(dc)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   // (a) gradients of the coupling parameters.  Vector path: every thread owns 4-channel groups of one row, so dy / x /
   // scale arrive as independent 16-byte loads and the column sums need one LDS atomic per channel and thread.
   const float g_ld = P.dld[b];
   T* dps = reinterpret_cast<T*>(P.dparams_save);
-  typedef typename Pack4<T>::type pack_t;
   if ((P.C & 3) == 0 && (P.ld & 3) == 0) {
     const int G4 = P.C >> 2;                                   // 4-channel groups per row
-    for (int e = threadIdx.x; e < 64 * G4; e += blockDim.x) {
-      const int p = e / G4, c = (e - p * G4) * 4;
-      const f32x4 gy = *reinterpret_cast<const f32x4*>(P.dy + (row0 + p) * P.ld + c);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(P.x + (row0 + p) * P.ld + c);
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(P.scale_save + (row0 + p) * P.C + c);
-      f32x4 ds, dxv;
-      pack_t tm, ts;
+    const int n = 64 * G4;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 2 * blockDim.x) {  // two items per thread with all six loads in flight
+      const int e1 = e0 + blockDim.x;
+      const int nit = e1 < n ? 2 : 1;
+      int pp[2], cc[2];
+      pp[0] = e0 / G4; cc[0] = (e0 - pp[0] * G4) * 4;
+      const int j1 = nit == 2 ? e1 : e0;
+      pp[1] = j1 / G4; cc[1] = (j1 - pp[1] * G4) * 4;
+      f32x4 gyv[2], xvv[2], scv[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float t = sc[q] - 1.f;
-        ds[q] = (gy[q] * xv[q] + g_ld / sc[q]) * 0.5f * (1.f - t * t);
-        dxv[q] = gy[q] * sc[q];
-        tm[q] = ET<T>::from_f32(gy[q]); ts[q] = ET<T>::from_f32(ds[q]);
-        atomicAdd(&colsum[c + q], gy[q]);
-        atomicAdd(&colsum[P.C + c + q], ds[q]);
+      for (int k = 0; k < 2; ++k) {
+        gyv[k] = *reinterpret_cast<const f32x4*>(P.dy + (row0 + pp[k]) * P.ld + cc[k]);
+        xvv[k] = *reinterpret_cast<const f32x4*>(P.x + (row0 + pp[k]) * P.ld + cc[k]);
+        scv[k] = *reinterpret_cast<const f32x4*>(P.scale_save + (row0 + pp[k]) * P.C + cc[k]);
       }
-      *reinterpret_cast<f32x4*>(dxd + p * P.C + c) = dxv;
-      *reinterpret_cast<pack_t*>(dp + p * dp_pitch + c * (int)sizeof(T)) = tm;
-      *reinterpret_cast<pack_t*>(dp + p * dp_pitch + (P.C + c) * (int)sizeof(T)) = ts;
-      if (dps) {
-        *reinterpret_cast<pack_t*>(dps + (row0 + p) * P.K3p + c) = tm;
-        *reinterpret_cast<pack_t*>(dps + (row0 + p) * P.K3p + P.C + c) = ts;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k < nit) {
+          const int p = pp[k], c = cc[k];
+          const f32x4 gy = gyv[k], xv = xvv[k], sc = scv[k];
+          f32x4 ds, dxv;
+          pack_t tm, ts;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float t = sc[q] - 1.f;
+            ds[q] = (gy[q] * xv[q] + g_ld / sc[q]) * 0.5f * (1.f - t * t);
+            dxv[q] = gy[q] * sc[q];
+            tm[q] = ET<T>::from_f32(gy[q]); ts[q] = ET<T>::from_f32(ds[q]);
+            atomicAdd(&colsum[c + q], gy[q]);
+            atomicAdd(&colsum[P.C + c + q], ds[q]);
+          }
+          *reinterpret_cast<f32x4*>(dxd + p * P.C + c) = dxv;
+          *reinterpret_cast<pack_t*>(dp + p * dp_pitch + c * (int)sizeof(T)) = tm;
+          *reinterpret_cast<pack_t*>(dp + p * dp_pitch + (P.C + c) * (int)sizeof(T)) = ts;
+          if (dps) {
+            *reinterpret_cast<pack_t*>(dps + (row0 + p) * P.K3p + c) = tm;
+            *reinterpret_cast<pack_t*>(dps + (row0 + p) * P.K3p + P.C + c) = ts;
+          }
+        }
       }
     }
     const int padc = P.K3p - N2;                               // zero the K padding (LDS tile and saved tensor)
@@ -436,28 +696,18 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
     for (int i = threadIdx.x; i < N2; i += blockDim.x) P.dbias_part[(long)b * N2 + i] = colsum[i];
 
   // (b) dA2[:, :H] = dparams x W2[:, :H]  , times ELU'(c) -> dc
-  if (P.dbg != 2 && P.dbg != 4) {
+  {
     const int NF = (P.H + 15) >> 4;
     f32x4 acc[4][kJ16];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < kJ16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const T* W2T = reinterpret_cast<const T*>(P.W2T);
-    constexpr int PF = 4;
+    const T* a2s = reinterpret_cast<const T*>(P.a2_save);
     const int nsteps = P.K3p / KS;
-    frag_t ring[PF][kJ16];
-    auto load_b = [&](int st, frag_t* b) {
+    if constexpr (FAST) {
 #pragma unroll
-      for (int j = 0; j < kJ16; ++j)
-        if (wave + kMcfWaves * j < NF) b[j] = load_wfrag<T>(W2T, P.K3p, (wave + kMcfWaves * j) * 16 + r, st * KS + E16 * gq);
-    };
-#pragma unroll
-    for (int d = 0; d < PF; ++d) if (d < nsteps) load_b(d, ring[d]);
-    for (int k0 = 0; k0 < nsteps; k0 += PF) {
-#pragma unroll
-      for (int d = 0; d < PF; ++d) {
-        const int st = k0 + d;
+      for (int st = 0; st < 4; ++st) {
         if (st < nsteps) {
           frag_t fa[4];
 #pragma unroll
@@ -467,13 +717,41 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
           for (int j = 0; j < kJ16; ++j)
             if (wave + kMcfWaves * j < NF) {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) mma64(fa[i], ring[d][j], acc[i][j]);
+              for (int i = 0; i < 4; ++i) mma64(fa[i], w2t[st][j], acc[i][j]);
             }
-          if (st + PF < nsteps) load_b(st + PF, ring[d]);
+        }
+      }
+    } else {
+      const T* W2T = reinterpret_cast<const T*>(P.W2T);
+      constexpr int PF = 4;
+      frag_t ring[PF][kJ16];
+      auto load_b = [&](int st, frag_t* bb) {
+#pragma unroll
+        for (int j = 0; j < kJ16; ++j)
+          if (wave + kMcfWaves * j < NF) bb[j] = load_wfrag<T>(W2T, P.K3p, (wave + kMcfWaves * j) * 16 + r, st * KS + E16 * gq);
+      };
+#pragma unroll
+      for (int d = 0; d < PF; ++d) if (d < nsteps) load_b(d, ring[d]);
+      for (int k0 = 0; k0 < nsteps; k0 += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+          const int st = k0 + d;
+          if (st < nsteps) {
+            frag_t fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              fa[i] = *reinterpret_cast<const frag_t*>(dp + (i * 16 + r) * dp_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
+#pragma unroll
+            for (int j = 0; j < kJ16; ++j)
+              if (wave + kMcfWaves * j < NF) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mma64(fa[i], ring[d][j], acc[i][j]);
+              }
+            if (st + PF < nsteps) load_b(st + PF, ring[d]);
+          }
         }
       }
     }
-    const T* a2s = reinterpret_cast<const T*>(P.a2_save);
     T* dcs = reinterpret_cast<T*>(P.dc_save);
 #pragma unroll
     for (int j = 0; j < kJ16; ++j) {
@@ -482,11 +760,13 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int p = i * 16 + r;
-          const pack_t cact = *reinterpret_cast<const pack_t*>(a2s + (row0 + p) * P.K2p + n);    // K2p, n multiples of 4
+          pack_t ca;
+          if constexpr (FAST) ca = cact[i][j];
+          else ca = *reinterpret_cast<const pack_t*>(a2s + (row0 + p) * P.K2p + n);    // K2p, n multiples of 4
           pack_t tv;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            tv[q] = ET<T>::from_f32(acc[i][j][q] * act_grad_from_out(IPOKE_ACT_ELU, ET<T>::to_f32(cact[q])));
+            tv[q] = ET<T>::from_f32(acc[i][j][q] * act_grad_from_out(IPOKE_ACT_ELU, ET<T>::to_f32(ca[q])));
           *reinterpret_cast<pack_t*>(dc + p * dc_pitch + n * (int)sizeof(T)) = tv;
           if (dcs) *reinterpret_cast<pack_t*>(dcs + (row0 + p) * P.Hq + n) = tv;
         }
@@ -503,9 +783,54 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
   __syncthreads();
 
   // (c) dx = dy*scale + sum_tap dc[p - off(tap)] x W1[:, tap, :]
-  //     16 (row-fragment, channel-fragment) pairs over the 8 waves: wave w owns channel fragment w & 3 and the two
-  //     row fragments 2*(w >> 2), 2*(w >> 2) + 1.
-  if (P.dbg != 3 && P.dbg != 4) {
+  if constexpr (FAST) {
+    // wave w: channel fragment w & 3, taps 3*(w >> 2) .. +2, all four row fragments; the two tap halves meet in LDS
+    const int NF = (P.C + 15) >> 4;
+    const int nfrag = wave & 3, kh = wave >> 2, hs = P.Hq / KS;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* zrow = dc + 64 * dc_pitch;
+    float* part = reinterpret_cast<float*>(dp);      // [64][C] fp32: the dparams tile is dead after (b)
+    const int n = nfrag * 16 + 4 * gq;
+    if (nfrag < NF) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const unsigned char* src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) src[i] = tap_src_adj(dc, zrow, dc_pitch, g, i * 16 + r, kh * 3 + t) + E16 * gq * (int)sizeof(T);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          if (st < hs) {
+            frag_t fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + st * KS * (int)sizeof(T));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma64(fa[i], w1t[t][st], acc[i]);
+          }
+        }
+      }
+      if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (n + q < P.C) part[(i * 16 + r) * P.C + n + q] = acc[i][q];
+      }
+    }
+    __syncthreads();
+    if (nfrag < NF && kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = i * 16 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (n + q < P.C) P.dx[(row0 + p) * P.ld + n + q] = dxd[p * P.C + n + q] + acc[i][q] + part[p * P.C + n + q];
+      }
+    }
+  } else {
+    //     16 (row-fragment, channel-fragment) pairs over the 8 waves: wave w owns channel fragment w & 3 and the two
+    //     row fragments 2*(w >> 2), 2*(w >> 2) + 1.
     const int NF = (P.C + 15) >> 4;       // <= 4 channel fragments
     const int nfrag = wave & 3, mbase = (wave >> 2) * 2;
     f32x4 acc[2];
@@ -539,11 +864,6 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
           if (n + q < P.C) P.dx[(row0 + p) * P.ld + n + q] = dxd[p * P.C + n + q] + acc[i][q];
       }
     }
-  }
-  const int rest = P.ld - P.C;
-  for (int e = threadIdx.x; e < 64 * rest; e += blockDim.x) {
-    const int p = e / rest, c = P.C + e - p * rest;
-    P.dx[(row0 + p) * P.ld + c] = P.dy[(row0 + p) * P.ld + c];
   }
 }
 
@@ -579,6 +899,12 @@ static int fill_params(McfParams& P, const ipoke_mcf_desc* d, int dtype) {
   return IPOKE_OK;
 }
 
+// the register-resident weight path covers the shipped widths (C <= 64, 4C + Cc <= 384) in bf16
+static bool fast_ok(const McfParams& P) {
+  static const bool off = getenv("IPOKE_MCF_NOFAST") != nullptr;
+  return !off && P.Cp <= kW1Steps * 32 && P.K2p <= kW2Steps * 32 && P.Hq <= 8 * 32 && P.K3p <= 4 * 32;
+}
+
 }  // namespace ipoke
 
 using namespace ipoke;
@@ -611,15 +937,17 @@ extern "C" int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   const size_t lds = lds_bytes(MT);
   IPK_REQUIRE(lds <= 158 * 1024, "MCF tile does not fit LDS");
   const int RS = 64 / MT;
-#define LAUNCH_FWD(TT, MF)                                                                      \
+#define LAUNCH_FWD(TT, MF, FAST)                                                                \
   do {                                                                                          \
-    rc = ensure_lds<mcf_fwd_kernel<TT, MF>>(lds); if (rc) return rc;                              \
-    hipLaunchKernelGGL((mcf_fwd_kernel<TT, MF>), dim3(d->B * RS), dim3(kMcfThreads), lds, s, P);        \
+    rc = ensure_lds<mcf_fwd_kernel<TT, MF, FAST>>(lds); if (rc) return rc;                        \
+    hipLaunchKernelGGL((mcf_fwd_kernel<TT, MF, FAST>), dim3(d->B * RS), dim3(kMcfThreads), lds, s, P);  \
   } while (0)
-  if (dtype == IPOKE_BF16) {
-    if (MT == 64) LAUNCH_FWD(bf16_t, 4); else if (MT == 32) LAUNCH_FWD(bf16_t, 2); else LAUNCH_FWD(bf16_t, 1);
+  if (dtype == IPOKE_BF16 && fast_ok(P)) {
+    if (MT == 64) LAUNCH_FWD(bf16_t, 4, true); else if (MT == 32) LAUNCH_FWD(bf16_t, 2, true); else LAUNCH_FWD(bf16_t, 1, true);
+  } else if (dtype == IPOKE_BF16) {
+    if (MT == 64) LAUNCH_FWD(bf16_t, 4, false); else if (MT == 32) LAUNCH_FWD(bf16_t, 2, false); else LAUNCH_FWD(bf16_t, 1, false);
   } else {
-    if (MT == 64) LAUNCH_FWD(float, 4); else if (MT == 32) LAUNCH_FWD(float, 2); else LAUNCH_FWD(float, 1);
+    if (MT == 64) LAUNCH_FWD(float, 4, false); else if (MT == 32) LAUNCH_FWD(float, 2, false); else LAUNCH_FWD(float, 1, false);
   }
 #undef LAUNCH_FWD
   IPK_LAUNCH_CHECK();
@@ -635,12 +963,15 @@ extern "C" int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream) {
   const size_t lds = (size_t)129 * (P.Cp * esz + 16) + (size_t)16 * (P.K2p * esz + 16) + (size_t)16 * 2 * P.C * 4 +
                      (size_t)128 * P.C * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == IPOKE_BF16) {
-    rc = ensure_lds<mcf_inv_kernel<bf16_t>>(lds); if (rc) return rc;
-    hipLaunchKernelGGL(mcf_inv_kernel<bf16_t>, dim3((d->B + 1) / 2), dim3(kMcfThreads), lds, s, P);
+  if (dtype == IPOKE_BF16 && fast_ok(P)) {
+    rc = ensure_lds<mcf_inv_kernel<bf16_t, true>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((mcf_inv_kernel<bf16_t, true>), dim3((d->B + 1) / 2), dim3(kMcfThreads), lds, s, P);
+  } else if (dtype == IPOKE_BF16) {
+    rc = ensure_lds<mcf_inv_kernel<bf16_t, false>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((mcf_inv_kernel<bf16_t, false>), dim3((d->B + 1) / 2), dim3(kMcfThreads), lds, s, P);
   } else {
-    rc = ensure_lds<mcf_inv_kernel<float>>(lds); if (rc) return rc;
-    hipLaunchKernelGGL(mcf_inv_kernel<float>, dim3((d->B + 1) / 2), dim3(kMcfThreads), lds, s, P);
+    rc = ensure_lds<mcf_inv_kernel<float, false>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((mcf_inv_kernel<float, false>), dim3((d->B + 1) / 2), dim3(kMcfThreads), lds, s, P);
   }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
@@ -654,12 +985,15 @@ extern "C" int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)65 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4;
   IPK_REQUIRE(lds <= 158 * 1024, "MCF backward tile does not fit LDS");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == IPOKE_BF16) {
-    rc = ensure_lds<mcf_bwd_kernel<bf16_t>>(lds); if (rc) return rc;
-    hipLaunchKernelGGL(mcf_bwd_kernel<bf16_t>, dim3(d->B), dim3(kMcfThreads), lds, s, P);
+  if (dtype == IPOKE_BF16 && fast_ok(P)) {
+    rc = ensure_lds<mcf_bwd_kernel<bf16_t, true>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((mcf_bwd_kernel<bf16_t, true>), dim3(d->B), dim3(kMcfThreads), lds, s, P);
+  } else if (dtype == IPOKE_BF16) {
+    rc = ensure_lds<mcf_bwd_kernel<bf16_t, false>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((mcf_bwd_kernel<bf16_t, false>), dim3(d->B), dim3(kMcfThreads), lds, s, P);
   } else {
-    rc = ensure_lds<mcf_bwd_kernel<float>>(lds); if (rc) return rc;
-    hipLaunchKernelGGL(mcf_bwd_kernel<float>, dim3(d->B), dim3(kMcfThreads), lds, s, P);
+    rc = ensure_lds<mcf_bwd_kernel<float, false>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((mcf_bwd_kernel<float, false>), dim3(d->B), dim3(kMcfThreads), lds, s, P);
   }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;

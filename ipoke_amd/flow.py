@@ -69,6 +69,7 @@ class FlowEngine:
         self.perm = torch.zeros(max(self.n_perm, 1), dtype=torch.int32, device=self.device)
         self.shadow = None
         self._ws = {}
+        self._io = {}
         self.shadow_stale = True
 
     def __del__(self):
@@ -111,6 +112,21 @@ class FlowEngine:
             self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
         return self._ws[key]
 
+    def _staging(self, B):
+        """Persistent input/output buffers per batch size: the native engine replays a captured hipGraph whenever it
+        is called with the same pointer arguments, so the boundary tensors must not move between steps."""
+        st = self._io.get(B)
+        if st is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            st = {"x": torch.empty(B, self.z, 8, 8, **f32), "cond": torch.empty(B, self.cond_channels, 8, 8, **f32),
+                  "out": torch.empty(B, self.z, 8, 8, **f32), "logdet": torch.empty(B, **f32),
+                  "d_out": torch.empty(B, self.z, 8, 8, **f32), "d_logdet": torch.empty(B, **f32),
+                  "dx": torch.empty(B, self.z, 8, 8, **f32)}
+            if len(self._io) >= 4:
+                self._io.pop(next(iter(self._io)))
+            self._io[B] = st
+        return st
+
     def prepare_weights(self):
         """Refresh the matrix-core weight shadows from the master weights (after every update)."""
         self._need_gpu()
@@ -127,23 +143,23 @@ class FlowEngine:
             raise ValueError(f"batch {B} exceeds max_batch={self.max_batch} of this flow")
         if tuple(x.shape[1:]) != (self.z, 8, 8):
             raise ValueError(f"flow input must be [B,{self.z},8,8], got {tuple(x.shape)}")
-        x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        st = self._staging(B)
+        st["x"].copy_(x.detach())
         if cond is not None:
             if tuple(cond.shape) != (B, self.cond_channels, 8, 8):
                 raise ValueError(f"cond must be [B,{self.cond_channels},8,8], got {tuple(cond.shape)}")
-            cond = cond.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            st["cond"].copy_(cond.detach())
         if self.shadow_stale:
             self.prepare_weights()
-        return x, cond, B
+        return st, B
 
     def forward(self, x, cond, save_for_backward=False):
-        x, cond, B = self._prep_inputs(x, cond)
-        out = torch.empty_like(x)
-        logdet = torch.empty(B, dtype=torch.float32, device=self.device)
+        st, B = self._prep_inputs(x, cond)
         ws = self.workspace(B, save_for_backward)
-        check(self.lib.ipoke_flow_forward(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(x), ptr(cond),
-                                          B, ptr(out), ptr(logdet), ptr(ws), int(save_for_backward), _lib.current_stream()))
-        return out, logdet
+        check(self.lib.ipoke_flow_forward(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(st["x"]),
+                                          ptr(st["cond"]), B, ptr(st["out"]), ptr(st["logdet"]), ptr(ws), int(save_for_backward),
+                                          _lib.current_stream()))
+        return st["out"].clone(), st["logdet"].clone()
 
     def init_forward(self, x):
         """Data-dependent initialisation pass (first forward of an uninitialised reference flow)."""
@@ -159,24 +175,24 @@ class FlowEngine:
         return out, logdet
 
     def reverse(self, z, cond):
-        z, cond, B = self._prep_inputs(z, cond)
-        x = torch.empty_like(z)
+        st, B = self._prep_inputs(z, cond)
         ws = self.workspace(B, False)
-        check(self.lib.ipoke_flow_reverse(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(z), ptr(cond), B,
-                                          ptr(x), ptr(ws), _lib.current_stream()))
-        return x
+        check(self.lib.ipoke_flow_reverse(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(st["x"]),
+                                          ptr(st["cond"]), B, ptr(st["out"]), ptr(ws), _lib.current_stream()))
+        return st["out"].clone()
 
     def backward(self, d_out, d_logdet, need_dx=False):
         self._need_gpu()
         B = d_out.shape[0]
-        d_out = d_out.to(dtype=torch.float32).contiguous()
-        d_logdet = d_logdet.to(dtype=torch.float32).contiguous()
+        st = self._staging(B)
+        st["d_out"].copy_(d_out)
+        st["d_logdet"].copy_(d_logdet)
         grads = self.ensure_grads()
-        dx = torch.empty_like(d_out) if need_dx else None
         ws = self.workspace(B, True)
-        check(self.lib.ipoke_flow_backward(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(d_out),
-                                           ptr(d_logdet), B, ptr(grads), ptr(dx), ptr(ws), _lib.current_stream()))
-        return dx
+        check(self.lib.ipoke_flow_backward(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(st["d_out"]),
+                                           ptr(st["d_logdet"]), B, ptr(grads), ptr(st["dx"]) if need_dx else None, ptr(ws),
+                                           _lib.current_stream()))
+        return st["dx"].clone() if need_dx else None
 
 
 class _FlowFunction(torch.autograd.Function):

@@ -30,7 +30,7 @@ def step():
     loss.backward()
     opt.step()
     return loss
-for i in range(2):
+for i in range(3):
     l = step()
 torch.cuda.synchronize()
 print("warm loss", l.item(), flush=True)
@@ -39,10 +39,14 @@ tt = {"fwd": 0, "bwd": 0, "opt": 0}
 t0 = time.time()
 for i in range(steps):
     evs[0].record()
+    th = time.time()
     out, logdet = m(x, cond)
+    host_fwd = time.time() - th
     loss = (0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()
     evs[1].record()
+    th = time.time()
     loss.backward()
+    host_bwd = time.time() - th
     evs[2].record()
     opt.step()
     evs[3].record()
@@ -50,4 +54,5 @@ for i in range(steps):
     tt["fwd"] += evs[0].elapsed_time(evs[1]); tt["bwd"] += evs[1].elapsed_time(evs[2]); tt["opt"] += evs[2].elapsed_time(evs[3])
 wall = (time.time() - t0) / steps * 1e3
 print(f"z={z} B={B} {dtype}: wall {wall:.1f} ms/step; gpu fwd {tt['fwd']/steps:.1f} bwd {tt['bwd']/steps:.1f} opt+prep {tt['opt']/steps:.1f} ms; loss {loss.item():.3f}")
+print(f"host enqueue fwd {host_fwd*1e3:.1f} ms bwd {host_bwd*1e3:.1f} ms")
 print(f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
