@@ -99,30 +99,53 @@ __global__ void actnorm_inv_kernel(const float* __restrict__ in, float* __restri
 // parameter gradients go to part[b][2C] (reduced over b by ipoke_reduce_rows):
 //   dx[m][c0+idx[j]] = dy[m][c0+j] * exp(ls[idx[j]])
 //   dls[c] = sum_m dy'[m][c] * x[m][c] * exp(ls[c]) + P * sum_b dld[b] ;  dbias[c] = sum_m dy'[m][c]
-__global__ void actnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
-                                   int P, int ld, int c0, int C, const float* __restrict__ ls,
-                                   const int* __restrict__ idx, const float* __restrict__ dld,
-                                   float* __restrict__ part) {
+__global__ __launch_bounds__(1024) void actnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dx, int P, int ld, int c0, int C,
+                                                           const float* __restrict__ ls, const int* __restrict__ idx,
+                                                           const float* __restrict__ dld, float* __restrict__ part) {
   extern __shared__ float sm[];   // [2][rows_par][C]
   const int tid = threadIdx.x, b = blockIdx.x;
   const long row0 = (long)b * P;
   const int rows_par = blockDim.x / C;      // host guarantees >= 1
   const int j = tid % C, r0 = tid / C;
+  // pass-through columns first (independent of everything else), four elements per thread in flight
+  for (int i0 = tid; i0 < P * ld; i0 += 4 * blockDim.x) {
+    float v[4]; bool w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      const int col = i % ld;
+      w[u] = i < P * ld && (col < c0 || col >= c0 + C);
+      if (w[u]) v[u] = dy[row0 * ld + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (w[u]) dx[row0 * ld + i0 + u * blockDim.x] = v[u];
+  }
   float a_ls = 0.f, a_b = 0.f;
   if (r0 < rows_par) {
     const int src = idx ? idx[j] : j;
     const float e = ls ? expf(ls[src]) : 1.f;
-    for (int m = r0; m < P; m += rows_par) {
-      const float g = dy[(row0 + m) * ld + c0 + j];
-      const float xv = ls ? x[(row0 + m) * ld + c0 + src] : 0.f;
-      dx[(row0 + m) * ld + c0 + src] = g * e;
-      a_ls += g * xv * e;
-      a_b += g;
+    for (int m0 = r0; m0 < P; m0 += 4 * rows_par) {       // four rows per thread with all loads in flight
+      float g[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = m0 + u * rows_par;
+        g[u] = 0.f; xv[u] = 0.f;
+        if (m < P) {
+          g[u] = dy[(row0 + m) * ld + c0 + j];
+          if (ls) xv[u] = x[(row0 + m) * ld + c0 + src];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = m0 + u * rows_par;
+        if (m < P) {
+          dx[(row0 + m) * ld + c0 + src] = g[u] * e;
+          a_ls += g[u] * xv[u] * e;
+          a_b += g[u];
+        }
+      }
     }
-  }
-  for (int i = tid; i < P * ld; i += blockDim.x) {       // pass-through columns
-    const int col = i % ld;
-    if (col < c0 || col >= c0 + C) dx[row0 * ld + i] = dy[row0 * ld + i];
   }
   if (!ls) return;
   if (r0 < rows_par) { sm[r0 * C + j] = a_ls; sm[(rows_par + r0) * C + j] = a_b; }
@@ -168,40 +191,58 @@ struct AffineArgs {
   int Cp, t_off, t_stride;
   int P, ld;
 };
-// sum the split-K partials (+bias) of one sample into LDS: raw_s[p][0:2Cp]
-__device__ __forceinline__ void affine_stage_raw(const AffineArgs& a, long row0, float* raw_s) {
+// sum the split-K partials (+bias) of `rows` positions starting at row0 into LDS: raw_s[p][0:2Cp]
+__device__ __forceinline__ void affine_stage_raw(const AffineArgs& a, long row0, int rows, float* raw_s) {
   const int n2 = 2 * a.Cp;
-  for (int e = threadIdx.x; e < a.P * n2; e += blockDim.x) {
+  for (int e = threadIdx.x; e < rows * n2; e += blockDim.x) {
     const int p = e / n2, j = e - p * n2;
     const float* r = a.raw + (row0 + p) * a.ldraw + j;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = 0.f;
     int s = 0;
-    for (; s + 3 < a.nsplit; s += 4) {
-      v0 += r[(long)s * a.split_stride]; v1 += r[(long)(s + 1) * a.split_stride];
-      v2 += r[(long)(s + 2) * a.split_stride]; v3 += r[(long)(s + 3) * a.split_stride];
+    for (; s + 7 < a.nsplit; s += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] += r[(long)(s + u) * a.split_stride];
     }
-    for (; s < a.nsplit; ++s) v0 += r[(long)s * a.split_stride];
-    float v = (v0 + v1) + (v2 + v3);
-    if (a.bias) v += a.bias[j];
-    raw_s[e] = v;
+    for (; s < a.nsplit; ++s) v[0] += r[(long)s * a.split_stride];
+    float t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    if (a.bias) t += a.bias[j];
+    raw_s[e] = t;
   }
   __syncthreads();
 }
+// untouched channels of `rows` positions: out = in
+__device__ __forceinline__ void affine_copy_rest(const AffineArgs& a, long row0, int rows, const float* __restrict__ in,
+                                                 float* __restrict__ out) {
+  const int total = rows * a.ld;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * blockDim.x) {
+    float v[4]; bool w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      const int col = i % a.ld;
+      const int rel = col - a.t_off;
+      const bool transformed = rel >= 0 && rel % a.t_stride == 0 && rel / a.t_stride < a.Cp;
+      w[u] = i < total && !transformed;
+      if (w[u]) v[u] = in[row0 * a.ld + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (w[u]) out[row0 * a.ld + i0 + u * blockDim.x] = v[u];
+  }
+}
+// grid = B * Q: Q slices of P/Q positions per sample (Q = 4 when the log-det slot is 4 wide, like the MCF kernels)
 __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out,
-                                  float* __restrict__ scale_out, float* __restrict__ logdet_slot, int slot_stride) {
+                                  float* __restrict__ scale_out, float* __restrict__ logdet_slot, int slot_stride, int Q) {
   extern __shared__ float raw_s[];
   __shared__ float red[8];
-  const int b = blockIdx.x;
-  const long row0 = (long)b * a.P;
-  affine_stage_raw(a, row0, raw_s);
-  for (int i = threadIdx.x; i < a.P * a.ld; i += blockDim.x) {
-    const int col = i % a.ld, p = i / a.ld;
-    const int rel = col - a.t_off;
-    const bool transformed = rel >= 0 && rel % a.t_stride == 0 && rel / a.t_stride < a.Cp;
-    if (!transformed) out[(row0 + p) * a.ld + col] = in[(row0 + p) * a.ld + col];
-  }
+  const int b = blockIdx.x / Q, q = blockIdx.x % Q;
+  const int rows = a.P / Q;
+  const long row0 = (long)b * a.P + (long)q * rows;
+  affine_copy_rest(a, row0, rows, in, out);
+  affine_stage_raw(a, row0, rows, raw_s);
   float ld_acc = 0.f;
-  for (int e = threadIdx.x; e < a.P * a.Cp; e += blockDim.x) {
+  for (int e = threadIdx.x; e < rows * a.Cp; e += blockDim.x) {
     const int p = e / a.Cp, i = e - p * a.Cp;
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
@@ -211,20 +252,16 @@ __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, fl
     ld_acc += logf(sc);
   }
   const float tot = block_sum(ld_acc, red);
-  if (threadIdx.x == 0 && logdet_slot) logdet_slot[(long)b * slot_stride] = tot;
+  if (threadIdx.x == 0 && logdet_slot) logdet_slot[(long)b * slot_stride + q] = tot;
 }
-__global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out) {
+__global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out, int Q) {
   extern __shared__ float raw_s[];
-  const int b = blockIdx.x;
-  const long row0 = (long)b * a.P;
-  affine_stage_raw(a, row0, raw_s);
-  for (int i = threadIdx.x; i < a.P * a.ld; i += blockDim.x) {
-    const int col = i % a.ld, p = i / a.ld;
-    const int rel = col - a.t_off;
-    const bool transformed = rel >= 0 && rel % a.t_stride == 0 && rel / a.t_stride < a.Cp;
-    if (!transformed) out[(row0 + p) * a.ld + col] = in[(row0 + p) * a.ld + col];
-  }
-  for (int e = threadIdx.x; e < a.P * a.Cp; e += blockDim.x) {
+  const int b = blockIdx.x / Q, q = blockIdx.x % Q;
+  const int rows = a.P / Q;
+  const long row0 = (long)b * a.P + (long)q * rows;
+  affine_copy_rest(a, row0, rows, in, out);
+  affine_stage_raw(a, row0, rows, raw_s);
+  for (int e = threadIdx.x; e < rows * a.Cp; e += blockDim.x) {
     const int p = e / a.Cp, i = e - p * a.Cp;
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
@@ -236,40 +273,69 @@ __global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, fl
 //   dx (zp channels: dy*scale, others: dy copied),  dparams T [m][ldp] = [dmu | ds | 0 pad],
 //   per-sample column sums of dparams (for the conv bias gradient) into dbias_part[b][2Cp].
 template <typename T>
-__global__ void affine_bwd_kernel(int Cp, int t_off, int t_stride, int P, int ld, const float* __restrict__ dy,
-                                  const float* __restrict__ x, const float* __restrict__ scale,
-                                  const float* __restrict__ dld, float* __restrict__ dx, T* __restrict__ dparams,
-                                  int ldp, float* __restrict__ dbias_part) {
+__global__ __launch_bounds__(1024) void affine_bwd_kernel(int Cp, int t_off, int t_stride, int P, int ld,
+                                                          const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ scale, const float* __restrict__ dld,
+                                                          float* __restrict__ dx, T* __restrict__ dparams, int ldp,
+                                                          float* __restrict__ dbias_part) {
   extern __shared__ float sm[];      // [2*Cp] column sums
   const int b = blockIdx.x;
   const long row0 = (long)b * P;
   for (int i = threadIdx.x; i < 2 * Cp; i += blockDim.x) sm[i] = 0.f;
-  __syncthreads();
-  for (int i = threadIdx.x; i < P * ld; i += blockDim.x) {
-    const int col = i % ld, p = i / ld;
-    const int rel = col - t_off;
-    const bool transformed = rel >= 0 && rel % t_stride == 0 && rel / t_stride < Cp;
-    if (!transformed) dx[(row0 + p) * ld + col] = dy[(row0 + p) * ld + col];
-  }
-  const float g_ld = dld[b];
-  for (int e = threadIdx.x; e < P * ldp; e += blockDim.x) {
-    const int p = e / ldp, j = e - p * ldp;
-    float v = 0.f;
-    if (j < 2 * Cp) {
-      const int i = j < Cp ? j : j - Cp;
-      const long off = (row0 + p) * ld + t_off + (long)i * t_stride;
-      const float g = dy[off];
-      if (j < Cp) {
-        v = g;                                               // d mu
-        dx[off] = g * scale[(row0 + p) * Cp + i];
-      } else {
-        const float sc = scale[(row0 + p) * Cp + i];
-        const float t = sc - 1.f;                            // tanh(s/2)
-        v = (g * x[off] + g_ld / sc) * 0.5f * (1.f - t * t);  // d s
+  {   // untouched channels: four elements per thread in flight
+    const int total = P * ld;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4 * blockDim.x) {
+      float v[4]; bool w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * blockDim.x;
+        const int col = i % ld;
+        const int rel = col - t_off;
+        const bool transformed = rel >= 0 && rel % t_stride == 0 && rel / t_stride < Cp;
+        w[u] = i < total && !transformed;
+        if (w[u]) v[u] = dy[row0 * ld + i];
       }
-      atomicAdd(&sm[j], v);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (w[u]) dx[row0 * ld + i0 + u * blockDim.x] = v[u];
     }
-    dparams[(row0 + p) * ldp + j] = ET<T>::from_f32(v);
+  }
+  __syncthreads();
+  const float g_ld = dld[b];
+  const int total = P * ldp;
+  for (int e0 = threadIdx.x; e0 < total; e0 += 4 * blockDim.x) {
+    float g[4], sc[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * blockDim.x;
+      const int p = e / ldp, j = e - p * ldp;
+      g[u] = 0.f; sc[u] = 1.f; xv[u] = 0.f;
+      if (e < total && j < 2 * Cp) {
+        const int i = j < Cp ? j : j - Cp;
+        const long off = (row0 + p) * ld + t_off + (long)i * t_stride;
+        g[u] = dy[off];
+        sc[u] = scale[(row0 + p) * Cp + i];
+        if (j >= Cp) xv[u] = x[off];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * blockDim.x;
+      if (e < total) {
+        const int p = e / ldp, j = e - p * ldp;
+        float v = 0.f;
+        if (j < 2 * Cp) {
+          if (j < Cp) {
+            v = g[u];                                                  // d mu
+            dx[(row0 + p) * ld + t_off + (long)j * t_stride] = g[u] * sc[u];
+          } else {
+            const float t = sc[u] - 1.f;                               // tanh(s/2)
+            v = (g[u] * xv[u] + g_ld / sc[u]) * 0.5f * (1.f - t * t);   // d s
+          }
+          atomicAdd(&sm[j], v);
+        }
+        dparams[(row0 + p) * ldp + j] = ET<T>::from_f32(v);
+      }
+    }
   }
   __syncthreads();
   if (dbias_part)
@@ -446,7 +512,7 @@ extern "C" int ipoke_actnorm_bwd(const float* dy, const float* x, float* dx, int
                                  float* part, void* stream) {
   IPK_REQUIRE(dy && dx && C >= 1 && C <= 256 && c0 + C <= ld && M == B * P, "bad arguments");
   IPK_REQUIRE(!log_scale || (x && dld && part), "parameter gradients need x, dld and the partial-sum buffer");
-  const int block = C <= 64 ? 256 : (C <= 128 ? 512 : 1024);
+  const int block = 1024;
   const int rows_par = block / C;
   hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(B), dim3(block), 2 * rows_par * C * sizeof(float), STREAM(stream), dy, x, dx,
                      P, ld, c0, C, log_scale, idx, dld, part);
@@ -475,15 +541,17 @@ extern "C" int ipoke_affine_fwd(const ipoke_affine_desc* d, const float* in, flo
                                 float* logdet_slot, int slot_stride, int B, void* stream) {
   int rc = check_affine(d); if (rc) return rc;
   IPK_REQUIRE(in && out, "null state");
-  hipLaunchKernelGGL(affine_fwd_kernel, dim3(B), dim3(512), (size_t)d->P * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d), in, out, scale_out,
-                     logdet_slot, slot_stride < 1 ? 1 : slot_stride);
+  const int Q = (slot_stride >= 4 || !logdet_slot) && d->P % 4 == 0 ? 4 : 1;
+  hipLaunchKernelGGL(affine_fwd_kernel, dim3(B * Q), dim3(256), (size_t)(d->P / Q) * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d),
+                     in, out, scale_out, logdet_slot, slot_stride < 1 ? 1 : slot_stride, Q);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
 extern "C" int ipoke_affine_inv(const ipoke_affine_desc* d, const float* in, float* out, int B, void* stream) {
   int rc = check_affine(d); if (rc) return rc;
   IPK_REQUIRE(in && out, "null state");
-  hipLaunchKernelGGL(affine_inv_kernel, dim3(B), dim3(512), (size_t)d->P * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d), in, out);
+  const int Q = d->P % 4 == 0 ? 4 : 1;
+  hipLaunchKernelGGL(affine_inv_kernel, dim3(B * Q), dim3(256), (size_t)(d->P / Q) * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d), in, out, Q);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
@@ -493,10 +561,10 @@ extern "C" int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, 
   IPK_REQUIRE(dy && x && scale && dld && dx && dparams && ldp >= 2 * Cp, "bad arguments");
   const size_t sm = 2 * Cp * sizeof(float);
   if (dtype == IPOKE_BF16)
-    hipLaunchKernelGGL(affine_bwd_kernel<bf16_t>, dim3(B), dim3(256), sm, STREAM(stream), Cp, t_off, t_stride, P, ld, dy, x,
+    hipLaunchKernelGGL(affine_bwd_kernel<bf16_t>, dim3(B), dim3(1024), sm, STREAM(stream), Cp, t_off, t_stride, P, ld, dy, x,
                        scale, dld, dx, (bf16_t*)dparams, ldp, dbias_part);
   else
-    hipLaunchKernelGGL(affine_bwd_kernel<float>, dim3(B), dim3(256), sm, STREAM(stream), Cp, t_off, t_stride, P, ld, dy, x,
+    hipLaunchKernelGGL(affine_bwd_kernel<float>, dim3(B), dim3(1024), sm, STREAM(stream), Cp, t_off, t_stride, P, ld, dy, x,
                        scale, dld, dx, (float*)dparams, ldp, dbias_part);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;

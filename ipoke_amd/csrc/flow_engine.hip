@@ -48,9 +48,9 @@ struct Op {
   int mcf_idx = -1;                            // running index among the MCF ops (batched weight gradients)
 };
 
-struct RelayoutJobH {
-  long src_off, dst_off, scale_off; int rows_pad, rows_real, taps, inner_pad, inner_real, ld;
-  long s_row, s_inner, s_tap; int scale_on_row, block_start;
+struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
+  long src_off, s_n, s_k, dstA, dstB, scale_off;
+  int taps, n_real, k_real, A_rows_pad, A_inner_pad, B_rows_pad, B_inner_pad, B_rows_real, tile, tiles_k, block_start;
 };
 struct WnJobH { long v_off, g_off, out_off; int rows, K, row_start; };
 struct LsRefH { long off; int C; };
@@ -113,12 +113,16 @@ struct Builder {
     f.shadow_elems = align_up(off + elems, 64);
     return off;
   }
-  void relayout(long src, long dst, long scale, int rows_pad, int rows_real, int taps, int inner_pad, int inner_real, int ld,
-                long s_row, long s_inner, long s_tap, int scale_on_row) {
-    RelayoutJobH j{src, dst, scale, rows_pad, rows_real, taps, inner_pad, inner_real, ld, s_row, s_inner, s_tap, scale_on_row, f.rblocks};
+  // W[n][k][tap] -> A[n][tap][k] (padded) and B[k][tap][n] (padded; rows >= B_rows_real zero)
+  void relayout_pair(long src, long s_n, long s_k, int taps, int n_real, int k_real, long scale, long dstA, int A_rows_pad,
+                     int A_inner_pad, long dstB, int B_rows_pad, int B_inner_pad, int B_rows_real) {
+    const int tile = taps == 1 ? 64 : 32;
+    const int n_ext = std::max(A_rows_pad, B_inner_pad), k_ext = std::max(A_inner_pad, B_rows_pad);
+    const int tiles_n = (n_ext + tile - 1) / tile, tiles_k = (k_ext + tile - 1) / tile;
+    RelayoutJobH j{src, s_n, s_k, dstA, dstB, scale, taps, n_real, k_real, A_rows_pad, A_inner_pad, B_rows_pad, B_inner_pad,
+                   B_rows_real, tile, tiles_k, f.rblocks};
     f.rjobs.push_back(j);
-    const long total = (long)rows_pad * ld;
-    f.rblocks += (int)((total + 2047) / 2048);
+    f.rblocks += tiles_n * tiles_k;
   }
 
   void actnorm(const std::string& pfx, int C_active, int c0, int Cn, const std::string* shuffle_pfx) {
@@ -160,10 +164,8 @@ struct Builder {
     op.sh_w1t = add_shadow((int64_t)Cr * 6 * op.Hq);
     op.sh_w2 = add_shadow((int64_t)N2r * op.K2p);
     op.sh_w2t = add_shadow((int64_t)Hr * op.K3p);
-    relayout(op.p_w1, op.sh_w1, -1, Hr, op.H, 6, op.Cp, C, op.K1p, (long)C * 6, 6, 1, 0);
-    relayout(op.p_w1, op.sh_w1t, -1, Cr, C, 6, op.Hq, op.H, 6 * op.Hq, 6, (long)C * 6, 1, 0);
-    relayout(op.p_v, op.sh_w2, op.wn_off, N2r, 2 * C, 1, op.K2p, K2, op.K2p, K2, 1, 0, 1);
-    relayout(op.p_v, op.sh_w2t, op.wn_off, Hr, op.H, 1, op.K3p, 2 * C, op.K3p, 1, K2, 0, 0);
+    relayout_pair(op.p_w1, (long)C * 6, 6, 6, op.H, C, -1, op.sh_w1, Hr, op.Cp, op.sh_w1t, Cr, op.Hq, C);
+    relayout_pair(op.p_v, K2, 1, 1, 2 * C, K2, op.wn_off, op.sh_w2, N2r, op.K2p, op.sh_w2t, Hr, op.K3p, op.H);
     op.slot = f.nslots++;
     op.mcf_idx = f.n_mcf++;
     f.ops.push_back(op);
@@ -201,14 +203,11 @@ struct Builder {
     op.sh_c3 = add_shadow((int64_t)N3 * 9 * hid);
     op.sh_c3t = add_shadow((int64_t)hid * 9 * op.Kc3);
     // conv1.weight [hid][cin][3][3]
-    relayout(op.p_c1, op.sh_c1, -1, hid, hid, 9, op.Kc1, op.cin, 9 * op.Kc1, (long)op.cin * 9, 9, 1, 0);
-    relayout(op.p_c1, op.sh_c1t, -1, op.cin, op.cin, 9, hid, hid, 9 * hid, 9, (long)op.cin * 9, 1, 0);
+    relayout_pair(op.p_c1, (long)op.cin * 9, 9, 9, hid, op.cin, -1, op.sh_c1, hid, op.Kc1, op.sh_c1t, op.cin, hid, op.cin);
     // conv2.weight [hid][hid]
-    relayout(op.p_c2, op.sh_c2, -1, hid, hid, 1, hid, hid, hid, hid, 1, 0, 0);
-    relayout(op.p_c2, op.sh_c2t, -1, hid, hid, 1, hid, hid, hid, 1, hid, 0, 0);
+    relayout_pair(op.p_c2, hid, 1, 1, hid, hid, -1, op.sh_c2, hid, hid, op.sh_c2t, hid, hid, hid);
     // conv3 weight_v [N3][hid][3][3] with weight-norm scale
-    relayout(op.p_v, op.sh_c3, op.wn_off, N3, N3, 9, hid, hid, 9 * hid, (long)hid * 9, 9, 1, 1);
-    relayout(op.p_v, op.sh_c3t, op.wn_off, hid, hid, 9, op.Kc3, N3, 9 * op.Kc3, 9, (long)hid * 9, 1, 0);
+    relayout_pair(op.p_v, (long)hid * 9, 9, 9, N3, hid, op.wn_off, op.sh_c3, N3, hid, op.sh_c3t, hid, op.Kc3, hid);
     op.slot = f.nslots++;
     f.ops.push_back(op);
   }
@@ -517,7 +516,12 @@ static int ensure_device(ipoke_flow* f) {
   IPK_HIP(hipMemcpy(f->d_wjobs, f->wjobs.data(), f->wjobs.size() * sizeof(WnJobH), hipMemcpyHostToDevice));
   IPK_HIP(hipMalloc(&f->d_lsrefs, f->lsrefs.size() * sizeof(LsRefH)));
   IPK_HIP(hipMemcpy(f->d_lsrefs, f->lsrefs.data(), f->lsrefs.size() * sizeof(LsRefH), hipMemcpyHostToDevice));
-  IPK_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+  {   // weight gradients are off the critical path: lowest priority so that chain kernels get the CUs first
+    int least = 0, greatest = 0;
+    IPK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    static const bool flat = getenv("IPOKE_SIDE_FLAT_PRIORITY") != nullptr;
+    IPK_HIP(hipStreamCreateWithPriority(&f->side, hipStreamNonBlocking, flat ? 0 : least));
+  }
   IPK_HIP(hipStreamCreateWithFlags(&f->cap, hipStreamNonBlocking));
   f->lanes.resize(kMaxLanes - 1);
   for (auto& l : f->lanes) IPK_HIP(hipStreamCreateWithFlags(&l, hipStreamNonBlocking));

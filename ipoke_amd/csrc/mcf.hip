@@ -448,10 +448,12 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_fwd_kernel(const McfParams P)
   fill_cond<T>(P, MT, [&](int row) { return (long)b * 64 + pos0 + row; }, a2, a2_pitch);
   __syncthreads();
   auto rowfn = [&](int row, const unsigned char*& tile, int& pos) { tile = xs; pos = pos0 + row; };
-  if constexpr (FAST) mcf_gemm1_pre<T, MF>(P, g, rowfn, xs + 64 * xs_pitch, a2, a2_pitch, wr);
-  else mcf_gemm1<T, MF>(P, g, rowfn, xs + 64 * xs_pitch, a2, a2_pitch);
+  if (!(P.dbg & 64)) {
+    if constexpr (FAST) mcf_gemm1_pre<T, MF>(P, g, rowfn, xs + 64 * xs_pitch, a2, a2_pitch, wr);
+    else mcf_gemm1<T, MF>(P, g, rowfn, xs + 64 * xs_pitch, a2, a2_pitch);
+  }
   __syncthreads();
-  if (P.a2_save) {
+  if (P.a2_save && !(P.dbg & 256)) {
     constexpr int E16 = ET<T>::E16;
     const int chunks = P.K2p / E16;
     T* dst = reinterpret_cast<T*>(P.a2_save) + ((long)b * 64 + pos0) * P.K2p;
@@ -461,9 +463,12 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_fwd_kernel(const McfParams P)
           *reinterpret_cast<const u32x4*>(a2 + row * a2_pitch + ch * 16);
     }
   }
-  if constexpr (FAST) mcf_gemm2_pre<T, MF>(P, a2, a2_pitch, prm, N2, wr);
-  else mcf_gemm2<T, MF>(P, a2, a2_pitch, prm, N2);
+  if (!(P.dbg & 128)) {
+    if constexpr (FAST) mcf_gemm2_pre<T, MF>(P, a2, a2_pitch, prm, N2, wr);
+    else mcf_gemm2<T, MF>(P, a2, a2_pitch, prm, N2);
+  }
   __syncthreads();
+  if (P.dbg & 512) return;
   float ld_acc = 0.f;
   if (vec) {
 #pragma unroll
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
       }
     }
     const int nfrag0 = wave0 & 3, kh0 = wave0 >> 2;
-    if (nfrag0 < ((P.C + 15) >> 4)) {
+    if (nfrag0 < ((P.C + 15) >> 4) && !(P.dbg & 16)) {
       const T* W1T = reinterpret_cast<const T*>(P.W1T);
       const int Ktot = 6 * P.Hq;
 #pragma unroll
@@ -608,7 +613,9 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
   unsigned char* dp = smem;                                       // [64][K3p] T
   unsigned char* dc = dp + 64 * dp_pitch;                         // [64][Hq]  T + one all-zero row
   float* dxd = reinterpret_cast<float*>(dc + 65 * dc_pitch);      // [64][C]   dy*scale
-  float* colsum = dxd + 64 * P.C;                                 // [2C]
+  float* colsum = dxd + 64 * P.C;                                 // [2C]   (scalar fallback path)
+  float* psum = colsum + N2;                                      // [<=64 rows][2C] per-thread partial column sums
+  float* red2 = psum + 4096;                                      // [Q][2C]
   const long row0 = (long)b * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
 
@@ -619,28 +626,31 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
   // (a) gradients of the coupling parameters.  Vector path: every thread owns 4-channel groups of one row, so dy / x /
   // scale arrive as independent 16-byte loads and the column sums need one LDS atomic per channel and thread.
   const float g_ld = P.dld[b];
-  T* dps = reinterpret_cast<T*>(P.dparams_save);
-  if ((P.C & 3) == 0 && (P.ld & 3) == 0) {
-    const int G4 = P.C >> 2;                                   // 4-channel groups per row
-    const int n = 64 * G4;
-    for (int e0 = threadIdx.x; e0 < n; e0 += 2 * blockDim.x) {  // two items per thread with all six loads in flight
-      const int e1 = e0 + blockDim.x;
-      const int nit = e1 < n ? 2 : 1;
-      int pp[2], cc[2];
-      pp[0] = e0 / G4; cc[0] = (e0 - pp[0] * G4) * 4;
-      const int j1 = nit == 2 ? e1 : e0;
-      pp[1] = j1 / G4; cc[1] = (j1 - pp[1] * G4) * 4;
+  T* dps = (P.dbg & 2) ? nullptr : reinterpret_cast<T*>(P.dparams_save);
+  const bool vec_a = (P.C & 3) == 0 && (P.ld & 3) == 0;
+  if (vec_a) {
+    // thread (r0, c4) owns the 4-channel group c4 of rows r0 and r0 + rows_par: both rows' loads are in flight together
+    // and the column sums start as per-thread partials (deterministic; LDS float atomics cost ~10 us here)
+    const int G4 = P.C >> 2;                                   // 4-channel groups per row (<= 16)
+    const int rows_par = kMcfThreads / G4;                     // >= 32
+    const int rows_used = rows_par < 64 ? rows_par : 64;
+    const int c4 = threadIdx.x % G4, r0 = threadIdx.x / G4, c = c4 * 4;
+    if (r0 < rows_used) {
+      const int nit = r0 + rows_par < 64 ? 2 : 1;
+      int pp[2];
+      pp[0] = r0; pp[1] = nit == 2 ? r0 + rows_par : r0;
       f32x4 gyv[2], xvv[2], scv[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        gyv[k] = *reinterpret_cast<const f32x4*>(P.dy + (row0 + pp[k]) * P.ld + cc[k]);
-        xvv[k] = *reinterpret_cast<const f32x4*>(P.x + (row0 + pp[k]) * P.ld + cc[k]);
-        scv[k] = *reinterpret_cast<const f32x4*>(P.scale_save + (row0 + pp[k]) * P.C + cc[k]);
+        gyv[k] = *reinterpret_cast<const f32x4*>(P.dy + (row0 + pp[k]) * P.ld + c);
+        xvv[k] = *reinterpret_cast<const f32x4*>(P.x + (row0 + pp[k]) * P.ld + c);
+        scv[k] = *reinterpret_cast<const f32x4*>(P.scale_save + (row0 + pp[k]) * P.C + c);
       }
+      f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sd = sg;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         if (k < nit) {
-          const int p = pp[k], c = cc[k];
+          const int p = pp[k];
           const f32x4 gy = gyv[k], xv = xvv[k], sc = scv[k];
           f32x4 ds, dxv;
           pack_t tm, ts;
@@ -650,8 +660,7 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
             ds[q] = (gy[q] * xv[q] + g_ld / sc[q]) * 0.5f * (1.f - t * t);
             dxv[q] = gy[q] * sc[q];
             tm[q] = ET<T>::from_f32(gy[q]); ts[q] = ET<T>::from_f32(ds[q]);
-            atomicAdd(&colsum[c + q], gy[q]);
-            atomicAdd(&colsum[P.C + c + q], ds[q]);
+            sg[q] += gy[q]; sd[q] += ds[q];
           }
           *reinterpret_cast<f32x4*>(dxd + p * P.C + c) = dxv;
           *reinterpret_cast<pack_t*>(dp + p * dp_pitch + c * (int)sizeof(T)) = tm;
@@ -662,6 +671,8 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
           }
         }
       }
+      *reinterpret_cast<f32x4*>(psum + r0 * N2 + c) = sg;
+      *reinterpret_cast<f32x4*>(psum + r0 * N2 + P.C + c) = sd;
     }
     const int padc = P.K3p - N2;                               // zero the K padding (LDS tile and saved tensor)
     for (int e = threadIdx.x; e < 64 * padc; e += blockDim.x) {
@@ -692,8 +703,27 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
     }
   }
   __syncthreads();
-  if (P.dbias_part)
+  if (vec_a) {
+    // column sums of the per-thread partials: Q threads per column, then one thread per column
+    const int rows_par = kMcfThreads / (P.C >> 2);
+    const int rows_used = rows_par < 64 ? rows_par : 64;
+    const int Q = kMcfThreads / N2;                            // >= 4
+    const int col = threadIdx.x % N2, part = threadIdx.x / N2;
+    if (part < Q) {
+      float t = 0.f;
+      for (int rr = part; rr < rows_used; rr += Q) t += psum[rr * N2 + col];
+      red2[part * N2 + col] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < N2 && P.dbias_part) {
+      float t = 0.f;
+      for (int q = 0; q < Q; ++q) t += red2[q * N2 + threadIdx.x];
+      P.dbias_part[(long)b * N2 + threadIdx.x] = t;
+    }
+  } else if (P.dbias_part) {
     for (int i = threadIdx.x; i < N2; i += blockDim.x) P.dbias_part[(long)b * N2 + i] = colsum[i];
+  }
+  if (P.dbg & 32) return;
 
   // (b) dA2[:, :H] = dparams x W2[:, :H]  , times ELU'(c) -> dc
   {
@@ -708,7 +738,7 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
     if constexpr (FAST) {
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        if (st < nsteps) {
+        if (st < nsteps && !(P.dbg & 4)) {
           frag_t fa[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -752,7 +782,7 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
         }
       }
     }
-    T* dcs = reinterpret_cast<T*>(P.dc_save);
+    T* dcs = (P.dbg & 2) ? nullptr : reinterpret_cast<T*>(P.dc_save);
 #pragma unroll
     for (int j = 0; j < kJ16; ++j) {
       const int n = (wave + kMcfWaves * j) * 16 + 4 * gq;
@@ -793,7 +823,7 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
     const unsigned char* zrow = dc + 64 * dc_pitch;
     float* part = reinterpret_cast<float*>(dp);      // [64][C] fp32: the dparams tile is dead after (b)
     const int n = nfrag * 16 + 4 * gq;
-    if (nfrag < NF) {
+    if (nfrag < NF && !(P.dbg & 8)) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const unsigned char* src[4];
@@ -982,7 +1012,7 @@ extern "C" int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   McfParams P;
   int rc = fill_params(P, d, dtype); if (rc) return rc;
   const int esz = dtype == IPOKE_BF16 ? 2 : 4;
-  const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)65 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4;
+  const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)65 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4 + (4096 + 512) * 4;
   IPK_REQUIRE(lds <= 158 * 1024, "MCF backward tile does not fit LDS");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16 && fast_ok(P)) {

@@ -7,22 +7,29 @@
 
 namespace ipoke {
 
-// dst[row][k], k = tap*inner_pad + i :  value = src[row*s_row + i*s_inner + tap*s_tap] * scale
+// One job = one weight tensor W[n][k][tap] of the state dict (tap stride 1; n = output channel, k = input channel)
+// and BOTH operand layouts derived from it, so the fp32 source is read once, coalesced, through an LDS tile:
+//   A[n][tap*A_inner_pad + k]   (rows padded to A_rows_pad)        -- forward operand, K contiguous
+//   B[k][tap*B_inner_pad + n]   (rows padded to B_rows_pad)        -- data-gradient operand (transposed)
+// value = W * scale[n] (weight norm) ; zero outside n_real x k_real and for B rows >= B_rows_real.
 struct RelayoutJob {
   long src_off;        // floats, into params
-  long dst_off;        // elements, into the shadow buffer
-  long scale_off;      // floats into the wn-scale buffer, or -1
-  int rows_pad, rows_real;
-  int taps, inner_pad, inner_real;
-  int ld;              // dst row pitch (elements) >= taps*inner_pad
-  long s_row, s_inner, s_tap;
-  int scale_on_row;    // 1: scale[row], 0: scale[i]
+  long s_n, s_k;       // source strides of n and k (floats)
+  long dstA, dstB;     // elements, into the shadow buffer
+  long scale_off;      // floats into the wn-scale buffer (indexed by n), or -1
+  int taps, n_real, k_real;
+  int A_rows_pad, A_inner_pad, B_rows_pad, B_inner_pad, B_rows_real;
+  int tile, tiles_k;   // tile edge (64 for 1x1, 32 otherwise), tiles along k
   int block_start;     // first block of this job
 };
 
+constexpr int kRelayoutLds = 64 * 65;    // >= 32*33*9 as well
+
 template <typename T>
-__global__ void relayout_kernel(const float* __restrict__ params, T* __restrict__ shadow, const float* __restrict__ wn_scale,
-                                const RelayoutJob* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void relayout_kernel(const float* __restrict__ params, T* __restrict__ shadow,
+                                                       const float* __restrict__ wn_scale, const RelayoutJob* __restrict__ jobs,
+                                                       int njobs) {
+  __shared__ float tile[32 * 33 * 9 > kRelayoutLds ? 32 * 33 * 9 : kRelayoutLds];   // [n_l][tap][k_l], k pitch TE+1
   // locate the job of this block (block_start is ascending)
   int lo = 0, hi = njobs - 1;
   while (lo < hi) {
@@ -30,19 +37,41 @@ __global__ void relayout_kernel(const float* __restrict__ params, T* __restrict_
     if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const RelayoutJob j = jobs[lo];
-  const long total = (long)j.rows_pad * j.ld;
-  const long base = ((long)blockIdx.x - j.block_start) * blockDim.x * 8;
-  for (int u = 0; u < 8; ++u) {
-    const long e = base + (long)u * blockDim.x + threadIdx.x;
-    if (e >= total) break;
-    const int row = (int)(e / j.ld), k = (int)(e - (long)row * j.ld);
-    const int tap = k / j.inner_pad, i = k - tap * j.inner_pad;
+  const int TE = j.tile, TP = TE + 1, taps = j.taps;
+  const int t_id = (int)blockIdx.x - j.block_start;
+  const int n0 = (t_id / j.tiles_k) * TE, k0 = (t_id % j.tiles_k) * TE;
+  const int total = TE * TE * taps;
+  // read in source order: tap fastest, then whichever of (n, k) has the smaller stride
+  const bool k_mid = j.s_k < j.s_n;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int t = e % taps, rest = e / taps;
+    const int m = rest % TE, sl = rest / TE;
+    const int nl = k_mid ? sl : m, kl = k_mid ? m : sl;
+    const int n = n0 + nl, k = k0 + kl;
     float v = 0.f;
-    if (row < j.rows_real && tap < j.taps && i < j.inner_real) {
-      v = params[j.src_off + row * j.s_row + i * j.s_inner + tap * j.s_tap];
-      if (j.scale_off >= 0) v *= wn_scale[j.scale_off + (j.scale_on_row ? row : i)];
+    if (n < j.n_real && k < j.k_real) {
+      v = params[j.src_off + n * j.s_n + k * j.s_k + t];
+      if (j.scale_off >= 0) v *= wn_scale[j.scale_off + n];
     }
-    shadow[j.dst_off + e] = ET<T>::from_f32(v);
+    tile[(nl * taps + t) * TP + kl] = v;
+  }
+  __syncthreads();
+  // A: rows n, columns (tap, k)
+  const int ldA = taps * j.A_inner_pad, ldB = taps * j.B_inner_pad;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int kl = e % TE, rest = e / TE;
+    const int t = rest % taps, nl = rest / taps;
+    const int n = n0 + nl, k = k0 + kl;
+    if (n < j.A_rows_pad && k < j.A_inner_pad)
+      shadow[j.dstA + (long)n * ldA + t * j.A_inner_pad + k] = ET<T>::from_f32(tile[(nl * taps + t) * TP + kl]);
+  }
+  // B: rows k, columns (tap, n)
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int nl = e % TE, rest = e / TE;
+    const int t = rest % taps, kl = rest / taps;
+    const int n = n0 + nl, k = k0 + kl;
+    if (k < j.B_rows_pad && n < j.B_inner_pad)
+      shadow[j.dstB + (long)k * ldB + t * j.B_inner_pad + n] = ET<T>::from_f32(k < j.B_rows_real ? tile[(nl * taps + t) * TP + kl] : 0.f);
   }
 }
 
