@@ -46,6 +46,7 @@ struct TnParams {
   float* dW; long w_sn, w_sc, w_st; int accumulate;
   int splitm, mb_per_split, rows_fixed, Kc_store;
   int tiles_n, tiles_k;
+  int ablate;          // developer experiment (IPOKE_TN_ABLATE): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
 };
 
 // decode output row m -> input base coordinates
@@ -647,8 +648,20 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
     return load_a_chunk<T>(p.A, p.a_f32, off, p.a_sc, p.a_coff, x_c, p.Kc_real);
   };
 
-  u32x4 ry[E16], rx[E16];
-  auto load_stage = [&](int mb) {
+  // Staging registers: NR reduction stages are in flight per thread (one wave per SIMD owns 512 VGPRs; a stage is
+  // 32 of them).  With a single stage in flight every iteration paid a full HBM/L2 latency for ~0.25 us of MFMA work.
+  // bf16: a thread stages dY *or* A (8 chunks); f32: 4 chunks of dY then 4 of A.
+  constexpr int NR = 4;
+  constexpr int XO = E16 == 8 ? 0 : 4;          // where the A chunks start inside a register set
+  u32x4 rs[NR][8];
+  auto load_stage = [&](int mb, u32x4* rset) {
+    u32x4* ry = rset;
+    u32x4* rx = rset + XO;
+    if (p.ablate & 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rset[i] = u32x4{0u, 0u, 0u, 0u};
+      return;
+    }
     const int mbase = mb * RM + mbk * E16;
     if (do_y) {
       const T* yp = reinterpret_cast<const T*>(p.dY) + (long)mbase * p.ldy + p.y_coff + ncol;
@@ -705,9 +718,10 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
       }
     }
   };
-  auto store_stage = [&](int buf) {
-    if (do_y) store_block(sY + buf * 128 * kPitch, ry);
-    if (do_x) store_block(sX + buf * 128 * kPitch, rx);
+  auto store_stage = [&](int buf, const u32x4* rset) {
+    if (p.ablate & 2) return;
+    if (do_y) store_block(sY + buf * 128 * kPitch, rset);
+    if (do_x) store_block(sX + buf * 128 * kPitch, rset + XO);
   };
 
   f32x4 acc[4][4];
@@ -716,41 +730,56 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (mb_begin < mb_end) {
-    load_stage(mb_begin);
-    store_stage(0);
+  const int nst = mb_end - mb_begin;
+  if (nst > 0) {
+    // register set k holds stages == k (mod NR); LDS buffer = stage parity
+#pragma unroll
+    for (int k = 0; k < NR; ++k) if (k < nst) load_stage(mb_begin + k, rs[k]);
+    store_stage(0, rs[0]);
+    if (NR < nst) load_stage(mb_begin + NR, rs[0]);
     __syncthreads();
-    for (int mb = mb_begin; mb < mb_end; ++mb) {
-      const int buf = (mb - mb_begin) & 1;
-      const bool more = mb + 1 < mb_end;
-      if (more) load_stage(mb + 1);
-      const int yrow = wm * 64 + (lane & 15), xrow = wn * 64 + (lane & 15);
-      const unsigned char* y_base = sY + buf * 128 * kPitch;
-      const unsigned char* x_base = sX + buf * 128 * kPitch;
+    for (int base = 0; base < nst; base += NR) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int q = s * 4 + (lane >> 4);
-        frag_t fy[4], fx[4];
+      for (int u = 0; u < NR; ++u) {
+        const int i = base + u;
+        if (i < nst) {
+          constexpr int kDummy = 0; (void)kDummy;
+          const int buf = u & 1;
+          const int yrow = wm * 64 + (lane & 15), xrow = wn * 64 + (lane & 15);
+          const unsigned char* y_base = sY + buf * 128 * kPitch;
+          const unsigned char* x_base = sX + buf * 128 * kPitch;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = yrow + i * 16;
-          fy[i] = *reinterpret_cast<const frag_t*>(y_base + row * kPitch + ((q ^ ((row >> LOGE) & 7)) * 16));
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int q = s2 * 4 + (lane >> 4);
+            frag_t fy[4], fx[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+              const int row = yrow + ii * 16;
+              fy[ii] = *reinterpret_cast<const frag_t*>(y_base + row * kPitch + ((q ^ ((row >> LOGE) & 7)) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int row = xrow + j * 16;
+              fx[j] = *reinterpret_cast<const frag_t*>(x_base + row * kPitch + ((q ^ ((row >> LOGE) & 7)) * 16));
+            }
+            if (!(p.ablate & 4)) {
+#pragma unroll
+              for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma64(fy[ii], fx[j], acc[ii][j]);
+            }
+          }
+          if (i + 1 < nst) {
+            store_stage(buf ^ 1, rs[(u + 1) % NR]);
+            if (i + 1 + NR < nst) load_stage(mb_begin + i + 1 + NR, rs[(u + 1) % NR]);
+          }
+          __syncthreads();
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = xrow + j * 16;
-          fx[j] = *reinterpret_cast<const frag_t*>(x_base + row * kPitch + ((q ^ ((row >> LOGE) & 7)) * 16));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) mma64(fy[i], fx[j], acc[i][j]);
       }
-      if (more) store_stage(buf ^ 1);
-      __syncthreads();
     }
   }
 
+  if (p.ablate & 8) return;
   // epilogue: acc[i][j][r] = dW[n = n0 + wm*64 + 16i + (lane&15)][k = k0 + wn*64 + 16j + 4*(lane>>4) + r]
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -916,6 +945,7 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     const int S = 1 << (p.g.lDo + p.g.lHo + p.g.lWo);
     p.rows_fixed = (RM % S == 0) ? 1 : 0;
   }
+  { static const int ab = getenv("IPOKE_TN_ABLATE") ? atoi(getenv("IPOKE_TN_ABLATE")) : 0; p.ablate = ab; }
   if (p.splitm < 1) p.splitm = 1;
   if (p.splitm > nmb) p.splitm = nmb;
   p.mb_per_split = ceil_div(nmb, p.splitm);
