@@ -174,12 +174,70 @@ def cpu_baseline_subprocess(config, clips, timeout_s):
                 "sample": f"cpu leg exceeded {timeout_s}s for {clips} clip(s); lower bound {clips * 16 / timeout_s:.4f} frames/s not reached"}
 
 
+def secondary(args, cfg, rank, world, device):
+    """c4: first-stage VAE train step; c5: sampling.  Same timing contract as the headline run."""
+    B, T, size, z = cfg["batch_size"], cfg["n_frames"], cfg["spatial_size"], cfg["z_dim"]
+    batch = synthetic_batch(B, T, size, seed=1 + rank, device=device)
+    if args.config == "c4":
+        from ipoke_amd.first_stage import SpadeCondMotionModel
+        from ipoke_amd.first_stage_train import FirstStageTrainer
+        torch.manual_seed(0)
+        model = SpadeCondMotionModel(configs.first_stage_config(size, z, T), dirs={}, dtype=args.dtype).to(device)
+        for p in model.parameters():
+            D.broadcast_(p.data, src=0)
+        trainer = FirstStageTrainer(model)
+        eps = torch.randn(B, z, 8, 8, generator=torch.Generator().manual_seed(7 + rank)).to(device)
+        if world > 1:
+            params = [p for p in model.parameters() if p.requires_grad]
+
+            def sync_grads():
+                flat = torch._utils._flatten_dense_tensors([p.grad for p in params])
+                D.allreduce_flat_(flat, 4)
+                flat.div_(world)
+                for p, g in zip(params, torch._utils._unflatten_dense_tensors(flat, [p.grad for p in params])):
+                    p.grad.copy_(g)
+            trainer.grad_hook = sync_grads
+        step = lambda i: trainer.step(batch["images"], eps)[0]
+        metric, frames = "video-frames/sec (first-stage VAE train step, L1 + KL)", world * B * T
+        workload = f"first_stage {T}x3x{size}x{size} clips, z={z}, encoder + ConvGRU + SPADE decoder fwd+bwd, per-GPU batch {B}"
+    else:
+        model = build_model(cfg, args.dtype, device)
+        with torch.no_grad():
+            model.forward_density(batch)                  # data-dependent init
+        randomise_couplings(model)
+        step = lambda i: model.forward_sample(batch, n_samples=1, n_logged_vids=1)
+        metric, frames = "video-frames/sec (sampling: reverse flow + decode)", world * B * (T - 1)
+        workload = f"{cfg['name']} forward_sample, z={z}, reverse flow + {T - 1}-frame decode at {size}x{size}, per-GPU batch {B}"
+    for i in range(args.warmup):
+        out = step(i)
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    torch.cuda.synchronize(); D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {"metric": metric, "value": round(frames / (elapsed / args.steps), 2), "unit": "video-frames/sec", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": workload, "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
+                           "weights": "random init of the named architecture (no checkpoints offline)"},
+                "roofline": kernel_roofline(B, args.dtype)}
+        if args.config == "c4":
+            line["loss"] = round(float(out.item()), 4)
+        print(json.dumps(line), flush=True)
+    D.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="c2 (default) is the configuration BASELINE.json's metric is quoted on; c4 = first-stage VAE train step "
+                         "(L1 + KL), c5 = sampling (reverse flow + 15-frame decode): secondary workloads of SURVEY.md §8d")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,6 +259,10 @@ def main():
     if args.batch:
         cfg["batch_size"] = args.batch
     B, T, size, z = cfg["batch_size"], cfg["n_frames"], cfg["spatial_size"], cfg["z_dim"]
+
+    if args.config in ("c4", "c5"):
+        secondary(args, cfg, rank, world, device)
+        return
 
     from ipoke_amd.trainer import SecondStageTrainer
     model = build_model(cfg, args.dtype, device)

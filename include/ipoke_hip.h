@@ -292,6 +292,52 @@ int ipoke_bilinear_cl(const float* x_nchw, float* y_cl, int N, int C, int Hi, in
 int ipoke_cl_to_nchw(const void* x_cl, int ld, float* y, int N, int C, int S, int dtype, void* stream);
 int ipoke_nchw_to_cl(const float* x, void* y_cl, int ld, int N, int C, int S, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * First-stage VAE training: backward of the helpers above.  These replace the
+ * autograd of SpadeCondMotionModel.forward (first_stage_motion_model.py:469-522) and of the L1 + KL part of
+ * MotionModel.training_step (:263-276); convolutions use ipoke_conv_forward (data gradient = the transposed /
+ * direct convolution with the same weights) and ipoke_conv_wgrad.
+ * ------------------------------------------------------------------------------------------- */
+/* statistics only: fills the workspace exactly as ipoke_groupnorm does (mean, rstd per (n, g)) */
+int ipoke_groupnorm_stats(const void* x, int ldx, int N, int S, int C, int G, float eps, float* workspace, int dtype, void* stream);
+/* backward of  y = act( xhat*gamma + beta [*(1 + mod_gamma) + mod_beta] [+ res] ):
+ *   dx, dres (= d/d res), dmod_gamma, dmod_beta (dtype, per position) and dgamma, dbeta (fp32 [C], written). */
+typedef struct {
+  const void* x; int32_t ldx;            /* saved input                                              */
+  const void* y; int32_t ldy;            /* saved output (needed when act != NONE)                   */
+  const void* dy; int32_t lddy;
+  void* dx; int32_t lddx;
+  void* dres; int32_t lddres;            /* NULL when the forward had no residual                    */
+  void* dmod_gamma; void* dmod_beta; int32_t ld_dmod;   /* NULL without SPADE modulation              */
+  int32_t N, S, C, G; float eps;
+  const float* gamma; const float* beta; /* [C] or NULL                                              */
+  const void* mod_gamma; int32_t ld_mod; /* saved modulation gamma                                   */
+  float* dgamma; float* dbeta;           /* [C] fp32 or NULL                                         */
+  int32_t act;
+  float* workspace;                      /* ipoke_groupnorm_bwd_workspace_floats(N, S, C, G) floats  */
+} ipoke_norm_bwd_desc;
+int64_t ipoke_groupnorm_bwd_workspace_floats(int N, int S, int C, int G);
+int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void* stream);
+/* out[:, :C] = dy * act'(y), out[:, C:Cpad] = 0   (backward of an activation fused into a conv / add epilogue) */
+int ipoke_act_bwd(const void* dy, int lddy, const void* y, int ldy, void* out, int ldo, int64_t M, int C, int Cpad, int act,
+                  int dtype, void* stream);
+/* bias gradients: out[c] (+)= sum_m src[m][c] */
+int64_t ipoke_colsum_workspace_floats(int64_t M, int C);
+int ipoke_colsum(const void* src, int ld, int64_t M, int C, int src_f32, float* out, int accumulate, float* workspace, int dtype,
+                 void* stream);
+/* ConvGRU cell (rnn.py:48-56) backward of the two element-wise stages */
+int ipoke_gru_update_bwd(const void* o_pre, const void* u, const void* h, int ldh, const void* d_hnew, int ld_dhnew, void* d_o_pre,
+                         void* d_u, void* d_h, int ld_dh, int64_t M, int Ch, int dtype, void* stream);
+int ipoke_gru_gates_bwd(const void* ur_pre, const void* h, int ldh, const void* d_hr, int ld_dhr, const void* d_u, void* d_ur_pre,
+                        void* d_h, int ld_dh, int64_t M, int Ch, int dtype, void* stream);
+/* reparameterize backward: dmulv = [dz + dmu | dz*eps*exp(lv/2)/2 + dlv]  (any of dz/dmu/dlv may be NULL) */
+int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, const float* dz, const float* dmu, const float* dlv, void* dmulv,
+                      int ldo, int64_t M, int Z, int dtype, void* stream);
+/* *loss_accum += scale * sum |yhat - x|, grad = scale * sign(yhat - x); yhat channels-last fp32, x fp32 [N][C][S]
+ * with sample stride x_sn (first_stage_motion_model.py:265: L1 between the generated and the true frames) */
+int ipoke_l1_loss(const float* yhat_cl, int ldy, const float* x_nchw, int N, int C, int S, int64_t x_sn, float scale,
+                  float* loss_accum, float* grad_cl, int ldg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

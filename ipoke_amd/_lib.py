@@ -46,6 +46,15 @@ class AffineDesc(Structure):
                 ("P", c_int32), ("ld", c_int32)]
 
 
+class NormBwdDesc(Structure):
+    _fields_ = [("x", c_void_p), ("ldx", c_int32), ("y", c_void_p), ("ldy", c_int32), ("dy", c_void_p), ("lddy", c_int32),
+                ("dx", c_void_p), ("lddx", c_int32), ("dres", c_void_p), ("lddres", c_int32),
+                ("dmod_gamma", c_void_p), ("dmod_beta", c_void_p), ("ld_dmod", c_int32),
+                ("N", c_int32), ("S", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
+                ("gamma", c_void_p), ("beta", c_void_p), ("mod_gamma", c_void_p), ("ld_mod", c_int32),
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("act", c_int32), ("workspace", c_void_p)]
+
+
 class McfDesc(Structure):
     _fields_ = [("x", c_void_p), ("y", c_void_p), ("ld", c_int32), ("C", c_int32), ("B", c_int32),
                 ("cond", c_void_p), ("Cc", c_int32),
@@ -118,6 +127,16 @@ SIGNATURES = {
     "ipoke_bilinear_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_cl_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_nchw_to_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_groupnorm_stats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
+    "ipoke_groupnorm_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
+    "ipoke_groupnorm_bwd": (c_int, [POINTER(NormBwdDesc), c_int, _P]),
+    "ipoke_act_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_colsum_workspace_floats": (c_int64, [c_int64, c_int]),
+    "ipoke_colsum": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, c_int, _P, c_int, _P]),
+    "ipoke_gru_update_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
+    "ipoke_gru_gates_bwd": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
+    "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
+    "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P]),
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),
     "ipoke_flow_destroy": (None, [_P]),
     "ipoke_flow_param_count": (c_int64, [_P]),

@@ -227,6 +227,25 @@ extern "C" int64_t ipoke_groupnorm_workspace_floats(int N, int S, int G) {
   return (int64_t)N * nchunks * G * 3 + (int64_t)N * G * 2;
 }
 
+extern "C" int ipoke_groupnorm_stats(const void* x, int ldx, int N, int S, int C, int G, float eps, float* workspace, int dtype,
+                                     void* stream) {
+  IPK_REQUIRE(x && workspace && C % G == 0, "bad arguments");
+  const int e16 = dtype == IPOKE_BF16 ? 8 : 4;
+  IPK_REQUIRE(C % e16 == 0 && ldx % e16 == 0 && C <= 4096, "channels must be a multiple of 16 bytes");
+  const int ppb = 128;
+  const int nchunks = (S + ppb - 1) / ppb;
+  float* part = workspace;
+  float* stats = part + (int64_t)N * nchunks * G * 3;
+  hipStream_t s = STREAM(stream);
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, N), dim3(256), 2 * C * sizeof(float), s, (const bf16_t*)x, S, ldx, C, G, ppb, part),
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, N), dim3(256), 2 * C * sizeof(float), s, (const float*)x, S, ldx, C, G, ppb, part));
+  IPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(64), 0, s, part, nchunks, G, eps, stats);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
 extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream) {
   IPK_REQUIRE(d && d->x && d->y && d->workspace, "null tensor");
   const int e16 = dtype == IPOKE_BF16 ? 8 : 4;

@@ -1,0 +1,369 @@
+// Backward kernels of the first-stage VAE (training row a18 / config c4): GroupNorm / InstanceNorm / SPADE
+// backward, activation backward, bias-gradient column sums, ConvGRU gate backward, reparameterisation backward
+// and the L1 reconstruction loss with its gradient.  Reference call sites whose autograd these replace:
+// motion_encoder.py:45-74 (GroupNorm+ReLU+residual), autoencoders/util.py:26-36, 223-233, 473-500 (norms, Spade),
+// motion_models/rnn.py:48-56 (ConvGRU), motion_encoder.py:218-222 (reparameterize),
+// first_stage_motion_model.py:263-272 (L1 term of the loss).
+//
+// Activations are channels-last [N*S][ld] of the compute dtype T; every reduction is fp32.
+#include "common.h"
+
+namespace ipoke {
+
+static inline int grid1d_b(long n, int block = 256, int cap = 4096) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// out = dy * act'(y)   (y = saved activation output)
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy, T* __restrict__ out, int ldo,
+                               long M, int C, int Cpad, int act) {
+  const long total = M * Cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / Cpad; const int c = (int)(i - m * Cpad);
+    float v = 0.f;
+    if (c < C) v = ET<T>::to_f32(dy[m * lddy + c]) * act_grad_from_out(act, ET<T>::to_f32(y[m * ldy + c]));
+    out[m * ldo + c] = ET<T>::from_f32(v);
+  }
+}
+
+// column sums of a T (or fp32) matrix: part[blk][C] per block of rows, then a second pass over blocks
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ src, int ld, long M, int C, int rows_per_block,
+                                                          float* __restrict__ part) {
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  // thread t owns column t % C over rows (t / C), stepping blockDim/C rows
+  extern __shared__ float sm[];          // [rows_par][C]
+  const int rows_par = blockDim.x / C > 0 ? blockDim.x / C : 1;
+  for (int c0 = 0; c0 < C; c0 += blockDim.x) {       // C > blockDim: several column passes
+    const int cols = C - c0 < (int)blockDim.x ? C - c0 : (int)blockDim.x;
+    const int rp = blockDim.x / cols > 0 ? blockDim.x / cols : 1;
+    const int c = threadIdx.x % cols, rr = threadIdx.x / cols;
+    float acc = 0.f;
+    if (rr < rp)
+      for (long r = r0 + rr; r < r1; r += rp) acc += ET<T>::to_f32(src[r * ld + c0 + c]);
+    sm[threadIdx.x] = (rr < rp) ? acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+      float t = 0.f;
+      for (int k = 0; k < rp; ++k) t += sm[k * cols + threadIdx.x];
+      part[(long)blockIdx.x * C + c0 + threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  (void)rows_par;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += part[(long)b * C + c];
+  out[c] = accumulate ? out[c] + t : t;
+}
+
+// ---------------------------------------------------------------------------------------------- GroupNorm backward
+struct NormBwd {
+  const void* x; int ldx; const void* y; int ldy; const void* dy; int lddy;
+  void* dx; int lddx; void* dres; int lddres; void* dmg; void* dmb; int ld_dmod;
+  int N, S, C, G;
+  const float* stats;                  // [N][G][2] mean, rstd (recomputed)
+  const float* gamma; const float* beta;
+  const void* mod_gamma; int ld_mod;
+  int act;
+  float* part;                         // [N][nchunks][2][C]  (sum du, sum du*xhat)
+  float* gsum;                         // [N][G][2]           (S1 = sum dxhat, S2 = sum dxhat*xhat)
+  int nchunks, pos_per_block;
+};
+// du for one element: dw = dy*act'(y); du = dw*(1+mg)
+template <typename T>
+__device__ __forceinline__ float norm_dw(const NormBwd& a, long m, int c) {
+  const float g = ET<T>::to_f32(reinterpret_cast<const T*>(a.dy)[m * a.lddy + c]);
+  if (a.act == IPOKE_ACT_NONE) return g;
+  return g * act_grad_from_out(a.act, ET<T>::to_f32(reinterpret_cast<const T*>(a.y)[m * a.ldy + c]));
+}
+// pass 1: per (n, chunk) and channel: sum_p du, sum_p du*xhat
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const NormBwd a) {
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * a.pos_per_block, p1 = min(a.S, p0 + a.pos_per_block);
+  const int cpg = a.C / a.G;
+  extern __shared__ float sm[];        // [2][rows_par][cols] scratch
+  for (int c0 = 0; c0 < a.C; c0 += blockDim.x) {
+    const int cols = a.C - c0 < (int)blockDim.x ? a.C - c0 : (int)blockDim.x;
+    const int rp = blockDim.x / cols > 0 ? blockDim.x / cols : 1;
+    const int cl = threadIdx.x % cols, rr = threadIdx.x / cols, c = c0 + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (rr < rp) {
+      const int g = c / cpg;
+      const float mean = a.stats[((long)n * a.G + g) * 2], rstd = a.stats[((long)n * a.G + g) * 2 + 1];
+      for (int p = p0 + rr; p < p1; p += rp) {
+        const long m = (long)n * a.S + p;
+        float du = norm_dw<T>(a, m, c);
+        if (a.mod_gamma) du *= 1.f + ET<T>::to_f32(reinterpret_cast<const T*>(a.mod_gamma)[m * a.ld_mod + c]);
+        const float xh = (ET<T>::to_f32(reinterpret_cast<const T*>(a.x)[m * a.ldx + c]) - mean) * rstd;
+        s1 += du; s2 += du * xh;
+      }
+    }
+    sm[threadIdx.x] = rr < rp ? s1 : 0.f;
+    sm[blockDim.x + threadIdx.x] = rr < rp ? s2 : 0.f;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int k = 0; k < rp; ++k) { t1 += sm[k * cols + threadIdx.x]; t2 += sm[blockDim.x + k * cols + threadIdx.x]; }
+      float* o = a.part + (((long)n * a.nchunks + chunk) * 2) * a.C;
+      o[c0 + threadIdx.x] = t1; o[a.C + c0 + threadIdx.x] = t2;
+    }
+    __syncthreads();
+  }
+}
+// pass 2: per (n, g): S1 = sum_c gamma_c * sum du, S2 = sum_c gamma_c * sum du*xhat ; per channel dgamma/dbeta over n, chunks
+__global__ void gn_bwd_finalize_kernel(const NormBwd a, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int cpg = a.C / a.G;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < a.N * a.G) {
+    const int n = tid / a.G, g = tid % a.G;
+    float S1 = 0.f, S2 = 0.f;
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+      const float* o = a.part + (((long)n * a.nchunks + ch) * 2) * a.C;
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        const float gm = a.gamma ? a.gamma[c] : 1.f;
+        S1 += gm * o[c]; S2 += gm * o[a.C + c];
+      }
+    }
+    a.gsum[(long)tid * 2] = S1; a.gsum[(long)tid * 2 + 1] = S2;
+  }
+  if (dgamma && tid < a.C) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int n = 0; n < a.N; ++n)
+      for (int ch = 0; ch < a.nchunks; ++ch) {
+        const float* o = a.part + (((long)n * a.nchunks + ch) * 2) * a.C;
+        t1 += o[tid]; t2 += o[a.C + tid];
+      }
+    dbeta[tid] = t1; dgamma[tid] = t2;
+  }
+}
+// pass 3: dx = rstd * (dxhat - (S1 + xhat*S2)/cnt), plus the residual / modulation gradients
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
+  const int cpg = a.C / a.G;
+  const float inv_cnt = 1.f / ((float)a.S * cpg);
+  const long total = (long)a.N * a.S * a.C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % a.C);
+    const long m = i / a.C;
+    const int n = (int)(m / a.S), g = c / cpg;
+    const float mean = a.stats[((long)n * a.G + g) * 2], rstd = a.stats[((long)n * a.G + g) * 2 + 1];
+    const float S1 = a.gsum[((long)n * a.G + g) * 2], S2 = a.gsum[((long)n * a.G + g) * 2 + 1];
+    const float dw = norm_dw<T>(a, m, c);
+    const float xh = (ET<T>::to_f32(reinterpret_cast<const T*>(a.x)[m * a.ldx + c]) - mean) * rstd;
+    float du = dw;
+    if (a.mod_gamma) {
+      const float mg = ET<T>::to_f32(reinterpret_cast<const T*>(a.mod_gamma)[m * a.ld_mod + c]);
+      du = dw * (1.f + mg);
+      const float u = a.gamma ? xh * a.gamma[c] + a.beta[c] : xh;
+      reinterpret_cast<T*>(a.dmg)[m * a.ld_dmod + c] = ET<T>::from_f32(dw * u);
+      reinterpret_cast<T*>(a.dmb)[m * a.ld_dmod + c] = ET<T>::from_f32(dw);
+    }
+    if (a.dres) reinterpret_cast<T*>(a.dres)[m * a.lddres + c] = ET<T>::from_f32(dw);
+    const float dxh = a.gamma ? du * a.gamma[c] : du;
+    reinterpret_cast<T*>(a.dx)[m * a.lddx + c] = ET<T>::from_f32(rstd * (dxh - (S1 + xh * S2) * inv_cnt));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- ConvGRU backward
+// update: h' = h*(1-u) + tanh(o_pre)*u
+template <typename T>
+__global__ void gru_update_bwd_kernel(const T* __restrict__ o_pre, const T* __restrict__ u, const T* __restrict__ h, int ldh,
+                                      const T* __restrict__ dhn, int lddhn, T* __restrict__ do_pre, T* __restrict__ du,
+                                      T* __restrict__ dh, int lddh, long M, int Ch) {
+  const long total = M * Ch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / Ch; const int c = (int)(i - m * Ch);
+    const float g = ET<T>::to_f32(dhn[m * lddhn + c]);
+    const float uu = ET<T>::to_f32(u[m * Ch + c]);
+    const float o = tanhf(ET<T>::to_f32(o_pre[m * Ch + c]));
+    const float hv = ET<T>::to_f32(h[m * ldh + c]);
+    do_pre[m * Ch + c] = ET<T>::from_f32(g * uu * (1.f - o * o));
+    du[m * Ch + c] = ET<T>::from_f32(g * (o - hv));
+    dh[m * lddh + c] = ET<T>::from_f32(g * (1.f - uu));
+  }
+}
+// gates: u = sigmoid(u_pre), r = sigmoid(r_pre), hr = h*r.  Inputs d_hr, d_u; outputs d_ur_pre [M][2Ch], dh
+template <typename T>
+__global__ void gru_gates_bwd_kernel(const T* __restrict__ ur_pre, const T* __restrict__ h, int ldh, const T* __restrict__ d_hr,
+                                     int ld_dhr, const T* __restrict__ d_u, T* __restrict__ d_ur_pre, T* __restrict__ dh, int lddh,
+                                     long M, int Ch) {
+  const long total = M * Ch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / Ch; const int c = (int)(i - m * Ch);
+    const float u = act_apply(IPOKE_ACT_SIGMOID, ET<T>::to_f32(ur_pre[m * 2 * Ch + c]));
+    const float r = act_apply(IPOKE_ACT_SIGMOID, ET<T>::to_f32(ur_pre[m * 2 * Ch + Ch + c]));
+    const float hv = ET<T>::to_f32(h[m * ldh + c]);
+    const float ghr = ET<T>::to_f32(d_hr[m * ld_dhr + c]);
+    const float gu = d_u ? ET<T>::to_f32(d_u[m * Ch + c]) : 0.f;
+    d_ur_pre[m * 2 * Ch + c] = ET<T>::from_f32(gu * u * (1.f - u));
+    d_ur_pre[m * 2 * Ch + Ch + c] = ET<T>::from_f32(ghr * hv * r * (1.f - r));
+    dh[m * lddh + c] = ET<T>::from_f32(ghr * r);
+  }
+}
+// z = mu + eps*exp(lv/2):  dmulv = [dz + dmu | dz*eps*0.5*exp(lv/2) + dlv]
+template <typename T>
+__global__ void reparam_bwd_kernel(const T* __restrict__ mulv, int ld, const float* __restrict__ eps, const float* __restrict__ dz,
+                                   const float* __restrict__ dmu, const float* __restrict__ dlv, T* __restrict__ dmulv, int ldo,
+                                   long M, int Z) {
+  const long total = M * ldo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / ldo; const int c = (int)(i - m * ldo);
+    float v = 0.f;
+    if (c < Z) {
+      v = (dz ? dz[m * Z + c] : 0.f) + (dmu ? dmu[m * Z + c] : 0.f);
+    } else if (c < 2 * Z) {
+      const int k = c - Z;
+      const float lv = ET<T>::to_f32(mulv[m * ld + c]);
+      v = (dlv ? dlv[m * Z + k] : 0.f);
+      if (dz && eps) v += dz[m * Z + k] * eps[m * Z + k] * 0.5f * expf(0.5f * lv);
+    }
+    dmulv[i] = ET<T>::from_f32(v);
+  }
+}
+// L1: loss += scale * sum |yhat - x| ; grad = scale * sign(yhat - x).  yhat channels-last fp32 [N*S][ldy], x fp32 [N][C][S]
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ yhat, int ldy, const float* __restrict__ x, int N, int C,
+                                                      int S, long x_sn, float scale, float* __restrict__ loss, float* __restrict__ grad,
+                                                      int ldg) {
+  __shared__ float red[8];
+  const long total = (long)N * S * C;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long m = i / C;
+    const int n = (int)(m / S), s = (int)(m % S);
+    const float d = yhat[m * ldy + c] - x[(long)n * x_sn + (long)c * S + s];
+    acc += fabsf(d);
+    if (grad) grad[m * ldg + c] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss, tot * scale);
+}
+
+}  // namespace ipoke
+
+using namespace ipoke;
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+#define DISPATCH_T(dtype, CALL_BF, CALL_F32) do { if ((dtype) == IPOKE_BF16) { CALL_BF; } else { CALL_F32; } } while (0)
+
+extern "C" int ipoke_act_bwd(const void* dy, int lddy, const void* y, int ldy, void* out, int ldo, int64_t M, int C, int Cpad,
+                             int act, int dtype, void* stream) {
+  IPK_REQUIRE(dy && y && out && Cpad >= C && ldo >= Cpad, "bad arguments");
+  const long total = (long)M * Cpad;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid1d_b(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)out, ldo, (long)M, C, Cpad, act),
+    hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid1d_b(total)), dim3(256), 0, STREAM(stream), (const float*)dy, lddy, (const float*)y, ldy, (float*)out, ldo, (long)M, C, Cpad, act));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+static const int kColsumRows = 512;
+extern "C" int64_t ipoke_colsum_workspace_floats(int64_t M, int C) { return ((M + kColsumRows - 1) / kColsumRows) * (int64_t)C; }
+/* out[c] (+)= sum_m src[m][c]; src of dtype (src_f32 = 1: fp32) */
+extern "C" int ipoke_colsum(const void* src, int ld, int64_t M, int C, int src_f32, float* out, int accumulate, float* workspace,
+                            int dtype, void* stream) {
+  IPK_REQUIRE(src && out && workspace && M >= 1 && C >= 1, "bad arguments");
+  const int nblk = (int)((M + kColsumRows - 1) / kColsumRows);
+  hipStream_t s = STREAM(stream);
+  if (src_f32 || dtype == IPOKE_F32)
+    hipLaunchKernelGGL(colsum_part_kernel<float>, dim3(nblk), dim3(256), 256 * sizeof(float), s, (const float*)src, ld, (long)M, C, kColsumRows, workspace);
+  else
+    hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, dim3(nblk), dim3(256), 256 * sizeof(float), s, (const bf16_t*)src, ld, (long)M, C, kColsumRows, workspace);
+  IPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, out, accumulate);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+static const int kNormBwdPos = 128;
+extern "C" int64_t ipoke_groupnorm_bwd_workspace_floats(int N, int S, int C, int G) {
+  const int nchunks = (S + kNormBwdPos - 1) / kNormBwdPos;
+  return ipoke_groupnorm_workspace_floats(N, S, G) + (int64_t)N * nchunks * 2 * C + (int64_t)N * G * 2;
+}
+
+// forward-statistics kernels of norm.hip (same translation-unit-independent entry point)
+extern "C" int ipoke_groupnorm_stats(const void* x, int ldx, int N, int S, int C, int G, float eps, float* workspace, int dtype,
+                                     void* stream);
+
+extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void* stream) {
+  IPK_REQUIRE(d && d->x && d->dy && d->dx && d->workspace, "null tensor");
+  IPK_REQUIRE(d->act == IPOKE_ACT_NONE || d->y, "the activation gradient needs the saved output");
+  IPK_REQUIRE(d->C % d->G == 0, "channels must be a multiple of the group count");
+  IPK_REQUIRE((d->mod_gamma == nullptr) == (d->dmod_gamma == nullptr) && (d->dmod_gamma == nullptr) == (d->dmod_beta == nullptr),
+              "modulation gradients come as a pair, with the saved modulation");
+  IPK_REQUIRE((d->dgamma == nullptr) == (d->dbeta == nullptr) && (!d->dgamma || d->gamma), "affine gradient pair");
+  hipStream_t s = STREAM(stream);
+  // statistics of the saved input, exactly as in the forward pass
+  int rc = ipoke_groupnorm_stats(d->x, d->ldx, d->N, d->S, d->C, d->G, d->eps, d->workspace, dtype, stream);
+  if (rc) return rc;
+  const int ppb_f = 128, nch_f = (d->S + ppb_f - 1) / ppb_f;
+  NormBwd a;
+  a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.dy = d->dy; a.lddy = d->lddy;
+  a.dx = d->dx; a.lddx = d->lddx; a.dres = d->dres; a.lddres = d->lddres; a.dmg = d->dmod_gamma; a.dmb = d->dmod_beta;
+  a.ld_dmod = d->ld_dmod; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
+  a.stats = d->workspace + (int64_t)d->N * nch_f * d->G * 3;
+  a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = d->mod_gamma; a.ld_mod = d->ld_mod; a.act = d->act;
+  a.nchunks = (d->S + kNormBwdPos - 1) / kNormBwdPos; a.pos_per_block = kNormBwdPos;
+  a.part = d->workspace + ipoke_groupnorm_workspace_floats(d->N, d->S, d->G);
+  a.gsum = a.part + (int64_t)d->N * a.nchunks * 2 * d->C;
+  IPK_REQUIRE(!a.gamma || a.beta || !a.mod_gamma, "SPADE with an affine norm needs beta");
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(a.nchunks, d->N), dim3(256), 2 * 256 * sizeof(float), s, a),
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(a.nchunks, d->N), dim3(256), 2 * 256 * sizeof(float), s, a));
+  IPK_LAUNCH_CHECK();
+  const int nfin = d->N * d->G > d->C ? d->N * d->G : d->C;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nfin + 255) / 256), dim3(256), 0, s, a, d->dgamma, d->dbeta);
+  IPK_LAUNCH_CHECK();
+  const long total = (long)d->N * d->S * d->C;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid1d_b(total)), dim3(256), 0, s, a),
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid1d_b(total)), dim3(256), 0, s, a));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_gru_update_bwd(const void* o_pre, const void* u, const void* h, int ldh, const void* d_hnew, int ld_dhnew,
+                                    void* d_o_pre, void* d_u, void* d_h, int ld_dh, int64_t M, int Ch, int dtype, void* stream) {
+  IPK_REQUIRE(o_pre && u && h && d_hnew && d_o_pre && d_u && d_h, "null tensor");
+  const long total = (long)M * Ch;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gru_update_bwd_kernel<bf16_t>, dim3(grid1d_b(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)o_pre, (const bf16_t*)u, (const bf16_t*)h, ldh, (const bf16_t*)d_hnew, ld_dhnew, (bf16_t*)d_o_pre, (bf16_t*)d_u, (bf16_t*)d_h, ld_dh, (long)M, Ch),
+    hipLaunchKernelGGL(gru_update_bwd_kernel<float>, dim3(grid1d_b(total)), dim3(256), 0, STREAM(stream), (const float*)o_pre, (const float*)u, (const float*)h, ldh, (const float*)d_hnew, ld_dhnew, (float*)d_o_pre, (float*)d_u, (float*)d_h, ld_dh, (long)M, Ch));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_gru_gates_bwd(const void* ur_pre, const void* h, int ldh, const void* d_hr, int ld_dhr, const void* d_u,
+                                   void* d_ur_pre, void* d_h, int ld_dh, int64_t M, int Ch, int dtype, void* stream) {
+  IPK_REQUIRE(ur_pre && h && d_hr && d_ur_pre && d_h, "null tensor");
+  const long total = (long)M * Ch;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(gru_gates_bwd_kernel<bf16_t>, dim3(grid1d_b(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)ur_pre, (const bf16_t*)h, ldh, (const bf16_t*)d_hr, ld_dhr, (const bf16_t*)d_u, (bf16_t*)d_ur_pre, (bf16_t*)d_h, ld_dh, (long)M, Ch),
+    hipLaunchKernelGGL(gru_gates_bwd_kernel<float>, dim3(grid1d_b(total)), dim3(256), 0, STREAM(stream), (const float*)ur_pre, (const float*)h, ldh, (const float*)d_hr, ld_dhr, (const float*)d_u, (float*)d_ur_pre, (float*)d_h, ld_dh, (long)M, Ch));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, const float* dz, const float* dmu, const float* dlv,
+                                 void* dmulv, int ldo, int64_t M, int Z, int dtype, void* stream) {
+  IPK_REQUIRE(mulv && dmulv && ldo >= 2 * Z, "bad arguments");
+  const long total = (long)M * ldo;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(reparam_bwd_kernel<bf16_t>, dim3(grid1d_b(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)mulv, ld, eps, dz, dmu, dlv, (bf16_t*)dmulv, ldo, (long)M, Z),
+    hipLaunchKernelGGL(reparam_bwd_kernel<float>, dim3(grid1d_b(total)), dim3(256), 0, STREAM(stream), (const float*)mulv, ld, eps, dz, dmu, dlv, (float*)dmulv, ldo, (long)M, Z));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_l1_loss(const float* yhat_cl, int ldy, const float* x_nchw, int N, int C, int S, int64_t x_sn, float scale,
+                             float* loss_accum, float* grad_cl, int ldg, void* stream) {
+  IPK_REQUIRE(yhat_cl && x_nchw && loss_accum && ldy >= C && (!grad_cl || ldg >= C), "bad arguments");
+  const long total = (long)N * S * C;
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(grid1d_b(total, 256, 1024)), dim3(256), 0, STREAM(stream), yhat_cl, ldy, x_nchw, N, C, S,
+                     (long)x_sn, scale, loss_accum, grad_cl, ldg);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}

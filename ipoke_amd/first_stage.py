@@ -4,9 +4,11 @@ the reference (models/first_stage_motion_model.py:469-522, modules/motion_models
 modules/autoencoders/{fully_conv_models,util}.py) so that reference checkpoints load with ``strict=False``
 exactly as ``PokeMotionModel.__initialize_first_stage`` does.
 
-This round implements the *inference* direction (what the second stage and sampling need: everything runs under
-``torch.no_grad`` there, second_stage_video.py:269-303).  Spectral-normalised convolutions are evaluated in eval
-mode (frozen u, v), i.e. ``W / sigma`` is folded into the cached weight operand.
+``forward`` / ``decode`` are the *inference* direction (what the second stage and sampling need: everything runs under
+``torch.no_grad`` there, second_stage_video.py:269-303); spectral-normalised convolutions are then evaluated in eval
+mode (frozen u, v), i.e. ``W / sigma`` is folded into the cached weight operand.  The differentiable pass used for
+first-stage training (L1 + KL) lives in ``ipoke_amd.first_stage_train`` and is reached through
+``SpadeCondMotionModel.training_loss``.
 """
 import math
 
@@ -435,8 +437,8 @@ class SpadeCondMotionModel(nn.Module):
 
     def __init__(self, config, dirs=None, train=False, dtype="bf16"):
         super().__init__()
-        if train:
-            raise NotImplementedError("first-stage *training* (GAN/VGG losses, backward of the VAE) is not part of this round")
+        # ``train=True`` in the reference additionally builds the GAN discriminators and the VGG perceptual loss
+        # (first_stage_motion_model.py:171-263); here training covers the L1 + KL terms.
         self.config, self.dirs, self.dtype = config, dirs, dtype
         arch = dict(config["architecture"])
         self.full_sequence = bool(config["training"].get("full_sequence", False))
@@ -473,3 +475,14 @@ class SpadeCondMotionModel(nn.Module):
         X_in = X if self.full_sequence else X[:, 1:]
         motion, mu, logvar = self.enc_motion(X_in.transpose(1, 2), eps=eps)
         return self.decode(motion, X[:, 0], X.shape[1] - 1), mu, logvar
+
+    def training_loss(self, X, eps, w_l1=10.0, w_kl=1e-7, power_iteration=None):
+        """Differentiable forward + ``w_l1 * L1 + w_kl * KL`` (first_stage_motion_model.py:263-276 without the GAN / VGG
+        terms).  Returns (loss, X_hat, mu, logvar); ``loss.backward()`` fills ``.grad`` of every parameter."""
+        from . import first_stage_train
+        return first_stage_train.first_stage_forward_loss(self, X, eps, w_l1, w_kl, power_iteration)
+
+    def invalidate_operands(self):
+        """Drop the cached inference weight operands (after an optimiser step or a state-dict load)."""
+        for m in self.modules():
+            m.__dict__.pop("_opcache", None)

@@ -1,0 +1,549 @@
+"""First-stage VAE *training* on the HIP kernels: encoder -> ConvGRU -> SPADE decoder with
+gradients, L1 + KL loss (reference models/first_stage_motion_model.py:469-522 forward, :263-276 loss terms,
+utils/losses.py:47-48 KL).
+
+The parameter holders are the modules of ``ipoke_amd.first_stage`` (reference state-dict names); this file adds the
+differentiable execution: every op is a ``torch.autograd.Function`` whose forward *and* backward are HIP kernels of
+libipoke_hip on channels-last activations --
+
+    convolution         ipoke_conv_forward  | data gradient: the transposed (direct) convolution with the same weights
+                                            | weight gradient: ipoke_conv_wgrad, written in PyTorch layout
+                                            | bias gradient: ipoke_colsum, fused activation: ipoke_act_bwd
+    Group/Instance/SPADE ipoke_groupnorm    | ipoke_groupnorm_bwd
+    ConvGRU gates        ipoke_gru_*        | ipoke_gru_*_bwd
+    reparameterize       ipoke_reparameterize | ipoke_reparam_bwd
+    tanh + L1            ipoke_l1_loss (value and gradient in one pass)
+
+PyTorch autograd only records the graph and carries the weight-side algebra (spectral-norm division
+``W / sigma`` with its gradient through sigma, the KL term on the [B, z, 8, 8] latents): plumbing on parameter-sized
+tensors.  In train mode every spectral-normalised conv runs one power iteration per forward *call*, i.e. T-1 times
+per step for the decoder (util.py:52, 252) -- kept, which is why the decoder is evaluated frame by frame.
+"""
+from ctypes import byref
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, nn as K, ops
+from . import first_stage as FS
+from ._lib import NormBwdDesc, NormDesc, WgradDesc, check, ptr
+
+_ws = {}
+
+
+def _workspace(n_floats, device, tag):
+    buf = _ws.get((tag, device))
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(max(int(n_floats), 1 << 16), dtype=torch.float32, device=device)
+        _ws[(tag, device)] = buf
+    return buf
+
+
+def _tdt(dtype):
+    return ops.torch_dtype(dtype)
+
+
+def _pad_cols(t, ld, dtype):
+    """[M, C] (any float dtype) -> compute dtype [M, ld], zero padded."""
+    if t.shape[1] == ld and t.dtype == _tdt(dtype):
+        return t.contiguous()
+    out = torch.zeros(t.shape[0], ld, dtype=_tdt(dtype), device=t.device)
+    out[:, :t.shape[1]] = t
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+class _ConvFn(torch.autograd.Function):
+    """y = act(conv(x, w) + bias).  ``x`` is the CL tensor [M, ld] (or None with ``meta['src']`` an fp32 image)."""
+
+    @staticmethod
+    def forward(ctx, x_t, w, bias, meta):
+        dt = meta["dtype"]
+        w5 = w.detach().unsqueeze(2) if w.dim() == 4 else w.detach()
+        wop, kc = K.weight_operand(w5, dt, meta["transposed"])
+        b = None if bias is None else bias.detach().float().contiguous()
+        src = meta.get("src")
+        x = None if src is not None else K.CL(x_t, meta["N"], meta["dhw"], meta["cin"])
+        y = K.conv(x, wop, kc, meta["cout"], meta["k"], meta["stride"], meta["pad"], dt, bias=b, act=meta["act"],
+                   transposed=meta["transposed"], out_pad=meta["out_pad"], out_f32=meta.get("out_f32", False), src_f32=src)
+        meta["odhw"] = y.dhw
+        ctx.meta = meta
+        ctx.save_for_backward(x_t, w, y.t if meta["act"] != _lib.ACT_NONE else None)
+        ctx.has_bias = bias is not None
+        return y.t
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_t, w, y_t = ctx.saved_tensors
+        m = ctx.meta
+        dt = m["dtype"]
+        e16 = K.e16(dt)
+        N, cin, cout, k, st, pd = m["N"], m["cin"], m["cout"], m["k"], m["stride"], m["pad"]
+        idhw, odhw = m["dhw"], m["odhw"]
+        M = dy.shape[0]
+        ldg = K.round_up(cout, e16)
+        lib = _lib.lib()
+        s = _lib.current_stream()
+        if m["act"] != _lib.ACT_NONE:
+            if m.get("out_f32", False):
+                raise RuntimeError("fused activation on an fp32 output has no backward here (the loss kernel owns tanh)")
+            g = torch.empty(M, ldg, dtype=_tdt(dt), device=dy.device)
+            dyc = dy.contiguous()
+            check(lib.ipoke_act_bwd(ptr(dyc), dyc.shape[1], ptr(y_t), y_t.shape[1], ptr(g), ldg, M, cout, ldg, m["act"],
+                                    ops._dt(dt), s))
+        else:
+            g = _pad_cols(dy, ldg, dt) if (dy.dtype != _tdt(dt) or dy.shape[1] != ldg) else dy.contiguous()
+        d_bias = None
+        if ctx.has_bias:
+            d_bias = torch.empty(cout, dtype=torch.float32, device=dy.device)
+            ws = _workspace(lib.ipoke_colsum_workspace_floats(M, cout), dy.device, "colsum")
+            check(lib.ipoke_colsum(ptr(g), ldg, M, cout, 0, ptr(d_bias), 0, ptr(ws), ops._dt(dt), s))
+        # ---- weight gradient, PyTorch layout
+        taps = k[0] * k[1] * k[2]
+        d_w = torch.empty(w.shape, dtype=torch.float32, device=dy.device)
+        wd = WgradDesc()
+        wd.kd, wd.kh, wd.kw = k
+        wd.sd, wd.sh, wd.sw = st
+        wd.pd, wd.ph, wd.pw = pd
+        wd.NB = N
+        src = m.get("src")
+        if not m["transposed"]:
+            wd.Di, wd.Hi, wd.Wi = idhw
+            wd.Do, wd.Ho, wd.Wo = odhw
+            if src is not None:
+                t_src, _, _, _, sst = src
+                wd.A = t_src.data_ptr(); wd.a_f32 = 1
+                wd.a_sn, wd.a_sc, wd.a_sd, wd.a_sh, wd.a_sw = sst
+                wd.Kc_real = cin; wd.Kc = K.round_up(cin, e16)
+            else:
+                ld = x_t.shape[1]
+                wd.A = x_t.data_ptr(); wd.a_f32 = 0
+                wd.a_sn = idhw[0] * idhw[1] * idhw[2] * ld; wd.a_sd = idhw[1] * idhw[2] * ld; wd.a_sh = idhw[2] * ld
+                wd.a_sw = ld; wd.a_sc = 1
+                wd.Kc_real = K.round_up(cin, e16); wd.Kc = wd.Kc_real
+            wd.Kc_store = cin
+            wd.dY = g.data_ptr(); wd.ldy = ldg; wd.Nout = cout
+            wd.w_sn = cin * taps; wd.w_sc = taps; wd.w_st = 1
+        else:
+            # ConvTranspose y = C_W^T x: dW[in][out][tap] is the weight gradient of the direct conv with "input" dy, "output" x
+            ld = x_t.shape[1]
+            wd.Di, wd.Hi, wd.Wi = odhw
+            wd.Do, wd.Ho, wd.Wo = idhw
+            wd.A = g.data_ptr(); wd.a_f32 = 0
+            wd.a_sn = odhw[0] * odhw[1] * odhw[2] * ldg; wd.a_sd = odhw[1] * odhw[2] * ldg; wd.a_sh = odhw[2] * ldg
+            wd.a_sw = ldg; wd.a_sc = 1
+            wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = cout
+            wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
+            wd.w_sn = cout * taps; wd.w_sc = taps; wd.w_st = 1
+        wd.dW = d_w.data_ptr()
+        check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+        # ---- data gradient: the adjoint convolution with the same weights
+        d_x = None
+        if x_t is not None and ctx.needs_input_grad[0]:
+            w5 = w.detach().unsqueeze(2) if w.dim() == 4 else w.detach()
+            gcl = K.CL(g, N, odhw, cout)
+            if not m["transposed"]:
+                # conv weight [cout, cin, k] read as a ConvTranspose weight [in=cout, out=cin, k]
+                wop, kc = K.weight_operand(w5, dt, transposed_conv=True)
+                opad = tuple(i - ((o - 1) * s_ - 2 * p + kk) for i, o, s_, p, kk in zip(idhw, odhw, st, pd, k))
+                dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt, transposed=True, out_pad=opad)
+            else:
+                wop, kc = K.weight_operand(w5, dt, transposed_conv=False)     # [in, out, k] read as conv weight [cout'=in]
+                dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt)
+            assert dx.dhw == tuple(idhw), (dx.dhw, idhw)
+            d_x = dx.t
+            if d_x.shape[1] != x_t.shape[1]:
+                d_x = _pad_cols(d_x[:, :min(d_x.shape[1], x_t.shape[1])], x_t.shape[1], dt)
+        return d_x, d_w, d_bias, None
+
+
+def conv(mod, x, dtype, act=_lib.ACT_NONE, out_f32=False, src=None, w=None):
+    """Differentiable ``_Conv.run``.  ``x``: CL (or None with ``src``); returns CL."""
+    if w is None:
+        w = effective_weight(mod)
+    N, dhw, cin = (src[1], src[3], src[2]) if src is not None else (x.N, x.dhw, x.C)
+    meta = dict(N=N, dhw=tuple(dhw), cin=cin, cout=mod.cout, k=mod.k, stride=mod.stride, pad=mod.pad, transposed=mod.transposed,
+                out_pad=(0, mod.pad[1], mod.pad[2]) if mod.transposed else (0, 0, 0), dtype=dtype, act=act, out_f32=out_f32, src=src)
+    y = _ConvFn.apply(None if src is not None else x.t, w, mod.bias, meta)
+    return K.CL(y, N, meta["odhw"], mod.cout)
+
+
+def effective_weight(mod, power_iteration=False):
+    """Conv weight as an autograd tensor: plain ``weight`` or ``weight_orig / sigma`` (torch spectral_norm semantics:
+    u, v are buffers updated without grad by one power iteration per call in train mode; sigma = u^T W v carries grad)."""
+    if not mod.snorm:
+        return mod.weight
+    w = mod.weight_orig
+    wm = (w.transpose(0, 1) if mod.transposed else w).reshape(mod.cout, -1)
+    if power_iteration:
+        with torch.no_grad():
+            mod.weight_v.copy_(F.normalize(torch.mv(wm.t(), mod.weight_u), dim=0, eps=1e-12))
+            mod.weight_u.copy_(F.normalize(torch.mv(wm, mod.weight_v), dim=0, eps=1e-12))
+    u, v = mod.weight_u.clone(), mod.weight_v.clone()
+    sigma = torch.dot(u, torch.mv(wm, v))
+    return w / sigma
+
+
+# ------------------------------------------------------------------------------------------------ norms
+class _NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_t, gamma, beta, mg_t, mb_t, res_t, meta):
+        dt = meta["dtype"]
+        N, S, C, G = meta["N"], meta["S"], meta["C"], meta["G"]
+        y = torch.empty_like(x_t)
+        d = NormDesc()
+        d.x = x_t.data_ptr(); d.ldx = x_t.shape[1]; d.y = y.data_ptr(); d.ldy = y.shape[1]; d.y_f32 = 0
+        d.N, d.S, d.C, d.G, d.eps = N, S, C, G, 1e-5
+        g32 = b32 = None
+        if gamma is not None:
+            g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+            d.gamma = g32.data_ptr(); d.beta = b32.data_ptr()
+        if mg_t is not None:
+            d.mod_gamma = mg_t.data_ptr(); d.mod_beta = mb_t.data_ptr(); d.ld_mod = mg_t.shape[1]
+        if res_t is not None:
+            d.res = res_t.data_ptr(); d.ld_res = res_t.shape[1]
+        d.act = meta["act"]
+        ws = _workspace(_lib.lib().ipoke_groupnorm_workspace_floats(N, S, G), x_t.device, "norm")
+        d.workspace = ws.data_ptr()
+        check(_lib.lib().ipoke_groupnorm(byref(d), ops._dt(dt), _lib.current_stream()))
+        if y.shape[1] > C:
+            y[:, C:].zero_()
+        ctx.meta = meta
+        ctx.save_for_backward(x_t, y, g32, b32, mg_t)
+        ctx.has = (gamma is not None, mg_t is not None, res_t is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_t, y, g32, b32, mg_t = ctx.saved_tensors
+        m = ctx.meta
+        dt = m["dtype"]
+        N, S, C, G = m["N"], m["S"], m["C"], m["G"]
+        has_affine, has_mod, has_res = ctx.has
+        dy = dy.contiguous()
+        dx = torch.zeros_like(x_t) if x_t.shape[1] > C else torch.empty_like(x_t)
+        d = NormBwdDesc()
+        d.x = x_t.data_ptr(); d.ldx = x_t.shape[1]; d.y = y.data_ptr(); d.ldy = y.shape[1]
+        d.dy = dy.data_ptr(); d.lddy = dy.shape[1]; d.dx = dx.data_ptr(); d.lddx = dx.shape[1]
+        d.N, d.S, d.C, d.G, d.eps = N, S, C, G, 1e-5
+        d.act = m["act"]
+        dres = dmg = dmb = dgamma = dbeta = None
+        if has_res:
+            dres = torch.zeros_like(x_t) if x_t.shape[1] > C else torch.empty_like(x_t)
+            d.dres = dres.data_ptr(); d.lddres = dres.shape[1]
+        if has_mod:
+            dmg = torch.zeros_like(mg_t); dmb = torch.zeros_like(mg_t)
+            d.dmod_gamma = dmg.data_ptr(); d.dmod_beta = dmb.data_ptr(); d.ld_dmod = dmg.shape[1]
+            d.mod_gamma = mg_t.data_ptr(); d.ld_mod = mg_t.shape[1]
+        if has_affine:
+            dgamma = torch.empty(C, dtype=torch.float32, device=dy.device); dbeta = torch.empty_like(dgamma)
+            d.gamma = g32.data_ptr(); d.beta = b32.data_ptr(); d.dgamma = dgamma.data_ptr(); d.dbeta = dbeta.data_ptr()
+        ws = _workspace(_lib.lib().ipoke_groupnorm_bwd_workspace_floats(N, S, C, G), dy.device, "normbwd")
+        d.workspace = ws.data_ptr()
+        check(_lib.lib().ipoke_groupnorm_bwd(byref(d), ops._dt(dt), _lib.current_stream()))
+        return dx, dgamma, dbeta, dmg, dmb, dres, None
+
+
+def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None):
+    meta = dict(N=x.N, S=x.S, C=x.C, G=groups, dtype=dtype, act=act)
+    y = _NormFn.apply(x.t, gamma, beta, None if mod is None else mod[0].t, None if mod is None else mod[1].t,
+                      None if res is None else res.t, meta)
+    return K.CL(y, x.N, x.dhw, x.C)
+
+
+def norm(mod, x, dtype, act=_lib.ACT_NONE, res=None):
+    if mod.kind == "group":
+        return group_norm(x, mod.groups, dtype, mod.weight, mod.bias, act=act, res=res)
+    return group_norm(x, mod.groups, dtype, act=act, res=res)
+
+
+class _AddActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a_t, b_t, C, act, dtype):
+        y = torch.zeros_like(a_t) if a_t.shape[1] > C else torch.empty_like(a_t)
+        check(_lib.lib().ipoke_add_act(ptr(a_t), a_t.shape[1], ptr(b_t), b_t.shape[1], ptr(y), y.shape[1], a_t.shape[0], C, act,
+                                       ops._dt(dtype), _lib.current_stream()))
+        ctx.save_for_backward(y)
+        ctx.args = (C, act, dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        C, act, dtype = ctx.args
+        if act == _lib.ACT_NONE:
+            return dy, dy, None, None, None
+        dy = dy.contiguous()
+        g = torch.empty_like(y)
+        check(_lib.lib().ipoke_act_bwd(ptr(dy), dy.shape[1], ptr(y), y.shape[1], ptr(g), g.shape[1], y.shape[0], C, y.shape[1], act,
+                                       ops._dt(dtype), _lib.current_stream()))
+        return g, g, None, None, None
+
+
+def add_act(a, b, dtype, act):
+    return K.CL(_AddActFn.apply(a.t, b.t, a.C, act, dtype), a.N, a.dhw, a.C)
+
+
+# ------------------------------------------------------------------------------------------------ ConvGRU
+class _GruGatesFn(torch.autograd.Function):
+    """(ur_pre [M,2Ch], h [M,ldh]) -> (h*sigmoid(r), sigmoid(u))"""
+
+    @staticmethod
+    def forward(ctx, ur_t, h_t, Ch, dtype):
+        M = ur_t.shape[0]
+        hr = torch.empty(M, Ch, dtype=ur_t.dtype, device=ur_t.device)
+        u = torch.empty(M, Ch, dtype=ur_t.dtype, device=ur_t.device)
+        check(_lib.lib().ipoke_gru_gates(ptr(ur_t), ptr(h_t), h_t.shape[1], ptr(hr), Ch, ptr(u), M, Ch, ops._dt(dtype),
+                                         _lib.current_stream()))
+        ctx.save_for_backward(ur_t, h_t)
+        ctx.args = (Ch, dtype)
+        return hr, u
+
+    @staticmethod
+    def backward(ctx, d_hr, d_u):
+        ur_t, h_t = ctx.saved_tensors
+        Ch, dtype = ctx.args
+        M = ur_t.shape[0]
+        d_hr = d_hr.contiguous(); d_u = d_u.contiguous()
+        d_ur = torch.zeros_like(ur_t)
+        d_h = torch.zeros_like(h_t)
+        check(_lib.lib().ipoke_gru_gates_bwd(ptr(ur_t), ptr(h_t), h_t.shape[1], ptr(d_hr), d_hr.shape[1], ptr(d_u), ptr(d_ur),
+                                             ptr(d_h), d_h.shape[1], M, Ch, ops._dt(dtype), _lib.current_stream()))
+        return d_ur, d_h, None, None
+
+
+class _GruUpdateFn(torch.autograd.Function):
+    """(o_pre [M,Ch..], u [M,Ch], h) -> h*(1-u) + tanh(o_pre)*u"""
+
+    @staticmethod
+    def forward(ctx, o_t, u_t, h_t, Ch, dtype):
+        M = o_t.shape[0]
+        o_c = o_t[:, :Ch].contiguous()
+        hn = torch.empty(M, Ch, dtype=o_t.dtype, device=o_t.device)
+        check(_lib.lib().ipoke_gru_update(ptr(o_c), ptr(u_t), ptr(h_t), h_t.shape[1], ptr(hn), Ch, M, Ch, ops._dt(dtype),
+                                          _lib.current_stream()))
+        ctx.save_for_backward(o_c, u_t, h_t)
+        ctx.args = (Ch, dtype, o_t.shape[1])
+        return hn
+
+    @staticmethod
+    def backward(ctx, d_hn):
+        o_c, u_t, h_t = ctx.saved_tensors
+        Ch, dtype, ldo = ctx.args
+        M = o_c.shape[0]
+        d_hn = d_hn.contiguous()
+        d_o = torch.empty_like(o_c); d_u = torch.empty_like(u_t); d_h = torch.zeros_like(h_t)
+        check(_lib.lib().ipoke_gru_update_bwd(ptr(o_c), ptr(u_t), ptr(h_t), h_t.shape[1], ptr(d_hn), d_hn.shape[1], ptr(d_o), ptr(d_u),
+                                              ptr(d_h), d_h.shape[1], M, Ch, ops._dt(dtype), _lib.current_stream()))
+        if ldo != Ch:
+            d_o = _pad_cols(d_o, ldo, dtype)
+        return d_o, d_u, d_h, None, None
+
+
+def gru_cell(cell, x, h, dtype):
+    """ConvGRUCell.run with gradients (rnn.py:48-56)."""
+    Ch = cell.hidden
+    xh = torch.cat([x.t[:, :x.C], h.t[:, :Ch]], dim=1)
+    xh_cl = K.CL(xh, x.N, x.dhw, x.C + Ch)
+    # update and reset gates share their input: one GEMM with the concatenated weights (update first)
+    w_ur = torch.cat([cell.update_gate.weight, cell.reset_gate.weight], 0)
+    b_ur = torch.cat([cell.update_gate.bias, cell.reset_gate.bias])
+    meta = dict(N=x.N, dhw=tuple(x.dhw), cin=x.C + Ch, cout=2 * Ch, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), transposed=False,
+                out_pad=(0, 0, 0), dtype=dtype, act=_lib.ACT_NONE, out_f32=False, src=None)
+    ur = _ConvFn.apply(xh, w_ur, b_ur, meta)
+    hr, u = _GruGatesFn.apply(ur[:, :2 * Ch].contiguous(), h.t, Ch, dtype)
+    xhr = torch.cat([x.t[:, :x.C], hr], dim=1)
+    o = conv(cell.out_gate, K.CL(xhr, x.N, x.dhw, x.C + Ch), dtype)
+    hn = _GruUpdateFn.apply(o.t, u, h.t, Ch, dtype)
+    return K.CL(hn, x.N, x.dhw, Ch)
+
+
+# ------------------------------------------------------------------------------------------------ latent
+class _ReparamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mulv_t, eps_s, Z, dtype):
+        M = mulv_t.shape[0]
+        z = torch.empty(M, Z, device=mulv_t.device); mu = torch.empty_like(z); lv = torch.empty_like(z)
+        check(_lib.lib().ipoke_reparameterize(ptr(mulv_t), mulv_t.shape[1], ptr(eps_s), ptr(z), ptr(mu), ptr(lv), M, Z,
+                                              ops._dt(dtype), _lib.current_stream()))
+        ctx.save_for_backward(mulv_t, eps_s)
+        ctx.args = (Z, dtype)
+        return z, mu, lv
+
+    @staticmethod
+    def backward(ctx, dz, dmu, dlv):
+        mulv_t, eps_s = ctx.saved_tensors
+        Z, dtype = ctx.args
+        M = mulv_t.shape[0]
+        out = torch.empty_like(mulv_t)
+        cz = lambda t: None if t is None else t.contiguous().float()
+        dz, dmu, dlv = cz(dz), cz(dmu), cz(dlv)
+        check(_lib.lib().ipoke_reparam_bwd(ptr(mulv_t), mulv_t.shape[1], ptr(eps_s), ptr(dz), ptr(dmu), ptr(dlv), ptr(out),
+                                           out.shape[1], M, Z, ops._dt(dtype), _lib.current_stream()))
+        return out, None, None, None
+
+
+class _L1TanhFn(torch.autograd.Function):
+    """frame = tanh(pre) ; returns (sum_scale |frame - x|, frame) with d/dpre produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, pre_t, x_nchw, scale):
+        N, C, H, W = x_nchw.shape
+        S = H * W
+        frame = torch.tanh(pre_t)                                     # [M, C] fp32: the returned reconstruction
+        loss = torch.zeros(1, device=pre_t.device)
+        grad = torch.empty_like(pre_t)
+        assert x_nchw.stride(1) == S and x_nchw.stride(2) == W and x_nchw.stride(3) == 1
+        check(_lib.lib().ipoke_l1_loss(ptr(frame), frame.shape[1], ptr(x_nchw), N, C, S, x_nchw.stride(0), float(scale), ptr(loss),
+                                       ptr(grad), grad.shape[1], _lib.current_stream()))
+        ctx.save_for_backward(grad, frame)
+        return loss[0], frame
+
+    @staticmethod
+    def backward(ctx, d_loss, d_frame):
+        grad, frame = ctx.saved_tensors
+        g = grad * (1.0 - frame * frame) * d_loss
+        return g, None, None
+
+
+# ------------------------------------------------------------------------------------------------ model pieces
+def basic_block(blk, x, dtype):
+    out = norm(blk.bn1, conv(blk.conv1, x, dtype), dtype, act=_lib.ACT_RELU)
+    res = x if blk.downsample is None else norm(blk.downsample[1], conv(blk.downsample[0], x, dtype), dtype)
+    return norm(blk.bn2, conv(blk.conv2, out, dtype), dtype, act=_lib.ACT_RELU, res=res)
+
+
+def encode(enc, x, eps):
+    """ResNetMotionEncoder.forward with gradients: x [B,3,T,H,W] fp32 -> (z, mu, logvar) as [M, Z] fp32 rows."""
+    dt = enc.dtype
+    B, C, T, H, W = x.shape
+    st = (x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4))
+    h = conv(enc.conv1, None, dt, src=(x, B, C, (T, H, W), st))
+    h = norm(enc.bn1, h, dt, act=_lib.ACT_RELU)
+    layers = [enc.layer1, enc.layer2, enc.layer3] + ([enc.layer4] if enc.stride4 is not None else []) + ([enc.layer5] if enc.has5 else [])
+    for layer in layers:
+        for blk in layer:
+            h = basic_block(blk, h, dt)
+    if h.dhw[0] != 1:
+        raise ValueError("temporal extent after the encoder must be 1")
+    w_head = torch.cat([enc.conv_mu.weight, enc.conv_var.weight], 0)
+    b_head = torch.cat([enc.conv_mu.bias, enc.conv_var.bias])
+    meta = dict(N=B, dhw=tuple(h.dhw), cin=h.C, cout=2 * enc.z_dim, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), transposed=False,
+                out_pad=(0, 0, 0), dtype=dt, act=_lib.ACT_NONE, out_f32=False, src=None)
+    mulv = _ConvFn.apply(h.t, w_head, b_head, meta)
+    eps_s = ops.to_state(eps)
+    z, mu, lv = _ReparamFn.apply(mulv, eps_s, enc.z_dim, dt)
+    return z, mu, lv, h.dhw
+
+
+def conv_block(blk, x, dtype, res=None, out_f32=False, pit=False):
+    w = effective_weight(blk.conv, pit)
+    if blk.norm is None:
+        act = FS.ACT[blk.activation] if res is None else _lib.ACT_NONE
+        if out_f32:
+            act = _lib.ACT_NONE             # the loss kernel applies tanh
+        y = conv(blk.conv, x, dtype, act=act, out_f32=out_f32, w=w)
+        return y if res is None else add_act(y, res, dtype, FS.ACT[blk.activation])
+    return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=FS.ACT[blk.activation], res=res)
+
+
+def convT_block(blk, x, dtype, pit=False):
+    w = effective_weight(blk.conv, pit)
+    if blk.norm is None:
+        return conv(blk.conv, x, dtype, act=blk.act, w=w)
+    return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=blk.act)
+
+
+def res_block(blk, x, dtype, pit=False):
+    first = convT_block if isinstance(blk.conv1, FS.Conv2dTransposeBlock) else conv_block
+    if blk.convolve_res:
+        rfirst = convT_block if isinstance(blk.res_conv, FS.Conv2dTransposeBlock) else conv_block
+        res = rfirst(blk.res_conv, x, dtype, pit=pit)
+    else:
+        res = x
+    return conv_block(blk.conv2, first(blk.conv1, x, dtype, pit=pit), dtype, res=res, pit=pit)
+
+
+def spade_modulation(sp, y_nchw, size, dtype):
+    N = y_nchw.shape[0]
+    ycl = K.bilinear_cl(y_nchw, size)
+    st = (size[0] * size[1] * 3, 1, 0, size[1] * 3, 3)
+    h = conv(sp.conv, None, dtype, act=_lib.ACT_LRELU02, src=(ycl, N, 3, (1, size[0], size[1]), st))
+    return conv(sp.conv_gamma, h, dtype), conv(sp.conv_beta, h, dtype)
+
+
+def decode_frame(gen, h, start_frame, dtype, pit):
+    """SpadeCondConvDecoder.forward for one frame; returns the pre-tanh output [M, 3] fp32 (CL)."""
+    x = res_block(gen.in_block, h, dtype, pit=pit)
+    size = 8
+    for blk, sp in zip(gen.blocks, gen.spade_blocks):
+        x = res_block(blk, x, dtype, pit=pit)
+        size *= 2
+        mod = spade_modulation(sp, start_frame, (size, size), dtype)       # recomputed per frame as in the reference
+        x = group_norm(x, sp.groups, dtype, mod=mod)
+    return conv_block(gen.out_conv, x, dtype, out_f32=True)
+
+
+def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteration=None):
+    """One differentiable pass of SpadeCondMotionModel + the L1 / KL loss terms.  Returns (loss, X_hat, mu, logvar)."""
+    _lib.require_gpu()
+    dt = model.dtype
+    pit = model.training if power_iteration is None else bool(power_iteration)
+    B, T = X.shape[0], X.shape[1]
+    X = X.float().contiguous()
+    X_in = X if model.full_sequence else X[:, 1:]
+    z, mu, lv, dhw = encode(model.enc_motion, X_in.transpose(1, 2), eps)
+    Z = model.enc_motion.z_dim
+    m = K.CL(_pad_cols(z, K.round_up(Z, K.e16(dt)), dt), B, dhw, Z)
+    hidden = [m] * model.n_layers
+    if model.use_motion_bias:
+        mb = model.motion_bias.expand(B, -1, -1, -1).permute(0, 2, 3, 1).reshape(-1, Z)
+        in_rnn = K.CL(_pad_cols(mb, K.round_up(Z, K.e16(dt)), dt), B, dhw, Z)
+    else:
+        in_rnn = m
+    x0 = X[:, 0].contiguous()
+    n_out = B * (T - 1) * 3 * X.shape[-1] * X.shape[-2]
+    l1 = 0.0
+    frames = []
+    for t in range(T - 1):
+        xin = in_rnn
+        new_hidden = []
+        for cell, h in zip(model.rnn.cells, hidden):
+            xin = gru_cell(cell, xin, h, dt)
+            new_hidden.append(xin)
+        hidden = new_hidden
+        pre = decode_frame(model.gen, hidden[-1], x0, dt, pit)
+        lt, frame = _L1TanhFn.apply(pre.t, X[:, t + 1], 1.0 / n_out)
+        l1 = l1 + lt
+        frames.append(frame.view(B, pre.dhw[1], pre.dhw[2], 3).permute(0, 3, 1, 2))
+    mu4 = mu.view(B, dhw[1], dhw[2], Z).permute(0, 3, 1, 2)
+    lv4 = lv.view(B, dhw[1], dhw[2], Z).permute(0, 3, 1, 2)
+    kl = -0.5 * torch.mean(torch.sum(1 + lv4 - mu4.pow(2) - lv4.exp(), dim=1))          # utils/losses.py:47-48
+    loss = w_l1 * l1 + w_kl * kl
+    return loss, torch.stack(frames, dim=1), mu4, lv4
+
+
+class FirstStageTrainer:
+    """Minimal training harness of c4: ``step(X)`` = forward, L1 + KL loss, backward, Adam step (the reference's
+    first-stage optimiser is ``Adam(lr, betas=(0.5, 0.9))`` over encoder + GRU + decoder, first_stage_motion_model.py:283-300)."""
+
+    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5):
+        self.model = model
+        self.opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr, betas=betas, weight_decay=weight_decay)
+        self.grad_hook = None           # data parallel: all-reduce of the gradients between backward and the update
+
+    def step(self, X, eps=None):
+        m = self.model
+        m.train()
+        if eps is None:
+            Z = m.enc_motion.z_dim
+            s = m.enc_motion.min_ssize
+            eps = torch.FloatTensor(X.shape[0], Z, s, s).normal_().to(X.device)      # CPU generator, motion_encoder.py:220
+        self.opt.zero_grad(set_to_none=True)
+        loss, X_hat, mu, lv = first_stage_forward_loss(m, X, eps)
+        loss.backward()
+        if self.grad_hook is not None:
+            self.grad_hook()
+        self.opt.step()
+        m.invalidate_operands()
+        return loss.detach(), X_hat.detach()

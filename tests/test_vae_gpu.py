@@ -94,3 +94,80 @@ def test_glue_make_flow_input(golden, dtype):
     e2 = (z.cpu() - t(g["flow_input"])).abs().max().item()
     print(f"glue[{dtype}] cond err {e1:.3e} flow_input err {e2:.3e}")
     assert e1 <= TOL[dtype] * 2 and e2 <= TOL[dtype]
+
+
+# ---------------------------------------------------------------------------------------------- first-stage training (a18 / c4)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_first_stage_train_slice(golden, dtype):
+    """Forward + L1/KL loss + backward of the whole VAE on the HIP kernels against the reference's autograd
+    (goldens: X_hat, loss and checksums of all 125 parameter gradients; eval-mode spectral norm as in the fixture)."""
+    g = golden("g5_first_stage_train_64")
+    m = first_stage(64, 32, 4, dtype)
+    X, eps = t(g["X"], "cuda"), t(g["eps"], "cuda")
+    loss, X_hat, mu, lv = m.training_loss(X, eps, power_iteration=False)
+    loss.backward()
+    err_x = (X_hat.detach().cpu() - t(g["X_hat"])).abs().max().item()
+    err_l = abs(loss.item() - float(g["loss"]))
+    print(f"first-stage train[{dtype}] X_hat err {err_x:.3e} loss {loss.item():.6f} (ref {float(g['loss']):.6f})")
+    assert err_x <= (TOL["f32"] if dtype == "f32" else 0.12)
+    assert err_l <= (2e-4 if dtype == "f32" else 5e-2) * max(1.0, abs(float(g["loss"])))
+    assert (mu.detach().cpu() - t(g["mu"])).abs().max().item() <= TOL[dtype]
+    params = dict(m.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    assert set(names) == {k for k, p in params.items() if p.grad is not None}
+    import zlib
+    worst = 0.0
+    bad = []
+    for k, ck in zip(names, g["grad_checksums"]):
+        gr = params[k].grad.detach().double().flatten().cpu()
+        idx = torch.randint(0, gr.numel(), (3,), generator=torch.Generator().manual_seed(zlib.crc32(k.encode())))
+        ref_sum, ref_abs = ck[0], ck[1]
+        scale = max(ref_abs, 1e-12)
+        e_sum = abs(gr.sum().item() - ref_sum) / scale
+        e_abs = abs(gr.abs().sum().item() - ref_abs) / scale
+        e_smp = max(abs(gr[i].item() - r) for i, r in zip(idx.tolist(), ck[2:])) / max(gr.abs().max().item(), 1e-12)
+        # sums: 2e-3 (f32) -- the L1 sub-gradient sign(x_hat - x) flips for pixels whose residual is below the forward
+        # error, which perturbs every upstream gradient at the 1e-3 level; single sampled elements see it undamped
+        tol, tol_smp = (2e-3, 1.5e-2) if dtype == "f32" else (0.25, 0.35)
+        # a bias in front of an Instance/GroupNorm has an analytically zero gradient: what both sides hold is rounding
+        # noise of the cancellation, compared on the scale of the layer's weight gradient instead
+        noise = ref_abs <= 1e-4 * g["grad_checksums"][names.index(k.replace(".bias", ".weight_orig"))][1] if (
+            k.endswith(".bias") and k.replace(".bias", ".weight_orig") in names) else False
+        if noise:
+            wabs = g["grad_checksums"][names.index(k.replace(".bias", ".weight_orig"))][1]
+            assert gr.abs().sum().item() <= 1e-3 * wabs, (k, gr.abs().sum().item(), wabs)
+            continue
+        worst = max(worst, e_sum, e_abs, e_smp)
+        if not (e_sum <= tol and e_abs <= tol and e_smp <= tol_smp):
+            bad.append((k, float(e_sum), float(e_abs), float(e_smp), float(ref_abs)))
+    print(f"first-stage train[{dtype}] worst relative gradient checksum error {worst:.3e}")
+    for b in bad:
+        print("   BAD", b)
+    assert not bad
+
+
+def test_first_stage_train_power_iteration(golden):
+    """Train-mode spectral norm: one power iteration per forward call (g5_spectral_train pins u1, v1 and the output)."""
+    from ipoke_amd import first_stage_train as FT, nn as K
+    g = golden("g5_spectral_train")
+    m = first_stage(64, 32, 16, "f32")
+    blk = m.gen.blocks[0].conv1
+    with torch.no_grad():
+        blk.conv.weight_u.copy_(t(g["u0"], "cuda")); blk.conv.weight_v.copy_(t(g["v0"], "cuda"))
+    x = K.from_nchw(t(g["x"], "cuda"), "f32")
+    y = FT.convT_block(blk, x, "f32", pit=True)
+    assert (blk.conv.weight_u.cpu() - t(g["u1"])).abs().max().item() <= 1e-5
+    assert (blk.conv.weight_v.cpu() - t(g["v1"])).abs().max().item() <= 1e-5
+    got = K.to_nchw(y, "f32").cpu()
+    assert (got - t(g["y"])).abs().max().item() <= 2e-4 * max(1.0, float(np.abs(g["y"]).max()))
+
+
+def test_first_stage_trainer_step_decreases_loss():
+    from ipoke_amd.first_stage_train import FirstStageTrainer
+    m = first_stage(64, 32, 4, "bf16")
+    tr = FirstStageTrainer(m, lr=2e-4)
+    X = torch.rand(2, 4, 3, 64, 64, generator=torch.Generator().manual_seed(3)).cuda() * 2 - 1
+    eps = torch.randn(2, 32, 8, 8, generator=torch.Generator().manual_seed(4)).cuda()
+    losses = [tr.step(X, eps)[0].item() for _ in range(4)]
+    print("first-stage trainer losses", losses)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
