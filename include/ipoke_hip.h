@@ -98,6 +98,8 @@ typedef struct {
   int32_t accumulate;                    /* 1: dW += */
   int32_t splitm;                        /* >1: reduction split over gridDim.y with fp32 atomics (dW must be pre-zeroed or accumulate) */
   int32_t Kc_store;                      /* channels per tap written to dW (0: Kc_real); < Kc_real when A carries zero padding */
+  int64_t split_stride;                  /* with splitm > 1: != 0 -> slice z of the reduction is *stored* to dW + z*split_stride
+                                            (deterministic; the caller sums the splitm slabs, e.g. ipoke_reduce_rows), 0 -> atomics */
 } ipoke_wgrad_desc;
 
 int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream);

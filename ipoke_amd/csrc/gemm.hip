@@ -46,6 +46,7 @@ struct TnParams {
   float* dW; long w_sn, w_sc, w_st; int accumulate;
   int splitm, mb_per_split, rows_fixed, Kc_store;
   int tiles_n, tiles_k;
+  long split_stride;   // > 0: split z stores its slab at dW + z*split_stride instead of atomics
   int ablate;          // developer experiment (IPOKE_TN_ABLATE): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
 };
 
@@ -790,12 +791,12 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
       const int k = k0 + wn * 64 + j * 16 + (lane >> 4) * 4;
       if (k >= p.Ktot) continue;
       const int tap = k / p.Kc, c = k - tap * p.Kc;     // 4 consecutive k share the tap (Kc % 4 == 0)
-      float* base = p.dW + (long)n * p.w_sn + (long)tap * p.w_st;
+      float* base = p.dW + (long)n * p.w_sn + (long)tap * p.w_st + (p.split_stride > 0 ? (long)z * p.split_stride : 0L);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (c + r < p.Kc_store) {
           float* q = base + (long)(c + r) * p.w_sc;
-          if (p.splitm > 1) atomicAdd(q, acc[i][j][r]);
+          if (p.splitm > 1 && p.split_stride == 0) atomicAdd(q, acc[i][j][r]);
           else *q = p.accumulate ? *q + acc[i][j][r] : acc[i][j][r];
         }
       }
@@ -1027,6 +1028,8 @@ static int fill_tn(TnParams& p, const ipoke_wgrad_desc* d, int dtype, bool batch
   p.dY = d->dY; p.ldy = d->ldy; p.y_coff = d->y_coff; p.Nout = d->Nout; p.Ktot = p.g.taps * d->Kc;
   p.dW = d->dW; p.w_sn = d->w_sn; p.w_sc = d->w_sc; p.w_st = d->w_st; p.accumulate = d->accumulate;
   p.splitm = d->splitm < 1 ? 1 : d->splitm;
+  p.split_stride = d->split_stride;
+  IPK_REQUIRE(p.split_stride >= 0 && !(p.split_stride > 0 && d->accumulate), "split slabs are stored, not accumulated");
   p.Kc_store = d->Kc_store > 0 ? d->Kc_store : d->Kc_real;
   IPK_REQUIRE(p.Kc_store <= d->Kc_real, "Kc_store exceeds Kc_real");
   return IPOKE_OK;

@@ -28,32 +28,50 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __re
   }
 }
 
-// column sums of a T (or fp32) matrix: part[blk][C] per block of rows, then a second pass over blocks
+// column sums of a T (or fp32) matrix: part[blk][C] per block of rows, then a second pass over blocks.
+// 16-byte loads: thread (rr, cg) owns the E16 columns of group cg over rows rr, rr + rows_par, ...
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ src, int ld, long M, int C, int rows_per_block,
                                                           float* __restrict__ part) {
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  // thread t owns column t % C over rows (t / C), stepping blockDim/C rows
-  extern __shared__ float sm[];          // [rows_par][C]
-  const int rows_par = blockDim.x / C > 0 ? blockDim.x / C : 1;
-  for (int c0 = 0; c0 < C; c0 += blockDim.x) {       // C > blockDim: several column passes
-    const int cols = C - c0 < (int)blockDim.x ? C - c0 : (int)blockDim.x;
-    const int rp = blockDim.x / cols > 0 ? blockDim.x / cols : 1;
-    const int c = threadIdx.x % cols, rr = threadIdx.x / cols;
-    float acc = 0.f;
-    if (rr < rp)
-      for (long r = r0 + rr; r < r1; r += rp) acc += ET<T>::to_f32(src[r * ld + c0 + c]);
-    sm[threadIdx.x] = (rr < rp) ? acc : 0.f;
+  __shared__ float sm[256 * 8];
+  const int ngroups = (C + E16 - 1) / E16;                       // ld >= ngroups*E16 (host-checked)
+  for (int g0 = 0; g0 < ngroups; g0 += blockDim.x) {
+    const int groups = ngroups - g0 < (int)blockDim.x ? ngroups - g0 : (int)blockDim.x;
+    const int rp = blockDim.x / groups;
+    const int cg = threadIdx.x % groups, rr = threadIdx.x / groups;
+    float acc[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) acc[e] = 0.f;
+    if (rr < rp) {
+      long r = r0 + rr;
+      for (; r + rp < r1; r += 2 * rp) {                         // two rows per trip: both loads in flight
+        const frag_t a = *reinterpret_cast<const frag_t*>(src + r * ld + (g0 + cg) * E16);
+        const frag_t b = *reinterpret_cast<const frag_t*>(src + (r + rp) * ld + (g0 + cg) * E16);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) acc[e] += ET<T>::to_f32(a[e]) + ET<T>::to_f32(b[e]);
+      }
+      if (r < r1) {
+        const frag_t a = *reinterpret_cast<const frag_t*>(src + r * ld + (g0 + cg) * E16);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) acc[e] += ET<T>::to_f32(a[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E16; ++e) sm[threadIdx.x * E16 + e] = rr < rp ? acc[e] : 0.f;
     __syncthreads();
-    if (threadIdx.x < cols) {
+    for (int i = threadIdx.x; i < groups * E16; i += blockDim.x) {
+      const int cgi = i / E16, e = i - cgi * E16;
       float t = 0.f;
-      for (int k = 0; k < rp; ++k) t += sm[k * cols + threadIdx.x];
-      part[(long)blockIdx.x * C + c0 + threadIdx.x] = t;
+      for (int k = 0; k < rp; ++k) t += sm[(k * groups + cgi) * E16 + e];
+      const int c = (g0 + cgi) * E16 + e;
+      if (c < C) part[(long)blockIdx.x * C + c] = t;
     }
     __syncthreads();
   }
-  (void)rows_par;
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,18 +281,22 @@ extern "C" int ipoke_act_bwd(const void* dy, int lddy, const void* y, int ldy, v
   return IPOKE_OK;
 }
 
-static const int kColsumRows = 512;
+static const int kColsumRows = 2048;
 extern "C" int64_t ipoke_colsum_workspace_floats(int64_t M, int C) { return ((M + kColsumRows - 1) / kColsumRows) * (int64_t)C; }
 /* out[c] (+)= sum_m src[m][c]; src of dtype (src_f32 = 1: fp32) */
 extern "C" int ipoke_colsum(const void* src, int ld, int64_t M, int C, int src_f32, float* out, int accumulate, float* workspace,
                             int dtype, void* stream) {
   IPK_REQUIRE(src && out && workspace && M >= 1 && C >= 1, "bad arguments");
+  {
+    const int e16 = (src_f32 || dtype == IPOKE_F32) ? 4 : 8;
+    IPK_REQUIRE(ld % e16 == 0 && ld >= (C + e16 - 1) / e16 * e16, "row pitch must cover the channel count rounded up to 16 bytes");
+  }
   const int nblk = (int)((M + kColsumRows - 1) / kColsumRows);
   hipStream_t s = STREAM(stream);
   if (src_f32 || dtype == IPOKE_F32)
-    hipLaunchKernelGGL(colsum_part_kernel<float>, dim3(nblk), dim3(256), 256 * sizeof(float), s, (const float*)src, ld, (long)M, C, kColsumRows, workspace);
+    hipLaunchKernelGGL(colsum_part_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)src, ld, (long)M, C, kColsumRows, workspace);
   else
-    hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, dim3(nblk), dim3(256), 256 * sizeof(float), s, (const bf16_t*)src, ld, (long)M, C, kColsumRows, workspace);
+    hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)src, ld, (long)M, C, kColsumRows, workspace);
   IPK_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, out, accumulate);
   IPK_LAUNCH_CHECK();

@@ -135,8 +135,20 @@ class _ConvFn(torch.autograd.Function):
             wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = cout
             wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
             wd.w_sn = cout * taps; wd.w_sc = taps; wd.w_st = 1
-        wd.dW = d_w.data_ptr()
-        check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+        # the reduction runs over every output position (up to B*128*128 rows) while dW has only a handful of 128x128
+        # tiles: split the rows over enough workgroups to fill the chip; every split stores its own slab, summed below
+        # (deterministic, and ~10x cheaper than fp32 atomics into the few thousand addresses of dW)
+        tiles = -(-wd.Nout // 128) * -(-(taps * wd.Kc) // 128)
+        rows = N * wd.Do * wd.Ho * wd.Wo
+        splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), 1024 // tiles))
+        if splitm > 1:
+            slabs = torch.empty(splitm, d_w.numel(), dtype=torch.float32, device=dy.device)
+            wd.splitm = splitm; wd.split_stride = d_w.numel(); wd.dW = slabs.data_ptr()
+            check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+            check(lib.ipoke_reduce_rows(ptr(slabs), ptr(d_w), splitm, d_w.numel(), s))
+        else:
+            wd.dW = d_w.data_ptr()
+            check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
         # ---- data gradient: the adjoint convolution with the same weights
         d_x = None
         if x_t is not None and ctx.needs_input_grad[0]:
