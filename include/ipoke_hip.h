@@ -198,6 +198,8 @@ int ipoke_wn_scale_multi(const float* params, float* scale, float* inv_norm, con
                          int total_rows, void* stream);
 int ipoke_wn_bwd_multi(const float* params, float* grads, const float* inv_norm, const void* jobs_dev, int njobs,
                        int total_rows, void* stream);
+int ipoke_wn_bwd_multi_range(const float* params, float* grads, const float* inv_norm, const void* jobs_dev, int job_begin, int njobs,
+                             int row_begin, int nrows, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -259,6 +261,18 @@ int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
 int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
                         const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
                         void* workspace, void* stream);
+/* The same backward issued in `npieces` groups of levels, last level first, for overlapping the data-parallel gradient
+ * exchange with the rest of the backward pass (DDP bucket hooks in the reference's Lightning run,
+ * experiments/second_stage_video.py:46-65).  After a group's kernels are queued, `ready_stream` is made to wait for them
+ * (without blocking the backward chain on `stream`) and `ready(user, piece, begin, end)` is called on the calling thread
+ * once per contiguous range grads[begin, end) that is final at that point of `ready_stream`; a collective launched there
+ * on (a stream ordered after) `ready_stream` overlaps the remaining pieces.  On return `stream` is ordered after
+ * `ready_stream`.  npieces = 1, ready_stream = stream, ready = NULL is ipoke_flow_backward. */
+typedef void (*ipoke_grad_ready_fn)(void* user, int piece, int64_t begin, int64_t end);
+int ipoke_flow_backward_pieces(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                               const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
+                               void* workspace, int npieces, void* ready_stream, ipoke_grad_ready_fn ready, void* user,
+                               void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ fails, a ``RuntimeError`` is raised.  Build the library with
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import CFUNCTYPE, POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libipoke_hip.so")
@@ -81,6 +81,7 @@ class FlowConfig(Structure):
 
 # name -> (restype, argtypes); every symbol declared in include/ipoke_hip.h
 _P = c_void_p
+GRAD_READY_FN = CFUNCTYPE(None, c_void_p, c_int, c_int64, c_int64)     # ipoke_grad_ready_fn(user, piece, begin, end)
 SIGNATURES = {
     "ipoke_last_error": (c_char_p, []),
     "ipoke_version": (c_int, []),
@@ -137,6 +138,8 @@ SIGNATURES = {
     "ipoke_gru_gates_bwd": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P]),
+    "ipoke_wn_bwd_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_flow_backward_pieces": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, GRAD_READY_FN, _P, _P]),
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),
     "ipoke_flow_destroy": (None, [_P]),
     "ipoke_flow_param_count": (c_int64, [_P]),

@@ -46,6 +46,7 @@ struct Op {
   int64_t ws_a = -1, ws_b = -1, ws_c = -1, ws_d = -1, ws_e = -1, ws_f = -1, ws_g = -1;
   int slot = -1;                               // log-det slot index
   int mcf_idx = -1;                            // running index among the MCF ops (batched weight gradients)
+  int level = 0;                               // multi-scale level the op belongs to
 };
 
 struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
@@ -83,6 +84,10 @@ struct ipoke_flow {
   // hipGraph replay of the ~5000-launch layer programs: keyed by every pointer argument + batch + mode
   struct GraphEntry { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int state = 0; uint64_t used = 0; };
   std::vector<GraphEntry> graphs; hipStream_t cap = nullptr; bool use_graph = false; uint64_t tick = 0;
+  // per level: flat parameter spans / weight-norm job and row ranges of its layers.* and priors.* tensors, op range
+  struct LevelSpan { int64_t p_lo[2], p_hi[2]; int wj_lo[2], wj_hi[2]; int row_lo[2], row_hi[2]; int op_lo, op_hi; };
+  std::vector<LevelSpan> levels;
+  std::vector<int> red_first;          // first reduction-table entry of op i (size nops + 1)
   int last_fwd_B = 0; bool have_saved = false;
   int P = 64;
 };
@@ -244,20 +249,27 @@ int build(ipoke_flow& f) {
   const int cstep = c.z_channels / c.factor;
   std::vector<int> Cs(L), fs(L);
   for (int l = 0; l < L; ++l) { Cs[l] = C; fs[l] = factor; C -= cstep; --factor; }
+  f.levels.assign(L, ipoke_flow::LevelSpan());
   for (int l = 0; l < L; ++l) {
     f.ops.clear();
+    auto& sp = f.levels[l];
+    sp.p_lo[0] = f.n_params; sp.wj_lo[0] = (int)f.wjobs.size(); sp.row_lo[0] = (int)f.wn_rows;
     for (int s = 0; s < c.num_steps[l]; ++s)
       b.step("flow.layers." + std::to_string(l) + "." + std::to_string(s), Cs[l]);
+    sp.p_hi[0] = f.n_params; sp.wj_hi[0] = (int)f.wjobs.size(); sp.row_hi[0] = (int)f.wn_rows;
     level_ops[l] = f.ops;
   }
   for (int l = 0; l < L; ++l) {
     f.ops.clear();
+    auto& sp = f.levels[l];
+    sp.p_lo[1] = f.n_params; sp.wj_lo[1] = (int)f.wjobs.size(); sp.row_lo[1] = (int)f.wn_rows;
     const std::string pfx = "flow.priors." + std::to_string(l);
     const std::string sh = pfx + ".conv1x1";
     b.actnorm("", Cs[l], 0, Cs[l], &sh);                         // bare shuffle
     b.nice(pfx + ".coupling", Cs[l], false, true, fs[l]);
     const int cout = Cs[l] / fs[l];
     b.actnorm(pfx + ".actnorm", Cs[l], Cs[l] - cout, cout, nullptr);
+    sp.p_hi[1] = f.n_params; sp.wj_hi[1] = (int)f.wjobs.size(); sp.row_hi[1] = (int)f.wn_rows;
     prior_ops[l] = f.ops;
   }
   for (int l = 0; l < L; ++l) {
@@ -268,9 +280,11 @@ int build(ipoke_flow& f) {
   }
   f.ops.clear();
   for (int l = 0; l < L; ++l) {
-    for (auto& o : level_ops[l]) f.ops.push_back(o);
-    for (auto& o : prior_ops[l]) f.ops.push_back(o);
-    for (auto& o : shuf_ops[l]) f.ops.push_back(o);
+    f.levels[l].op_lo = (int)f.ops.size();
+    for (auto& o : level_ops[l]) { f.ops.push_back(o); f.ops.back().level = l; }
+    for (auto& o : prior_ops[l]) { f.ops.push_back(o); f.ops.back().level = l; }
+    for (auto& o : shuf_ops[l]) { f.ops.push_back(o); f.ops.back().level = l; }
+    f.levels[l].op_hi = (int)f.ops.size();
   }
   int k = 0;
   for (auto& o : f.ops) if (o.type == OP_MCF) o.mcf_idx = k++;     // execution order
@@ -443,8 +457,10 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
               "batch table layout mismatch");
   std::vector<WgEntryH> w1(f->n_mcf), w2(f->n_mcf);
   std::vector<RedEntryH> red;
+  f->red_first.assign(f->ops.size() + 1, 0);
   for (size_t i = 0; i < f->ops.size(); ++i) {
     const Op& op = f->ops[i];
+    f->red_first[i] = (int)red.size();
     const long dbp = (long)(plan.dbias_part / 4) + (long)i * (B + 1) * 128;
     if (op.type == OP_MCF) {
       const McfGeom g = mcf_geom(op.order);
@@ -459,6 +475,7 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
     }
   }
   drop_graphs(f);    // captured launches hold the old table addresses
+  f->red_first[f->ops.size()] = (int)red.size();
   if (f->d_w1tab) { (void)hipFree(f->d_w1tab); (void)hipFree(f->d_w2tab); (void)hipFree(f->d_redtab); }
   IPK_HIP(hipMalloc(&f->d_w1tab, w1.size() * sizeof(WgEntryH)));
   IPK_HIP(hipMalloc(&f->d_w2tab, w2.size() * sizeof(WgEntryH)));
@@ -837,7 +854,8 @@ extern "C" int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int3
 // ------------------------------------------------------------------------------------------------
 static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
                         const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
-                        void* workspace, hipStream_t stream_h) {
+                        void* workspace, hipStream_t stream_h, int npieces = 1, hipStream_t ready_stream = nullptr,
+                        ipoke_grad_ready_fn ready = nullptr, void* user = nullptr) {
   void* stream = reinterpret_cast<void*>(stream_h);
   int rc = common_checks(f, B); if (rc) return rc;
   rc = ensure_device(f); if (rc) return rc;
@@ -889,6 +907,53 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     hipEvent_t e = next_event(f);
     IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0));
   }
+  // pieces: groups of consecutive levels, last level first, of roughly equal step counts
+  hipStream_t rs = ready_stream ? ready_stream : s;
+  std::vector<std::pair<int, int>> pieces;            // (lowest level, highest level)
+  {
+    const int L = (int)f->levels.size();
+    int total = 0;
+    for (int l = 0; l < L; ++l) total += f->cfg.num_steps[l];
+    const int np = npieces < 1 ? 1 : (npieces > L ? L : npieces);
+    int hi = L - 1, acc = 0, done = 0;
+    for (int l = L - 1; l >= 0; --l) {
+      acc += f->cfg.num_steps[l];
+      const int left = np - (int)pieces.size();
+      if (l == 0 || (left > 1 && (acc >= (total - done + left - 1) / left || l == left - 1))) {
+        pieces.push_back({l, hi}); hi = l - 1; done += acc; acc = 0;
+      }
+    }
+  }
+  auto finish_piece = [&](int lvl_lo, int lvl_hi, int piece) -> int {
+    int r = flush_mcf(); if (r) return r;
+    r = join_lanes(f, lanes, rs); if (r) return r;                  // the chain up to here ...
+    if (f->use_side && f->side != rs) {                              // ... and the weight gradients of this piece
+      hipEvent_t e = next_event(f);
+      IPK_HIP(hipEventRecord(e, f->side)); IPK_HIP(hipStreamWaitEvent(rs, e, 0));
+    }
+    void* rstream = reinterpret_cast<void*>(rs);
+    // bias / ActNorm parameter gradients: multi-tensor reduction over the per-sample partial sums of the piece's layers
+    const int r0 = f->red_first[f->levels[lvl_lo].op_lo], r1 = f->red_first[f->levels[lvl_hi].op_hi];
+    if (r1 > r0) {
+      r = ipoke_reduce_rows_multi(reinterpret_cast<const float*>(c.ws), grads,
+                                  reinterpret_cast<const unsigned char*>(f->d_redtab) + (size_t)r0 * ipoke_reduce_entry_size(), r1 - r0, B,
+                                  rstream);
+      if (r) return r;
+    }
+    for (int kind = 0; kind < 2; ++kind) {                           // layers.* and priors.* are separate flat regions
+      const auto& lo = f->levels[lvl_lo]; const auto& hi = f->levels[lvl_hi];
+      r = ipoke_wn_bwd_multi_range(params, grads, c.wn_inv(), f->d_wjobs, lo.wj_lo[kind], hi.wj_hi[kind] - lo.wj_lo[kind],
+                                   lo.row_lo[kind], hi.row_hi[kind] - lo.row_lo[kind], rstream);
+      if (r) return r;
+    }
+    if (ready)
+      for (int kind = 0; kind < 2; ++kind) {
+        const int64_t b0 = f->levels[lvl_lo].p_lo[kind], b1 = f->levels[lvl_hi].p_hi[kind];
+        if (b1 > b0) ready(user, piece, b0, b1);
+      }
+    return IPOKE_OK;
+  };
+  size_t pk = 0;
   int cur = 0;
   const int64_t goff[2] = {c.plan.g0, c.plan.g1};
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
@@ -971,17 +1036,15 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
     }
     cur ^= 1;
+    if (i == f->levels[pieces[pk].first].op_lo) {        // the lowest op of the current piece has been queued
+      rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc;
+      ++pk;
+    }
   }
-  rc = flush_mcf(); if (rc) return rc;
-  rc = join_lanes(f, lanes, s); if (rc) return rc;
-  // bias / ActNorm parameter gradients: one multi-tensor reduction over the per-sample partial sums of every layer
-  rc = ipoke_reduce_rows_multi(reinterpret_cast<const float*>(c.ws), grads, f->d_redtab, f->n_red, B, stream); if (rc) return rc;
-  if (f->use_side) {
+  if (rs != s) {        // later work on the caller's stream (optimizer step) sees every gradient
     hipEvent_t e = next_event(f);
-    IPK_HIP(hipEventRecord(e, f->side)); IPK_HIP(hipStreamWaitEvent(s, e, 0));
+    IPK_HIP(hipEventRecord(e, rs)); IPK_HIP(hipStreamWaitEvent(s, e, 0));
   }
-  rc = ipoke_wn_bwd_multi(params, grads, c.wn_inv(), f->d_wjobs, (int)f->wjobs.size(), (int)f->wn_rows, stream);
-  if (rc) return rc;
   if (dx_nchw) { rc = ipoke_state_to_nchw(c.rowsf(goff[cur], c.ld), dx_nchw, B, z, f->P, c.ld, stream); if (rc) return rc; }
   return IPOKE_OK;
 }
@@ -997,4 +1060,16 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
   return with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
     return run_backward(f, params, perm, shadow, d_out_nchw, d_logdet, B, grads, dx_nchw, workspace, s);
   });
+}
+
+extern "C" int ipoke_flow_backward_pieces(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
+                                          const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
+                                          void* workspace, int npieces, void* ready_stream, ipoke_grad_ready_fn ready, void* user,
+                                          void* stream) {
+  IPK_REQUIRE(f != nullptr, "null flow handle");
+  if (!f->have_saved || f->last_fwd_B != B)
+    return fail(IPOKE_ERR_STATE, "ipoke_flow_backward needs a preceding ipoke_flow_forward(save_for_backward=1) with the same batch");
+  // host callbacks cannot be captured: always eager
+  return run_backward(f, params, perm, shadow, d_out_nchw, d_logdet, B, grads, dx_nchw, workspace,
+                      reinterpret_cast<hipStream_t>(stream), npieces, reinterpret_cast<hipStream_t>(ready_stream), ready, user);
 }

@@ -102,9 +102,9 @@ __global__ void wn_scale_kernel(const float* __restrict__ params, float* __restr
 
 // in place on the gradient buffer: grads[v_off..] holds dW_eff on entry and dv on exit; dg is written.
 __global__ void wn_bwd_kernel(const float* __restrict__ params, float* __restrict__ grads, const float* __restrict__ inv_norm,
-                              const WnJob* __restrict__ jobs, int njobs, int total_rows) {
-  const int grow = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (grow >= total_rows) return;
+                              const WnJob* __restrict__ jobs, int njobs, int row_base, int total_rows) {
+  const int grow = row_base + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (grow >= row_base + total_rows) return;
   int lo = 0, hi = njobs - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -155,7 +155,17 @@ extern "C" int ipoke_wn_bwd_multi(const float* params, float* grads, const float
                                   int total_rows, void* stream) {
   IPK_REQUIRE(params && grads && inv_norm && jobs_dev && njobs > 0, "bad arguments");
   hipLaunchKernelGGL(wn_bwd_kernel, dim3(ceil_div(total_rows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     params, grads, inv_norm, (const WnJob*)jobs_dev, njobs, total_rows);
+                     params, grads, inv_norm, (const WnJob*)jobs_dev, njobs, 0, total_rows);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+/* the same for a contiguous sub-range of jobs covering global rows [row_begin, row_begin + nrows) */
+extern "C" int ipoke_wn_bwd_multi_range(const float* params, float* grads, const float* inv_norm, const void* jobs_dev, int job_begin,
+                                        int njobs, int row_begin, int nrows, void* stream) {
+  IPK_REQUIRE(params && grads && inv_norm && jobs_dev && njobs >= 0 && nrows >= 0, "bad arguments");
+  if (njobs == 0 || nrows == 0) return IPOKE_OK;
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(ceil_div(nrows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     params, grads, inv_norm, (const WnJob*)jobs_dev + job_begin, njobs, row_begin, nrows);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -45,6 +45,17 @@ def allreduce_flat_(flat, n_buckets=8):
     return flat
 
 
+def allreduce_async(t):
+    """Start the sum of ``t`` over all ranks on the current stream's timeline; returns a handle whose ``wait()`` orders the
+    then-current stream after the collective (a no-op handle in single-process runs)."""
+    if world_size() == 1:
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def broadcast_(t, src=0):
     if world_size() > 1:
         dist.broadcast(t, src=src)

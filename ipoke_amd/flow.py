@@ -71,6 +71,9 @@ class FlowEngine:
         self._ws = {}
         self._io = {}
         self.shadow_stale = True
+        # data-parallel overlap: (npieces, torch.cuda.Stream, fn(begin, end)) -> the backward is issued in pieces and fn is
+        # called as soon as grads[begin:end] is final on that stream (see ipoke_flow_backward_pieces)
+        self.grad_ready_hook = None
 
     def __del__(self):
         try:
@@ -189,9 +192,17 @@ class FlowEngine:
         st["d_logdet"].copy_(d_logdet)
         grads = self.ensure_grads()
         ws = self.workspace(B, True)
-        check(self.lib.ipoke_flow_backward(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(st["d_out"]),
-                                           ptr(st["d_logdet"]), B, ptr(grads), ptr(st["dx"]) if need_dx else None, ptr(ws),
-                                           _lib.current_stream()))
+        if self.grad_ready_hook is None:
+            check(self.lib.ipoke_flow_backward(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow), ptr(st["d_out"]),
+                                               ptr(st["d_logdet"]), B, ptr(grads), ptr(st["dx"]) if need_dx else None, ptr(ws),
+                                               _lib.current_stream()))
+        else:
+            npieces, ready_stream, fn = self.grad_ready_hook
+            cb = _lib.GRAD_READY_FN(lambda user, piece, begin, end: fn(int(begin), int(end)))
+            check(self.lib.ipoke_flow_backward_pieces(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow),
+                                                      ptr(st["d_out"]), ptr(st["d_logdet"]), B, ptr(grads),
+                                                      ptr(st["dx"]) if need_dx else None, ptr(ws), int(npieces),
+                                                      c_void_p(ready_stream.cuda_stream), cb, None, _lib.current_stream()))
         return st["dx"].clone() if need_dx else None
 
 

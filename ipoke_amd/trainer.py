@@ -1,17 +1,37 @@
 """Training loop counterpart of ``experiments/second_stage_video.py:46-65`` (pl.Trainer.fit) for one process per GPU:
 LR rule -> training_step -> backward -> gradient all-reduce (RCCL) -> fused Adam-amsgrad."""
+import os
+
 import torch
 
 from . import dist as D
 
 
 class SecondStageTrainer:
-    def __init__(self, model, n_grad_buckets=8):
+    """``overlap``: issue the backward in ``n_grad_buckets`` groups of levels and all-reduce each group's slice of the flat
+    gradient buffer as soon as it is final, on a separate stream, while the remaining levels are still differentiating
+    (the role of DDP's bucket hooks in the reference's Lightning run).  Without overlap the flat buffer is all-reduced in
+    ``n_grad_buckets`` slices after the backward pass."""
+
+    def __init__(self, model, n_grad_buckets=6, overlap=None):
         self.model = model
         self.opt = model.configure_optimizers()[0]
         self.world = D.world_size()
         self.n_grad_buckets = n_grad_buckets
+        if overlap is None:
+            overlap = os.environ.get("IPOKE_NO_OVERLAP", "0") != "1"
+        self.overlap = bool(overlap) and self.world > 1
+        self._pending = []
+        if self.overlap:
+            self.ready_stream = torch.cuda.Stream()
+            model.flow.engine.grad_ready_hook = (n_grad_buckets, self.ready_stream, self._grads_ready)
         model.flow.train()
+
+    def _grads_ready(self, begin, end):
+        """grads[begin:end] is final at the current point of ``ready_stream``: start its all-reduce there."""
+        flat = self.model.flow.flat_grads
+        with torch.cuda.stream(self.ready_stream):
+            self._pending.append(D.allreduce_async(flat[begin:end]))
 
     def sync_initial_state(self, batch):
         """Data-dependent ActNorm init happens on the first forward (macow2.py:503-505).  Under DDP the reference lets
@@ -28,7 +48,11 @@ class SecondStageTrainer:
         m.on_train_batch_start(batch, batch_idx, 0)
         loss = m.training_step(batch, batch_idx)
         loss.backward()
-        if self.world > 1:
+        if self.overlap:
+            for h in self._pending:
+                h.wait()                      # orders the current stream after the collective
+            self._pending.clear()
+        elif self.world > 1:
             D.allreduce_flat_(m.flow.flat_grads, self.n_grad_buckets)
         self.opt.step(grad_scale=1.0 / self.world)
         m.global_step += 1

@@ -30,8 +30,16 @@ def _worker(rank, world, port, out):
     # fused-step semantics: the mean is applied as grad_scale = 1/world on the summed gradients
     g = torch.full((8,), 2.0 * (rank + 1)); D.allreduce_flat_(g, 2)
     ok_mean = torch.allclose(g / world, torch.full((8,), 3.0))
+    # overlapped exchange: the flat buffer is reduced piece by piece (last levels first) with async handles, as
+    # SecondStageTrainer does from the engine's gradient-ready callback
+    flat2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    pieces = [(800, 1003), (400, 800), (96, 400), (0, 96)]
+    handles = [D.allreduce_async(flat2[b:e]) for b, e in pieces]
+    for h in handles:
+        h.wait()
+    ok_pieces = torch.equal(flat2, expect)
     D.barrier()
-    out[rank] = (ok_sum, ok_bcast, mx, ok_mean)
+    out[rank] = (ok_sum, ok_bcast, mx, ok_mean and ok_pieces)
     dist.destroy_process_group()
 
 

@@ -90,3 +90,48 @@ def test_reduced_flow_data_init(golden):
             assert (v.cpu() - t(g["postfilled." + k])).abs().max().item() <= 2e-5, k
         if k.endswith("initialized"):
             assert int(v) == 1
+
+
+def test_backward_in_pieces_matches_and_covers_all_parameters():
+    """ipoke_flow_backward_pieces (the overlap path of data-parallel training): same gradients as the one-shot backward,
+    and the ready callback announces every parameter exactly once, last levels first."""
+    from ipoke_amd import configs
+    from ipoke_amd.flow import SupervisedMacowTransformer
+    arch = configs.reduced_flow_arch()
+    m = SupervisedMacowTransformer(arch, dtype="f32", max_batch=4, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(4, arch["flow_in_channels"], 8, 8, device="cuda", generator=gen)
+    cond = torch.randn(4, arch["h_channels"], 8, 8, device="cuda", generator=gen)
+    with torch.no_grad():
+        m(x, cond)
+        for name, p in m.named_parameters():
+            if name.endswith("weight_g"):
+                p.fill_(0.07)
+    m.mark_weights_updated()
+    m.train()
+
+    def run():
+        m.flat_grads.zero_()
+        out, logdet = m(x, cond)
+        ((out ** 2).sum() * 0.5 - logdet.sum()).backward()
+        torch.cuda.synchronize()
+        return m.flat_grads.clone()
+
+    ref = run()
+    again = run()
+    noise = (again - ref).abs().max().item()        # the split-K data gradients accumulate with fp32 atomics
+    ranges = []
+    stream = torch.cuda.Stream()
+    m.engine.grad_ready_hook = (3, stream, lambda b, e: ranges.append((b, e)))
+    got = run()
+    m.engine.grad_ready_hook = None
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= max(4 * noise, 1e-6 * scale), ((got - ref).abs().max().item(), noise, scale)
+    assert len(ranges) >= 3
+    covered = torch.zeros(m.engine.n_params, dtype=torch.int32)
+    for b, e in ranges:
+        covered[b:e] += 1
+    assert int(covered.min()) == 1 and int(covered.max()) == 1
+    # per region (layers.*, priors.*) the ranges arrive from the end of the flat buffer towards its start
+    starts = [b for b, _ in ranges[::2]]
+    assert starts == sorted(starts, reverse=True)
