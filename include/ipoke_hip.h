@@ -192,8 +192,9 @@ int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream);
 /* multi-tensor weight preparation (job tables are built by the flow engine) */
 int ipoke_relayout_job_size(void);
 int ipoke_wn_job_size(void);
+/* block_job_dev: optional int32 [total_blocks] map block -> job (NULL: every block searches the job table) */
 int ipoke_relayout_multi(const float* params, void* shadow, const float* wn_scale, const void* jobs_dev, int njobs,
-                         int total_blocks, int dtype, void* stream);
+                         int total_blocks, const int32_t* block_job_dev, int dtype, void* stream);
 int ipoke_wn_scale_multi(const float* params, float* scale, float* inv_norm, const void* jobs_dev, int njobs,
                          int total_rows, void* stream);
 int ipoke_wn_bwd_multi(const float* params, float* grads, const float* inv_norm, const void* jobs_dev, int njobs,

@@ -116,7 +116,7 @@ SIGNATURES = {
     "ipoke_mcf_bwd": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_relayout_job_size": (c_int, []),
     "ipoke_wn_job_size": (c_int, []),
-    "ipoke_relayout_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ipoke_relayout_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_int, _P]),
     "ipoke_wn_scale_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "ipoke_wn_bwd_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "ipoke_groupnorm_workspace_floats": (c_int64, [c_int, c_int, c_int]),

@@ -75,7 +75,7 @@ struct ipoke_flow {
   std::vector<RelayoutJobH> rjobs; int rblocks = 0;
   std::vector<WnJobH> wjobs;
   std::vector<LsRefH> lsrefs;
-  void* d_rjobs = nullptr; void* d_wjobs = nullptr; void* d_lsrefs = nullptr;
+  void* d_rjobs = nullptr; void* d_wjobs = nullptr; void* d_lsrefs = nullptr; void* d_rblockjob = nullptr;
   hipStream_t side = nullptr;
   std::vector<hipStream_t> lanes;     // extra streams for sub-batch lanes 1..kMaxLanes-1 (lane 0 = caller's stream)
   int n_lanes = 1;
@@ -529,6 +529,15 @@ static int ensure_device(ipoke_flow* f) {
               "job table layout mismatch");
   IPK_HIP(hipMalloc(&f->d_rjobs, f->rjobs.size() * sizeof(RelayoutJobH)));
   IPK_HIP(hipMemcpy(f->d_rjobs, f->rjobs.data(), f->rjobs.size() * sizeof(RelayoutJobH), hipMemcpyHostToDevice));
+  {   // block -> job map of the relayout launch (saves every block a 12-step search through the job table)
+    std::vector<int32_t> bj((size_t)f->rblocks);
+    for (size_t k = 0; k < f->rjobs.size(); ++k) {
+      const int b0 = f->rjobs[k].block_start, b1 = k + 1 < f->rjobs.size() ? f->rjobs[k + 1].block_start : f->rblocks;
+      for (int b = b0; b < b1; ++b) bj[b] = (int32_t)k;
+    }
+    IPK_HIP(hipMalloc(&f->d_rblockjob, bj.size() * sizeof(int32_t)));
+    IPK_HIP(hipMemcpy(f->d_rblockjob, bj.data(), bj.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   IPK_HIP(hipMalloc(&f->d_wjobs, f->wjobs.size() * sizeof(WnJobH)));
   IPK_HIP(hipMemcpy(f->d_wjobs, f->wjobs.data(), f->wjobs.size() * sizeof(WnJobH), hipMemcpyHostToDevice));
   IPK_HIP(hipMalloc(&f->d_lsrefs, f->lsrefs.size() * sizeof(LsRefH)));
@@ -552,6 +561,7 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   if (f->d_rjobs) (void)hipFree(f->d_rjobs);
   if (f->d_wjobs) (void)hipFree(f->d_wjobs);
   if (f->d_lsrefs) (void)hipFree(f->d_lsrefs);
+  if (f->d_rblockjob) (void)hipFree(f->d_rblockjob);
   if (f->d_w1tab) (void)hipFree(f->d_w1tab);
   if (f->d_w2tab) (void)hipFree(f->d_w2tab);
   if (f->d_redtab) (void)hipFree(f->d_redtab);
@@ -607,7 +617,8 @@ extern "C" int ipoke_flow_prepare_weights(ipoke_flow* f, const float* params, vo
   int rc = ipoke_wn_scale_multi(params, wn_scale, wn_inv, f->d_wjobs, (int)f->wjobs.size(), (int)f->wn_rows, stream);
   if (rc) return rc;
   void* sh = reinterpret_cast<unsigned char*>(shadow) + 2 * align_up(f->wn_rows, 64) * 4;
-  return ipoke_relayout_multi(params, sh, wn_scale, f->d_rjobs, (int)f->rjobs.size(), f->rblocks, f->cfg.dtype, stream);
+  return ipoke_relayout_multi(params, sh, wn_scale, f->d_rjobs, (int)f->rjobs.size(), f->rblocks,
+                              reinterpret_cast<const int32_t*>(f->d_rblockjob), f->cfg.dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtPar
 
 // =============================================================================================
 // weight gradient
-template <typename T>
+template <typename T, int NR>
 __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
   TnParams p = pin;
   if (pin.batch) {                       // batched launch: blockIdx.z selects operands and the 2-D tap geometry
@@ -652,7 +652,6 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
   // Staging registers: NR reduction stages are in flight per thread (one wave per SIMD owns 512 VGPRs; a stage is
   // 32 of them).  With a single stage in flight every iteration paid a full HBM/L2 latency for ~0.25 us of MFMA work.
   // bf16: a thread stages dY *or* A (8 chunks); f32: 4 chunks of dY then 4 of A.
-  constexpr int NR = 4;
   constexpr int XO = E16 == 8 ? 0 : 4;          // where the A chunks start inside a register set
   u32x4 rs[NR][8];
   auto load_stage = [&](int mb, u32x4* rset) {
@@ -951,11 +950,19 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   if (p.splitm > nmb) p.splitm = nmb;
   p.mb_per_split = ceil_div(nmb, p.splitm);
   const size_t lds = 4 * 128 * kPitch + 256 * sizeof(int);
-  auto kern = igemm_tn_kernel<T>;
-  static bool attr_done = false;
-  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  static const int nr = getenv("IPOKE_TN_NR") ? atoi(getenv("IPOKE_TN_NR")) : 2;   // measured: 2 stages in flight beat 4 (54 vs 61 us at the NICE conv2 shape)
   dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, (unsigned)nbatch);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  if (nr == 2) {
+    auto kern = igemm_tn_kernel<T, 2>;
+    static bool attr_done = false;
+    if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  } else {
+    auto kern = igemm_tn_kernel<T, 4>;
+    static bool attr_done = false;
+    if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

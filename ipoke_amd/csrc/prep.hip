@@ -23,56 +23,100 @@ struct RelayoutJob {
   int block_start;     // first block of this job
 };
 
-constexpr int kRelayoutLds = 64 * 65;    // >= 32*33*9 as well
+template <typename T> struct RPack4;
+template <> struct RPack4<bf16_t> { typedef __attribute__((ext_vector_type(4))) __bf16 type; };
+template <> struct RPack4<float> { typedef f32x4 type; };
+
+// one tile of one job; TAPS and the tile edge are compile-time so that the index arithmetic is shifts and constant divisions
+template <typename T, int TAPS, int TE>
+__device__ __forceinline__ void relayout_tile(const RelayoutJob& j, const float* __restrict__ params, T* __restrict__ shadow,
+                                              const float* __restrict__ wn_scale, int n0, int k0, float* tile) {
+  constexpr int TP = TE + 1;
+  constexpr int total = TE * TE * TAPS;
+  typedef typename RPack4<T>::type pack_t;
+  const bool k_mid = j.s_k < j.s_n;
+  if (TAPS == 1 && j.s_k == 1 && ((j.s_n | j.src_off) & 3) == 0) {
+    // 1x1 weights, k contiguous: 16-byte loads
+    for (int e = threadIdx.x; e < total / 4; e += 256) {
+      const int kl = (e % (TE / 4)) * 4, nl = e / (TE / 4);
+      const int n = n0 + nl, k = k0 + kl;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < j.n_real && k < j.k_real) {
+        if (k + 3 < j.k_real) {
+          v = *reinterpret_cast<const f32x4*>(params + j.src_off + (long)n * j.s_n + k);
+        } else {
+          for (int q = 0; q < 4; ++q) if (k + q < j.k_real) v[q] = params[j.src_off + (long)n * j.s_n + k + q];
+        }
+        if (j.scale_off >= 0) { const float sc = wn_scale[j.scale_off + n]; v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc; }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tile[nl * TP + kl + q] = v[q];
+    }
+  } else {
+    // read in source order: tap fastest, then whichever of (n, k) has the smaller stride
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int t = e % TAPS, rest = e / TAPS;
+      const int m = rest % TE, sl = rest / TE;
+      const int nl = k_mid ? sl : m, kl = k_mid ? m : sl;
+      const int n = n0 + nl, k = k0 + kl;
+      float v = 0.f;
+      if (n < j.n_real && k < j.k_real) {
+        v = params[j.src_off + (long)n * j.s_n + (long)k * j.s_k + t];
+        if (j.scale_off >= 0) v *= wn_scale[j.scale_off + n];
+      }
+      tile[(nl * TAPS + t) * TP + kl] = v;
+    }
+  }
+  __syncthreads();
+  const int ldA = TAPS * j.A_inner_pad, ldB = TAPS * j.B_inner_pad;
+  // A: rows n, columns (tap, k); four consecutive k per thread (all pads are multiples of 4)
+  for (int e = threadIdx.x; e < total / 4; e += 256) {
+    const int kl = (e % (TE / 4)) * 4, rest = e / (TE / 4);
+    const int t = rest % TAPS, nl = rest / TAPS;
+    const int n = n0 + nl, k = k0 + kl;
+    if (n < j.A_rows_pad && k < j.A_inner_pad) {
+      pack_t o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = ET<T>::from_f32(tile[(nl * TAPS + t) * TP + kl + q]);
+      *reinterpret_cast<pack_t*>(shadow + j.dstA + (long)n * ldA + t * j.A_inner_pad + k) = o;
+    }
+  }
+  // B: rows k, columns (tap, n); four consecutive n per thread
+  for (int e = threadIdx.x; e < total / 4; e += 256) {
+    const int nl = (e % (TE / 4)) * 4, rest = e / (TE / 4);
+    const int t = rest % TAPS, kl = rest / TAPS;
+    const int n = n0 + nl, k = k0 + kl;
+    if (k < j.B_rows_pad && n < j.B_inner_pad) {
+      pack_t o;
+      const bool live = k < j.B_rows_real;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = ET<T>::from_f32(live ? tile[((nl + q) * TAPS + t) * TP + kl] : 0.f);
+      *reinterpret_cast<pack_t*>(shadow + j.dstB + (long)k * ldB + t * j.B_inner_pad + n) = o;
+    }
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void relayout_kernel(const float* __restrict__ params, T* __restrict__ shadow,
                                                        const float* __restrict__ wn_scale, const RelayoutJob* __restrict__ jobs,
-                                                       int njobs) {
-  __shared__ float tile[32 * 33 * 9 > kRelayoutLds ? 32 * 33 * 9 : kRelayoutLds];   // [n_l][tap][k_l], k pitch TE+1
-  // locate the job of this block (block_start is ascending)
-  int lo = 0, hi = njobs - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+                                                       int njobs, const int* __restrict__ block_job) {
+  __shared__ __attribute__((aligned(16))) float tile[32 * 33 * 9];   // [n_l][tap][k_l], k pitch TE+1 (>= 64*65)
+  int lo = 0;
+  if (block_job) {
+    lo = block_job[blockIdx.x];
+  } else {                     // locate the job of this block (block_start is ascending)
+    int hi = njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
   }
   const RelayoutJob j = jobs[lo];
-  const int TE = j.tile, TP = TE + 1, taps = j.taps;
   const int t_id = (int)blockIdx.x - j.block_start;
-  const int n0 = (t_id / j.tiles_k) * TE, k0 = (t_id % j.tiles_k) * TE;
-  const int total = TE * TE * taps;
-  // read in source order: tap fastest, then whichever of (n, k) has the smaller stride
-  const bool k_mid = j.s_k < j.s_n;
-  for (int e = threadIdx.x; e < total; e += 256) {
-    const int t = e % taps, rest = e / taps;
-    const int m = rest % TE, sl = rest / TE;
-    const int nl = k_mid ? sl : m, kl = k_mid ? m : sl;
-    const int n = n0 + nl, k = k0 + kl;
-    float v = 0.f;
-    if (n < j.n_real && k < j.k_real) {
-      v = params[j.src_off + n * j.s_n + k * j.s_k + t];
-      if (j.scale_off >= 0) v *= wn_scale[j.scale_off + n];
-    }
-    tile[(nl * taps + t) * TP + kl] = v;
-  }
-  __syncthreads();
-  // A: rows n, columns (tap, k)
-  const int ldA = taps * j.A_inner_pad, ldB = taps * j.B_inner_pad;
-  for (int e = threadIdx.x; e < total; e += 256) {
-    const int kl = e % TE, rest = e / TE;
-    const int t = rest % taps, nl = rest / taps;
-    const int n = n0 + nl, k = k0 + kl;
-    if (n < j.A_rows_pad && k < j.A_inner_pad)
-      shadow[j.dstA + (long)n * ldA + t * j.A_inner_pad + k] = ET<T>::from_f32(tile[(nl * taps + t) * TP + kl]);
-  }
-  // B: rows k, columns (tap, n)
-  for (int e = threadIdx.x; e < total; e += 256) {
-    const int nl = e % TE, rest = e / TE;
-    const int t = rest % taps, kl = rest / taps;
-    const int n = n0 + nl, k = k0 + kl;
-    if (k < j.B_rows_pad && n < j.B_inner_pad)
-      shadow[j.dstB + (long)k * ldB + t * j.B_inner_pad + n] = ET<T>::from_f32(k < j.B_rows_real ? tile[(nl * taps + t) * TP + kl] : 0.f);
-  }
+  const int n0 = (t_id / j.tiles_k) * j.tile, k0 = (t_id % j.tiles_k) * j.tile;
+  if (j.taps == 1) relayout_tile<T, 1, 64>(j, params, shadow, wn_scale, n0, k0, tile);
+  else if (j.taps == 9) relayout_tile<T, 9, 32>(j, params, shadow, wn_scale, n0, k0, tile);
+  else relayout_tile<T, 6, 32>(j, params, shadow, wn_scale, n0, k0, tile);
 }
 
 // weight-norm rows: scale[n] = g[n] / ||v[n]||, inv_norm[n] = 1/||v[n]||.  One wave per row.
@@ -131,15 +175,15 @@ extern "C" int ipoke_relayout_job_size(void) { return (int)sizeof(RelayoutJob); 
 extern "C" int ipoke_wn_job_size(void) { return (int)sizeof(WnJob); }
 
 extern "C" int ipoke_relayout_multi(const float* params, void* shadow, const float* wn_scale, const void* jobs_dev, int njobs,
-                                    int total_blocks, int dtype, void* stream) {
+                                    int total_blocks, const int32_t* block_job_dev, int dtype, void* stream) {
   IPK_REQUIRE(params && shadow && jobs_dev && njobs > 0 && total_blocks > 0, "bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16)
     hipLaunchKernelGGL(relayout_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, s, params, (bf16_t*)shadow, wn_scale,
-                       (const RelayoutJob*)jobs_dev, njobs);
+                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev);
   else
     hipLaunchKernelGGL(relayout_kernel<float>, dim3(total_blocks), dim3(256), 0, s, params, (float*)shadow, wn_scale,
-                       (const RelayoutJob*)jobs_dev, njobs);
+                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
