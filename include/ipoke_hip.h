@@ -183,6 +183,12 @@ typedef struct {
   const void* W2T; const void* W1T;
   const float* dy; const float* dld; float* dx;
   void* dparams_save; void* dc_save; float* dbias_part;
+  /* optional fused ActNorm2dFlow on the same C channels right after the coupling (MaCowUnit: MCF -> MCF -> ActNorm,
+   * macow2.py:957-995): fwd writes y = (scale*x + mu)*exp(post_log_scale) + post_bias; bwd takes dy with respect to that
+   * output, needs it saved (y_post) and writes the ActNorm's per-sample parameter-gradient partials
+   * post_part[b] = [d_log_scale(C) | d_bias(C)] in the layout of ipoke_actnorm_bwd.  Requires C % 4 == 0, ld % 4 == 0. */
+  const float* post_log_scale; const float* post_bias;
+  const float* y_post; float* post_part;
 } ipoke_mcf_desc;
 int ipoke_mcf_shadow_dims(int C, int Cc, int dtype, int32_t* dims8);
 int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream);

@@ -47,6 +47,8 @@ struct Op {
   int slot = -1;                               // log-det slot index
   int mcf_idx = -1;                            // running index among the MCF ops (batched weight gradients)
   int level = 0;                               // multi-scale level the op belongs to
+  int fuse_act = -1;                           // MCF: index of the ActNorm executed inside this layer's kernels
+  bool fused = false;                          // ActNorm: executed by the preceding MCF layer (forward / backward)
 };
 
 struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
@@ -288,6 +290,15 @@ int build(ipoke_flow& f) {
   }
   int k = 0;
   for (auto& o : f.ops) if (o.type == OP_MCF) o.mcf_idx = k++;     // execution order
+  // MaCowUnit: MCF, MCF, ActNorm, MCF, MCF, ActNorm -- the ActNorm runs inside the preceding MCF kernels
+  static const bool nofuse = getenv("IPOKE_NO_ACTNORM_FUSION") != nullptr;
+  for (size_t i = 0; !nofuse && i + 1 < f.ops.size(); ++i) {
+    Op& a = f.ops[i]; Op& b2 = f.ops[i + 1];
+    if (a.type == OP_MCF && b2.type == OP_ACTNORM && b2.idx_fwd < 0 && b2.p_ls >= 0 && b2.c0 == 0 && b2.Cn == a.C &&
+        a.C % 4 == 0 && c.z_channels % 4 == 0 && a.level == b2.level) {
+      a.fuse_act = (int)i + 1; b2.fused = true;
+    }
+  }
   return IPOKE_OK;
 }
 
@@ -306,7 +317,8 @@ int max_splitk(const ipoke_flow& f, int B) {
   const int M = B * f.P;
   const int tiles = ceil_div(M, 64);
   const int nkb = ceil_div(9 * f.cfg.hidden, 128 / f.esz);
-  int s = (384 + tiles - 1) / tiles;
+  static const int target = getenv("IPOKE_SPLITK_TARGET") ? atoi(getenv("IPOKE_SPLITK_TARGET")) : 384;   // workgroups per N tile
+  int s = (target + tiles - 1) / tiles;
   if (s < 1) s = 1;
   if (s > nkb) s = nkb;
   if (s > 32) s = 32;
@@ -735,7 +747,9 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
   for (size_t i = 0; i < f->ops.size(); ++i) {
     const Op& op = f->ops[i];
     if (init && op.type != OP_ACTNORM) continue;   // zero-initialised couplings are the identity (macow_utils.py:231-250)
-    const int nxt = save ? (int)i + 1 : (cur ^ 1);
+    if (!init && op.fused) continue;               // done by the preceding MCF launch, which wrote this op's output state
+    const bool fuse = !init && op.type == OP_MCF && op.fuse_act >= 0;
+    const int nxt = save ? (int)i + (fuse ? 2 : 1) : (cur ^ 1);
     for (const Ctx& l : lanes) {
       const float* in = l.state(cur); float* out = l.state(nxt);
       if (op.type == OP_ACTNORM) {
@@ -752,6 +766,7 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
         d.x = in; d.y = out;
         d.logdet_slot = l.slot(op.slot);
         d.rows_per_block = rpb;   // 16: 4 slices per sample -> slot width 4
+        if (fuse) { d.post_log_scale = params + f->ops[op.fuse_act].p_ls; d.post_bias = params + f->ops[op.fuse_act].p_bias; }
         if (save) { d.a2_save = l.rows(op.ws_a, (int64_t)op.K2p * f->esz); d.scale_save = l.rowsf(op.ws_b, op.C); }
         rc = ipoke_mcf_fwd(&d, l.dtype, l.stream());
       } else {
@@ -969,6 +984,10 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   const int64_t goff[2] = {c.plan.g0, c.plan.g1};
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
     const Op& op = f->ops[i];
+    if (op.fused) {                                  // differentiated inside the preceding MCF layer's backward kernel
+      if (i == f->levels[pieces[pk].first].op_lo) { rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc; ++pk; }
+      continue;
+    }
     for (const Ctx& l : lanes) {
       const float* gin = l.rowsf(goff[cur], l.ld); float* gout = l.rowsf(goff[cur ^ 1], l.ld);
       const float* xin = l.state(i);                 // saved input of op i
@@ -983,6 +1002,12 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
         d.dparams_save = l.rows(op.ws_c, (int64_t)op.K3p * f->esz); d.dc_save = l.rows(op.ws_d, (int64_t)op.Hq * f->esz);
         d.dbias_part = l.dbp(i, 2 * op.C);
         d.y = gout;   // unused by the backward kernel, must be non-null for the shared validator
+        if (op.fuse_act >= 0) {
+          const Op& an = f->ops[op.fuse_act];
+          d.post_log_scale = params + an.p_ls; d.post_bias = params + an.p_bias;
+          d.y_post = l.state(i + 2);                 // saved output of the fused pair
+          d.post_part = l.dbp(op.fuse_act, 2 * an.Cn);
+        }
         rc = ipoke_mcf_bwd(&d, l.dtype, l.stream()); if (rc) return rc;
       } else {
         const void* h1 = l.rows(op.ws_a, hb); const void* h2 = l.rows(op.ws_b, hb);

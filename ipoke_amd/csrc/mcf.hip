@@ -94,6 +94,8 @@ struct McfParams {
   void* dparams_save;                // T [M][K3p]
   void* dc_save;                     // T [M][Hq]
   float* dbias_part;                 // [B][2C]
+  const float* post_ls; const float* post_bias;   // fused ActNorm after the coupling (or NULL)
+  const float* y_post; float* post_part;          // backward of the fused ActNorm
   int dbg;                           // developer ablation switch (IPOKE_MCF_ABLATE)
 };
 
@@ -485,6 +487,11 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_fwd_kernel(const McfParams P)
           yv[q] = sc[q] * xe[k][q] + mu[q];
           ld_acc += logf(sc[q]);
         }
+        if (P.post_ls) {                      // fused ActNorm (its log-det is a constant handled by actnorm_logdet)
+          const f32x4 pl = *reinterpret_cast<const f32x4*>(P.post_ls + c), pb = *reinterpret_cast<const f32x4*>(P.post_bias + c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) yv[q] = yv[q] * expf(pl[q]) + pb[q];
+        }
         *reinterpret_cast<f32x4*>(P.y + (row0 + p) * P.ld + c) = yv;
         if (P.scale_save) *reinterpret_cast<f32x4*>(P.scale_save + (row0 + p) * P.C + c) = sc;
       }
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
   float* dxd = reinterpret_cast<float*>(dc + 65 * dc_pitch);      // [64][C]   dy*scale
   float* colsum = dxd + 64 * P.C;                                 // [2C]   (scalar fallback path)
   float* psum = colsum + N2;                                      // [<=64 rows][2C] per-thread partial column sums
-  float* red2 = psum + 4096;                                      // [Q][2C]
+  float* red2 = psum + 2 * 4096;                                  // [2][Q][2C]  (second halves: fused ActNorm sums)
   const long row0 = (long)b * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
 
@@ -639,14 +646,31 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
       const int nit = r0 + rows_par < 64 ? 2 : 1;
       int pp[2];
       pp[0] = r0; pp[1] = nit == 2 ? r0 + rows_par : r0;
-      f32x4 gyv[2], xvv[2], scv[2];
+      f32x4 gyv[2], xvv[2], scv[2], ypv[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         gyv[k] = *reinterpret_cast<const f32x4*>(P.dy + (row0 + pp[k]) * P.ld + c);
         xvv[k] = *reinterpret_cast<const f32x4*>(P.x + (row0 + pp[k]) * P.ld + c);
         scv[k] = *reinterpret_cast<const f32x4*>(P.scale_save + (row0 + pp[k]) * P.C + c);
+        if (P.post_ls) ypv[k] = *reinterpret_cast<const f32x4*>(P.y_post + (row0 + pp[k]) * P.ld + c);
       }
-      f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sd = sg;
+      f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sd = sg, s_ls = sg, s_b = sg;
+      if (P.post_ls) {
+        // backward of the fused ActNorm: dls = sum dy*(y_post - bias), dbias = sum dy, gradient passed on = dy*exp(ls)
+        const f32x4 pl = *reinterpret_cast<const f32x4*>(P.post_ls + c), pb = *reinterpret_cast<const f32x4*>(P.post_bias + c);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (k < nit) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float g0 = gyv[k][q];
+              s_ls[q] += g0 * (ypv[k][q] - pb[q]);
+              s_b[q] += g0;
+              gyv[k][q] = g0 * expf(pl[q]);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         if (k < nit) {
@@ -673,6 +697,10 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
       }
       *reinterpret_cast<f32x4*>(psum + r0 * N2 + c) = sg;
       *reinterpret_cast<f32x4*>(psum + r0 * N2 + P.C + c) = sd;
+      if (P.post_ls) {
+        *reinterpret_cast<f32x4*>(psum + 4096 + r0 * N2 + c) = s_ls;
+        *reinterpret_cast<f32x4*>(psum + 4096 + r0 * N2 + P.C + c) = s_b;
+      }
     }
     const int padc = P.K3p - N2;                               // zero the K padding (LDS tile and saved tensor)
     for (int e = threadIdx.x; e < 64 * padc; e += blockDim.x) {
@@ -710,15 +738,25 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
     const int Q = kMcfThreads / N2;                            // >= 4
     const int col = threadIdx.x % N2, part = threadIdx.x / N2;
     if (part < Q) {
-      float t = 0.f;
+      float t = 0.f, t2 = 0.f;
       for (int rr = part; rr < rows_used; rr += Q) t += psum[rr * N2 + col];
       red2[part * N2 + col] = t;
+      if (P.post_ls) {
+        for (int rr = part; rr < rows_used; rr += Q) t2 += psum[4096 + rr * N2 + col];
+        red2[512 + part * N2 + col] = t2;
+      }
     }
     __syncthreads();
     if (threadIdx.x < N2 && P.dbias_part) {
       float t = 0.f;
       for (int q = 0; q < Q; ++q) t += red2[q * N2 + threadIdx.x];
       P.dbias_part[(long)b * N2 + threadIdx.x] = t;
+    }
+    if (threadIdx.x < N2 && P.post_ls && P.post_part) {
+      float t = 0.f;
+      for (int q = 0; q < Q; ++q) t += red2[512 + q * N2 + threadIdx.x];
+      // [d_log_scale | d_bias]; the log-det term of the ActNorm adds P * dld[b] to every d_log_scale
+      P.post_part[(long)b * N2 + threadIdx.x] = threadIdx.x < P.C ? t + 64.f * g_ld : t;
     }
   } else if (P.dbias_part) {
     for (int i = threadIdx.x; i < N2; i += blockDim.x) P.dbias_part[(long)b * N2 + i] = colsum[i];
@@ -925,6 +963,9 @@ static int fill_params(McfParams& P, const ipoke_mcf_desc* d, int dtype) {
   P.a2_save = d->a2_save; P.scale_save = d->scale_save; P.ld_slot = d->logdet_slot;
   P.W2T = d->W2T; P.W1T = d->W1T; P.dy = d->dy; P.dld = d->dld; P.dx = d->dx;
   P.dparams_save = d->dparams_save; P.dc_save = d->dc_save; P.dbias_part = d->dbias_part;
+  P.post_ls = d->post_log_scale; P.post_bias = d->post_bias; P.y_post = d->y_post; P.post_part = d->post_part;
+  IPK_REQUIRE((P.post_ls == nullptr) == (P.post_bias == nullptr), "fused ActNorm needs log_scale and bias");
+  IPK_REQUIRE(!P.post_ls || (((d->C | d->ld) & 3) == 0), "fused ActNorm needs C % 4 == 0 and ld % 4 == 0");
   { static const int dbg = getenv("IPOKE_MCF_ABLATE") ? atoi(getenv("IPOKE_MCF_ABLATE")) : 0; P.dbg = dbg; }
   return IPOKE_OK;
 }
@@ -1009,10 +1050,11 @@ extern "C" int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream) {
 
 extern "C" int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream) {
   IPK_REQUIRE(d && d->x && d->dy && d->dx && d->dld && d->W2T && d->W1T && d->a2_save && d->scale_save, "null tensor");
+  IPK_REQUIRE(!d->post_log_scale || d->y_post, "the fused ActNorm backward needs the saved output");
   McfParams P;
   int rc = fill_params(P, d, dtype); if (rc) return rc;
   const int esz = dtype == IPOKE_BF16 ? 2 : 4;
-  const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)65 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4 + (4096 + 512) * 4;
+  const size_t lds = (size_t)64 * (P.K3p * esz + 16) + (size_t)65 * (P.Hq * esz + 16) + (size_t)64 * P.C * 4 + 2 * P.C * 4 + (2 * 4096 + 2 * 512) * 4;
   IPK_REQUIRE(lds <= 158 * 1024, "MCF backward tile does not fit LDS");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16 && fast_ok(P)) {
