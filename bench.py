@@ -87,8 +87,18 @@ def kernel_roofline(B, dtype, iters=50):
     avg_s = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * M * hid * hid
     achieved = flops / avg_s / 1e12
+    # HBM-side bytes per launch of this kernel at this shape from the PMC passes committed under profiles/
+    # (FETCH_SIZE x 2 -- the gfx950 correction for 16-byte-per-lane streaming reads -- plus WRITE_SIZE); null for other shapes
+    traffic = None
+    if M == 1280 and dtype == "bf16":
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_nice_conv2_gemm_pmc.json")))
+            traffic = round((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+        except Exception:
+            traffic = None
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_nice_conv2_gemm_pmc.json)",
+            "algorithmic_bytes_per_launch": int(2 * (M * hid + hid * hid + M * hid)),
             "kernel": "igemm_nt (NICE conv2 1x1, M=%d N=K=2048, %s)" % (M, dtype), "avg_launch_us": round(avg_s * 1e6, 2),
             "algorithmic_gflop_per_launch": round(flops / 1e9, 3)}
 
