@@ -935,6 +935,180 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
   return launch_nt<T, 2, 2, 4, 4>(p, s);                              // 128 x 128
 }
 
+// =============================================================================================
+// Weight gradient, LDS-DMA variant (bf16, dense operands): dW[n][k] = sum_m dY[m][n] * A[src(m, tap)][c].
+// Both operands are reduced over their SLOW memory dimension (rows m), which is what made the register-staged kernel
+// spend half its time loading, transposing (v_perm) and storing.  Here a stage of 64 rows of each operand goes
+// global -> LDS untouched with global_load_lds_dwordx4 (row-major [m][128] images, NSTAGE-deep ring) and the transposed
+// matrix-core fragments are read with ds_read_b64_tr_b16: for a 16-lane group whose lane j supplies the address of
+// row j/4, columns 4*(j%4).. of a 4x16 block, lane i receives column i of the block (4 consecutive m) -- two reads give
+// the 8 reduction elements of a 16x16x32 MFMA operand (semantics measured with scripts/exp/tr_probe.hip).
+// The 16-byte source chunks of row r are permuted by p ^ 2*h(r), h(r) = (r & 3) | ((r >> 3) & 1) << 2, so that the eight
+// rows one LDS cycle touches fall into different bank groups.
+__device__ __forceinline__ int tn_swz(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
+
+template <int NSTAGE>
+__global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams p) {
+  typedef bf16_t T;
+  typedef typename ET<T>::frag frag_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tr4_t;
+  constexpr int RM = 64;                        // reduction rows per stage
+  constexpr int TILE = RM * 256;                // one operand image: 64 rows x 128 columns of bf16
+  constexpr int STAGE = 2 * TILE;
+  constexpr int L = 4;                          // DMA instructions per thread and stage (2 per operand)
+  static_assert((NSTAGE - 2) * L <= 63, "vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* taptab = reinterpret_cast<int*>(smem + NSTAGE * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn2 = wave >> 2, wk = wave & 3;     // wave tile: 64 (n) x 32 (k)
+  const GeomDev& g = p.g;
+  const int tn = blockIdx.x % p.tiles_n, tk = blockIdx.x / p.tiles_n;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int z = blockIdx.y;
+  const int nmb_total = (g.M + RM - 1) / RM;
+  const int mb_begin = z * p.mb_per_split, mb_end = min(nmb_total, mb_begin + p.mb_per_split);
+  const int nst = mb_end - mb_begin;
+
+  fill_taptab(taptab, g);
+  __syncthreads();
+
+  // ---- DMA bookkeeping: instruction i of this thread fills row rloc[i] = 4*(wave + 8*i) + lane/16, LDS chunk lane%16,
+  //      with the source chunk (lane%16) ^ swz(row) -- the same for both instructions of a thread
+  const int pchunk = lane & 15;
+  const int rl0 = 4 * wave + (lane >> 4);
+  const int schunk = pchunk ^ tn_swz(rl0);
+  const T* dY = reinterpret_cast<const T*>(p.dY);
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+  const int ncol = n0 + schunk * 8;             // dY column of this lane's chunk
+  const bool y_ok = ncol < p.ldy - p.y_coff && ncol < ((p.Nout + 7) & ~7);
+  const int kcol = k0 + schunk * 8;             // A (im2col) column of this lane's chunk
+  const int x_tap = kcol / p.Kc, x_c = kcol - x_tap * p.Kc;
+  const bool x_ok = kcol < p.Ktot && x_c < p.Kc_real;
+  const int x_tapcode = x_ok ? taptab[x_tap] : 0;
+  const int S = 1 << (g.lDo + g.lHo + g.lWo);
+  constexpr unsigned kBad = 0xffffffffu;
+  unsigned x_fix[2] = {kBad, kBad};
+  if (p.rows_fixed && x_ok) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const RowPos r = decode_row(g, rl0 + 32 * i, p.a_sn);      // row inside the reduction block (whole samples)
+      int id, ih, iw;
+      if (tap_coords(g, r, x_tapcode, id, ih, iw))
+        x_fix[i] = (unsigned)(r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw + p.a_coff + x_c);
+    }
+  }
+  auto issue = [&](int slot, int mb, bool real) {
+    unsigned char* sy = smem + slot * STAGE;
+    unsigned char* sx = sy + TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb * RM + rl0 + 32 * i;
+      const T* src = zero;
+      if (real && y_ok && m < g.M) src = dY + (long)m * p.ldy + p.y_coff + ncol;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sy + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb * RM + rl0 + 32 * i;
+      const T* src = zero;
+      if (real && x_ok && m < g.M) {
+        if (p.rows_fixed) {
+          if (x_fix[i] != kBad) src = A + (long)(mb * (RM / S)) * p.a_sn + x_fix[i];
+        } else {
+          const RowPos r = decode_row(g, m, p.a_sn);
+          int id, ih, iw;
+          if (tap_coords(g, r, x_tapcode, id, ih, iw))
+            src = A + r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw + p.a_coff + x_c;
+        }
+      }
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sx + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside an operand image), loop invariant
+  // lane (i16 = lane & 15, grp = lane >> 4): reduction rows 8*grp + 4*half + (i16 >> 2) of k-step ks, columns base + 4*(i16 & 3)
+  const int i16 = lane & 15, grp = lane >> 4;
+  const int rrow = 8 * grp + (i16 >> 2);
+  const int hsw = tn_swz(rrow);                  // swz(row) is the same for +4*half and +32*ks
+  auto frag_off = [&](int colbase) {             // colbase: multiple of 16 inside the 128-wide image
+    const int col = colbase + 4 * (i16 & 3);
+    return rrow * 256 + (((col >> 3) ^ hsw) * 16) + ((col >> 2) & 1) * 8;
+  };
+  int y_rd[4], x_rd[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y_rd[i] = frag_off(wn2 * 64 + 16 * i);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) x_rd[j] = TILE + frag_off(wk * 32 + 16 * j);
+  auto tr_frag = [&](const unsigned char* base, int off) -> frag_t {
+    const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) tr4_t*)(base + off));
+    const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) tr4_t*)(base + off + 4 * 256));
+    frag_t f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    return f;
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int issued = 0;
+#pragma unroll
+  for (int s2 = 0; s2 < NSTAGE - 1; ++s2) { issue(s2, mb_begin + issued, issued < nst); ++issued; }
+  int slot = 0;
+  for (int it = 0; it < nst; ++it) {
+    wait_vmcnt<(NSTAGE - 2) * L>();               // this wave's share of the oldest slot has landed
+    __builtin_amdgcn_s_barrier();                 // ... and everybody else's; the slot refilled below is no longer read
+    issue((slot + NSTAGE - 1) % NSTAGE, mb_begin + issued, issued < nst); ++issued;
+    const unsigned char* base = smem + slot * STAGE;
+    slot = (slot + 1) % NSTAGE;
+    if (!(p.ablate & 4)) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        frag_t fy[4], fx[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fy[i] = tr_frag(base, y_rd[i] + ks * 32 * 256);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fx[j] = tr_frag(base, x_rd[j] + ks * 32 * 256);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma64(fy[i], fx[j], acc[i][j]);
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  if (p.ablate & 8) return;
+
+  // epilogue: acc[i][j][r] = dW[n = n0 + wn2*64 + 16i + (lane&15)][k = k0 + wk*32 + 16j + 4*(lane>>4) + r]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn2 * 64 + i * 16 + (lane & 15);
+    if (n >= p.Nout) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 32 + j * 16 + (lane >> 4) * 4;
+      if (k >= p.Ktot) continue;
+      const int tap = k / p.Kc, c = k - tap * p.Kc;     // 4 consecutive k share the tap (Kc % 4 == 0)
+      float* base = p.dW + (long)n * p.w_sn + (long)tap * p.w_st + (p.split_stride > 0 ? (long)z * p.split_stride : 0L);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (c + r < p.Kc_store) {
+          float* q = base + (long)(c + r) * p.w_sc;
+          if (p.splitm > 1 && p.split_stride == 0) atomicAdd(q, acc[i][j][r]);
+          else *q = p.accumulate ? *q + acc[i][j][r] : acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   constexpr int RM = 128 / (int)sizeof(T);
@@ -950,6 +1124,21 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   if (p.splitm > nmb) p.splitm = nmb;
   p.mb_per_split = ceil_div(nmb, p.splitm);
   const size_t lds = 4 * 128 * kPitch + 256 * sizeof(int);
+  // LDS-DMA + transposed-read kernel: bf16, dense operands with 16-byte aligned rows
+  static const int glds = getenv("IPOKE_TN_GLDS") ? atoi(getenv("IPOKE_TN_GLDS")) : 1;
+  if (glds && sizeof(T) == 2 && nbatch == 1 && !p.a_f32 && p.a_sc == 1 && (p.a_coff & 7) == 0 && (p.Kc & 7) == 0 &&
+      (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && ((p.a_sn | p.a_sd | p.a_sh | p.a_sw) & 7) == 0 &&
+      (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.dY) & 15) == 0) {
+    constexpr int NST = 4;
+    const size_t lds2 = (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
+    auto kern = igemm_tn_glds_kernel<NST>;
+    static bool attr_done2 = false;
+    if (!attr_done2) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2 = true; }
+    dim3 grid2((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, 1u);
+    hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, s, p);
+    IPK_LAUNCH_CHECK();
+    return IPOKE_OK;
+  }
   static const int nr = getenv("IPOKE_TN_NR") ? atoi(getenv("IPOKE_TN_NR")) : 2;   // measured: 2 stages in flight beat 4 (54 vs 61 us at the NICE conv2 shape)
   dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, (unsigned)nbatch);
   if (nr == 2) {
