@@ -922,7 +922,23 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
     if (glds_mode == 10) return launch_nt_glds<T, 2, 4, 4, 2, 4, 1>(p, s);         // 128 x 128, 8 waves, 4 slots
     if (glds_mode == 11) return launch_nt_glds<T, 4, 2, 2, 4, 2, 2>(p, s);         // 128 x 128, 8 waves (4x2)
     if (glds_mode == 12) return launch_nt_glds<T, 2, 4, 2, 2, 4, 1>(p, s);         // 64 x 128, 8 waves
-    if ((long)ceil_div(M, 128) * ceil_div(N, 128) >= 100) return launch_nt_glds<T, 2, 4, 4, 2, 2, 2>(p, s);   // 8 waves
+    if (glds_mode == 13) return launch_nt_glds<T, 1, 8, 5, 1, 2, 2>(p, s);         // 80 x 128, 8 waves (M = 1280 -> 256 tiles)
+    if (glds_mode == 14) return launch_nt_glds<T, 1, 8, 5, 1, 4, 1>(p, s);         // 80 x 128, 8 waves, 4 slots
+    if (glds_mode == 15) return launch_nt_glds<T, 1, 8, 5, 1, 3, 2>(p, s);         // 80 x 128, 8 waves, 3 slots x 2 K-blocks
+    {
+      // Row-tile height: the flow's GEMMs have M = 64*B rows (1280 at B = 20) and N = 2048, i.e. 160 tiles of 128 x 128 on
+      // 256 CUs.  80- or 160-row tiles give exactly 256 workgroups at B = 20 / 40; pick the height with the least
+      // (rounds of 256 workgroups) x (rows per workgroup), preferring taller tiles on a tie.
+      const long tn128 = ceil_div(N, 128);
+      int best = 128; long best_cost = ((long)ceil_div(M, 128) * tn128 + 255) / 256 * 128;
+      if (M % 160 == 0) { const long c = ((long)(M / 160) * tn128 + 255) / 256 * 160; if (c <= best_cost) { best = 160; best_cost = c; } }
+      if (M % 80 == 0) { const long c = ((long)(M / 80) * tn128 + 255) / 256 * 80; if (c < best_cost) { best = 80; best_cost = c; } }
+      if ((long)ceil_div(M, 128) * tn128 >= 100) {
+        if (best == 80) return launch_nt_glds<T, 1, 8, 5, 1, 4, 1>(p, s);          // 80 x 128, 8 waves, 4 slots
+        if (best == 160) return launch_nt_glds<T, 2, 4, 5, 2, 2, 2>(p, s);         // 160 x 128, 8 waves
+        return launch_nt_glds<T, 2, 4, 4, 2, 2, 2>(p, s);                          // 128 x 128, 8 waves
+      }
+    }
     return launch_nt_glds<T, 2, 2, 2, 2, 4>(p, s);
   }
   if (N <= 64) return launch_nt<T, 4, 1, 1, 4>(p, s);                  // 64 x 64 tiles, skinny N (split-K upstream)

@@ -26,6 +26,7 @@ def _worker(rank, world, port, overlap, out):
     from ipoke_amd.utils.detfill import deterministic_fill_
     D.init_from_env(backend="gloo")
     torch.cuda.set_device(0)
+    torch.manual_seed(1234 + rank)        # the encoder's reparameterisation noise comes from the CPU generator
     arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
     arch["flow_mid_channels_factor"] = 2
     conf = configs.second_stage_config(64, 32, 16, batch_size=2, arch=arch)
@@ -64,4 +65,9 @@ def test_overlapped_gradient_exchange_matches_plain():
     # gradients leave run-to-run noise at the 1e-6 level, which Adam's m/sqrt(v) normalisation passes on to the update)
     scale = a0[3].abs().max().item()
     assert (a0[3] - b0[3]).abs().max().item() <= 1e-4 * scale
-    assert abs(a0[1] - b0[1]) <= 1e-6 * a0[2] and all(abs(x - y) <= 2e-3 * abs(x) for x, y in zip(a0[0], b0[0]))
+    print("losses plain", a0[0], "overlapped", b0[0])
+    assert abs(a0[1] - b0[1]) <= 1e-6 * a0[2]
+    # step 0 runs on identical parameters; later steps see Adam's amplification of the gradient noise (the update of a
+    # parameter whose gradient is rounding noise is +-lr regardless of its size)
+    assert abs(a0[0][0] - b0[0][0]) <= 1e-5 * max(1.0, abs(a0[0][0]))
+    assert all(abs(x - y) <= 2e-5 * max(1.0, abs(x)) for x, y in zip(a0[0], b0[0]))
