@@ -352,14 +352,18 @@ __global__ void reduce_rows_kernel(const float* __restrict__ src, float* __restr
 
 // ------------------------------------------------------------------ log-det bookkeeping and the loss
 // logdet[b] = const_term + sum_l slots[l][b*slot_w .. +slot_w)
+// one block per sample; the ~1000 layer slots are summed in a fixed order (thread-strided partials, then a block tree)
 __global__ void logdet_finalize_kernel(const float* __restrict__ slots, int nslots, int B, int slot_w, float const_term,
                                        const float* __restrict__ const_dev, float* __restrict__ logdet) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float t = const_term + (const_dev ? const_dev[0] : 0.f);
-  for (int l = 0; l < nslots; ++l)
-    for (int w = 0; w < slot_w; ++w) t += slots[((long)l * B + b) * slot_w + w];
-  logdet[b] = t;
+  __shared__ float red[8];
+  const int b = blockIdx.x;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < nslots * slot_w; i += blockDim.x) {
+    const int l = i / slot_w, w = i - l * slot_w;
+    t += slots[((long)l * B + b) * slot_w + w];
+  }
+  const float tot = block_sum(t, red);
+  if (threadIdx.x == 0) logdet[b] = tot + const_term + (const_dev ? const_dev[0] : 0.f);
 }
 // out_scalar[0] = P * sum over `n` ActNorm layers of sum_c log_scale  (batch independent, macow2.py:512)
 struct LsRef { long off; int C; };
@@ -367,10 +371,12 @@ __global__ void actnorm_logdet_kernel(const float* __restrict__ params, const Ls
                                       float* __restrict__ out_scalar) {
   __shared__ float red[8];
   float t = 0.f;
-  for (int l = 0; l < n; ++l) {
-    const float* ls = params + refs[l].off;
-    for (int c = threadIdx.x; c < refs[l].C; c += blockDim.x) t += ls[c];
-  }
+  // C <= 64 per layer: 4 layers per pass of the 256 threads (fixed assignment -> deterministic sum)
+  const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
+  for (int l = sub; l < n; l += 4)
+    if (c < refs[l].C) t += params[refs[l].off + c];
+  for (int l = 0; l < n; ++l)                       // layers wider than 64 channels (not in the shipped configs)
+    for (int cc = 64 + threadIdx.x; cc < refs[l].C; cc += blockDim.x) t += params[refs[l].off + cc];
   const float tot = block_sum(t, red);
   if (threadIdx.x == 0) out_scalar[0] = tot * (float)P;
 }
@@ -586,7 +592,7 @@ extern "C" int ipoke_reduce_rows_multi(const float* src, float* dst, const void*
 extern "C" int ipoke_logdet_finalize(const float* slots, int nslots, int B, int slot_w, float const_term,
                                      const float* const_dev, float* logdet, void* stream) {
   IPK_REQUIRE(logdet && (nslots == 0 || slots), "bad arguments");
-  hipLaunchKernelGGL(logdet_finalize_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, STREAM(stream), slots, nslots, B, slot_w,
+  hipLaunchKernelGGL(logdet_finalize_kernel, dim3(B), dim3(256), 0, STREAM(stream), slots, nslots, B, slot_w,
                      const_term, const_dev, logdet);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;

@@ -964,8 +964,14 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
 __device__ __forceinline__ int tn_swz(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
 template <int NSTAGE>
-__global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams p) {
+__global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) {
   typedef bf16_t T;
+  TnParams p = pin;
+  if (pin.batch) {                       // batched launch: blockIdx.z selects operands and the 2-D tap geometry
+    const TnBatchEntry e = pin.batch[blockIdx.z];
+    p.A = pin.a_base + e.a_off; p.dY = pin.y_base + e.y_off; p.dW = pin.w_base + e.w_off;
+    p.g.khw = e.kh * e.kw; p.g.kw = e.kw; p.g.taps = e.kh * e.kw; p.g.ph = e.ph; p.g.pw = e.pw;
+  }
   typedef typename ET<T>::frag frag_t;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -1142,15 +1148,17 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   const size_t lds = 4 * 128 * kPitch + 256 * sizeof(int);
   // LDS-DMA + transposed-read kernel: bf16, dense operands with 16-byte aligned rows
   static const int glds = getenv("IPOKE_TN_GLDS") ? atoi(getenv("IPOKE_TN_GLDS")) : 1;
-  if (glds && sizeof(T) == 2 && nbatch == 1 && !p.a_f32 && p.a_sc == 1 && (p.a_coff & 7) == 0 && (p.Kc & 7) == 0 &&
+  // (batched launches: the engine's workspace offsets are 256-byte aligned)
+  if (glds && sizeof(T) == 2 && !p.a_f32 && p.a_sc == 1 && (p.a_coff & 7) == 0 && (p.Kc & 7) == 0 &&
       (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && ((p.a_sn | p.a_sd | p.a_sh | p.a_sw) & 7) == 0 &&
-      (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.dY) & 15) == 0) {
+      (p.batch ? ((reinterpret_cast<uintptr_t>(p.a_base) | reinterpret_cast<uintptr_t>(p.y_base)) & 15) == 0
+               : ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.dY)) & 15) == 0)) {
     constexpr int NST = 4;
     const size_t lds2 = (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
     auto kern = igemm_tn_glds_kernel<NST>;
     static bool attr_done2 = false;
     if (!attr_done2) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2 = true; }
-    dim3 grid2((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, 1u);
+    dim3 grid2((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, (unsigned)nbatch);
     hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, s, p);
     IPK_LAUNCH_CHECK();
     return IPOKE_OK;
