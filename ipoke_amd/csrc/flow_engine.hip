@@ -6,6 +6,7 @@
 // gradient GEMMs are forked onto a side stream so that they overlap the serial data-gradient chain.
 //
 // Host code only (compiled by hipcc together with the kernels).
+#include <functional>
 #include <memory>
 #include <vector>
 #include <string>
@@ -950,8 +951,10 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       }
     }
   }
+  std::function<int()> flush_nice_fn = []() { return (int)IPOKE_OK; };
   auto finish_piece = [&](int lvl_lo, int lvl_hi, int piece) -> int {
-    int r = flush_mcf(); if (r) return r;
+    int r = flush_nice_fn(); if (r) return r;
+    r = flush_mcf(); if (r) return r;
     r = join_lanes(f, lanes, rs); if (r) return r;                  // the chain up to here ...
     if (f->use_side && f->side != rs) {                              // ... and the weight gradients of this piece
       hipEvent_t e = next_event(f);
@@ -979,6 +982,47 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       }
     return IPOKE_OK;
   };
+  // NICE weight gradients are not started right behind their coupling: the couplings come in pairs whose data-gradient
+  // GEMMs want the whole chip, and a weight-gradient kernel that is already running holds its CUs for 30 us.  They are
+  // queued when the chain moves on to the (latency-bound, 20..80 workgroup) masked-conv layers.
+  std::vector<int> pend_nice;
+  auto flush_nice = [&]() -> int {
+    if (pend_nice.empty()) return IPOKE_OK;
+    int rc = wgrads_wait_lanes(); if (rc) return rc;
+    for (int oi : pend_nice) {
+      const Op& op = f->ops[oi];
+        const void* h1 = c.at<void>(op.ws_a); const void* h2 = c.at<void>(op.ws_b);
+        const void* dprm = c.at<void>(op.ws_d); const void* dp2 = c.at<void>(op.ws_e); const void* dp1 = c.at<void>(op.ws_f);
+        ipoke_wgrad_desc w;
+        auto base8 = [&](int k, int pad) {
+          std::memset(&w, 0, sizeof(w));
+          w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = w.kw = k;
+          w.sd = w.sh = w.sw = 1; w.ph = w.pw = pad;
+        };
+        // conv3 (effective weight; weight-norm backward runs at the end)
+        base8(3, 1);
+        w.A = h2; w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
+        w.dY = dprm; w.ldy = op.Kc3; w.Nout = 2 * op.cout;
+        w.dW = grads + op.p_v; w.w_sn = (int64_t)hid * 9; w.w_sc = 9; w.w_st = 1;
+        rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+        // conv2
+        base8(1, 0);
+        w.A = h1; w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
+        w.dY = dp2; w.ldy = hid; w.Nout = hid;
+        w.dW = grads + op.p_c2; w.w_sn = hid; w.w_sc = 1; w.w_st = 0;
+        rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+        // conv1 (input = conditioning channels of the saved state)
+        base8(3, 1);
+        w.A = c.at<void>(op.ws_g); w.a_f32 = 0; w.a_sn = 64L * op.Kc1; w.a_sh = 8L * op.Kc1; w.a_sw = op.Kc1; w.a_sc = 1;
+        w.Kc_real = op.Kc1; w.Kc = op.Kc1;
+        w.dY = dp1; w.ldy = hid; w.Nout = hid;
+        w.dW = grads + op.p_c1; w.w_sn = (int64_t)op.cin * 9; w.w_sc = 9; w.w_st = 1; w.Kc_store = op.cin;
+        rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+    }
+    pend_nice.clear();
+    return IPOKE_OK;
+  };
+  flush_nice_fn = flush_nice;
   size_t pk = 0;
   int cur = 0;
   const int64_t goff[2] = {c.plan.g0, c.plan.g1};
@@ -988,6 +1032,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       if (i == f->levels[pieces[pk].first].op_lo) { rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc; ++pk; }
       continue;
     }
+    if (op.type != OP_NICE) { rc = flush_nice(); if (rc) return rc; }
     for (const Ctx& l : lanes) {
       const float* gin = l.rowsf(goff[cur], l.ld); float* gout = l.rowsf(goff[cur ^ 1], l.ld);
       const float* xin = l.state(i);                 // saved input of op i
@@ -1042,34 +1087,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       if (pend_lo < 0) { pend_hi = op.mcf_idx; pend_op = i; }
       pend_lo = op.mcf_idx;
     } else if (op.type == OP_NICE) {
-      rc = wgrads_wait_lanes(); if (rc) return rc;
-      const void* h1 = c.at<void>(op.ws_a); const void* h2 = c.at<void>(op.ws_b);
-      const void* dprm = c.at<void>(op.ws_d); const void* dp2 = c.at<void>(op.ws_e); const void* dp1 = c.at<void>(op.ws_f);
-      ipoke_wgrad_desc w;
-      auto base8 = [&](int k, int pad) {
-        std::memset(&w, 0, sizeof(w));
-        w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = w.kw = k;
-        w.sd = w.sh = w.sw = 1; w.ph = w.pw = pad;
-      };
-      // conv3 (effective weight; weight-norm backward runs at the end)
-      base8(3, 1);
-      w.A = h2; w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
-      w.dY = dprm; w.ldy = op.Kc3; w.Nout = 2 * op.cout;
-      w.dW = grads + op.p_v; w.w_sn = (int64_t)hid * 9; w.w_sc = 9; w.w_st = 1;
-      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
-      // conv2
-      base8(1, 0);
-      w.A = h1; w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
-      w.dY = dp2; w.ldy = hid; w.Nout = hid;
-      w.dW = grads + op.p_c2; w.w_sn = hid; w.w_sc = 1; w.w_st = 0;
-      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
-      // conv1 (input = conditioning channels of the saved state)
-      base8(3, 1);
-      w.A = c.at<void>(op.ws_g); w.a_f32 = 0; w.a_sn = 64L * op.Kc1; w.a_sh = 8L * op.Kc1; w.a_sw = op.Kc1; w.a_sc = 1;
-      w.Kc_real = op.Kc1; w.Kc = op.Kc1;
-      w.dY = dp1; w.ldy = hid; w.Nout = hid;
-      w.dW = grads + op.p_c1; w.w_sn = (int64_t)op.cin * 9; w.w_sc = 9; w.w_st = 1; w.Kc_store = op.cin;
-      rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+      pend_nice.push_back(i);      // weight gradients: launched when the chain leaves this group of couplings
     }
     cur ^= 1;
     if (i == f->levels[pieces[pk].first].op_lo) {        // the lowest op of the current piece has been queued
