@@ -171,6 +171,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is not built. ipoke_amd has no CPU fallback; "
                 "run `make -C ipoke_amd/csrc` (or __graft_entry__.build()) first.")
+        # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Load it FIRST so that this library binds to the same
+        # HIP runtime instance (same SONAME): with the order reversed the process holds two runtimes and the second one
+        # finds no device ("no ROCm-capable device is detected" from the first kernel-attribute call).
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the .so does not export it

@@ -43,6 +43,28 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         self.flow.engine.prepare_weights()
         return loss
 
+    # ---- piecewise step: the update of a slice can start as soon as its gradients are final (overlap with backward) ----
+    def begin_step(self):
+        self.steps += 1
+        self._covered = 0
+
+    @torch.no_grad()
+    def step_range(self, begin, end, grad_scale=1.0):
+        """Adam-amsgrad update of flat[begin:end] on the current stream (same kernel, same step count for every slice)."""
+        g = self.param_groups[0]
+        flat, grads = self.flow.flat_params, self.flow.flat_grads
+        sl = slice(begin, end)
+        check(_lib.lib().ipoke_adam_amsgrad_step(
+            ptr(flat[sl]), ptr(grads[sl]), ptr(self.exp_avg[sl]), ptr(self.exp_avg_sq[sl]), ptr(self.max_exp_avg_sq[sl]), end - begin,
+            float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+            self.steps, float(grad_scale), _lib.current_stream()))
+        self._covered += end - begin
+
+    def finish_step(self):
+        if self._covered != self.flow.flat_params.numel():
+            raise RuntimeError(f"piecewise optimizer step covered {self._covered} of {self.flow.flat_params.numel()} parameters")
+        self.flow.engine.prepare_weights()
+
     def state_dict(self):
         return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "max_exp_avg_sq": self.max_exp_avg_sq, "param_groups": [{k: v for k, v in g.items() if k != "params"}

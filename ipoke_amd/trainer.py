@@ -8,10 +8,10 @@ from . import dist as D
 
 
 class SecondStageTrainer:
-    """``overlap``: issue the backward in ``n_grad_buckets`` groups of levels and all-reduce each group's slice of the flat
-    gradient buffer as soon as it is final, on a separate stream, while the remaining levels are still differentiating
-    (the role of DDP's bucket hooks in the reference's Lightning run).  Without overlap the flat buffer is all-reduced in
-    ``n_grad_buckets`` slices after the backward pass."""
+    """``overlap``: issue the backward in ``n_grad_buckets`` groups of levels; as soon as a group's slice of the flat gradient
+    buffer is final it is all-reduced (data parallel; the role of DDP's bucket hooks in the reference's Lightning run) and
+    the fused Adam-amsgrad update of that slice is applied, on a separate stream, while the remaining levels are still
+    differentiating.  Without overlap the flat buffer is all-reduced in slices and updated after the backward pass."""
 
     def __init__(self, model, n_grad_buckets=6, overlap=None):
         self.model = model
@@ -20,18 +20,23 @@ class SecondStageTrainer:
         self.n_grad_buckets = n_grad_buckets
         if overlap is None:
             overlap = os.environ.get("IPOKE_NO_OVERLAP", "0") != "1"
+        # one GPU: measured 88.2 ms with the per-group Adam updates running underneath the backward chain vs 87.1 ms with the
+        # single update after it (the HBM-bound update slows the chain by as much as it hides) -> piecewise only when
+        # there is an exchange to overlap
         self.overlap = bool(overlap) and self.world > 1
-        self._pending = []
         if self.overlap:
             self.ready_stream = torch.cuda.Stream()
             model.flow.engine.grad_ready_hook = (n_grad_buckets, self.ready_stream, self._grads_ready)
         model.flow.train()
 
     def _grads_ready(self, begin, end):
-        """grads[begin:end] is final at the current point of ``ready_stream``: start its all-reduce there."""
+        """grads[begin:end] is final at the current point of ``ready_stream``: all-reduce it there (data parallel) and
+        apply the optimizer update to that slice, all without blocking the backward chain."""
         flat = self.model.flow.flat_grads
         with torch.cuda.stream(self.ready_stream):
-            self._pending.append(D.allreduce_async(flat[begin:end]))
+            if self.world > 1:
+                D.allreduce_async(flat[begin:end]).wait()        # orders ready_stream after the collective, host does not block
+            self.opt.step_range(begin, end, grad_scale=1.0 / self.world)
 
     def sync_initial_state(self, batch):
         """Data-dependent ActNorm init happens on the first forward (macow2.py:503-505).  Under DDP the reference lets
@@ -47,13 +52,14 @@ class SecondStageTrainer:
         m = self.model
         m.on_train_batch_start(batch, batch_idx, 0)
         loss = m.training_step(batch, batch_idx)
-        loss.backward()
         if self.overlap:
-            for h in self._pending:
-                h.wait()                      # orders the current stream after the collective
-            self._pending.clear()
-        elif self.world > 1:
-            D.allreduce_flat_(m.flow.flat_grads, self.n_grad_buckets)
-        self.opt.step(grad_scale=1.0 / self.world)
+            self.opt.begin_step()
+            loss.backward()                   # exchanges and updates every slice from the engine's callbacks; on return the
+            self.opt.finish_step()            # current stream is ordered after the ready stream
+        else:
+            loss.backward()
+            if self.world > 1:
+                D.allreduce_flat_(m.flow.flat_grads, self.n_grad_buckets)
+            self.opt.step(grad_scale=1.0 / self.world)
         m.global_step += 1
         return loss
