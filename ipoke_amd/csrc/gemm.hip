@@ -533,7 +533,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtPar
     for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(sub + b_rd[j][hs]);
   };
   int slot = 0;
-  for (int kb = kb_begin; kb < kb_end; kb += KPB) {
+  if (p.ablate == 5) { wait_vmcnt<0>(); return; }                 // developer: launch + prologue only
+  if (p.ablate == 7) return;                                      // developer: launch + setup, nothing in flight... (DMAs issued)
+  for (int kb = kb_begin; kb < (p.ablate == 6 ? kb_begin : kb_end); kb += KPB) {
     wait_vmcnt<(NSTAGE - 2) * L * KPB>();      // this wave's share of the oldest slot has landed
     if (p.ablate < 3) __builtin_amdgcn_s_barrier();   // ... and everybody else's; all reads of the slot refilled below are done
     if (p.ablate == 0 || p.ablate == 1) issue_slot((slot + NSTAGE - 1) % NSTAGE);
@@ -924,7 +926,8 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
     if (glds_mode == 12) return launch_nt_glds<T, 2, 4, 2, 2, 4, 1>(p, s);         // 64 x 128, 8 waves
     if (glds_mode == 13) return launch_nt_glds<T, 1, 8, 5, 1, 2, 2>(p, s);         // 80 x 128, 8 waves (M = 1280 -> 256 tiles)
     if (glds_mode == 14) return launch_nt_glds<T, 1, 8, 5, 1, 4, 1>(p, s);         // 80 x 128, 8 waves, 4 slots
-    if (glds_mode == 15) return launch_nt_glds<T, 1, 8, 5, 1, 3, 2>(p, s);         // 80 x 128, 8 waves, 3 slots x 2 K-blocks
+    if (glds_mode == 15) return launch_nt_glds<T, 1, 8, 5, 1, 5, 1>(p, s);         // 80 x 128, 8 waves, 5 slots
+    if (glds_mode == 16) return launch_nt_glds<T, 1, 8, 5, 1, 3, 1>(p, s);         // 80 x 128, 8 waves, 3 slots
     {
       // Row-tile height: the flow's GEMMs have M = 64*B rows (1280 at B = 20) and N = 2048, i.e. 160 tiles of 128 x 128 on
       // 256 CUs.  80- or 160-row tiles give exactly 256 workgroups at B = 20 / 40; pick the height with the least
@@ -934,7 +937,8 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
       if (M % 160 == 0) { const long c = ((long)(M / 160) * tn128 + 255) / 256 * 160; if (c <= best_cost) { best = 160; best_cost = c; } }
       if (M % 80 == 0) { const long c = ((long)(M / 80) * tn128 + 255) / 256 * 80; if (c < best_cost) { best = 80; best_cost = c; } }
       if ((long)ceil_div(M, 128) * tn128 >= 100) {
-        if (best == 80) return launch_nt_glds<T, 1, 8, 5, 1, 4, 1>(p, s);          // 80 x 128, 8 waves, 4 slots
+        if (best == 80) return launch_nt_glds<T, 1, 8, 5, 1, 3, 1>(p, s);          // 80 x 128, 8 waves, 3 slots (deeper rings measure no faster:
+                                                                                   // the DMA path saturates at ~65 GB/s per CU)
         if (best == 160) return launch_nt_glds<T, 2, 4, 5, 2, 2, 2>(p, s);         // 160 x 128, 8 waves
         return launch_nt_glds<T, 2, 4, 4, 2, 2, 2>(p, s);                          // 128 x 128, 8 waves
       }
