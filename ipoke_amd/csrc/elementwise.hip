@@ -618,7 +618,10 @@ extern "C" int ipoke_adam_amsgrad_step(float* p, const float* g, float* m, float
   IPK_REQUIRE(p && g && m && v && vmax && n > 0 && step >= 1, "bad arguments");
   IPK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) == 0, "16-byte alignment");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, STREAM(stream), p, g, m, v,
+  // Persistent grid-stride launch.  (Smaller grids that leave wave slots to other streams were measured: no gain, the
+  // step's other HBM-bound kernels share the same bandwidth.)
+  static const int adam_blocks = getenv("IPOKE_ADAM_BLOCKS") ? atoi(getenv("IPOKE_ADAM_BLOCKS")) : 4096;
+  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for((n + 3) / 4, 256, adam_blocks)), dim3(256), 0, STREAM(stream), p, g, m, v,
                      vmax, (long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;

@@ -135,7 +135,18 @@ __global__ void wn_scale_kernel(const float* __restrict__ params, float* __restr
   const int row = grow - j.row_start, lane = threadIdx.x & 63;
   const float* v = params + j.v_off + (long)row * j.K;
   float s = 0.f;
-  for (int k = lane; k < j.K; k += 64) s += v[k] * v[k];
+  if ((j.K & 3) == 0 && (((j.v_off + (long)row * j.K)) & 3) == 0) {       // 16-byte loads, two in flight per lane
+    const f32x4* v4 = reinterpret_cast<const f32x4*>(v);
+    const int n4 = j.K >> 2;
+    int k = lane;
+    for (; k + 64 < n4; k += 128) {
+      const f32x4 a = v4[k], b = v4[k + 64];
+      s += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+    }
+    if (k < n4) { const f32x4 a = v4[k]; s += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]; }
+  } else {
+    for (int k = lane; k < j.K; k += 64) s += v[k] * v[k];
+  }
   s = wave_sum(s);
   if (lane == 0) {
     const float nrm = sqrtf(s);
@@ -158,12 +169,45 @@ __global__ void wn_bwd_kernel(const float* __restrict__ params, float* __restric
   const int row = grow - j.row_start, lane = threadIdx.x & 63;
   const float* v = params + j.v_off + (long)row * j.K;
   float* dw = grads + j.v_off + (long)row * j.K;
+  const bool vec = (j.K & 3) == 0 && (((j.v_off + (long)row * j.K)) & 3) == 0;
   float dot = 0.f;
-  for (int k = lane; k < j.K; k += 64) dot += dw[k] * v[k];
+  if (vec) {
+    const f32x4* v4 = reinterpret_cast<const f32x4*>(v);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dw);
+    const int n4 = j.K >> 2;
+    int k = lane;
+    for (; k + 64 < n4; k += 128) {
+      const f32x4 a0 = v4[k], b0 = d4[k], a1 = v4[k + 64], b1 = d4[k + 64];
+      dot += a0[0] * b0[0] + a0[1] * b0[1] + a0[2] * b0[2] + a0[3] * b0[3] + a1[0] * b1[0] + a1[1] * b1[1] + a1[2] * b1[2] + a1[3] * b1[3];
+    }
+    if (k < n4) { const f32x4 a0 = v4[k], b0 = d4[k]; dot += a0[0] * b0[0] + a0[1] * b0[1] + a0[2] * b0[2] + a0[3] * b0[3]; }
+  } else {
+    for (int k = lane; k < j.K; k += 64) dot += dw[k] * v[k];
+  }
   dot = wave_sum(dot);
   const float inv = inv_norm[j.out_off + row], g = params[j.g_off + row];
   const float a = g * inv, bcoef = g * dot * inv * inv * inv;
-  for (int k = lane; k < j.K; k += 64) dw[k] = a * dw[k] - bcoef * v[k];
+  if (vec) {
+    const f32x4* v4 = reinterpret_cast<const f32x4*>(v);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dw);
+    const int n4 = j.K >> 2;
+    int k = lane;
+    for (; k + 64 < n4; k += 128) {
+      const f32x4 a0 = v4[k], a1 = v4[k + 64];
+      f32x4 b0 = d4[k], b1 = d4[k + 64];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { b0[q] = a * b0[q] - bcoef * a0[q]; b1[q] = a * b1[q] - bcoef * a1[q]; }
+      d4[k] = b0; d4[k + 64] = b1;
+    }
+    if (k < n4) {
+      const f32x4 a0 = v4[k]; f32x4 b0 = d4[k];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b0[q] = a * b0[q] - bcoef * a0[q];
+      d4[k] = b0;
+    }
+  } else {
+    for (int k = lane; k < j.K; k += 64) dw[k] = a * dw[k] - bcoef * v[k];
+  }
   if (lane == 0) grads[j.g_off + row] = dot * inv;
 }
 

@@ -74,6 +74,8 @@ class FlowEngine:
         # data-parallel overlap: (npieces, torch.cuda.Stream, fn(begin, end)) -> the backward is issued in pieces and fn is
         # called as soon as grads[begin:end] is final on that stream (see ipoke_flow_backward_pieces)
         self.grad_ready_hook = None
+        # event after which the parameters / weight shadows are final (optimizer step issued on another stream)
+        self.params_ready_event = None
 
     def __del__(self):
         try:
@@ -146,6 +148,9 @@ class FlowEngine:
             raise ValueError(f"batch {B} exceeds max_batch={self.max_batch} of this flow")
         if tuple(x.shape[1:]) != (self.z, 8, 8):
             raise ValueError(f"flow input must be [B,{self.z},8,8], got {tuple(x.shape)}")
+        if self.params_ready_event is not None:
+            torch.cuda.current_stream().wait_event(self.params_ready_event)
+            self.params_ready_event = None
         st = self._staging(B)
         st["x"].copy_(x.detach())
         if cond is not None:
@@ -167,6 +172,9 @@ class FlowEngine:
     def init_forward(self, x):
         """Data-dependent initialisation pass (first forward of an uninitialised reference flow)."""
         self._need_gpu()
+        if self.params_ready_event is not None:
+            torch.cuda.current_stream().wait_event(self.params_ready_event)
+            self.params_ready_event = None
         x = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
         B = x.shape[0]
         out = torch.empty_like(x)
