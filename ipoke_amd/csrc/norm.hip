@@ -10,39 +10,63 @@
 namespace ipoke {
 
 // x: [N][S][ldx] of T, channels [0, C) normalised in G groups of cpg = C/G consecutive channels.
-// part: [N][nchunks][G][3] = (count, mean, M2)
+// part: [N][nchunks][G][3] = (count, mean, M2).
+// Thread (rr, cg) owns the E16 channels of column group cg over rows rr, rr + rows_par, ... of the chunk: partial sums stay
+// in registers, meet in LDS once, and are reduced in a fixed order (no float atomics: they serialise and are not
+// reproducible).  C <= 64*E16 per pass of 256 threads; wider tensors take several passes.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int S, int ldx, int C, int G, int pos_per_block,
                                                        float* __restrict__ part) {
-  extern __shared__ float sm[];     // [2][C]
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  __shared__ float sm[2][256 * E16];      // per-thread partial sums, then per-channel totals in sm[.][0:C]
+  __shared__ float tot[2][4096];          // per-channel sum / sum of squares of the chunk
   const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
   const int p0 = chunk * pos_per_block, p1 = min(S, p0 + pos_per_block);
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sm[i] = 0.f;
-  __syncthreads();
-  constexpr int E16 = ET<T>::E16;
-  const int cvec = C / E16;                          // host guarantees C % E16 == 0
-  const int lanes_c = min(cvec, (int)blockDim.x);
-  const int cv = threadIdx.x % lanes_c, prow = threadIdx.x / lanes_c, prows = blockDim.x / lanes_c;
+  const int cvec = C / E16;                          // host guarantees C % E16 == 0 and C <= 4096
   const T* xb = x + ((long)n * S) * ldx;
-  for (int cc = cv; cc < cvec; cc += lanes_c) {
+  for (int g0 = 0; g0 < cvec; g0 += 256) {
+    const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
+    const int rp = 256 / groups;
+    const int cg = threadIdx.x % groups, rr = threadIdx.x / groups;
     float s[E16], q[E16];
 #pragma unroll
     for (int e = 0; e < E16; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    if (prow < prows) {
-      for (int p = p0 + prow; p < p1; p += prows) {
-        const typename ET<T>::frag v = *reinterpret_cast<const typename ET<T>::frag*>(xb + (long)p * ldx + cc * E16);
+    if (rr < rp) {
+      int p = p0 + rr;
+      for (; p + rp < p1; p += 2 * rp) {            // two rows per trip: both loads in flight
+        const frag_t a = *reinterpret_cast<const frag_t*>(xb + (long)p * ldx + (g0 + cg) * E16);
+        const frag_t b = *reinterpret_cast<const frag_t*>(xb + (long)(p + rp) * ldx + (g0 + cg) * E16);
 #pragma unroll
-        for (int e = 0; e < E16; ++e) { const float f = ET<T>::to_f32(v[e]); s[e] += f; q[e] += f * f; }
+        for (int e = 0; e < E16; ++e) {
+          const float fa = ET<T>::to_f32(a[e]), fb = ET<T>::to_f32(b[e]);
+          s[e] += fa + fb; q[e] += fa * fa + fb * fb;
+        }
+      }
+      if (p < p1) {
+        const frag_t a = *reinterpret_cast<const frag_t*>(xb + (long)p * ldx + (g0 + cg) * E16);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) { const float fa = ET<T>::to_f32(a[e]); s[e] += fa; q[e] += fa * fa; }
       }
     }
 #pragma unroll
-    for (int e = 0; e < E16; ++e) { atomicAdd(&sm[cc * E16 + e], s[e]); atomicAdd(&sm[C + cc * E16 + e], q[e]); }
+    for (int e = 0; e < E16; ++e) {
+      sm[0][threadIdx.x * E16 + e] = rr < rp ? s[e] : 0.f;
+      sm[1][threadIdx.x * E16 + e] = rr < rp ? q[e] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < groups * E16; i += 256) {
+      const int cgi = i / E16, e = i - cgi * E16;
+      float ts = 0.f, tq = 0.f;
+      for (int k = 0; k < rp; ++k) { ts += sm[0][(k * groups + cgi) * E16 + e]; tq += sm[1][(k * groups + cgi) * E16 + e]; }
+      tot[0][(g0 + cgi) * E16 + e] = ts; tot[1][(g0 + cgi) * E16 + e] = tq;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int cpg = C / G;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     float s = 0.f, q = 0.f;
-    for (int c = 0; c < cpg; ++c) { s += sm[g * cpg + c]; q += sm[C + g * cpg + c]; }
+    for (int c = 0; c < cpg; ++c) { s += tot[0][g * cpg + c]; q += tot[1][g * cpg + c]; }
     const float cnt = (float)(p1 - p0) * cpg;
     const float mean = cnt > 0 ? s / cnt : 0.f;
     float m2 = q - s * mean;
@@ -51,22 +75,43 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     o[0] = cnt; o[1] = mean; o[2] = m2;
   }
 }
-// stats[n][g] = (mean, rstd)
-__global__ void gn_finalize_kernel(const float* __restrict__ part, int nchunks, int G, float eps, float* __restrict__ stats) {
+// stats[n][g] = (mean, rstd): Chan's parallel merge of the chunk statistics; 16 threads per group, then a fixed-order merge
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunks, int G, float eps,
+                                                          float* __restrict__ stats) {
+  __shared__ float sc[256], sme[256], sm2[256];
   const int n = blockIdx.x;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+  constexpr int PAR = 16;
+  const int gl = threadIdx.x / PAR, pr = threadIdx.x % PAR;          // 16 groups per pass
+  for (int g0 = 0; g0 < G; g0 += 256 / PAR) {
+    const int g = g0 + gl;
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int c = 0; c < nchunks; ++c) {
-      const float* o = part + (((long)n * nchunks + c) * G + g) * 3;
-      const float cb = o[0];
-      if (cb <= 0.f) continue;
-      const float delta = o[1] - mean, tot = cnt + cb;
-      mean += delta * cb / tot;
-      m2 += o[2] + delta * delta * cnt * cb / tot;
-      cnt = tot;
+    if (g < G) {
+      for (int c = pr; c < nchunks; c += PAR) {
+        const float* o = part + (((long)n * nchunks + c) * G + g) * 3;
+        const float cb = o[0];
+        if (cb <= 0.f) continue;
+        const float delta = o[1] - mean, tot = cnt + cb;
+        mean += delta * cb / tot;
+        m2 += o[2] + delta * delta * cnt * cb / tot;
+        cnt = tot;
+      }
     }
-    stats[((long)n * G + g) * 2] = mean;
-    stats[((long)n * G + g) * 2 + 1] = rsqrtf(m2 / cnt + eps);     // biased variance, as torch group_norm
+    sc[threadIdx.x] = cnt; sme[threadIdx.x] = mean; sm2[threadIdx.x] = m2;
+    __syncthreads();
+    if (pr == 0 && g < G) {
+      float C0 = 0.f, M0 = 0.f, Q0 = 0.f;
+      for (int k = 0; k < PAR; ++k) {
+        const float cb = sc[gl * PAR + k];
+        if (cb <= 0.f) continue;
+        const float delta = sme[gl * PAR + k] - M0, tot = C0 + cb;
+        M0 += delta * cb / tot;
+        Q0 += sm2[gl * PAR + k] + delta * delta * C0 * cb / tot;
+        C0 = tot;
+      }
+      stats[((long)n * G + g) * 2] = M0;
+      stats[((long)n * G + g) * 2 + 1] = rsqrtf(Q0 / C0 + eps);     // biased variance, as torch group_norm
+    }
+    __syncthreads();
   }
 }
 struct NormApply {
@@ -77,45 +122,61 @@ struct NormApply {
   const void* mod_gamma; const void* mod_beta; int ld_mod;   // SPADE: T [N*S][ld_mod]; y = xhat*(1+mg)+mb
   const void* res; int ld_res;     // optional residual added before the activation
   int act;
+  int pos_per_block;
 };
+// grid (chunks, N): a block normalises pos_per_block positions of ONE sample, so the per-channel scale / shift
+// (rstd*gamma, beta - mean*rstd*gamma) are built once in LDS and the inner loop is one FMA per element, no divisions.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
   constexpr int E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
-  const int cvec = a.C / E16;
-  const long total = (long)a.N * a.S * cvec;
+  __shared__ float sscale[4096], sshift[4096];
+  const int n = blockIdx.y;
   const int cpg = a.C / a.G;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % cvec);
-    const long m = i / cvec;
-    const int n = (int)(m / a.S);
-    const frag_t v = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cc * E16);
-    frag_t r, mg, mb;
-    if (a.res) r = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.res) + m * a.ld_res + cc * E16);
-    if (a.mod_gamma) {
-      mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + m * a.ld_mod + cc * E16);
-      mb = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_beta) + m * a.ld_mod + cc * E16);
-    }
-    float o[E16];
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    const int g = c / cpg;
+    const float mean = a.stats[((long)n * a.G + g) * 2], rstd = a.stats[((long)n * a.G + g) * 2 + 1];
+    const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+    sscale[c] = rstd * gm; sshift[c] = bt - mean * rstd * gm;
+  }
+  __syncthreads();
+  const int cvec = a.C / E16;
+  const int p0 = blockIdx.x * a.pos_per_block, p1 = min(a.S, p0 + a.pos_per_block);
+  for (int g0 = 0; g0 < cvec; g0 += 256) {
+    const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
+    const int rp = 256 / groups;
+    const int cc = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
+    if (rr >= rp) continue;
+    float sc[E16], sh[E16];
 #pragma unroll
-    for (int e = 0; e < E16; ++e) {
-      const int c = cc * E16 + e, g = c / cpg;
-      const float mean = a.stats[((long)n * a.G + g) * 2], rstd = a.stats[((long)n * a.G + g) * 2 + 1];
-      float f = (ET<T>::to_f32(v[e]) - mean) * rstd;
-      if (a.gamma) f = f * a.gamma[c] + a.beta[c];
-      if (a.mod_gamma) f = f * (1.f + ET<T>::to_f32(mg[e])) + ET<T>::to_f32(mb[e]);
-      if (a.res) f += ET<T>::to_f32(r[e]);
-      o[e] = act_apply(a.act, f);
-    }
-    if (a.y_f32) {
-      float* yp = reinterpret_cast<float*>(a.y) + m * a.ldy + cc * E16;
+    for (int e = 0; e < E16; ++e) { sc[e] = sscale[cc * E16 + e]; sh[e] = sshift[cc * E16 + e]; }
+    for (int p = p0 + rr; p < p1; p += rp) {
+      const long m = (long)n * a.S + p;
+      const frag_t v = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cc * E16);
+      frag_t r, mg, mb;
+      if (a.res) r = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.res) + m * a.ld_res + cc * E16);
+      if (a.mod_gamma) {
+        mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + m * a.ld_mod + cc * E16);
+        mb = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_beta) + m * a.ld_mod + cc * E16);
+      }
+      float o[E16];
 #pragma unroll
-      for (int e = 0; e < E16; ++e) yp[e] = o[e];
-    } else {
-      frag_t w;
+      for (int e = 0; e < E16; ++e) {
+        float f = ET<T>::to_f32(v[e]) * sc[e] + sh[e];
+        if (a.mod_gamma) f = f * (1.f + ET<T>::to_f32(mg[e])) + ET<T>::to_f32(mb[e]);
+        if (a.res) f += ET<T>::to_f32(r[e]);
+        o[e] = act_apply(a.act, f);
+      }
+      if (a.y_f32) {
+        float* yp = reinterpret_cast<float*>(a.y) + m * a.ldy + cc * E16;
 #pragma unroll
-      for (int e = 0; e < E16; ++e) w[e] = ET<T>::from_f32(o[e]);
-      *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.y) + m * a.ldy + cc * E16) = w;
+        for (int e = 0; e < E16; ++e) yp[e] = o[e];
+      } else {
+        frag_t w;
+#pragma unroll
+        for (int e = 0; e < E16; ++e) w[e] = ET<T>::from_f32(o[e]);
+        *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.y) + m * a.ldy + cc * E16) = w;
+      }
     }
   }
 }
@@ -238,10 +299,10 @@ extern "C" int ipoke_groupnorm_stats(const void* x, int ldx, int N, int S, int C
   float* stats = part + (int64_t)N * nchunks * G * 3;
   hipStream_t s = STREAM(stream);
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, N), dim3(256), 2 * C * sizeof(float), s, (const bf16_t*)x, S, ldx, C, G, ppb, part),
-    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, N), dim3(256), 2 * C * sizeof(float), s, (const float*)x, S, ldx, C, G, ppb, part));
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, N), dim3(256), 0, s, (const bf16_t*)x, S, ldx, C, G, ppb, part),
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, N), dim3(256), 0, s, (const float*)x, S, ldx, C, G, ppb, part));
   IPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(64), 0, s, part, nchunks, G, eps, stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, nchunks, G, eps, stats);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
@@ -258,19 +319,20 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
   float* stats = part + (int64_t)d->N * nchunks * d->G * 3;
   hipStream_t s = STREAM(stream);
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, d->N), dim3(256), 2 * d->C * sizeof(float), s, (const bf16_t*)d->x, d->S, d->ldx, d->C, d->G, ppb, part),
-    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, d->N), dim3(256), 2 * d->C * sizeof(float), s, (const float*)d->x, d->S, d->ldx, d->C, d->G, ppb, part));
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, d->N), dim3(256), 0, s, (const bf16_t*)d->x, d->S, d->ldx, d->C, d->G, ppb, part),
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, d->N), dim3(256), 0, s, (const float*)d->x, d->S, d->ldx, d->C, d->G, ppb, part));
   IPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->N), dim3(64), 0, s, part, nchunks, d->G, d->eps, stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->N), dim3(256), 0, s, part, nchunks, d->G, d->eps, stats);
   IPK_LAUNCH_CHECK();
   NormApply a;
   a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.y_f32 = d->y_f32; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
   a.stats = stats; a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = d->mod_gamma; a.mod_beta = d->mod_beta; a.ld_mod = d->ld_mod;
   a.res = d->res; a.ld_res = d->ld_res; a.act = d->act;
-  const long total = (long)d->N * d->S * (d->C / e16);
+  a.pos_per_block = 256;
+  const int achunks = (d->S + a.pos_per_block - 1) / a.pos_per_block;
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid1d(total)), dim3(256), 0, s, a),
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid1d(total)), dim3(256), 0, s, a));
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(achunks, d->N), dim3(256), 0, s, a),
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(achunks, d->N), dim3(256), 0, s, a));
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
