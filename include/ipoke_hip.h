@@ -100,6 +100,8 @@ typedef struct {
   int32_t Kc_store;                      /* channels per tap written to dW (0: Kc_real); < Kc_real when A carries zero padding */
   int64_t split_stride;                  /* with splitm > 1: != 0 -> slice z of the reduction is *stored* to dW + z*split_stride
                                             (deterministic; the caller sums the splitm slabs, e.g. ipoke_reduce_rows), 0 -> atomics */
+  int32_t max_workgroups;                /* > 0: issue the output tiles in launches of at most this many workgroups, so that a
+                                            weight gradient running on a side stream never holds every CU of the chip */
 } ipoke_wgrad_desc;
 
 int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream);

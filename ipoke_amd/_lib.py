@@ -37,7 +37,7 @@ class WgradDesc(Structure):
         ("a_coff", c_int32), ("Kc_real", c_int32), ("Kc", c_int32),
         ("dY", c_void_p), ("ldy", c_int32), ("y_coff", c_int32), ("Nout", c_int32),
         ("dW", c_void_p), ("w_sn", c_int64), ("w_sc", c_int64), ("w_st", c_int64),
-        ("accumulate", c_int32), ("splitm", c_int32), ("Kc_store", c_int32), ("split_stride", c_int64)]
+        ("accumulate", c_int32), ("splitm", c_int32), ("Kc_store", c_int32), ("split_stride", c_int64), ("max_workgroups", c_int32)]
 
 
 class AffineDesc(Structure):

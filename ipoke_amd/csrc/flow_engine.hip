@@ -994,10 +994,14 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
         const void* h1 = c.at<void>(op.ws_a); const void* h2 = c.at<void>(op.ws_b);
         const void* dprm = c.at<void>(op.ws_d); const void* dp2 = c.at<void>(op.ws_e); const void* dp1 = c.at<void>(op.ws_f);
         ipoke_wgrad_desc w;
+        // cap on workgroups per weight-gradient launch (leaving CUs to the chain): measured 79.6 ms uncapped, 81.0 at 128,
+        // 88.7 at 96 -- the side stream becomes the critical path, so off by default
+        static const int tn_cap = getenv("IPOKE_TN_MAX_WGS") ? atoi(getenv("IPOKE_TN_MAX_WGS")) : 0;
         auto base8 = [&](int k, int pad) {
           std::memset(&w, 0, sizeof(w));
           w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = w.kw = k;
           w.sd = w.sh = w.sw = 1; w.ph = w.pw = pad;
+          w.max_workgroups = f->use_side ? tn_cap : 0;
         };
         // conv3 (effective weight; weight-norm backward runs at the end)
         base8(3, 1);

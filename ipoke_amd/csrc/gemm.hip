@@ -47,6 +47,7 @@ struct TnParams {
   int splitm, mb_per_split, rows_fixed, Kc_store;
   int tiles_n, tiles_k;
   long split_stride;   // > 0: split z stores its slab at dW + z*split_stride instead of atomics
+  int tile0, max_wgs;  // first output tile of this launch / cap on workgroups per launch (0: none)
   int ablate;          // developer experiment (IPOKE_TN_ABLATE): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
 };
 
@@ -587,7 +588,8 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const GeomDev& g = p.g;
-  const int tn = blockIdx.x % p.tiles_n, tk = blockIdx.x / p.tiles_n;
+  const int tile = (int)blockIdx.x + p.tile0;
+  const int tn = tile % p.tiles_n, tk = tile / p.tiles_n;
   const int n0 = tn * TN_, k0 = tk * TK_;
   const int z = blockIdx.y;
   const int nmb_total = (g.M + RM - 1) / RM;
@@ -991,7 +993,8 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn2 = wave >> 2, wk = wave & 3;     // wave tile: 64 (n) x 32 (k)
   const GeomDev& g = p.g;
-  const int tn = blockIdx.x % p.tiles_n, tk = blockIdx.x / p.tiles_n;
+  const int tile = (int)blockIdx.x + p.tile0;
+  const int tn = tile % p.tiles_n, tk = tile / p.tiles_n;
   const int n0 = tn * 128, k0 = tk * 128;
   const int z = blockIdx.y;
   const int nmb_total = (g.M + RM - 1) / RM;
@@ -1162,9 +1165,14 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     auto kern = igemm_tn_glds_kernel<NST>;
     static bool attr_done2 = false;
     if (!attr_done2) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2 = true; }
-    dim3 grid2((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, (unsigned)nbatch);
-    hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, s, p);
-    IPK_LAUNCH_CHECK();
+    const int ntiles = p.tiles_n * p.tiles_k;
+    const int cap = p.max_wgs > 0 ? p.max_wgs : ntiles;
+    for (int t0 = 0; t0 < ntiles; t0 += cap) {
+      p.tile0 = t0;
+      dim3 grid2((unsigned)std::min(cap, ntiles - t0), (unsigned)p.splitm, (unsigned)nbatch);
+      hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, s, p);
+      IPK_LAUNCH_CHECK();
+    }
     return IPOKE_OK;
   }
   static const int nr = getenv("IPOKE_TN_NR") ? atoi(getenv("IPOKE_TN_NR")) : 2;   // measured: 2 stages in flight beat 4 (54 vs 61 us at the NICE conv2 shape)
@@ -1253,6 +1261,7 @@ static int fill_tn(TnParams& p, const ipoke_wgrad_desc* d, int dtype, bool batch
   p.dW = d->dW; p.w_sn = d->w_sn; p.w_sc = d->w_sc; p.w_st = d->w_st; p.accumulate = d->accumulate;
   p.splitm = d->splitm < 1 ? 1 : d->splitm;
   p.split_stride = d->split_stride;
+  p.tile0 = 0; p.max_wgs = d->max_workgroups;
   IPK_REQUIRE(p.split_stride >= 0 && !(p.split_stride > 0 && d->accumulate), "split slabs are stored, not accumulated");
   p.Kc_store = d->Kc_store > 0 ? d->Kc_store : d->Kc_real;
   IPK_REQUIRE(p.Kc_store <= d->Kc_real, "Kc_store exceeds Kc_real");
