@@ -340,7 +340,11 @@ typedef struct {
   float* dgamma; float* dbeta;           /* [C] fp32 or NULL                                         */
   int32_t act;
   float* workspace;                      /* ipoke_groupnorm_bwd_workspace_floats(N, S, C, G) floats  */
+  const float* stats;                    /* optional [N][G][2] (mean, rstd) kept from the forward pass (the tail of the forward
+                                            workspace, see ipoke_groupnorm_stats_offset); NULL: recomputed from x */
 } ipoke_norm_bwd_desc;
+/* float offset of the (mean, rstd) table inside the workspace ipoke_groupnorm / ipoke_groupnorm_stats just filled */
+int64_t ipoke_groupnorm_stats_offset(int N, int S, int G);
 int64_t ipoke_groupnorm_bwd_workspace_floats(int N, int S, int C, int G);
 int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void* stream);
 /* out[:, :C] = dy * act'(y), out[:, C:Cpad] = 0   (backward of an activation fused into a conv / add epilogue) */

@@ -52,7 +52,7 @@ class NormBwdDesc(Structure):
                 ("dmod_gamma", c_void_p), ("dmod_beta", c_void_p), ("ld_dmod", c_int32),
                 ("N", c_int32), ("S", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
                 ("gamma", c_void_p), ("beta", c_void_p), ("mod_gamma", c_void_p), ("ld_mod", c_int32),
-                ("dgamma", c_void_p), ("dbeta", c_void_p), ("act", c_int32), ("workspace", c_void_p)]
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("act", c_int32), ("workspace", c_void_p), ("stats", c_void_p)]
 
 
 class McfDesc(Structure):
@@ -130,6 +130,7 @@ SIGNATURES = {
     "ipoke_cl_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_nchw_to_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_groupnorm_stats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
+    "ipoke_groupnorm_stats_offset": (c_int64, [c_int, c_int, c_int]),
     "ipoke_groupnorm_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "ipoke_groupnorm_bwd": (c_int, [POINTER(NormBwdDesc), c_int, _P]),
     "ipoke_act_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, _P]),

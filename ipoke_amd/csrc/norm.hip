@@ -288,6 +288,11 @@ extern "C" int64_t ipoke_groupnorm_workspace_floats(int N, int S, int G) {
   return (int64_t)N * nchunks * G * 3 + (int64_t)N * G * 2;
 }
 
+extern "C" int64_t ipoke_groupnorm_stats_offset(int N, int S, int G) {
+  const int ppb = 128;
+  return (int64_t)N * ((S + ppb - 1) / ppb) * G * 3;
+}
+
 extern "C" int ipoke_groupnorm_stats(const void* x, int ldx, int N, int S, int C, int G, float eps, float* workspace, int dtype,
                                      void* stream) {
   IPK_REQUIRE(x && workspace && C % G == 0, "bad arguments");

@@ -101,92 +101,161 @@ __device__ __forceinline__ float norm_dw(const NormBwd& a, long m, int c) {
   if (a.act == IPOKE_ACT_NONE) return g;
   return g * act_grad_from_out(a.act, ET<T>::to_f32(reinterpret_cast<const T*>(a.y)[m * a.ldy + c]));
 }
-// pass 1: per (n, chunk) and channel: sum_p du, sum_p du*xhat
+// pass 1: per (n, chunk) and channel: sum_p du, sum_p du*xhat.  Thread (rr, cg) owns the E16 channels of column group cg
+// over rows rr, rr + rows_par, ... (16-byte loads, register partial sums, one fixed-order LDS reduction).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const NormBwd a) {
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  __shared__ float sm[2][256 * E16];
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int p0 = chunk * a.pos_per_block, p1 = min(a.S, p0 + a.pos_per_block);
   const int cpg = a.C / a.G;
-  extern __shared__ float sm[];        // [2][rows_par][cols] scratch
-  for (int c0 = 0; c0 < a.C; c0 += blockDim.x) {
-    const int cols = a.C - c0 < (int)blockDim.x ? a.C - c0 : (int)blockDim.x;
-    const int rp = blockDim.x / cols > 0 ? blockDim.x / cols : 1;
-    const int cl = threadIdx.x % cols, rr = threadIdx.x / cols, c = c0 + cl;
-    float s1 = 0.f, s2 = 0.f;
+  const int cvec = a.C / E16;
+  for (int g0 = 0; g0 < cvec; g0 += 256) {
+    const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
+    const int rp = 256 / groups;
+    const int cg = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
+    float s1[E16], s2[E16], mean[E16], rstd[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) {
+      s1[e] = 0.f; s2[e] = 0.f;
+      const int g = (cg * E16 + e) / cpg;
+      mean[e] = a.stats[((long)n * a.G + g) * 2]; rstd[e] = a.stats[((long)n * a.G + g) * 2 + 1];
+    }
     if (rr < rp) {
-      const int g = c / cpg;
-      const float mean = a.stats[((long)n * a.G + g) * 2], rstd = a.stats[((long)n * a.G + g) * 2 + 1];
       for (int p = p0 + rr; p < p1; p += rp) {
         const long m = (long)n * a.S + p;
-        float du = norm_dw<T>(a, m, c);
-        if (a.mod_gamma) du *= 1.f + ET<T>::to_f32(reinterpret_cast<const T*>(a.mod_gamma)[m * a.ld_mod + c]);
-        const float xh = (ET<T>::to_f32(reinterpret_cast<const T*>(a.x)[m * a.ldx + c]) - mean) * rstd;
-        s1 += du; s2 += du * xh;
+        const frag_t gy = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.dy) + m * a.lddy + cg * E16);
+        const frag_t xv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
+        frag_t yv, mg;
+        if (a.act != IPOKE_ACT_NONE) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
+        if (a.mod_gamma) mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + m * a.ld_mod + cg * E16);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) {
+          float du = ET<T>::to_f32(gy[e]);
+          if (a.act != IPOKE_ACT_NONE) du *= act_grad_from_out(a.act, ET<T>::to_f32(yv[e]));
+          if (a.mod_gamma) du *= 1.f + ET<T>::to_f32(mg[e]);
+          const float xh = (ET<T>::to_f32(xv[e]) - mean[e]) * rstd[e];
+          s1[e] += du; s2[e] += du * xh;
+        }
       }
     }
-    sm[threadIdx.x] = rr < rp ? s1 : 0.f;
-    sm[blockDim.x + threadIdx.x] = rr < rp ? s2 : 0.f;
+#pragma unroll
+    for (int e = 0; e < E16; ++e) {
+      sm[0][threadIdx.x * E16 + e] = rr < rp ? s1[e] : 0.f;
+      sm[1][threadIdx.x * E16 + e] = rr < rp ? s2[e] : 0.f;
+    }
     __syncthreads();
-    if (threadIdx.x < cols) {
+    for (int i = threadIdx.x; i < groups * E16; i += 256) {
+      const int cgi = i / E16, e = i - cgi * E16;
       float t1 = 0.f, t2 = 0.f;
-      for (int k = 0; k < rp; ++k) { t1 += sm[k * cols + threadIdx.x]; t2 += sm[blockDim.x + k * cols + threadIdx.x]; }
+      for (int k = 0; k < rp; ++k) { t1 += sm[0][(k * groups + cgi) * E16 + e]; t2 += sm[1][(k * groups + cgi) * E16 + e]; }
       float* o = a.part + (((long)n * a.nchunks + chunk) * 2) * a.C;
-      o[c0 + threadIdx.x] = t1; o[a.C + c0 + threadIdx.x] = t2;
+      o[(g0 + cgi) * E16 + e] = t1; o[a.C + (g0 + cgi) * E16 + e] = t2;
     }
     __syncthreads();
   }
 }
-// pass 2: per (n, g): S1 = sum_c gamma_c * sum du, S2 = sum_c gamma_c * sum du*xhat ; per channel dgamma/dbeta over n, chunks
-__global__ void gn_bwd_finalize_kernel(const NormBwd a, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int cpg = a.C / a.G;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid < a.N * a.G) {
-    const int n = tid / a.G, g = tid % a.G;
+// pass 2a: per (n, g): S1 = sum_c gamma_c * sum du, S2 = sum_c gamma_c * sum du*xhat.  One block per sample, 16 threads per group.
+__global__ __launch_bounds__(256) void gn_bwd_groupsum_kernel(const NormBwd a) {
+  __shared__ float r1[256], r2[256];
+  const int n = blockIdx.x, cpg = a.C / a.G;
+  constexpr int PAR = 16;
+  const int gl = threadIdx.x / PAR, pr = threadIdx.x % PAR;
+  for (int g0 = 0; g0 < a.G; g0 += 256 / PAR) {
+    const int g = g0 + gl;
     float S1 = 0.f, S2 = 0.f;
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-      const float* o = a.part + (((long)n * a.nchunks + ch) * 2) * a.C;
-      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    if (g < a.G) {
+      for (int k = pr; k < a.nchunks * cpg; k += PAR) {
+        const int ch = k / cpg, c = g * cpg + (k - ch * cpg);
+        const float* o = a.part + (((long)n * a.nchunks + ch) * 2) * a.C;
         const float gm = a.gamma ? a.gamma[c] : 1.f;
         S1 += gm * o[c]; S2 += gm * o[a.C + c];
       }
     }
-    a.gsum[(long)tid * 2] = S1; a.gsum[(long)tid * 2 + 1] = S2;
-  }
-  if (dgamma && tid < a.C) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int n = 0; n < a.N; ++n)
-      for (int ch = 0; ch < a.nchunks; ++ch) {
-        const float* o = a.part + (((long)n * a.nchunks + ch) * 2) * a.C;
-        t1 += o[tid]; t2 += o[a.C + tid];
-      }
-    dbeta[tid] = t1; dgamma[tid] = t2;
+    r1[threadIdx.x] = S1; r2[threadIdx.x] = S2;
+    __syncthreads();
+    if (pr == 0 && g < a.G) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int k = 0; k < PAR; ++k) { t1 += r1[gl * PAR + k]; t2 += r2[gl * PAR + k]; }
+      a.gsum[((long)n * a.G + g) * 2] = t1; a.gsum[((long)n * a.G + g) * 2 + 1] = t2;
+    }
+    __syncthreads();
   }
 }
-// pass 3: dx = rstd * (dxhat - (S1 + xhat*S2)/cnt), plus the residual / modulation gradients
+// pass 2b: dgamma / dbeta per channel over all samples and chunks; 16 channels x 16 row lanes per block
+__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const NormBwd a, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float r1[256], r2[256];
+  const int cl = threadIdx.x % 16, rl = threadIdx.x / 16;
+  const int c = blockIdx.x * 16 + cl;
+  float t1 = 0.f, t2 = 0.f;
+  if (c < a.C) {
+    for (int k = rl; k < a.N * a.nchunks; k += 16) {
+      const float* o = a.part + ((long)k * 2) * a.C;
+      t1 += o[c]; t2 += o[a.C + c];
+    }
+  }
+  r1[threadIdx.x] = t1; r2[threadIdx.x] = t2;
+  __syncthreads();
+  if (rl == 0 && c < a.C) {
+    float u1 = 0.f, u2 = 0.f;
+    for (int k = 0; k < 16; ++k) { u1 += r1[k * 16 + cl]; u2 += r2[k * 16 + cl]; }
+    dbeta[c] = u1; dgamma[c] = u2;
+  }
+}
+// pass 3: dx = rstd * (dxhat - (S1 + xhat*S2)/cnt), plus the residual / modulation gradients.  Grid (chunks, N): the
+// per-channel constants of the sample live in LDS, the inner loop is 16-byte loads / stores without divisions.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
-  const int cpg = a.C / a.G;
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  extern __shared__ float lds[];            // [6][C]: mean, rstd, gamma, beta, S1/cnt, S2/cnt
+  const int n = blockIdx.y, cpg = a.C / a.G, C = a.C;
   const float inv_cnt = 1.f / ((float)a.S * cpg);
-  const long total = (long)a.N * a.S * a.C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % a.C);
-    const long m = i / a.C;
-    const int n = (int)(m / a.S), g = c / cpg;
-    const float mean = a.stats[((long)n * a.G + g) * 2], rstd = a.stats[((long)n * a.G + g) * 2 + 1];
-    const float S1 = a.gsum[((long)n * a.G + g) * 2], S2 = a.gsum[((long)n * a.G + g) * 2 + 1];
-    const float dw = norm_dw<T>(a, m, c);
-    const float xh = (ET<T>::to_f32(reinterpret_cast<const T*>(a.x)[m * a.ldx + c]) - mean) * rstd;
-    float du = dw;
-    if (a.mod_gamma) {
-      const float mg = ET<T>::to_f32(reinterpret_cast<const T*>(a.mod_gamma)[m * a.ld_mod + c]);
-      du = dw * (1.f + mg);
-      const float u = a.gamma ? xh * a.gamma[c] + a.beta[c] : xh;
-      reinterpret_cast<T*>(a.dmg)[m * a.ld_dmod + c] = ET<T>::from_f32(dw * u);
-      reinterpret_cast<T*>(a.dmb)[m * a.ld_dmod + c] = ET<T>::from_f32(dw);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    lds[c] = a.stats[((long)n * a.G + g) * 2]; lds[C + c] = a.stats[((long)n * a.G + g) * 2 + 1];
+    lds[2 * C + c] = a.gamma ? a.gamma[c] : 1.f; lds[3 * C + c] = a.beta ? a.beta[c] : 0.f;
+    lds[4 * C + c] = a.gsum[((long)n * a.G + g) * 2] * inv_cnt; lds[5 * C + c] = a.gsum[((long)n * a.G + g) * 2 + 1] * inv_cnt;
+  }
+  __syncthreads();
+  const int cvec = C / E16;
+  const int p0 = blockIdx.x * a.pos_per_block, p1 = min(a.S, p0 + a.pos_per_block);
+  for (int g0 = 0; g0 < cvec; g0 += 256) {
+    const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
+    const int rp = 256 / groups;
+    const int cg = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
+    if (rr >= rp) continue;
+    for (int p = p0 + rr; p < p1; p += rp) {
+      const long m = (long)n * a.S + p;
+      const frag_t gy = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.dy) + m * a.lddy + cg * E16);
+      const frag_t xv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
+      frag_t yv, mg;
+      if (a.act != IPOKE_ACT_NONE) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
+      if (a.mod_gamma) mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + m * a.ld_mod + cg * E16);
+      frag_t odx, odw, odmg;
+#pragma unroll
+      for (int e = 0; e < E16; ++e) {
+        const int c = cg * E16 + e;
+        float dw = ET<T>::to_f32(gy[e]);
+        if (a.act != IPOKE_ACT_NONE) dw *= act_grad_from_out(a.act, ET<T>::to_f32(yv[e]));
+        const float xh = (ET<T>::to_f32(xv[e]) - lds[c]) * lds[C + c];
+        float du = dw;
+        if (a.mod_gamma) {
+          du = dw * (1.f + ET<T>::to_f32(mg[e]));
+          odmg[e] = ET<T>::from_f32(dw * (xh * lds[2 * C + c] + lds[3 * C + c]));
+        }
+        odw[e] = ET<T>::from_f32(dw);
+        odx[e] = ET<T>::from_f32(lds[C + c] * (du * lds[2 * C + c] - (lds[4 * C + c] + xh * lds[5 * C + c])));
+      }
+      *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dx) + m * a.lddx + cg * E16) = odx;
+      if (a.dres) *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dres) + m * a.lddres + cg * E16) = odw;
+      if (a.mod_gamma) {
+        *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dmg) + m * a.ld_dmod + cg * E16) = odmg;
+        *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dmb) + m * a.ld_dmod + cg * E16) = odw;
+      }
     }
-    if (a.dres) reinterpret_cast<T*>(a.dres)[m * a.lddres + c] = ET<T>::from_f32(dw);
-    const float dxh = a.gamma ? du * a.gamma[c] : du;
-    reinterpret_cast<T*>(a.dx)[m * a.lddx + c] = ET<T>::from_f32(rstd * (dxh - (S1 + xh * S2) * inv_cnt));
   }
 }
 
@@ -321,31 +390,41 @@ extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void
               "modulation gradients come as a pair, with the saved modulation");
   IPK_REQUIRE((d->dgamma == nullptr) == (d->dbeta == nullptr) && (!d->dgamma || d->gamma), "affine gradient pair");
   hipStream_t s = STREAM(stream);
-  // statistics of the saved input, exactly as in the forward pass
-  int rc = ipoke_groupnorm_stats(d->x, d->ldx, d->N, d->S, d->C, d->G, d->eps, d->workspace, dtype, stream);
-  if (rc) return rc;
+  const int e16 = dtype == IPOKE_BF16 ? 8 : 4;
+  IPK_REQUIRE(d->C % e16 == 0 && d->ldx % e16 == 0 && d->lddy % e16 == 0 && d->lddx % e16 == 0 && (!d->y || d->ldy % e16 == 0) &&
+              (!d->dres || d->lddres % e16 == 0) && (!d->mod_gamma || (d->ld_mod % e16 == 0 && d->ld_dmod % e16 == 0)) && d->C <= 4096,
+              "channels and pitches must be multiples of 16 bytes");
   const int ppb_f = 128, nch_f = (d->S + ppb_f - 1) / ppb_f;
   NormBwd a;
+  if (d->stats) {
+    a.stats = d->stats;                    // (mean, rstd) saved by the forward pass
+  } else {                                 // recomputed from the saved input, exactly as in the forward pass
+    int rc = ipoke_groupnorm_stats(d->x, d->ldx, d->N, d->S, d->C, d->G, d->eps, d->workspace, dtype, stream);
+    if (rc) return rc;
+    a.stats = d->workspace + (int64_t)d->N * nch_f * d->G * 3;
+  }
   a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.dy = d->dy; a.lddy = d->lddy;
   a.dx = d->dx; a.lddx = d->lddx; a.dres = d->dres; a.lddres = d->lddres; a.dmg = d->dmod_gamma; a.dmb = d->dmod_beta;
   a.ld_dmod = d->ld_dmod; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
-  a.stats = d->workspace + (int64_t)d->N * nch_f * d->G * 3;
   a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = d->mod_gamma; a.ld_mod = d->ld_mod; a.act = d->act;
   a.nchunks = (d->S + kNormBwdPos - 1) / kNormBwdPos; a.pos_per_block = kNormBwdPos;
   a.part = d->workspace + ipoke_groupnorm_workspace_floats(d->N, d->S, d->G);
   a.gsum = a.part + (int64_t)d->N * a.nchunks * 2 * d->C;
   IPK_REQUIRE(!a.gamma || a.beta || !a.mod_gamma, "SPADE with an affine norm needs beta");
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(a.nchunks, d->N), dim3(256), 2 * 256 * sizeof(float), s, a),
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(a.nchunks, d->N), dim3(256), 2 * 256 * sizeof(float), s, a));
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(a.nchunks, d->N), dim3(256), 0, s, a),
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(a.nchunks, d->N), dim3(256), 0, s, a));
   IPK_LAUNCH_CHECK();
-  const int nfin = d->N * d->G > d->C ? d->N * d->G : d->C;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nfin + 255) / 256), dim3(256), 0, s, a, d->dgamma, d->dbeta);
+  hipLaunchKernelGGL(gn_bwd_groupsum_kernel, dim3(d->N), dim3(256), 0, s, a);
   IPK_LAUNCH_CHECK();
-  const long total = (long)d->N * d->S * d->C;
+  if (d->dgamma) {
+    hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((d->C + 15) / 16), dim3(256), 0, s, a, d->dgamma, d->dbeta);
+    IPK_LAUNCH_CHECK();
+  }
+  const size_t lds = (size_t)6 * d->C * sizeof(float);
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid1d_b(total)), dim3(256), 0, s, a),
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid1d_b(total)), dim3(256), 0, s, a));
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(a.nchunks, d->N), dim3(256), lds, s, a),
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(a.nchunks, d->N), dim3(256), lds, s, a));
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -220,14 +220,16 @@ class _NormFn(torch.autograd.Function):
         check(_lib.lib().ipoke_groupnorm(byref(d), ops._dt(dt), _lib.current_stream()))
         if y.shape[1] > C:
             y[:, C:].zero_()
+        off = _lib.lib().ipoke_groupnorm_stats_offset(N, S, G)
+        stats = ws[off:off + N * G * 2].clone()               # (mean, rstd): kept for the backward pass
         ctx.meta = meta
-        ctx.save_for_backward(x_t, y, g32, b32, mg_t)
+        ctx.save_for_backward(x_t, y, g32, b32, mg_t, stats)
         ctx.has = (gamma is not None, mg_t is not None, res_t is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x_t, y, g32, b32, mg_t = ctx.saved_tensors
+        x_t, y, g32, b32, mg_t, stats = ctx.saved_tensors
         m = ctx.meta
         dt = m["dtype"]
         N, S, C, G = m["N"], m["S"], m["C"], m["G"]
@@ -252,6 +254,7 @@ class _NormFn(torch.autograd.Function):
             d.gamma = g32.data_ptr(); d.beta = b32.data_ptr(); d.dgamma = dgamma.data_ptr(); d.dbeta = dbeta.data_ptr()
         ws = _workspace(_lib.lib().ipoke_groupnorm_bwd_workspace_floats(N, S, C, G), dy.device, "normbwd")
         d.workspace = ws.data_ptr()
+        d.stats = stats.data_ptr()
         check(_lib.lib().ipoke_groupnorm_bwd(byref(d), ops._dt(dt), _lib.current_stream()))
         return dx, dgamma, dbeta, dmg, dmb, dres, None
 
