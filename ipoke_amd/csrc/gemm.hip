@@ -914,7 +914,12 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
   }
   static const int glds_mode = getenv("IPOKE_NT_GLDS") ? atoi(getenv("IPOKE_NT_GLDS")) : 1;
   if (glds_mode && !p.a_f32 && forced == 0) {
-    if (N <= 64) return launch_nt_glds<T, 4, 1, 1, 4, 4>(p, s);                     // 64 x 64, skinny N
+    if (N <= 64) {
+      static const int skinny = getenv("IPOKE_NT_SKINNY") ? atoi(getenv("IPOKE_NT_SKINNY")) : 0;
+      if (skinny == 1 && M % 128 == 0) return launch_nt_glds<T, 4, 2, 2, 2, 4, 1>(p, s);   // 128 x 64, 8 waves: half the weight re-reads
+      if (skinny == 2 && M % 128 == 0) return launch_nt_glds<T, 4, 2, 2, 2, 3, 2>(p, s);
+      return launch_nt_glds<T, 4, 1, 1, 4, 4>(p, s);                     // 64 x 64, skinny N
+    }
     if (glds_mode == 2) return launch_nt_glds<T, 2, 2, 4, 4, 4>(p, s);             // 128 x 128, 4 stages (128 KB LDS)
     if (glds_mode == 3) return launch_nt_glds<T, 2, 2, 2, 4, 4>(p, s);             // 64 x 128
     if (glds_mode == 4) return launch_nt_glds<T, 2, 2, 2, 2, 4>(p, s);             // 64 x 64
