@@ -311,7 +311,7 @@ def main():
             "step_hbm_frac_12P": round(12 * P_bytes / (ms * 1e-3) / 8e12, 4),
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_clips, args.cpu_timeout)
         print(json.dumps(line), flush=True)
     D.barrier()
