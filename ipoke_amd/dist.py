@@ -19,7 +19,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # IPOKE_DIST_BACKEND=gloo: test hook -- several ranks sharing one GPU (RCCL needs one GPU per rank)
+            backend = os.environ.get("IPOKE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("IPOKE_DIST_SINGLE_GPU") == "1":
+            local = 0
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -57,8 +60,10 @@ def allreduce_async(t):
 
 
 def broadcast_(t, src=0):
+    """In-place broadcast (also of parameter buffers that require grad: the collective works on the detached storage)."""
     if world_size() > 1:
-        dist.broadcast(t, src=src)
+        with torch.no_grad():
+            dist.broadcast(t.detach(), src=src)
     return t
 
 

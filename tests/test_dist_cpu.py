@@ -23,7 +23,7 @@ def _worker(rank, world, port, out):
     D.allreduce_flat_(flat, n_buckets=8)
     expect = torch.arange(n, dtype=torch.float32) * sum(range(1, world + 1))
     ok_sum = torch.equal(flat, expect)
-    p = torch.full((17,), float(rank))
+    p = torch.full((17,), float(rank)).requires_grad_(True)      # parameter buffers require grad
     D.broadcast_(p, src=0)
     ok_bcast = bool((p == 0).all())
     mx = D.max_over_ranks(1.0 + rank, torch.device("cpu"))

@@ -41,6 +41,7 @@ def _worker(rank, world, port, overlap, out):
              "poke": [torch.zeros(2, 2, 64, 64).cuda(), torch.zeros(2, 5, 2, dtype=torch.int64).cuda()]}
     trainer = SecondStageTrainer(model, n_grad_buckets=3, overlap=overlap)
     assert trainer.overlap == overlap
+    trainer.sync_initial_state(batch)             # as bench.py does: init pass + broadcast of rank 0's parameters
     losses = [trainer.train_step(batch, i).item() for i in range(3)]
     torch.cuda.synchronize()
     p = model.flow.flat_params.detach().cpu()
