@@ -281,11 +281,11 @@ def main():
     trainer.sync_initial_state(batch)                 # data-dependent init on rank 0's statistics, then broadcast
     randomise_couplings(model)
     for i in range(args.warmup):
-        trainer.train_step(batch, i)
+        trainer.train_step(batch, i, next_batch=batch)
     D.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = trainer.train_step(batch, args.warmup + i)
+        loss = trainer.train_step(batch, args.warmup + i, next_batch=batch)
     torch.cuda.synchronize(); D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     loss_val = float(loss.item())

@@ -105,7 +105,7 @@ _norm_ws = {}
 
 def _workspace(N, S, G, device):
     n = _lib.lib().ipoke_groupnorm_workspace_floats(N, S, G)
-    key = (device, )
+    key = (device, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)   # one scratch buffer per stream
     buf = _norm_ws.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=device)

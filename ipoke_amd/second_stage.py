@@ -182,8 +182,25 @@ class PokeMotionModel(nn.Module):
             length = X.size(1) - 1
         return self.first_stage_model.decode(motion, X[:, 0], length)
 
+    def prefetch_flow_input(self, batch, stream):
+        """Run the frozen encoders for ``batch`` on ``stream`` now; the next ``forward_density(batch)`` (same object) picks the
+        result up.  The encoders do not depend on the flow's parameters, so this overlaps with the current step's
+        backward pass (what a data-loader worker does for the reference's frozen first stage)."""
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            flow_input, cond = self.make_flow_input(batch)
+            ev = torch.cuda.Event(); ev.record(stream)
+        flow_input.record_stream(cur); cond.record_stream(cur)
+        self._prefetched = (batch, flow_input, cond, ev)
+
     def forward_density(self, batch):
-        flow_input, cond = self.make_flow_input(batch)
+        pf = getattr(self, "_prefetched", None)
+        if pf is not None and pf[0] is batch:
+            self._prefetched = None
+            torch.cuda.current_stream().wait_event(pf[3])
+            flow_input, cond = pf[1], pf[2]
+        else:
+            flow_input, cond = self.make_flow_input(batch)
         out, logdet = self.flow(flow_input.detach(), cond, reverse=False)
         return out, logdet
 

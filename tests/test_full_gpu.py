@@ -133,3 +133,43 @@ def test_forward_sample_with_injected_latent(golden, dtype):
     print(f"[{dtype}] sample: motion err {e_m:.3e}, video max err {e_v.max().item():.3e} mean {e_v.mean().item():.3e}")
     assert e_m <= (1e-4 if dtype == "f32" else 0.1)
     assert e_v.max().item() <= (5e-4 if dtype == "f32" else 0.2) and e_v.mean().item() <= (2e-5 if dtype == "f32" else 2e-2)
+
+
+def test_encoder_prefetch_does_not_change_training():
+    """train_step(batch, next_batch=...) runs the next batch's frozen encoders on a side stream during the current backward:
+    same losses and parameters as the plain loop (the encoder's CPU-generator draws keep their order)."""
+    from ipoke_amd import configs
+    from ipoke_amd.second_stage import PokeMotionModel
+    from ipoke_amd.trainer import SecondStageTrainer
+    from ipoke_amd.utils.detfill import deterministic_fill_
+
+    def run(prefetch):
+        torch.manual_seed(99)
+        arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+        arch["flow_mid_channels_factor"] = 2
+        model = PokeMotionModel(configs.second_stage_config(64, 32, 16, batch_size=2, arch=arch), dirs={}, dtype="f32",
+                                device="cuda:0", max_batch=2)
+        for part, pfx in ((model.first_stage_model, "first_stage."), (model.poke_embedder, "poke_embedder."),
+                          (model.conditioner, "conditioner."), (model.flow, "flow.")):
+            deterministic_fill_(part, prefix=pfx)
+        model.flow.sync_buffers()
+        batches = []
+        for k in range(3):
+            g = torch.Generator().manual_seed(20 + k)
+            batches.append({"images": (torch.rand(2, 16, 3, 64, 64, generator=g) * 2 - 1).cuda(),
+                            "flow": torch.randn(2, 2, 64, 64, generator=g).cuda(),
+                            "poke": [torch.zeros(2, 2, 64, 64).cuda(), torch.zeros(2, 5, 2, dtype=torch.int64).cuda()]})
+        tr = SecondStageTrainer(model)
+        if not prefetch:
+            tr.prefetch_stream = None
+        losses = []
+        for k in range(3):
+            nxt = batches[k + 1] if k + 1 < 3 else None
+            losses.append(tr.train_step(batches[k], k, next_batch=nxt).item())
+        torch.cuda.synchronize()
+        return losses, model.flow.flat_params.detach().cpu()[::499].clone()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert all(abs(a - b) <= 2e-5 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
+    assert (p0 - p1).abs().max().item() <= 2e-5 * p0.abs().max().item()
