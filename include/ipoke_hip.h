@@ -168,6 +168,10 @@ int ipoke_flow_nll(const float* z_state, const float* logdet, int B, int P, int 
 /* torch.optim.Adam(amsgrad=True) step over a flat fp32 buffer (second_stage_video.py:648-650) */
 int ipoke_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1,
                             float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* the same with a cap on the persistent grid (0: default), for an update issued underneath other work */
+int ipoke_adam_amsgrad_step_grid(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks,
+                                 void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused masked convolutional flow (macow2.py:25-288, macow_utils.py:407-499).

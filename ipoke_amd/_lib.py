@@ -111,6 +111,8 @@ SIGNATURES = {
     "ipoke_flow_nll": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     "ipoke_adam_amsgrad_step": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
                                         c_float, _P]),
+    "ipoke_adam_amsgrad_step_grid": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
+                                             c_float, c_int, _P]),
     "ipoke_mcf_shadow_dims": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
     "ipoke_mcf_fwd": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_mcf_inv": (c_int, [POINTER(McfDesc), c_int, _P]),

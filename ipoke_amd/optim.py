@@ -54,10 +54,10 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         g = self.param_groups[0]
         flat, grads = self.flow.flat_params, self.flow.flat_grads
         sl = slice(begin, end)
-        check(_lib.lib().ipoke_adam_amsgrad_step(
+        check(_lib.lib().ipoke_adam_amsgrad_step_grid(
             ptr(flat[sl]), ptr(grads[sl]), ptr(self.exp_avg[sl]), ptr(self.exp_avg_sq[sl]), ptr(self.max_exp_avg_sq[sl]), end - begin,
             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-            self.steps, float(grad_scale), _lib.current_stream()))
+            self.steps, float(grad_scale), 256, _lib.current_stream()))      # one workgroup per CU: runs underneath backward
         self._covered += end - begin
 
     def finish_step(self):

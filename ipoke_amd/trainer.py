@@ -20,10 +20,9 @@ class SecondStageTrainer:
         self.n_grad_buckets = n_grad_buckets
         if overlap is None:
             overlap = os.environ.get("IPOKE_NO_OVERLAP", "0") != "1"
-        # one GPU: measured 88.2 ms with the per-group Adam updates running underneath the backward chain vs 87.1 ms with the
-        # single update after it (the HBM-bound update slows the chain by as much as it hides) -> piecewise only when
-        # there is an exchange to overlap
-        self.overlap = bool(overlap) and self.world > 1
+        # Also on one GPU (no exchange): the per-group Adam updates run underneath the backward chain with a one-workgroup-
+        # per-CU grid (81.3 vs 82.3 ms; with the stand-alone 4096-workgroup grid they starve the chain: 85.2 ms).
+        self.overlap = bool(overlap) and torch.cuda.is_available()
         if self.overlap:
             self.ready_stream = torch.cuda.Stream()
             model.flow.engine.grad_ready_hook = (n_grad_buckets, self.ready_stream, self._grads_ready)
