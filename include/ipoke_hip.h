@@ -207,6 +207,10 @@ int ipoke_wn_job_size(void);
 /* block_job_dev: optional int32 [total_blocks] map block -> job (NULL: every block searches the job table) */
 int ipoke_relayout_multi(const float* params, void* shadow, const float* wn_scale, const void* jobs_dev, int njobs,
                          int total_blocks, const int32_t* block_job_dev, int dtype, void* stream);
+int ipoke_relayout_multi_range(const float* params, void* shadow, const float* wn_scale, const void* jobs_dev, int njobs,
+                               int block_begin, int nblocks, const int32_t* block_job_dev, int dtype, void* stream);
+int ipoke_wn_scale_multi_range(const float* params, float* scale, float* inv_norm, const void* jobs_dev, int job_begin, int njobs,
+                               int row_begin, int nrows, void* stream);
 int ipoke_wn_scale_multi(const float* params, float* scale, float* inv_norm, const void* jobs_dev, int njobs,
                          int total_rows, void* stream);
 int ipoke_wn_bwd_multi(const float* params, float* grads, const float* inv_norm, const void* jobs_dev, int njobs,
@@ -270,6 +274,9 @@ int ipoke_flow_init_forward(ipoke_flow* f, float* params, const int32_t* perm, c
 /* x = flow(z, cond, reverse=True)   (INN.py:475-476, macow2.py:901-920) */
 int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow, const float* z_nchw,
                        const float* cond_nchw, int B, float* x_nchw, void* workspace, void* stream);
+/* refresh only the shadows derived from the parameters in params[begin, end) (a range announced by
+ * ipoke_flow_backward_pieces, i.e. whole levels): lets the weight preparation follow the per-group optimizer update */
+int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* params, void* shadow, int64_t begin, int64_t end, void* stream);
 /* parameter gradients (written, not accumulated) and optionally d/dx, given d/d_out and d/d_logdet */
 int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
                         const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,

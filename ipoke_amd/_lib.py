@@ -142,6 +142,9 @@ SIGNATURES = {
     "ipoke_gru_gates_bwd": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P]),
+    "ipoke_relayout_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "ipoke_wn_scale_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_flow_prepare_weights_range": (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
     "ipoke_wn_bwd_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_flow_backward_pieces": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, GRAD_READY_FN, _P, _P]),
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),

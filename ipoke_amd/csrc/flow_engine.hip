@@ -634,6 +634,37 @@ extern "C" int ipoke_flow_prepare_weights(ipoke_flow* f, const float* params, vo
                               reinterpret_cast<const int32_t*>(f->d_rblockjob), f->cfg.dtype, stream);
 }
 
+extern "C" int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* params, void* shadow, int64_t begin, int64_t end,
+                                                void* stream) {
+  IPK_REQUIRE(f && params && shadow && begin >= 0 && end >= begin, "bad arguments");
+  { int rc0 = ensure_device(f); if (rc0) return rc0; }
+  float* wn_scale = reinterpret_cast<float*>(shadow);
+  float* wn_inv = wn_scale + align_up(f->wn_rows, 64);
+  // job tables are in parameter order: the jobs whose source tensor starts inside [begin, end) are contiguous
+  int w0 = 0, w1 = 0;
+  while (w0 < (int)f->wjobs.size() && f->wjobs[w0].v_off < begin) ++w0;
+  w1 = w0;
+  while (w1 < (int)f->wjobs.size() && f->wjobs[w1].v_off < end) ++w1;
+  if (w1 > w0) {
+    const int row0 = f->wjobs[w0].row_start;
+    const int row1 = w1 < (int)f->wjobs.size() ? f->wjobs[w1].row_start : (int)f->wn_rows;
+    int rc = ipoke_wn_scale_multi_range(params, wn_scale, wn_inv, f->d_wjobs, w0, w1 - w0, row0, row1 - row0, stream);
+    if (rc) return rc;
+  }
+  int j0 = 0, j1 = 0;
+  while (j0 < (int)f->rjobs.size() && f->rjobs[j0].src_off < begin) ++j0;
+  j1 = j0;
+  while (j1 < (int)f->rjobs.size() && f->rjobs[j1].src_off < end) ++j1;
+  if (j1 > j0) {
+    const int b0 = f->rjobs[j0].block_start;
+    const int b1 = j1 < (int)f->rjobs.size() ? f->rjobs[j1].block_start : f->rblocks;
+    void* sh = reinterpret_cast<unsigned char*>(shadow) + 2 * align_up(f->wn_rows, 64) * 4;
+    return ipoke_relayout_multi_range(params, sh, wn_scale, f->d_rjobs, (int)f->rjobs.size(), b0, b1 - b0,
+                                      reinterpret_cast<const int32_t*>(f->d_rblockjob), f->cfg.dtype, stream);
+  }
+  return IPOKE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Lanes: split the batch into up to n_lanes contiguous sample ranges, lane 0 on the caller's stream.
 static int make_lanes(const Ctx& full, int want, std::vector<Ctx>& lanes) {

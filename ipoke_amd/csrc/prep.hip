@@ -99,20 +99,21 @@ __device__ __forceinline__ void relayout_tile(const RelayoutJob& j, const float*
 template <typename T>
 __global__ __launch_bounds__(256) void relayout_kernel(const float* __restrict__ params, T* __restrict__ shadow,
                                                        const float* __restrict__ wn_scale, const RelayoutJob* __restrict__ jobs,
-                                                       int njobs, const int* __restrict__ block_job) {
+                                                       int njobs, const int* __restrict__ block_job, int block_base) {
   __shared__ __attribute__((aligned(16))) float tile[32 * 33 * 9];   // [n_l][tap][k_l], k pitch TE+1 (>= 64*65)
+  const int bid = (int)blockIdx.x + block_base;          // global block id (a launch may cover a sub-range of the jobs)
   int lo = 0;
   if (block_job) {
-    lo = block_job[blockIdx.x];
+    lo = block_job[bid];
   } else {                     // locate the job of this block (block_start is ascending)
     int hi = njobs - 1;
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+      if (jobs[mid].block_start <= bid) lo = mid; else hi = mid - 1;
     }
   }
   const RelayoutJob j = jobs[lo];
-  const int t_id = (int)blockIdx.x - j.block_start;
+  const int t_id = bid - j.block_start;
   const int n0 = (t_id / j.tiles_k) * j.tile, k0 = (t_id % j.tiles_k) * j.tile;
   if (j.taps == 1) relayout_tile<T, 1, 64>(j, params, shadow, wn_scale, n0, k0, tile);
   else if (j.taps == 9) relayout_tile<T, 9, 32>(j, params, shadow, wn_scale, n0, k0, tile);
@@ -123,9 +124,9 @@ __global__ __launch_bounds__(256) void relayout_kernel(const float* __restrict__
 struct WnJob { long v_off, g_off, out_off; int rows, K; int row_start; };
 
 __global__ void wn_scale_kernel(const float* __restrict__ params, float* __restrict__ scale, float* __restrict__ inv_norm,
-                                const WnJob* __restrict__ jobs, int njobs, int total_rows) {
-  const int grow = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (grow >= total_rows) return;
+                                const WnJob* __restrict__ jobs, int njobs, int row_base, int total_rows) {
+  const int grow = row_base + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (grow >= row_base + total_rows) return;
   int lo = 0, hi = njobs - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -220,22 +221,33 @@ extern "C" int ipoke_wn_job_size(void) { return (int)sizeof(WnJob); }
 
 extern "C" int ipoke_relayout_multi(const float* params, void* shadow, const float* wn_scale, const void* jobs_dev, int njobs,
                                     int total_blocks, const int32_t* block_job_dev, int dtype, void* stream) {
-  IPK_REQUIRE(params && shadow && jobs_dev && njobs > 0 && total_blocks > 0, "bad arguments");
+  return ipoke_relayout_multi_range(params, shadow, wn_scale, jobs_dev, njobs, 0, total_blocks, block_job_dev, dtype, stream);
+}
+/* blocks [block_begin, block_begin + nblocks) of the job table only (the jobs of a contiguous range of tensors) */
+extern "C" int ipoke_relayout_multi_range(const float* params, void* shadow, const float* wn_scale, const void* jobs_dev, int njobs,
+                                          int block_begin, int nblocks, const int32_t* block_job_dev, int dtype, void* stream) {
+  IPK_REQUIRE(params && shadow && jobs_dev && njobs > 0 && nblocks >= 0 && block_begin >= 0, "bad arguments");
+  if (nblocks == 0) return IPOKE_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == IPOKE_BF16)
-    hipLaunchKernelGGL(relayout_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, s, params, (bf16_t*)shadow, wn_scale,
-                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev);
+    hipLaunchKernelGGL(relayout_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, s, params, (bf16_t*)shadow, wn_scale,
+                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev, block_begin);
   else
-    hipLaunchKernelGGL(relayout_kernel<float>, dim3(total_blocks), dim3(256), 0, s, params, (float*)shadow, wn_scale,
-                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev);
+    hipLaunchKernelGGL(relayout_kernel<float>, dim3(nblocks), dim3(256), 0, s, params, (float*)shadow, wn_scale,
+                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev, block_begin);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
 extern "C" int ipoke_wn_scale_multi(const float* params, float* scale, float* inv_norm, const void* jobs_dev, int njobs,
                                     int total_rows, void* stream) {
-  IPK_REQUIRE(params && scale && inv_norm && jobs_dev && njobs > 0, "bad arguments");
-  hipLaunchKernelGGL(wn_scale_kernel, dim3(ceil_div(total_rows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     params, scale, inv_norm, (const WnJob*)jobs_dev, njobs, total_rows);
+  return ipoke_wn_scale_multi_range(params, scale, inv_norm, jobs_dev, 0, njobs, 0, total_rows, stream);
+}
+extern "C" int ipoke_wn_scale_multi_range(const float* params, float* scale, float* inv_norm, const void* jobs_dev, int job_begin,
+                                          int njobs, int row_begin, int nrows, void* stream) {
+  IPK_REQUIRE(params && scale && inv_norm && jobs_dev && njobs >= 0 && nrows >= 0, "bad arguments");
+  if (njobs == 0 || nrows == 0) return IPOKE_OK;
+  hipLaunchKernelGGL(wn_scale_kernel, dim3(ceil_div(nrows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     params, scale, inv_norm, (const WnJob*)jobs_dev + job_begin, njobs, row_begin, nrows);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -140,6 +140,14 @@ class FlowEngine:
         check(self.lib.ipoke_flow_prepare_weights(self.handle, ptr(self.params), ptr(self.shadow), _lib.current_stream()))
         self.shadow_stale = False
 
+    def prepare_weights_range(self, begin, end):
+        """Refresh the shadows of the parameters in flat[begin:end] (whole levels) on the current stream."""
+        self._need_gpu()
+        if self.shadow is None:
+            self.shadow = torch.empty(self.lib.ipoke_flow_shadow_bytes(self.handle), dtype=torch.uint8, device=self.device)
+        check(self.lib.ipoke_flow_prepare_weights_range(self.handle, ptr(self.params), ptr(self.shadow), int(begin), int(end),
+                                                        _lib.current_stream()))
+
     # ---- compute -------------------------------------------------------------------------
     def _prep_inputs(self, x, cond):
         self._need_gpu()

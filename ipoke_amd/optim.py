@@ -58,12 +58,13 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
             ptr(flat[sl]), ptr(grads[sl]), ptr(self.exp_avg[sl]), ptr(self.exp_avg_sq[sl]), ptr(self.max_exp_avg_sq[sl]), end - begin,
             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
             self.steps, float(grad_scale), 256, _lib.current_stream()))      # one workgroup per CU: runs underneath backward
+        self.flow.engine.prepare_weights_range(begin, end)                   # ... and so does the refresh of its shadows
         self._covered += end - begin
 
     def finish_step(self):
         if self._covered != self.flow.flat_params.numel():
             raise RuntimeError(f"piecewise optimizer step covered {self._covered} of {self.flow.flat_params.numel()} parameters")
-        self.flow.engine.prepare_weights()
+        self.flow.engine.shadow_stale = False       # every slice refreshed its shadows right after its update
 
     def state_dict(self):
         return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
