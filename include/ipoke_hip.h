@@ -281,7 +281,7 @@ int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* params, void* s
 int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
                         const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
                         void* workspace, void* stream);
-/* The same backward issued in `npieces` groups of levels, last level first, for overlapping the data-parallel gradient
+/* The same backward issued in `npieces` groups of consecutive MaCowSteps / priors (equal parameter counts), last level first, for overlapping the data-parallel gradient
  * exchange with the rest of the backward pass (DDP bucket hooks in the reference's Lightning run,
  * experiments/second_stage_video.py:46-65).  After a group's kernels are queued, `ready_stream` is made to wait for them
  * (without blocking the backward chain on `stream`) and `ready(user, piece, begin, end)` is called on the calling thread

@@ -88,8 +88,11 @@ struct ipoke_flow {
   struct GraphEntry { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int state = 0; uint64_t used = 0; };
   std::vector<GraphEntry> graphs; hipStream_t cap = nullptr; bool use_graph = false; uint64_t tick = 0;
   // per level: flat parameter spans / weight-norm job and row ranges of its layers.* and priors.* tensors, op range
-  struct LevelSpan { int64_t p_lo[2], p_hi[2]; int wj_lo[2], wj_hi[2]; int row_lo[2], row_hi[2]; int op_lo, op_hi; };
-  std::vector<LevelSpan> levels;
+  // Units of the piecewise backward, in execution order: every MaCowStep of a level (kind 0, parameters in the layers.*
+  // region) and every level's prior + shuffle (kind 1, priors.* region).  Consecutive units of one kind are adjacent in
+  // the flat parameter buffer, the weight-norm job table and its row numbering.
+  struct Unit { int64_t p_lo, p_hi; int wj_lo, wj_hi, row_lo, row_hi; int kind; int op_lo, op_hi; };
+  std::vector<Unit> units;
   std::vector<int> red_first;          // first reduction-table entry of op i (size nops + 1)
   int last_fwd_B = 0; bool have_saved = false;
   int P = 64;
@@ -252,27 +255,29 @@ int build(ipoke_flow& f) {
   const int cstep = c.z_channels / c.factor;
   std::vector<int> Cs(L), fs(L);
   for (int l = 0; l < L; ++l) { Cs[l] = C; fs[l] = factor; C -= cstep; --factor; }
-  f.levels.assign(L, ipoke_flow::LevelSpan());
+  std::vector<std::vector<ipoke_flow::Unit>> step_units(L);
+  std::vector<ipoke_flow::Unit> prior_units(L);
   for (int l = 0; l < L; ++l) {
     f.ops.clear();
-    auto& sp = f.levels[l];
-    sp.p_lo[0] = f.n_params; sp.wj_lo[0] = (int)f.wjobs.size(); sp.row_lo[0] = (int)f.wn_rows;
-    for (int s = 0; s < c.num_steps[l]; ++s)
+    for (int s = 0; s < c.num_steps[l]; ++s) {
+      ipoke_flow::Unit u{f.n_params, 0, (int)f.wjobs.size(), 0, (int)f.wn_rows, 0, 0, (int)f.ops.size(), 0};
       b.step("flow.layers." + std::to_string(l) + "." + std::to_string(s), Cs[l]);
-    sp.p_hi[0] = f.n_params; sp.wj_hi[0] = (int)f.wjobs.size(); sp.row_hi[0] = (int)f.wn_rows;
+      u.p_hi = f.n_params; u.wj_hi = (int)f.wjobs.size(); u.row_hi = (int)f.wn_rows; u.op_hi = (int)f.ops.size();
+      step_units[l].push_back(u);
+    }
     level_ops[l] = f.ops;
   }
   for (int l = 0; l < L; ++l) {
     f.ops.clear();
-    auto& sp = f.levels[l];
-    sp.p_lo[1] = f.n_params; sp.wj_lo[1] = (int)f.wjobs.size(); sp.row_lo[1] = (int)f.wn_rows;
+    ipoke_flow::Unit u{f.n_params, 0, (int)f.wjobs.size(), 0, (int)f.wn_rows, 0, 1, 0, 0};
     const std::string pfx = "flow.priors." + std::to_string(l);
     const std::string sh = pfx + ".conv1x1";
     b.actnorm("", Cs[l], 0, Cs[l], &sh);                         // bare shuffle
     b.nice(pfx + ".coupling", Cs[l], false, true, fs[l]);
     const int cout = Cs[l] / fs[l];
     b.actnorm(pfx + ".actnorm", Cs[l], Cs[l] - cout, cout, nullptr);
-    sp.p_hi[1] = f.n_params; sp.wj_hi[1] = (int)f.wjobs.size(); sp.row_hi[1] = (int)f.wn_rows;
+    u.p_hi = f.n_params; u.wj_hi = (int)f.wjobs.size(); u.row_hi = (int)f.wn_rows;
+    prior_units[l] = u;
     prior_ops[l] = f.ops;
   }
   for (int l = 0; l < L; ++l) {
@@ -282,12 +287,17 @@ int build(ipoke_flow& f) {
     shuf_ops[l] = f.ops;
   }
   f.ops.clear();
+  f.units.clear();
   for (int l = 0; l < L; ++l) {
-    f.levels[l].op_lo = (int)f.ops.size();
+    const int base = (int)f.ops.size();
     for (auto& o : level_ops[l]) { f.ops.push_back(o); f.ops.back().level = l; }
+    for (auto u : step_units[l]) { u.op_lo += base; u.op_hi += base; f.units.push_back(u); }
+    ipoke_flow::Unit pu = prior_units[l];
+    pu.op_lo = (int)f.ops.size();
     for (auto& o : prior_ops[l]) { f.ops.push_back(o); f.ops.back().level = l; }
     for (auto& o : shuf_ops[l]) { f.ops.push_back(o); f.ops.back().level = l; }
-    f.levels[l].op_hi = (int)f.ops.size();
+    pu.op_hi = (int)f.ops.size();
+    f.units.push_back(pu);
   }
   int k = 0;
   for (auto& o : f.ops) if (o.type == OP_MCF) o.mcf_idx = k++;     // execution order
@@ -965,20 +975,21 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     hipEvent_t e = next_event(f);
     IPK_HIP(hipEventRecord(e, s)); IPK_HIP(hipStreamWaitEvent(f->side, e, 0));
   }
-  // pieces: groups of consecutive levels, last level first, of roughly equal step counts
+  // pieces: groups of consecutive units (steps / priors), last unit first, of roughly equal parameter counts
   hipStream_t rs = ready_stream ? ready_stream : s;
-  std::vector<std::pair<int, int>> pieces;            // (lowest level, highest level)
+  std::vector<std::pair<int, int>> pieces;            // (lowest unit, highest unit)
   {
-    const int L = (int)f->levels.size();
-    int total = 0;
-    for (int l = 0; l < L; ++l) total += f->cfg.num_steps[l];
-    const int np = npieces < 1 ? 1 : (npieces > L ? L : npieces);
-    int hi = L - 1, acc = 0, done = 0;
-    for (int l = L - 1; l >= 0; --l) {
-      acc += f->cfg.num_steps[l];
+    const int U = (int)f->units.size();
+    int64_t total = 0;
+    for (const auto& u : f->units) total += u.p_hi - u.p_lo;
+    const int np = npieces < 1 ? 1 : (npieces > U ? U : npieces);
+    int hi = U - 1;
+    int64_t acc = 0, done = 0;
+    for (int u = U - 1; u >= 0; --u) {
+      acc += f->units[u].p_hi - f->units[u].p_lo;
       const int left = np - (int)pieces.size();
-      if (l == 0 || (left > 1 && (acc >= (total - done + left - 1) / left || l == left - 1))) {
-        pieces.push_back({l, hi}); hi = l - 1; done += acc; acc = 0;
+      if (u == 0 || (left > 1 && (acc >= (total - done + left - 1) / left || u == left - 1))) {
+        pieces.push_back({u, hi}); hi = u - 1; done += acc; acc = 0;
       }
     }
   }
@@ -993,24 +1004,31 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     }
     void* rstream = reinterpret_cast<void*>(rs);
     // bias / ActNorm parameter gradients: multi-tensor reduction over the per-sample partial sums of the piece's layers
-    const int r0 = f->red_first[f->levels[lvl_lo].op_lo], r1 = f->red_first[f->levels[lvl_hi].op_hi];
+    const int r0 = f->red_first[f->units[lvl_lo].op_lo], r1 = f->red_first[f->units[lvl_hi].op_hi];
     if (r1 > r0) {
       r = ipoke_reduce_rows_multi(reinterpret_cast<const float*>(c.ws), grads,
                                   reinterpret_cast<const unsigned char*>(f->d_redtab) + (size_t)r0 * ipoke_reduce_entry_size(), r1 - r0, B,
                                   rstream);
       if (r) return r;
     }
-    for (int kind = 0; kind < 2; ++kind) {                           // layers.* and priors.* are separate flat regions
-      const auto& lo = f->levels[lvl_lo]; const auto& hi = f->levels[lvl_hi];
-      r = ipoke_wn_bwd_multi_range(params, grads, c.wn_inv(), f->d_wjobs, lo.wj_lo[kind], hi.wj_hi[kind] - lo.wj_lo[kind],
-                                   lo.row_lo[kind], hi.row_hi[kind] - lo.row_lo[kind], rstream);
+    // layers.* and priors.* are separate flat regions: the units of one kind inside the piece form one contiguous range each
+    int64_t p0[2] = {-1, -1}, p1[2] = {-1, -1};
+    int wj0[2] = {0, 0}, wj1[2] = {0, 0}, rw0[2] = {0, 0}, rw1[2] = {0, 0};
+    for (int u = lvl_lo; u <= lvl_hi; ++u) {
+      const auto& un = f->units[u];
+      const int k = un.kind;
+      if (p0[k] < 0) { p0[k] = un.p_lo; wj0[k] = un.wj_lo; rw0[k] = un.row_lo; }
+      p1[k] = un.p_hi; wj1[k] = un.wj_hi; rw1[k] = un.row_hi;
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      if (p0[kind] < 0) continue;
+      r = ipoke_wn_bwd_multi_range(params, grads, c.wn_inv(), f->d_wjobs, wj0[kind], wj1[kind] - wj0[kind], rw0[kind],
+                                   rw1[kind] - rw0[kind], rstream);
       if (r) return r;
     }
     if (ready)
-      for (int kind = 0; kind < 2; ++kind) {
-        const int64_t b0 = f->levels[lvl_lo].p_lo[kind], b1 = f->levels[lvl_hi].p_hi[kind];
-        if (b1 > b0) ready(user, piece, b0, b1);
-      }
+      for (int kind = 0; kind < 2; ++kind)
+        if (p0[kind] >= 0 && p1[kind] > p0[kind]) ready(user, piece, p0[kind], p1[kind]);
     return IPOKE_OK;
   };
   // NICE weight gradients are not started right behind their coupling: the couplings come in pairs whose data-gradient
@@ -1064,7 +1082,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
     const Op& op = f->ops[i];
     if (op.fused) {                                  // differentiated inside the preceding MCF layer's backward kernel
-      if (i == f->levels[pieces[pk].first].op_lo) { rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc; ++pk; }
+      if (i == f->units[pieces[pk].first].op_lo) { rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc; ++pk; }
       continue;
     }
     if (op.type != OP_NICE) { rc = flush_nice(); if (rc) return rc; }
@@ -1125,7 +1143,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       pend_nice.push_back(i);      // weight gradients: launched when the chain leaves this group of couplings
     }
     cur ^= 1;
-    if (i == f->levels[pieces[pk].first].op_lo) {        // the lowest op of the current piece has been queued
+    if (i == f->units[pieces[pk].first].op_lo) {        // the lowest op of the current piece has been queued
       rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc;
       ++pk;
     }

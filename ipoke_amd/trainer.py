@@ -13,11 +13,11 @@ class SecondStageTrainer:
     the fused Adam-amsgrad update of that slice is applied, on a separate stream, while the remaining levels are still
     differentiating.  Without overlap the flat buffer is all-reduced in slices and updated after the backward pass."""
 
-    def __init__(self, model, n_grad_buckets=6, overlap=None):
+    def __init__(self, model, n_grad_buckets=12, overlap=None):
         self.model = model
         self.opt = model.configure_optimizers()[0]
         self.world = D.world_size()
-        self.n_grad_buckets = n_grad_buckets
+        self.n_grad_buckets = n_grad_buckets = int(os.environ.get("IPOKE_PIECES", n_grad_buckets))
         if overlap is None:
             overlap = os.environ.get("IPOKE_NO_OVERLAP", "0") != "1"
         # Also on one GPU (no exchange): the per-group Adam updates run underneath the backward chain with a one-workgroup-

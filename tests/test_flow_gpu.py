@@ -122,7 +122,7 @@ def test_backward_in_pieces_matches_and_covers_all_parameters():
     noise = (again - ref).abs().max().item()        # the split-K data gradients accumulate with fp32 atomics
     ranges = []
     stream = torch.cuda.Stream()
-    m.engine.grad_ready_hook = (3, stream, lambda b, e: ranges.append((b, e)))
+    m.engine.grad_ready_hook = (5, stream, lambda b, e: ranges.append((b, e)))
     got = run()
     m.engine.grad_ready_hook = None
     scale = ref.abs().max().item()
@@ -133,5 +133,7 @@ def test_backward_in_pieces_matches_and_covers_all_parameters():
         covered[b:e] += 1
     assert int(covered.min()) == 1 and int(covered.max()) == 1
     # per region (layers.*, priors.*) the ranges arrive from the end of the flat buffer towards its start
-    starts = [b for b, _ in ranges[::2]]
-    assert starts == sorted(starts, reverse=True)
+    prior0 = min(off for name, off, shape, kind in m.engine.tensors if name.startswith("flow.priors.") and kind == 0)
+    for region in (lambda b: b < prior0, lambda b: b >= prior0):
+        starts = [b for b, _ in ranges if region(b)]
+        assert starts and starts == sorted(starts, reverse=True)
