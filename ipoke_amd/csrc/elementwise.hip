@@ -197,16 +197,16 @@ __device__ __forceinline__ void affine_stage_raw(const AffineArgs& a, long row0,
   for (int e = threadIdx.x; e < rows * n2; e += blockDim.x) {
     const int p = e / n2, j = e - p * n2;
     const float* r = a.raw + (row0 + p) * a.ldraw + j;
-    float v[8];
+    // every split's partial is requested at once (nsplit <= 32): one memory latency instead of nsplit / 8
+    float v[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = 0.f;
-    int s = 0;
-    for (; s + 7 < a.nsplit; s += 8) {
+    for (int u = 0; u < 32; ++u) v[u] = u < a.nsplit ? r[(long)u * a.split_stride] : 0.f;
+    for (int s = 32; s < a.nsplit; ++s) v[0] += r[(long)s * a.split_stride];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] += r[(long)(s + u) * a.split_stride];
-    }
-    for (; s < a.nsplit; ++s) v[0] += r[(long)s * a.split_stride];
-    float t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+      for (int u = 0; u < w; ++u) v[u] += v[u + w];
+    float t = v[0];
     if (a.bias) t += a.bias[j];
     raw_s[e] = t;
   }
