@@ -189,42 +189,6 @@ def test_conv_wgrad_vs_torch(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("order", ["A", "B", "C", "D"])
-@pytest.mark.parametrize("C", [8, 32])
-def test_mcf_forward_inverse(golden, C, order, dtype):
-    g = golden("g1_flow_units")
-    ks = (2, 3) if order in "AB" else (3, 2)
-    o = flow_ref.MaskedConvFlow(C, ks, order, 128)
-    deterministic_fill_(o, prefix=f"mcf{C}{order}.")
-    sd = {k: v.to(DEV) for k, v in o.state_dict().items()}
-    sh = mcf_shadows(sd, "", C, 128, dtype)
-    x, h = t(g[f"x_{C}"], DEV), t(g[f"h_{C}"], DEV)
-    B = x.shape[0]
-    xs, cond = ops.to_state(x), ops.cond_prepare(h, dtype)
-    y = torch.empty_like(xs)
-    ld = torch.zeros(B, 4, device=DEV)
-    d = ops.mcf_desc(xs, C, B, cond, sh["W1"], sh["W2"], sh["bias"], "ABCD".index(order))
-    d.y = y.data_ptr(); d.logdet_slot = ld.data_ptr(); d.rows_per_block = 16
-    _lib.check(_lib.lib().ipoke_mcf_fwd(d, _lib.DTYPES[dtype], _lib.current_stream()))
-    torch.cuda.synchronize()
-    tol = TOLS[dtype]
-    e_y = (ops.from_state(y, B, C).cpu() - t(g[f"mcf_{C}_{order}_y"])).abs().max().item()
-    e_ld = (ld.sum(1).cpu() - t(g[f"mcf_{C}_{order}_logdet"])).abs().max().item()
-    print(f"mcf {C}{order}[{dtype}] y err {e_y:.3e} logdet err {e_ld:.3e}")
-    assert e_y <= tol * 4 and e_ld <= tol * 200
-    # inverse of the golden output
-    yin = ops.to_state(t(g[f"mcf_{C}_{order}_y"], DEV))
-    xr = torch.empty_like(yin)
-    d2 = ops.mcf_desc(yin, C, B, cond, sh["W1"], sh["W2"], sh["bias"], "ABCD".index(order))
-    d2.y = xr.data_ptr()
-    _lib.check(_lib.lib().ipoke_mcf_inv(d2, _lib.DTYPES[dtype], _lib.current_stream()))
-    torch.cuda.synchronize()
-    e_x = (ops.from_state(xr, B, C).cpu() - t(g[f"mcf_{C}_{order}_inv"])).abs().max().item()
-    print(f"mcf {C}{order}[{dtype}] inverse err {e_x:.3e}")
-    assert e_x <= tol * 10
-
-
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_engine_weight_shadows_match_torch_layouts(dtype):
     """ipoke_flow_prepare_weights (multi-tensor relayout + weight norm) against torch re-statements."""
     from ctypes import c_int64
