@@ -201,6 +201,21 @@ int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream);
 int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream);
 int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream);
 
+/* Fused MaCowUnit (macow2.py:957-995: conv1(A) -> conv2(B) -> actnorm1 -> conv3(C) -> conv4(D) -> actnorm2) in ONE launch per
+ * direction, one workgroup per sample; bf16 only (ipoke_macow_unit_supported).  d4 = the four masked-conv descriptors in forward
+ * order, filled as for the per-layer calls with these differences:
+ *   forward : d4[0].x is the unit's input; d4[k].x (k > 0) is ignored (the state stays on chip); d4[k].y may be NULL for k < 3
+ *             (intermediate states not stored; the backward pass needs them); d4[3].y also receives the pass-through channels;
+ *             d4[k].logdet_slot[b * w] receives the layer's whole log-det of sample b, w = 64 / d4[0].rows_per_block (the slot
+ *             width of the per-layer call with that setting; 1 when rows_per_block == 0); post_log_scale / post_bias on d4[1]
+ *             and d4[3] are the two ActNorms.
+ *   backward: d4[k].x = saved input state of layer k; d4[3].dy = incoming gradient, d4[0].dx = gradient passed on, d4[0].dld;
+ *             per layer a2_save / scale_save (from forward), dparams_save / dc_save / dbias_part (outputs), and for the layers
+ *             followed by an ActNorm y_post (its saved output) / post_part. */
+int ipoke_macow_unit_supported(int C, int Cc, int dtype);
+int ipoke_macow_unit_fwd(const ipoke_mcf_desc* d4, int dtype, void* stream);
+int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* stream);
+
 /* multi-tensor weight preparation (job tables are built by the flow engine) */
 int ipoke_relayout_job_size(void);
 int ipoke_wn_job_size(void);

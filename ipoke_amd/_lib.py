@@ -117,6 +117,9 @@ SIGNATURES = {
     "ipoke_mcf_fwd": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_mcf_inv": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_mcf_bwd": (c_int, [POINTER(McfDesc), c_int, _P]),
+    "ipoke_macow_unit_supported": (c_int, [c_int, c_int, c_int]),
+    "ipoke_macow_unit_fwd": (c_int, [POINTER(McfDesc), c_int, _P]),
+    "ipoke_macow_unit_bwd": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_relayout_job_size": (c_int, []),
     "ipoke_wn_job_size": (c_int, []),
     "ipoke_relayout_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_int, _P]),

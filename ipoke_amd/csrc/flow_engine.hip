@@ -50,6 +50,8 @@ struct Op {
   int level = 0;                               // multi-scale level the op belongs to
   int fuse_act = -1;                           // MCF: index of the ActNorm executed inside this layer's kernels
   bool fused = false;                          // ActNorm: executed by the preceding MCF layer (forward / backward)
+  bool unit_head = false;                      // MCF: first of the six ops of a MaCowUnit that one fused launch executes
+  int unit_of = -1;                            // index of the unit's first op for every op inside such a unit
 };
 
 struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
@@ -308,6 +310,21 @@ int build(ipoke_flow& f) {
     if (a.type == OP_MCF && b2.type == OP_ACTNORM && b2.idx_fwd < 0 && b2.p_ls >= 0 && b2.c0 == 0 && b2.Cn == a.C &&
         a.C % 4 == 0 && c.z_channels % 4 == 0 && a.level == b2.level) {
       a.fuse_act = (int)i + 1; b2.fused = true;
+    }
+  }
+  // MaCowUnit = MCF, MCF(+ActNorm), ActNorm, MCF, MCF(+ActNorm), ActNorm of one width: one fused launch per direction
+  // (mcf_unit.hip) where the matrix-core dtype supports it
+  static const bool nounit = getenv("IPOKE_NO_UNIT_FUSION") != nullptr;
+  for (size_t i = 0; !nounit && i + 5 < f.ops.size(); ++i) {
+    const Op* o = &f.ops[i];
+    const bool pat = o[0].type == OP_MCF && o[1].type == OP_MCF && o[2].type == OP_ACTNORM && o[3].type == OP_MCF &&
+                     o[4].type == OP_MCF && o[5].type == OP_ACTNORM && o[0].fuse_act < 0 && o[1].fuse_act == (int)i + 2 &&
+                     o[3].fuse_act < 0 && o[4].fuse_act == (int)i + 5 && o[2].fused && o[5].fused && o[0].unit_of < 0 &&
+                     o[0].C == o[1].C && o[0].C == o[3].C && o[0].C == o[4].C;
+    if (pat && ipoke_macow_unit_supported(o[0].C, c.cond_channels, c.dtype)) {
+      f.ops[i].unit_head = true;
+      for (int k = 0; k < 6; ++k) f.ops[i + k].unit_of = (int)i;
+      i += 5;
     }
   }
   return IPOKE_OK;
@@ -789,6 +806,28 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
   for (size_t i = 0; i < f->ops.size(); ++i) {
     const Op& op = f->ops[i];
     if (init && op.type != OP_ACTNORM) continue;   // zero-initialised couplings are the identity (macow_utils.py:231-250)
+    if (!init && op.unit_head) {                   // whole MaCowUnit (ops i .. i+5) in one launch
+      const int nxt = save ? (int)i + 6 : (cur ^ 1);
+      static const int lidx[4] = {0, 1, 3, 4};     // the four masked convs among the six ops
+      static const int oidx[4] = {1, 3, 4, 6};     // state index (relative to i) each of them writes when states are saved
+      for (const Ctx& l : lanes) {
+        ipoke_mcf_desc d4[4];
+        for (int k = 0; k < 4; ++k) {
+          const Op& mk = f->ops[i + lidx[k]];
+          mcf_desc(l, mk, d4[k]);
+          d4[k].x = k == 0 ? l.state(cur) : nullptr;
+          d4[k].y = k == 3 ? l.state(nxt) : (save ? l.state((int)i + oidx[k]) : nullptr);
+          d4[k].logdet_slot = l.slot(mk.slot);
+          d4[k].rows_per_block = 16;               // slot width 4, as the per-layer launches
+          if (mk.fuse_act >= 0) { d4[k].post_log_scale = params + f->ops[mk.fuse_act].p_ls; d4[k].post_bias = params + f->ops[mk.fuse_act].p_bias; }
+          if (save) { d4[k].a2_save = l.rows(mk.ws_a, (int64_t)mk.K2p * f->esz); d4[k].scale_save = l.rowsf(mk.ws_b, mk.C); }
+        }
+        rc = ipoke_macow_unit_fwd(d4, l.dtype, l.stream()); if (rc) return rc;
+      }
+      cur = nxt;
+      i += 5;
+      continue;
+    }
     if (!init && op.fused) continue;               // done by the preceding MCF launch, which wrote this op's output state
     const bool fuse = !init && op.type == OP_MCF && op.fuse_act >= 0;
     const int nxt = save ? (int)i + (fuse ? 2 : 1) : (cur ^ 1);
@@ -1081,6 +1120,41 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   const int64_t goff[2] = {c.plan.g0, c.plan.g1};
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
     const Op& op = f->ops[i];
+    if (op.unit_of >= 0 && i == op.unit_of + 5) {     // whole MaCowUnit (ops h .. h+5) differentiated by one launch
+      const int h = op.unit_of;
+      rc = flush_nice(); if (rc) return rc;
+      static const int lidx[4] = {0, 1, 3, 4};
+      for (const Ctx& l : lanes) {
+        ipoke_mcf_desc d4[4];
+        for (int k = 0; k < 4; ++k) {
+          const int j = h + lidx[k];
+          const Op& mk = f->ops[j];
+          mcf_desc(l, mk, d4[k]);
+          d4[k].x = l.state(j);
+          d4[k].a2_save = l.rows(mk.ws_a, (int64_t)mk.K2p * f->esz); d4[k].scale_save = l.rowsf(mk.ws_b, mk.C);
+          d4[k].dparams_save = l.rows(mk.ws_c, (int64_t)mk.K3p * f->esz); d4[k].dc_save = l.rows(mk.ws_d, (int64_t)mk.Hq * f->esz);
+          d4[k].dbias_part = l.dbp(j, 2 * mk.C);
+          if (mk.fuse_act >= 0) {
+            const Op& an = f->ops[mk.fuse_act];
+            d4[k].post_log_scale = params + an.p_ls; d4[k].post_bias = params + an.p_bias;
+            d4[k].y_post = l.state(j + 2);
+            d4[k].post_part = l.dbp(mk.fuse_act, 2 * an.Cn);
+          }
+        }
+        d4[3].dy = l.rowsf(goff[cur], l.ld); d4[0].dx = l.rowsf(goff[cur ^ 1], l.ld); d4[0].dld = l.dld();
+        rc = ipoke_macow_unit_bwd(d4, l.dtype, l.stream()); if (rc) return rc;
+      }
+      for (int k = 3; k >= 0; --k) {                 // weight gradients: deferred, batched per run of same-width layers
+        const int j = h + lidx[k];
+        const Op& mk = f->ops[j];
+        if (pend_lo >= 0 && (f->ops[pend_op].C != mk.C || pend_hi - pend_lo + 1 >= 256)) { rc = flush_mcf(); if (rc) return rc; }
+        if (pend_lo < 0) { pend_hi = mk.mcf_idx; pend_op = j; }
+        pend_lo = mk.mcf_idx;
+      }
+      cur ^= 1;
+      i = h;                                         // the loop decrement moves on to op h - 1
+      continue;
+    }
     if (op.fused) {                                  // differentiated inside the preceding MCF layer's backward kernel
       if (i == f->units[pieces[pk].first].op_lo) { rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc; ++pk; }
       continue;

@@ -1,0 +1,665 @@
+// Fused MaCowUnit kernels (reference models/modules/INN/macow2.py:957-995):
+//     MCF(A) -> MCF(B) -> ActNorm -> MCF(C) -> MCF(D) -> ActNorm
+// in ONE launch per direction, one 8-wave workgroup per sample.  The per-layer kernels of mcf.hip are each bound by
+// their own launch + weight-fetch latency (7..25 us for 19 MFLOP per sample); here the 8x8xC latent stays in LDS (fp32
+// master copy + matrix-core operand copy) across the four masked convolutions, the conditioning rows are staged once,
+// and the weight fragments of layer k+1 are requested into the registers layer k has just finished with, so that only
+// the first layer of a unit pays a memory latency.  Everything a backward pass needs (per-layer input states, ELU
+// outputs, coupling scales) is written on the way, exactly as the per-layer kernels write it.
+//
+// bf16 matrix-core inputs only (the register-resident weight path); f32 parity mode runs the per-layer kernels.
+#include <cstring>
+#include <type_traits>
+
+#include "mcf_dev.h"
+
+namespace ipoke {
+
+struct UnitLayer {
+  const void* W1; const void* W2; const float* bias2;       // forward operands
+  const void* W1T; const void* W2T;                         // backward operands
+  float* y;                                                 // fwd: output state of this layer (NULL: not stored)
+  void* a2_save; float* scale_save; float* ld_slot;
+  const float* post_ls; const float* post_bias;             // ActNorm behind this layer (NULL: none)
+  const float* x;                                           // bwd / inverse: saved input state of this layer
+  const float* y_post; float* post_part;                    // bwd of the ActNorm: its saved output, [B][2C] partial sums
+  void* dparams_save; void* dc_save; float* dbias_part;
+  int order;
+};
+struct UnitParams {
+  UnitLayer L[4];
+  const float* x; const void* cond; const float* dy; const float* dld; float* dx;
+  int ld, C, B, Cc, H, Cp, K1p, K2p, K3p, Hq, slot_w;
+};
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// Weight fragments are fetched through buffer descriptors: the base lives in SGPRs, every lane needs ONE 32-bit byte offset
+// per fragment column (instead of a 64-bit address per fragment, which the compiler kept live across the layer loop and
+// spilled), the tap / K-step part of the address is a scalar offset, and rows beyond the matrix read as zero (hardware
+// range check) so that no load sits behind a branch.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+static constexpr int kOob = 0x40000000;         // scalar offset beyond any weight matrix: the load returns zeros
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ typename ET<T>::frag buf_frag(rsrc_t rs, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return __builtin_bit_cast(typename ET<T>::frag, v);
+}
+
+// Width classes: every loop bound of the matrix-core phases is a compile-time constant of the class, rows / K steps a
+// narrower layer does not have read as zero weights (range-checked loads) against zero-padded LDS tiles.  No branch sits
+// inside a contraction, so the compiler pipelines LDS reads under the matrix cores.  (The per-layer kernels guard every
+// fragment with `wave + 8 j < NF`, a per-lane condition to the compiler: each pair of MFMAs ends up in its own basic block.)
+//   WIDE  : 32 < C <= 64  (Cp = 64, H <= 256, K2p <= 384, K3p <= 128, Hq <= 256)
+//   narrow:      C <= 32  (Cp = 32, H <= 128, K2p <= 256, K3p <=  64, Hq <= 128)
+template <bool WIDE> struct UC {
+  static constexpr int CS = WIDE ? 2 : 1;       // 32-deep K steps per tap of the shifted conv
+  static constexpr int J1 = WIDE ? 2 : 1;       // hidden-channel fragments per wave (8 waves x J1 x 16 >= H)
+  static constexpr int N2S = WIDE ? 12 : 8;     // K steps of the 1x1 conv
+  static constexpr int N3S = WIDE ? 4 : 2;      // K steps of its transpose (2C)
+  static constexpr int HS = WIDE ? 8 : 4;       // K steps per tap of the shifted conv's transpose (4C)
+};
+
+template <typename T, bool WIDE>
+__device__ __forceinline__ void unit_load_w1(McfW<T>& w, const void* W1, const UnitParams& U) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
+  const rsrc_t rs = make_rsrc(W1, ((U.H + 15) & ~15) * U.K1p * (int)sizeof(T));
+  int voff[UC<WIDE>::J1];
+#pragma unroll
+  for (int j = 0; j < UC<WIDE>::J1; ++j) voff[j] = (((wave + kMcfWaves * j) * 16 + r) * U.K1p + E16 * gq) * (int)sizeof(T);
+#pragma unroll
+  for (int tap = 0; tap < 6; ++tap)
+#pragma unroll
+    for (int st = 0; st < UC<WIDE>::CS; ++st) {
+      const int soff = (tap * U.Cp + st * KS) * (int)sizeof(T);
+#pragma unroll
+      for (int j = 0; j < UC<WIDE>::J1; ++j) w.w1[tap][st][j] = buf_frag<T>(rs, voff[j], soff);
+    }
+}
+template <typename T, bool WIDE>
+__device__ __forceinline__ void unit_load_w2(McfW<T>& w, const void* W2, const UnitParams& U) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
+  const rsrc_t rs = make_rsrc(W2, ((2 * U.C + 15) & ~15) * U.K2p * (int)sizeof(T));
+  const int n2 = U.K2p / KS;
+  const int voff = ((wave * 16 + r) * U.K2p + E16 * gq) * (int)sizeof(T);
+#pragma unroll
+  for (int st = 0; st < UC<WIDE>::N2S; ++st)
+    w.w2[st][0] = buf_frag<T>(rs, voff, st < n2 ? st * KS * (int)sizeof(T) : kOob);   // unused K steps: out of range, zeros, no traffic
+}
+
+// fp32 transforms of the bf16-net mode: hardware exp / log / rcp (1-2 ulp) instead of the libm-grade tanhf / logf / expm1f
+// of the per-layer (parity-mode) kernels.  tanh(s/2) + 1 == 2 / (1 + exp(-s)); the ELU output is rounded to bf16 anyway.
+__device__ __forceinline__ float fast_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+__device__ __forceinline__ float fast_scale(float s) { return __fdividef(2.f, 1.f + __expf(-s)); }
+
+// ------------------------------------------------------------------------------------------------ forward
+// hidden = ELU(A1 x W1^T) for rows [32 h, 32 h + 32) -> a2[row][0:H]
+template <typename T, bool WIDE>
+__device__ __forceinline__ void unit_gemm1(const unsigned char* xs, int xs_pitch, const McfGeom& g, unsigned char* a2, int a2_pitch,
+                                           int H, const McfW<T>& w, int h, int lane, int wave) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16, J1 = UC<WIDE>::J1;
+  typedef typename ET<T>::frag frag_t;
+  const int r = lane & 15, gq = lane >> 4;
+  const unsigned char* zrow = xs + 64 * xs_pitch;
+  f32x4 acc[2][J1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < J1; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < 6; ++tap) {
+    const unsigned char* src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) src[i] = tap_src_fwd(xs, zrow, xs_pitch, g, (2 * h + i) * 16 + r, tap) + E16 * gq * (int)sizeof(T);
+#pragma unroll
+    for (int st = 0; st < UC<WIDE>::CS; ++st) {
+      frag_t fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + st * KS * (int)sizeof(T));
+#pragma unroll
+      for (int j = 0; j < J1; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mma64(fa[i], w.w1[tap][st][j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J1; ++j) {
+    const int n = (wave + kMcfWaves * j) * 16 + 4 * gq;
+    if (n < H) {     // H is a multiple of 8: the 4 columns of a lane are all valid or all invalid
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        typename Pack4<T>::type tv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tv[q] = ET<T>::from_f32(fast_elu(acc[i][j][q]));
+        *reinterpret_cast<typename Pack4<T>::type*>(a2 + ((2 * h + i) * 16 + r) * a2_pitch + n * (int)sizeof(T)) = tv;
+      }
+    }
+  }
+}
+// raw (mu, s)[row][0:2C] = A2 x W2^T for all 64 rows (bias added by the epilogue)
+template <typename T, bool WIDE>
+__device__ __forceinline__ void unit_gemm2(const unsigned char* a2, int a2_pitch, float* prm, int N2, const McfW<T>& w, int lane, int wave) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  const int r = lane & 15, gq = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < UC<WIDE>::N2S; ++st) {
+    frag_t fa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      fa[i] = *reinterpret_cast<const frag_t*>(a2 + (i * 16 + r) * a2_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mma64(fa[i], w.w2[st][0], acc[i]);
+  }
+  const int n = wave * 16 + 4 * gq;
+  if (n < N2) {      // 2C is a multiple of 4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(prm + (i * 16 + r) * N2 + n) = acc[i];
+  }
+}
+
+template <typename T, bool WIDE>
+__global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitParams U) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  McfW<T> wr;
+  unit_load_w1<T, WIDE>(wr, U.L[0].W1, U);         // every weight fragment of layer A is in flight from here on
+  unit_load_w2<T, WIDE>(wr, U.L[0].W2, U);
+  const int C = U.C, N2 = 2 * C, ld = U.ld;
+  constexpr int K2c = UC<WIDE>::N2S * 32;                          // tile width of the class (zero beyond K2p)
+  const int xs_pitch = U.Cp * (int)sizeof(T) + 16;
+  constexpr int a2_pitch = K2c * (int)sizeof(T) + 16;
+  unsigned char* xs = smem;                                        // T [64 + zero row][Cp]
+  unsigned char* a2 = xs + 65 * xs_pitch;                          // T [64][K2c]: [ELU(c) | ELU(cond) | 0]
+  float* prm = reinterpret_cast<float*>(a2 + 64 * a2_pitch);       // [64][2C] raw (mu, s)
+  float* xf = prm + 64 * N2;                                       // [64][C] fp32 state
+  float* bias_s = xf + 64 * C;                                     // [4][2C]
+  float* post_s = bias_s + 4 * N2;                                 // [4][2][C]: exp(log_scale), bias of the ActNorms
+  float* red = post_s + 8 * C;                                     // [8]
+  const long row0 = (long)b * 64;
+  const int G2 = C >> 1;
+
+  for (int i = tid; i < (65 * xs_pitch + 64 * a2_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < 4 * N2; i += kMcfThreads) bias_s[i] = U.L[i / N2].bias2[i % N2];
+  for (int i = tid; i < 4 * C; i += kMcfThreads) {
+    const UnitLayer& Lk = U.L[i / C];
+    const int c = i % C;
+    post_s[(i / C) * 2 * C + c] = Lk.post_ls ? __expf(Lk.post_ls[c]) : 1.f;
+    post_s[(i / C) * 2 * C + C + c] = Lk.post_ls ? Lk.post_bias[c] : 0.f;
+  }
+  if (U.L[3].y && ld > C) {                         // pass-through channels go straight to the unit's output state
+    const int R2 = (ld - C) >> 1;
+    for (int e = tid; e < 64 * R2; e += kMcfThreads) {
+      const int p = e / R2, c = C + (e - p * R2) * 2;
+      *reinterpret_cast<f32x2*>(U.L[3].y + (row0 + p) * ld + c) = *reinterpret_cast<const f32x2*>(U.x + (row0 + p) * ld + c);
+    }
+  }
+  __syncthreads();                                  // the zero fill above precedes the staging below
+  {   // ELU(cond) rows of this sample behind the hidden columns (the same for the four layers)
+    constexpr int E16 = ET<T>::E16;
+    const int chunks = U.Cc / E16;
+    const T* cond = reinterpret_cast<const T*>(U.cond) + row0 * U.Cc;
+    for (int i = tid; i < 64 * chunks; i += kMcfThreads) {
+      const int row = i / chunks, ch = i - row * chunks;
+      *reinterpret_cast<u32x4*>(a2 + row * a2_pitch + (U.H + ch * E16) * (int)sizeof(T)) = *reinterpret_cast<const u32x4*>(cond + (long)row * U.Cc + ch * E16);
+    }
+  }
+  for (int e = tid; e < 64 * G2; e += kMcfThreads) {
+    const int p = e / G2, c = (e - p * G2) * 2;
+    const f32x2 v = *reinterpret_cast<const f32x2*>(U.x + (row0 + p) * ld + c);
+    *reinterpret_cast<f32x2*>(xf + p * C + c) = v;
+    bf16x2 tv; tv[0] = ET<T>::from_f32(v[0]); tv[1] = ET<T>::from_f32(v[1]);
+    *reinterpret_cast<bf16x2*>(xs + p * xs_pitch + c * (int)sizeof(T)) = tv;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const UnitLayer& Lk = U.L[k];
+    const McfGeom g = mcf_geom(Lk.order);
+    // lane indices from an opaque copy of the thread id: keeps the addresses of the phases out of the layer loop's
+    // live-in set (they would sit next to the 144 weight registers for the whole kernel)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63, wave = tl >> 6;
+    // two passes of 32 rows: halves the accumulator / A-fragment registers next to the weight registers
+    unit_gemm1<T, WIDE>(xs, xs_pitch, g, a2, a2_pitch, U.H, wr, 0, lane, wave);
+    unit_gemm1<T, WIDE>(xs, xs_pitch, g, a2, a2_pitch, U.H, wr, 1, lane, wave);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k < 3) unit_load_w1<T, WIDE>(wr, U.L[k + 1].W1, U);      // next layer's shifted-conv weights: their registers are free
+    __syncthreads();
+    if (Lk.a2_save) {
+      constexpr int E16 = ET<T>::E16;
+      const int chunks = U.K2p / E16;
+      T* dst = reinterpret_cast<T*>(Lk.a2_save) + row0 * U.K2p;
+      for (int i = tid; i < 64 * chunks; i += kMcfThreads) {
+        const int row = i / chunks, ch = i - row * chunks;
+        *reinterpret_cast<u32x4*>(dst + (long)row * U.K2p + ch * E16) = *reinterpret_cast<const u32x4*>(a2 + row * a2_pitch + ch * 16);
+      }
+    }
+    unit_gemm2<T, WIDE>(a2, a2_pitch, prm, N2, wr, lane, wave);
+    __syncthreads();
+    // affine coupling (+ ActNorm): y = (tanh(s/2) + 1) x + mu ; the fp32 state and its operand copy are updated in place
+    float ld_acc = 0.f;
+    const float* bk = bias_s + k * N2;
+    const float* pe = post_s + k * 2 * C;
+#pragma unroll 1
+    for (int e = tl; e < 64 * G2; e += kMcfThreads) {
+      const int p = e / G2, c = (e - p * G2) * 2;
+      const f32x2 mu = *reinterpret_cast<const f32x2*>(prm + p * N2 + c);
+      const f32x2 sv = *reinterpret_cast<const f32x2*>(prm + p * N2 + C + c);
+      const f32x2 xv = *reinterpret_cast<const f32x2*>(xf + p * C + c);
+      f32x2 sc, yv;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        sc[q] = fast_scale(sv[q] + bk[C + c + q]);
+        yv[q] = sc[q] * xv[q] + (mu[q] + bk[c + q]);
+      }
+      ld_acc += __logf(sc[0] * sc[1]);
+      if (Lk.scale_save) *reinterpret_cast<f32x2*>(Lk.scale_save + (row0 + p) * C + c) = sc;
+      if (Lk.post_ls) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) yv[q] = yv[q] * pe[c + q] + pe[C + c + q];
+      }
+      *reinterpret_cast<f32x2*>(xf + p * C + c) = yv;
+      bf16x2 tv; tv[0] = ET<T>::from_f32(yv[0]); tv[1] = ET<T>::from_f32(yv[1]);
+      *reinterpret_cast<bf16x2*>(xs + p * xs_pitch + c * (int)sizeof(T)) = tv;
+      if (Lk.y) *reinterpret_cast<f32x2*>(Lk.y + (row0 + p) * ld + c) = yv;
+    }
+    const float tot = block_sum(ld_acc, red);       // two barriers: the state update above is complete behind them
+    if (tid == 0 && Lk.ld_slot) Lk.ld_slot[(long)b * U.slot_w] = tot;
+    // the 1x1 weights of the next layer are not needed before its second contraction: requested here, they land
+    // underneath its first one (and do not add to the register pressure of the epilogue above)
+    if (k < 3) unit_load_w2<T, WIDE>(wr, U.L[k + 1].W2, U);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Gradient of the whole unit: D, C (through the second ActNorm), then B, A (through the first).  The running gradient
+// stays in LDS as fp32 [64][C]; per layer the three phases of mcf_bwd_kernel: (a) gradients of the coupling parameters,
+// (b) back through the weight-normed 1x1 conv and ELU, (c) adjoint of the shifted convolution.  Weight fragments of the
+// next (= previous in forward order) layer are requested as soon as a phase has consumed the current ones.
+template <typename T, bool WIDE>
+__global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitParams U) {
+  constexpr int J1 = UC<WIDE>::J1, N3S = UC<WIDE>::N3S, HS = UC<WIDE>::HS;
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  typedef typename Pack4<T>::type pack_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 15, gq = lane >> 4;
+  const int C = U.C, N2 = 2 * C, ld = U.ld, H = U.H;
+  const int n3 = U.K3p / KS, hs = U.Hq / KS;
+  const int nfrag = wave & 3, kh = wave >> 2;
+  const long row0 = (long)b * 64;
+  frag_t w2t[N3S][J1];
+  frag_t w1t[3][HS];
+  pack_t cact[4][J1];
+  const int Hr = (H + 15) & ~15;
+  int vo_w2t[J1], vo_ca[J1];
+#pragma unroll
+  for (int j = 0; j < J1; ++j) {
+    vo_w2t[j] = (((wave + kMcfWaves * j) * 16 + r) * U.K3p + E16 * gq) * (int)sizeof(T);
+    vo_ca[j] = (r * U.K2p + (wave + kMcfWaves * j) * 16 + 4 * gq) * (int)sizeof(T);
+  }
+  const int vo_w1t = ((nfrag * 16 + r) * 6 * U.Hq + kh * 3 * U.Hq + E16 * gq) * (int)sizeof(T);
+  auto load_w2t = [&](const UnitLayer& Lk) {
+    const rsrc_t rs = make_rsrc(Lk.W2T, Hr * U.K3p * (int)sizeof(T));
+#pragma unroll
+    for (int st = 0; st < N3S; ++st) {
+      const int soff = st < n3 ? st * KS * (int)sizeof(T) : kOob;
+#pragma unroll
+      for (int j = 0; j < J1; ++j) w2t[st][j] = buf_frag<T>(rs, vo_w2t[j], soff);
+    }
+  };
+  auto load_cact = [&](const UnitLayer& Lk) {     // saved ELU outputs of this sample, the 4 columns a lane owns in phase (b)
+    const rsrc_t rs = make_rsrc(reinterpret_cast<const T*>(Lk.a2_save) + row0 * U.K2p, 64 * U.K2p * (int)sizeof(T));
+#pragma unroll
+    for (int j = 0; j < J1; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo_ca[j], i * 16 * U.K2p * (int)sizeof(T), 0);
+        cact[i][j] = __builtin_bit_cast(pack_t, v);
+      }
+  };
+  auto load_w1t = [&](const UnitLayer& Lk) {
+    const rsrc_t rs = make_rsrc(Lk.W1T, ((C + 15) & ~15) * 6 * U.Hq * (int)sizeof(T));
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int st = 0; st < HS; ++st)
+        w1t[t][st] = buf_frag<T>(rs, vo_w1t, st < hs ? (t * U.Hq + st * KS) * (int)sizeof(T) : kOob);
+  };
+  load_w2t(U.L[3]); load_cact(U.L[3]); load_w1t(U.L[3]);
+
+  constexpr int dp_pitch = N3S * 32 * (int)sizeof(T) + 16;        // class widths: columns beyond K3p / Hq stay zero
+  constexpr int dc_pitch = HS * 32 * (int)sizeof(T) + 16;
+  unsigned char* dp = smem;                                       // T [64][K3p]  (later: fp32 [64][C] tap-half partials)
+  unsigned char* dc = dp + 64 * dp_pitch;                         // T [64 + zero row][Hq]
+  float* gb = reinterpret_cast<float*>(dc + 65 * dc_pitch);       // [64][C] running gradient / dy*scale
+  float* psum = gb + 64 * C;                                      // [2][rows_par <= 64][2C] per-thread partial column sums
+  float* red2 = psum + 2 * 4096;                                  // [2][Q][2C]
+  // one-time: zero tiles (K padding and the zero row stay zero), incoming gradient, pass-through channels
+  for (int i = tid; i < (64 * dp_pitch + 65 * dc_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  const int G2 = C >> 1;
+  for (int e = tid; e < 64 * G2; e += kMcfThreads) {
+    const int p = e / G2, c = (e - p * G2) * 2;
+    *reinterpret_cast<f32x2*>(gb + p * C + c) = *reinterpret_cast<const f32x2*>(U.dy + (row0 + p) * ld + c);
+  }
+  if (ld > C) {
+    const int R2 = (ld - C) >> 1;
+    for (int e = tid; e < 64 * R2; e += kMcfThreads) {
+      const int p = e / R2, c = C + (e - p * R2) * 2;
+      *reinterpret_cast<f32x2*>(U.dx + (row0 + p) * ld + c) = *reinterpret_cast<const f32x2*>(U.dy + (row0 + p) * ld + c);
+    }
+  }
+  const float g_ld = U.dld[b];
+  const int rows_par = kMcfThreads / G2;                          // >= 16 (C <= 64)
+  const int rows_used = rows_par < 64 ? rows_par : 64;
+  const int c2 = (tid % G2) * 2, r0 = tid / G2;
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 3; k >= 0; --k) {
+    const UnitLayer& Lk = U.L[k];
+    const McfGeom g = mcf_geom(Lk.order);
+    // Lane-derived indices are recomputed per layer from an opaque copy of the thread id: otherwise every LDS / global
+    // address of the three phases is hoisted out of the layer loop and kept live next to the 144 weight registers.
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63, wave = tl >> 6, r = lane & 15, gq = lane >> 4, nfrag = wave & 3, kh = wave >> 2;
+    const int c2 = (tl % G2) * 2, r0 = tl / G2;
+    // (a) thread (r0, c2) owns the channel pair c2 of rows r0, r0 + rows_par, ... (at most 4)
+    if (r0 < rows_used) {
+      f32x2 xv[4], scv[4], ypv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = r0 + i * rows_par;
+        if (p < 64) {
+          xv[i] = *reinterpret_cast<const f32x2*>(Lk.x + (row0 + p) * ld + c2);
+          scv[i] = *reinterpret_cast<const f32x2*>(Lk.scale_save + (row0 + p) * C + c2);
+          if (Lk.post_ls) ypv[i] = *reinterpret_cast<const f32x2*>(Lk.y_post + (row0 + p) * ld + c2);
+        }
+      }
+      f32x2 sg = {0.f, 0.f}, sd = sg, s_ls = sg, s_b = sg;
+      f32x2 pl = {0.f, 0.f}, pb = pl;
+      if (Lk.post_ls) {
+        pl = *reinterpret_cast<const f32x2*>(Lk.post_ls + c2); pb = *reinterpret_cast<const f32x2*>(Lk.post_bias + c2);
+        pl[0] = __expf(pl[0]); pl[1] = __expf(pl[1]);
+      }
+      T* dps = reinterpret_cast<T*>(Lk.dparams_save);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = r0 + i * rows_par;
+        if (p < 64) {
+          f32x2 gy = *reinterpret_cast<const f32x2*>(gb + p * C + c2);
+          if (Lk.post_ls) {
+            // ActNorm behind this layer: dls = sum dy (y_post - bias), dbias = sum dy, gradient passed on = dy exp(ls)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              s_ls[q] += gy[q] * (ypv[i][q] - pb[q]);
+              s_b[q] += gy[q];
+              gy[q] *= pl[q];
+            }
+          }
+          f32x2 ds, dxv;
+          bf16x2 tm, ts;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float sc = scv[i][q], t = sc - 1.f;
+            ds[q] = (gy[q] * xv[i][q] + __fdividef(g_ld, sc)) * 0.5f * (1.f - t * t);
+            dxv[q] = gy[q] * sc;
+            tm[q] = ET<T>::from_f32(gy[q]); ts[q] = ET<T>::from_f32(ds[q]);
+            sg[q] += gy[q]; sd[q] += ds[q];
+          }
+          *reinterpret_cast<f32x2*>(gb + p * C + c2) = dxv;
+          *reinterpret_cast<bf16x2*>(dp + p * dp_pitch + c2 * (int)sizeof(T)) = tm;
+          *reinterpret_cast<bf16x2*>(dp + p * dp_pitch + (C + c2) * (int)sizeof(T)) = ts;
+          *reinterpret_cast<bf16x2*>(dps + (row0 + p) * U.K3p + c2) = tm;
+          *reinterpret_cast<bf16x2*>(dps + (row0 + p) * U.K3p + C + c2) = ts;
+        }
+      }
+      *reinterpret_cast<f32x2*>(psum + r0 * N2 + c2) = sg;
+      *reinterpret_cast<f32x2*>(psum + r0 * N2 + C + c2) = sd;
+      if (Lk.post_ls) {
+        *reinterpret_cast<f32x2*>(psum + 4096 + r0 * N2 + c2) = s_ls;
+        *reinterpret_cast<f32x2*>(psum + 4096 + r0 * N2 + C + c2) = s_b;
+      }
+    }
+    {   // zero the K padding of the saved coupling-parameter gradients (read by the weight-gradient GEMM)
+      T* dps = reinterpret_cast<T*>(Lk.dparams_save);
+      const int padc = U.K3p - N2;
+      for (int e = tid; e < 64 * padc; e += kMcfThreads) {
+        const int p = e / padc, j = N2 + e - p * padc;
+        dps[(row0 + p) * U.K3p + j] = (T)0.f;
+      }
+    }
+    __syncthreads();
+    {   // column sums of the per-thread partials: Q threads per column, then one thread per column
+      const int Q = kMcfThreads / N2;                            // >= 4
+      const int col = tid % N2, part = tid / N2;
+      if (part < Q) {
+        float t = 0.f, t2 = 0.f;
+        for (int rr = part; rr < rows_used; rr += Q) t += psum[rr * N2 + col];
+        red2[part * N2 + col] = t;
+        if (Lk.post_ls) {
+          for (int rr = part; rr < rows_used; rr += Q) t2 += psum[4096 + rr * N2 + col];
+          red2[512 + part * N2 + col] = t2;
+        }
+      }
+    }
+    // (b) dA2[:, :H] = dparams x W2[:, :H], times ELU'(c) -> dc ; two passes of 32 rows (accumulator registers)
+    {
+      T* dcs = reinterpret_cast<T*>(Lk.dc_save);
+      auto pass_b = [&](auto half_c) {
+        constexpr int h = decltype(half_c)::value;
+        f32x4 acc[2][J1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < J1; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < N3S; ++st) {
+          frag_t fa[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            fa[i] = *reinterpret_cast<const frag_t*>(dp + ((2 * h + i) * 16 + r) * dp_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
+#pragma unroll
+          for (int j = 0; j < J1; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mma64(fa[i], w2t[st][j], acc[i][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < J1; ++j) {
+          const int n = (wave + kMcfWaves * j) * 16 + 4 * gq;
+          if (n < H) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int p = (2 * h + i) * 16 + r;
+              const pack_t ca = cact[2 * h + i][j];
+              pack_t tv;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                tv[q] = ET<T>::from_f32(acc[i][j][q] * act_grad_from_out(IPOKE_ACT_ELU, ET<T>::to_f32(ca[q])));
+              *reinterpret_cast<pack_t*>(dc + p * dc_pitch + n * (int)sizeof(T)) = tv;
+              *reinterpret_cast<pack_t*>(dcs + (row0 + p) * U.Hq + n) = tv;
+            }
+          }
+        }
+      };
+      pass_b(std::integral_constant<int, 0>());
+      __builtin_amdgcn_sched_barrier(0);
+      pass_b(std::integral_constant<int, 1>());
+      __builtin_amdgcn_sched_barrier(0);
+      if (k > 0) { load_w2t(U.L[k - 1]); load_cact(U.L[k - 1]); }
+      const int padc = U.Hq - H;
+      for (int e = tid; e < 64 * padc; e += kMcfThreads) {
+        const int p = e / padc, c = H + e - p * padc;
+        dcs[(row0 + p) * U.Hq + c] = (T)0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < N2 && Lk.dbias_part) {
+      const int Q = kMcfThreads / N2;
+      float t = 0.f;
+      for (int q = 0; q < Q; ++q) t += red2[q * N2 + tid];
+      Lk.dbias_part[(long)b * N2 + tid] = t;
+    }
+    if (tid < N2 && Lk.post_ls && Lk.post_part) {
+      const int Q = kMcfThreads / N2;
+      float t = 0.f;
+      for (int q = 0; q < Q; ++q) t += red2[512 + q * N2 + tid];
+      // [d_log_scale | d_bias]; the log-det term of the ActNorm adds P * dld[b] to every d_log_scale
+      Lk.post_part[(long)b * N2 + tid] = tid < C ? t + 64.f * g_ld : t;
+    }
+    // (c) g = dy*scale + sum_tap dc[p - off(tap)] x W1[:, tap, :] : wave w owns channel fragment w & 3 and taps 3*(w >> 2) .. +2;
+    //     two passes of 32 rows; the two tap halves meet in LDS
+    {
+      const unsigned char* zrow = dc + 64 * dc_pitch;
+      float* part = reinterpret_cast<float*>(dp);               // fp32 [64][C]: the dparams tile is dead after (b)
+      const int n = nfrag * 16 + 4 * gq;
+      f32x4 acc_lo[2], acc_hi[2];
+      auto pass_c = [&](auto half_c, f32x4* acc) {
+        constexpr int h = decltype(half_c)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const unsigned char* src[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            src[i] = tap_src_adj(dc, zrow, dc_pitch, g, (2 * h + i) * 16 + r, kh * 3 + t) + E16 * gq * (int)sizeof(T);
+#pragma unroll
+          for (int st = 0; st < HS; ++st) {
+            frag_t fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + st * KS * (int)sizeof(T));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mma64(fa[i], w1t[t][st], acc[i]);
+          }
+        }
+      };
+      pass_c(std::integral_constant<int, 0>(), acc_lo);
+      __builtin_amdgcn_sched_barrier(0);
+      pass_c(std::integral_constant<int, 1>(), acc_hi);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k > 0) load_w1t(U.L[k - 1]);
+      if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (n + q < C) part[(i * 16 + r) * C + n + q] = i < 2 ? acc_lo[i & 1][q] : acc_hi[i & 1][q];
+      }
+      __syncthreads();
+      if (kh == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = i * 16 + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (n + q < C) {
+              const float v = gb[p * C + n + q] + (i < 2 ? acc_lo[i & 1][q] : acc_hi[i & 1][q]) + part[p * C + n + q];
+              gb[p * C + n + q] = v;
+              if (k == 0) U.dx[(row0 + p) * ld + n + q] = v;
+            }
+        }
+      }
+      __syncthreads();
+      if (k > 0) {   // `part` aliased the dparams tile: restore the zero K padding phase (a) does not rewrite
+        const int padc = N3S * 32 - N2;
+        for (int e = tid; e < 64 * padc; e += kMcfThreads) {
+          const int p = e / padc, j = N2 + e - p * padc;
+          *reinterpret_cast<T*>(dp + p * dp_pitch + j * (int)sizeof(T)) = (T)0.f;
+        }
+      }
+    }
+  }
+}
+
+static int unit_params(UnitParams& U, const ipoke_mcf_desc* d, int dtype, bool bwd) {
+  IPK_REQUIRE(d, "null descriptor array");
+  IPK_REQUIRE(dtype == IPOKE_BF16, "the fused MaCowUnit kernels take bf16 matrix-core inputs; f32 runs the per-layer kernels");
+  const int C = d[0].C, ld = d[0].ld, Cc = d[0].Cc, B = d[0].B;
+  IPK_REQUIRE(C >= 2 && C <= 64 && C % 2 == 0 && ld >= C && ld % 2 == 0, "even channel counts up to 64, even state pitch");
+  IPK_REQUIRE(Cc % 8 == 0 && 4 * C + Cc <= kW2Steps * 32, "conditioning width must be a multiple of 8 with 4C + Cc <= 384");
+  IPK_REQUIRE(B >= 1 && d[0].cond, "bad batch / null cond");
+  std::memset(&U, 0, sizeof(U));
+  U.ld = ld; U.C = C; U.B = B; U.Cc = Cc; U.cond = d[0].cond;
+  U.H = 4 * C; U.Cp = round_up(C, 32); U.K1p = 6 * U.Cp; U.K2p = round_up(U.H + Cc, 32); U.K3p = round_up(2 * C, 32);
+  U.Hq = round_up(U.H, 32);
+  for (int k = 0; k < 4; ++k) {
+    const ipoke_mcf_desc& s = d[k];
+    IPK_REQUIRE(s.C == C && s.ld == ld && s.Cc == Cc && s.B == B && s.cond == d[0].cond, "the four layers of a unit share C, ld, cond, B");
+    IPK_REQUIRE(s.order >= 0 && s.order <= 3, "order is 0..3 (A..D)");
+    IPK_REQUIRE((s.post_log_scale == nullptr) == (s.post_bias == nullptr), "fused ActNorm needs log_scale and bias");
+    UnitLayer& L = U.L[k];
+    L.W1 = s.W1; L.W2 = s.W2; L.bias2 = s.bias2; L.W1T = s.W1T; L.W2T = s.W2T; L.y = s.y; L.a2_save = s.a2_save;
+    L.scale_save = s.scale_save; L.ld_slot = s.logdet_slot; L.post_ls = s.post_log_scale; L.post_bias = s.post_bias;
+    L.x = s.x; L.y_post = s.y_post; L.post_part = s.post_part; L.dparams_save = s.dparams_save; L.dc_save = s.dc_save;
+    L.dbias_part = s.dbias_part; L.order = s.order;
+    if (!bwd) IPK_REQUIRE(s.W1 && s.W2 && s.bias2, "null forward operand");
+    else {
+      IPK_REQUIRE(s.W1T && s.W2T && s.x && s.a2_save && s.scale_save && s.dparams_save && s.dc_save, "null backward operand");
+      IPK_REQUIRE(!s.post_log_scale || s.y_post, "the fused ActNorm backward needs the saved output");
+    }
+  }
+  U.x = d[0].x; U.dy = d[3].dy; U.dld = d[0].dld; U.dx = d[0].dx;
+  U.slot_w = d[0].rows_per_block > 0 ? 64 / d[0].rows_per_block : 1;
+  return IPOKE_OK;
+}
+
+}  // namespace ipoke
+
+using namespace ipoke;
+
+extern "C" int ipoke_macow_unit_supported(int C, int Cc, int dtype) {
+  return dtype == IPOKE_BF16 && C >= 2 && C <= 64 && C % 2 == 0 && Cc % 8 == 0 && 4 * C + Cc <= kW2Steps * 32;
+}
+
+extern "C" int ipoke_macow_unit_fwd(const ipoke_mcf_desc* d4, int dtype, void* stream) {
+  UnitParams U;
+  int rc = unit_params(U, d4, dtype, false); if (rc) return rc;
+  IPK_REQUIRE(U.x && U.L[3].y, "null input / output state");
+  const bool wide = U.Cp > 32;
+  const size_t lds = (size_t)65 * (U.Cp * 2 + 16) + (size_t)64 * ((wide ? 384 : 256) * 2 + 16) + (size_t)64 * 2 * U.C * 4 +
+                     (size_t)64 * U.C * 4 + (size_t)(8 * U.C + 8 * U.C + 8) * 4;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (wide) {
+    rc = ensure_lds<macow_unit_fwd_kernel<bf16_t, true>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((macow_unit_fwd_kernel<bf16_t, true>), dim3(U.B), dim3(kMcfThreads), lds, s, U);
+  } else {
+    rc = ensure_lds<macow_unit_fwd_kernel<bf16_t, false>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((macow_unit_fwd_kernel<bf16_t, false>), dim3(U.B), dim3(kMcfThreads), lds, s, U);
+  }
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* stream) {
+  UnitParams U;
+  int rc = unit_params(U, d4, dtype, true); if (rc) return rc;
+  IPK_REQUIRE(U.dy && U.dld && U.dx, "null gradient tensor");
+  const bool wide = U.Cp > 32;
+  const size_t dp_bytes = (size_t)64 * ((wide ? 128 : 64) * 2 + 16);
+  const size_t lds = dp_bytes + (size_t)65 * ((wide ? 256 : 128) * 2 + 16) + (size_t)64 * U.C * 4 + (2 * 4096 + 2 * 512) * 4;
+  IPK_REQUIRE((size_t)64 * U.C * 4 <= dp_bytes, "tap-half partials must fit the dparams tile");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (wide) {
+    rc = ensure_lds<macow_unit_bwd_kernel<bf16_t, true>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((macow_unit_bwd_kernel<bf16_t, true>), dim3(U.B), dim3(kMcfThreads), lds, s, U);
+  } else {
+    rc = ensure_lds<macow_unit_bwd_kernel<bf16_t, false>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((macow_unit_bwd_kernel<bf16_t, false>), dim3(U.B), dim3(kMcfThreads), lds, s, U);
+  }
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}

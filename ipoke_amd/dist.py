@@ -1,8 +1,11 @@
 """Data-parallel helpers: one process per GPU, torch.distributed over RCCL ("nccl" backend on ROCm) / gloo on CPU.
 
 The flow's gradients live in ONE flat fp32 buffer, so the gradient exchange of a step (N1 in SURVEY.md: 4.2-4.95 GB)
-is a handful of large all-reduces over contiguous slices instead of DDP's ~200 25-MB buckets; xGMI is
-point-to-point, large messages keep every link busy.  The mean is folded into the fused Adam step (grad_scale).
+is a handful of large collectives over contiguous slices instead of DDP's ~200 25-MB buckets; xGMI is
+point-to-point, large messages keep every link busy.  Default exchange (ipoke_amd.trainer, ipoke_amd.optim): per slice a
+reduce-scatter, the fused Adam-amsgrad update of this rank's 1/world shard (optimizer state sharded, ZeRO-1), an all-gather
+of the updated parameters; the mean is folded into the update (grad_scale).  The plain all-reduce + replicated update is
+kept as the reference path (IPOKE_NO_ZERO1=1) and for the non-overlapped mode.
 """
 import os
 
@@ -57,6 +60,27 @@ def allreduce_async(t):
                 return True
         return _Done()
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def shard_layout(n, world):
+    """(shard, main): a slice of n floats is cut into `world` equal shards of `shard` floats (multiples of 4: 16-byte
+    aligned shard boundaries for the fused optimizer kernel); the trailing n - main < 4 * world floats do not divide."""
+    shard = (n // (4 * world)) * 4
+    return shard, shard * world
+
+
+def reduce_scatter_async(out, inp):
+    """out <- this rank's 1/world slice of sum_ranks(inp) (inp.numel() == world * out.numel()); handle as allreduce_async."""
+    return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def all_gather_async(out, inp):
+    """out <- concatenation over ranks of inp (out.numel() == world * inp.numel())."""
+    return dist.all_gather_into_tensor(out, inp, async_op=True)
 
 
 def broadcast_(t, src=0):

@@ -34,6 +34,10 @@ class FlowEngine:
         for key in ("attention", "condition_nice", "cond_conv", "use1x1", "multistack", "augmented_input"):
             if arch.get(key, False):
                 raise NotImplementedError(f"architecture option {key}=True is outside the shipped iPOKE configs")
+        if float(arch.get("p_dropout", 0.0)) > 0.0:
+            raise NotImplementedError("p_dropout > 0 is not implemented (0.0 in every shipped config)")
+        if arch.get("reshape", "none") != "none":
+            raise NotImplementedError("reshape != 'none' is not implemented (every shipped config uses 'none')")
         if arch.get("transform", "affine") != "affine" or arch.get("prior_transform", "affine") != "affine":
             raise NotImplementedError("only the affine transform is implemented (shipped configs)")
         if arch.get("activation", "elu") != "elu" or arch.get("coupling_type", "conv") != "conv":
@@ -214,11 +218,24 @@ class FlowEngine:
                                                _lib.current_stream()))
         else:
             npieces, ready_stream, fn = self.grad_ready_hook
-            cb = _lib.GRAD_READY_FN(lambda user, piece, begin, end: fn(int(begin), int(end)))
+            failure = []
+
+            def _ready(user, piece, begin, end):
+                # an exception must not cross the C frame (ctypes would print and swallow it): keep the first one,
+                # skip the remaining slices, re-raise after the native call has returned
+                if failure:
+                    return
+                try:
+                    fn(int(begin), int(end))
+                except BaseException as exc:          # noqa: BLE001
+                    failure.append(exc)
+            cb = _lib.GRAD_READY_FN(_ready)
             check(self.lib.ipoke_flow_backward_pieces(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow),
                                                       ptr(st["d_out"]), ptr(st["d_logdet"]), B, ptr(grads),
                                                       ptr(st["dx"]) if need_dx else None, ptr(ws), int(npieces),
                                                       c_void_p(ready_stream.cuda_stream), cb, None, _lib.current_stream()))
+            if failure:
+                raise failure[0]
         return st["dx"].clone() if need_dx else None
 
 
@@ -357,6 +374,12 @@ class SupervisedMacowTransformer(nn.Module):
         else:
             raise NotImplementedError("partially initialised flows (mixed `initialized` flags) are not supported")
         self.engine.shadow_stale = True
+
+    def adopt_engine_perm(self):
+        """Write the engine's permutation table back into the named int64 shuffle buffers (after a broadcast of it)."""
+        perm = self.engine.perm.to("cpu", torch.int64)
+        for name, off, n in self._idx_names:
+            self.named_tensor(name).copy_(perm[off:off + n])
 
     def mark_weights_updated(self):
         """Call after changing parameters outside of the fused optimizer (e.g. manual edits)."""

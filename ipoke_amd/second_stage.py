@@ -154,6 +154,8 @@ class PokeMotionModel(nn.Module):
         if self.embed_poke_and_image:
             poke = torch.cat([poke, X[:, 0]], dim=1)
         self.first_stage_model.eval(); self.poke_embedder.eval()
+        if self.use_cond:
+            self.conditioner.eval()                   # :271-272
         with torch.no_grad():
             poke_emb, *_ = self.poke_embedder.encoder(poke)
             if self.use_cond:
@@ -187,9 +189,17 @@ class PokeMotionModel(nn.Module):
         result up.  The encoders do not depend on the flow's parameters, so this overlaps with the current step's
         backward pass (what a data-loader worker does for the reference's frozen first stage)."""
         cur = torch.cuda.current_stream()
+        # the side stream starts after everything already queued on the caller's stream: the batch may have been produced
+        # there (non-blocking H2D copies, GPU-side augmentation), and so are the lazily built weight operands of the first
+        # call.  It is issued right after the forward pass, so the overlap with the backward pass is kept.
+        stream.wait_stream(cur)
         with torch.cuda.stream(stream):
             flow_input, cond = self.make_flow_input(batch)
             ev = torch.cuda.Event(); ev.record(stream)
+        for v in batch.values():                       # tensors the side stream reads must not be recycled under it
+            for t_ in (v if isinstance(v, (list, tuple)) else [v]):
+                if torch.is_tensor(t_) and t_.is_cuda:
+                    t_.record_stream(stream)
         flow_input.record_stream(cur); cond.record_stream(cur)
         self._prefetched = (batch, flow_input, cond, ev)
 

@@ -15,6 +15,11 @@ class SecondStageTrainer:
 
     def __init__(self, model, n_grad_buckets=12, overlap=None):
         self.model = model
+        tr, bs = model.config["training"], model.config["data"]["batch_size"]
+        if tr.get("min_acc_batch_size", 0) > bs:
+            # experiments/experiment.py:83-88 turns this into Lightning's accumulate_grad_batches; the engine writes (not
+            # accumulates) the flat gradient buffer on every backward pass
+            raise NotImplementedError("gradient accumulation (training.min_acc_batch_size > data.batch_size) is not implemented")
         self.opt = model.configure_optimizers()[0]
         self.world = D.world_size()
         self.n_grad_buckets = n_grad_buckets = int(os.environ.get("IPOKE_PIECES", n_grad_buckets))
@@ -23,9 +28,14 @@ class SecondStageTrainer:
         # Also on one GPU (no exchange): the per-group Adam updates run underneath the backward chain with a one-workgroup-
         # per-CU grid (81.3 vs 82.3 ms; with the stand-alone 4096-workgroup grid they starve the chain: 85.2 ms).
         self.overlap = bool(overlap) and torch.cuda.is_available()
+        # data parallel: reduce-scatter + sharded update + all-gather per slice (ZeRO-1 over the flat buffer) instead of
+        # all-reduce + replicated update; IPOKE_GRAD_EXCHANGE=bf16 halves the bytes of the reduce-scatter
+        self.zero1 = self.world > 1 and self.overlap and os.environ.get("IPOKE_NO_ZERO1", "0") != "1"
+        if self.zero1:
+            gd = torch.bfloat16 if os.environ.get("IPOKE_GRAD_EXCHANGE", "f32") == "bf16" else torch.float32
+            self.opt.enable_sharding(self.world, D.rank(), gd)
         if self.overlap:
-            self.ready_stream = torch.cuda.Stream()
-            model.flow.engine.grad_ready_hook = (n_grad_buckets, self.ready_stream, self._grads_ready)
+            self.ready_stream = torch.cuda.Stream()      # the hook itself is installed around the backward of train_step only
         # train_step(batch, next_batch=...): the frozen encoders (first stage, poke, image) of the NEXT batch do not depend on the
         # flow's parameters; they are issued on their own stream right after this step's forward and run underneath its
         # latency-bound backward chain (86.2 -> 83.2 ms at c2).  Every step still runs one encoder pass.
@@ -44,6 +54,9 @@ class SecondStageTrainer:
         apply the optimizer update to that slice, all without blocking the backward chain."""
         flat = self.model.flow.flat_grads
         with torch.cuda.stream(self.ready_stream):
+            if self.zero1:
+                self.opt.step_range_sharded(begin, end, grad_scale=1.0 / self.world)
+                return
             if self.world > 1:
                 D.allreduce_async(flat[begin:end]).wait()        # orders ready_stream after the collective, host does not block
             self.opt.step_range(begin, end, grad_scale=1.0 / self.world)
@@ -56,7 +69,31 @@ class SecondStageTrainer:
             self.model.forward_density(batch)
         D.broadcast_(self.model.flow.flat_params, src=0)
         D.broadcast_(self.model.flow.engine.perm, src=0)
+        # the named int64 idx buffers of the state dict follow the engine's (now rank 0's) permutation: a later
+        # sync_buffers() / state_dict() on any rank sees the same shuffle as the weights
+        self.model.flow.adopt_engine_perm()
         self.model.flow.mark_weights_updated()
+
+    def on_train_epoch_start(self, num_training_batches):
+        """Call at every epoch start with this rank's number of batches (min(len(loader), max_batches_per_epoch): what
+        Lightning's ``trainer.num_training_batches`` holds): the reference's linear LR decay ends at
+        n_epochs * num_training_batches (second_stage_video.py:317-323).  Without it the horizon stays at
+        n_epochs * max_batches_per_epoch, the value for loaders at least that long."""
+        self.model.on_train_epoch_start(num_training_batches)
+
+    def fit(self, batches_per_epoch, n_epochs=None, get_batch=None):
+        """Minimal counterpart of pl.Trainer.fit: ``get_batch(epoch, i)`` supplies batches already resident on the GPU."""
+        n_epochs = self.model.config["training"]["n_epochs"] if n_epochs is None else n_epochs
+        n = min(int(batches_per_epoch), int(self.model.config["training"].get("max_batches_per_epoch", batches_per_epoch)))
+        loss = None
+        for epoch in range(n_epochs):
+            self.model.current_epoch = epoch
+            self.on_train_epoch_start(n)
+            nxt = get_batch(epoch, 0)
+            for i in range(n):
+                batch, nxt = nxt, (get_batch(epoch, i + 1) if i + 1 < n else None)
+                loss = self.train_step(batch, i, next_batch=nxt)
+        return loss
 
     def train_step(self, batch, batch_idx=0, next_batch=None):
         m = self.model
@@ -66,8 +103,13 @@ class SecondStageTrainer:
             m.prefetch_flow_input(next_batch, self.prefetch_stream)
         if self.overlap:
             self.opt.begin_step()
-            loss.backward()                   # exchanges and updates every slice from the engine's callbacks; on return the
-            self._optimizer_step(self.opt.finish_step)     # current stream is ordered after the ready stream
+            eng = m.flow.engine
+            eng.grad_ready_hook = (self.n_grad_buckets, self.ready_stream, self._grads_ready)
+            try:
+                loss.backward()               # exchanges and updates every slice from the engine's callbacks; on return the
+            finally:                          # current stream is ordered after the ready stream
+                eng.grad_ready_hook = None    # a backward outside train_step must not apply optimizer updates
+            self._optimizer_step(self.opt.finish_step)
         else:
             loss.backward()
             if self.world > 1:

@@ -38,8 +38,30 @@ def _worker(rank, world, port, out):
     for h in handles:
         h.wait()
     ok_pieces = torch.equal(flat2, expect)
+    # ZeRO-1 exchange of a slice (reduce-scatter -> update of the own shard -> all-gather, trailing elements all-reduced):
+    # same parameters on every rank as all-reduce + replicated update, for slice lengths that do not divide
+    ok_zero1 = True
+    for nn in (1003, 64, 5, 4 * world, 4 * world + 3):
+        g_loc = torch.arange(nn, dtype=torch.float32) * (rank + 1) + rank
+        p0 = torch.linspace(-1, 1, nn)
+        ref_g = g_loc.clone(); D.allreduce_flat_(ref_g, 1)
+        ref_p = p0 - 0.1 * ref_g / world
+        sh, main = D.shard_layout(nn, world)
+        assert sh % 4 == 0 and main <= nn and nn - main < 4 * world
+        p1 = p0.clone()
+        if sh > 0:
+            red = torch.empty(sh)
+            D.reduce_scatter_async(red, g_loc[:main].clone()).wait()
+            lo = rank * sh
+            own = p1[lo:lo + sh] - 0.1 * red / world
+            D.all_gather_async(p1[:main], own.clone()).wait()
+        if main < nn:
+            tail = g_loc[main:].clone()
+            D.allreduce_async(tail).wait()
+            p1[main:] -= 0.1 * tail / world
+        ok_zero1 = ok_zero1 and torch.allclose(p1, ref_p, rtol=0, atol=1e-6)
     D.barrier()
-    out[rank] = (ok_sum, ok_bcast, mx, ok_mean and ok_pieces)
+    out[rank] = (ok_sum, ok_bcast, mx, ok_mean and ok_pieces and ok_zero1)
     dist.destroy_process_group()
 
 

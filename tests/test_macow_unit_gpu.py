@@ -1,0 +1,174 @@
+"""Fused MaCowUnit kernels (csrc/mcf_unit.hip: conv1(A) -> conv2(B) -> actnorm1 -> conv3(C) -> conv4(D) -> actnorm2 in one
+launch per direction) against (i) the oracle's MaCowUnit (plain PyTorch fp32 restatement of macow2.py:925-995, autograd for
+the backward pass) and (ii) the chain of per-layer kernels, layer by layer, on every tensor the backward pass and the
+weight-gradient GEMMs consume."""
+import pytest
+import torch
+
+from ipoke_amd import _lib, ops
+from ipoke_amd.utils.detfill import deterministic_fill_
+from oracle import flow_ref
+from tests.helpers import mcf_shadows, tdt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DT = "bf16"
+
+
+def _unit(C, ld, B, seed):
+    o = flow_ref.MaCowUnit(C, (2, 3), 128)
+    deterministic_fill_(o, prefix=f"unit{C}.")
+    with torch.no_grad():
+        for an in (o.actnorm1, o.actnorm2):
+            an.initialized.fill_(1)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, ld, 8, 8, generator=gen)
+    h = torch.randn(B, 128, 8, 8, generator=gen)
+    layers = [o.conv1, o.conv2, o.conv3, o.conv4]
+    shs = [mcf_shadows({k: v.detach().to(DEV) for k, v in l.state_dict().items()}, "", C, 128, DT) for l in layers]
+    posts = [None, o.actnorm1, None, o.actnorm2]
+    return o, x, h, shs, posts
+
+
+def _descs(C, ld, B, cond, shs, posts, keep):
+    d4 = (_lib.McfDesc * 4)()
+    for k in range(4):
+        d = d4[k]
+        d.ld, d.C, d.B = ld, C, B
+        d.cond, d.Cc = cond.data_ptr(), cond.shape[1]
+        sh = shs[k]
+        d.W1, d.W2, d.bias2 = sh["W1"].data_ptr(), sh["W2"].data_ptr(), sh["bias"].data_ptr()
+        d.W1T, d.W2T = sh["W1T"].data_ptr(), sh["W2T"].data_ptr()
+        d.order = k
+        d.rows_per_block = 16
+        if posts[k] is not None:
+            ls = posts[k].log_scale.detach().flatten().to(DEV).contiguous()
+            pb = posts[k].bias.detach().flatten().to(DEV).contiguous()
+            keep += [ls, pb]
+            d.post_log_scale, d.post_bias = ls.data_ptr(), pb.data_ptr()
+    return d4
+
+
+@pytest.mark.parametrize("C,ld", [(8, 8), (30, 32), (32, 64), (60, 64), (64, 64)])
+def test_macow_unit_forward_backward(C, ld):
+    B = 3
+    M = B * 64
+    o, x, h, shs, posts = _unit(C, ld, B, 100 + C)
+    dims = shs[0]["dims"]
+    xs = ops.to_state(x.to(DEV))                      # [M][ld]: channels >= C pass through
+    cond = ops.cond_prepare(h.to(DEV), DT)
+    keep = []
+    L = _lib.lib()
+    # ---------------- fused forward
+    d4 = _descs(C, ld, B, cond, shs, posts, keep)
+    ys = [torch.full((M, ld), float("nan"), device=DEV) for _ in range(4)]
+    a2 = [torch.zeros(M, dims["K2p"], device=DEV, dtype=tdt(DT)) for _ in range(4)]
+    sc = [torch.zeros(M, C, device=DEV) for _ in range(4)]
+    slots = torch.zeros(4, B, 4, device=DEV)
+    d4[0].x = xs.data_ptr()
+    for k in range(4):
+        d4[k].y = ys[k].data_ptr(); d4[k].a2_save = a2[k].data_ptr(); d4[k].scale_save = sc[k].data_ptr()
+        d4[k].logdet_slot = slots[k].data_ptr()
+    _lib.check(L.ipoke_macow_unit_fwd(d4, _lib.DTYPES[DT], _lib.current_stream()))
+    torch.cuda.synchronize()
+    # ---------------- per-layer chain (the ActNorms as their own launches)
+    cur = xs
+    ref_states, ref_a2, ref_sc, ref_ld = [], [], [], []
+    for k in range(4):
+        y = torch.empty_like(cur)
+        a2k = torch.zeros(M, dims["K2p"], device=DEV, dtype=tdt(DT)); sck = torch.zeros(M, C, device=DEV)
+        ldk = torch.zeros(B, 4, device=DEV)
+        d = ops.mcf_desc(cur, C, B, cond, shs[k]["W1"], shs[k]["W2"], shs[k]["bias"], k)
+        d.y = y.data_ptr(); d.logdet_slot = ldk.data_ptr(); d.rows_per_block = 16
+        d.a2_save = a2k.data_ptr(); d.scale_save = sck.data_ptr()
+        _lib.check(L.ipoke_mcf_fwd(d, _lib.DTYPES[DT], _lib.current_stream()))
+        if posts[k] is not None:
+            y = ops.actnorm_fwd(y, 0, C, posts[k].log_scale.detach().flatten().to(DEV), posts[k].bias.detach().flatten().to(DEV))
+        ref_states.append(y); ref_a2.append(a2k); ref_sc.append(sck); ref_ld.append(ldk.sum(1))
+        cur = y
+    torch.cuda.synchronize()
+    for k in range(4):
+        got, ref = ys[k][:, :C] if k < 3 else ys[k], ref_states[k][:, :C] if k < 3 else ref_states[k]
+        # The fused kernels use the hardware exp / log / rcp for the fp32 transforms and exp(x) - 1 for the (bf16-rounded)
+        # ELU; the per-layer kernels use libm-grade tanhf / logf / expm1f.  Differences: ~1e-6 relative in the scales, an
+        # occasional bf16 ulp in a hidden activation (4e-3 relative), which moves (mu, s) of that position by ~1e-3.
+        e = (got - ref).abs().max().item()
+        assert e <= 1e-2, (k, e)
+        assert (a2[k].float() - ref_a2[k].float()).abs().max().item() <= 3e-2, k
+        assert (sc[k] - ref_sc[k]).abs().max().item() <= 5e-3, k
+        assert (slots[k].sum(1) - ref_ld[k]).abs().max().item() <= 5e-2, k
+    # ---------------- oracle (fp32 CPU): output and log-det
+    xo = x[:, :C].clone().requires_grad_(True)
+    yo, ldo = o(xo, h=h)
+    got_y = ops.from_state(ys[3], B, ld).cpu()
+    e_y = (got_y[:, :C] - yo.detach()).abs().max().item()
+    e_pass = (got_y[:, C:] - x[:, C:]).abs().max().item() if ld > C else 0.0
+    const_ld = 64.0 * (o.actnorm1.log_scale.sum() + o.actnorm2.log_scale.sum()).item()
+    e_ld = (slots.sum(dim=(0, 2)).cpu() + const_ld - ldo.detach()).abs().max().item()
+    print(f"unit C={C} ld={ld}: y err {e_y:.3e} pass-through err {e_pass:.1e} logdet err {e_ld:.3e}")
+    assert e_y <= 8e-2 and e_pass == 0.0 and e_ld <= 0.5
+    # ---------------- fused backward of 0.5*sum(y^2) - sum(logdet) : dy = y on the active channels
+    gen = torch.Generator().manual_seed(7)
+    dy = ys[3].clone()
+    if ld > C:
+        dy[:, C:] = torch.randn(M, ld - C, generator=gen).to(DEV)
+    dld = torch.full((B,), -1.0, device=DEV)
+    dx = torch.full((M, ld), float("nan"), device=DEV)
+    dprm = [torch.full((M, dims["K3p"]), float("nan"), device=DEV, dtype=tdt(DT)) for _ in range(4)]
+    dc = [torch.full((M, dims["Hq"]), float("nan"), device=DEV, dtype=tdt(DT)) for _ in range(4)]
+    dbp = [torch.zeros(B, 2 * C, device=DEV) for _ in range(4)]
+    ppart = [torch.zeros(B, 2 * C, device=DEV) for _ in range(4)]
+    b4 = _descs(C, ld, B, cond, shs, posts, keep)
+    ins = [xs, ys[0], ys[1], ys[2]]
+    for k in range(4):
+        b4[k].x = ins[k].data_ptr(); b4[k].a2_save = a2[k].data_ptr(); b4[k].scale_save = sc[k].data_ptr()
+        b4[k].dparams_save = dprm[k].data_ptr(); b4[k].dc_save = dc[k].data_ptr(); b4[k].dbias_part = dbp[k].data_ptr()
+        if posts[k] is not None:
+            b4[k].y_post = ys[k].data_ptr(); b4[k].post_part = ppart[k].data_ptr()
+    b4[3].dy = dy.data_ptr(); b4[0].dx = dx.data_ptr(); b4[0].dld = dld.data_ptr()
+    _lib.check(L.ipoke_macow_unit_bwd(b4, _lib.DTYPES[DT], _lib.current_stream()))
+    torch.cuda.synchronize()
+    # per-layer backward chain on the same saved tensors
+    g = dy
+    for k in (3, 2, 1, 0):
+        if posts[k] is not None:
+            g, dls_ref, db_ref = ops.actnorm_bwd(g, _pre_actnorm(ys[k], posts[k], C), 0, C,
+                                                 posts[k].log_scale.detach().flatten().to(DEV), None, dld, B)
+            got = ppart[k].sum(0)
+            s = max(dls_ref.abs().max().item(), 1.0)
+            assert (got[:C] - dls_ref).abs().max().item() <= 2e-4 * s and (got[C:] - db_ref).abs().max().item() <= 2e-4 * s, k
+        gx = torch.empty_like(g)
+        rp = torch.zeros(M, dims["K3p"], device=DEV, dtype=tdt(DT)); rc = torch.zeros(M, dims["Hq"], device=DEV, dtype=tdt(DT))
+        rb = torch.zeros(B, 2 * C, device=DEV)
+        d = ops.mcf_desc(ins[k], C, B, cond, shs[k]["W1"], shs[k]["W2"], shs[k]["bias"], k)
+        d.y = gx.data_ptr(); d.dy = g.data_ptr(); d.dx = gx.data_ptr(); d.dld = dld.data_ptr()
+        d.W2T = shs[k]["W2T"].data_ptr(); d.W1T = shs[k]["W1T"].data_ptr()
+        d.a2_save = a2[k].data_ptr(); d.scale_save = sc[k].data_ptr()
+        d.dparams_save = rp.data_ptr(); d.dc_save = rc.data_ptr(); d.dbias_part = rb.data_ptr()
+        _lib.check(L.ipoke_mcf_bwd(d, _lib.DTYPES[DT], _lib.current_stream()))
+        torch.cuda.synchronize()
+        for name, got, ref in (("dparams", dprm[k], rp), ("dc", dc[k], rc)):
+            assert torch.isfinite(got.float()).all(), (k, name)
+            e = (got.float() - ref.float()).abs().max().item() / max(ref.float().abs().max().item(), 1e-6)
+            assert e <= 2e-2, (k, name, e)
+        e = (dbp[k].sum(0) - rb.sum(0)).abs().max().item() / max(rb.sum(0).abs().max().item(), 1e-6)
+        assert e <= 1e-3, (k, "dbias", e)
+        g = gx
+    e_dx = (dx - g).abs().max().item() / g.abs().max().item()
+    assert torch.isfinite(dx).all() and e_dx <= 2e-2, e_dx
+    # oracle autograd: gradient with respect to the unit's input
+    (0.5 * (yo ** 2).sum() - ldo.sum()).backward()
+    got_dx = ops.from_state(dx, B, ld).cpu()
+    e_o = (got_dx[:, :C] - xo.grad).abs().max().item() / xo.grad.abs().max().item()
+    e_p = (got_dx[:, C:] - ops.from_state(dy, B, ld).cpu()[:, C:]).abs().max().item() if ld > C else 0.0
+    print(f"unit C={C} ld={ld}: dx vs per-layer chain {e_dx:.3e}, vs oracle autograd {e_o:.3e}")
+    assert e_o <= 5e-2 and e_p == 0.0
+
+
+def _pre_actnorm(y_post, an, C):
+    """input of an ActNorm from its output (the per-layer backward wants the saved input)"""
+    ls = an.log_scale.detach().flatten().to(y_post.device)
+    b = an.bias.detach().flatten().to(y_post.device)
+    x = y_post.clone()
+    x[:, :C] = (y_post[:, :C] - b) / ls.exp()
+    return x
