@@ -175,7 +175,10 @@ int ipoke_adam_amsgrad_step_grid(float* p, const float* g, float* m, float* v, f
 
 /* ---------------------------------------------------------------------------------------------
  * Fused masked convolutional flow (macow2.py:25-288, macow_utils.py:407-499).
- * Weight operands are the shadows produced by ipoke_flow_prepare_weights (dims: ipoke_mcf_shadow_dims).
+ * Weight operands are the shadows produced by ipoke_flow_prepare_weights (dims: ipoke_mcf_shadow_dims): matrices
+ * [rows][K] (W1: k = tap*Cp + c; W2: k over [hidden | cond]; W1T / W2T: their transposes), zero padded, stored
+ * FRAGMENT-TILED: tiles of 16 rows x 64 bytes of K, tile (rb, ks) at ((rb * K/Kt + ks) * 1024) bytes (Kt = 64 / element size),
+ * inside a tile the 16-byte chunk q of row r at (16 q + r) * 16 bytes -- one wave-wide fragment load is one contiguous KB.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   const float* x; float* y;       /* state in / out (distinct buffers), fwd: x->y, inv: y_in -> x_out */

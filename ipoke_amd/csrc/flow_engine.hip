@@ -56,7 +56,7 @@ struct Op {
 
 struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
   long src_off, s_n, s_k, dstA, dstB, scale_off;
-  int taps, n_real, k_real, A_rows_pad, A_inner_pad, B_rows_pad, B_inner_pad, B_rows_real, tile, tiles_k, block_start;
+  int taps, n_real, k_real, A_rows_pad, A_inner_pad, B_rows_pad, B_inner_pad, B_rows_real, tile, tiles_k, block_start, frag_tiled;
 };
 struct WnJobH { long v_off, g_off, out_off; int rows, K, row_start; };
 struct LsRefH { long off; int C; };
@@ -128,12 +128,12 @@ struct Builder {
   }
   // W[n][k][tap] -> A[n][tap][k] (padded) and B[k][tap][n] (padded; rows >= B_rows_real zero)
   void relayout_pair(long src, long s_n, long s_k, int taps, int n_real, int k_real, long scale, long dstA, int A_rows_pad,
-                     int A_inner_pad, long dstB, int B_rows_pad, int B_inner_pad, int B_rows_real) {
+                     int A_inner_pad, long dstB, int B_rows_pad, int B_inner_pad, int B_rows_real, int frag_tiled = 0) {
     const int tile = taps == 1 ? 64 : 32;
     const int n_ext = std::max(A_rows_pad, B_inner_pad), k_ext = std::max(A_inner_pad, B_rows_pad);
     const int tiles_n = (n_ext + tile - 1) / tile, tiles_k = (k_ext + tile - 1) / tile;
     RelayoutJobH j{src, s_n, s_k, dstA, dstB, scale, taps, n_real, k_real, A_rows_pad, A_inner_pad, B_rows_pad, B_inner_pad,
-                   B_rows_real, tile, tiles_k, f.rblocks};
+                   B_rows_real, tile, tiles_k, f.rblocks, frag_tiled};
     f.rjobs.push_back(j);
     f.rblocks += tiles_n * tiles_k;
   }
@@ -177,8 +177,9 @@ struct Builder {
     op.sh_w1t = add_shadow((int64_t)Cr * 6 * op.Hq);
     op.sh_w2 = add_shadow((int64_t)N2r * op.K2p);
     op.sh_w2t = add_shadow((int64_t)Hr * op.K3p);
-    relayout_pair(op.p_w1, (long)C * 6, 6, 6, op.H, C, -1, op.sh_w1, Hr, op.Cp, op.sh_w1t, Cr, op.Hq, C);
-    relayout_pair(op.p_v, K2, 1, 1, 2 * C, K2, op.wn_off, op.sh_w2, N2r, op.K2p, op.sh_w2t, Hr, op.K3p, op.H);
+    // masked-conv operands in the fragment-tiled order (prep.hip: tiled_offset)
+    relayout_pair(op.p_w1, (long)C * 6, 6, 6, op.H, C, -1, op.sh_w1, Hr, op.Cp, op.sh_w1t, Cr, op.Hq, C, 1);
+    relayout_pair(op.p_v, K2, 1, 1, 2 * C, K2, op.wn_off, op.sh_w2, N2r, op.K2p, op.sh_w2t, Hr, op.K3p, op.H, 1);
     op.slot = f.nslots++;
     op.mcf_idx = f.n_mcf++;
     f.ops.push_back(op);

@@ -65,9 +65,14 @@ __device__ __forceinline__ const unsigned char* tap_src_adj(const unsigned char*
   return ((unsigned)yy < 8u && (unsigned)xx < 8u) ? tile + (yy * 8 + xx) * pitch : zrow;
 }
 
+// 16-byte chunk [k, k + E16) of row `row` of a weight operand stored in the fragment-tiled order (prep.hip: tiled_offset):
+// tiles of 16 rows x 64 bytes, lane-linear inside, so that a wave's B-fragment load is one contiguous KB.
 template <typename T>
 __device__ __forceinline__ typename ET<T>::frag load_wfrag(const T* W, int ldw, int row, int k) {
-  return *reinterpret_cast<const typename ET<T>::frag*>(W + (long)row * ldw + k);
+  constexpr int KS = 64 / (int)sizeof(T), E16 = ET<T>::E16;
+  const int ks = k / KS, cq = k - ks * KS;
+  const long off = ((long)(row >> 4) * (ldw / KS) + ks) * (16 * KS) + (cq / E16) * (16 * E16) + (row & 15) * E16;
+  return *reinterpret_cast<const typename ET<T>::frag*>(W + off);
 }
 
 struct McfParams {

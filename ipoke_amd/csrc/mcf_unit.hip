@@ -30,7 +30,15 @@ struct UnitParams {
   UnitLayer L[4];
   const float* x; const void* cond; const float* dy; const float* dld; float* dx;
   int ld, C, B, Cc, H, Cp, K1p, K2p, K3p, Hq, slot_w;
+#ifdef IPOKE_UNIT_STAMPS
+  unsigned long long* stamps;       // probe build only (scripts/exp): shader-clock stamps of block 0
+#endif
 };
+#ifdef IPOKE_UNIT_STAMPS
+#define UNIT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && U.stamps) U.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UNIT_STAMP(i) do { } while (0)
+#endif
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -65,33 +73,36 @@ template <bool WIDE> struct UC {
   static constexpr int HS = WIDE ? 8 : 4;       // K steps per tap of the shifted conv's transpose (4C)
 };
 
+// Operands are stored fragment-tiled (prep.hip: tiled_offset): fragment (row block rb, K step ks) of a matrix with nks steps
+// per row is the KB at (rb * nks + ks) KB, lane l at byte 16 l.
 template <typename T, bool WIDE>
 __device__ __forceinline__ void unit_load_w1(McfW<T>& w, const void* W1, const UnitParams& U) {
-  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
+  constexpr int KS = K64<T>::value;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nks = U.K1p / KS;
   const rsrc_t rs = make_rsrc(W1, ((U.H + 15) & ~15) * U.K1p * (int)sizeof(T));
   int voff[UC<WIDE>::J1];
 #pragma unroll
-  for (int j = 0; j < UC<WIDE>::J1; ++j) voff[j] = (((wave + kMcfWaves * j) * 16 + r) * U.K1p + E16 * gq) * (int)sizeof(T);
+  for (int j = 0; j < UC<WIDE>::J1; ++j) voff[j] = (wave + kMcfWaves * j) * nks * 1024 + lane * 16;
 #pragma unroll
   for (int tap = 0; tap < 6; ++tap)
 #pragma unroll
     for (int st = 0; st < UC<WIDE>::CS; ++st) {
-      const int soff = (tap * U.Cp + st * KS) * (int)sizeof(T);
+      const int soff = (tap * UC<WIDE>::CS + st) * 1024;
 #pragma unroll
       for (int j = 0; j < UC<WIDE>::J1; ++j) w.w1[tap][st][j] = buf_frag<T>(rs, voff[j], soff);
     }
 }
 template <typename T, bool WIDE>
 __device__ __forceinline__ void unit_load_w2(McfW<T>& w, const void* W2, const UnitParams& U) {
-  constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
-  const rsrc_t rs = make_rsrc(W2, ((2 * U.C + 15) & ~15) * U.K2p * (int)sizeof(T));
+  constexpr int KS = K64<T>::value;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n2 = U.K2p / KS;
-  const int voff = ((wave * 16 + r) * U.K2p + E16 * gq) * (int)sizeof(T);
+  const rsrc_t rs = make_rsrc(W2, ((2 * U.C + 15) & ~15) * U.K2p * (int)sizeof(T));
+  const int voff = wave * n2 * 1024 + lane * 16;
 #pragma unroll
   for (int st = 0; st < UC<WIDE>::N2S; ++st)
-    w.w2[st][0] = buf_frag<T>(rs, voff, st < n2 ? st * KS * (int)sizeof(T) : kOob);   // unused K steps: out of range, zeros, no traffic
+    w.w2[st][0] = buf_frag<T>(rs, voff, st < n2 ? st * 1024 : kOob);   // unused K steps: out of range, zeros, no traffic
 }
 
 // fp32 transforms of the bf16-net mode: hardware exp / log / rcp (1-2 ulp) instead of the libm-grade tanhf / logf / expm1f
@@ -145,7 +156,8 @@ __device__ __forceinline__ void unit_gemm1(const unsigned char* xs, int xs_pitch
 }
 // raw (mu, s)[row][0:2C] = A2 x W2^T for all 64 rows (bias added by the epilogue)
 template <typename T, bool WIDE>
-__device__ __forceinline__ void unit_gemm2(const unsigned char* a2, int a2_pitch, float* prm, int N2, const McfW<T>& w, int lane, int wave) {
+__device__ __forceinline__ void unit_gemm2(const unsigned char* a2, int a2_pitch, float* prm, int N2, int prm_ld, const McfW<T>& w, int lane,
+                                           int wave) {
   constexpr int KS = K64<T>::value, E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
   const int r = lane & 15, gq = lane >> 4;
@@ -164,7 +176,7 @@ __device__ __forceinline__ void unit_gemm2(const unsigned char* a2, int a2_pitch
   const int n = wave * 16 + 4 * gq;
   if (n < N2) {      // 2C is a multiple of 4
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(prm + (i * 16 + r) * N2 + n) = acc[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(prm + (i * 16 + r) * prm_ld + n) = acc[i];
   }
 }
 
@@ -175,28 +187,47 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitP
   McfW<T> wr;
   unit_load_w1<T, WIDE>(wr, U.L[0].W1, U);         // every weight fragment of layer A is in flight from here on
   unit_load_w2<T, WIDE>(wr, U.L[0].W2, U);
+  UNIT_STAMP(0);
   const int C = U.C, N2 = 2 * C, ld = U.ld;
   constexpr int K2c = UC<WIDE>::N2S * 32;                          // tile width of the class (zero beyond K2p)
   const int xs_pitch = U.Cp * (int)sizeof(T) + 16;
   constexpr int a2_pitch = K2c * (int)sizeof(T) + 16;
   unsigned char* xs = smem;                                        // T [64 + zero row][Cp]
   unsigned char* a2 = xs + 65 * xs_pitch;                          // T [64][K2c]: [ELU(c) | ELU(cond) | 0]
-  float* prm = reinterpret_cast<float*>(a2 + 64 * a2_pitch);       // [64][2C] raw (mu, s)
-  float* xf = prm + 64 * N2;                                       // [64][C] fp32 state
+  const int prm_ld = N2 + 4;                                       // +4 floats: the fragment-shaped 16-byte stores of 16 rows hit 64 distinct banks
+  float* prm = reinterpret_cast<float*>(a2 + 64 * a2_pitch);       // [64][2C (+4)] raw (mu, s)
+  float* xf = prm + 64 * prm_ld;                                   // [64][C] fp32 state
   float* bias_s = xf + 64 * C;                                     // [4][2C]
   float* post_s = bias_s + 4 * N2;                                 // [4][2][C]: exp(log_scale), bias of the ActNorms
   float* red = post_s + 8 * C;                                     // [8]
   const long row0 = (long)b * 64;
   const int G2 = C >> 1;
+  const float inv_g2 = 1.f / (float)G2;
 
-  for (int i = tid; i < (65 * xs_pitch + 64 * a2_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
-  for (int i = tid; i < 4 * N2; i += kMcfThreads) bias_s[i] = U.L[i / N2].bias2[i % N2];
-  for (int i = tid; i < 4 * C; i += kMcfThreads) {
-    const UnitLayer& Lk = U.L[i / C];
-    const int c = i % C;
-    post_s[(i / C) * 2 * C + c] = Lk.post_ls ? __expf(Lk.post_ls[c]) : 1.f;
-    post_s[(i / C) * 2 * C + C + c] = Lk.post_ls ? Lk.post_bias[c] : 0.f;
+  // Everything the prologue reads from global memory is requested first (the sample's state, its conditioning rows, the
+  // biases / ActNorm parameters of the four layers), then the LDS tiles are zeroed while those loads are in flight.
+  constexpr int E16c = ET<T>::E16;
+  const int cchunks = U.Cc / E16c;                               // 16-byte chunks per conditioning row (<= 16)
+  const T* condp = reinterpret_cast<const T*>(U.cond) + row0 * U.Cc;
+  f32x2 xin[4]; u32x4 cin[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * kMcfThreads;
+    const int p = (int)(((float)e + 0.5f) * inv_g2), c = (e - p * G2) * 2;
+    if (e < 64 * G2) xin[i] = *reinterpret_cast<const f32x2*>(U.x + (row0 + p) * ld + c);
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * kMcfThreads;
+    if (e < 64 * cchunks) cin[i] = *reinterpret_cast<const u32x4*>(condp + (long)(e / cchunks) * U.Cc + (e % cchunks) * E16c);
+  }
+  float bias_v = 0.f, post_e = 1.f, post_b = 0.f;
+  if (tid < 4 * N2) bias_v = U.L[tid / N2].bias2[tid % N2];      // 4 * 2C <= 512
+  if (tid < 4 * C) {
+    const UnitLayer& Lq = U.L[tid / C];
+    if (Lq.post_ls) { post_e = Lq.post_ls[tid % C]; post_b = Lq.post_bias[tid % C]; }
+  }
+  for (int i = tid; i < (65 * xs_pitch + 64 * a2_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
   if (U.L[3].y && ld > C) {                         // pass-through channels go straight to the unit's output state
     const int R2 = (ld - C) >> 1;
     for (int e = tid; e < 64 * R2; e += kMcfThreads) {
@@ -205,23 +236,30 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitP
     }
   }
   __syncthreads();                                  // the zero fill above precedes the staging below
-  {   // ELU(cond) rows of this sample behind the hidden columns (the same for the four layers)
-    constexpr int E16 = ET<T>::E16;
-    const int chunks = U.Cc / E16;
-    const T* cond = reinterpret_cast<const T*>(U.cond) + row0 * U.Cc;
-    for (int i = tid; i < 64 * chunks; i += kMcfThreads) {
-      const int row = i / chunks, ch = i - row * chunks;
-      *reinterpret_cast<u32x4*>(a2 + row * a2_pitch + (U.H + ch * E16) * (int)sizeof(T)) = *reinterpret_cast<const u32x4*>(cond + (long)row * U.Cc + ch * E16);
+  if (tid < 4 * N2) bias_s[tid] = bias_v;
+  if (tid < 4 * C) {
+    const UnitLayer& Lq = U.L[tid / C];
+    post_s[(tid / C) * 2 * C + tid % C] = Lq.post_ls ? __expf(post_e) : 1.f;
+    post_s[(tid / C) * 2 * C + C + tid % C] = post_b;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {      // ELU(cond) rows of this sample behind the hidden columns (the same for the four layers)
+    const int e = tid + i * kMcfThreads;
+    if (e < 64 * cchunks)
+      *reinterpret_cast<u32x4*>(a2 + (e / cchunks) * a2_pitch + (U.H + (e % cchunks) * E16c) * (int)sizeof(T)) = cin[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * kMcfThreads;
+    const int p = (int)(((float)e + 0.5f) * inv_g2), c = (e - p * G2) * 2;
+    if (e < 64 * G2) {
+      *reinterpret_cast<f32x2*>(xf + p * C + c) = xin[i];
+      bf16x2 tv; tv[0] = ET<T>::from_f32(xin[i][0]); tv[1] = ET<T>::from_f32(xin[i][1]);
+      *reinterpret_cast<bf16x2*>(xs + p * xs_pitch + c * (int)sizeof(T)) = tv;
     }
   }
-  for (int e = tid; e < 64 * G2; e += kMcfThreads) {
-    const int p = e / G2, c = (e - p * G2) * 2;
-    const f32x2 v = *reinterpret_cast<const f32x2*>(U.x + (row0 + p) * ld + c);
-    *reinterpret_cast<f32x2*>(xf + p * C + c) = v;
-    bf16x2 tv; tv[0] = ET<T>::from_f32(v[0]); tv[1] = ET<T>::from_f32(v[1]);
-    *reinterpret_cast<bf16x2*>(xs + p * xs_pitch + c * (int)sizeof(T)) = tv;
-  }
   __syncthreads();
+  UNIT_STAMP(1);
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) {
     const UnitLayer& Lk = U.L[k];
@@ -235,8 +273,10 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitP
     unit_gemm1<T, WIDE>(xs, xs_pitch, g, a2, a2_pitch, U.H, wr, 0, lane, wave);
     unit_gemm1<T, WIDE>(xs, xs_pitch, g, a2, a2_pitch, U.H, wr, 1, lane, wave);
     __builtin_amdgcn_sched_barrier(0);
+    UNIT_STAMP(2 + 6 * k);
     if (k < 3) unit_load_w1<T, WIDE>(wr, U.L[k + 1].W1, U);      // next layer's shifted-conv weights: their registers are free
     __syncthreads();
+    UNIT_STAMP(3 + 6 * k);
     if (Lk.a2_save) {
       constexpr int E16 = ET<T>::E16;
       const int chunks = U.K2p / E16;
@@ -246,36 +286,56 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitP
         *reinterpret_cast<u32x4*>(dst + (long)row * U.K2p + ch * E16) = *reinterpret_cast<const u32x4*>(a2 + row * a2_pitch + ch * 16);
       }
     }
-    unit_gemm2<T, WIDE>(a2, a2_pitch, prm, N2, wr, lane, wave);
+    UNIT_STAMP(4 + 6 * k);
+    unit_gemm2<T, WIDE>(a2, a2_pitch, prm, N2, prm_ld, wr, lane, wave);
+    UNIT_STAMP(5 + 6 * k);
     __syncthreads();
+    UNIT_STAMP(6 + 6 * k);
     // affine coupling (+ ActNorm): y = (tanh(s/2) + 1) x + mu ; the fp32 state and its operand copy are updated in place
     float ld_acc = 0.f;
     const float* bk = bias_s + k * N2;
     const float* pe = post_s + k * 2 * C;
-#pragma unroll 1
-    for (int e = tl; e < 64 * G2; e += kMcfThreads) {
-      const int p = e / G2, c = (e - p * G2) * 2;
-      const f32x2 mu = *reinterpret_cast<const f32x2*>(prm + p * N2 + c);
-      const f32x2 sv = *reinterpret_cast<const f32x2*>(prm + p * N2 + C + c);
-      const f32x2 xv = *reinterpret_cast<const f32x2*>(xf + p * C + c);
-      f32x2 sc, yv;
+    {
+      // up to four (row, channel pair) items per thread, all LDS operands in flight before the transcendental math
+      f32x2 mu[4], sv[4], xv[4];
+      int pi[4], ci[4];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        sc[q] = fast_scale(sv[q] + bk[C + c + q]);
-        yv[q] = sc[q] * xv[q] + (mu[q] + bk[c + q]);
+      for (int i = 0; i < 4; ++i) {
+        const int e = tl + i * kMcfThreads;
+        pi[i] = (int)(((float)e + 0.5f) * inv_g2);              // e / G2, exact for e < 2048, G2 <= 32
+        ci[i] = (e - pi[i] * G2) * 2;
+        if (e < 64 * G2) {
+          mu[i] = *reinterpret_cast<const f32x2*>(prm + pi[i] * prm_ld + ci[i]);
+          sv[i] = *reinterpret_cast<const f32x2*>(prm + pi[i] * prm_ld + C + ci[i]);
+          xv[i] = *reinterpret_cast<const f32x2*>(xf + pi[i] * C + ci[i]);
+        }
       }
-      ld_acc += __logf(sc[0] * sc[1]);
-      if (Lk.scale_save) *reinterpret_cast<f32x2*>(Lk.scale_save + (row0 + p) * C + c) = sc;
-      if (Lk.post_ls) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) yv[q] = yv[q] * pe[c + q] + pe[C + c + q];
+      for (int i = 0; i < 4; ++i) {
+        const int e = tl + i * kMcfThreads;
+        if (e < 64 * G2) {
+          const int p = pi[i], c = ci[i];
+          f32x2 sc, yv;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            sc[q] = fast_scale(sv[i][q] + bk[C + c + q]);
+            yv[q] = sc[q] * xv[i][q] + (mu[i][q] + bk[c + q]);
+          }
+          ld_acc += __logf(sc[0] * sc[1]);
+          if (Lk.scale_save) *reinterpret_cast<f32x2*>(Lk.scale_save + (row0 + p) * C + c) = sc;
+          if (Lk.post_ls) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) yv[q] = yv[q] * pe[c + q] + pe[C + c + q];
+          }
+          *reinterpret_cast<f32x2*>(xf + p * C + c) = yv;
+          bf16x2 tv; tv[0] = ET<T>::from_f32(yv[0]); tv[1] = ET<T>::from_f32(yv[1]);
+          *reinterpret_cast<bf16x2*>(xs + p * xs_pitch + c * (int)sizeof(T)) = tv;
+          if (Lk.y) *reinterpret_cast<f32x2*>(Lk.y + (row0 + p) * ld + c) = yv;
+        }
       }
-      *reinterpret_cast<f32x2*>(xf + p * C + c) = yv;
-      bf16x2 tv; tv[0] = ET<T>::from_f32(yv[0]); tv[1] = ET<T>::from_f32(yv[1]);
-      *reinterpret_cast<bf16x2*>(xs + p * xs_pitch + c * (int)sizeof(T)) = tv;
-      if (Lk.y) *reinterpret_cast<f32x2*>(Lk.y + (row0 + p) * ld + c) = yv;
     }
     const float tot = block_sum(ld_acc, red);       // two barriers: the state update above is complete behind them
+    UNIT_STAMP(7 + 6 * k);
     if (tid == 0 && Lk.ld_slot) Lk.ld_slot[(long)b * U.slot_w] = tot;
     // the 1x1 weights of the next layer are not needed before its second contraction: requested here, they land
     // underneath its first one (and do not add to the register pressure of the epilogue above)
@@ -308,15 +368,15 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
   int vo_w2t[J1], vo_ca[J1];
 #pragma unroll
   for (int j = 0; j < J1; ++j) {
-    vo_w2t[j] = (((wave + kMcfWaves * j) * 16 + r) * U.K3p + E16 * gq) * (int)sizeof(T);
+    vo_w2t[j] = (wave + kMcfWaves * j) * n3 * 1024 + lane * 16;
     vo_ca[j] = (r * U.K2p + (wave + kMcfWaves * j) * 16 + 4 * gq) * (int)sizeof(T);
   }
-  const int vo_w1t = ((nfrag * 16 + r) * 6 * U.Hq + kh * 3 * U.Hq + E16 * gq) * (int)sizeof(T);
+  const int vo_w1t = (nfrag * 6 * hs + kh * 3 * hs) * 1024 + lane * 16;
   auto load_w2t = [&](const UnitLayer& Lk) {
     const rsrc_t rs = make_rsrc(Lk.W2T, Hr * U.K3p * (int)sizeof(T));
 #pragma unroll
     for (int st = 0; st < N3S; ++st) {
-      const int soff = st < n3 ? st * KS * (int)sizeof(T) : kOob;
+      const int soff = st < n3 ? st * 1024 : kOob;
 #pragma unroll
       for (int j = 0; j < J1; ++j) w2t[st][j] = buf_frag<T>(rs, vo_w2t[j], soff);
     }
@@ -337,23 +397,26 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int st = 0; st < HS; ++st)
-        w1t[t][st] = buf_frag<T>(rs, vo_w1t, st < hs ? (t * U.Hq + st * KS) * (int)sizeof(T) : kOob);
+        w1t[t][st] = buf_frag<T>(rs, vo_w1t, st < hs ? (t * hs + st) * 1024 : kOob);
   };
   load_w2t(U.L[3]); load_cact(U.L[3]); load_w1t(U.L[3]);
+  UNIT_STAMP(0);
 
   constexpr int dp_pitch = N3S * 32 * (int)sizeof(T) + 16;        // class widths: columns beyond K3p / Hq stay zero
   constexpr int dc_pitch = HS * 32 * (int)sizeof(T) + 16;
   unsigned char* dp = smem;                                       // T [64][K3p]  (later: fp32 [64][C] tap-half partials)
   unsigned char* dc = dp + 64 * dp_pitch;                         // T [64 + zero row][Hq]
   float* gb = reinterpret_cast<float*>(dc + 65 * dc_pitch);       // [64][C] running gradient / dy*scale
-  float* psum = gb + 64 * C;                                      // [2][rows_par <= 64][2C] per-thread partial column sums
+  const int CP = ((C + 3) & ~3) + 4;                              // row pitch of gb / part: 16-byte rows + 4 floats, so that the
+                                                                  // fragment-shaped accesses of phase (c) are bank-conflict free
+  float* psum = gb + 64 * CP;                                     // [2][rows_par <= 64][2C] per-thread partial column sums
   float* red2 = psum + 2 * 4096;                                  // [2][Q][2C]
   // one-time: zero tiles (K padding and the zero row stay zero), incoming gradient, pass-through channels
   for (int i = tid; i < (64 * dp_pitch + 65 * dc_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
   const int G2 = C >> 1;
   for (int e = tid; e < 64 * G2; e += kMcfThreads) {
     const int p = e / G2, c = (e - p * G2) * 2;
-    *reinterpret_cast<f32x2*>(gb + p * C + c) = *reinterpret_cast<const f32x2*>(U.dy + (row0 + p) * ld + c);
+    *reinterpret_cast<f32x2*>(gb + p * CP + c) = *reinterpret_cast<const f32x2*>(U.dy + (row0 + p) * ld + c);
   }
   if (ld > C) {
     const int R2 = (ld - C) >> 1;
@@ -377,6 +440,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
     asm volatile("" : "+v"(tl));
     const int lane = tl & 63, wave = tl >> 6, r = lane & 15, gq = lane >> 4, nfrag = wave & 3, kh = wave >> 2;
     const int c2 = (tl % G2) * 2, r0 = tl / G2;
+    UNIT_STAMP(1 + 6 * (3 - k));
     // (a) thread (r0, c2) owns the channel pair c2 of rows r0, r0 + rows_par, ... (at most 4)
     if (r0 < rows_used) {
       f32x2 xv[4], scv[4], ypv[4];
@@ -400,7 +464,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
       for (int i = 0; i < 4; ++i) {
         const int p = r0 + i * rows_par;
         if (p < 64) {
-          f32x2 gy = *reinterpret_cast<const f32x2*>(gb + p * C + c2);
+          f32x2 gy = *reinterpret_cast<const f32x2*>(gb + p * CP + c2);
           if (Lk.post_ls) {
             // ActNorm behind this layer: dls = sum dy (y_post - bias), dbias = sum dy, gradient passed on = dy exp(ls)
 #pragma unroll
@@ -420,7 +484,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
             tm[q] = ET<T>::from_f32(gy[q]); ts[q] = ET<T>::from_f32(ds[q]);
             sg[q] += gy[q]; sd[q] += ds[q];
           }
-          *reinterpret_cast<f32x2*>(gb + p * C + c2) = dxv;
+          *reinterpret_cast<f32x2*>(gb + p * CP + c2) = dxv;
           *reinterpret_cast<bf16x2*>(dp + p * dp_pitch + c2 * (int)sizeof(T)) = tm;
           *reinterpret_cast<bf16x2*>(dp + p * dp_pitch + (C + c2) * (int)sizeof(T)) = ts;
           *reinterpret_cast<bf16x2*>(dps + (row0 + p) * U.K3p + c2) = tm;
@@ -442,7 +506,9 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
         dps[(row0 + p) * U.K3p + j] = (T)0.f;
       }
     }
+    UNIT_STAMP(2 + 6 * (3 - k));
     __syncthreads();
+    UNIT_STAMP(3 + 6 * (3 - k));
     {   // column sums of the per-thread partials: Q threads per column, then one thread per column
       const int Q = kMcfThreads / N2;                            // >= 4
       const int col = tid % N2, part = tid / N2;
@@ -506,7 +572,9 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
         dcs[(row0 + p) * U.Hq + c] = (T)0.f;
       }
     }
+    UNIT_STAMP(4 + 6 * (3 - k));
     __syncthreads();
+    UNIT_STAMP(5 + 6 * (3 - k));
     if (tid < N2 && Lk.dbias_part) {
       const int Q = kMcfThreads / N2;
       float t = 0.f;
@@ -529,51 +597,70 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
       f32x4 acc_lo[2], acc_hi[2];
       auto pass_c = [&](auto half_c, f32x4* acc) {
         constexpr int h = decltype(half_c)::value;
+        constexpr int NS = 3 * HS, PD = 3;           // K steps of this wave's tap half; A fragments requested PD steps ahead
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* src[3][2];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const unsigned char* src[2];
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            src[i] = tap_src_adj(dc, zrow, dc_pitch, g, (2 * h + i) * 16 + r, kh * 3 + t) + E16 * gq * (int)sizeof(T);
+            src[t][i] = tap_src_adj(dc, zrow, dc_pitch, g, (2 * h + i) * 16 + r, kh * 3 + t) + E16 * gq * (int)sizeof(T);
+        // every MFMA needs its own A fragment here (one channel fragment per wave): without the explicit look-ahead the
+        // compiler issues read -> wait -> MFMA one at a time and the phase runs at LDS latency (19 k cycles per layer measured)
+        frag_t fa[PD + 1][2];
 #pragma unroll
-          for (int st = 0; st < HS; ++st) {
-            frag_t fa[2];
+        for (int s0 = 0; s0 < PD; ++s0)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const frag_t*>(src[i] + st * KS * (int)sizeof(T));
+          for (int i = 0; i < 2; ++i) fa[s0][i] = *reinterpret_cast<const frag_t*>(src[s0 / HS][i] + (s0 % HS) * KS * (int)sizeof(T));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) mma64(fa[i], w1t[t][st], acc[i]);
+        for (int s0 = 0; s0 < NS; ++s0) {
+          if (s0 + PD < NS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              fa[(s0 + PD) % (PD + 1)][i] = *reinterpret_cast<const frag_t*>(src[(s0 + PD) / HS][i] + ((s0 + PD) % HS) * KS * (int)sizeof(T));
           }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) mma64(fa[s0 % (PD + 1)][i], w1t[s0 / HS][s0 % HS], acc[i]);
         }
       };
       pass_c(std::integral_constant<int, 0>(), acc_lo);
       __builtin_amdgcn_sched_barrier(0);
+      UNIT_STAMP(32 + 4 * (3 - k));
       pass_c(std::integral_constant<int, 1>(), acc_hi);
       __builtin_amdgcn_sched_barrier(0);
+      UNIT_STAMP(33 + 4 * (3 - k));
       if (k > 0) load_w1t(U.L[k - 1]);
-      if (kh == 1) {
+      UNIT_STAMP(34 + 4 * (3 - k));
+      // the two tap halves meet in LDS: 16-byte accesses, a lane's 4 channels are contiguous (columns >= C are padding)
+      if (kh == 1 && n < C) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (n + q < C) part[(i * 16 + r) * C + n + q] = i < 2 ? acc_lo[i & 1][q] : acc_hi[i & 1][q];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(part + (i * 16 + r) * CP + n) = i < 2 ? acc_lo[i & 1] : acc_hi[i & 1];
       }
       __syncthreads();
-      if (kh == 0) {
+      if (kh == 0 && n < C) {
+        const bool vec_out = k == 0 && n + 3 < C && (ld & 3) == 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int p = i * 16 + r;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(gb + p * CP + n), a1 = *reinterpret_cast<const f32x4*>(part + p * CP + n);
+          const f32x4 a2v = i < 2 ? acc_lo[i & 1] : acc_hi[i & 1];
+          f32x4 v;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (n + q < C) {
-              const float v = gb[p * C + n + q] + (i < 2 ? acc_lo[i & 1][q] : acc_hi[i & 1][q]) + part[p * C + n + q];
-              gb[p * C + n + q] = v;
-              if (k == 0) U.dx[(row0 + p) * ld + n + q] = v;
+          for (int q = 0; q < 4; ++q) v[q] = a0[q] + a2v[q] + a1[q];
+          *reinterpret_cast<f32x4*>(gb + p * CP + n) = v;
+          if (k == 0) {
+            if (vec_out) *reinterpret_cast<f32x4*>(U.dx + (row0 + p) * ld + n) = v;
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (n + q < C) U.dx[(row0 + p) * ld + n + q] = v[q];
             }
+          }
         }
       }
       __syncthreads();
+      UNIT_STAMP(35 + 4 * (3 - k));
+      UNIT_STAMP(6 + 6 * (3 - k));
       if (k > 0) {   // `part` aliased the dparams tile: restore the zero K padding phase (a) does not rewrite
         const int padc = N3S * 32 - N2;
         for (int e = tid; e < 64 * padc; e += kMcfThreads) {
@@ -590,7 +677,7 @@ static int unit_params(UnitParams& U, const ipoke_mcf_desc* d, int dtype, bool b
   IPK_REQUIRE(dtype == IPOKE_BF16, "the fused MaCowUnit kernels take bf16 matrix-core inputs; f32 runs the per-layer kernels");
   const int C = d[0].C, ld = d[0].ld, Cc = d[0].Cc, B = d[0].B;
   IPK_REQUIRE(C >= 2 && C <= 64 && C % 2 == 0 && ld >= C && ld % 2 == 0, "even channel counts up to 64, even state pitch");
-  IPK_REQUIRE(Cc % 8 == 0 && 4 * C + Cc <= kW2Steps * 32, "conditioning width must be a multiple of 8 with 4C + Cc <= 384");
+  IPK_REQUIRE(Cc % 8 == 0 && Cc <= 128 && 4 * C + Cc <= kW2Steps * 32, "conditioning width: multiple of 8, <= 128, 4C + Cc <= 384");
   IPK_REQUIRE(B >= 1 && d[0].cond, "bad batch / null cond");
   std::memset(&U, 0, sizeof(U));
   U.ld = ld; U.C = C; U.B = B; U.Cc = Cc; U.cond = d[0].cond;
@@ -621,16 +708,24 @@ static int unit_params(UnitParams& U, const ipoke_mcf_desc* d, int dtype, bool b
 
 using namespace ipoke;
 
+#ifdef IPOKE_UNIT_STAMPS
+static unsigned long long* g_stamps = nullptr;
+extern "C" void ipoke_macow_unit_set_stamps(void* p) { g_stamps = reinterpret_cast<unsigned long long*>(p); }
+#endif
+
 extern "C" int ipoke_macow_unit_supported(int C, int Cc, int dtype) {
-  return dtype == IPOKE_BF16 && C >= 2 && C <= 64 && C % 2 == 0 && Cc % 8 == 0 && 4 * C + Cc <= kW2Steps * 32;
+  return dtype == IPOKE_BF16 && C >= 2 && C <= 64 && C % 2 == 0 && Cc % 8 == 0 && Cc <= 128 && 4 * C + Cc <= kW2Steps * 32;
 }
 
 extern "C" int ipoke_macow_unit_fwd(const ipoke_mcf_desc* d4, int dtype, void* stream) {
   UnitParams U;
   int rc = unit_params(U, d4, dtype, false); if (rc) return rc;
   IPK_REQUIRE(U.x && U.L[3].y, "null input / output state");
+#ifdef IPOKE_UNIT_STAMPS
+  U.stamps = g_stamps;
+#endif
   const bool wide = U.Cp > 32;
-  const size_t lds = (size_t)65 * (U.Cp * 2 + 16) + (size_t)64 * ((wide ? 384 : 256) * 2 + 16) + (size_t)64 * 2 * U.C * 4 +
+  const size_t lds = (size_t)65 * (U.Cp * 2 + 16) + (size_t)64 * ((wide ? 384 : 256) * 2 + 16) + (size_t)64 * (2 * U.C + 4) * 4 +
                      (size_t)64 * U.C * 4 + (size_t)(8 * U.C + 8 * U.C + 8) * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (wide) {
@@ -648,10 +743,14 @@ extern "C" int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* s
   UnitParams U;
   int rc = unit_params(U, d4, dtype, true); if (rc) return rc;
   IPK_REQUIRE(U.dy && U.dld && U.dx, "null gradient tensor");
+#ifdef IPOKE_UNIT_STAMPS
+  U.stamps = g_stamps;
+#endif
   const bool wide = U.Cp > 32;
   const size_t dp_bytes = (size_t)64 * ((wide ? 128 : 64) * 2 + 16);
-  const size_t lds = dp_bytes + (size_t)65 * ((wide ? 256 : 128) * 2 + 16) + (size_t)64 * U.C * 4 + (2 * 4096 + 2 * 512) * 4;
-  IPK_REQUIRE((size_t)64 * U.C * 4 <= dp_bytes, "tap-half partials must fit the dparams tile");
+  const size_t CP = ((U.C + 3) & ~3) + 4;
+  const size_t lds = dp_bytes + (size_t)65 * ((wide ? 256 : 128) * 2 + 16) + (size_t)64 * CP * 4 + (2 * 4096 + 2 * 512) * 4;
+  IPK_REQUIRE((size_t)64 * CP * 4 <= dp_bytes, "tap-half partials must fit the dparams tile");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (wide) {
     rc = ensure_lds<macow_unit_bwd_kernel<bf16_t, true>>(lds); if (rc) return rc;

@@ -21,7 +21,19 @@ struct RelayoutJob {
   int A_rows_pad, A_inner_pad, B_rows_pad, B_inner_pad, B_rows_real;
   int tile, tiles_k;   // tile edge (64 for 1x1, 32 otherwise), tiles along k
   int block_start;     // first block of this job
+  int frag_tiled;      // 1: both operands in the fragment-tiled order of the MCF kernels (tiled_offset below)
 };
+
+// Fragment-tiled order of the masked-conv-flow weight operands: the matrix [rows][ld] is cut into tiles of 16 rows x 64 bytes
+// of K (one matrix-core B fragment of one wave: lane l = 16 * (K chunk) + row holds 16 bytes), tile (rb, ks) at
+// (rb * ld/KS + ks) KB, lane-linear inside.  One wave-wide 16-byte load then reads ONE contiguous KB instead of sixteen
+// 64-byte row segments (half-used cache lines: 24 B/clk/CU measured; the weight stream of a layer bounds the MCF kernels).
+template <typename T>
+__device__ __forceinline__ long tiled_offset(int row, int col, int ld) {
+  constexpr int KS = 64 / (int)sizeof(T), E16 = 16 / (int)sizeof(T);
+  const int rb = row >> 4, r = row & 15, ks = col / KS, cq = col - ks * KS;
+  return ((long)rb * (ld / KS) + ks) * (16 * KS) + (cq / E16) * (16 * E16) + r * E16 + (cq % E16);
+}
 
 template <typename T> struct RPack4;
 template <> struct RPack4<bf16_t> { typedef __attribute__((ext_vector_type(4))) __bf16 type; };
@@ -78,7 +90,8 @@ __device__ __forceinline__ void relayout_tile(const RelayoutJob& j, const float*
       pack_t o;
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = ET<T>::from_f32(tile[(nl * TAPS + t) * TP + kl + q]);
-      *reinterpret_cast<pack_t*>(shadow + j.dstA + (long)n * ldA + t * j.A_inner_pad + k) = o;
+      const long off = j.frag_tiled ? tiled_offset<T>(n, t * j.A_inner_pad + k, ldA) : (long)n * ldA + t * j.A_inner_pad + k;
+      *reinterpret_cast<pack_t*>(shadow + j.dstA + off) = o;
     }
   }
   // B: rows k, columns (tap, n); four consecutive n per thread
@@ -91,7 +104,8 @@ __device__ __forceinline__ void relayout_tile(const RelayoutJob& j, const float*
       const bool live = k < j.B_rows_real;
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = ET<T>::from_f32(live ? tile[((nl + q) * TAPS + t) * TP + kl] : 0.f);
-      *reinterpret_cast<pack_t*>(shadow + j.dstB + (long)k * ldB + t * j.B_inner_pad + n) = o;
+      const long off = j.frag_tiled ? tiled_offset<T>(k, t * j.B_inner_pad + n, ldB) : (long)k * ldB + t * j.B_inner_pad + n;
+      *reinterpret_cast<pack_t*>(shadow + j.dstB + off) = o;
     }
   }
 }

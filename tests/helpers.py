@@ -43,6 +43,16 @@ def wn_scale(g, v):
     return g.flatten() / v.flatten(1).norm(dim=1)
 
 
+def frag_tile(buf):
+    """[rows][K] (rows % 16 == 0, K bytes % 64 == 0) -> the fragment-tiled order of the MCF weight operands (prep.hip:
+    tiled_offset): tiles of 16 rows x 64 bytes, 16-byte chunk q of row r at (16 q + r) * 16 bytes inside the tile."""
+    rows, K = buf.shape
+    e16 = 16 // buf.element_size()
+    ks = 4 * e16
+    assert rows % 16 == 0 and K % ks == 0
+    return buf.view(rows // 16, 16, K // ks, 4, e16).permute(0, 2, 3, 1, 4).contiguous().view(rows, K)
+
+
 def mcf_shadows(sd, prefix, C, Cc, dtype):
     """Shadows of one MaskedConvFlow from its (reference-keyed) state dict."""
     d = ops.mcf_dims(C, Cc, dtype)
@@ -58,7 +68,7 @@ def mcf_shadows(sd, prefix, C, Cc, dtype):
     weff = (v.flatten(1) * sc.view(-1, 1))[:, :H]                 # [2C][H]
     W2T = torch.zeros(d["Hr"], d["K3p"], device=v.device)
     W2T[:H, :2 * C] = weff.t()
-    return dict(W1=W1, W1T=W1T, W2=W2, W2T=W2T.to(tdt(dtype)).contiguous(), bias=b, dims=d)
+    return dict(W1=frag_tile(W1), W1T=frag_tile(W1T), W2=frag_tile(W2), W2T=frag_tile(W2T.to(tdt(dtype)).contiguous()), bias=b, dims=d)
 
 
 def synthetic_batch(B, T, size, seed=1, device="cpu"):
