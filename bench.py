@@ -286,6 +286,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.train_step(batch, args.warmup + i, next_batch=batch)
+    host_s = time.perf_counter() - t0                 # host time to queue the steps (the GPU is still running)
     torch.cuda.synchronize(); D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     loss_val = float(loss.item())
@@ -306,6 +307,7 @@ def main():
                        "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
                        "weights": "random init of the named architecture (no checkpoints offline)"},
             "loss": round(loss_val, 3),
+            "host_queue_ms_per_step": round(host_s / args.steps * 1e3, 2),
             "algorithmic_tflop_per_step_per_gpu": round(step_tflop, 2),
             "step_mfma_frac": round(step_tflop / (ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4),
             "step_hbm_frac_12P": round(12 * P_bytes / (ms * 1e-3) / 8e12, 4),

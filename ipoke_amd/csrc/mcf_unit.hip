@@ -185,8 +185,6 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitP
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   McfW<T> wr;
-  unit_load_w1<T, WIDE>(wr, U.L[0].W1, U);         // every weight fragment of layer A is in flight from here on
-  unit_load_w2<T, WIDE>(wr, U.L[0].W2, U);
   UNIT_STAMP(0);
   const int C = U.C, N2 = 2 * C, ld = U.ld;
   constexpr int K2c = UC<WIDE>::N2S * 32;                          // tile width of the class (zero beyond K2p)
@@ -227,6 +225,10 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitP
     const UnitLayer& Lq = U.L[tid / C];
     if (Lq.post_ls) { post_e = Lq.post_ls[tid % C]; post_b = Lq.post_bias[tid % C]; }
   }
+  // ... and behind them every weight fragment of layer A (vector-memory results return in issue order: requested first,
+  // the 295 KB of weights would hold the few KB of the prologue back)
+  unit_load_w1<T, WIDE>(wr, U.L[0].W1, U);
+  unit_load_w2<T, WIDE>(wr, U.L[0].W2, U);
   for (int i = tid; i < (65 * xs_pitch + 64 * a2_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
   if (U.L[3].y && ld > C) {                         // pass-through channels go straight to the unit's output state
     const int R2 = (ld - C) >> 1;
@@ -399,7 +401,6 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
       for (int st = 0; st < HS; ++st)
         w1t[t][st] = buf_frag<T>(rs, vo_w1t, st < hs ? (t * hs + st) * 1024 : kOob);
   };
-  load_w2t(U.L[3]); load_cact(U.L[3]); load_w1t(U.L[3]);
   UNIT_STAMP(0);
 
   constexpr int dp_pitch = N3S * 32 * (int)sizeof(T) + 16;        // class widths: columns beyond K3p / Hq stay zero
@@ -412,11 +413,24 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
   float* psum = gb + 64 * CP;                                     // [2][rows_par <= 64][2C] per-thread partial column sums
   float* red2 = psum + 2 * 4096;                                  // [2][Q][2C]
   // one-time: zero tiles (K padding and the zero row stay zero), incoming gradient, pass-through channels
-  for (int i = tid; i < (64 * dp_pitch + 65 * dc_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  // (the incoming gradient is requested before the weights: vector-memory results return in issue order)
   const int G2 = C >> 1;
-  for (int e = tid; e < 64 * G2; e += kMcfThreads) {
-    const int p = e / G2, c = (e - p * G2) * 2;
-    *reinterpret_cast<f32x2*>(gb + p * CP + c) = *reinterpret_cast<const f32x2*>(U.dy + (row0 + p) * ld + c);
+  const float inv_g2 = 1.f / (float)G2;
+  f32x2 gin[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * kMcfThreads;
+    const int p = (int)(((float)e + 0.5f) * inv_g2), c = (e - p * G2) * 2;     // e / G2, exact for e < 2048
+    if (e < 64 * G2) gin[i] = *reinterpret_cast<const f32x2*>(U.dy + (row0 + p) * ld + c);
+  }
+  const float g_ld = U.dld[b];
+  load_w2t(U.L[3]); load_cact(U.L[3]); load_w1t(U.L[3]);
+  for (int i = tid; i < (64 * dp_pitch + 65 * dc_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * kMcfThreads;
+    const int p = (int)(((float)e + 0.5f) * inv_g2), c = (e - p * G2) * 2;
+    if (e < 64 * G2) *reinterpret_cast<f32x2*>(gb + p * CP + c) = gin[i];
   }
   if (ld > C) {
     const int R2 = (ld - C) >> 1;
@@ -425,7 +439,6 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
       *reinterpret_cast<f32x2*>(U.dx + (row0 + p) * ld + c) = *reinterpret_cast<const f32x2*>(U.dy + (row0 + p) * ld + c);
     }
   }
-  const float g_ld = U.dld[b];
   const int rows_par = kMcfThreads / G2;                          // >= 16 (C <= 64)
   const int rows_used = rows_par < 64 ? rows_par : 64;
   const int c2 = (tid % G2) * 2, r0 = tid / G2;

@@ -184,7 +184,7 @@ class PokeMotionModel(nn.Module):
             length = X.size(1) - 1
         return self.first_stage_model.decode(motion, X[:, 0], length)
 
-    def prefetch_flow_input(self, batch, stream):
+    def prefetch_flow_input(self, batch, stream, after=None):
         """Run the frozen encoders for ``batch`` on ``stream`` now; the next ``forward_density(batch)`` (same object) picks the
         result up.  The encoders do not depend on the flow's parameters, so this overlaps with the current step's
         backward pass (what a data-loader worker does for the reference's frozen first stage)."""
@@ -192,7 +192,13 @@ class PokeMotionModel(nn.Module):
         # the side stream starts after everything already queued on the caller's stream: the batch may have been produced
         # there (non-blocking H2D copies, GPU-side augmentation), and so are the lazily built weight operands of the first
         # call.  It is issued right after the forward pass, so the overlap with the backward pass is kept.
-        stream.wait_stream(cur)
+        # ``after``: an event recorded on the caller's stream behind which the side stream may start (the trainer records
+        # it right after the forward pass and calls this once the backward pass is queued, so that the host does not hold
+        # the backward chain back by the ~7 ms it takes to queue the encoders)
+        if after is not None:
+            stream.wait_event(after)
+        else:
+            stream.wait_stream(cur)
         with torch.cuda.stream(stream):
             flow_input, cond = self.make_flow_input(batch)
             ev = torch.cuda.Event(); ev.record(stream)

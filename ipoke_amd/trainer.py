@@ -99,8 +99,10 @@ class SecondStageTrainer:
         m = self.model
         m.on_train_batch_start(batch, batch_idx, 0)
         loss = m.training_step(batch, batch_idx)
-        if next_batch is not None and self.prefetch_stream is not None:
-            m.prefetch_flow_input(next_batch, self.prefetch_stream)
+        prefetch = next_batch is not None and self.prefetch_stream is not None
+        if prefetch:
+            fwd_done = torch.cuda.Event()
+            fwd_done.record()                 # the encoders of the next batch may start behind the forward pass ...
         if self.overlap:
             self.opt.begin_step()
             eng = m.flow.engine
@@ -109,9 +111,13 @@ class SecondStageTrainer:
                 loss.backward()               # exchanges and updates every slice from the engine's callbacks; on return the
             finally:                          # current stream is ordered after the ready stream
                 eng.grad_ready_hook = None    # a backward outside train_step must not apply optimizer updates
+            if prefetch:                      # ... but are queued after the backward pass (host order = GPU start order)
+                m.prefetch_flow_input(next_batch, self.prefetch_stream, after=fwd_done)
             self._optimizer_step(self.opt.finish_step)
         else:
             loss.backward()
+            if prefetch:
+                m.prefetch_flow_input(next_batch, self.prefetch_stream, after=fwd_done)
             if self.world > 1:
                 D.allreduce_flat_(m.flow.flat_grads, self.n_grad_buckets)
             self._optimizer_step(lambda: self.opt.step(grad_scale=1.0 / self.world))
