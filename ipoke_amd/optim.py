@@ -58,7 +58,9 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         check(_lib.lib().ipoke_adam_amsgrad_step_grid(
             ptr(flat[sl]), ptr(grads[sl]), ptr(self.exp_avg[sl]), ptr(self.exp_avg_sq[sl]), ptr(self.max_exp_avg_sq[sl]), end - begin,
             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-            self.steps, float(grad_scale), 256, _lib.current_stream()))      # one workgroup per CU: runs underneath backward
+            self.steps, float(grad_scale), 128, _lib.current_stream()))      # persistent grid on half the CUs: runs underneath backward
+        # (a fused MaCowUnit workgroup cannot share a CU with one of these: 2 x 240 + 52 registers > 512; with a workgroup on
+        # every CU the chain stalled until the slice update had finished -- 74.3 vs 72.6 ms per step)
         self.flow.engine.prepare_weights_range(begin, end)                   # ... and so does the refresh of its shadows
         self._covered += end - begin
 
@@ -107,7 +109,7 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
                 red = red.float()
             lo = begin + self.rank * sh
             m, v, vmax = self._shard_state(begin, sh)
-            check(L.ipoke_adam_amsgrad_step_grid(ptr(flat[lo:lo + sh]), ptr(red), ptr(m), ptr(v), ptr(vmax), sh, *hyper, 256,
+            check(L.ipoke_adam_amsgrad_step_grid(ptr(flat[lo:lo + sh]), ptr(red), ptr(m), ptr(v), ptr(vmax), sh, *hyper, 128,
                                                  _lib.current_stream()))
             own = flat[lo:lo + sh].clone()                 # out-of-place input: valid for every backend
             D.all_gather_async(flat[begin:begin + main], own).wait()
