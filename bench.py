@@ -103,6 +103,37 @@ def kernel_roofline(B, dtype, iters=50):
             "algorithmic_gflop_per_launch": round(flops / 1e9, 3)}
 
 
+MCF_GFLOP = {32: 2.53, 64: 8.95}          # the 800 masked-conv flows of one sample, forward
+
+
+def insitu_rooflines(run_step, B, z, dtype):
+    """One extra (untimed) step with HIP events around every launch of the dominant kernel families, on the streams they
+    run on, while the rest of the step -- side-stream weight gradients, optimizer slices -- runs as usual."""
+    from ctypes import c_double, c_int
+    L = _lib.lib()
+    tags = (c_int * 4)(1, 2, 3, 4)
+    counts, mean = (c_int * 4)(), (c_double * 4)()
+    torch.cuda.synchronize()
+    _lib.check(L.ipoke_timing_start())
+    run_step()
+    _lib.check(L.ipoke_timing_stop(tags, 4, counts, mean))
+    hid, M = 2048, B * 64
+    gemm_gf = 2.0 * M * hid * hid / 1e9
+    unit_gf = B * MCF_GFLOP[z] / 200.0             # 200 MaCowUnits (4 flows each): mean over the 15 channel widths
+
+    def entry(k, kernel, gflop, what):
+        us = mean[k]
+        ach = gflop / us * 1e3 if us > 0 else 0.0           # GFLOP / us = 1000 TFLOP/s
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "kernel": kernel, "launches_in_step": int(counts[k]),
+                "avg_launch_us": round(us, 2), "algorithmic_gflop_per_launch": round(gflop, 3), "measured": what}
+    how = "HIP events around each launch on its own stream inside one full train step (in situ, side streams active)"
+    return [entry(0, f"igemm_nt_glds (NICE conv2 1x1 forward + data gradient, M={M} N=K=2048, {dtype})", gemm_gf, how),
+            entry(1, f"igemm_tn_glds (NICE conv2 weight gradient, 2048x2048 over M={M}, {dtype}; side stream)", gemm_gf, how),
+            entry(2, "macow_unit_fwd (4 masked-conv flows + 2 ActNorms per launch; mean over channel widths 8..64)", unit_gf, how),
+            entry(3, "macow_unit_bwd (data path of the same unit; FLOPs counted as the forward's)", unit_gf, how)]
+
+
 def usable_cores():
     """Host cores this process may actually use: CPU affinity capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -137,11 +168,14 @@ def cpu_baseline(cfg, clips=1, seed=1):
     flow = flow_ref.SupervisedMacowTransformer(configs.flow_arch(z))
     for m, pfx in ((fs, "first_stage."), (pe, "poke_embedder."), (ce, "conditioner.")):
         deterministic_fill_(m, prefix=pfx)
+    gen = torch.Generator().manual_seed(0)
     with torch.no_grad():
-        for k, v in flow.state_dict().items():      # cheap stable init: identity couplings, initialised flags
+        for k, v in flow.state_dict().items():      # the GPU leg's state: initialised flags, randomise_couplings() gains
             if k.endswith("initialized"):
                 v.fill_(1)
-            elif k.endswith(("weight_g", "bias")):
+            elif k.endswith("weight_g"):
+                v.copy_(0.02 + 0.01 * torch.rand(v.shape, generator=gen))
+            elif k.endswith("bias"):
                 v.zero_()
             elif k.endswith("log_scale"):
                 v.zero_()
@@ -149,20 +183,24 @@ def cpu_baseline(cfg, clips=1, seed=1):
     loss_fn = flow_ref.FlowLoss()
     batch = synthetic_batch(clips, T, size, seed, "cpu")
     t_build = time.time() - t_build
-    t0 = time.time()
-    with torch.no_grad():
-        poke_emb, *_ = pe.encoder(batch["flow"])
-        cond, *_ = ce.encoder(batch["images"][:, 0])
-        motion, mu, _ = fs.enc_motion(batch["images"].transpose(1, 2))
-    opt.zero_grad()
-    out, logdet = flow(motion.detach(), torch.cat([cond, poke_emb], 1))
-    loss, _ = loss_fn(out, logdet)
-    loss.backward()
-    opt.step()
-    dt = time.time() - t0
+
+    def step():
+        with torch.no_grad():
+            poke_emb, *_ = pe.encoder(batch["flow"])
+            cond, *_ = ce.encoder(batch["images"][:, 0])
+            motion, mu, _ = fs.enc_motion(batch["images"].transpose(1, 2))
+        opt.zero_grad()
+        out, logdet = flow(motion.detach(), torch.cat([cond, poke_emb], 1))
+        loss, _ = loss_fn(out, logdet)
+        loss.backward()
+        opt.step()
+
+    t0 = time.time(); step(); t_warm = time.time() - t0            # warm-up (allocator, thread pools, first-touch of 15 GB)
+    t0 = time.time(); step(); dt = time.time() - t0
     return {"value": round(clips * T / dt, 4), "unit": "video-frames/sec", "cores": ncores, "kind": "port",
-            "sample": f"{clips} clip(s) of the same workload (16x3x{size}x{size}, z={z}): encoders + flow fwd + FlowLoss + bwd + "
-                      f"Adam-amsgrad, oracle/ PyTorch fp32 CPU, one step = {dt:.1f}s (model build {t_build:.0f}s untimed)"}
+            "sample": f"{clips} clip(s) of the same workload (16x3x{size}x{size}, z={z}), same coupling initialisation as the GPU leg: "
+                      f"encoders + flow fwd + FlowLoss + bwd + Adam-amsgrad, oracle/ PyTorch fp32 CPU; 1 warm-up step ({t_warm:.1f}s), "
+                      f"1 timed step = {dt:.1f}s (model build {t_build:.0f}s untimed)"}
 
 
 def cpu_baseline_subprocess(config, clips, timeout_s):
@@ -243,8 +281,8 @@ def secondary(args, cfg, rank, world, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="c2 (default) is the configuration BASELINE.json's metric is quoted on; c4 = first-stage VAE train step "
                          "(L1 + KL), c5 = sampling (reverse flow + 15-frame decode): secondary workloads of SURVEY.md §8d")
@@ -283,19 +321,30 @@ def main():
     for i in range(args.warmup):
         trainer.train_step(batch, i, next_batch=batch)
     D.barrier(); torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
+        marks[i].record()                             # per-step boundaries on the stream (no host synchronisation)
         loss = trainer.train_step(batch, args.warmup + i, next_batch=batch)
-    host_s = time.perf_counter() - t0                 # host time to queue the steps (the GPU is still running)
+    marks[args.steps].record()
     torch.cuda.synchronize(); D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     loss_val = float(loss.item())
     ms = elapsed / args.steps * 1e3
     frames = world * B * T
     value = frames / (elapsed / args.steps)
 
+    insitu = insitu_rooflines(lambda: trainer.train_step(batch, args.warmup + args.steps, next_batch=batch), B, z, args.dtype) \
+        if args.dtype == "bf16" else None
     if rank == 0:
         roof = kernel_roofline(B, args.dtype)
+        if insitu:                       # the dominant kernel as it runs INSIDE the step; the isolated figure is kept beside it
+            iso = roof
+            roof = dict(insitu[0]); roof["traffic"] = iso["traffic"]; roof["traffic_unit"] = iso["traffic_unit"]
+            roof["algorithmic_bytes_per_launch"] = iso["algorithmic_bytes_per_launch"]
+            roof["isolated_avg_launch_us"] = iso["avg_launch_us"]; roof["isolated_frac"] = iso["frac"]
         P_bytes = model.flow.engine.n_params * 4
         step_tflop = B * (3 * FLOW_GFLOP[z] + ENC_GFLOP[size] + 0.47) / 1e3
         line = {
@@ -307,12 +356,14 @@ def main():
                        "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
                        "weights": "random init of the named architecture (no checkpoints offline)"},
             "loss": round(loss_val, 3),
-            "host_queue_ms_per_step": round(host_s / args.steps * 1e3, 2),
+            "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(per_step[0], 3), "ms_per_step_max": round(per_step[-1], 3),
             "algorithmic_tflop_per_step_per_gpu": round(step_tflop, 2),
             "step_mfma_frac": round(step_tflop / (ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4),
             "step_hbm_frac_12P": round(12 * P_bytes / (ms * 1e-3) / 8e12, 4),
             "roofline": roof,
         }
+        if insitu:
+            line["roofline_other_kernels"] = insitu[1:]
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_clips, args.cpu_timeout)
         print(json.dumps(line), flush=True)

@@ -7,3 +7,48 @@ int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 extern "C" const char* ipoke_last_error(void) { return ipoke::g_last_error.c_str(); }
 extern "C" int ipoke_version(void) { return 100; }
 extern "C" int ipoke_dtype_size(int dtype) { return dtype == IPOKE_BF16 ? 2 : dtype == IPOKE_F32 ? 4 : -1; }
+
+// ---- in-situ kernel timing (bench.py roofline): HIP events around tagged launches, recorded on the stream the kernel is
+// launched on, while the whole step runs as usual.  Off unless ipoke_timing_start() was called; never used in a timed step.
+#include <vector>
+namespace ipoke {
+struct TimedLaunch { int tag; hipEvent_t e0, e1; };
+static bool g_timing = false;
+static std::vector<TimedLaunch> g_timed;
+static std::vector<hipEvent_t> g_pool;
+static size_t g_pool_next = 0;
+static hipEvent_t pooled_event() {
+  if (g_pool_next == g_pool.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); g_pool.push_back(e); }
+  return g_pool[g_pool_next++];
+}
+bool timing_active() { return g_timing; }
+int timing_begin(int tag, hipStream_t s) {
+  if (!g_timing) return -1;
+  TimedLaunch t{tag, pooled_event(), pooled_event()};
+  (void)hipEventRecord(t.e0, s);
+  g_timed.push_back(t);
+  return (int)g_timed.size() - 1;
+}
+void timing_end(int slot, hipStream_t s) {
+  if (slot >= 0) (void)hipEventRecord(g_timed[slot].e1, s);
+}
+}  // namespace ipoke
+extern "C" int ipoke_timing_start(void) {
+  ipoke::g_timed.clear(); ipoke::g_pool_next = 0; ipoke::g_timing = true;
+  return IPOKE_OK;
+}
+/* stops recording; for every tag in tags[0..ntags) writes the number of recorded launches and their mean duration (us).
+ * Synchronises the device. */
+extern "C" int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us) {
+  ipoke::g_timing = false;
+  IPK_HIP(hipDeviceSynchronize());
+  for (int k = 0; k < ntags; ++k) { counts[k] = 0; mean_us[k] = 0.0; }
+  for (const auto& t : ipoke::g_timed) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) continue;
+    for (int k = 0; k < ntags; ++k) if (tags[k] == t.tag) { counts[k] += 1; mean_us[k] += 1e3 * ms; }
+  }
+  for (int k = 0; k < ntags; ++k) if (counts[k]) mean_us[k] /= counts[k];
+  ipoke::g_timed.clear();
+  return IPOKE_OK;
+}

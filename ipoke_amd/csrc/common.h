@@ -31,6 +31,16 @@ int fail(int code, const std::string& msg);
 
 #define IPK_LAUNCH_CHECK() IPK_HIP(hipGetLastError())
 
+// ---- in-situ timing of tagged launches (common.cpp; bench.py's roofline objects) ---------------------------------
+bool timing_active();
+int timing_begin(int tag, hipStream_t s);
+void timing_end(int slot, hipStream_t s);
+struct TimedScope {       // records an event pair around the launches issued while it is alive (no-op unless timing is on)
+  int slot; hipStream_t s;
+  TimedScope(int tag, hipStream_t st) : slot(tag != 0 && timing_active() ? timing_begin(tag, st) : -1), s(st) {}
+  ~TimedScope() { timing_end(slot, s); }
+};
+
 // ---- element traits --------------------------------------------------------
 template <typename T> struct ET;
 template <> struct ET<bf16_t> {

@@ -31,7 +31,7 @@ struct NtParams {
   const void* W; int ldw; int Nout; int Ktot;
   const float* bias; int act; const void* dact; int ld_dact, dact_act;
   void* C; int c_f32, c_acc; long ldc; int c_coff, c_cstride;
-  int splitk, kb_per_split, n_pad, ablate;
+  int splitk, kb_per_split, n_pad;
   int tiles_m, tiles_n, xa, xb;
 };
 
@@ -48,7 +48,6 @@ struct TnParams {
   int tiles_n, tiles_k;
   long split_stride;   // > 0: split z stores its slab at dW + z*split_stride instead of atomics
   int tile0, max_wgs;  // first output tile of this launch / cap on workgroups per launch (0: none)
-  int ablate;          // developer experiment (IPOKE_TN_ABLATE): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
 };
 
 // decode output row m -> input base coordinates
@@ -534,15 +533,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtPar
     for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(sub + b_rd[j][hs]);
   };
   int slot = 0;
-  if (p.ablate == 5) { wait_vmcnt<0>(); return; }                 // developer: launch + prologue only
-  if (p.ablate == 7) return;                                      // developer: launch + setup, nothing in flight... (DMAs issued)
-  for (int kb = kb_begin; kb < (p.ablate == 6 ? kb_begin : kb_end); kb += KPB) {
+  for (int kb = kb_begin; kb < kb_end; kb += KPB) {
     wait_vmcnt<(NSTAGE - 2) * L * KPB>();      // this wave's share of the oldest slot has landed
-    if (p.ablate < 3) __builtin_amdgcn_s_barrier();   // ... and everybody else's; all reads of the slot refilled below are done
-    if (p.ablate == 0 || p.ablate == 1) issue_slot((slot + NSTAGE - 1) % NSTAGE);
+    __builtin_amdgcn_s_barrier();                     // ... and everybody else's; all reads of the slot refilled below are done
+    issue_slot((slot + NSTAGE - 1) % NSTAGE);
     const unsigned char* base = smem + slot * STAGE;
     slot = (slot + 1) % NSTAGE;
-    if (p.ablate == 1) continue;
     const int nsub = min(KPB, kb_end - kb);
     // 2*nsub half-steps; fragments of half-step h+1 are fetched while the matrix cores work on h
     frag_t fa[2][MREP], fb[2][NREP];
@@ -550,7 +546,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtPar
 #pragma unroll
     for (int h = 0; h < 2 * KPB; ++h) {
       if (h < 2 * nsub) {
-        if (h + 1 < 2 * nsub && p.ablate != 4) load_frags(base + ((h + 1) >> 1) * SUB, (h + 1) & 1, fa[(h + 1) & 1], fb[(h + 1) & 1]);
+        if (h + 1 < 2 * nsub) load_frags(base + ((h + 1) >> 1) * SUB, (h + 1) & 1, fa[(h + 1) & 1], fb[(h + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
 #pragma unroll
@@ -661,11 +657,6 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
   auto load_stage = [&](int mb, u32x4* rset) {
     u32x4* ry = rset;
     u32x4* rx = rset + XO;
-    if (p.ablate & 1) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) rset[i] = u32x4{0u, 0u, 0u, 0u};
-      return;
-    }
     const int mbase = mb * RM + mbk * E16;
     if (do_y) {
       const T* yp = reinterpret_cast<const T*>(p.dY) + (long)mbase * p.ldy + p.y_coff + ncol;
@@ -723,7 +714,6 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
     }
   };
   auto store_stage = [&](int buf, const u32x4* rset) {
-    if (p.ablate & 2) return;
     if (do_y) store_block(sY + buf * 128 * kPitch, rset);
     if (do_x) store_block(sX + buf * 128 * kPitch, rset + XO);
   };
@@ -766,12 +756,10 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
               const int row = xrow + j * 16;
               fx[j] = *reinterpret_cast<const frag_t*>(x_base + row * kPitch + ((q ^ ((row >> LOGE) & 7)) * 16));
             }
-            if (!(p.ablate & 4)) {
 #pragma unroll
-              for (int ii = 0; ii < 4; ++ii)
+            for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma64(fy[ii], fx[j], acc[ii][j]);
-            }
+              for (int j = 0; j < 4; ++j) mma64(fy[ii], fx[j], acc[ii][j]);
           }
           if (i + 1 < nst) {
             store_stage(buf ^ 1, rs[(u + 1) % NR]);
@@ -783,7 +771,6 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
     }
   }
 
-  if (p.ablate & 8) return;
   // epilogue: acc[i][j][r] = dW[n = n0 + wm*64 + 16i + (lane&15)][k = k0 + wn*64 + 16j + 4*(lane>>4) + r]
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -1102,23 +1089,20 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     issue((slot + NSTAGE - 1) % NSTAGE, mb_begin + issued, issued < nst); ++issued;
     const unsigned char* base = smem + slot * STAGE;
     slot = (slot + 1) % NSTAGE;
-    if (!(p.ablate & 4)) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        frag_t fy[4], fx[2];
+    for (int ks = 0; ks < 2; ++ks) {
+      frag_t fy[4], fx[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fy[i] = tr_frag(base, y_rd[i] + ks * 32 * 256);
+      for (int i = 0; i < 4; ++i) fy[i] = tr_frag(base, y_rd[i] + ks * 32 * 256);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fx[j] = tr_frag(base, x_rd[j] + ks * 32 * 256);
+      for (int j = 0; j < 2; ++j) fx[j] = tr_frag(base, x_rd[j] + ks * 32 * 256);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma64(fy[i], fx[j], acc[i][j]);
-      }
+        for (int j = 0; j < 2; ++j) mma64(fy[i], fx[j], acc[i][j]);
     }
   }
   wait_vmcnt<0>();
-  if (p.ablate & 8) return;
 
   // epilogue: acc[i][j][r] = dW[n = n0 + wn2*64 + 16i + (lane&15)][k = k0 + wk*32 + 16j + 4*(lane>>4) + r]
 #pragma unroll
@@ -1153,7 +1137,6 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     const int S = 1 << (p.g.lDo + p.g.lHo + p.g.lWo);
     p.rows_fixed = (RM % S == 0) ? 1 : 0;
   }
-  { static const int ab = getenv("IPOKE_TN_ABLATE") ? atoi(getenv("IPOKE_TN_ABLATE")) : 0; p.ablate = ab; }
   if (p.splitm < 1) p.splitm = 1;
   if (p.splitm > nmb) p.splitm = nmb;
   p.mb_per_split = ceil_div(nmb, p.splitm);
@@ -1227,7 +1210,6 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   p.C = d->C; p.c_f32 = d->c_f32; p.c_acc = d->c_accumulate; p.ldc = d->ldc; p.c_coff = d->c_coff;
   p.c_cstride = d->c_cstride <= 0 ? 1 : d->c_cstride;
   p.splitk = d->splitk < 1 ? 1 : d->splitk;
-  p.ablate = getenv("IPOKE_ABLATE") ? atoi(getenv("IPOKE_ABLATE")) : 0;      // developer experiment: 1 = loads only, 2 = math only
   p.n_pad = d->Nout;
   if (!d->c_f32 && p.splitk == 1) {
     const long lim = d->ldc - d->c_coff;
@@ -1241,6 +1223,7 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
     IPK_REQUIRE(p.c_cstride == 1 && !d->c_accumulate, "dtype outputs are dense, non-accumulating");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TimedScope ts(p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 && p.splitk == 1 ? IPOKE_TAG_NT_SQUARE : 0, s);
   return dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
 }
 
@@ -1277,6 +1260,7 @@ extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stre
   TnParams p;
   int rc = fill_tn(p, d, dtype, false); if (rc) return rc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TimedScope ts(p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 ? IPOKE_TAG_TN_SQUARE : 0, s);
   return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s) : launch_tn<float>(p, s);
 }
 

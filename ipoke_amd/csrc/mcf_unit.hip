@@ -741,6 +741,7 @@ extern "C" int ipoke_macow_unit_fwd(const ipoke_mcf_desc* d4, int dtype, void* s
   const size_t lds = (size_t)65 * (U.Cp * 2 + 16) + (size_t)64 * ((wide ? 384 : 256) * 2 + 16) + (size_t)64 * (2 * U.C + 4) * 4 +
                      (size_t)64 * U.C * 4 + (size_t)(8 * U.C + 8 * U.C + 8) * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TimedScope ts(IPOKE_TAG_UNIT_FWD, s);
   if (wide) {
     rc = ensure_lds<macow_unit_fwd_kernel<bf16_t, true>>(lds); if (rc) return rc;
     hipLaunchKernelGGL((macow_unit_fwd_kernel<bf16_t, true>), dim3(U.B), dim3(kMcfThreads), lds, s, U);
@@ -765,6 +766,7 @@ extern "C" int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* s
   const size_t lds = dp_bytes + (size_t)65 * ((wide ? 256 : 128) * 2 + 16) + (size_t)64 * CP * 4 + (2 * 4096 + 2 * 512) * 4;
   IPK_REQUIRE((size_t)64 * CP * 4 <= dp_bytes, "tap-half partials must fit the dparams tile");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TimedScope ts(IPOKE_TAG_UNIT_BWD, s);
   if (wide) {
     rc = ensure_lds<macow_unit_bwd_kernel<bf16_t, true>>(lds); if (rc) return rc;
     hipLaunchKernelGGL((macow_unit_bwd_kernel<bf16_t, true>), dim3(U.B), dim3(kMcfThreads), lds, s, U);

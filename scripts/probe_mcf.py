@@ -44,4 +44,4 @@ def run(fn, n=256):
     for i in range(n): check(fn(ctypes.byref(descs[i % NW]), _lib.BF16, s))
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-print(f"C={C} B={B} ablate={os.environ.get('IPOKE_MCF_ABLATE','0')}: fwd {run(lib.ipoke_mcf_fwd):.1f} us  bwd {run(lib.ipoke_mcf_bwd):.1f} us")
+print(f"C={C} B={B}: fwd {run(lib.ipoke_mcf_fwd):.1f} us  bwd {run(lib.ipoke_mcf_bwd):.1f} us")

@@ -35,4 +35,4 @@ def run(ds, n=200):
 c2 = mk(1, 0, hid, hid, hid, hid, 1, 0)
 c3 = mk(3, 1, hid, 64, 64, hid * 9, 9, 1)
 c1 = mk(3, 1, 32, hid, hid, 32 * 9, 9, 1)
-print(f"B={B} ablate={os.environ.get('IPOKE_TN_ABLATE','0')}: conv2 {run(c2):.1f} us  conv3 {run(c3):.1f} us  conv1 {run(c1):.1f} us")
+print(f"B={B}: conv2 {run(c2):.1f} us  conv3 {run(c3):.1f} us  conv1 {run(c1):.1f} us")
