@@ -64,6 +64,22 @@ def randomise_couplings(model, seed=0):
     model.flow.mark_weights_updated()
 
 
+def pmc_traffic(kernel_substr, grid_size):
+    """HBM-side bytes per launch from the committed in-situ PMC passes (separate rocprofv3 --pmc runs of this bench, summarised
+    by scripts/pmc_summary.py): 2 x FETCH_SIZE (the gfx950 correction for 16-byte-per-lane streaming reads) + WRITE_SIZE, KB."""
+    try:
+        tot = 0.0
+        for counter, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            rows = json.load(open(os.path.join(ROOT, "profiles", f"r02_bench_pmc_{counter}.json")))
+            hit = [r for r in rows if kernel_substr in r["kernel"] and r["grid_size"] == grid_size and r["counter"] == counter]
+            if not hit:
+                return None
+            tot += mul * hit[0]["mean"] * 1024.0
+        return round(tot)
+    except Exception:
+        return None
+
+
 def kernel_roofline(B, dtype, iters=50):
     """Time the dominant GEMM ([B*64,2048] x [2048,2048]^T, 1x1 conv + ELU) on its own launches with HIP events."""
     dev = "cuda"
@@ -91,13 +107,9 @@ def kernel_roofline(B, dtype, iters=50):
     # (FETCH_SIZE x 2 -- the gfx950 correction for 16-byte-per-lane streaming reads -- plus WRITE_SIZE); null for other shapes
     traffic = None
     if M == 1280 and dtype == "bf16":
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_nice_conv2_gemm_pmc.json")))
-            traffic = round((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
-        except Exception:
-            traffic = None
+        traffic = pmc_traffic("igemm_nt_glds_kernel<bool _Accum, int, E, 8, 5, 1, 3, 1, t", str(256 * 512))
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_nice_conv2_gemm_pmc.json)",
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch: 2 x FETCH_SIZE + WRITE_SIZE of this kernel's dispatches INSIDE the train step (rocprofv3 --pmc, profiles/r02_bench_pmc_*.json)",
             "algorithmic_bytes_per_launch": int(2 * (M * hid + hid * hid + M * hid)),
             "kernel": "igemm_nt (NICE conv2 1x1, M=%d N=K=2048, %s)" % (M, dtype), "avg_launch_us": round(avg_s * 1e6, 2),
             "algorithmic_gflop_per_launch": round(flops / 1e9, 3)}

@@ -260,6 +260,15 @@ int ipoke_wn_bwd_multi_range(const float* params, float* grads, const float* inv
 int ipoke_timing_start(void);
 int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us);
 
+/* LU-parametrised invertible 1x1 convolution (macow2.py:596-649), used by the flow engine when use1x1 is set: prepare builds
+ * [W | W^-1 | wl | wu] (C*C floats each) per job in the workspace; apply: out[:, :C] = in[:, :C] mat^T (or mat), rest copied;
+ * wgrad writes dl, du, dlog_s of one layer into the flat gradient buffer. */
+int ipoke_lu_job_size(void);
+int ipoke_lu_prepare(const float* params, const float* fbuf, float* workspace, const void* jobs_dev, int njobs, void* stream);
+int ipoke_lu_apply(const float* in, float* out, int B, int ld, int C, const float* mat, int transposed, void* stream);
+int ipoke_lu_wgrad(const float* dy, const float* x, int B, int P8, int ld, const float* params, const float* fbuf,
+                   const float* workspace, const void* job_dev, const float* dld, float* grads, void* stream);
+
 typedef struct ipoke_flow ipoke_flow;
 typedef struct {
   int32_t z_channels;       /* flow_in_channels                               */
@@ -271,6 +280,7 @@ typedef struct {
   int32_t kernel_h, kernel_w;
   int32_t dtype;            /* IPOKE_F32 / IPOKE_BF16                         */
   int32_t max_batch;
+  int32_t use1x1;           /* LU-parametrised invertible 1x1 convs as the per-level shuffle layers (macow2.py:862) */
 } ipoke_flow_config;
 
 int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out);
@@ -280,9 +290,14 @@ int64_t ipoke_flow_index_count(const ipoke_flow* f);
 int32_t ipoke_flow_tensor_count(const ipoke_flow* f);
 int32_t ipoke_flow_op_count(const ipoke_flow* f);
 /* kind: 0 float parameter (offset in floats), 1 forward_shuffle_idx, 2 backward_shuffle_idx (offset in
- * int32 entries of perm), 3 uint8 `initialized` flag (host-side state only, offset -1) */
+ * int32 entries of perm), 3 uint8 `initialized` flag (host-side state only, offset -1), 4 float buffer (offset in floats of
+ * the float-buffer table: InvertibleConvLU1d's permutated / sign_s / lmask / umask / eye) */
 int ipoke_flow_tensor_info(const ipoke_flow* f, int i, char* name, int name_cap, int64_t* offset, int32_t* ndim,
                            int64_t* shape4, int32_t* kind);
+/* float buffers of the state dict (use1x1 only): element count of the table, and the caller-owned device copy the layer
+ * program reads (must be set before forward / reverse / backward when the count is non-zero) */
+int64_t ipoke_flow_float_buffer_count(const ipoke_flow* f);
+int ipoke_flow_set_float_buffers(ipoke_flow* f, const float* fbuf_dev);
 int64_t ipoke_flow_shadow_bytes(const ipoke_flow* f);
 /* introspection: fields of op i = {type, C, c0, Cn, p_ls, p_bias, idx_fwd, idx_bwd, order, p_w1, p_b, p_g, p_v, sh_w1,
  * sh_w1t, sh_w2, sh_w2t, wn_off, cin, cout, z_off, z_stride, t_off, t_stride, p_c1, p_c2, sh_c1, sh_c1t, sh_c2, sh_c2t,

@@ -77,7 +77,7 @@ class NormDesc(Structure):
 class FlowConfig(Structure):
     _fields_ = [("z_channels", c_int32), ("hidden", c_int32), ("cond_channels", c_int32), ("factor", c_int32),
                 ("n_levels", c_int32), ("num_steps", c_int32 * 32), ("kernel_h", c_int32), ("kernel_w", c_int32),
-                ("dtype", c_int32), ("max_batch", c_int32)]
+                ("dtype", c_int32), ("max_batch", c_int32), ("use1x1", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/ipoke_hip.h
@@ -161,6 +161,12 @@ SIGNATURES = {
     "ipoke_flow_tensor_info": (c_int, [_P, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32)]),
     "ipoke_flow_shadow_bytes": (c_int64, [_P]),
+    "ipoke_flow_float_buffer_count": (c_int64, [_P]),
+    "ipoke_flow_set_float_buffers": (c_int, [_P, _P]),
+    "ipoke_lu_job_size": (c_int, []),
+    "ipoke_lu_prepare": (c_int, [_P, _P, _P, _P, c_int, _P]),
+    "ipoke_lu_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "ipoke_lu_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "ipoke_flow_op_info": (c_int, [_P, c_int, POINTER(c_int64)]),
     "ipoke_flow_shadow_base": (c_int64, [_P]),
     "ipoke_flow_workspace_bytes": (c_int64, [_P, c_int, c_int]),

@@ -16,8 +16,8 @@
 
 namespace ipoke {
 
-enum OpType { OP_ACTNORM = 0, OP_MCF = 1, OP_NICE = 2 };
-enum TensorKind { TK_PARAM = 0, TK_IDX_FWD = 1, TK_IDX_BWD = 2, TK_FLAG = 3 };
+enum OpType { OP_ACTNORM = 0, OP_MCF = 1, OP_NICE = 2, OP_LU = 3 };
+enum TensorKind { TK_PARAM = 0, TK_IDX_FWD = 1, TK_IDX_BWD = 2, TK_FLAG = 3, TK_FBUF = 4 };
 
 struct TensorInfo {
   std::string name;
@@ -52,6 +52,7 @@ struct Op {
   bool fused = false;                          // ActNorm: executed by the preceding MCF layer (forward / backward)
   bool unit_head = false;                      // MCF: first of the six ops of a MaCowUnit that one fused launch executes
   int unit_of = -1;                            // index of the unit's first op for every op inside such a unit
+  int lu_idx = -1;                             // OP_LU: index into the LU job table
 };
 
 struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
@@ -60,6 +61,7 @@ struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
 };
 struct WnJobH { long v_off, g_off, out_off; int rows, K, row_start; };
 struct LsRefH { long off; int C; };
+struct LuJobH { long p_l, p_u, p_logs, b_perm, b_sign, b_lmask, b_umask, b_eye, w_off; int C, pad; };   // mirrors LuJob of lu.hip
 
 }  // namespace ipoke
 
@@ -70,7 +72,8 @@ struct ipoke_flow {
   int esz = 2, e16 = 8, ks = 32;
   std::vector<TensorInfo> tensors;
   std::vector<Op> ops;
-  int64_t n_params = 0, n_perm = 0;
+  int64_t n_params = 0, n_perm = 0, n_fbuf = 0;
+  std::vector<LuJobH> lujobs; void* d_lujobs = nullptr; const float* fbuf = nullptr;
   int64_t shadow_elems = 0;           // T elements
   int64_t wn_rows = 0;
   int nslots = 0;
@@ -93,7 +96,7 @@ struct ipoke_flow {
   // Units of the piecewise backward, in execution order: every MaCowStep of a level (kind 0, parameters in the layers.*
   // region) and every level's prior + shuffle (kind 1, priors.* region).  Consecutive units of one kind are adjacent in
   // the flat parameter buffer, the weight-norm job table and its row numbering.
-  struct Unit { int64_t p_lo, p_hi; int wj_lo, wj_hi, row_lo, row_hi; int kind; int op_lo, op_hi; };
+  struct Unit { int64_t p_lo, p_hi; int wj_lo, wj_hi, row_lo, row_hi; int kind; int op_lo, op_hi; int64_t p2_lo = -1, p2_hi = -1; };
   std::vector<Unit> units;
   std::vector<int> red_first;          // first reduction-table entry of op i (size nops + 1)
   int last_fwd_B = 0; bool have_saved = false;
@@ -121,6 +124,26 @@ struct Builder {
     return off;
   }
   void add_flag(const std::string& name) { f.tensors.push_back({name, -1, {}, TK_FLAG}); }
+  int64_t add_fbuf(const std::string& name, std::vector<int64_t> shape) {
+    int64_t n = 1; for (auto s : shape) n *= s;
+    const int64_t off = f.n_fbuf;
+    f.tensors.push_back({name, off, shape, TK_FBUF});
+    f.n_fbuf = align_up(off + n, 4);
+    return off;
+  }
+  // InvertibleConvLU1d (macow2.py:596-649): parameters l, u, log_s; buffers permutated, sign_s, lmask, umask, eye
+  void lu(const std::string& pfx, int C) {
+    Op op; op.type = OP_LU; op.C = C; op.lu_idx = (int)f.lujobs.size();
+    LuJobH j{};
+    j.C = C;
+    j.p_l = add_param(pfx + ".l", {C, C}); j.p_u = add_param(pfx + ".u", {C, C}); j.p_logs = add_param(pfx + ".log_s", {C});
+    j.b_perm = add_fbuf(pfx + ".permutated", {C, C}); j.b_sign = add_fbuf(pfx + ".sign_s", {C});
+    j.b_lmask = add_fbuf(pfx + ".lmask", {C, C}); j.b_umask = add_fbuf(pfx + ".umask", {C, C}); j.b_eye = add_fbuf(pfx + ".eye", {C, C});
+    j.w_off = (long)op.lu_idx * 4 * 64 * 64;
+    f.lujobs.push_back(j);
+    f.lsrefs.push_back({j.p_logs, C});          // log-det = P8 * sum(log_s): a constant per sample, like the ActNorms'
+    f.ops.push_back(op);
+  }
   int64_t add_shadow(int64_t elems) {
     const int64_t off = f.shadow_elems;
     f.shadow_elems = align_up(off + elems, 64);
@@ -286,7 +309,10 @@ int build(ipoke_flow& f) {
   for (int l = 0; l < L; ++l) {
     f.ops.clear();
     const std::string sh = "flow.shuffle_layers." + std::to_string(l);
-    b.actnorm("", Cs[l], 0, Cs[l], &sh);
+    prior_units[l].p2_lo = f.n_params;
+    if (c.use1x1) b.lu(sh, Cs[l]); else b.actnorm("", Cs[l], 0, Cs[l], &sh);
+    prior_units[l].p2_hi = f.n_params;
+    if (prior_units[l].p2_hi == prior_units[l].p2_lo) prior_units[l].p2_lo = prior_units[l].p2_hi = -1;
     shuf_ops[l] = f.ops;
   }
   f.ops.clear();
@@ -338,6 +364,7 @@ struct Plan {
   int64_t state0 = 0, state_stride = 0;     // saved states S[0..nops]
   int64_t g0 = 0, g1 = 0;                   // gradient ping-pong
   int64_t tmp_h1 = 0, tmp_h2 = 0, tmp_zc = 0;   // shared hidden buffers when nothing is saved
+  int64_t lu = 0;                               // [W | W^-1 | wl | wu] of every LU 1x1 conv
 };
 constexpr int kMaxLanes = 4;
 int64_t take(int64_t& cur, int64_t bytes) { const int64_t o = cur; cur = align_up(cur + bytes, 256); return o; }
@@ -366,6 +393,7 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
   p.partials_lane = align_up((int64_t)32 * M * 64 * 4, 256);   // upper bound of splitk * M_lane * 64 floats
   p.partials = take(cur, kMaxLanes * p.partials_lane);
   p.state_stride = align_up(M * ld * 4, 256);
+  p.lu = take(cur, (int64_t)f.lujobs.size() * 4 * 64 * 64 * 4 + 256);
   if (mode == 0) {
     p.state0 = take(cur, 2 * p.state_stride);
     p.tmp_h1 = take(cur, M * hid * f.esz);
@@ -470,6 +498,18 @@ void mcf_desc(const Ctx& c, const Op& op, ipoke_mcf_desc& d) {
   d.ld = c.ld; d.C = op.C; d.B = c.B; d.cond = c.cond(); d.Cc = c.f->cfg.cond_channels;
   d.W1 = c.sh(op.sh_w1); d.W2 = c.sh(op.sh_w2); d.bias2 = c.params + op.p_b; d.order = op.order;
   d.W1T = c.sh(op.sh_w1t); d.W2T = c.sh(op.sh_w2t);
+}
+
+// W, W^-1, wl, wu of every LU 1x1 conv into the workspace (one launch; the matrices depend on the current parameters)
+int lu_prepare_all(const Ctx& c) {
+  ipoke_flow* f = c.f;
+  if (f->lujobs.empty()) return IPOKE_OK;
+  IPK_REQUIRE(f->fbuf != nullptr, "use1x1: ipoke_flow_set_float_buffers has not been called");
+  IPK_REQUIRE(f->n_lanes == 1, "use1x1 does not support sub-batch lanes");
+  return ipoke_lu_prepare(c.params, f->fbuf, c.at<float>(c.plan.lu), f->d_lujobs, (int)f->lujobs.size(), c.stream());
+}
+const float* lu_mat(const Ctx& c, const Op& op, int which) {     // 0 W, 1 W^-1
+  return c.at<float>(c.plan.lu) + (int64_t)op.lu_idx * 4 * 64 * 64 + (int64_t)which * op.C * op.C;
 }
 
 int common_checks(ipoke_flow* f, int B) {
@@ -581,6 +621,11 @@ static int ensure_device(ipoke_flow* f) {
   }
   IPK_HIP(hipMalloc(&f->d_wjobs, f->wjobs.size() * sizeof(WnJobH)));
   IPK_HIP(hipMemcpy(f->d_wjobs, f->wjobs.data(), f->wjobs.size() * sizeof(WnJobH), hipMemcpyHostToDevice));
+  if (!f->lujobs.empty()) {
+    IPK_REQUIRE((int)sizeof(LuJobH) == ipoke_lu_job_size(), "LU job table layout mismatch");
+    IPK_HIP(hipMalloc(&f->d_lujobs, f->lujobs.size() * sizeof(LuJobH)));
+    IPK_HIP(hipMemcpy(f->d_lujobs, f->lujobs.data(), f->lujobs.size() * sizeof(LuJobH), hipMemcpyHostToDevice));
+  }
   IPK_HIP(hipMalloc(&f->d_lsrefs, f->lsrefs.size() * sizeof(LsRefH)));
   IPK_HIP(hipMemcpy(f->d_lsrefs, f->lsrefs.data(), f->lsrefs.size() * sizeof(LsRefH), hipMemcpyHostToDevice));
   {   // weight gradients are off the critical path: lowest priority so that chain kernels get the CUs first
@@ -602,6 +647,7 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   if (f->d_rjobs) (void)hipFree(f->d_rjobs);
   if (f->d_wjobs) (void)hipFree(f->d_wjobs);
   if (f->d_lsrefs) (void)hipFree(f->d_lsrefs);
+  if (f->d_lujobs) (void)hipFree(f->d_lujobs);
   if (f->d_rblockjob) (void)hipFree(f->d_rblockjob);
   if (f->d_w1tab) (void)hipFree(f->d_w1tab);
   if (f->d_w2tab) (void)hipFree(f->d_w2tab);
@@ -616,6 +662,12 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
 
 extern "C" int64_t ipoke_flow_param_count(const ipoke_flow* f) { return f ? f->n_params : -1; }
 extern "C" int64_t ipoke_flow_index_count(const ipoke_flow* f) { return f ? f->n_perm : -1; }
+extern "C" int64_t ipoke_flow_float_buffer_count(const ipoke_flow* f) { return f ? f->n_fbuf : -1; }
+extern "C" int ipoke_flow_set_float_buffers(ipoke_flow* f, const float* fbuf_dev) {
+  IPK_REQUIRE(f != nullptr, "null flow handle");
+  f->fbuf = fbuf_dev;
+  return IPOKE_OK;
+}
 extern "C" int32_t ipoke_flow_tensor_count(const ipoke_flow* f) { return f ? (int32_t)f->tensors.size() : -1; }
 extern "C" int32_t ipoke_flow_op_count(const ipoke_flow* f) { return f ? (int32_t)f->ops.size() : -1; }
 extern "C" int ipoke_flow_tensor_info(const ipoke_flow* f, int i, char* name, int name_cap, int64_t* offset, int32_t* ndim,
@@ -798,6 +850,7 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
     if (rc) return rc;
   }
   IPK_HIP(hipMemsetAsync(c.at<void>(c.plan.slots), 0, (size_t)f->nslots * B * 4 * sizeof(float), c.s));
+  rc = lu_prepare_all(c); if (rc) return rc;
   // the data-dependent ActNorm init needs whole-batch statistics: one lane
   std::vector<Ctx> lanes;
   rc = make_lanes(c, init ? 1 : f->n_lanes, lanes); if (rc) return rc;
@@ -806,7 +859,7 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
   int cur = 0;
   for (size_t i = 0; i < f->ops.size(); ++i) {
     const Op& op = f->ops[i];
-    if (init && op.type != OP_ACTNORM) continue;   // zero-initialised couplings are the identity (macow_utils.py:231-250)
+    if (init && op.type != OP_ACTNORM && op.type != OP_LU) continue;   // zero-initialised couplings are the identity (macow_utils.py:231-250)
     if (!init && op.unit_head) {                   // whole MaCowUnit (ops i .. i+5) in one launch
       const int nxt = save ? (int)i + 6 : (cur ^ 1);
       static const int lidx[4] = {0, 1, 3, 4};     // the four masked convs among the six ops
@@ -834,7 +887,9 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
     const int nxt = save ? (int)i + (fuse ? 2 : 1) : (cur ^ 1);
     for (const Ctx& l : lanes) {
       const float* in = l.state(cur); float* out = l.state(nxt);
-      if (op.type == OP_ACTNORM) {
+      if (op.type == OP_LU) {
+        rc = ipoke_lu_apply(in, out, l.B, l.ld, op.C, lu_mat(l, op, 0), 0, l.stream());
+      } else if (op.type == OP_ACTNORM) {
         const float* ls = op.p_ls >= 0 ? params + op.p_ls : nullptr;
         const float* bs = op.p_bias >= 0 ? params + op.p_bias : nullptr;
         const int32_t* idx = op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr;
@@ -893,7 +948,7 @@ extern "C" int ipoke_flow_init_forward(ipoke_flow* f, float* params, const int32
   IPK_REQUIRE(f && params, "null argument");
   // weight-norm layers with zero_init: g <- 0/(std+1e-6) = 0, bias <- -mean*0 = 0 (macow_utils.py:231-250)
   for (const Op& op : f->ops) {
-    if (op.type == OP_ACTNORM) continue;
+    if (op.type == OP_ACTNORM || op.type == OP_LU) continue;
     const int n = op.type == OP_MCF ? 2 * op.C : 2 * op.cout;
     IPK_HIP(hipMemsetAsync(params + op.p_g, 0, n * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
     IPK_HIP(hipMemsetAsync(params + op.p_b, 0, n * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
@@ -916,6 +971,7 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
   rc = ipoke_nchw_to_state(z_nchw, c.state(0), B, z, f->P, c.ld, stream); if (rc) return rc;
   rc = ipoke_cond_prepare(cond_nchw, c.cond(), B, f->cfg.cond_channels, f->P, IPOKE_ACT_ELU, c.dtype, stream);
   if (rc) return rc;
+  rc = lu_prepare_all(c); if (rc) return rc;
   std::vector<Ctx> lanes;
   rc = make_lanes(c, f->n_lanes, lanes); if (rc) return rc;
   rc = fork_lanes(f, c.s, lanes); if (rc) return rc;
@@ -925,7 +981,9 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
     const Op& op = f->ops[i];
     for (const Ctx& l : lanes) {
       const float* in = l.state(cur); float* out = l.state(cur ^ 1);
-      if (op.type == OP_ACTNORM) {
+      if (op.type == OP_LU) {
+        rc = ipoke_lu_apply(in, out, l.B, l.ld, op.C, lu_mat(l, op, 1), 0, l.stream());
+      } else if (op.type == OP_ACTNORM) {
         rc = ipoke_actnorm_inv(in, out, (int)l.M, l.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
                                op.p_bias >= 0 ? params + op.p_bias : nullptr, op.idx_bwd >= 0 ? perm + op.idx_bwd : nullptr,
                                l.stream());
@@ -1052,13 +1110,15 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       if (r) return r;
     }
     // layers.* and priors.* are separate flat regions: the units of one kind inside the piece form one contiguous range each
-    int64_t p0[2] = {-1, -1}, p1[2] = {-1, -1};
-    int wj0[2] = {0, 0}, wj1[2] = {0, 0}, rw0[2] = {0, 0}, rw1[2] = {0, 0};
+    // (use1x1: the LU convs' parameters form a third region, flow.shuffle_layers.*, without weight-norm rows)
+    int64_t p0[3] = {-1, -1, -1}, p1[3] = {-1, -1, -1};
+    int wj0[3] = {0, 0, 0}, wj1[3] = {0, 0, 0}, rw0[3] = {0, 0, 0}, rw1[3] = {0, 0, 0};
     for (int u = lvl_lo; u <= lvl_hi; ++u) {
       const auto& un = f->units[u];
       const int k = un.kind;
       if (p0[k] < 0) { p0[k] = un.p_lo; wj0[k] = un.wj_lo; rw0[k] = un.row_lo; }
       p1[k] = un.p_hi; wj1[k] = un.wj_hi; rw1[k] = un.row_hi;
+      if (un.p2_lo >= 0) { if (p0[2] < 0) p0[2] = un.p2_lo; p1[2] = un.p2_hi; }
     }
     for (int kind = 0; kind < 2; ++kind) {
       if (p0[kind] < 0) continue;
@@ -1067,7 +1127,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       if (r) return r;
     }
     if (ready)
-      for (int kind = 0; kind < 2; ++kind)
+      for (int kind = 0; kind < 3; ++kind)
         if (p0[kind] >= 0 && p1[kind] > p0[kind]) ready(user, piece, p0[kind], p1[kind]);
     return IPOKE_OK;
   };
@@ -1164,7 +1224,15 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     for (const Ctx& l : lanes) {
       const float* gin = l.rowsf(goff[cur], l.ld); float* gout = l.rowsf(goff[cur ^ 1], l.ld);
       const float* xin = l.state(i);                 // saved input of op i
-      if (op.type == OP_ACTNORM) {
+      if (op.type == OP_LU) {
+        // dx = dy W (W^T applied per position); parameter gradients straight into the flat buffer (the forward pass of
+        // this step left [W | W^-1 | wl | wu] in the workspace)
+        rc = ipoke_lu_apply(gin, gout, l.B, l.ld, op.C, lu_mat(l, op, 0), 1, l.stream()); if (rc) return rc;
+        rc = ipoke_lu_wgrad(gin, xin, l.B, f->P, l.ld, params, f->fbuf, l.at<float>(l.plan.lu),
+                            reinterpret_cast<const unsigned char*>(f->d_lujobs) + (size_t)op.lu_idx * sizeof(LuJobH), l.dld(), grads,
+                            l.stream());
+        if (rc) return rc;
+      } else if (op.type == OP_ACTNORM) {
         rc = ipoke_actnorm_bwd(gin, xin, gout, (int)l.M, l.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
                                op.idx_fwd >= 0 ? perm + op.idx_fwd : nullptr, l.dld(), l.B, f->P, l.dbp(i, 2 * op.Cn), l.stream());
         if (rc) return rc;

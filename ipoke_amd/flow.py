@@ -24,14 +24,14 @@ import torch.nn as nn
 from . import _lib
 from ._lib import check, ptr
 
-TK_PARAM, TK_IDX_FWD, TK_IDX_BWD, TK_FLAG = 0, 1, 2, 3
+TK_PARAM, TK_IDX_FWD, TK_IDX_BWD, TK_FLAG, TK_FBUF = 0, 1, 2, 3, 4
 
 
 class FlowEngine:
     """Owner of the native handle and of the flat device buffers."""
 
     def __init__(self, arch, dtype="bf16", max_batch=64, device=None):
-        for key in ("attention", "condition_nice", "cond_conv", "use1x1", "multistack", "augmented_input"):
+        for key in ("attention", "condition_nice", "cond_conv", "multistack", "augmented_input"):
             if arch.get(key, False):
                 raise NotImplementedError(f"architecture option {key}=True is outside the shipped iPOKE configs")
         if float(arch.get("p_dropout", 0.0)) > 0.0:
@@ -57,6 +57,7 @@ class FlowEngine:
         cfg.kernel_h, cfg.kernel_w = int(arch["kernel_size"][0]), int(arch["kernel_size"][1])
         cfg.dtype = self.dtype
         cfg.max_batch = int(max_batch)
+        cfg.use1x1 = int(bool(arch.get("use1x1", False)))
         self.cfg = cfg
         self.z, self.cond_channels, self.max_batch = cfg.z_channels, cfg.cond_channels, cfg.max_batch
         h = c_void_p()
@@ -64,6 +65,7 @@ class FlowEngine:
         self.handle = h
         self.n_params = self.lib.ipoke_flow_param_count(h)
         self.n_perm = self.lib.ipoke_flow_index_count(h)
+        self.n_fbuf = self.lib.ipoke_flow_float_buffer_count(h)
         self.n_ops = self.lib.ipoke_flow_op_count(h)
         self.tensors = self._tensor_table()
         self.device = torch.device(device) if device is not None else (
@@ -71,6 +73,10 @@ class FlowEngine:
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
         self.grads = None
         self.perm = torch.zeros(max(self.n_perm, 1), dtype=torch.int32, device=self.device)
+        # float buffers of the state dict (use1x1: the LU convs' permutated / sign_s / masks), read in place by the engine
+        self.fbuf = torch.zeros(max(self.n_fbuf, 1), dtype=torch.float32, device=self.device)
+        if self.n_fbuf > 0 and self.device.type == "cuda":
+            check(self.lib.ipoke_flow_set_float_buffers(h, ptr(self.fbuf)))
         self.shadow = None
         self._ws = {}
         self._io = {}
@@ -297,6 +303,11 @@ class SupervisedMacowTransformer(nn.Module):
             elif kind in (TK_IDX_FWD, TK_IDX_BWD):
                 parent.register_buffer(leaf, torch.arange(shape[0], dtype=torch.int64, device=eng.device))
                 self._idx_names.append((name, off, shape[0]))
+            elif kind == TK_FBUF:                  # float buffers are views of the engine's table, like the parameters
+                n = 1
+                for s_ in shape:
+                    n *= s_
+                parent.register_buffer(leaf, eng.fbuf[off:off + n].view(shape))
             else:
                 parent.register_buffer(leaf, torch.tensor(0, dtype=torch.uint8, device=eng.device))
                 self._flag_names.append(name)
@@ -341,8 +352,8 @@ class SupervisedMacowTransformer(nn.Module):
                     t.zero_()
                 elif leaf == "weight_v":
                     t.normal_(0.0, 0.05)
-                elif leaf == "weight_g":
-                    pass                                   # set from ||v|| below
+                elif leaf == "weight_g" or leaf in ("l", "u", "log_s"):
+                    pass                                   # set from ||v|| / by _reset_lu below
                 else:                                      # plain conv weights: kaiming_uniform(a=sqrt(5))
                     fan_in = shape[1] * shape[2] * shape[3]
                     bound = 1.0 / fan_in ** 0.5
@@ -351,6 +362,7 @@ class SupervisedMacowTransformer(nn.Module):
                 t.copy_(torch.randperm(shape[0]).to(t.device))
             elif kind == TK_FLAG:
                 t.zero_()
+        self._reset_lu()
         for name, (kind, off, shape) in self._views.items():
             if kind == TK_PARAM and name.endswith("weight_g"):
                 v = self.named_tensor(name[:-1] + "v")
@@ -359,6 +371,26 @@ class SupervisedMacowTransformer(nn.Module):
                 fwd = self.named_tensor(name.replace("backward_shuffle_idx", "forward_shuffle_idx"))
                 self.named_tensor(name).copy_(torch.argsort(fwd))
         self.sync_buffers()
+
+    @torch.no_grad()
+    def _reset_lu(self):
+        """InvertibleConvLU1d.__init__ (macow2.py:597-621): LU decomposition of a random rotation."""
+        mods = sorted({n.rsplit(".", 1)[0] for n, (kind, _, _) in self._views.items() if kind == TK_FBUF})
+        if not mods:
+            return
+        import numpy as np
+        import scipy.linalg as alg
+        for m in mods:
+            nf = self._views[m + ".log_s"][2][0]
+            w_init = np.linalg.qr(np.random.randn(nf, nf))[0].astype(np.float32)
+            p, l, u = alg.lu(w_init)
+            s = np.diag(u)
+            lmask = np.tril(np.ones_like(w_init), -1)
+            vals = {"permutated": p, "sign_s": np.sign(s), "lmask": lmask, "umask": lmask.T, "eye": np.eye(nf, dtype=np.float32),
+                    "l": l, "u": np.triu(u, k=1), "log_s": np.log(np.abs(s))}
+            for leaf, v in vals.items():
+                t_ = self.named_tensor(m + "." + leaf)
+                t_.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(t_.device).view(t_.shape))
 
     def sync_buffers(self):
         """Mirror the int64 shuffle buffers / uint8 flags of the state dict into the engine (after loading)."""

@@ -111,6 +111,16 @@ class PokeMotionModel(nn.Module):
         sd = torch.load(path_or_sd, map_location="cpu") if isinstance(path_or_sd, str) else path_or_sd
         return sd["state_dict"] if "state_dict" in sd else sd
 
+    def load_checkpoint(self, ckpt, strict=False):
+        """Counterpart of ``SecondStageVideoModel``'s ``load_from_checkpoint(..., strict=False)`` (experiments/
+        second_stage_video.py:22, experiments/experiment.py:107-143): a Lightning ``.ckpt`` (path or loaded dict) whose
+        ``state_dict`` holds ``flow.flow.*`` (weight_g / weight_v, int64 shuffle indices, uint8 ``initialized`` flags),
+        ``first_stage_model.*`` (spectral-norm ``weight_orig / weight_u / weight_v``), ``poke_embedder.*``, ``conditioner.*``."""
+        res = self.load_state_dict(self._sd(ckpt), strict=strict)
+        self.flow.sync_buffers()
+        self.first_stage_model.enc_motion.conv1.invalidate()
+        return res
+
     def load_first_stage(self, ckpt):
         self.first_stage_model.load_state_dict(self._sd(ckpt), strict=False)
         self.first_stage_model.enc_motion.conv1.invalidate()

@@ -82,6 +82,46 @@ class Shuffle(nn.Module):
         return x[:, self.forward_shuffle_idx], 0
 
 
+class InvertibleConvLU1d(nn.Module):
+    """LU-parametrised invertible 1x1 convolution.  Reference macow2.py:596-649 (selected by ``use1x1`` for the per-level
+    ``shuffle_layers`` only: MultiScaleInternal :862; the priors' and steps' conv1x1 stay Shuffles, :551 is never passed
+    use_1x1 and :1017 is hard-wired).  W = P (L * lmask + I) (U * umask + diag(sign_s exp(log_s))); log-det = H W sum(log_s);
+    the inverse multiplies the three matrix inverses (torch.inverse in the reference)."""
+
+    def __init__(self, nf):
+        super().__init__()
+        import numpy as np
+        import scipy.linalg as alg
+        self.nf = nf
+        w_init = np.linalg.qr(np.random.randn(nf, nf))[0].astype(np.float32)
+        p, l, u = alg.lu(w_init)
+        s = np.diag(u)
+        u = np.triu(u, k=1)
+        lmask = np.tril(np.ones_like(w_init), -1)
+        self.register_buffer("permutated", torch.FloatTensor(p))
+        self.register_buffer("sign_s", torch.FloatTensor(np.sign(s)))
+        self.register_buffer("lmask", torch.FloatTensor(lmask))
+        self.register_buffer("umask", torch.FloatTensor(lmask.T.copy()))
+        self.register_buffer("eye", torch.FloatTensor(np.eye(nf)))
+        self.l = nn.Parameter(torch.FloatTensor(l))
+        self.u = nn.Parameter(torch.FloatTensor(u))
+        self.log_s = nn.Parameter(torch.FloatTensor(np.log(np.abs(s))))
+
+    def matrices(self):
+        wl = self.l * self.lmask + self.eye
+        wu = self.u * self.umask + torch.diag(self.sign_s * torch.exp(self.log_s))
+        return wl, wu
+
+    def forward(self, x, reverse=False):
+        wl, wu = self.matrices()
+        if not reverse:
+            w = self.permutated @ (wl @ wu)
+            logdet = self.log_s.sum() * x.shape[2] * x.shape[3] * torch.ones(x.shape[0])
+            return torch.einsum("ij,bjhw->bihw", w, x), logdet
+        w = torch.inverse(wu) @ (torch.inverse(wl) @ torch.inverse(self.permutated))
+        return torch.einsum("ij,bjhw->bihw", w, x)
+
+
 def affine_params(raw):
     """(mu, scale) from the coupling net output; reference macow_utils.py:49-52 (alpha = 1)."""
     mu, s = raw.chunk(2, dim=1)
@@ -397,7 +437,7 @@ class MultiScalePrior(nn.Module):
 class MultiScaleInternal(nn.Module):
     """Level loop with channel split-off.  Reference macow2.py:821-920."""
 
-    def __init__(self, num_steps, channels, hidden, h_channels, factor, kernel_size):
+    def __init__(self, num_steps, channels, hidden, h_channels, factor, kernel_size, use_1x1=False):
         super().__init__()
         self.reshape = "none"
         self.layers = nn.ModuleList()
@@ -407,7 +447,7 @@ class MultiScaleInternal(nn.Module):
         for n in num_steps:
             self.layers.append(nn.ModuleList([MaCowStep(channels, kernel_size, hidden, h_channels) for _ in range(n)]))
             self.priors.append(MultiScalePrior(channels, hidden, factor))
-            self.shuffle_layers.append(Shuffle(channels))
+            self.shuffle_layers.append(InvertibleConvLU1d(channels) if use_1x1 else Shuffle(channels))   # macow2.py:862
             channels -= step
             factor -= 1
         self.z_channels = channels
@@ -422,7 +462,8 @@ class MultiScaleInternal(nn.Module):
                     logdet = logdet + ld
                 x, ld = prior(x, h=h)
                 logdet = logdet + ld
-                x, _ = shuffle(x)
+                x, ld = shuffle(x)
+                logdet = logdet + ld                      # integer 0 for a Shuffle (flow_blocks.py:324)
                 outs.append(x[:, prior.z1_channels:])
                 x = x[:, :prior.z1_channels]
             outs.append(x)
@@ -446,13 +487,14 @@ class SupervisedMacowTransformer(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        for unsupported in ("attention", "condition_nice", "cond_conv", "use1x1"):
+        for unsupported in ("attention", "condition_nice", "cond_conv"):
             if config.get(unsupported, False):
                 raise NotImplementedError(f"oracle covers shipped configs only ({unsupported}=True is not one)")
         assert config["transform"] == "affine" and config["prior_transform"] == "affine"
         assert config["activation"] == "elu" and config["coupling_type"] == "conv"
         self.flow = MultiScaleInternal(config["num_steps"], config["flow_in_channels"], config["flow_mid_channels"],
-                                       config["h_channels"], config["factor"], tuple(config["kernel_size"]))
+                                       config["h_channels"], config["factor"], tuple(config["kernel_size"]),
+                                       use_1x1=bool(config.get("use1x1", False)))
 
     def forward(self, x, cond, reverse=False):
         if reverse:

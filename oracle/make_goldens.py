@@ -261,6 +261,40 @@ def g2_reduced_flow():
     npz("g2_reduced_flow_init", **arrs)
 
 
+def g2_lu_flow():
+    """G2-LU: the reduced full-topology flow with ``use1x1`` (LU-parametrised invertible 1x1 convolutions as the per-level
+    shuffle layers, macow2.py:596-649, 862): out, log-det, reverse, every parameter gradient.  The LU buffers / parameters come
+    from the reference constructor's numpy draws (seeded) and are stored; everything else is the name-keyed fill."""
+    INN = ref_import.ref("models.modules.INN.INN")
+    loss_m = ref_import.ref("models.modules.INN.loss")
+    arch = configs.reduced_flow_arch(); arch["use1x1"] = True
+    np.random.seed(11)
+    R = INN.SupervisedMacowTransformer(copy.deepcopy(arch))
+    lu_state = {k: v.clone() for k, v in R.state_dict().items() if ".shuffle_layers." in k}
+    np.random.seed(12)
+    O = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch))
+    assert list(R.state_dict()) == list(O.state_dict()), "state-dict keys/order differ from the reference (use1x1)"
+    deterministic_fill_(R, prefix="flow."); deterministic_fill_(O, prefix="flow.")
+    R.load_state_dict(lu_state, strict=False); O.load_state_dict(lu_state, strict=False)
+    x, cond = rn((3, 16, 8, 8), 13), rn((3, 128, 8, 8), 14)
+    out, logdet, loss, log = _loss_and_grads(R, loss_m.FlowLoss(), x, cond, 1234)
+    oo, ol, oloss, olog = _loss_and_grads(O, flow_ref.FlowLoss(), x, cond, 1234)
+    close(oo, out, 2e-5, "G2-LU out"); close(ol, logdet, 1e-3, "G2-LU logdet"); close(oloss, loss, 1e-3, "G2-LU loss")
+    rev = R(out.detach(), cond, reverse=True)
+    close(O(oo.detach(), cond, reverse=True), rev, 5e-5, "G2-LU reverse")
+    arrs = dict(x=x, cond=cond, out=out, logdet=logdet, loss=loss, reverse=rev, roundtrip_err=(rev - x).abs().max())
+    for k, v in lu_state.items():
+        arrs["lu." + k] = v
+    worst = 0.0
+    for (k, p_), (k2, q) in zip(R.named_parameters(), O.named_parameters()):
+        assert k == k2
+        arrs["grad." + k] = p_.grad
+        worst = max(worst, (p_.grad - q.grad).abs().max().item() / (p_.grad.abs().max().item() + 1e-12))
+    assert worst < 1e-4, worst
+    print(f"  G2-LU oracle-vs-reference worst relative grad error {worst:.2e}")
+    npz("g2_reduced_flow_lu", **arrs)
+
+
 # ---------------------------------------------------------------------------
 def g3_full_flow(z_dim=32):
     """G3: full-size flow (1.05 B parameters): activations, log-det, loss, per-parameter gradient checksums."""
@@ -615,7 +649,7 @@ def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
-            "g2": g2_reduced_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
+            "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
             "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128}
     for name in (which or list(jobs)):
         print(f"[{name}]")

@@ -82,10 +82,12 @@ def test_full_size_topology_matches_reference_census(z, expected_params):
     assert "flow.priors.14.actnorm.bias" in dict(names) and "flow.shuffle_layers.14.backward_shuffle_idx" in dict(names)
 
 
-def test_reduced_topology_keys_equal_oracle_state_dict():
+@pytest.mark.parametrize("use1x1", [False, True])
+def test_reduced_topology_keys_equal_oracle_state_dict(use1x1):
     from ipoke_amd.flow import SupervisedMacowTransformer
     from oracle import flow_ref
     arch = configs.reduced_flow_arch()
+    arch["use1x1"] = use1x1       # LU-parametrised 1x1 convs as shuffle layers: l, u, log_s + five float buffers per level
     m = SupervisedMacowTransformer(arch, dtype="f32", device="cpu")
     o = flow_ref.SupervisedMacowTransformer(arch)
     sa, sb = m.state_dict(), o.state_dict()
@@ -94,6 +96,18 @@ def test_reduced_topology_keys_equal_oracle_state_dict():
         assert tuple(sa[k].shape) == tuple(sb[k].shape) and sa[k].dtype == sb[k].dtype, k
     m.load_state_dict(sb)                                    # reference-keyed checkpoint loads, buffers are mirrored
     assert torch.equal(m.engine.perm[:16].long(), o.flow.layers[0][0].conv1x1.forward_shuffle_idx)
+    if use1x1:                                               # float buffers are views of the engine's table
+        lu = o.flow.shuffle_layers[0]
+        assert torch.equal(m.state_dict()["flow.shuffle_layers.0.permutated"], lu.permutated)
+        off = dict((n, o_) for n, o_, _, _ in m.engine.tensors)["flow.shuffle_layers.0.permutated"]
+        assert torch.equal(m.engine.fbuf[off:off + 256].view(16, 16), lu.permutated)
+        # the host mirror's own initialiser produces a valid decomposition: P (L*lmask+I) (U*umask+diag(s)) is orthogonal
+        m2 = SupervisedMacowTransformer(arch, dtype="f32", device="cpu")
+        sd = m2.state_dict(); pre = "flow.shuffle_layers.0."
+        wl = sd[pre + "l"] * sd[pre + "lmask"] + sd[pre + "eye"]
+        wu = sd[pre + "u"] * sd[pre + "umask"] + torch.diag(sd[pre + "sign_s"] * sd[pre + "log_s"].exp())
+        w = sd[pre + "permutated"] @ wl @ wu
+        assert (w @ w.t() - torch.eye(16)).abs().max() <= 1e-4
     assert m.flow.reshape == "none"
     with pytest.raises(RuntimeError):                        # no CPU fallback: compute needs the GPU
         m(torch.zeros(1, 16, 8, 8), torch.zeros(1, 128, 8, 8))

@@ -65,6 +65,42 @@ def test_reduced_flow_gradients(golden, dtype):
     assert worst <= TOL[dtype]["grad"]
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_reduced_flow_with_lu_1x1_convs(golden, dtype):
+    """use1x1: the per-level shuffle layers are LU-parametrised invertible 1x1 convolutions (macow2.py:596-649, 862) --
+    forward, log-det, reverse and every parameter gradient (incl. l, u, log_s) against the reference (G2-LU)."""
+    g = golden("g2_reduced_flow_lu")
+    arch = configs.reduced_flow_arch(); arch["use1x1"] = True
+    from ipoke_amd.flow import SupervisedMacowTransformer
+    m = SupervisedMacowTransformer(copy.deepcopy(arch), dtype=dtype, device="cuda", init="none")
+    deterministic_fill_(m, prefix="flow.")
+    m.load_state_dict({k[3:]: t(v) for k, v in g.items() if k.startswith("lu.")}, strict=False)
+    m.sync_buffers()
+    m.train()
+    x, cond = t(g["x"], "cuda"), t(g["cond"], "cuda")
+    out, logdet = m(x, cond)
+    tol = TOL[dtype]
+    e_out = (out.detach().cpu() - t(g["out"])).abs().max().item()
+    e_ld = (logdet.detach().cpu() - t(g["logdet"])).abs().max().item()
+    print(f"[{dtype}] LU flow: out err {e_out:.3e}, logdet err {e_ld:.3e}")
+    assert e_out <= tol["out"] and e_ld <= tol["logdet"]
+    loss = (0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()
+    loss.backward()
+    worst, worst_key = 0.0, None
+    for name, p in m.named_parameters():
+        ref = t(g["grad." + name])
+        err = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-6)
+        if err > worst:
+            worst, worst_key = err, name
+    print(f"[{dtype}] LU flow: worst relative grad error {worst:.3e} at {worst_key}")
+    assert worst <= tol["grad"]
+    with torch.no_grad():
+        rev = m(t(g["out"], "cuda"), cond, reverse=True)
+    e_rev = (rev.cpu() - t(g["reverse"])).abs().max().item()
+    print(f"[{dtype}] LU flow: reverse err {e_rev:.3e}")
+    assert e_rev <= tol["rev"]
+
+
 def test_reduced_flow_data_init(golden):
     """First forward with initialized == 0 (data-dependent ActNorm init, zero-init couplings)."""
     g = golden("g2_reduced_flow_init")

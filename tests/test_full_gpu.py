@@ -128,3 +128,48 @@ def test_encoder_prefetch_does_not_change_training():
     l1, p1 = run(True)
     assert all(abs(a - b) <= 2e-5 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
     assert (p0 - p1).abs().max().item() <= 2e-5 * p0.abs().max().item()
+
+
+def test_lightning_checkpoint_loads_and_reproduces_the_oracle(tmp_path):
+    """f4: a Lightning-layout ``.ckpt`` written from the oracle's modules (reference state-dict keys: ``flow.flow.*`` with
+    weight_g / weight_v, int64 shuffle indices, uint8 ``initialized`` flags; ``first_stage_model.*`` with spectral-norm
+    ``weight_orig / weight_u / weight_v``; ``poke_embedder.*``, ``conditioner.*``) loads through
+    ``PokeMotionModel.load_checkpoint`` and reproduces the oracle's forward_density on the same batch."""
+    from ipoke_amd.second_stage import PokeMotionModel
+    from oracle import flow_ref, vae_ref
+    from tests.helpers import synthetic_batch
+    arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+    arch["flow_mid_channels_factor"] = 2
+    conf = configs.second_stage_config(64, 32, 16, batch_size=2, arch=arch)
+    ofs = vae_ref.SpadeCondMotionModel(copy.deepcopy(conf["first_stage"])).eval()
+    ope = vae_ref.FirstStageWrapper(copy.deepcopy(conf["poke_embedder"])).eval()
+    oce = vae_ref.FirstStageWrapper(copy.deepcopy(conf["conditioner_model"])).eval()
+    oarch = copy.deepcopy(arch); oarch.update(flow_in_channels=32, h_channels=128, flow_mid_channels=64)
+    oflow = flow_ref.SupervisedMacowTransformer(oarch)
+    sd = {}
+    for prefix, mod in (("first_stage_model.", ofs), ("poke_embedder.", ope), ("conditioner.", oce), ("flow.", oflow)):
+        deterministic_fill_(mod, prefix="ckpt." + prefix)
+        sd.update({prefix + k: v.clone() for k, v in mod.state_dict().items()})
+    assert any(v.dtype == torch.int64 for v in sd.values()) and any(v.dtype == torch.uint8 for v in sd.values())
+    assert any(k.endswith("weight_orig") for k in sd) and any(k.endswith("weight_g") for k in sd)
+    path = str(tmp_path / "last.ckpt")
+    torch.save({"state_dict": sd, "epoch": 3, "global_step": 1234, "pytorch-lightning_version": "1.1.0",
+                "optimizer_states": [], "lr_schedulers": []}, path)
+    m = PokeMotionModel(conf, dirs={}, dtype="f32", device="cuda", max_batch=2)
+    res = m.load_checkpoint(path)
+    assert not res.missing_keys and not res.unexpected_keys
+    batch = synthetic_batch(2, 16, 64, device="cuda")
+    torch.manual_seed(5)
+    out, logdet = m.forward_density(batch)
+    torch.manual_seed(5)
+    eps = torch.FloatTensor(2, 32, 8, 8).normal_()
+    cpu = synthetic_batch(2, 16, 64)
+    with torch.no_grad():
+        poke_emb, *_ = ope.encoder(cpu["flow"])
+        cond, *_ = oce.encoder(cpu["images"][:, 0])
+        z, mu, _ = ofs.enc_motion(cpu["images"].transpose(1, 2), eps=eps)
+        o_out, o_ld = oflow(z, torch.cat([cond, poke_emb], 1))
+    e_out = (out.detach().cpu() - o_out).abs().max().item()
+    e_ld = (logdet.detach().cpu() - o_ld).abs().max().item()
+    print(f"ckpt round trip: out err {e_out:.3e} logdet err {e_ld:.3e}")
+    assert e_out <= 2e-4 and e_ld <= 2e-2

@@ -92,6 +92,32 @@ def test_reduced_flow_full_topology(golden):
         assert (p.grad - ref).abs().max() <= 1e-4 * (ref.abs().max() + 1e-6), k
 
 
+def test_lu_conv_unit_and_flow(golden):
+    """InvertibleConvLU1d (macow2.py:596-649): the reference's unit golden, and the reduced flow with use1x1 (G2-LU)."""
+    g = golden("g1_flow_units")
+    lu = flow_ref.InvertibleConvLU1d(8)
+    with torch.no_grad():
+        for k in ("permutated", "sign_s", "l", "u", "log_s"):
+            getattr(lu, k).copy_(t(g["lu_8_" + k]))
+    x = t(g["x_8"])
+    y, ld = lu(x)
+    assert (y - t(g["lu_8_y"])).abs().max() <= 1e-6 and (ld - t(g["lu_8_logdet"])).abs().max() <= 1e-5
+    assert (lu(y, reverse=True) - t(g["lu_8_inv"])).abs().max() <= 1e-5
+    g = golden("g2_reduced_flow_lu")
+    arch = configs.reduced_flow_arch(); arch["use1x1"] = True
+    o = flow_ref.SupervisedMacowTransformer(arch)
+    deterministic_fill_(o, prefix="flow.")
+    o.load_state_dict({k[3:]: t(v) for k, v in g.items() if k.startswith("lu.")}, strict=False)
+    x, cond = t(g["x"]), t(g["cond"])
+    out, logdet = o(x, cond)
+    assert (out - t(g["out"])).abs().max() <= 2e-5 and (logdet - t(g["logdet"])).abs().max() <= 1e-3
+    assert (o(out.detach(), cond, reverse=True) - t(g["reverse"])).abs().max() <= 5e-5
+    (0.5 * (out ** 2).sum(dim=[1, 2, 3]).mean() - logdet.mean()).backward()
+    for k, p in o.named_parameters():
+        ref = t(g["grad." + k])
+        assert (p.grad - ref).abs().max() <= 1e-4 * (ref.abs().max() + 1e-6), k
+
+
 def test_identity_at_init_and_data_init(golden):
     """Known answers: after the initialising forward every coupling is the identity; logdet = 64 * sum log_scale."""
     g = golden("g2_reduced_flow_init")
