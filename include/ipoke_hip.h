@@ -218,6 +218,9 @@ int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream);
 int ipoke_macow_unit_supported(int C, int Cc, int dtype);
 int ipoke_macow_unit_fwd(const ipoke_mcf_desc* d4, int dtype, void* stream);
 int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* stream);
+/*   inverse : d4[3].x = the unit's OUTPUT state, d4[0].y = the reconstructed input (distinct buffers); W1 / W2 / bias2 /
+ *             post_* per layer as for the forward call; two samples per workgroup, the 4 x 8 strips of macow2.py:174-288 */
+int ipoke_macow_unit_inv(const ipoke_mcf_desc* d4, int dtype, void* stream);
 
 /* multi-tensor weight preparation (job tables are built by the flow engine) */
 int ipoke_relayout_job_size(void);
@@ -296,6 +299,10 @@ int ipoke_flow_tensor_info(const ipoke_flow* f, int i, char* name, int name_cap,
                            int64_t* shape4, int32_t* kind);
 /* float buffers of the state dict (use1x1 only): element count of the table, and the caller-owned device copy the layer
  * program reads (must be set before forward / reverse / backward when the count is non-zero) */
+/* hipGraph mode: the layer program of forward / reverse / one-shot backward is captured on the second call with a given
+ * set of pointer arguments and replayed afterwards (IPOKE_GRAPH=1 sets the initial state; default off: on ROCm 7.2 the replay
+ * of the ~1 000-node programs is 1-2 % slower than the eager launches, whose host cost is hidden behind the GPU anyway) */
+int ipoke_flow_set_graph(ipoke_flow* f, int enable);
 int64_t ipoke_flow_float_buffer_count(const ipoke_flow* f);
 int ipoke_flow_set_float_buffers(ipoke_flow* f, const float* fbuf_dev);
 int64_t ipoke_flow_shadow_bytes(const ipoke_flow* f);

@@ -120,6 +120,7 @@ SIGNATURES = {
     "ipoke_macow_unit_supported": (c_int, [c_int, c_int, c_int]),
     "ipoke_macow_unit_fwd": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_macow_unit_bwd": (c_int, [POINTER(McfDesc), c_int, _P]),
+    "ipoke_macow_unit_inv": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_relayout_job_size": (c_int, []),
     "ipoke_wn_job_size": (c_int, []),
     "ipoke_relayout_multi": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_int, _P]),
@@ -161,6 +162,7 @@ SIGNATURES = {
     "ipoke_flow_tensor_info": (c_int, [_P, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32)]),
     "ipoke_flow_shadow_bytes": (c_int64, [_P]),
+    "ipoke_flow_set_graph": (c_int, [_P, c_int]),
     "ipoke_flow_float_buffer_count": (c_int64, [_P]),
     "ipoke_flow_set_float_buffers": (c_int, [_P, _P]),
     "ipoke_lu_job_size": (c_int, []),

@@ -662,6 +662,12 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
 
 extern "C" int64_t ipoke_flow_param_count(const ipoke_flow* f) { return f ? f->n_params : -1; }
 extern "C" int64_t ipoke_flow_index_count(const ipoke_flow* f) { return f ? f->n_perm : -1; }
+/* replay the layer programs (forward / reverse / one-shot backward) as captured hipGraphs (1) or launch them eagerly (0) */
+extern "C" int ipoke_flow_set_graph(ipoke_flow* f, int enable) {
+  IPK_REQUIRE(f != nullptr, "null flow handle");
+  f->use_graph = enable != 0;
+  return IPOKE_OK;
+}
 extern "C" int64_t ipoke_flow_float_buffer_count(const ipoke_flow* f) { return f ? f->n_fbuf : -1; }
 extern "C" int ipoke_flow_set_float_buffers(ipoke_flow* f, const float* fbuf_dev) {
   IPK_REQUIRE(f != nullptr, "null flow handle");
@@ -979,6 +985,24 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
   int cur = 0;
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
     const Op& op = f->ops[i];
+    if (op.unit_of >= 0 && i == op.unit_of + 5) {     // whole MaCowUnit (ops h .. h+5) inverted by one launch
+      const int h = op.unit_of;
+      static const int lidx[4] = {0, 1, 3, 4};
+      for (const Ctx& l : lanes) {
+        ipoke_mcf_desc d4[4];
+        for (int k = 0; k < 4; ++k) {
+          const Op& mk = f->ops[h + lidx[k]];
+          mcf_desc(l, mk, d4[k]);
+          if (mk.fuse_act >= 0) { d4[k].post_log_scale = params + f->ops[mk.fuse_act].p_ls; d4[k].post_bias = params + f->ops[mk.fuse_act].p_bias; }
+        }
+        d4[3].x = l.state(cur); d4[0].y = l.state(cur ^ 1);
+        d4[0].x = d4[3].x; d4[3].y = d4[0].y;          // (the shared validator wants input / output on the first / last layer)
+        rc = ipoke_macow_unit_inv(d4, l.dtype, l.stream()); if (rc) return rc;
+      }
+      cur ^= 1;
+      i = h;
+      continue;
+    }
     for (const Ctx& l : lanes) {
       const float* in = l.state(cur); float* out = l.state(cur ^ 1);
       if (op.type == OP_LU) {

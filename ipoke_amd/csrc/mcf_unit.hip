@@ -685,6 +685,185 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
   }
 }
 
+// ------------------------------------------------------------------------------------------------ inverse (sampling)
+// x = unit^-1(y): ActNorm2^-1, D^-1, C^-1, ActNorm1^-1, B^-1, A^-1 in one launch, two samples per workgroup (a strip of 8
+// positions per sample fills one 16-row matrix-core tile, as in mcf_inv_kernel).  A masked conv flow is inverted strip by
+// strip (8 rows / columns, macow2.py:174-288): the conditioner of a strip only sees strips already reconstructed.  The
+// state stays in LDS for the 4 x 8 strips; the weight fragments of the next layer are requested while the last strip of the
+// current one is being processed.
+template <typename T, bool WIDE>
+__global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitParams U) {
+  constexpr int KS = K64<T>::value, E16 = ET<T>::E16, J1 = UC<WIDE>::J1;
+  typedef typename ET<T>::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * 2, nb = min(2, U.B - b0);
+  const int C = U.C, N2 = 2 * C, ld = U.ld, H = U.H;
+  constexpr int K2c = UC<WIDE>::N2S * 32;
+  const int xs_pitch = U.Cp * (int)sizeof(T) + 16;
+  constexpr int a2_pitch = K2c * (int)sizeof(T) + 16;
+  const int prm_ld = N2 + 4;
+  unsigned char* xs = smem;                                        // T [2][64 + zero row][Cp]: reconstructed inputs (operand copy)
+  unsigned char* a2 = xs + 2 * 65 * xs_pitch;                      // T [16][K2c]
+  unsigned char* cs = a2 + 16 * a2_pitch;                          // T [2][64][Cc]: ELU(cond) of the two samples
+  float* prm = reinterpret_cast<float*>(cs + 2 * 64 * U.Cc * (int)sizeof(T));     // [16][2C (+4)]
+  float* yf = prm + 16 * prm_ld;                                   // [2][64][C] fp32 state: y on entry of a layer, x on exit
+  float* bias_s = yf + 2 * 64 * C;                                 // [4][2C]
+  float* post_s = bias_s + 4 * N2;                                 // [4][2][C]: exp(log_scale) + 1e-8, bias of the ActNorms
+  const long row0 = (long)b0 * 64;
+  const int G2 = C >> 1;
+  const int rows = nb * 64;
+
+  // prologue: small loads first (results return in issue order), then the weights of layer D
+  f32x2 yin[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + i * kMcfThreads;
+    const int p = e / G2, c = (e - p * G2) * 2;
+    if (e < rows * G2) yin[i] = *reinterpret_cast<const f32x2*>(U.L[3].x + (row0 + p) * ld + c);
+  }
+  float bias_v = 0.f, post_e = 0.f, post_b = 0.f;
+  if (tid < 4 * N2) bias_v = U.L[tid / N2].bias2[tid % N2];
+  if (tid < 4 * C) {
+    const UnitLayer& Lq = U.L[tid / C];
+    if (Lq.post_ls) { post_e = Lq.post_ls[tid % C]; post_b = Lq.post_bias[tid % C]; }
+  }
+  McfW<T> wr;
+  unit_load_w1<T, WIDE>(wr, U.L[3].W1, U);
+  unit_load_w2<T, WIDE>(wr, U.L[3].W2, U);
+  for (int i = tid; i < (2 * 65 * xs_pitch + 16 * a2_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  {   // ELU(cond) rows of both samples
+    const int cchunks = U.Cc / E16;
+    const T* condp = reinterpret_cast<const T*>(U.cond) + row0 * U.Cc;
+    for (int e = tid; e < rows * cchunks; e += kMcfThreads)
+      *reinterpret_cast<u32x4*>(cs + (long)e * 16) = *reinterpret_cast<const u32x4*>(condp + (long)e * E16);
+  }
+  if (ld > C) {                                     // pass-through channels
+    const int R2 = (ld - C) >> 1;
+    for (int e = tid; e < rows * R2; e += kMcfThreads) {
+      const int p = e / R2, c = C + (e - p * R2) * 2;
+      *reinterpret_cast<f32x2*>(U.L[0].y + (row0 + p) * ld + c) = *reinterpret_cast<const f32x2*>(U.L[3].x + (row0 + p) * ld + c);
+    }
+  }
+  if (tid < 4 * N2) bias_s[tid] = bias_v;
+  if (tid < 4 * C) {
+    const UnitLayer& Lq = U.L[tid / C];
+    post_s[(tid / C) * 2 * C + tid % C] = Lq.post_ls ? __expf(post_e) + 1e-8f : 1.f;      // macow2.py:520
+    post_s[(tid / C) * 2 * C + C + tid % C] = post_b;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + i * kMcfThreads;
+    const int p = e / G2, c = (e - p * G2) * 2;
+    if (e < rows * G2) *reinterpret_cast<f32x2*>(yf + p * C + c) = yin[i];
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 3; k >= 0; --k) {
+    const UnitLayer& Lk = U.L[k];
+    const McfGeom g = mcf_geom(Lk.order);
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63, wave = tl >> 6, r = lane & 15, gq = lane >> 4;
+    if (Lk.post_ls) {                               // the ActNorm behind this layer, inverted first
+      const float* pe = post_s + k * 2 * C;
+      for (int e = tl; e < rows * G2; e += kMcfThreads) {
+        const int p = e / G2, c = (e - p * G2) * 2;
+        f32x2 v = *reinterpret_cast<const f32x2*>(yf + p * C + c);
+        v[0] = __fdividef(v[0] - pe[C + c], pe[c]); v[1] = __fdividef(v[1] - pe[C + c + 1], pe[c + 1]);
+        *reinterpret_cast<f32x2*>(yf + p * C + c) = v;
+      }
+      __syncthreads();
+    }
+    const bool rows_first = Lk.order < 2, backwards = (Lk.order & 1);
+    const float* bk = bias_s + k * N2;
+#pragma unroll 1
+    for (int step = 0; step < 8; ++step) {
+      const int si = backwards ? 7 - step : step;
+      // conditioning rows of the strip behind the hidden columns of the 16-row tile
+      {
+        const int cchunks = U.Cc / E16;
+        for (int e = tl; e < 16 * cchunks; e += kMcfThreads) {
+          const int row = e / cchunks, ch = e - row * cchunks;
+          const int sidx = row >> 3, j = row & 7;
+          const int pos = rows_first ? si * 8 + j : j * 8 + si;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (sidx < nb) v = *reinterpret_cast<const u32x4*>(cs + ((sidx * 64 + pos) * cchunks + ch) * 16);
+          *reinterpret_cast<u32x4*>(a2 + row * a2_pitch + (H + ch * E16) * (int)sizeof(T)) = v;
+        }
+      }
+      {   // hidden = ELU(shifted conv of the strips reconstructed so far)
+        const int sidx = r >> 3, j = r & 7;
+        const int pos = rows_first ? si * 8 + j : j * 8 + si;
+        const unsigned char* tile = xs + sidx * 65 * xs_pitch;
+        const unsigned char* zrow = tile + 64 * xs_pitch;
+        f32x4 acc[J1];
+#pragma unroll
+        for (int jj = 0; jj < J1; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 6; ++tap) {
+          const unsigned char* src = tap_src_fwd(tile, zrow, xs_pitch, g, pos, tap) + E16 * gq * (int)sizeof(T);
+#pragma unroll
+          for (int st = 0; st < UC<WIDE>::CS; ++st) {
+            const frag_t fa = *reinterpret_cast<const frag_t*>(src + st * KS * (int)sizeof(T));
+#pragma unroll
+            for (int jj = 0; jj < J1; ++jj) mma64(fa, wr.w1[tap][st][jj], acc[jj]);
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < J1; ++jj) {
+          const int n = (wave + kMcfWaves * jj) * 16 + 4 * gq;
+          if (n < H) {
+            typename Pack4<T>::type tv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tv[q] = ET<T>::from_f32(fast_elu(acc[jj][q]));
+            *reinterpret_cast<typename Pack4<T>::type*>(a2 + r * a2_pitch + n * (int)sizeof(T)) = tv;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (step == 7 && k > 0) unit_load_w1<T, WIDE>(wr, U.L[k - 1].W1, U);
+      __syncthreads();
+      {   // raw (mu, s) of the 16 rows
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < UC<WIDE>::N2S; ++st) {
+          const frag_t fa = *reinterpret_cast<const frag_t*>(a2 + r * a2_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
+          mma64(fa, wr.w2[st][0], acc);
+        }
+        const int n = wave * 16 + 4 * gq;
+        if (n < N2) *reinterpret_cast<f32x4*>(prm + r * prm_ld + n) = acc;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (step == 7 && k > 0) unit_load_w2<T, WIDE>(wr, U.L[k - 1].W2, U);
+      __syncthreads();
+      // x = (y - mu) / (scale + 1e-12)   (macow_utils.py:61-66); the strip joins the operand tile
+      for (int e = tl; e < 16 * G2; e += kMcfThreads) {
+        const int row = e / G2, c = (e - row * G2) * 2;
+        const int sidx = row >> 3, j = row & 7;
+        if (sidx < nb) {
+          const int pos = rows_first ? si * 8 + j : j * 8 + si;
+          const f32x2 mu = *reinterpret_cast<const f32x2*>(prm + row * prm_ld + c);
+          const f32x2 sv = *reinterpret_cast<const f32x2*>(prm + row * prm_ld + C + c);
+          const f32x2 yv = *reinterpret_cast<const f32x2*>(yf + (sidx * 64 + pos) * C + c);
+          f32x2 xv;
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            xv[q] = __fdividef(yv[q] - (mu[q] + bk[c + q]), fast_scale(sv[q] + bk[C + c + q]) + 1e-12f);
+          *reinterpret_cast<f32x2*>(yf + (sidx * 64 + pos) * C + c) = xv;
+          bf16x2 tv; tv[0] = ET<T>::from_f32(xv[0]); tv[1] = ET<T>::from_f32(xv[1]);
+          *reinterpret_cast<bf16x2*>(xs + (sidx * 65 + pos) * xs_pitch + c * (int)sizeof(T)) = tv;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < rows * G2; e += kMcfThreads) {
+    const int p = e / G2, c = (e - p * G2) * 2;
+    *reinterpret_cast<f32x2*>(U.L[0].y + (row0 + p) * ld + c) = *reinterpret_cast<const f32x2*>(yf + p * C + c);
+  }
+}
+
 static int unit_params(UnitParams& U, const ipoke_mcf_desc* d, int dtype, bool bwd) {
   IPK_REQUIRE(d, "null descriptor array");
   IPK_REQUIRE(dtype == IPOKE_BF16, "the fused MaCowUnit kernels take bf16 matrix-core inputs; f32 runs the per-layer kernels");
@@ -773,6 +952,27 @@ extern "C" int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* s
   } else {
     rc = ensure_lds<macow_unit_bwd_kernel<bf16_t, false>>(lds); if (rc) return rc;
     hipLaunchKernelGGL((macow_unit_bwd_kernel<bf16_t, false>), dim3(U.B), dim3(kMcfThreads), lds, s, U);
+  }
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* d4 in forward order; d4[3].x = the unit's OUTPUT state (input of the inverse), d4[0].y = the reconstructed unit input. */
+extern "C" int ipoke_macow_unit_inv(const ipoke_mcf_desc* d4, int dtype, void* stream) {
+  UnitParams U;
+  int rc = unit_params(U, d4, dtype, false); if (rc) return rc;
+  IPK_REQUIRE(U.L[3].x && U.L[0].y && U.L[3].x != U.L[0].y, "null / aliased state");
+  const bool wide = U.Cp > 32;
+  const size_t lds = (size_t)2 * 65 * (U.Cp * 2 + 16) + (size_t)16 * ((wide ? 384 : 256) * 2 + 16) + (size_t)2 * 64 * U.Cc * 2 +
+                     (size_t)16 * (2 * U.C + 4) * 4 + (size_t)2 * 64 * U.C * 4 + (size_t)(8 * U.C + 8 * U.C) * 4;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int grid = (U.B + 1) / 2;
+  if (wide) {
+    rc = ensure_lds<macow_unit_inv_kernel<bf16_t, true>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((macow_unit_inv_kernel<bf16_t, true>), dim3(grid), dim3(kMcfThreads), lds, s, U);
+  } else {
+    rc = ensure_lds<macow_unit_inv_kernel<bf16_t, false>>(lds); if (rc) return rc;
+    hipLaunchKernelGGL((macow_unit_inv_kernel<bf16_t, false>), dim3(grid), dim3(kMcfThreads), lds, s, U);
   }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;

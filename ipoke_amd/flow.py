@@ -413,6 +413,11 @@ class SupervisedMacowTransformer(nn.Module):
         for name, off, n in self._idx_names:
             self.named_tensor(name).copy_(perm[off:off + n])
 
+    def set_graph_mode(self, enable=True):
+        """Replay forward / reverse as captured hipGraphs (BASELINE configs[4]: "hipGraph-captured" sampling).  The first call
+        with a given batch size runs eagerly, the second captures, later ones replay; results are bit-identical."""
+        check(self.engine.lib.ipoke_flow_set_graph(self.engine.handle, int(bool(enable))))
+
     def mark_weights_updated(self):
         """Call after changing parameters outside of the fused optimizer (e.g. manual edits)."""
         self.engine.shadow_stale = True

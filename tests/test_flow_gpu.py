@@ -173,3 +173,24 @@ def test_backward_in_pieces_matches_and_covers_all_parameters():
     for region in (lambda b: b < prior0, lambda b: b >= prior0):
         starts = [b for b, _ in ranges if region(b)]
         assert starts and starts == sorted(starts, reverse=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_hipgraph_replay_is_bit_identical_to_eager(golden, dtype):
+    """configs[4] (sampling, "hipGraph-captured"): reverse and forward replayed from captured graphs give the same bits as
+    the eager launches (call 1 eager, call 2 captures, calls 3+ replay)."""
+    g = golden("g2_reduced_flow")
+    m = build(configs.reduced_flow_arch(), dtype).eval()
+    x, cond = t(g["x"], "cuda"), t(g["cond"], "cuda")
+    z = t(g["out"], "cuda")
+    with torch.no_grad():
+        ref_rev = m(z, cond, reverse=True).clone()
+        ref_out, ref_ld = m(x, cond)
+        ref_out, ref_ld = ref_out.clone(), ref_ld.clone()
+        m.set_graph_mode(True)
+        for it in range(4):
+            rev = m(z, cond, reverse=True)
+            out, ld = m(x, cond)
+            assert torch.equal(rev, ref_rev) and torch.equal(out, ref_out) and torch.equal(ld, ref_ld), it
+        m.set_graph_mode(False)
+        assert torch.equal(m(z, cond, reverse=True), ref_rev)

@@ -107,6 +107,20 @@ def test_macow_unit_forward_backward(C, ld):
     e_ld = (slots.sum(dim=(0, 2)).cpu() + const_ld - ldo.detach()).abs().max().item()
     print(f"unit C={C} ld={ld}: y err {e_y:.3e} pass-through err {e_pass:.1e} logdet err {e_ld:.3e}")
     assert e_y <= 8e-2 and e_pass == 0.0 and e_ld <= 0.5
+    # ---------------- fused inverse (sampling direction): reconstructs the input; same result as the oracle's reverse of y
+    i4 = _descs(C, ld, B, cond, shs, posts, keep)
+    xrec = torch.full((M, ld), float("nan"), device=DEV)
+    i4[3].x = ys[3].data_ptr(); i4[0].y = xrec.data_ptr(); i4[0].x = ys[3].data_ptr(); i4[3].y = xrec.data_ptr()
+    _lib.check(L.ipoke_macow_unit_inv(i4, _lib.DTYPES[DT], _lib.current_stream()))
+    torch.cuda.synchronize()
+    got_x = ops.from_state(xrec, B, ld).cpu()
+    e_rt = (got_x[:, :C] - x[:, :C]).abs().max().item()
+    with torch.no_grad():
+        xo_rev = o(got_y[:, :C], h=h, reverse=True)
+    e_or = (got_x[:, :C] - xo_rev).abs().max().item()
+    e_pt = (got_x[:, C:] - got_y[:, C:]).abs().max().item() if ld > C else 0.0
+    print(f"unit C={C} ld={ld}: inverse round trip {e_rt:.3e}, vs oracle reverse of the same y {e_or:.3e}")
+    assert torch.isfinite(got_x).all() and e_rt <= 5e-2 and e_or <= 5e-2 and e_pt == 0.0
     # ---------------- fused backward of 0.5*sum(y^2) - sum(logdet) : dy = y on the active channels
     gen = torch.Generator().manual_seed(7)
     dy = ys[3].clone()
