@@ -33,7 +33,21 @@ struct NtParams {
   void* C; int c_f32, c_acc; long ldc; int c_coff, c_cstride;
   int splitk, kb_per_split, n_pad;
   int tiles_m, tiles_n, xa, xb;
+#ifdef IPOKE_GEMM_STAMPS
+  long long* stamps = nullptr;   // probe build only (scripts/probe_gemm_stamps.py): 4 wall-clock stamps per workgroup
+#endif
 };
+
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 1     // probe build: fragment reads kept alive, matrix cores idle
+#define GEMM_MMA(a, b, c) asm volatile("" :: "v"(a), "v"(b))
+#else
+#define GEMM_MMA(a, b, c) mma64(a, b, c)
+#endif
+#ifdef IPOKE_GEMM_STAMPS
+#define GEMM_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(blockIdx.x + blockIdx.y * gridDim.x) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define GEMM_STAMP(i) do {} while (0)
+#endif
 
 // one problem of a batched weight-gradient launch (blockIdx.z): byte/float offsets against the launch's bases
 struct TnBatchEntry { long a_off, y_off, w_off; int kh, kw, ph, pw; };
@@ -135,16 +149,90 @@ __device__ __forceinline__ float fast_act(int act, float x) {
 // (An epilogue unrolled over the 16 register fragments costs more in instruction-cache misses than the whole
 // K loop of the small GEMMs of the flow.)
 // acc[i][j][r] = C[m0 + wm*MREP*16 + 16i + (lane&15)][n0 + wn*NREP*16 + 16j + 4*(lane>>4) + r]
-template <typename T, int WM, int WN, int MREP, int NREP>
+//
+// Fast path (interior tiles of the dtype-output GEMMs with no / ELU activation -- every NICE convolution of the flow): the
+// general sweep below is ~1500 instructions of branches that each launch executes once, i.e. straight out of a cold
+// instruction cache, and on gfx9 its bias / derivative-mask loads wait on vmcnt, which also counts the previous
+// iteration's stores; measured 3.2-3.7 us per launch at the 80 x 128 tile.  The fast path is branch-free: a thread owns ONE
+// 4-column group (so its bias is loaded once) in ITER rows, the derivative-mask loads of all rows are issued before the
+// accumulators are parked, and ELU / mask are applied by select.
+template <typename T, int WM, int WN, int MREP, int NREP, int NTHR = WM * WN * 64>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP][NREP], unsigned char* smem, int m0, int n0,
-                                            int wm, int wn, int z) {
+                                            int wm, int wn, int z, bool writer = true) {
   typedef typename Pack4<T>::type pack_t;
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr int EP = BN * 4 + 16;                      // staging pitch in bytes
   const GeomDev& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
+  constexpr int G4F = BN / 4;
+  if constexpr ((BM * G4F) % NTHR == 0 && NTHR % G4F == 0) {
+    constexpr int ITER = BM * G4F / NTHR, RSTEP = NTHR / G4F;
+    const bool fast = p.splitk == 1 && !p.c_f32 && (p.Nout & 3) == 0 && m0 + BM <= g.M && n0 + BN <= p.Nout &&
+                      ((p.ldc | p.c_coff) & 3) == 0 && (p.act == IPOKE_ACT_NONE || p.act == IPOKE_ACT_ELU) &&
+                      (!p.dact || ((p.ld_dact & 3) == 0 && p.dact_act == IPOKE_ACT_ELU));
+    if (fast) {
+      const int c4 = tid % G4F, r0 = tid / G4F, n = n0 + 4 * c4;
+      f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+      pack_t dy[ITER];
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) dy[k] = pack_t{};
+      if (p.dact) {
+        const T* dp = reinterpret_cast<const T*>(p.dact) + (long)(m0 + r0) * p.ld_dact + n;
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) dy[k] = *reinterpret_cast<const pack_t*>(dp + (long)k * RSTEP * p.ld_dact);
+      }
+      __syncthreads();
+      if (writer) {
+        unsigned char* base = smem + (wm * MREP * 16 + (lane & 15)) * EP + (wn * NREP * 16 + (lane >> 4) * 4) * 4;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(base + i * 16 * EP + j * 64) = acc[i][j];
+      }
+      __syncthreads();
+      const bool elu = p.act == IPOKE_ACT_ELU, mask = p.dact != nullptr;
+      T* Cp = reinterpret_cast<T*>(p.C) + (long)(m0 + r0) * p.ldc + p.c_coff + n;
+      const unsigned char* sp = smem + r0 * EP + c4 * 16;
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(sp + k * RSTEP * EP);
+        v += b4;
+        pack_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = fast_act<T>(IPOKE_ACT_ELU, v[r]);
+          float x = elu ? e : v[r];
+          const float y = ET<T>::to_f32(dy[k][r]);
+          x *= (mask && y <= 0.f) ? y + 1.f : 1.f;
+          o[r] = ET<T>::from_f32(x);
+        }
+        *reinterpret_cast<pack_t*>(Cp + (long)k * RSTEP * p.ldc) = o;
+      }
+      return;
+    }
+    // split-K partial sums of an interior tile (conv3 of every coupling net): raw fp32 rows, nothing to apply
+    if (p.splitk > 1 && !p.c_acc && m0 + BM <= g.M && n0 + BN <= p.ldc && (p.ldc & 3) == 0) {
+      const int c4 = tid % G4F, r0 = tid / G4F;
+      __syncthreads();
+      if (writer) {
+        unsigned char* base = smem + (wm * MREP * 16 + (lane & 15)) * EP + (wn * NREP * 16 + (lane >> 4) * 4) * 4;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(base + i * 16 * EP + j * 64) = acc[i][j];
+      }
+      __syncthreads();
+      float* P = reinterpret_cast<float*>(p.C) + ((long)z * g.M + m0 + r0) * p.ldc + n0 + 4 * c4;
+      const unsigned char* sp = smem + r0 * EP + c4 * 16;
+#pragma unroll
+      for (int k = 0; k < ITER; ++k)
+        *reinterpret_cast<f32x4*>(P + (long)k * RSTEP * p.ldc) = *reinterpret_cast<const f32x4*>(sp + k * RSTEP * EP);
+      return;
+    }
+  }
   __syncthreads();
-  {
+  if (writer) {      // (waves of the second K half of an in-workgroup K split hold nothing of their own any more)
     unsigned char* base = smem + (wm * MREP * 16 + (lane & 15)) * EP + (wn * NREP * 16 + (lane >> 4) * 4) * 4;
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
@@ -370,9 +458,14 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtParams p) {
-  constexpr int NTHR = WM * WN * 64;               // 4 or 8 wave64 (8 waves = two per SIMD: one's LDS reads hide under the other's MFMAs)
+// WK = 2: in-workgroup K split.  The waves form two groups that own the two 32-deep halves of every K-block and the same
+// WM x WN output tiling; the partial accumulators meet in LDS once, before the epilogue.  A wave then owns a tile twice as
+// wide for the same number of waves (e.g. 80 x 32 instead of 80 x 16 at 8 waves on an 80 x 128 tile): 7 instead of 12
+// fragment reads per 10 MFMAs, 56 instead of 96 KB of LDS reads per K-block -- the fragment reads, not the matrix cores,
+// bound the math side of these small-M GEMMs (every wave re-reads the whole A tile).
+template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE, int WK = 1>
+__global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const NtParams p) {
+  constexpr int NTHR = WM * WN * WK * 64;          // 4 or 8 wave64 (8 waves = two per SIMD: one's LDS reads hide under the other's MFMAs)
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr int E16 = ET<T>::E16;
   constexpr int BK = 128 / (int)sizeof(T);
@@ -388,9 +481,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtPar
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* dummy = smem + NSTAGE * STAGE;                         // 1 KB per wave: landing zone of padding DMAs
   int* taptab = reinterpret_cast<int*>(smem + NSTAGE * STAGE + NTHR * 16);
+  GEMM_STAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wk = wave / (WM * WN), wr = wave % (WM * WN);
+  const int wm = wr / WN, wn = wr % WN;
   const GeomDev& g = p.g;
   int tm, tn;
   {
@@ -521,7 +616,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtPar
   int kb_issue = kb_begin;                        // next K-block to be requested
   auto issue_slot = [&](int slot) {
 #pragma unroll
-    for (int u = 0; u < KPB; ++u) { issue(slot * STAGE + u * SUB, kb_issue < kb_end); ++kb_issue; }
+    for (int u = 0; u < KPB; ++u) {
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 2      // probe build: no operand traffic (every DMA goes to the dummy zone)
+      issue(slot * STAGE + u * SUB, false);
+#elif defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 3    // probe build: no DMA instructions at all
+#else
+      issue(slot * STAGE + u * SUB, kb_issue < kb_end);
+#endif
+      ++kb_issue;
+    }
   };
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue_slot(s);
@@ -532,30 +635,81 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_glds_kernel(const NtPar
 #pragma unroll
     for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(sub + b_rd[j][hs]);
   };
+  int a_rdw[MREP], b_rdw[NREP];                  // WK = 2: offsets of this wave group's K half (a runtime select, done once)
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) a_rdw[i] = wk ? a_rd[i][1] : a_rd[i][0];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) b_rdw[j] = wk ? b_rd[j][1] : b_rd[j][0];
+  auto load_half = [&](const unsigned char* sub, frag_t* fa, frag_t* fb) {
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) fa[i] = *reinterpret_cast<const frag_t*>(sub + a_rdw[i]);
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(sub + b_rdw[j]);
+  };
   int slot = 0;
   for (int kb = kb_begin; kb < kb_end; kb += KPB) {
     wait_vmcnt<(NSTAGE - 2) * L * KPB>();      // this wave's share of the oldest slot has landed
     __builtin_amdgcn_s_barrier();                     // ... and everybody else's; all reads of the slot refilled below are done
+    if (kb == kb_begin) GEMM_STAMP(1);
     issue_slot((slot + NSTAGE - 1) % NSTAGE);
     const unsigned char* base = smem + slot * STAGE;
     slot = (slot + 1) % NSTAGE;
     const int nsub = min(KPB, kb_end - kb);
-    // 2*nsub half-steps; fragments of half-step h+1 are fetched while the matrix cores work on h
-    frag_t fa[2][MREP], fb[2][NREP];
-    load_frags(base, 0, fa[0], fb[0]);
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 4      // probe build: operand stream only
+    if (nsub < 0)
+#endif
+    if constexpr (WK == 1) {
+      // 2*nsub half-steps; fragments of half-step h+1 are fetched while the matrix cores work on h
+      frag_t fa[2][MREP], fb[2][NREP];
+      load_frags(base, 0, fa[0], fb[0]);
 #pragma unroll
-    for (int h = 0; h < 2 * KPB; ++h) {
-      if (h < 2 * nsub) {
-        if (h + 1 < 2 * nsub) load_frags(base + ((h + 1) >> 1) * SUB, (h + 1) & 1, fa[(h + 1) & 1], fb[(h + 1) & 1]);
+      for (int h = 0; h < 2 * KPB; ++h) {
+        if (h < 2 * nsub) {
+          if (h + 1 < 2 * nsub) load_frags(base + ((h + 1) >> 1) * SUB, (h + 1) & 1, fa[(h + 1) & 1], fb[(h + 1) & 1]);
 #pragma unroll
-        for (int i = 0; i < MREP; ++i)
+          for (int i = 0; i < MREP; ++i)
 #pragma unroll
-          for (int j = 0; j < NREP; ++j) mma64(fa[h & 1][i], fb[h & 1][j], acc[i][j]);
+            for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[h & 1][i], fb[h & 1][j], acc[i][j]);
+        }
+      }
+    } else {
+      // this wave group owns K half `wk` of every K-block of the slot
+      frag_t fa[2][MREP], fb[2][NREP];
+      load_half(base, fa[0], fb[0]);
+#pragma unroll
+      for (int t = 0; t < KPB; ++t) {
+        if (t < nsub) {
+          if (t + 1 < nsub) load_half(base + (t + 1) * SUB, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+#pragma unroll
+          for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[t & 1][i], fb[t & 1][j], acc[i][j]);
+        }
       }
     }
   }
   wait_vmcnt<0>();                         // only padding DMAs (to the dummy zone) can still be in flight
-  nt_epilogue<T, WM, WN, MREP, NREP>(p, acc, smem, m0, n0, wm, wn, z);
+  GEMM_STAMP(2);
+  if constexpr (WK > 1) {                  // the two K halves meet: group 1 hands its partial sums to group 0 through LDS
+    constexpr int EP = BN * 4 + 16;
+    unsigned char* st2 = smem + BM * EP + (wm * MREP * 16 + (lane & 15)) * EP + (wn * NREP * 16 + (lane >> 4) * 4) * 4;
+    __syncthreads();                       // every read of the ring is done
+    if (wk == 1) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(st2 + i * 16 * EP + j * 64) = acc[i][j];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(st2 + i * 16 * EP + j * 64);
+    }
+  }
+  nt_epilogue<T, WM, WN, MREP, NREP, NTHR>(p, acc, smem, m0, n0, wm, wn, z, wk == 0);
+  GEMM_STAMP(3);
 }
 
 // =============================================================================================
@@ -834,7 +988,7 @@ static void pick_xcd_map(NtParams& p) {
   }
 }
 
-template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE>
+template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE, int WK = 1>
 static int launch_nt_glds_impl(NtParams& p, hipStream_t s) {
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr int BK = 128 / (int)sizeof(T);
@@ -844,22 +998,23 @@ static int launch_nt_glds_impl(NtParams& p, hipStream_t s) {
   if (p.splitk < 1) p.splitk = 1;
   p.kb_per_split = ceil_div(nkb, p.splitk);
   pick_xcd_map(p);
-  const size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * 128 + WM * WN * 64 * 16 + 256 * sizeof(int);
-  auto kern = igemm_nt_glds_kernel<T, WM, WN, MREP, NREP, NSTAGE, KPB, SIMPLE>;
+  size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * 128 + WM * WN * WK * 64 * 16 + 256 * sizeof(int);
+  if (lds < (size_t)WK * BM * (BN * 4 + 16)) lds = (size_t)WK * BM * (BN * 4 + 16);      // epilogue staging (+ the K halves' hand-over)
+  auto kern = igemm_nt_glds_kernel<T, WM, WN, MREP, NREP, NSTAGE, KPB, SIMPLE, WK>;
   static bool attr_done = false;
   if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
   dim3 grid((unsigned)((long)p.tiles_m * p.tiles_n), (unsigned)p.splitk);
-  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * WK * 64), lds, s, p);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
 
-template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB = 1>
+template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB = 1, int WK = 1>
 static int launch_nt_glds(NtParams& p, hipStream_t s) {
   constexpr int BK = 128 / (int)sizeof(T);
   const bool simple = p.Kc % BK == 0 && p.Kc_real == p.Kc && p.ldw >= p.Ktot;
-  return simple ? launch_nt_glds_impl<T, WM, WN, MREP, NREP, NSTAGE, KPB, true>(p, s)
-                : launch_nt_glds_impl<T, WM, WN, MREP, NREP, NSTAGE, KPB, false>(p, s);
+  return simple ? launch_nt_glds_impl<T, WM, WN, MREP, NREP, NSTAGE, KPB, true, WK>(p, s)
+                : launch_nt_glds_impl<T, WM, WN, MREP, NREP, NSTAGE, KPB, false, WK>(p, s);
 }
 
 template <typename T, int WM, int WN, int MREP, int NREP>
@@ -907,21 +1062,8 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
       if (skinny == 2 && M % 128 == 0) return launch_nt_glds<T, 4, 2, 2, 2, 3, 2>(p, s);
       return launch_nt_glds<T, 4, 1, 1, 4, 4>(p, s);                     // 64 x 64, skinny N
     }
-    if (glds_mode == 2) return launch_nt_glds<T, 2, 2, 4, 4, 4>(p, s);             // 128 x 128, 4 stages (128 KB LDS)
-    if (glds_mode == 3) return launch_nt_glds<T, 2, 2, 2, 4, 4>(p, s);             // 64 x 128
-    if (glds_mode == 4) return launch_nt_glds<T, 2, 2, 2, 2, 4>(p, s);             // 64 x 64
-    if (glds_mode == 5) return launch_nt_glds<T, 2, 2, 4, 4, 2, 2>(p, s);          // 128 x 128, 2 slots x 2 K-blocks
-    if (glds_mode == 6) return launch_nt_glds<T, 2, 2, 2, 4, 3, 2>(p, s);          // 64 x 128, 3 slots x 2 K-blocks
-    if (glds_mode == 7) return launch_nt_glds<T, 2, 2, 2, 2, 3, 4>(p, s);          // 64 x 64, 3 slots x 4 K-blocks
-    if (glds_mode == 8) return launch_nt_glds<T, 2, 2, 2, 2, 4, 2>(p, s);          // 64 x 64, 4 slots x 2 K-blocks
-    if (glds_mode == 9) return launch_nt_glds<T, 2, 4, 4, 2, 2, 2>(p, s);          // 128 x 128, 8 waves, 2 slots x 2 K-blocks
-    if (glds_mode == 10) return launch_nt_glds<T, 2, 4, 4, 2, 4, 1>(p, s);         // 128 x 128, 8 waves, 4 slots
-    if (glds_mode == 11) return launch_nt_glds<T, 4, 2, 2, 4, 2, 2>(p, s);         // 128 x 128, 8 waves (4x2)
-    if (glds_mode == 12) return launch_nt_glds<T, 2, 4, 2, 2, 4, 1>(p, s);         // 64 x 128, 8 waves
-    if (glds_mode == 13) return launch_nt_glds<T, 1, 8, 5, 1, 2, 2>(p, s);         // 80 x 128, 8 waves (M = 1280 -> 256 tiles)
-    if (glds_mode == 14) return launch_nt_glds<T, 1, 8, 5, 1, 4, 1>(p, s);         // 80 x 128, 8 waves, 4 slots
-    if (glds_mode == 15) return launch_nt_glds<T, 1, 8, 5, 1, 5, 1>(p, s);         // 80 x 128, 8 waves, 5 slots
-    if (glds_mode == 16) return launch_nt_glds<T, 1, 8, 5, 1, 3, 1>(p, s);         // 80 x 128, 8 waves, 3 slots
+    if (glds_mode == 16) return launch_nt_glds<T, 1, 8, 5, 1, 3, 1>(p, s);         // developer A/B: 80 x 128, 8 waves of 80 x 16, 3 slots
+    if (glds_mode == 17) return launch_nt_glds<T, 1, 4, 5, 2, 2, 2, 2>(p, s);      // developer A/B: 2 K-halves x 4 waves of 80 x 32, 2 slots x 2
     {
       // Row-tile height: the flow's GEMMs have M = 64*B rows (1280 at B = 20) and N = 2048, i.e. 160 tiles of 128 x 128 on
       // 256 CUs.  80- or 160-row tiles give exactly 256 workgroups at B = 20 / 40; pick the height with the least
@@ -931,8 +1073,11 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
       if (M % 160 == 0) { const long c = ((long)(M / 160) * tn128 + 255) / 256 * 160; if (c <= best_cost) { best = 160; best_cost = c; } }
       if (M % 80 == 0) { const long c = ((long)(M / 80) * tn128 + 255) / 256 * 80; if (c < best_cost) { best = 80; best_cost = c; } }
       if ((long)ceil_div(M, 128) * tn128 >= 100) {
-        if (best == 80) return launch_nt_glds<T, 1, 8, 5, 1, 3, 1>(p, s);          // 80 x 128, 8 waves, 3 slots (deeper rings measure no faster:
-                                                                                   // the DMA path saturates at ~65 GB/s per CU)
+        // 80 x 128: two K-halves x 4 waves of 80 x 32, 3 slots.  Isolated 21.9-24 us at conv2 against 24.7 for 8 waves of
+        // 80 x 16 (fewer fragment reads); inside the train step both measure the same (side-stream contention dominates),
+        // and the 2 x 2-slot variant, faster still in isolation, is slower there (106 KB of LDS per workgroup).  Deeper
+        // rings measure no faster: the operand stream alone (no math) runs at ~70 GB/s per CU.
+        if (best == 80) return launch_nt_glds<T, 1, 4, 5, 2, 3, 1, 2>(p, s);
         if (best == 160) return launch_nt_glds<T, 2, 4, 5, 2, 2, 2>(p, s);         // 160 x 128, 8 waves
         return launch_nt_glds<T, 2, 4, 4, 2, 2, 2>(p, s);                          // 128 x 128, 8 waves
       }
@@ -1105,6 +1250,8 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   wait_vmcnt<0>();
 
   // epilogue: acc[i][j][r] = dW[n = n0 + wn2*64 + 16i + (lane&15)][k = k0 + wk*32 + 16j + 4*(lane>>4) + r]
+  const bool vec4 = p.w_sc == 1 && !p.accumulate && !(p.splitm > 1 && p.split_stride == 0) && ((p.w_sn | p.w_st | p.split_stride) & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(p.dW) & 15) == 0 && (p.Kc & 3) == 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + wn2 * 64 + i * 16 + (lane & 15);
@@ -1115,6 +1262,10 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
       if (k >= p.Ktot) continue;
       const int tap = k / p.Kc, c = k - tap * p.Kc;     // 4 consecutive k share the tap (Kc % 4 == 0)
       float* base = p.dW + (long)n * p.w_sn + (long)tap * p.w_st + (p.split_stride > 0 ? (long)z * p.split_stride : 0L);
+      if (vec4 && c + 3 < p.Kc_store) {                 // dense rows (1x1 convs): one 16-byte store instead of four
+        *reinterpret_cast<f32x4*>(base + c) = acc[i][j];
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (c + r < p.Kc_store) {
@@ -1184,6 +1335,11 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
 
 using namespace ipoke;
 
+#ifdef IPOKE_GEMM_STAMPS
+static long long* g_gemm_stamps = nullptr;
+extern "C" void ipoke_gemm_set_stamps(long long* base) { g_gemm_stamps = base; }
+#endif
+
 extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream) {
   IPK_REQUIRE(d != nullptr, "null descriptor");
   IPK_REQUIRE(dtype == IPOKE_F32 || dtype == IPOKE_BF16, "bad dtype");
@@ -1223,6 +1379,10 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
     IPK_REQUIRE(p.c_cstride == 1 && !d->c_accumulate, "dtype outputs are dense, non-accumulating");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#ifdef IPOKE_GEMM_STAMPS
+  p.stamps = g_gemm_stamps;
+  if (g_gemm_stamps) g_gemm_stamps += 4 * 4096;                // one slab of 4096 workgroups per launch
+#endif
   TimedScope ts(p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 && p.splitk == 1 ? IPOKE_TAG_NT_SQUARE : 0, s);
   return dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
 }
@@ -1257,6 +1417,9 @@ static int fill_tn(TnParams& p, const ipoke_wgrad_desc* d, int dtype, bool batch
 }
 
 extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream) {
+#ifdef IPOKE_PROBE_NO_WGRAD
+  return IPOKE_OK;
+#endif
   TnParams p;
   int rc = fill_tn(p, d, dtype, false); if (rc) return rc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1270,6 +1433,9 @@ extern "C" int ipoke_wgrad_batch_entry_size(void) { return (int)sizeof(TnBatchEn
  * from the entry) in one launch.  entries_dev[i] = {a_off bytes, y_off bytes, w_off floats, kh, kw, ph, pw}. */
 extern "C" int ipoke_conv_wgrad_batched(const ipoke_wgrad_desc* d, const void* entries_dev, int nbatch, const void* a_base,
                                         const void* y_base, float* w_base, int dtype, void* stream) {
+#ifdef IPOKE_PROBE_NO_WGRAD
+  return IPOKE_OK;
+#endif
   IPK_REQUIRE(entries_dev && nbatch >= 1 && a_base && y_base && w_base, "bad batch arguments");
   TnParams p;
   int rc = fill_tn(p, d, dtype, true); if (rc) return rc;
