@@ -87,6 +87,13 @@ int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
 /* n back-to-back native launches of the same convolution (kernel timing without host round trips) */
 int ipoke_conv_forward_repeat(const ipoke_conv_desc* d, int dtype, int n, void* stream);
 
+/* Split count the library wants for the skinny 3x3 convolutions of the coupling nets (conv3 forward: split-K partial
+ * slabs; conv1 data gradient: atomic accumulation) at M = 64*B output rows and Kc input channels -- callers size their
+ * partial-sum slabs with it and pass it as ipoke_conv_desc.splitk.  0: no preference (the stationary-input kernel does
+ * not apply).  Reference call sites: conv3 / conv1 of NICEConvBlock (models/modules/INN/macow_utils.py:270-281,
+ * 3x3, padding 1, on the 8x8 latent). */
+int ipoke_conv3x3_skinny_splitk(int M, int Kc, int dtype);
+
 /* Weight gradient: dW[n][tap*Kc + c] (+)= sum_m dY[m][n] * A[src(m,tap)][c].
  * dY is dtype [M][ldy]; A as in ipoke_conv_desc (fp32 or dtype).  Output fp32, written through a
  * (n, c, tap) stride triple so PyTorch's [out][in][k...] layout is produced directly. */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "ipoke_dtype_size": (c_int, [c_int]),
     "ipoke_conv_forward": (c_int, [POINTER(ConvDesc), c_int, _P]),
     "ipoke_conv_forward_repeat": (c_int, [POINTER(ConvDesc), c_int, c_int, _P]),
+    "ipoke_conv3x3_skinny_splitk": (c_int, [c_int, c_int, c_int]),
     "ipoke_conv_wgrad": (c_int, [POINTER(WgradDesc), c_int, _P]),
     "ipoke_wgrad_batch_entry_size": (c_int, []),
     "ipoke_conv_wgrad_batched": (c_int, [POINTER(WgradDesc), _P, c_int, _P, _P, _P, c_int, _P]),

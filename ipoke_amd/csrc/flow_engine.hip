@@ -371,6 +371,10 @@ int64_t take(int64_t& cur, int64_t bytes) { const int64_t o = cur; cur = align_u
 
 int max_splitk(const ipoke_flow& f, int B) {
   const int M = B * f.P;
+  {   // the stationary-input 3x3 kernel splits over 64-channel chunks and knows its own tile height
+    const int s8 = ipoke_conv3x3_skinny_splitk(M, f.cfg.hidden, f.cfg.dtype);
+    if (s8 > 0) return s8;
+  }
   const int tiles = ceil_div(M, 64);
   const int nkb = ceil_div(9 * f.cfg.hidden, 128 / f.esz);
   static const int target = getenv("IPOKE_SPLITK_TARGET") ? atoi(getenv("IPOKE_SPLITK_TARGET")) : 384;   // workgroups per N tile

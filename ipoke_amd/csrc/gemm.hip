@@ -988,6 +988,218 @@ static void pick_xcd_map(NtParams& p) {
   }
 }
 
+// =============================================================================================
+// 3x3 convolution (stride 1, pad 1) on 8x8 maps with a wide dense input and a skinny output: conv3 of every coupling net
+// (2048 -> 2*cout <= 64 channels, split-K partials) and the data gradient of conv1 (2048 -> cin channels, accumulated
+// into the gradient state).  As an implicit GEMM the K = 9 * 2048 reduction re-reads every input row nine times (once
+// per tap) and every 64-row tile re-reads the whole filter: 92 MB of L2 -> LDS traffic per launch at B = 20 for 5 MB of
+// input and 2.4 MB of filter.  Here the reduction runs chunk-major (64 input channels at a time, the 9 taps inside): a
+// tile of two whole samples keeps the chunk's [128 rows x 64 channels] image in LDS ONCE and the nine taps read it
+// through shifted row addresses -- a lane whose tap falls outside the 8x8 map reads a zero row instead -- so only the
+// filter streams (29 MB per launch).
+// The math side of these kernels is bound by LDS fragment reads, not by the matrix cores (measured with the DMA
+// instructions compiled out: a 4 x 2 arrangement of 32 x 32 wave tiles needs 96 KB of ds_read_b128 per K-block and runs
+// at 350 ns per K-block, ~130 B/clk of LDS reads, against 110 ns of MFMA time).  So the 8 waves are arranged as
+// 2 (row halves) x 4 (K groups): a wave owns a 64 x 64 tile -- 16 fragment reads per 32 MFMAs, 32 KB per K-block -- of
+// every fourth K-block (tap), four K-blocks are consumed per barrier, and the four groups' accumulators meet in LDS
+// (two hand-over rounds) before the epilogue.
+// Split-K is over channel chunks (blockIdx.y); the epilogue is nt_epilogue (partials / atomics / dense outputs).
+__global__ __launch_bounds__(512) void conv3x3_s8_kernel(const NtParams p) {
+  typedef bf16_t T;
+  typedef typename ET<T>::frag frag_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int BM = 128, BN = 64, NTHR = 512, R = 12;     // ring: three rounds of four filter K-blocks
+  constexpr int ABUF = BM * 128, WSLOT = BN * 128;
+  constexpr int A_IT = BM * 8 / NTHR;                      // DMA instructions per thread and input chunk (2)
+  constexpr int MREP = 4, NREP = 4;
+  constexpr int EP = BN * 4 + 16;                          // nt_epilogue's staging pitch
+  constexpr unsigned kInvalid = 0xffffffffu;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* abuf = smem;                              // 2 x ABUF: the input chunk, double-buffered
+  unsigned char* zrow = smem + 2 * ABUF;                   // 256 bytes of zeros: the "outside the map" row
+  unsigned char* ring = zrow + 256;                        // R filter K-blocks
+  unsigned char* dummy = ring + R * WSLOT;                 // landing zone of padding DMAs, 1 KB per wave
+  GEMM_STAMP(0);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mh = wave & 1, kq = wave >> 1;
+  const GeomDev& g = p.g;
+  const int m0 = blockIdx.x * BM, z = blockIdx.y;
+  const int nchunks = p.Kc >> 6;
+  const int c_begin = z * p.kb_per_split, c_end = min(nchunks, c_begin + p.kb_per_split);
+  const int nch = max(0, c_end - c_begin), nkb = nch * 9, nrounds = (nkb + 3) >> 2;
+  const int sgn = g.transposed ? -1 : 1;
+
+  if (tid < 16) reinterpret_cast<f32x4*>(zrow)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const T* Abase = reinterpret_cast<const T*>(p.A);
+  const T* Wbase = reinterpret_cast<const T*>(p.W);
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+  unsigned a_src[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int ch = (wave + 8 * i) * 64 + lane, row = ch >> 3, pos = ch & 7, m = m0 + row;
+    a_src[i] = kInvalid;
+    if (m < g.M) {
+      const long off = (long)(m >> 6) * p.a_sn + (long)((m >> 3) & 7) * p.a_sh + (long)(m & 7) * p.a_sw + p.a_coff;
+      a_src[i] = (unsigned)(off + c_begin * 64 + ((pos ^ ((row >> 1) & 7)) * 8));
+    }
+  }
+  // filter DMA of a round: wave w brings rows 32*(w >> 2) .. +31 (4 instructions of 8 rows) of K-block 4r + (w & 3)
+  unsigned w_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = 32 * (wave >> 2) + 8 * j + (lane >> 3), pos = lane & 7;
+    w_src[j] = n < p.Nout ? (unsigned)((long)n * p.ldw + c_begin * 64 + ((pos ^ ((n >> 1) & 7)) * 8)) : kInvalid;
+  }
+  int wi_g = wave & 3, wi_c = 0, wi_t = wave & 3;          // K-block index / (chunk, tap) of this wave's next filter request
+  auto issue_w = [&]() {
+    const bool in = wi_g < nkb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 3
+      continue;
+#endif
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 2
+      const bool real = false;
+#else
+      const bool real = in && w_src[j] != kInvalid;
+#endif
+      const T* src = real ? Wbase + w_src[j] + (long)wi_t * p.Kc + wi_c * 64 : zero;
+      unsigned char* dst = in ? ring + (wi_g % R) * WSLOT + (4 * (wave >> 2) + j) * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+    wi_g += 4; wi_t += 4;
+    if (wi_t >= 9) { wi_t -= 9; ++wi_c; }
+  };
+  int a_next = 0;                                          // next input chunk to request
+  auto issue_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 3
+      continue;
+#endif
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 2
+      const bool real = false;
+#else
+      const bool real = a_next < nch && a_src[i] != kInvalid;
+#endif
+      const T* src = real ? Abase + a_src[i] + a_next * 64 : zero;
+      unsigned char* dst = a_next < nch ? abuf + (a_next & 1) * ABUF + (wave + 8 * i) * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+    ++a_next;
+  };
+  issue_a();                 // chunk 0
+  issue_w(); issue_w();      // rounds 0 and 1
+
+  // fragment bookkeeping: row r of the tile is position (y, x) = ((r >> 3) & 7, r & 7) of sample r >> 6
+  unsigned vmask[MREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    const int r = i * 16 + (lane & 15);                    // row inside this wave's sample (mh)
+    const int y = (r >> 3) & 7, x = r & 7;
+    unsigned vm = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + sgn * (t / 3 - 1), xx = x + sgn * (t % 3 - 1);
+      if ((unsigned)yy < 8u && (unsigned)xx < 8u) vm |= 1u << t;
+    }
+    vmask[i] = vm;
+  }
+  const int qlo = lane >> 4;
+  int b_rd[NREP];                                          // half-step 0; half-step 1 is the chunk position ^ 4, i.e. byte offset ^ 64
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int n = j * 16 + (lane & 15);
+    b_rd[j] = n * 128 + ((qlo ^ ((n >> 1) & 7)) * 16);
+  }
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int gk = kq, ci = 0, t = kq;                             // this wave's K-block of the round: index, chunk, tap
+  for (int r = 0; r < nrounds; ++r) {
+    wait_vmcnt<4>();                 // everything but this wave's share of round r + 1 has landed (input chunks included)
+    __builtin_amdgcn_s_barrier();
+    if (r == 0) GEMM_STAMP(1);
+    // the first K-block of this round lies in chunk (4r)/9: request the chunk after it once (its buffer held chunk - 1,
+    // whose last K-block was consumed before this barrier)
+    if (a_next <= (4 * r) / 9 + 1) issue_a();          // (issued before the filter blocks: the wait above counts those only)
+    issue_w();                       // round r + 2 into the slots of round r - 1
+    if (gk < nkb) {
+      const unsigned char* ab = abuf + (ci & 1) * ABUF + mh * 64 * 128;
+      const unsigned char* wb = ring + (gk % R) * WSLOT;
+      const int th = t / 3, tw = t - 3 * th;
+      const int shift = sgn * ((th - 1) * 8 + (tw - 1));
+      const unsigned char* arow[MREP]; int aswz[MREP];
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) {
+        const bool ok = (vmask[i] >> t) & 1u;
+        const int sr = i * 16 + (lane & 15) + shift;       // row inside the sample
+        arow[i] = ok ? ab + sr * 128 : zrow;
+        aswz[i] = ok ? (sr >> 1) & 7 : 0;
+      }
+      frag_t fa[2][MREP], fb[2][NREP];
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) fa[hs][i] = *reinterpret_cast<const frag_t*>(arow[i] + (((hs * 4 + qlo) ^ aswz[i]) * 16));
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) fb[hs][j] = *reinterpret_cast<const frag_t*>(wb + (b_rd[j] ^ (hs * 64)));
+      }
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[hs][i], fb[hs][j], acc[i][j]);
+    }
+    gk += 4; t += 4;
+    if (t >= 9) { t -= 9; ++ci; }
+  }
+  wait_vmcnt<0>();
+  GEMM_STAMP(2);
+  // the four K groups meet: groups 2, 3 hand over to groups 0, 1, then group 1 to group 0 (nt_epilogue's staging layout)
+  {
+    unsigned char* st = smem + (mh * MREP * 16 + (lane & 15)) * EP + (lane >> 4) * 16;
+    __syncthreads();                 // the ring and the input buffers are dead
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const int give_lo = round == 0 ? 2 : 1, take_hi = round == 0 ? 2 : 1;      // givers: kq in [give_lo, 2*give_lo); takers: kq < take_hi
+      if (kq >= give_lo && kq < 2 * give_lo) {
+        unsigned char* d = st + (kq - give_lo) * BM * EP;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(d + i * 16 * EP + j * 64) = acc[i][j];
+      }
+      __syncthreads();
+      if (kq < take_hi) {
+        const unsigned char* d = st + kq * BM * EP;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(d + i * 16 * EP + j * 64);
+      }
+      if (round == 0) __syncthreads();
+    }
+  }
+  nt_epilogue<T, 2, 1, MREP, NREP, NTHR>(p, acc, smem, m0, 0, mh, 0, z, kq == 0);
+  GEMM_STAMP(3);
+}
+
+// chunks of 64 input channels per split such that (row tiles) x (splits) stays within one round of workgroups
+static int conv3x3_s8_splits(int M, int Kc, int TS) {
+  const int tiles = ceil_div(M, 64 * TS), nchunks = Kc / 64;
+  int want = 256 / tiles; if (want < 1) want = 1; if (want > 32) want = 32; if (want > nchunks) want = nchunks;
+  const int cps = ceil_div(nchunks, want);
+  return ceil_div(nchunks, cps);
+}
+
 template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE, int WK = 1>
 static int launch_nt_glds_impl(NtParams& p, hipStream_t s) {
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
@@ -1040,10 +1252,47 @@ static int launch_nt(NtParams& p, hipStream_t s) {
   return IPOKE_OK;
 }
 
+static int s8_samples_per_tile() {
+  static const int ts = getenv("IPOKE_S8") ? (atoi(getenv("IPOKE_S8")) ? 2 : 0) : 2;      // developer A/B: IPOKE_S8=0 turns the kernel off
+  return ts;
+}
+static bool s8_applicable(const NtParams& p) {
+  const GeomDev& g = p.g;
+  return s8_samples_per_tile() > 0 && !p.a_f32 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Hi == 8 && g.Wi == 8 &&
+         g.lDo == 0 && g.lHo == 3 && g.lWo == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 1 && g.pw == 1 &&
+         p.Kc % 64 == 0 && p.Kc_real == p.Kc && p.Kc >= 256 && p.Nout <= 64 && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot &&
+         ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && (long)(g.M >> 6) * p.a_sn + 7 * p.a_sh + 7 * p.a_sw + p.Kc < (1L << 31) &&
+         (long)p.Nout * p.ldw < (1L << 31);
+}
+static int launch_conv3x3_s8(NtParams& p, hipStream_t s) {
+  constexpr int BM = 128;
+  const size_t lds = 2 * BM * 128 + 256 + 12 * 64 * 128 + 512 * 16;
+  auto kern = conv3x3_s8_kernel;
+  static bool attr_done = false;
+  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  p.tiles_m = ceil_div(p.g.M, BM); p.tiles_n = 1; p.xa = p.xb = 0;
+  p.kb_per_split = ceil_div(p.Kc / 64, p.splitk);
+  dim3 grid((unsigned)p.tiles_m, (unsigned)p.splitk);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+// Split count for the skinny 3x3 convolutions of the coupling nets (conv3 forward, conv1 data gradient) at M output rows
+// and Kc input channels: callers size their partial-sum slabs with it.  0: the kernel does not apply (caller's choice).
+extern "C" int ipoke_conv3x3_skinny_splitk(int M, int Kc, int dtype) {
+  const int ts = s8_samples_per_tile();
+  if (dtype != IPOKE_BF16 || ts <= 0 || Kc % 64 != 0 || Kc < 256 || M % 64 != 0) return 0;
+  return conv3x3_s8_splits(M, Kc, ts);
+}
+
 template <typename T>
 static int dispatch_nt(NtParams& p, hipStream_t s) {
   // Tile choice: fill the 256 CUs with one wave of tiles when the problem allows it.
   const int M = p.g.M, N = p.Nout;
+  if constexpr (sizeof(T) == 2) {
+    if (s8_applicable(p)) return launch_conv3x3_s8(p, s);
+  }
   static const int forced = getenv("IPOKE_NT_TILE") ? atoi(getenv("IPOKE_NT_TILE")) : 0;     // developer override
   switch (forced) {
     case 1: return launch_nt<T, 4, 1, 1, 4>(p, s);

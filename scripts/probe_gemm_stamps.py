@@ -10,7 +10,8 @@ from ipoke_amd import _lib, ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 pad = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-N, M, dev = 2048, B * 64, "cuda"
+kind = sys.argv[4] if len(sys.argv) > 4 else "conv2"      # conv2: 1x1 hid->hid;  conv3: 3x3 K -> 64 columns, split-K partials
+N, M, dev = (2048 if kind == "conv2" else 64), B * 64, "cuda"
 td = torch.bfloat16
 P = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", os.environ.get("PROBE_LIB", "libgemm_probe.so")))
 P.ipoke_conv_forward.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -21,10 +22,18 @@ sets = []
 for i in range(NS):
     a = torch.randn(M, lda, device=dev).to(td)
     w = (torch.randn(N, ldw, device=dev) / K ** 0.5).to(td)
-    c = torch.empty(M, ldc, device=dev, dtype=td)
-    d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0))
-    d.A = a.data_ptr(); d.a_sn = 64 * lda; d.a_sh = 8 * lda; d.a_sw = lda; d.a_sc = 1; d.Kc_real = K; d.Kc = K
-    d.W = w.data_ptr(); d.ldw = ldw; d.Nout = N; d.act = _lib.ACT_ELU; d.C = c.data_ptr(); d.ldc = ldc
+    if kind == "conv2":
+        c = torch.empty(M, ldc, device=dev, dtype=td)
+        d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0))
+        d.A = a.data_ptr(); d.a_sn = 64 * lda; d.a_sh = 8 * lda; d.a_sw = lda; d.a_sc = 1; d.Kc_real = K; d.Kc = K
+        d.W = w.data_ptr(); d.ldw = ldw; d.Nout = N; d.act = _lib.ACT_ELU; d.C = c.data_ptr(); d.ldc = ldc
+    else:
+        SK = int(os.environ.get("SPLITK", "20"))
+        w = (torch.randn(N, 9 * K, device=dev) / K ** 0.5).to(td)
+        c = torch.empty(SK, M, 64, device=dev, dtype=torch.float32)
+        d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        d.A = a.data_ptr(); d.a_sn = 64 * lda; d.a_sh = 8 * lda; d.a_sw = lda; d.a_sc = 1; d.Kc_real = K; d.Kc = K
+        d.W = w.data_ptr(); d.ldw = 9 * K; d.Nout = N; d.act = 0; d.C = c.data_ptr(); d.ldc = 64; d.c_f32 = 1; d.splitk = SK
     sets.append((d, a, w, c))
 dt, stream = ops._dt("bf16"), _lib.current_stream()
 st = torch.zeros(NL, 4096, 4, dtype=torch.int64, device=dev)

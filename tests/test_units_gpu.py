@@ -147,6 +147,43 @@ def test_conv_forward_state_input_and_splitk(dtype):
     assert (got2.cpu() - ref2).abs().max() <= TOLS[dtype] * 3
 
 
+@pytest.mark.parametrize("B,Cout", [(5, 60), (4, 32), (20, 64)])
+def test_conv3x3_skinny_stationary_input(B, Cout):
+    """The chunk-major 3x3 kernel for wide dense inputs and <= 64 outputs (conv3 of NICEConvBlock, macow_utils.py:281, and
+    the data gradient of its conv1, :270): split-K partial slabs with the library's own split count (odd B = a half-empty
+    last tile), and the transposed form accumulated atomically into a strided fp32 state."""
+    Cin = 512
+    gen = torch.Generator().manual_seed(B * 100 + Cout)
+    x = torch.randn(B, Cin, 1, 8, 8, generator=gen)
+    w = torch.randn(Cout, Cin, 1, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    sk = _lib.lib().ipoke_conv3x3_skinny_splitk(B * 64, Cin, _lib.BF16)
+    assert 1 <= sk <= 32
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv3d(xb, wb, None, padding=(0, 1, 1))
+    got = _run_conv(x.to(DEV), w.to(DEV), "bf16", (1, 1, 1), (0, 1, 1), splitk=sk)
+    err = (got.cpu() - ref).abs().max().item()
+    print(f"skinny 3x3 B={B} Cout={Cout} splitk={sk}: max err {err:.3e}")
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item())          # same bf16 operands, fp32 accumulation in another order
+    # data-gradient form: transposed taps, accumulated into every second column of a 64-wide fp32 state
+    wt = torch.randn(Cin, Cout, 1, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    reft = F.conv_transpose3d(xb, wt.bfloat16().float(), None, padding=(0, 1, 1))
+    M = B * 64
+    d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1), True)
+    xa = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV).bfloat16()
+    d.A = xa.data_ptr(); d.a_sn = 64 * Cin; d.a_sd = 0; d.a_sh = 8 * Cin; d.a_sw = Cin; d.a_sc = 1; d.Kc_real = Cin; d.Kc = Cin
+    ws = shadow_nt(wt.transpose(0, 1).contiguous().to(DEV), Cin, dtype="bf16")
+    d.W = ws.data_ptr(); d.ldw = ws.shape[1]; d.Nout = min(Cout, 32)
+    state = torch.randn(M, 64, generator=gen).to(DEV)
+    before = state.clone()
+    d.C = state.data_ptr(); d.c_f32 = 1; d.c_accumulate = 1; d.ldc = 64; d.c_coff = 1; d.c_cstride = 2; d.splitk = sk
+    ops.conv_forward(d, "bf16")
+    torch.cuda.synchronize()
+    add = (state - before).cpu()
+    want = reft[:, :d.Nout, 0].permute(0, 2, 3, 1).reshape(M, d.Nout)
+    assert (add[:, 1:2 * d.Nout:2] - want).abs().max() <= 2e-3 * max(1.0, want.abs().max().item())
+    assert add[:, 0::2].abs().max() == 0 and (2 * d.Nout >= 64 or add[:, 2 * d.Nout + 1::2].abs().max() == 0)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES[:6], ids=[c[0] for c in CONV_CASES[:6]])
 def test_conv_wgrad_vs_torch(case, dtype):
