@@ -262,7 +262,8 @@ int ipoke_wn_bwd_multi_range(const float* params, float* grads, const float* inv
 /* In-situ timing for the benchmark's roofline objects: between ipoke_timing_start() and ipoke_timing_stop() every launch of
  * a tagged kernel family is bracketed by HIP events on the stream it is launched on (the rest of the step runs as usual).
  * Tags: 1 = ipoke_conv_forward with a 1x1 kernel and Nout = K >= 1024 (the NICE conv2 GEMM and its data gradient),
- *       2 = ipoke_conv_wgrad of the same shape, 3 = ipoke_macow_unit_fwd, 4 = ipoke_macow_unit_bwd. */
+ *       2 = ipoke_conv_wgrad / _batched of the same shape (a batched launch counts once per problem and its time is divided
+ *       by the problem count), 3 = ipoke_macow_unit_fwd, 4 = ipoke_macow_unit_bwd. */
 #define IPOKE_TAG_NT_SQUARE 1
 #define IPOKE_TAG_TN_SQUARE 2
 #define IPOKE_TAG_UNIT_FWD 3

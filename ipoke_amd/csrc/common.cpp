@@ -12,7 +12,7 @@ extern "C" int ipoke_dtype_size(int dtype) { return dtype == IPOKE_BF16 ? 2 : dt
 // launched on, while the whole step runs as usual.  Off unless ipoke_timing_start() was called; never used in a timed step.
 #include <vector>
 namespace ipoke {
-struct TimedLaunch { int tag; hipEvent_t e0, e1; };
+struct TimedLaunch { int tag, units; hipEvent_t e0, e1; };
 static bool g_timing = false;
 static std::vector<TimedLaunch> g_timed;
 static std::vector<hipEvent_t> g_pool;
@@ -22,9 +22,9 @@ static hipEvent_t pooled_event() {
   return g_pool[g_pool_next++];
 }
 bool timing_active() { return g_timing; }
-int timing_begin(int tag, hipStream_t s) {
+int timing_begin(int tag, hipStream_t s, int units) {
   if (!g_timing) return -1;
-  TimedLaunch t{tag, pooled_event(), pooled_event()};
+  TimedLaunch t{tag, units < 1 ? 1 : units, pooled_event(), pooled_event()};
   (void)hipEventRecord(t.e0, s);
   g_timed.push_back(t);
   return (int)g_timed.size() - 1;
@@ -37,8 +37,8 @@ extern "C" int ipoke_timing_start(void) {
   ipoke::g_timed.clear(); ipoke::g_pool_next = 0; ipoke::g_timing = true;
   return IPOKE_OK;
 }
-/* stops recording; for every tag in tags[0..ntags) writes the number of recorded launches and their mean duration (us).
- * Synchronises the device. */
+/* stops recording; for every tag in tags[0..ntags) writes the number of recorded problems (a batched launch counts one per
+ * problem) and the mean duration per problem (us).  Synchronises the device. */
 extern "C" int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us) {
   ipoke::g_timing = false;
   IPK_HIP(hipDeviceSynchronize());
@@ -46,7 +46,7 @@ extern "C" int ipoke_timing_stop(const int* tags, int ntags, int* counts, double
   for (const auto& t : ipoke::g_timed) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) continue;
-    for (int k = 0; k < ntags; ++k) if (tags[k] == t.tag) { counts[k] += 1; mean_us[k] += 1e3 * ms; }
+    for (int k = 0; k < ntags; ++k) if (tags[k] == t.tag) { counts[k] += t.units; mean_us[k] += 1e3 * ms; }
   }
   for (int k = 0; k < ntags; ++k) if (counts[k]) mean_us[k] /= counts[k];
   ipoke::g_timed.clear();

@@ -33,11 +33,11 @@ int fail(int code, const std::string& msg);
 
 // ---- in-situ timing of tagged launches (common.cpp; bench.py's roofline objects) ---------------------------------
 bool timing_active();
-int timing_begin(int tag, hipStream_t s);
+int timing_begin(int tag, hipStream_t s, int units = 1);
 void timing_end(int slot, hipStream_t s);
 struct TimedScope {       // records an event pair around the launches issued while it is alive (no-op unless timing is on)
   int slot; hipStream_t s;
-  TimedScope(int tag, hipStream_t st) : slot(tag != 0 && timing_active() ? timing_begin(tag, st) : -1), s(st) {}
+  TimedScope(int tag, hipStream_t st, int units = 1) : slot(tag != 0 && timing_active() ? timing_begin(tag, st, units) : -1), s(st) {}
   ~TimedScope() { timing_end(slot, s); }
 };
 

@@ -47,6 +47,7 @@ struct Op {
   int64_t ws_a = -1, ws_b = -1, ws_c = -1, ws_d = -1, ws_e = -1, ws_f = -1, ws_g = -1;
   int slot = -1;                               // log-det slot index
   int mcf_idx = -1;                            // running index among the MCF ops (batched weight gradients)
+  int nice_idx = -1;                           // running index among the NICE ops (batched weight gradients)
   int level = 0;                               // multi-scale level the op belongs to
   int fuse_act = -1;                           // MCF: index of the ActNorm executed inside this layer's kernels
   bool fused = false;                          // ActNorm: executed by the preceding MCF layer (forward / backward)
@@ -80,6 +81,8 @@ struct ipoke_flow {
   int n_mcf = 0;
   // per-batch-size device tables of the batched weight-gradient / reduction launches
   int tab_B = 0; void* d_w1tab = nullptr; void* d_w2tab = nullptr; void* d_redtab = nullptr; int n_red = 0;
+  void* d_ntab[3] = {nullptr, nullptr, nullptr};   // NICE conv1 / conv2 / conv3 weight-gradient batch entries, by nice_idx
+  int n_nice = 0;
   std::vector<RelayoutJobH> rjobs; int rblocks = 0;
   std::vector<WnJobH> wjobs;
   std::vector<LsRefH> lsrefs;
@@ -330,6 +333,8 @@ int build(ipoke_flow& f) {
   }
   int k = 0;
   for (auto& o : f.ops) if (o.type == OP_MCF) o.mcf_idx = k++;     // execution order
+  f.n_nice = 0;
+  for (auto& o : f.ops) if (o.type == OP_NICE) o.nice_idx = f.n_nice++;
   // MaCowUnit: MCF, MCF, ActNorm, MCF, MCF, ActNorm -- the ActNorm runs inside the preceding MCF kernels
   static const bool nofuse = getenv("IPOKE_NO_ACTNORM_FUSION") != nullptr;
   for (size_t i = 0; !nofuse && i + 1 < f.ops.size(); ++i) {
@@ -541,6 +546,7 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
   IPK_REQUIRE((int)sizeof(WgEntryH) == ipoke_wgrad_batch_entry_size() && (int)sizeof(RedEntryH) == ipoke_reduce_entry_size(),
               "batch table layout mismatch");
   std::vector<WgEntryH> w1(f->n_mcf), w2(f->n_mcf);
+  std::vector<WgEntryH> nt[3] = {std::vector<WgEntryH>(f->n_nice), std::vector<WgEntryH>(f->n_nice), std::vector<WgEntryH>(f->n_nice)};
   std::vector<RedEntryH> red;
   f->red_first.assign(f->ops.size() + 1, 0);
   for (size_t i = 0; i < f->ops.size(); ++i) {
@@ -553,6 +559,9 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
       w2[op.mcf_idx] = {(long)op.ws_a, (long)op.ws_c, (long)op.p_v, 1, 1, 0, 0};
       red.push_back({dbp, (long)op.p_b, 2 * op.C, 2 * op.C});
     } else if (op.type == OP_NICE) {
+      nt[0][op.nice_idx] = {(long)op.ws_g, (long)op.ws_f, (long)op.p_c1, 3, 3, 1, 1};     // conv1: saved conditioning columns x d(pre-act 1)
+      nt[1][op.nice_idx] = {(long)op.ws_a, (long)op.ws_e, (long)op.p_c2, 1, 1, 0, 0};     // conv2: h1 x d(pre-act 2)
+      nt[2][op.nice_idx] = {(long)op.ws_b, (long)op.ws_d, (long)op.p_v, 3, 3, 1, 1};      // conv3: h2 x d(raw shift / scale)
       red.push_back({dbp, (long)op.p_b, 2 * op.cout, 2 * op.cout});
     } else if (op.p_ls >= 0) {
       red.push_back({dbp, (long)op.p_ls, 2 * op.Cn, op.Cn});
@@ -562,6 +571,11 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
   drop_graphs(f);    // captured launches hold the old table addresses
   f->red_first[f->ops.size()] = (int)red.size();
   if (f->d_w1tab) { (void)hipFree(f->d_w1tab); (void)hipFree(f->d_w2tab); (void)hipFree(f->d_redtab); }
+  for (int k = 0; k < 3; ++k) {
+    if (f->d_ntab[k]) (void)hipFree(f->d_ntab[k]);
+    IPK_HIP(hipMalloc(&f->d_ntab[k], nt[k].size() * sizeof(WgEntryH)));
+    IPK_HIP(hipMemcpy(f->d_ntab[k], nt[k].data(), nt[k].size() * sizeof(WgEntryH), hipMemcpyHostToDevice));
+  }
   IPK_HIP(hipMalloc(&f->d_w1tab, w1.size() * sizeof(WgEntryH)));
   IPK_HIP(hipMalloc(&f->d_w2tab, w2.size() * sizeof(WgEntryH)));
   IPK_HIP(hipMalloc(&f->d_redtab, red.size() * sizeof(RedEntryH)));
@@ -654,6 +668,7 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   if (f->d_lujobs) (void)hipFree(f->d_lujobs);
   if (f->d_rblockjob) (void)hipFree(f->d_rblockjob);
   if (f->d_w1tab) (void)hipFree(f->d_w1tab);
+  for (int k = 0; k < 3; ++k) if (f->d_ntab[k]) (void)hipFree(f->d_ntab[k]);
   if (f->d_w2tab) (void)hipFree(f->d_w2tab);
   if (f->d_redtab) (void)hipFree(f->d_redtab);
   for (auto e : f->events) (void)hipEventDestroy(e);
@@ -1166,39 +1181,53 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   auto flush_nice = [&]() -> int {
     if (pend_nice.empty()) return IPOKE_OK;
     int rc = wgrads_wait_lanes(); if (rc) return rc;
-    for (int oi : pend_nice) {
-      const Op& op = f->ops[oi];
-        const void* h1 = c.at<void>(op.ws_a); const void* h2 = c.at<void>(op.ws_b);
-        const void* dprm = c.at<void>(op.ws_d); const void* dp2 = c.at<void>(op.ws_e); const void* dp1 = c.at<void>(op.ws_f);
-        ipoke_wgrad_desc w;
-        // cap on workgroups per weight-gradient launch (leaving CUs to the chain): measured 79.6 ms uncapped, 81.0 at 128,
-        // 88.7 at 96 -- the side stream becomes the critical path, so off by default
-        static const int tn_cap = getenv("IPOKE_TN_MAX_WGS") ? atoi(getenv("IPOKE_TN_MAX_WGS")) : 0;
-        auto base8 = [&](int k, int pad) {
-          std::memset(&w, 0, sizeof(w));
-          w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = w.kw = k;
-          w.sd = w.sh = w.sw = 1; w.ph = w.pw = pad;
-          w.max_workgroups = f->use_side ? tn_cap : 0;
-        };
-        // conv3 (effective weight; weight-norm backward runs at the end)
-        base8(3, 1);
-        w.A = h2; w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
-        w.dY = dprm; w.ldy = op.Kc3; w.Nout = 2 * op.cout;
-        w.dW = grads + op.p_v; w.w_sn = (int64_t)hid * 9; w.w_sc = 9; w.w_st = 1;
-        rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
-        // conv2
-        base8(1, 0);
-        w.A = h1; w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
-        w.dY = dp2; w.ldy = hid; w.Nout = hid;
-        w.dW = grads + op.p_c2; w.w_sn = hid; w.w_sc = 1; w.w_st = 0;
-        rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
-        // conv1 (input = conditioning channels of the saved state)
-        base8(3, 1);
-        w.A = c.at<void>(op.ws_g); w.a_f32 = 0; w.a_sn = 64L * op.Kc1; w.a_sh = 8L * op.Kc1; w.a_sw = op.Kc1; w.a_sc = 1;
-        w.Kc_real = op.Kc1; w.Kc = op.Kc1;
-        w.dY = dp1; w.ldy = hid; w.Nout = hid;
-        w.dW = grads + op.p_c1; w.w_sn = (int64_t)op.cin * 9; w.w_sc = 9; w.w_st = 1; w.Kc_store = op.cin;
-        rc = ipoke_conv_wgrad(&w, c.dtype, wstream); if (rc) return rc;
+    // cap on workgroups per weight-gradient launch (leaving CUs to the chain): measured 79.6 ms uncapped, 81.0 at 128,
+    // 88.7 at 96 -- the side stream becomes the critical path, so off by default
+    static const int tn_cap = getenv("IPOKE_TN_MAX_WGS") ? atoi(getenv("IPOKE_TN_MAX_WGS")) : 0;
+    // The pending couplings (a pair or two pairs of one flow step: same widths) go out as three batched launches, one per
+    // convolution, blockIdx.z = coupling: conv1 (48 output tiles) and conv3 (144) are latency chains of 20 reduction
+    // stages that leave most of the chip idle when launched one coupling at a time.
+    size_t i0 = 0;
+    while (i0 < pend_nice.size()) {
+      const Op& op = f->ops[pend_nice[i0]];
+      size_t i1 = i0 + 1;                                   // pend_nice is in backward order: nice_idx descends by one
+      while (i1 < pend_nice.size()) {
+        const Op& o2 = f->ops[pend_nice[i1]];
+        if (o2.nice_idx != f->ops[pend_nice[i1 - 1]].nice_idx - 1 || o2.Kc1 != op.Kc1 || o2.cin != op.cin || o2.cout != op.cout ||
+            o2.Kc3 != op.Kc3) break;
+        ++i1;
+      }
+      const int nb = (int)(i1 - i0), lo = f->ops[pend_nice[i1 - 1]].nice_idx;
+      ipoke_wgrad_desc w;
+      auto base8 = [&](int k, int pad) {
+        std::memset(&w, 0, sizeof(w));
+        w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = w.kw = k;
+        w.sd = w.sh = w.sw = 1; w.ph = w.pw = pad;
+        w.max_workgroups = f->use_side ? tn_cap : 0;
+      };
+      auto entries = [&](int k) {
+        return reinterpret_cast<const unsigned char*>(f->d_ntab[k]) + (size_t)lo * ipoke_wgrad_batch_entry_size();
+      };
+      // conv3 (effective weight; weight-norm backward runs at the end)
+      base8(3, 1);
+      w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
+      w.ldy = op.Kc3; w.Nout = 2 * op.cout;
+      w.w_sn = (int64_t)hid * 9; w.w_sc = 9; w.w_st = 1;
+      rc = ipoke_conv_wgrad_batched(&w, entries(2), nb, c.ws, c.ws, grads, c.dtype, wstream); if (rc) return rc;
+      // conv2
+      base8(1, 0);
+      w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
+      w.ldy = hid; w.Nout = hid;
+      w.w_sn = hid; w.w_sc = 1; w.w_st = 0;
+      rc = ipoke_conv_wgrad_batched(&w, entries(1), nb, c.ws, c.ws, grads, c.dtype, wstream); if (rc) return rc;
+      // conv1 (input = conditioning channels of the saved state)
+      base8(3, 1);
+      w.a_f32 = 0; w.a_sn = 64L * op.Kc1; w.a_sh = 8L * op.Kc1; w.a_sw = op.Kc1; w.a_sc = 1;
+      w.Kc_real = op.Kc1; w.Kc = op.Kc1;
+      w.ldy = hid; w.Nout = hid;
+      w.w_sn = (int64_t)op.cin * 9; w.w_sc = 9; w.w_st = 1; w.Kc_store = op.cin;
+      rc = ipoke_conv_wgrad_batched(&w, entries(0), nb, c.ws, c.ws, grads, c.dtype, wstream); if (rc) return rc;
+      i0 = i1;
     }
     pend_nice.clear();
     return IPOKE_OK;

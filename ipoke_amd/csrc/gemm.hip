@@ -1692,6 +1692,7 @@ extern "C" int ipoke_conv_wgrad_batched(const ipoke_wgrad_desc* d, const void* e
   p.a_base = reinterpret_cast<const unsigned char*>(a_base); p.y_base = reinterpret_cast<const unsigned char*>(y_base);
   p.w_base = w_base;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TimedScope ts(p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 ? IPOKE_TAG_TN_SQUARE : 0, s, nbatch);
   return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s, nbatch) : launch_tn<float>(p, s, nbatch);
 }
 
