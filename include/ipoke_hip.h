@@ -429,6 +429,32 @@ int ipoke_gru_update_bwd(const void* o_pre, const void* u, const void* h, int ld
                          void* d_u, void* d_h, int ld_dh, int64_t M, int Ch, int dtype, void* stream);
 int ipoke_gru_gates_bwd(const void* ur_pre, const void* h, int ldh, const void* d_hr, int ld_dhr, const void* d_u, void* d_ur_pre,
                         void* d_h, int ld_dh, int64_t M, int Ch, int dtype, void* stream);
+/* ---- first-stage training helpers (vae_train.hip) ------------------------------------------------------------------
+ * Conv weight in PyTorch layout (fp32 [cout][cin][taps], or ConvTranspose storage [cin][cout][taps] with transposed = 1) ->
+ * the [cout][taps*kc] operand of the compute dtype that ipoke_conv_forward reads, scaled by *inv_scale (device, may be NULL:
+ * 1/sigma of spectral norm).  Replaces the reshape/permute/pad/cast chain of nn.Conv2d's weight on every call. */
+int ipoke_conv_weight_operand(const float* w, int cout, int cin, int taps, int transposed, const float* inv_scale, void* out, int kc,
+                              int dtype, void* stream);
+/* torch.nn.utils.spectral_norm (reference: models/modules/autoencoders/util.py:52,252): one power iteration
+ * v = normalize(W^T u), u = normalize(W v) (iterate != 0; u, v updated in place, eps as in F.normalize) and
+ * sigma = u^T W v with W = weight.reshape(cout, -1) (weight.transpose(0,1).reshape(cout, -1) when transposed).
+ * out = {sigma, 1/sigma}; snapshot (optional, cout + cin*taps floats) receives the u | v sigma was computed with.
+ * workspace: ipoke_spectral_workspace_floats() floats, zeroed once by the caller. */
+long ipoke_spectral_workspace_floats(int cout, int cin, int taps);
+int ipoke_spectral_sigma(const float* w, int cout, int cin, int taps, int transposed, float* u, float* v, int iterate, float eps,
+                         float* out, float* snapshot, float* workspace, void* stream);
+/* in place: gradient w.r.t. w_orig / sigma -> gradient w.r.t. w_orig:  (G - <G, W/sigma> u v^T) / sigma.
+ * workspace: 2 floats, zeroed once by the caller. */
+int ipoke_spectral_bwd(const float* w, int cout, int cin, int taps, int transposed, float* grad, const float* snapshot,
+                       const float* sig, float* workspace, void* stream);
+/* torch.optim.Adam (amsgrad off, coupled weight decay; reference first_stage_motion_model.py:283-300) over `count` tensors;
+ * p/g/m/v/n are HOST arrays of device pointers / element counts (passed to the kernel by value, 48 tensors per launch). */
+int ipoke_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, int count, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* KL(q || N(0, I)) as in utils/losses.py:47-48: loss[0] += -0.5 * mean over positions of sum_c (1 + lv - mu^2 - exp(lv));
+ * dmu / dlv receive its gradient.  fp32 [positions * Z], any common element order. */
+int ipoke_kl_loss(const float* mu, const float* lv, int64_t positions, int Z, float* loss, float* dmu, float* dlv, void* stream);
+
 /* reparameterize backward: dmulv = [dz + dmu | dz*eps*exp(lv/2)/2 + dlv]  (any of dz/dmu/dlv may be NULL) */
 int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, const float* dz, const float* dmu, const float* dlv, void* dmulv,
                       int ldo, int64_t M, int Z, int dtype, void* stream);

@@ -145,6 +145,13 @@ SIGNATURES = {
     "ipoke_colsum": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, c_int, _P, c_int, _P]),
     "ipoke_gru_update_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_gru_gates_bwd": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
+    "ipoke_conv_weight_operand": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
+    "ipoke_spectral_workspace_floats": (ctypes.c_long, [c_int, c_int, c_int]),
+    "ipoke_spectral_sigma": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, ctypes.c_float, _P, _P, _P, _P]),
+    "ipoke_spectral_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "ipoke_adam_multi": (c_int, [_P, _P, _P, _P, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                 ctypes.c_float, c_int, ctypes.c_float, _P]),
+    "ipoke_kl_loss": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P]),
     "ipoke_relayout_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),

@@ -1,0 +1,247 @@
+// First-stage (video VAE) training helpers that used to be PyTorch glue around the convolution kernels:
+//   * conv weight (PyTorch layout, fp32) -> matrix-core operand [Cout][taps*Kc] of the compute dtype, optionally scaled by a
+//     device-resident 1/sigma (spectral norm), in one launch;
+//   * spectral normalisation: one power iteration + sigma = u^T W v (torch.nn.utils.spectral_norm semantics, used by every
+//     decoder convolution: reference models/modules/autoencoders/util.py:52,252 via first_stage_motion_model.py:263-276) and
+//     the backward of w_eff = w_orig / sigma;
+//   * multi-tensor Adam (torch.optim.Adam semantics, coupled weight decay; first_stage_motion_model.py:283-300);
+//   * KL(q || N(0,1)) value and gradient in one pass (utils/losses.py:47-48).
+// All of it is HBM-bound streaming work: every weight element is read once per pass (twice per power iteration).
+#include "common.h"
+
+namespace ipoke {
+
+// ---------------------------------------------------------------------------------------------- weight operand
+// w: [cout][cin][taps] (transposed = 0) or [cin][cout][taps] (transposed = 1: ConvTranspose storage, read as a conv weight)
+template <typename T>
+__global__ void conv_weight_operand_kernel(const float* __restrict__ w, int cout, int cin, int taps, int transposed,
+                                           const float* __restrict__ inv_scale, T* __restrict__ out, int kc) {
+  const long total = (long)cout * taps * kc;
+  const float s = inv_scale ? *inv_scale : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % kc); const long r = i / kc;
+    const int t = (int)(r % taps), o = (int)(r / taps);
+    float v = 0.f;
+    if (c < cin) v = s * (transposed ? w[((long)c * cout + o) * taps + t] : w[((long)o * cin + c) * taps + t]);
+    out[i] = ET<T>::from_f32(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- spectral norm
+// The weight matrix W [R][C] is a strided view of the conv weight: element (r, c = c1 * n2 + c2) at r*s_r + c1*s_1 + c2.
+struct SnView { const float* w; int R, C, n2; long s_r, s_1; };
+__device__ __forceinline__ float sn_at(const SnView& V, int r, int c) {
+  const int c1 = c / V.n2, c2 = c - c1 * V.n2;
+  return V.w[(long)r * V.s_r + (long)c1 * V.s_1 + c2];
+}
+// tv[c] = sum_r W[r][c] u[r];  acc[0] += sum_c tv[c]^2
+__global__ __launch_bounds__(256) void sn_cols_kernel(SnView V, const float* __restrict__ u, float* __restrict__ tv, float* __restrict__ acc) {
+  __shared__ float red[4];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f;
+  if (c < V.C) {
+    const int c1 = c / V.n2, c2 = c - c1 * V.n2;
+    const float* col = V.w + (long)c1 * V.s_1 + c2;
+    for (int r = 0; r < V.R; ++r) s = fmaf(col[(long)r * V.s_r], u[r], s);
+    tv[c] = s;
+  }
+  const float sq = block_sum(s * s, red);
+  if (threadIdx.x == 0) atomicAdd(acc, sq);
+}
+// one wave per row: tu[r] = sum_c W[r][c] vhat[c], vhat = iterate ? tv / max(||tv||, eps) : v;  acc[1] += tu[r]^2
+// (iterate: block 0 also stores vhat into v)
+__global__ __launch_bounds__(256) void sn_rows_kernel(SnView V, const float* __restrict__ tv, float* __restrict__ v, float* __restrict__ tu,
+                                                      float* __restrict__ acc, int iterate, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv = iterate ? 1.f / fmaxf(sqrtf(acc[0]), eps) : 1.f;
+  const float* src = iterate ? tv : v;
+  const int r = blockIdx.x * 4 + wave;
+  if (r < V.R) {
+    float s = 0.f;
+    for (int c = lane; c < V.C; c += 64) s = fmaf(sn_at(V, r, c), src[c] * inv, s);
+    s = wave_sum(s);
+    if (lane == 0) { tu[r] = s; atomicAdd(acc + 1, s * s); }
+  }
+  if (iterate && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < V.C; c += 256) v[c] = tv[c] * inv;
+}
+// u = iterate ? tu / max(||tu||, eps) : u;  sigma = sum_r u[r] tu[r];  out = {sigma, 1/sigma};  snapshot = [u | v];  acc reset
+__global__ __launch_bounds__(256) void sn_final_kernel(int R, int C, float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ tu,
+                                                       float* __restrict__ acc, float* __restrict__ out, float* __restrict__ snap, int iterate,
+                                                       float eps) {
+  __shared__ float red[4];
+  const float inv = iterate ? 1.f / fmaxf(sqrtf(acc[1]), eps) : 1.f;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float ur = iterate ? tu[r] * inv : u[r];
+    if (iterate) u[r] = ur;
+    if (snap) snap[r] = ur;
+    s = fmaf(ur, tu[r], s);
+  }
+  if (snap) for (int c = threadIdx.x; c < C; c += 256) snap[R + c] = v[c];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; acc[0] = 0.f; acc[1] = 0.f; }
+}
+// backward of w_eff = w / sigma with sigma = u^T W v (u, v constants):  dW = (G - <G, W_eff> u v^T) / sigma
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(SnView V, const float* __restrict__ g, float* __restrict__ acc) {
+  __shared__ float red[4];
+  const long total = (long)V.R * V.C;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / V.C), c = (int)(i - (long)r * V.C);
+    const int c1 = c / V.n2, c2 = c - c1 * V.n2;
+    const long off = (long)r * V.s_r + (long)c1 * V.s_1 + c2;
+    s = fmaf(g[off], V.w[off], s);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(SnView V, float* __restrict__ g, const float* __restrict__ snap, const float* __restrict__ sig,
+                                                           float* __restrict__ acc, unsigned* __restrict__ done) {
+  const long total = (long)V.R * V.C;
+  const float inv = sig[1], dot = acc[0] * inv;          // <G, W/sigma>
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / V.C), c = (int)(i - (long)r * V.C);
+    const int c1 = c / V.n2, c2 = c - c1 * V.n2;
+    const long off = (long)r * V.s_r + (long)c1 * V.s_1 + c2;
+    g[off] = (g[off] - dot * snap[r] * snap[V.R + c]) * inv;
+  }
+  // the last block to finish clears the accumulator for the next call
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(done, 1u) == gridDim.x - 1) { acc[0] = 0.f; *done = 0u; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- multi-tensor Adam
+constexpr int kAdamMax = 48;
+struct AdamPack { float* p[kAdamMax]; const float* g[kAdamMax]; float* m[kAdamMax]; float* v[kAdamMax]; long n[kAdamMax]; };
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamPack P, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                         float bc2_sqrt, float grad_scale) {
+  const int t = blockIdx.y;
+  float* __restrict__ p = P.p[t]; const float* __restrict__ g = P.g[t]; float* __restrict__ m = P.m[t]; float* __restrict__ v = P.v[t];
+  const long n = P.n[t];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gr = g[i] * grad_scale + wd * p[i];
+    const float mm = beta1 * m[i] + (1.f - beta1) * gr;
+    const float vv = beta2 * v[i] + (1.f - beta2) * gr * gr;
+    m[i] = mm; v[i] = vv;
+    p[i] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- KL
+// kl = -0.5/Mpos * sum_{m,c} (1 + lv - mu^2 - exp(lv));  dmu = mu / Mpos, dlv = 0.5 (exp(lv) - 1) / Mpos   (times `scale`)
+__global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ mu, const float* __restrict__ lv, long n, float inv_m,
+                                                      float* __restrict__ loss, float* __restrict__ dmu, float* __restrict__ dlv) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float a = mu[i], b = lv[i], e = expf(b);
+    s += 1.f + b - a * a - e;
+    dmu[i] = a * inv_m;
+    dlv[i] = 0.5f * (e - 1.f) * inv_m;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(loss, -0.5f * inv_m * s);
+}
+
+static int grid1(long n, int cap = 2048) { long g = (n + 255) / 256; if (g < 1) g = 1; if (g > cap) g = cap; return (int)g; }
+
+}  // namespace ipoke
+
+using namespace ipoke;
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int ipoke_conv_weight_operand(const float* w, int cout, int cin, int taps, int transposed, const float* inv_scale, void* out,
+                                         int kc, int dtype, void* stream) {
+  IPK_REQUIRE(w && out && cout >= 1 && cin >= 1 && taps >= 1 && kc >= cin, "bad arguments");
+  IPK_REQUIRE(dtype == IPOKE_F32 || dtype == IPOKE_BF16, "bad dtype");
+  const long total = (long)cout * taps * kc;
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(conv_weight_operand_kernel<bf16_t>, dim3(grid1(total)), dim3(256), 0, STREAM(stream), w, cout, cin, taps, transposed,
+                       inv_scale, reinterpret_cast<bf16_t*>(out), kc);
+  else
+    hipLaunchKernelGGL(conv_weight_operand_kernel<float>, dim3(grid1(total)), dim3(256), 0, STREAM(stream), w, cout, cin, taps, transposed,
+                       inv_scale, reinterpret_cast<float*>(out), kc);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+static SnView sn_view(const float* w, int cout, int cin, int taps, int transposed) {
+  // W = weight.reshape(cout, -1), or weight.transpose(0, 1).reshape(cout, -1) for ConvTranspose storage [cin][cout][taps]
+  SnView V; V.w = w; V.R = cout; V.C = cin * taps; V.n2 = taps;
+  if (!transposed) { V.s_r = (long)cin * taps; V.s_1 = taps; }
+  else { V.s_r = taps; V.s_1 = (long)cout * taps; }
+  return V;
+}
+
+extern "C" long ipoke_spectral_workspace_floats(int cout, int cin, int taps) { return (long)cout + (long)cin * taps + 4; }
+
+/* One power iteration (iterate != 0; u, v updated in place) and sigma = u^T W v; out = {sigma, 1/sigma}; snapshot (optional,
+ * cout + cin*taps floats) receives the u | v that sigma was computed with (what the backward needs).  workspace:
+ * ipoke_spectral_workspace_floats floats, zero-initialised once by the caller (the kernels leave its accumulators at zero). */
+extern "C" int ipoke_spectral_sigma(const float* w, int cout, int cin, int taps, int transposed, float* u, float* v, int iterate, float eps,
+                                    float* out, float* snapshot, float* workspace, void* stream) {
+  IPK_REQUIRE(w && u && v && out && workspace && cout >= 1 && cin >= 1 && taps >= 1, "bad arguments");
+  const SnView V = sn_view(w, cout, cin, taps, transposed);
+  float* acc = workspace; float* tu = workspace + 4; float* tv = tu + cout;
+  if (iterate) {
+    hipLaunchKernelGGL(sn_cols_kernel, dim3((V.C + 255) / 256), dim3(256), 0, STREAM(stream), V, u, tv, acc);
+    IPK_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(sn_rows_kernel, dim3((V.R + 3) / 4), dim3(256), 0, STREAM(stream), V, tv, v, tu, acc, iterate, eps);
+  IPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sn_final_kernel, dim3(1), dim3(256), 0, STREAM(stream), V.R, V.C, u, v, tu, acc, out, snapshot, iterate, eps);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* In place: grad (gradient w.r.t. w_orig / sigma, PyTorch weight layout) -> gradient w.r.t. w_orig.  snapshot / sig: as written by
+ * ipoke_spectral_sigma for the forward call; workspace: 2 zero-initialised floats (accumulator, block counter). */
+extern "C" int ipoke_spectral_bwd(const float* w, int cout, int cin, int taps, int transposed, float* grad, const float* snapshot,
+                                  const float* sig, float* workspace, void* stream) {
+  IPK_REQUIRE(w && grad && snapshot && sig && workspace, "bad arguments");
+  const SnView V = sn_view(w, cout, cin, taps, transposed);
+  const long total = (long)V.R * V.C;
+  const int g = grid1(total, 512);
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(g), dim3(256), 0, STREAM(stream), V, grad, workspace);
+  IPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(g), dim3(256), 0, STREAM(stream), V, grad, snapshot, sig, workspace,
+                     reinterpret_cast<unsigned*>(workspace + 1));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* torch.optim.Adam (no amsgrad, coupled weight decay) over `count` tensors given as host arrays of device pointers. */
+extern "C" int ipoke_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, int count,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  IPK_REQUIRE(p && g && m && v && n && count >= 1 && step >= 1, "bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  for (int t0 = 0; t0 < count; t0 += kAdamMax) {
+    const int k = count - t0 < kAdamMax ? count - t0 : kAdamMax;
+    AdamPack P;
+    long nmax = 1;
+    for (int i = 0; i < kAdamMax; ++i) {
+      const int j = i < k ? t0 + i : t0;
+      P.p[i] = p[j]; P.g[i] = g[j]; P.m[i] = m[j]; P.v[i] = v[j]; P.n[i] = i < k ? (long)n[j] : 0;
+      IPK_REQUIRE(i >= k || (p[j] && g[j] && m[j] && v[j]), "null tensor");
+      if (i < k && n[j] > nmax) nmax = (long)n[j];
+    }
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(grid1(nmax, 256), k), dim3(256), 0, STREAM(stream), P, lr, beta1, beta2, eps, weight_decay, bc1,
+                       bc2s, grad_scale);
+    IPK_LAUNCH_CHECK();
+  }
+  return IPOKE_OK;
+}
+
+/* loss[0] += -0.5 * mean_over_positions(sum_c(1 + lv - mu^2 - exp(lv))); dmu / dlv receive d kl / d mu, d kl / d lv.
+ * mu, lv, dmu, dlv: fp32 [positions * Z] in any (identical) element order. */
+extern "C" int ipoke_kl_loss(const float* mu, const float* lv, int64_t positions, int Z, float* loss, float* dmu, float* dlv, void* stream) {
+  IPK_REQUIRE(mu && lv && loss && dmu && dlv && positions >= 1 && Z >= 1, "bad arguments");
+  const long n = (long)positions * Z;
+  hipLaunchKernelGGL(kl_loss_kernel, dim3(grid1(n, 256)), dim3(256), 0, STREAM(stream), mu, lv, n, 1.f / (float)positions, loss, dmu, dlv);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}

@@ -14,15 +14,18 @@ libipoke_hip on channels-last activations --
     reparameterize       ipoke_reparameterize | ipoke_reparam_bwd
     tanh + L1            ipoke_l1_loss (value and gradient in one pass)
 
-PyTorch autograd only records the graph and carries the weight-side algebra (spectral-norm division
-``W / sigma`` with its gradient through sigma, the KL term on the [B, z, 8, 8] latents): plumbing on parameter-sized
-tensors.  In train mode every spectral-normalised conv runs one power iteration per forward *call*, i.e. T-1 times
-per step for the decoder (util.py:52, 252) -- kept, which is why the decoder is evaluated frame by frame.
+    spectral norm        ipoke_spectral_sigma (power iteration + sigma) | ipoke_spectral_bwd; 1/sigma is folded into
+                         ipoke_conv_weight_operand (fp32 PyTorch-layout weight -> matrix-core operand, one launch)
+    KL                   ipoke_kl_loss (value and gradient in one pass)
+    Adam                 ipoke_adam_multi (multi-tensor, torch.optim.Adam semantics)
+
+PyTorch autograd only records the graph.  In train mode every spectral-normalised conv runs one power iteration per
+forward *call*, i.e. T-1 times per step for the decoder (util.py:52, 252) -- kept, which is why the decoder is
+evaluated frame by frame.
 """
 from ctypes import byref
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib, nn as K, ops
 from . import first_stage as FS
@@ -52,6 +55,30 @@ def _pad_cols(t, ld, dtype):
     return out
 
 
+def _weight_operand(w, dtype, transposed_conv, inv_scale=None):
+    """fp32 conv weight in PyTorch layout -> ([rows][taps*kc] operand of the compute dtype, kc); ``transposed_conv`` reads
+    ConvTranspose storage [in][out][k] as the conv weight [out][in][k]; ``inv_scale``: device scalar (1/sigma)."""
+    w = w.contiguous()
+    taps = 1
+    for k in w.shape[2:]:
+        taps *= int(k)
+    rows, cols = (w.shape[1], w.shape[0]) if transposed_conv else (w.shape[0], w.shape[1])
+    kc = K.round_up(cols, K.e16(dtype))
+    out = torch.empty(rows, taps * kc, dtype=_tdt(dtype), device=w.device)
+    check(_lib.lib().ipoke_conv_weight_operand(ptr(w), rows, cols, taps, int(bool(transposed_conv)),
+                                               None if inv_scale is None else ptr(inv_scale), ptr(out), kc, ops._dt(dtype),
+                                               _lib.current_stream()))
+    return out, kc
+
+
+class _SnWeight:
+    """A spectral-normalised weight as the convolution consumes it: ``weight_orig`` plus the device-side {sigma, 1/sigma}
+    and the u | v snapshot of this call (the buffers themselves move on with every later power iteration)."""
+
+    def __init__(self, w_orig, sig, snap, transposed, mod):
+        self.w_orig, self.sig, self.snap, self.transposed, self.mod = w_orig, sig, snap, transposed, mod
+
+
 # ------------------------------------------------------------------------------------------------ convolution
 class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, w) + bias).  ``x`` is the CL tensor [M, ld] (or None with ``meta['src']`` an fp32 image)."""
@@ -59,8 +86,8 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_t, w, bias, meta):
         dt = meta["dtype"]
-        w5 = w.detach().unsqueeze(2) if w.dim() == 4 else w.detach()
-        wop, kc = K.weight_operand(w5, dt, meta["transposed"])
+        sn = meta.get("sn")                       # (sig, snap): w is weight_orig, the operand carries 1/sigma
+        wop, kc = _weight_operand(w.detach(), dt, meta["transposed"], None if sn is None else sn[0][1:])
         b = None if bias is None else bias.detach().float().contiguous()
         src = meta.get("src")
         x = None if src is not None else K.CL(x_t, meta["N"], meta["dhw"], meta["cin"])
@@ -149,18 +176,26 @@ class _ConvFn(torch.autograd.Function):
         else:
             wd.dW = d_w.data_ptr()
             check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+        sn = m.get("sn")
+        if sn is not None:                        # d_w is the gradient w.r.t. weight_orig / sigma: fold sigma's own gradient in
+            sig, snap, bws = sn
+            t_w = 1
+            for kk in w.shape[2:]:
+                t_w *= int(kk)
+            r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
+            check(lib.ipoke_spectral_bwd(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snap), ptr(sig), ptr(bws), s))
         # ---- data gradient: the adjoint convolution with the same weights
         d_x = None
         if x_t is not None and ctx.needs_input_grad[0]:
-            w5 = w.detach().unsqueeze(2) if w.dim() == 4 else w.detach()
+            inv = None if sn is None else sn[0][1:]
             gcl = K.CL(g, N, odhw, cout)
             if not m["transposed"]:
                 # conv weight [cout, cin, k] read as a ConvTranspose weight [in=cout, out=cin, k]
-                wop, kc = K.weight_operand(w5, dt, transposed_conv=True)
+                wop, kc = _weight_operand(w.detach(), dt, True, inv)
                 opad = tuple(i - ((o - 1) * s_ - 2 * p + kk) for i, o, s_, p, kk in zip(idhw, odhw, st, pd, k))
                 dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt, transposed=True, out_pad=opad)
             else:
-                wop, kc = K.weight_operand(w5, dt, transposed_conv=False)     # [in, out, k] read as conv weight [cout'=in]
+                wop, kc = _weight_operand(w.detach(), dt, False, inv)         # [in, out, k] read as conv weight [cout'=in]
                 dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt)
             assert dx.dhw == tuple(idhw), (dx.dhw, idhw)
             d_x = dx.t
@@ -176,24 +211,37 @@ def conv(mod, x, dtype, act=_lib.ACT_NONE, out_f32=False, src=None, w=None):
     N, dhw, cin = (src[1], src[3], src[2]) if src is not None else (x.N, x.dhw, x.C)
     meta = dict(N=N, dhw=tuple(dhw), cin=cin, cout=mod.cout, k=mod.k, stride=mod.stride, pad=mod.pad, transposed=mod.transposed,
                 out_pad=(0, mod.pad[1], mod.pad[2]) if mod.transposed else (0, 0, 0), dtype=dtype, act=act, out_f32=out_f32, src=src)
+    if isinstance(w, _SnWeight):
+        bws = getattr(w.mod, "_sn_bwd_ws", None)
+        if bws is None or bws.device != w.w_orig.device:
+            bws = w.mod._sn_bwd_ws = torch.zeros(2, dtype=torch.float32, device=w.w_orig.device)
+        meta["sn"] = (w.sig, w.snap, bws)
+        w = w.w_orig
     y = _ConvFn.apply(None if src is not None else x.t, w, mod.bias, meta)
     return K.CL(y, N, meta["odhw"], mod.cout)
 
 
 def effective_weight(mod, power_iteration=False):
-    """Conv weight as an autograd tensor: plain ``weight`` or ``weight_orig / sigma`` (torch spectral_norm semantics:
-    u, v are buffers updated without grad by one power iteration per call in train mode; sigma = u^T W v carries grad)."""
+    """The conv weight as ``conv`` takes it: the plain ``weight`` parameter, or for spectral norm a ``_SnWeight`` --
+    torch spectral_norm semantics: u, v are buffers updated without grad by one power iteration per call in train mode;
+    sigma = u^T W v carries grad (ipoke_spectral_sigma / ipoke_spectral_bwd), the division by sigma happens while the
+    matrix-core operand is written."""
     if not mod.snorm:
         return mod.weight
     w = mod.weight_orig
-    wm = (w.transpose(0, 1) if mod.transposed else w).reshape(mod.cout, -1)
-    if power_iteration:
-        with torch.no_grad():
-            mod.weight_v.copy_(F.normalize(torch.mv(wm.t(), mod.weight_u), dim=0, eps=1e-12))
-            mod.weight_u.copy_(F.normalize(torch.mv(wm, mod.weight_v), dim=0, eps=1e-12))
-    u, v = mod.weight_u.clone(), mod.weight_v.clone()
-    sigma = torch.dot(u, torch.mv(wm, v))
-    return w / sigma
+    taps = 1
+    for k in w.shape[2:]:
+        taps *= int(k)
+    rows, cols = (w.shape[1], w.shape[0]) if mod.transposed else (w.shape[0], w.shape[1])
+    lib = _lib.lib()
+    ws = getattr(mod, "_sn_ws", None)
+    if ws is None or ws.device != w.device:
+        ws = mod._sn_ws = torch.zeros(int(lib.ipoke_spectral_workspace_floats(rows, cols, taps)), dtype=torch.float32, device=w.device)
+    sig = torch.empty(2, dtype=torch.float32, device=w.device)
+    snap = torch.empty(rows + cols * taps, dtype=torch.float32, device=w.device)
+    check(lib.ipoke_spectral_sigma(ptr(w), rows, cols, taps, int(mod.transposed), ptr(mod.weight_u), ptr(mod.weight_v),
+                                   int(bool(power_iteration)), 1e-12, ptr(sig), ptr(snap), ptr(ws), _lib.current_stream()))
+    return _SnWeight(w, sig, snap, mod.transposed, mod)
 
 
 # ------------------------------------------------------------------------------------------------ norms
@@ -398,6 +446,24 @@ class _ReparamFn(torch.autograd.Function):
         return out, None, None, None
 
 
+class _KLFn(torch.autograd.Function):
+    """-0.5 * mean_{b,h,w} sum_c (1 + lv - mu^2 - exp(lv))  (utils/losses.py:47-48) on the [M, Z] latents."""
+
+    @staticmethod
+    def forward(ctx, mu, lv):
+        mu, lv = mu.contiguous(), lv.contiguous()
+        loss = torch.zeros(1, device=mu.device)
+        dmu = torch.empty_like(mu); dlv = torch.empty_like(lv)
+        check(_lib.lib().ipoke_kl_loss(ptr(mu), ptr(lv), mu.shape[0], mu.shape[1], ptr(loss), ptr(dmu), ptr(dlv), _lib.current_stream()))
+        ctx.save_for_backward(dmu, dlv)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, d):
+        dmu, dlv = ctx.saved_tensors
+        return dmu * d, dlv * d
+
+
 class _L1TanhFn(torch.autograd.Function):
     """frame = tanh(pre) ; returns (sum_scale |frame - x|, frame) with d/dpre produced in the same pass."""
 
@@ -533,7 +599,7 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
         frames.append(frame.view(B, pre.dhw[1], pre.dhw[2], 3).permute(0, 3, 1, 2))
     mu4 = mu.view(B, dhw[1], dhw[2], Z).permute(0, 3, 1, 2)
     lv4 = lv.view(B, dhw[1], dhw[2], Z).permute(0, 3, 1, 2)
-    kl = -0.5 * torch.mean(torch.sum(1 + lv4 - mu4.pow(2) - lv4.exp(), dim=1))          # utils/losses.py:47-48
+    kl = _KLFn.apply(mu, lv)                                                             # utils/losses.py:47-48
     loss = w_l1 * l1 + w_kl * kl
     return loss, torch.stack(frames, dim=1), mu4, lv4
 
@@ -542,10 +608,32 @@ class FirstStageTrainer:
     """Minimal training harness of c4: ``step(X)`` = forward, L1 + KL loss, backward, Adam step (the reference's
     first-stage optimiser is ``Adam(lr, betas=(0.5, 0.9))`` over encoder + GRU + decoder, first_stage_motion_model.py:283-300)."""
 
-    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5):
+    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8):
+        import ctypes
         self.model = model
-        self.opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr, betas=betas, weight_decay=weight_decay)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.lr, self.betas, self.weight_decay, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(weight_decay), float(eps)
+        self.exp_avg = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.steps = 0
+        self._ct = ctypes
         self.grad_hook = None           # data parallel: all-reduce of the gradients between backward and the update
+
+    def _adam(self):
+        """torch.optim.Adam(lr, betas, weight_decay) over every parameter that received a gradient: one multi-tensor launch
+        per 48 tensors (ipoke_adam_multi)."""
+        ct = self._ct
+        idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if not idx:
+            return
+        self.steps += 1
+        n = len(idx)
+        grads = [self.params[i].grad.contiguous() for i in idx]
+        arr = lambda ts: (ct.c_void_p * n)(*[t.data_ptr() for t in ts])
+        sizes = (ct.c_int64 * n)(*[self.params[i].numel() for i in idx])
+        check(_lib.lib().ipoke_adam_multi(arr([self.params[i].data for i in idx]), arr(grads), arr([self.exp_avg[i] for i in idx]),
+                                          arr([self.exp_avg_sq[i] for i in idx]), sizes, n, self.lr, self.betas[0], self.betas[1],
+                                          self.eps, self.weight_decay, self.steps, 1.0, _lib.current_stream()))
 
     def step(self, X, eps=None):
         m = self.model
@@ -554,11 +642,12 @@ class FirstStageTrainer:
             Z = m.enc_motion.z_dim
             s = m.enc_motion.min_ssize
             eps = torch.FloatTensor(X.shape[0], Z, s, s).normal_().to(X.device)      # CPU generator, motion_encoder.py:220
-        self.opt.zero_grad(set_to_none=True)
+        for p in self.params:
+            p.grad = None
         loss, X_hat, mu, lv = first_stage_forward_loss(m, X, eps)
         loss.backward()
         if self.grad_hook is not None:
             self.grad_hook()
-        self.opt.step()
+        self._adam()
         m.invalidate_operands()
         return loss.detach(), X_hat.detach()
