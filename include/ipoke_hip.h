@@ -455,6 +455,15 @@ int ipoke_adam_multi(float* const* p, const float* const* g, float* const* m, fl
  * dmu / dlv receive its gradient.  fp32 [positions * Z], any common element order. */
 int ipoke_kl_loss(const float* mu, const float* lv, int64_t positions, int Z, float* loss, float* dmu, float* dlv, void* stream);
 
+/* Pooling of the first-stage temporal discriminator on channels-last rows (reference patchgan_3d.py:202 MaxPool3d(3, (1,2,2), 1)
+ * and :209 AvgPool3d((1, s, s))).  dims = {N, C, Di, Hi, Wi, Do, Ho, Wo, kd, kh, kw, sd, sh, sw, pd, ph, pw}; idx int32
+ * [out rows][C] keeps the chosen input row (first maximum in d, h, w scan order, as torch) for the backward pass, which is
+ * a gather (no atomics).  avgpool_rows: mean over the S consecutive rows of each of G groups. */
+int ipoke_maxpool3d_fwd(const int* dims, const void* x, int ldx, void* y, int ldy, int* idx, int dtype, void* stream);
+int ipoke_maxpool3d_bwd(const int* dims, const void* dy, int ldy, const int* idx, void* dx, int ldx, int dtype, void* stream);
+int ipoke_avgpool_rows(const void* x, int ldx, void* y, int ldy, int64_t G, int S, int C, int dtype, void* stream);
+int ipoke_avgpool_rows_bwd(const void* dy, int ldy, void* dx, int ldx, int64_t G, int S, int C, int dtype, void* stream);
+
 /* reparameterize backward: dmulv = [dz + dmu | dz*eps*exp(lv/2)/2 + dlv]  (any of dz/dmu/dlv may be NULL) */
 int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, const float* dz, const float* dmu, const float* dlv, void* dmulv,
                       int ldo, int64_t M, int Z, int dtype, void* stream);

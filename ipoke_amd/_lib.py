@@ -151,6 +151,10 @@ SIGNATURES = {
     "ipoke_spectral_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "ipoke_adam_multi": (c_int, [_P, _P, _P, _P, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, c_int, ctypes.c_float, _P]),
+    "ipoke_maxpool3d_fwd": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P]),
+    "ipoke_maxpool3d_bwd": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P]),
+    "ipoke_avgpool_rows": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, _P]),
+    "ipoke_avgpool_rows_bwd": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, _P]),
     "ipoke_kl_loss": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P]),

@@ -147,6 +147,76 @@ __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) atomicAdd(loss, -0.5f * inv_m * s);
 }
 
+// ---------------------------------------------------------------------------------------------- pooling (discriminators)
+// MaxPool3d on channels-last rows (reference patchgan_3d.py:202: kernel 3, stride (1,2,2), padding 1).  The first maximum in
+// (d, h, w) scan order wins, as in torch; its input row is kept for the backward pass.
+struct PoolGeom { int N, C, Di, Hi, Wi, Do, Ho, Wo, kd, kh, kw, sd, sh, sw, pd, ph, pw; };
+template <typename T>
+__global__ void maxpool3d_fwd_kernel(PoolGeom g, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int* __restrict__ idx) {
+  const long total = (long)g.N * g.Do * g.Ho * g.Wo * g.C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % g.C); long r = i / g.C;
+    const int ow = (int)(r % g.Wo); long t = r / g.Wo;
+    const int oh = (int)(t % g.Ho); t /= g.Ho;
+    const int od = (int)(t % g.Do); const int n = (int)(t / g.Do);
+    float best = -INFINITY; int arg = -1;
+    for (int a = 0; a < g.kd; ++a) {
+      const int d = od * g.sd - g.pd + a; if ((unsigned)d >= (unsigned)g.Di) continue;
+      for (int b = 0; b < g.kh; ++b) {
+        const int h = oh * g.sh - g.ph + b; if ((unsigned)h >= (unsigned)g.Hi) continue;
+        for (int e = 0; e < g.kw; ++e) {
+          const int w = ow * g.sw - g.pw + e; if ((unsigned)w >= (unsigned)g.Wi) continue;
+          const int row = ((n * g.Di + d) * g.Hi + h) * g.Wi + w;
+          const float v = ET<T>::to_f32(x[(long)row * ldx + c]);
+          if (v > best || arg < 0) { best = v; arg = row; }
+        }
+      }
+    }
+    y[r * ldy + c] = ET<T>::from_f32(best);
+    idx[r * g.C + c] = arg;
+  }
+}
+// gather form (no atomics): an input position collects dy of every window that chose it
+template <typename T>
+__global__ void maxpool3d_bwd_kernel(PoolGeom g, const T* __restrict__ dy, int ldy, const int* __restrict__ idx, T* __restrict__ dx, int ldx) {
+  const long total = (long)g.N * g.Di * g.Hi * g.Wi * ldx;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldx); const long row = i / ldx;
+    float s = 0.f;
+    if (c < g.C) {
+      const int w = (int)(row % g.Wi); long t = row / g.Wi;
+      const int h = (int)(t % g.Hi); t /= g.Hi;
+      const int d = (int)(t % g.Di); const int n = (int)(t / g.Di);
+      for (int od = max(0, (d + g.pd - g.kd + g.sd) / g.sd); od <= min(g.Do - 1, (d + g.pd) / g.sd); ++od)
+        for (int oh = max(0, (h + g.ph - g.kh + g.sh) / g.sh); oh <= min(g.Ho - 1, (h + g.ph) / g.sh); ++oh)
+          for (int ow = max(0, (w + g.pw - g.kw + g.sw) / g.sw); ow <= min(g.Wo - 1, (w + g.pw) / g.sw); ++ow) {
+            const long o = ((long)(n * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+            if (idx[o * g.C + c] == (int)row) s += ET<T>::to_f32(dy[o * ldy + c]);
+          }
+    }
+    dx[i] = ET<T>::from_f32(s);
+  }
+}
+// mean over the S = H*W positions of each (sample, frame): x [G*S][ldx] -> y [G][ldy];  backward broadcasts dy / S
+template <typename T>
+__global__ void avgpool_rows_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, long G, int S, int C) {
+  const long total = G * ldy;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldy); const long gi = i / ldy;
+    float s = 0.f;
+    if (c < C) for (int k = 0; k < S; ++k) s += ET<T>::to_f32(x[(gi * S + k) * ldx + c]);
+    y[i] = ET<T>::from_f32(s / (float)S);
+  }
+}
+template <typename T>
+__global__ void avgpool_rows_bwd_kernel(const T* __restrict__ dy, int ldy, T* __restrict__ dx, int ldx, long G, int S, int C) {
+  const long total = G * S * ldx;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldx); const long row = i / ldx;
+    dx[i] = ET<T>::from_f32(c < C ? ET<T>::to_f32(dy[(row / S) * ldy + c]) / (float)S : 0.f);
+  }
+}
+
 static int grid1(long n, int cap = 2048) { long g = (n + 255) / 256; if (g < 1) g = 1; if (g > cap) g = cap; return (int)g; }
 
 }  // namespace ipoke
@@ -242,6 +312,58 @@ extern "C" int ipoke_kl_loss(const float* mu, const float* lv, int64_t positions
   IPK_REQUIRE(mu && lv && loss && dmu && dlv && positions >= 1 && Z >= 1, "bad arguments");
   const long n = (long)positions * Z;
   hipLaunchKernelGGL(kl_loss_kernel, dim3(grid1(n, 256)), dim3(256), 0, STREAM(stream), mu, lv, n, 1.f / (float)positions, loss, dmu, dlv);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+static int pool_geom(PoolGeom& g, const int* dims) {
+  g.N = dims[0]; g.C = dims[1]; g.Di = dims[2]; g.Hi = dims[3]; g.Wi = dims[4]; g.Do = dims[5]; g.Ho = dims[6]; g.Wo = dims[7];
+  g.kd = dims[8]; g.kh = dims[9]; g.kw = dims[10]; g.sd = dims[11]; g.sh = dims[12]; g.sw = dims[13]; g.pd = dims[14]; g.ph = dims[15]; g.pw = dims[16];
+  IPK_REQUIRE(g.N >= 1 && g.C >= 1 && g.kd >= 1 && g.kh >= 1 && g.kw >= 1 && g.sd >= 1 && g.sh >= 1 && g.sw >= 1, "bad pooling geometry");
+  IPK_REQUIRE((long)g.N * g.Di * g.Hi * g.Wi < (1L << 31), "input rows exceed int32");
+  return IPOKE_OK;
+}
+
+/* MaxPool3d on channels-last rows.  dims = {N, C, Di, Hi, Wi, Do, Ho, Wo, kd, kh, kw, sd, sh, sw, pd, ph, pw};
+ * x [N*Di*Hi*Wi][ldx], y [N*Do*Ho*Wo][ldy] of the compute dtype; idx int32 [N*Do*Ho*Wo][C] = chosen input row. */
+extern "C" int ipoke_maxpool3d_fwd(const int* dims, const void* x, int ldx, void* y, int ldy, int* idx, int dtype, void* stream) {
+  IPK_REQUIRE(dims && x && y && idx, "null argument");
+  PoolGeom g; int rc = pool_geom(g, dims); if (rc) return rc;
+  const long total = (long)g.N * g.Do * g.Ho * g.Wo * g.C;
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(maxpool3d_fwd_kernel<bf16_t>, dim3(grid1(total, 4096)), dim3(256), 0, STREAM(stream), g, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, idx);
+  else
+    hipLaunchKernelGGL(maxpool3d_fwd_kernel<float>, dim3(grid1(total, 4096)), dim3(256), 0, STREAM(stream), g, (const float*)x, ldx, (float*)y, ldy, idx);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_maxpool3d_bwd(const int* dims, const void* dy, int ldy, const int* idx, void* dx, int ldx, int dtype, void* stream) {
+  IPK_REQUIRE(dims && dy && dx && idx, "null argument");
+  PoolGeom g; int rc = pool_geom(g, dims); if (rc) return rc;
+  const long total = (long)g.N * g.Di * g.Hi * g.Wi * ldx;
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(maxpool3d_bwd_kernel<bf16_t>, dim3(grid1(total, 4096)), dim3(256), 0, STREAM(stream), g, (const bf16_t*)dy, ldy, idx, (bf16_t*)dx, ldx);
+  else
+    hipLaunchKernelGGL(maxpool3d_bwd_kernel<float>, dim3(grid1(total, 4096)), dim3(256), 0, STREAM(stream), g, (const float*)dy, ldy, idx, (float*)dx, ldx);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+/* Mean over the S consecutive rows of each of G groups (AvgPool3d((1, H, W)) on channels-last rows) and its backward. */
+extern "C" int ipoke_avgpool_rows(const void* x, int ldx, void* y, int ldy, int64_t G, int S, int C, int dtype, void* stream) {
+  IPK_REQUIRE(x && y && G >= 1 && S >= 1 && C >= 1 && ldx >= C && ldy >= C, "bad arguments");
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(avgpool_rows_kernel<bf16_t>, dim3(grid1(G * ldy)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (long)G, S, C);
+  else
+    hipLaunchKernelGGL(avgpool_rows_kernel<float>, dim3(grid1(G * ldy)), dim3(256), 0, STREAM(stream), (const float*)x, ldx, (float*)y, ldy, (long)G, S, C);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_avgpool_rows_bwd(const void* dy, int ldy, void* dx, int ldx, int64_t G, int S, int C, int dtype, void* stream) {
+  IPK_REQUIRE(dy && dx && G >= 1 && S >= 1 && C >= 1 && ldx >= C && ldy >= C, "bad arguments");
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(avgpool_rows_bwd_kernel<bf16_t>, dim3(grid1(G * S * ldx)), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, ldy, (bf16_t*)dx, ldx, (long)G, S, C);
+  else
+    hipLaunchKernelGGL(avgpool_rows_bwd_kernel<float>, dim3(grid1(G * S * ldx)), dim3(256), 0, STREAM(stream), (const float*)dy, ldy, (float*)dx, ldx, (long)G, S, C);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 from ipoke_amd import configs                                    # noqa: E402
 from ipoke_amd.utils.detfill import deterministic_fill_          # noqa: E402
-from oracle import flow_ref, ref_import, vae_ref                 # noqa: E402
+from oracle import disc_ref, flow_ref, ref_import, vae_ref       # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -645,12 +645,95 @@ def g_128():
     npz("g6_glue_128", batch_seed=3, eps=epsg, flow_input=flow_input, cond=cond)
 
 
+def g8_disc():
+    """G8: the first-stage temporal discriminator (patchgan_3d.py:171-304, config d_t of config/first_stage.yaml:65-75) at
+    64x64, 8 frames, B = 2: predictions, the four feature maps, hinge discriminator loss with every parameter gradient,
+    the generator-side loss (-mean(pred) + feature matching) with its gradient w.r.t. the fake clip, the gradient penalty
+    value, and one train-mode forward (power iteration of every spectral-normalised conv)."""
+    d3 = ref_import.ref("models.modules.discriminators.patchgan_3d")
+    cfg = {"bce_loss": False, "gp_weight": 1.0, "num_classes": 1, "patch_temp_disc": False}
+    m = d3.resnet(config=dict(cfg), spatial_size=64, sequence_length=9)
+    deterministic_fill_(m, prefix="disc_t.")
+    o = disc_ref.TemporalDiscriminator(64, dict(cfg))
+    assert set(m.state_dict()) == set(o.state_dict()), set(m.state_dict()) ^ set(o.state_dict())
+    o.load_state_dict(m.state_dict())
+    m.eval(); o.eval()
+    X_true = (torch.rand(2, 3, 8, 64, 64, generator=gen(81)) * 2 - 1)
+    X_fake = (torch.rand(2, 3, 8, 64, 64, generator=gen(82)) * 2 - 1)
+    arrs = dict(X_true=X_true, X_fake=X_fake)
+
+    def disc_side(net):
+        net.zero_grad()
+        xt = X_true.clone().requires_grad_(True)
+        pf, _ = net(X_fake)
+        pt, fm = net(xt)
+        loss = (net.loss(pf, real=False) + net.loss(pt, real=True)) / 2.0
+        gp = net.gp2(pt, xt)
+        loss.backward(retain_graph=True)
+        grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+        net.zero_grad()
+        gp.backward()
+        gp_grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        return pf, pt, fm, loss, gp, grads, gp_grads
+
+    pf, pt, fm, loss, gp, grads, gp_grads = disc_side(m)
+    pfo, pto, fmo, losso, gpo, gradso, gp_gradso = disc_side(o)
+    close(pfo, pf, 2e-5, "G8 pred fake"); close(pto, pt, 2e-5, "G8 pred true"); close(losso, loss, 1e-5, "G8 loss_d")
+    assert abs(gpo.item() - gp.item()) <= 1e-4 * abs(gp.item()), (gpo.item(), gp.item())
+    for a, b in zip(fmo, fm):
+        close(a, b, 5e-5, "G8 fmap")
+    worst = 0.0
+    for k in grads:
+        e = (grads[k] - gradso[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-8)
+        worst = max(worst, e)
+        assert e <= 2e-3, (k, e)
+    print(f"  oracle vs reference: worst relative parameter-gradient error {worst:.2e}; gp {gp.item():.6f}")
+    arrs.update(pred_fake=pf, pred_true=pt, loss_d=loss, gp=gp)
+    for i, f in enumerate(fm):
+        arrs[f"fmap{i}_checksum"] = checksum(f, f"fmap{i}")
+        arrs[f"fmap{i}_slice"] = f[:, :4, :, :3, :3]
+    names = sorted(grads)
+    arrs["grad_names"] = np.array(names)
+    arrs["grad_checksums"] = np.stack([checksum(grads[k], k) for k in names])
+    gnames = sorted(gp_grads)
+    arrs["gp_grad_names"] = np.array(gnames)
+    arrs["gp_grad_checksums"] = np.stack([checksum(gp_grads[k], "gp." + k) for k in gnames])
+
+    def gen_side(net):
+        xf = X_fake.clone().requires_grad_(True)
+        pg, ff = net(xf)
+        with torch.no_grad():
+            _, ft = net(X_true)
+        lg = -pg.mean() + net.fmap_loss(ff, ft)
+        lg.backward()
+        return lg, xf.grad
+
+    lg, dxf = gen_side(m)
+    lgo, dxfo = gen_side(o)
+    close(lgo, lg, 1e-5, "G8 generator loss")
+    assert (dxf - dxfo).abs().max().item() <= 2e-3 * dxf.abs().max().item()
+    arrs.update(loss_g=lg, dx_fake_checksum=checksum(dxf, "dx_fake"), dx_fake_slice=dxf[:, :, :2, :6, :6])
+
+    # train mode: one forward = one power iteration per spectral-normalised conv
+    m.train(); o.train()
+    with torch.no_grad():
+        ptr_, _ = m(X_true)
+        ptro, _ = o(X_true)
+    close(ptro, ptr_, 2e-5, "G8 train-mode pred")
+    arrs["pred_true_train"] = ptr_
+    for k in ("conv1", "layer2.0.downsample.0", "layer4.1.conv2"):
+        mod = m.get_submodule(k)
+        arrs[f"u1.{k}"] = mod.weight_u.clone(); arrs[f"v1_checksum.{k}"] = checksum(mod.weight_v, "v1." + k)
+        close(o.get_submodule(k).weight_u, mod.weight_u, 1e-5, "G8 u after power iteration")
+    npz("g8_temporal_disc_64", **arrs)
+
+
 def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
             "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
-            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128}
+            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc}
     for name in (which or list(jobs)):
         print(f"[{name}]")
         t = time.time()

@@ -188,3 +188,37 @@ def test_first_stage_l1_kl_training_slice(golden):
     Xh, mu, lv = m(X, eps=t(g["eps"]))
     loss = vae_ref.first_stage_loss(X, Xh, mu, lv)
     assert (Xh - t(g["X_hat"])).abs().max() <= 5e-5 and abs(loss.item() - float(g["loss"])) <= 1e-4
+
+
+def _checksum(x, key):
+    import zlib
+    x = x.detach().double().flatten().cpu()
+    idx = torch.randint(0, x.numel(), (3,), generator=torch.Generator().manual_seed(zlib.crc32(key.encode())))
+    return np.array([x.sum().item(), x.abs().sum().item(), *x[idx].tolist()])
+
+
+def test_temporal_discriminator(golden):
+    """G8: oracle/disc_ref.py against the reference's patchgan_3d.resnet outputs (predictions, feature maps, hinge loss and
+    every parameter gradient, gradient penalty, generator-side loss and input gradient)."""
+    from oracle import disc_ref
+    g = golden("g8_temporal_disc_64")
+    cfg = {"bce_loss": False, "gp_weight": 1.0, "num_classes": 1, "patch_temp_disc": False}
+    o = disc_ref.TemporalDiscriminator(64, cfg)
+    deterministic_fill_(o, prefix="disc_t.")
+    o.eval()
+    Xt, Xf = t(g["X_true"]), t(g["X_fake"])
+    xt = Xt.clone().requires_grad_(True)
+    pf, _ = o(Xf)
+    pt, fm = o(xt)
+    assert (pf - t(g["pred_fake"])).abs().max() <= 2e-5 and (pt - t(g["pred_true"])).abs().max() <= 2e-5
+    for i, f in enumerate(fm):
+        assert (f[:, :4, :, :3, :3] - t(g[f"fmap{i}_slice"])).abs().max() <= 5e-5
+        assert np.allclose(_checksum(f, f"fmap{i}"), g[f"fmap{i}_checksum"], rtol=1e-4, atol=1e-3)
+    loss = (o.loss(pf, real=False) + o.loss(pt, real=True)) / 2.0
+    gp = o.gp2(pt, xt)
+    assert abs(loss.item() - float(g["loss_d"])) <= 1e-5 and abs(gp.item() - float(g["gp"])) <= 1e-4 * float(g["gp"])
+    loss.backward()
+    grads = dict(o.named_parameters())
+    for k, want in zip(g["grad_names"], g["grad_checksums"]):
+        got = _checksum(grads[str(k)].grad, str(k))
+        assert np.allclose(got, want, rtol=2e-3, atol=1e-5 * max(1.0, abs(want[1]))), k
