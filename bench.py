@@ -107,7 +107,7 @@ def kernel_roofline(B, dtype, iters=50):
     # (FETCH_SIZE x 2 -- the gfx950 correction for 16-byte-per-lane streaming reads -- plus WRITE_SIZE); null for other shapes
     traffic = None
     if M == 1280 and dtype == "bf16":
-        traffic = pmc_traffic("igemm_nt_glds_kernel<bool _Accum, int, E, 8, 5, 1, 3, 1, t", str(256 * 512))
+        traffic = pmc_traffic("igemm_nt_glds_kernel<bool _Accum, int, E, 4, 5, 2, 3, 1, true, 2>", str(256 * 512))
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch: 2 x FETCH_SIZE + WRITE_SIZE of this kernel's dispatches INSIDE the train step (rocprofv3 --pmc, profiles/r02_bench_pmc_*.json)",
             "algorithmic_bytes_per_launch": int(2 * (M * hid + hid * hid + M * hid)),
