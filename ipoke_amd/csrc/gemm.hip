@@ -17,7 +17,8 @@ static constexpr int kPitch = 144;   // 128 B of K per LDS row + 16 B pad
 
 struct GeomDev {
   int M;
-  int lDo, lHo, lWo;         // log2 of output dims
+  int lDo, lHo, lWo;         // log2 of output dims (pow2 != 0), else unused: rows decode with Do, Ho, Wo by division
+  int Do, Ho, Wo, pow2, S;   // output extents; S = Do*Ho*Wo output positions per sample
   int Di, Hi, Wi;
   int khw, kw, taps;         // kh*kw, kw, kd*kh*kw
   int sd, sh, sw, pd, ph, pw;
@@ -70,12 +71,19 @@ struct RowPos { long nb; int d0, h0, w0; int ok; };
 __device__ __forceinline__ RowPos decode_row(const GeomDev& g, int m, long a_sn) {
   RowPos r;
   r.ok = m < g.M;
-  const int ow = m & ((1 << g.lWo) - 1);
-  const int t1 = m >> g.lWo;
-  const int oh = t1 & ((1 << g.lHo) - 1);
-  const int t2 = t1 >> g.lHo;
-  const int od = t2 & ((1 << g.lDo) - 1);
-  const int n = t2 >> g.lDo;
+  int ow, oh, od, n;
+  if (g.pow2) {
+    ow = m & ((1 << g.lWo) - 1);
+    const int t1 = m >> g.lWo;
+    oh = t1 & ((1 << g.lHo) - 1);
+    const int t2 = t1 >> g.lHo;
+    od = t2 & ((1 << g.lDo) - 1);
+    n = t2 >> g.lDo;
+  } else {                    // e.g. the 15x15 / 14x14 maps of the 4x4 stride-1 PatchGAN convolutions
+    const int t1 = m / g.Wo; ow = m - t1 * g.Wo;
+    const int t2 = t1 / g.Ho; oh = t1 - t2 * g.Ho;
+    n = t2 / g.Do; od = t2 - n * g.Do;
+  }
   r.nb = (long)n * a_sn;
   if (!g.transposed) {
     r.d0 = od * g.sd - g.pd; r.h0 = oh * g.sh - g.ph; r.w0 = ow * g.sw - g.pw;
@@ -771,7 +779,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
   // loop invariant; only the sample index advances.  Offsets are 32-bit element offsets (host-checked).
   constexpr unsigned kBad = 0xffffffffu;
   unsigned x_fix[E16];
-  const int S = 1 << (g.lDo + g.lHo + g.lWo);
+  const int S = g.S;
   if (p.rows_fixed && do_x) {
 #pragma unroll
     for (int i = 0; i < E16; ++i) {
@@ -953,7 +961,9 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
 static int make_geom(GeomDev& g, int NB, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int kd, int kh, int kw,
                      int sd, int sh, int sw, int pd, int ph, int pw, int transposed) {
   g.lDo = ilog2_exact(Do); g.lHo = ilog2_exact(Ho); g.lWo = ilog2_exact(Wo);
-  IPK_REQUIRE(g.lDo >= 0 && g.lHo >= 0 && g.lWo >= 0, "output extents must be powers of two");
+  IPK_REQUIRE(Do >= 1 && Ho >= 1 && Wo >= 1 && (long)NB * Do * Ho * Wo < (1L << 31), "bad output extents");
+  g.Do = Do; g.Ho = Ho; g.Wo = Wo; g.S = Do * Ho * Wo;
+  g.pow2 = (g.lDo >= 0 && g.lHo >= 0 && g.lWo >= 0) ? 1 : 0;      // rows decode by shifts, else by division
   g.lsd = ilog2_exact(sd); g.lsh = ilog2_exact(sh); g.lsw = ilog2_exact(sw);
   IPK_REQUIRE(g.lsd >= 0 && g.lsh >= 0 && g.lsw >= 0, "strides must be powers of two");
   IPK_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1 && kd * kh * kw <= 256, "unsupported kernel extent");
@@ -1404,7 +1414,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   const int x_tap = kcol / p.Kc, x_c = kcol - x_tap * p.Kc;
   const bool x_ok = kcol < p.Ktot && x_c < p.Kc_real;
   const int x_tapcode = x_ok ? taptab[x_tap] : 0;
-  const int S = 1 << (g.lDo + g.lHo + g.lWo);
+  const int S = g.S;
   constexpr unsigned kBad = 0xffffffffu;
   unsigned x_fix[2] = {kBad, kBad};
   if (p.rows_fixed && x_ok) {
@@ -1534,8 +1544,7 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   p.tiles_k = ceil_div(p.Ktot, 128);
   const int nmb = ceil_div(p.g.M, RM);
   {
-    const int S = 1 << (p.g.lDo + p.g.lHo + p.g.lWo);
-    p.rows_fixed = (RM % S == 0) ? 1 : 0;
+    p.rows_fixed = (RM % p.g.S == 0) ? 1 : 0;
   }
   if (p.splitm < 1) p.splitm = 1;
   if (p.splitm > nmb) p.splitm = nmb;

@@ -167,3 +167,61 @@ class TemporalDiscriminator(nn.Module):
     def gp2(self, pred, x):
         raise NotImplementedError("gradient penalty (patchgan_3d.py:285-294) needs double backward through the HIP convolution / "
                                   "GroupNorm kernels: not built yet (DESIGN.md section 9)")
+
+
+class PatchDiscriminator(nn.Module):
+    """The first-stage 2-D PatchGAN ``PatchDiscriminator(config=d_s)`` (reference patchgan.py:368-470 with the default
+    InstanceNorm2d): spectral-normalised 4x4 convolutions with bias -- stride 2 three times, then stride 1 and the 1-channel
+    head (maps of 15 and 14 pixels at 128 px: the convolution kernels decode non-power-of-two extents by division) --,
+    InstanceNorm + LeakyReLU(0.2) after the inner ones.  ``forward(x[N,3,H,W]) -> (pred [N,1,h,w] fp32, [feature maps])``."""
+
+    def __init__(self, config, dtype="bf16"):
+        super().__init__()
+        self.dtype = dtype
+        self.bce_loss = bool(config.get("bce_loss", False))
+        self.gp_weight = float(config.get("gp_weight", 0.0))
+        if self.bce_loss:
+            raise NotImplementedError("bce_loss discriminators are not on the path (config/first_stage.yaml:79 uses the hinge loss)")
+        if config.get("deep_disc", False):
+            raise NotImplementedError("deep_disc is not used by the shipped configs")
+        n_layers = int(config.get("n_layers", 3))
+        ndf = 64
+        self.in_conv = FS._Conv(3, ndf, 4, 2, 1, bias=True, snorm=True, dims=2)
+        self.layers, self.norms = nn.ModuleList(), nn.ModuleList()
+        mult = 1
+        for n in range(1, n_layers):
+            prev, mult = mult, min(2 ** n, 8)
+            self.layers.append(FS._Conv(ndf * prev, ndf * mult, 4, 2, 1, bias=True, snorm=True, dims=2))
+            self.norms.append(FS._Norm("in", ndf * mult))
+        prev, mult = mult, min(2 ** n_layers, 8)
+        self.layers.append(FS._Conv(ndf * prev, ndf * mult, 4, 1, 1, bias=True, snorm=True, dims=2))
+        self.norms.append(FS._Norm("in", ndf * mult))
+        self.out_conv = FS._Conv(ndf * mult, 1, 4, 1, 1, bias=True, snorm=True, dims=2)
+
+    def forward(self, x, power_iteration=None):
+        _lib.require_gpu()
+        dt = self.dtype
+        pit = self.training if power_iteration is None else bool(power_iteration)
+        N, C, H, W = x.shape
+        w0 = T.effective_weight(self.in_conv, pit)
+        if x.requires_grad:
+            xcl = T._pad_cols(x.permute(0, 2, 3, 1).reshape(-1, C), K.round_up(C, K.e16(dt)), dt)
+            h = T.conv(self.in_conv, K.CL(xcl, N, (1, H, W), C), dt, act=_lib.ACT_LRELU02, w=w0)
+        else:
+            x = x.float()
+            st = (x.stride(0), x.stride(1), 0, x.stride(2), x.stride(3))
+            h = T.conv(self.in_conv, None, dt, act=_lib.ACT_LRELU02, src=(x, N, C, (1, H, W), st), w=w0)
+        fmap = []
+        for cv, nm in zip(self.layers, self.norms):
+            h = T.norm(nm, T.conv(cv, h, dt, w=T.effective_weight(cv, pit)), dt, act=_lib.ACT_LRELU02)
+            fmap.append(h)
+        o = T.conv(self.out_conv, h, dt, out_f32=True, w=T.effective_weight(self.out_conv, pit))
+        pred = o.t[:, :1].float().reshape(N, o.dhw[1], o.dhw[2], 1).permute(0, 3, 1, 2)
+        return pred, fmap
+
+    loss = staticmethod(TemporalDiscriminator.loss)
+    fmap_loss = staticmethod(TemporalDiscriminator.fmap_loss)
+
+    def gp(self, pred, x):
+        raise NotImplementedError("gradient penalty (patchgan.py:438-447) needs double backward: not built (DESIGN.md section 9); "
+                                  "config/first_stage.yaml:80 sets d_s.gp_weight = 0")

@@ -12,6 +12,9 @@ Follows reference models/modules/discriminators/patchgan_3d.py:
     loss (:263-274)      hinge: mean(relu(1 - pred)) for real, mean(relu(1 + pred)) for fake
     gp2 (:285-294)       mean over the batch of sum((d sum(pred) / d x)^2)  (create_graph=True)
     fmap_loss (:297-304) mean over the four feature maps of mean |f1 - f2|
+The 2-D PatchGAN (``PatchDiscriminator`` below) follows models/modules/discriminators/patchgan.py:368-470: spectral-normalised
+4x4 convolutions with bias (stride 2, 2, 2, then 1 and the 1-channel output head, padding 1), InstanceNorm2d (no affine) +
+LeakyReLU(0.2) after every inner convolution, feature maps after each of them; hinge loss and feature-matching loss as above.
 State-dict keys equal the reference's (``conv1.weight_orig / weight_u / weight_v``, ``gn1.weight``, ``layer1.0.conv1...``,
 ``layer2.0.downsample.0.weight_orig``, ``fc.weight``).  Parity is pinned by oracle/make_goldens.py job g8 (outputs, losses
 and gradients of this module asserted against the reference module on the same inputs and weights).
@@ -110,3 +113,56 @@ class TemporalDiscriminator(nn.Module):
     @staticmethod
     def fmap_loss(f1, f2):
         return sum((a - b).abs().mean() for a, b in zip(f1, f2)) / len(f1)
+
+
+class SNConv2d(nn.Module):
+    """Conv2d with bias under torch.nn.utils.spectral_norm semantics."""
+
+    def __init__(self, cin, cout, k, stride, pad, bias=True):
+        super().__init__()
+        self.stride, self.pad = stride, pad
+        self.weight_orig = nn.Parameter(torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        self.register_buffer("weight_u", F.normalize(torch.randn(cout), dim=0, eps=1e-12))
+        self.register_buffer("weight_v", F.normalize(torch.randn(cin * k * k), dim=0, eps=1e-12))
+
+    def forward(self, x):
+        wm = self.weight_orig.reshape(self.weight_orig.shape[0], -1)
+        if self.training:
+            with torch.no_grad():
+                v = F.normalize(torch.mv(wm.t(), self.weight_u), dim=0, eps=1e-12)
+                u = F.normalize(torch.mv(wm, v), dim=0, eps=1e-12)
+                self.weight_v.copy_(v); self.weight_u.copy_(u)
+        u, v = self.weight_u.clone(), self.weight_v.clone()
+        return F.conv2d(x, self.weight_orig / torch.dot(u, torch.mv(wm, v)), self.bias, self.stride, self.pad)
+
+
+class PatchDiscriminator(nn.Module):
+    """``PatchDiscriminator(config=d_s)`` of the reference with its default InstanceNorm2d (patchgan.py:368-418)."""
+
+    def __init__(self, config):
+        super().__init__()
+        n_layers = config.get("n_layers", 3)
+        ndf = 64
+        self.in_conv = SNConv2d(3, ndf, 4, 2, 1)
+        self.layers, self.norms = nn.ModuleList(), nn.ModuleList()
+        mult = 1
+        for n in range(1, n_layers):
+            prev, mult = mult, min(2 ** n, 8)
+            self.layers.append(SNConv2d(ndf * prev, ndf * mult, 4, 2, 1))
+            self.norms.append(nn.InstanceNorm2d(ndf * mult))
+        prev, mult = mult, min(2 ** n_layers, 8)
+        self.layers.append(SNConv2d(ndf * prev, ndf * mult, 4, 1, 1))
+        self.norms.append(nn.InstanceNorm2d(ndf * mult))
+        self.out_conv = SNConv2d(ndf * mult, 1, 4, 1, 1)
+
+    def forward(self, x):
+        x = F.leaky_relu(self.in_conv(x), 0.2)
+        fmap = []
+        for conv, norm in zip(self.layers, self.norms):
+            x = F.leaky_relu(norm(conv(x)), 0.2)
+            fmap.append(x)
+        return self.out_conv(x), fmap
+
+    loss = staticmethod(TemporalDiscriminator.loss)
+    fmap_loss = staticmethod(TemporalDiscriminator.fmap_loss)

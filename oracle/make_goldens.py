@@ -728,12 +728,76 @@ def g8_disc():
     npz("g8_temporal_disc_64", **arrs)
 
 
+def g9_patch_disc():
+    """G9: the first-stage 2-D PatchGAN (patchgan.py:368-470, config d_s of config/first_stage.yaml:77-85) on 64x64 frames,
+    B = 4: prediction map (6x6), the three feature maps (16, 8, 7 pixels: the stride-1 4x4 convolutions leave the powers of
+    two), hinge discriminator loss with every parameter gradient, generator-side loss with the gradient w.r.t. the fake
+    frames, and a train-mode forward."""
+    pg = ref_import.ref("models.modules.discriminators.patchgan")
+    cfg = {"bce_loss": False, "gp_weight": 0.0}
+    m = pg.PatchDiscriminator(dict(cfg))
+    deterministic_fill_(m, prefix="disc_s.")
+    o = disc_ref.PatchDiscriminator(dict(cfg))
+    assert set(m.state_dict()) == set(o.state_dict()), set(m.state_dict()) ^ set(o.state_dict())
+    o.load_state_dict(m.state_dict())
+    m.eval(); o.eval()
+    x_true = torch.rand(4, 3, 64, 64, generator=gen(91)) * 2 - 1
+    x_fake = torch.rand(4, 3, 64, 64, generator=gen(92)) * 2 - 1
+    arrs = dict(x_true=x_true, x_fake=x_fake)
+
+    def disc_side(net):
+        net.zero_grad()
+        pf, _ = net(x_fake)
+        pt, fm = net(x_true)
+        loss = (net.loss(pf, real=False) + net.loss(pt, real=True)) / 2.0
+        loss.backward()
+        return pf, pt, fm, loss, {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    pf, pt, fm, loss, grads = disc_side(m)
+    pfo, pto, fmo, losso, gradso = disc_side(o)
+    close(pfo, pf, 2e-5, "G9 pred fake"); close(pto, pt, 2e-5, "G9 pred true"); close(losso, loss, 1e-5, "G9 loss")
+    for a, b in zip(fmo, fm):
+        close(a, b, 5e-5, "G9 fmap")
+    for k in grads:
+        assert (grads[k] - gradso[k]).abs().max().item() <= 2e-3 * (grads[k].abs().max().item() + 1e-8), k
+    arrs.update(pred_fake=pf, pred_true=pt, loss_d=loss)
+    for i, f in enumerate(fm):
+        arrs[f"fmap{i}_checksum"] = checksum(f, f"fmap{i}")
+        arrs[f"fmap{i}_slice"] = f[:, :4, :3, :3]
+    names = sorted(grads)
+    arrs["grad_names"] = np.array(names)
+    arrs["grad_checksums"] = np.stack([checksum(grads[k], k) for k in names])
+
+    def gen_side(net):
+        xf = x_fake.clone().requires_grad_(True)
+        pg_, ff = net(xf)
+        with torch.no_grad():
+            _, ft = net(x_true)
+        lg = -pg_.mean() + net.fmap_loss(ff, ft)
+        lg.backward()
+        return lg, xf.grad
+
+    lg, dxf = gen_side(m)
+    lgo, dxfo = gen_side(o)
+    close(lgo, lg, 1e-5, "G9 generator loss")
+    assert (dxf - dxfo).abs().max().item() <= 2e-3 * dxf.abs().max().item()
+    arrs.update(loss_g=lg, dx_fake_checksum=checksum(dxf, "dx_fake"), dx_fake_slice=dxf[:, :, :6, :6])
+    m.train(); o.train()
+    with torch.no_grad():
+        ptr_, _ = m(x_true)
+        ptro, _ = o(x_true)
+    close(ptro, ptr_, 2e-5, "G9 train-mode pred")
+    arrs["pred_true_train"] = ptr_
+    arrs["u1.in_conv"] = m.in_conv.weight_u.clone(); arrs["u1.out_conv"] = m.out_conv.weight_u.clone()
+    npz("g9_patch_disc_64", **arrs)
+
+
 def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
             "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
-            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc}
+            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc}
     for name in (which or list(jobs)):
         print(f"[{name}]")
         t = time.time()

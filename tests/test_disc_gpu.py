@@ -105,3 +105,68 @@ def test_generator_side_and_train_mode(golden, dtype):
         mod = m.get_submodule(k)
         assert (mod.weight_u.cpu() - t(g[f"u1.{k}"])).abs().max().item() <= 1e-5
         assert np.allclose(_checksum(mod.weight_v, "v1." + k), g[f"v1_checksum.{k}"], rtol=1e-4, atol=1e-5)
+
+
+PCFG = {"bce_loss": False, "gp_weight": 0.0}
+
+
+def _nchw2(f):
+    return f.t[:, :f.C].float().reshape(f.N, f.dhw[1], f.dhw[2], f.C).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_patch_discriminator(golden, dtype):
+    """2-D PatchGAN (patchgan.py:368-470) against golden G9: prediction map, feature maps (16 / 8 / 7 pixels), hinge loss with
+    every parameter gradient, generator-side gradient w.r.t. the fake frames, train-mode power iterations."""
+    from ipoke_amd.discriminator import PatchDiscriminator
+    g = golden("g9_patch_disc_64")
+    tol = TOL[dtype]
+    m = PatchDiscriminator(PCFG, dtype=dtype)
+    deterministic_fill_(m, prefix="disc_s.")
+    m = m.to(DEV).eval()
+    xt, xf = t(g["x_true"], DEV), t(g["x_fake"], DEV)
+    pf, _ = m(xf)
+    pt, fm = m(xt)
+    scale = max(1.0, float(np.abs(g["pred_true"]).max()))
+    e = max((pf.cpu() - t(g["pred_fake"])).abs().max().item(), (pt.cpu() - t(g["pred_true"])).abs().max().item())
+    print(f"[{dtype}] patch pred {tuple(pt.shape)} err {e:.2e} (|pred| <= {scale:.2f})")
+    assert tuple(pt.shape) == tuple(g["pred_true"].shape) and e <= max(tol["pred"], 2e-5 if dtype == "f32" else 2e-2) * scale
+    for i, f in enumerate(fm):
+        full = _nchw2(f)
+        want = t(g[f"fmap{i}_slice"])
+        err = (full[:, :4, :3, :3].cpu() - want).abs().max().item()
+        cs, ws = _checksum(full, f"fmap{i}"), g[f"fmap{i}_checksum"]
+        assert err <= tol["fmap"] * max(1.0, want.abs().max().item()), (i, err)
+        assert abs(cs[1] - ws[1]) <= (2e-4 if dtype == "f32" else 1e-2) * ws[1]
+    loss = (m.loss(pf, real=False) + m.loss(pt, real=True)) / 2.0
+    assert abs(loss.item() - float(g["loss_d"])) <= max(tol["loss"], 1e-5 if dtype == "f32" else 1e-2) * max(1.0, abs(float(g["loss_d"])))
+    loss.backward()
+    grads = dict(m.named_parameters())
+    worst = 0.0
+    for k, want in zip(g["grad_names"], g["grad_checksums"]):
+        got = _checksum(grads[str(k)].grad, str(k))
+        if want[1] < 1e-6:            # biases in front of an InstanceNorm: the exact gradient is zero, only round-off remains
+            assert got[1] <= (2e-3 if dtype == "f32" else 5e-2), (k, got, want)
+            continue
+        rel = abs(got[1] - want[1]) / max(want[1], 1e-12)
+        worst = max(worst, rel)
+        assert rel <= tol["grad"], (k, got, want)
+    print(f"[{dtype}] patch worst parameter-gradient abs-sum deviation {worst:.2e}")
+    xg = xf.clone().requires_grad_(True)
+    pg, ff = m(xg)
+    with torch.no_grad():
+        _, ft = m(xt)
+    lg = -pg.mean() + m.fmap_loss(ff, ft)
+    assert abs(lg.item() - float(g["loss_g"])) <= max(tol["loss"], 1e-5 if dtype == "f32" else 1e-2) * max(1.0, abs(float(g["loss_g"])))
+    lg.backward()
+    want = t(g["dx_fake_slice"])
+    err = (xg.grad[:, :, :6, :6].cpu() - want).abs().max().item()
+    cs, ws = _checksum(xg.grad, "dx_fake"), g["dx_fake_checksum"]
+    print(f"[{dtype}] patch d loss_g / d x_fake slice err {err:.2e} (max {want.abs().max():.2e}); abs-sum {cs[1]:.4e} vs {ws[1]:.4e}")
+    assert err <= tol["dx"] * want.abs().max().item() and abs(cs[1] - ws[1]) <= tol["dx_sum"] * ws[1]
+    m.train()
+    with torch.no_grad():
+        ptr_, _ = m(xt)
+    assert (ptr_.cpu() - t(g["pred_true_train"])).abs().max().item() <= max(tol["pred"], 2e-5 if dtype == "f32" else 2e-2) * scale
+    assert (m.in_conv.weight_u.cpu() - t(g["u1.in_conv"])).abs().max().item() <= 1e-5
+    assert (m.out_conv.weight_u.cpu() - t(g["u1.out_conv"])).abs().max().item() <= 1e-5

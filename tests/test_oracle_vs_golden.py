@@ -222,3 +222,24 @@ def test_temporal_discriminator(golden):
     for k, want in zip(g["grad_names"], g["grad_checksums"]):
         got = _checksum(grads[str(k)].grad, str(k))
         assert np.allclose(got, want, rtol=2e-3, atol=1e-5 * max(1.0, abs(want[1]))), k
+
+
+def test_patch_discriminator(golden):
+    """G9: oracle/disc_ref.PatchDiscriminator against the reference's 2-D PatchGAN outputs."""
+    from oracle import disc_ref
+    g = golden("g9_patch_disc_64")
+    o = disc_ref.PatchDiscriminator({"bce_loss": False, "gp_weight": 0.0})
+    deterministic_fill_(o, prefix="disc_s.")
+    o.eval()
+    pf, _ = o(t(g["x_fake"]))
+    pt, fm = o(t(g["x_true"]))
+    assert (pf - t(g["pred_fake"])).abs().max() <= 2e-5 and (pt - t(g["pred_true"])).abs().max() <= 2e-5
+    for i, f in enumerate(fm):
+        assert (f[:, :4, :3, :3] - t(g[f"fmap{i}_slice"])).abs().max() <= 5e-5
+    loss = (o.loss(pf, real=False) + o.loss(pt, real=True)) / 2.0
+    assert abs(loss.item() - float(g["loss_d"])) <= 1e-5
+    loss.backward()
+    grads = dict(o.named_parameters())
+    for k, want in zip(g["grad_names"], g["grad_checksums"]):
+        got = _checksum(grads[str(k)].grad, str(k))
+        assert np.allclose(got, want, rtol=2e-3, atol=1e-5 * max(1.0, abs(want[1]))), k

@@ -109,6 +109,9 @@ CONV_CASES = [
     ("conv3d_t211", 2, 16, (4, 8, 8), 32, (3, 3, 3), (2, 1, 1), (1, 1, 1), False),
     ("convT2d", 2, 32, (1, 8, 8), 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), True),
     ("big_m", 20, 64, (1, 8, 8), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),
+    # 4x4 stride-1 padding-1 convolutions of the PatchGAN (patchgan.py:402-418): 16 -> 15 -> 14, not powers of two
+    ("patch_s1", 3, 16, (1, 16, 16), 24, (1, 4, 4), (1, 1, 1), (0, 1, 1), False),
+    ("patch_out", 2, 32, (1, 15, 15), 1, (1, 4, 4), (1, 1, 1), (0, 1, 1), False),
 ]
 
 
@@ -185,7 +188,7 @@ def test_conv3x3_skinny_stationary_input(B, Cout):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("case", CONV_CASES[:6], ids=[c[0] for c in CONV_CASES[:6]])
+@pytest.mark.parametrize("case", CONV_CASES[:6] + CONV_CASES[-2:], ids=[c[0] for c in CONV_CASES[:6] + CONV_CASES[-2:]])
 def test_conv_wgrad_vs_torch(case, dtype):
     name, N, Cin, dhw, Cout, k, s, p, tr = case
     gen = torch.Generator().manual_seed(hash(name) % 1000 + 1)
