@@ -464,6 +464,18 @@ int ipoke_maxpool3d_bwd(const int* dims, const void* dy, int ldy, const int* idx
 int ipoke_avgpool_rows(const void* x, int ldx, void* y, int ldy, int64_t G, int S, int C, int dtype, void* stream);
 int ipoke_avgpool_rows_bwd(const void* dy, int ldy, void* dx, int ldx, int64_t G, int S, int C, int dtype, void* stream);
 
+/* GroupNorm tangent for the discriminators' gradient penalty (patchgan_3d.py:285-294), evaluated forward-over-reverse (see
+ * vae_train.hip): ydot = act'(y) (gamma r (xdot - <xdot> - xhat <xhat xdot>) + resdot) per (sample, group); the backward
+ * returns the gradients on xdot, on the PRIMAL input x (the second-order term, through the statistics), on resdot and on
+ * gamma (fp32 [C], atomically accumulated).  x, xdot, y, q, ... are channels-last rows of the compute dtype. */
+int ipoke_groupnorm_jvp(const void* x, int ldx, const void* xdot, int ldxd, const void* y, int ldy, const void* resdot, int ldres,
+                        void* ydot, int ldyd, const float* gamma, int N, int S, int C, int G, int act, float eps, int dtype, void* stream);
+int ipoke_groupnorm_jvp_bwd(const void* x, int ldx, const void* xdot, int ldxd, const void* y, int ldy, const void* q, int ldq,
+                            void* dxdot, int lddxd, void* dx, int lddx, void* dresdot, int lddres, float* dgamma, const float* gamma,
+                            int N, int S, int C, int G, int act, float eps, int dtype, void* stream);
+/* y[o][c] = x[idx[o][c]][c]: the tangent of MaxPool3d under the primal pass's selection (idx of ipoke_maxpool3d_fwd). */
+int ipoke_gather_rows(const void* x, int ldx, const int* idx, void* y, int ldy, int64_t Mo, int C, int dtype, void* stream);
+
 /* reparameterize backward: dmulv = [dz + dmu | dz*eps*exp(lv/2)/2 + dlv]  (any of dz/dmu/dlv may be NULL) */
 int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, const float* dz, const float* dmu, const float* dlv, void* dmulv,
                       int ldo, int64_t M, int Z, int dtype, void* stream);

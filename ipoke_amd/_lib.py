@@ -155,6 +155,11 @@ SIGNATURES = {
     "ipoke_maxpool3d_bwd": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P]),
     "ipoke_avgpool_rows": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, _P]),
     "ipoke_avgpool_rows_bwd": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, _P]),
+    "ipoke_groupnorm_jvp": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float,
+                                    c_int, _P]),
+    "ipoke_groupnorm_jvp_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P,
+                                        c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "ipoke_gather_rows": (c_int, [_P, c_int, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_kl_loss": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P]),

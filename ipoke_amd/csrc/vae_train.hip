@@ -8,6 +8,7 @@
 //   * KL(q || N(0,1)) value and gradient in one pass (utils/losses.py:47-48).
 // All of it is HBM-bound streaming work: every weight element is read once per pass (twice per power iteration).
 #include "common.h"
+#include <cstring>
 
 namespace ipoke {
 
@@ -217,6 +218,87 @@ __global__ void avgpool_rows_bwd_kernel(const T* __restrict__ dy, int ldy, T* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------- GroupNorm tangent (gradient penalty)
+// The gradient penalty of the discriminators (patchgan_3d.py:285-294: mean_b |d sum(pred) / d x|^2, differentiated w.r.t. the
+// parameters) is evaluated forward-over-reverse: with g = d sum(pred)/dx from an ordinary backward pass and v = (2/B) g held
+// constant, d reg / d theta = d/d theta [ D_v sum(pred) ], the derivative of the network along v.  D_v is propagated by a
+// tangent forward pass next to the primal one: convolutions are linear (the same kernels run on the tangent), ReLU and
+// max-pooling apply the primal pass's masks / selections, and GroupNorm contributes the only second-order term:
+//   y = gamma xhat + beta, xhat = (x - mu) r:    ydot = gamma r (u - mean(u) - xhat mean(xhat u)),  u = xdot
+// (the same projection as GroupNorm's backward), then act'(y) and the residual tangent.  Its backward, for an upstream
+// gradient q on ydot, with w = gamma act'(y) q and per-group means a = <w>, b = <w xhat>, c = <w u>, ub = <u>, m = <xhat u>:
+//   d/d xdot = r (w - a - xhat b)
+//   d/d x    = -r^2 [ xhat (c - a ub - 3 b m) + m (w - a) + b (u - ub) ]          (through mu, r and xhat)
+//   d/d gamma_c = sum act'(y) q r (u - ub - xhat m),   d/d resdot = act'(y) q
+// One workgroup per (sample, group); element e of the group is position e / cpg, channel g*cpg + e % cpg.
+struct GnJvp {
+  const void* x; int ldx; const void* xd; int ldxd; const void* y; int ldy; const void* resd; int ldres;
+  void* yd; int ldyd;                 // forward output
+  const void* q; int ldq; void* dxd; int lddxd; void* dx; int lddx; void* dresd; int lddresd; float* dgamma;   // backward
+  const float* gamma; int N, S, C, G, act; float eps;
+};
+template <typename T>
+__device__ __forceinline__ float gj_ld(const void* p, long m, int ld, int c) { return ET<T>::to_f32(reinterpret_cast<const T*>(p)[m * ld + c]); }
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gn_jvp_kernel(const GnJvp a) {
+  __shared__ float red[4];
+  const int n = blockIdx.x / a.G, g = blockIdx.x % a.G, cpg = a.C / a.G;
+  const long cnt = (long)a.S * cpg;
+  const float inv = 1.f / (float)cnt;
+  float s1 = 0.f, s2 = 0.f;
+  for (long e = threadIdx.x; e < cnt; e += 256) {
+    const long m = (long)n * a.S + e / cpg; const int c = g * cpg + (int)(e % cpg);
+    const float xv = gj_ld<T>(a.x, m, a.ldx, c);
+    s1 += xv; s2 += xv * xv;
+  }
+  const float mu = block_sum(s1, red) * inv;
+  const float var = fmaxf(block_sum(s2, red) * inv - mu * mu, 0.f);
+  const float r = rsqrtf(var + a.eps);
+  float su = 0.f, sxu = 0.f, sw = 0.f, swx = 0.f, swu = 0.f;
+  for (long e = threadIdx.x; e < cnt; e += 256) {
+    const long m = (long)n * a.S + e / cpg; const int c = g * cpg + (int)(e % cpg);
+    const float xh = (gj_ld<T>(a.x, m, a.ldx, c) - mu) * r, u = gj_ld<T>(a.xd, m, a.ldxd, c);
+    su += u; sxu += xh * u;
+    if (BWD) {
+      float w = gj_ld<T>(a.q, m, a.ldq, c) * (a.gamma ? a.gamma[c] : 1.f);
+      if (a.act != IPOKE_ACT_NONE) w *= act_grad_from_out(a.act, gj_ld<T>(a.y, m, a.ldy, c));
+      sw += w; swx += w * xh; swu += w * u;
+    }
+  }
+  const float ub = block_sum(su, red) * inv, mm = block_sum(sxu, red) * inv;
+  float aa = 0.f, bb = 0.f, cc = 0.f;
+  if (BWD) { aa = block_sum(sw, red) * inv; bb = block_sum(swx, red) * inv; cc = block_sum(swu, red) * inv; }
+  const float k0 = cc - aa * ub - 3.f * bb * mm;
+  for (long e = threadIdx.x; e < cnt; e += 256) {
+    const long m = (long)n * a.S + e / cpg; const int c = g * cpg + (int)(e % cpg);
+    const float xh = (gj_ld<T>(a.x, m, a.ldx, c) - mu) * r, u = gj_ld<T>(a.xd, m, a.ldxd, c);
+    const float gm = a.gamma ? a.gamma[c] : 1.f;
+    const float da = a.act != IPOKE_ACT_NONE ? act_grad_from_out(a.act, gj_ld<T>(a.y, m, a.ldy, c)) : 1.f;
+    const float proj = r * (u - ub - xh * mm);                    // d xhat along u
+    if (!BWD) {
+      float yd = gm * proj;
+      if (a.resd) yd += gj_ld<T>(a.resd, m, a.ldres, c);
+      reinterpret_cast<T*>(a.yd)[m * a.ldyd + c] = ET<T>::from_f32(yd * da);
+    } else {
+      const float qd = gj_ld<T>(a.q, m, a.ldq, c) * da;           // act'(y) q
+      const float w = qd * gm;
+      reinterpret_cast<T*>(a.dxd)[m * a.lddxd + c] = ET<T>::from_f32(r * (w - aa - xh * bb));
+      reinterpret_cast<T*>(a.dx)[m * a.lddx + c] = ET<T>::from_f32(-r * r * (xh * k0 + mm * (w - aa) + bb * (u - ub)));
+      if (a.dresd) reinterpret_cast<T*>(a.dresd)[m * a.lddresd + c] = ET<T>::from_f32(qd);
+      if (a.dgamma) atomicAdd(a.dgamma + c, qd * proj);
+    }
+  }
+}
+// y[o][c] = x[idx[o][c]][c]: the tangent of max-pooling (the primal pass's selection); its backward is ipoke_maxpool3d_bwd
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ x, int ldx, const int* __restrict__ idx, T* __restrict__ y, int ldy, long Mo, int C) {
+  const long total = Mo * ldy;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldy); const long o = i / ldy;
+    y[i] = c < C ? x[(long)idx[o * C + c] * ldx + c] : ET<T>::from_f32(0.f);
+  }
+}
+
 static int grid1(long n, int cap = 2048) { long g = (n + 255) / 256; if (g < 1) g = 1; if (g > cap) g = cap; return (int)g; }
 
 }  // namespace ipoke
@@ -364,6 +446,50 @@ extern "C" int ipoke_avgpool_rows_bwd(const void* dy, int ldy, void* dx, int ldx
     hipLaunchKernelGGL(avgpool_rows_bwd_kernel<bf16_t>, dim3(grid1(G * S * ldx)), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, ldy, (bf16_t*)dx, ldx, (long)G, S, C);
   else
     hipLaunchKernelGGL(avgpool_rows_bwd_kernel<float>, dim3(grid1(G * S * ldx)), dim3(256), 0, STREAM(stream), (const float*)dy, ldy, (float*)dx, ldx, (long)G, S, C);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* GroupNorm tangent (see the comment at gn_jvp_kernel).  desc: the GnJvp fields as a flat argument list. */
+static int gn_jvp_fill(GnJvp& a, const void* x, int ldx, const void* xd, int ldxd, const void* y, int ldy, const float* gamma, int N, int S,
+                       int C, int G, int act, float eps) {
+  IPK_REQUIRE(x && xd && N >= 1 && S >= 1 && C >= 1 && G >= 1 && C % G == 0, "bad GroupNorm tangent arguments");
+  IPK_REQUIRE(act == IPOKE_ACT_NONE || y, "the activation mask needs the primal output");
+  std::memset(&a, 0, sizeof(a));
+  a.x = x; a.ldx = ldx; a.xd = xd; a.ldxd = ldxd; a.y = y; a.ldy = ldy; a.gamma = gamma; a.N = N; a.S = S; a.C = C; a.G = G; a.act = act; a.eps = eps;
+  return IPOKE_OK;
+}
+extern "C" int ipoke_groupnorm_jvp(const void* x, int ldx, const void* xdot, int ldxd, const void* y, int ldy, const void* resdot, int ldres,
+                                   void* ydot, int ldyd, const float* gamma, int N, int S, int C, int G, int act, float eps, int dtype,
+                                   void* stream) {
+  GnJvp a; int rc = gn_jvp_fill(a, x, ldx, xdot, ldxd, y, ldy, gamma, N, S, C, G, act, eps); if (rc) return rc;
+  IPK_REQUIRE(ydot, "null output");
+  a.resd = resdot; a.ldres = ldres; a.yd = ydot; a.ldyd = ldyd;
+  if (dtype == IPOKE_BF16) hipLaunchKernelGGL((gn_jvp_kernel<bf16_t, false>), dim3(N * G), dim3(256), 0, STREAM(stream), a);
+  else hipLaunchKernelGGL((gn_jvp_kernel<float, false>), dim3(N * G), dim3(256), 0, STREAM(stream), a);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+/* q: gradient on ydot.  Outputs: dxdot, dx (gradient on the PRIMAL input, through the statistics), dresdot (optional), dgamma
+ * (optional, fp32 [C], accumulated atomically: zero it first). */
+extern "C" int ipoke_groupnorm_jvp_bwd(const void* x, int ldx, const void* xdot, int ldxd, const void* y, int ldy, const void* q, int ldq,
+                                       void* dxdot, int lddxd, void* dx, int lddx, void* dresdot, int lddres, float* dgamma,
+                                       const float* gamma, int N, int S, int C, int G, int act, float eps, int dtype, void* stream) {
+  GnJvp a; int rc = gn_jvp_fill(a, x, ldx, xdot, ldxd, y, ldy, gamma, N, S, C, G, act, eps); if (rc) return rc;
+  IPK_REQUIRE(q && dxdot && dx, "null tensor");
+  a.q = q; a.ldq = ldq; a.dxd = dxdot; a.lddxd = lddxd; a.dx = dx; a.lddx = lddx; a.dresd = dresdot; a.lddresd = lddres; a.dgamma = dgamma;
+  if (dtype == IPOKE_BF16) hipLaunchKernelGGL((gn_jvp_kernel<bf16_t, true>), dim3(N * G), dim3(256), 0, STREAM(stream), a);
+  else hipLaunchKernelGGL((gn_jvp_kernel<float, true>), dim3(N * G), dim3(256), 0, STREAM(stream), a);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+/* y[o][c] = x[idx[o][c]][c] for c < C (zero beyond): the tangent of MaxPool3d given the primal pass's selection. */
+extern "C" int ipoke_gather_rows(const void* x, int ldx, const int* idx, void* y, int ldy, int64_t Mo, int C, int dtype, void* stream) {
+  IPK_REQUIRE(x && idx && y && Mo >= 1 && C >= 1 && ldy >= C, "bad arguments");
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(grid1(Mo * ldy, 4096)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx, idx, (bf16_t*)y, ldy, (long)Mo, C);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid1(Mo * ldy, 4096)), dim3(256), 0, STREAM(stream), (const float*)x, ldx, idx, (float*)y, ldy, (long)Mo, C);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

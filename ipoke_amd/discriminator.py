@@ -8,9 +8,12 @@ Parameter names equal the reference's state dict (``conv1.weight_orig / weight_u
 MaxPool3d / AvgPool3d from vae_train.hip.  Supported: predictions and the four feature maps, hinge / feature-matching /
 generator losses, gradients w.r.t. the parameters and w.r.t. the input clip.
 
-NOT yet supported: the gradient penalty ``gp2`` (:285-294) -- it differentiates the input gradient again
-(``create_graph=True``), i.e. needs the backward kernels themselves as differentiable ops; DESIGN.md §9 holds the plan.
-``gp2`` raises instead of silently falling back to PyTorch.
+The gradient penalty ``gp2`` (:285-294, ``create_graph=True`` in the reference) is evaluated forward-over-reverse instead of by
+double backward: g = d sum(pred) / dx from an ordinary backward pass gives the value mean_b |g_b|^2; with v = (2/B) g held
+constant, d reg / d theta = d/d theta [D_v sum(pred)], and D_v is propagated by a tangent pass that runs next to a primal pass
+-- the same convolution kernels on the tangent (convolutions are linear), the primal ReLU masks and max-pool selections, and
+``ipoke_groupnorm_jvp`` for the one second-order term (GroupNorm statistics).  One more ordinary backward pass then yields the
+parameter gradients.  No PyTorch double backward is involved.
 """
 import math
 
@@ -70,6 +73,82 @@ def max_pool3d(x, k, s, p, dtype):
     y, _ = _MaxPool3dFn.apply(x.t, x.N, x.C, tuple(x.dhw), tuple(k), tuple(s), tuple(p), dtype)
     odhw = tuple((i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip(x.dhw, k, s, p))
     return K.CL(y, x.N, odhw, x.C)
+
+
+class _NormJvpFn(torch.autograd.Function):
+    """Tangent of GroupNorm (+ residual, + ReLU mask of the primal output): see ipoke_groupnorm_jvp."""
+
+    @staticmethod
+    def forward(ctx, x_t, xd_t, y_t, resd_t, gamma, meta):
+        dt = meta["dtype"]
+        yd = torch.zeros_like(xd_t) if xd_t.shape[1] > meta["C"] else torch.empty_like(xd_t)
+        g32 = None if gamma is None else gamma.detach().float().contiguous()
+        check(_lib.lib().ipoke_groupnorm_jvp(ptr(x_t), x_t.shape[1], ptr(xd_t), xd_t.shape[1], ptr(y_t), y_t.shape[1],
+                                             None if resd_t is None else ptr(resd_t), 0 if resd_t is None else resd_t.shape[1],
+                                             ptr(yd), yd.shape[1], None if g32 is None else ptr(g32), meta["N"], meta["S"], meta["C"],
+                                             meta["G"], meta["act"], 1e-5, ops._dt(dt), _lib.current_stream()))
+        ctx.save_for_backward(x_t, xd_t, y_t, g32)
+        ctx.meta, ctx.has_res = meta, resd_t is not None
+        return yd
+
+    @staticmethod
+    def backward(ctx, q):
+        x_t, xd_t, y_t, g32 = ctx.saved_tensors
+        m = ctx.meta
+        q = q.contiguous()
+        dxd = torch.zeros_like(xd_t) if xd_t.shape[1] > m["C"] else torch.empty_like(xd_t)
+        dx = torch.zeros_like(x_t) if x_t.shape[1] > m["C"] else torch.empty_like(x_t)
+        dres = (torch.zeros_like(xd_t) if xd_t.shape[1] > m["C"] else torch.empty_like(xd_t)) if ctx.has_res else None
+        dgamma = None if g32 is None else torch.zeros(m["C"], dtype=torch.float32, device=q.device)
+        check(_lib.lib().ipoke_groupnorm_jvp_bwd(ptr(x_t), x_t.shape[1], ptr(xd_t), xd_t.shape[1], ptr(y_t), y_t.shape[1], ptr(q), q.shape[1],
+                                                 ptr(dxd), dxd.shape[1], ptr(dx), dx.shape[1], None if dres is None else ptr(dres),
+                                                 0 if dres is None else dres.shape[1], None if dgamma is None else ptr(dgamma),
+                                                 None if g32 is None else ptr(g32), m["N"], m["S"], m["C"], m["G"], m["act"], 1e-5,
+                                                 ops._dt(m["dtype"]), _lib.current_stream()))
+        return dx, dxd, None, dres, dgamma, None
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """Tangent of MaxPool3d: the primal pass's selection applied to the tangent (backward = the pooling backward)."""
+
+    @staticmethod
+    def forward(ctx, xd_t, idx, dims, C, dtype):
+        Mo = idx.shape[0]
+        y = torch.empty(Mo, xd_t.shape[1], dtype=xd_t.dtype, device=xd_t.device)
+        check(_lib.lib().ipoke_gather_rows(ptr(xd_t), xd_t.shape[1], ptr(idx), ptr(y), y.shape[1], Mo, C, ops._dt(dtype), _lib.current_stream()))
+        ctx.save_for_backward(idx)
+        ctx.args = (dims, xd_t.shape, dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dims, xshape, dtype = ctx.args
+        dy = dy.contiguous()
+        dx = torch.empty(xshape, dtype=dy.dtype, device=dy.device)
+        check(_lib.lib().ipoke_maxpool3d_bwd(dims.ctypes.data, ptr(dy), dy.shape[1], ptr(idx), ptr(dx), dx.shape[1], ops._dt(dtype),
+                                             _lib.current_stream()))
+        return dx, None, None, None, None
+
+
+def _norm_pair(mod, xp, xd, dt, act, res=None, resd=None):
+    """(GroupNorm(+res)(+act) of the primal, its tangent)."""
+    yp = T.norm(mod, xp, dt, act=act, res=res)
+    meta = dict(N=xp.N, S=xp.S, C=xp.C, G=mod.groups, dtype=dt, act=act)
+    yd = _NormJvpFn.apply(xp.t, xd.t, yp.t, None if resd is None else resd.t, mod.weight if mod.kind == "group" else None, meta)
+    return yp, K.CL(yd, xp.N, xp.dhw, xp.C)
+
+
+def _block_pair(blk, xp, xd, dt):
+    w1, w2 = T.effective_weight(blk.conv1, False), T.effective_weight(blk.conv2, False)
+    op, od = _norm_pair(blk.bn1, T.conv(blk.conv1, xp, dt, w=w1), T.conv(blk.conv1, xd, dt, w=w1), dt, _lib.ACT_RELU)
+    op, od = T.conv(blk.conv2, op, dt, w=w2), T.conv(blk.conv2, od, dt, w=w2)
+    rp, rd = xp, xd
+    if blk.downsample is not None:
+        ds = blk.downsample
+        wd = T.effective_weight(ds[0], False)
+        rp, rd = _norm_pair(ds[1], T.conv(ds[0], xp, dt, w=wd), T.conv(ds[0], xd, dt, w=wd), dt, _lib.ACT_NONE)
+    return _norm_pair(blk.bn2, op, od, dt, _lib.ACT_RELU, res=rp, resd=rd)
 
 
 class _Block(nn.Module):
@@ -164,9 +243,50 @@ class TemporalDiscriminator(nn.Module):
             tot = tot + (a.t[:, :a.C].float() - b.t[:, :b.C].float()).abs().mean()
         return tot / len(fmap1)
 
-    def gp2(self, pred, x):
-        raise NotImplementedError("gradient penalty (patchgan_3d.py:285-294) needs double backward through the HIP convolution / "
-                                  "GroupNorm kernels: not built yet (DESIGN.md section 9)")
+    def forward_with_tangent(self, x, v):
+        """Primal forward of ``x`` and, next to it, the derivative of every activation along the input direction ``v`` (both
+        [B, 3, T, H, W] fp32, neither needs a gradient).  Returns (pred, pred_dot).  Spectral-norm buffers are not iterated."""
+        _lib.require_gpu()
+        dt = self.dtype
+        B, C, Tn, H, W = x.shape
+        x, v = x.float().contiguous(), v.float().contiguous()
+        st = (x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4))
+        w1 = T.effective_weight(self.conv1, False)
+        hp = T.conv(self.conv1, None, dt, src=(x, B, C, (Tn, H, W), st), w=w1)
+        hd = T.conv(self.conv1, None, dt, src=(v, B, C, (Tn, H, W), st), w=w1)
+        hp, hd = _norm_pair(self.gn1, hp, hd, dt, _lib.ACT_RELU)
+        k, s_, p_ = (3, 3, 3), (1, 2, 2), (1, 1, 1)
+        yp, idx = _MaxPool3dFn.apply(hp.t, hp.N, hp.C, tuple(hp.dhw), k, s_, p_, dt)
+        odhw = tuple((i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip(hp.dhw, k, s_, p_))
+        dims = torch.tensor([hp.N, hp.C, *hp.dhw, *odhw, *k, *s_, *p_], dtype=torch.int32).numpy()
+        yd = _GatherRowsFn.apply(hd.t, idx, dims, hp.C, dt)
+        hp, hd = K.CL(yp, B, odhw, hp.C), K.CL(yd, B, odhw, hp.C)
+        for li in range(1, 5):
+            for blk in getattr(self, f"layer{li}"):
+                hp, hd = _block_pair(blk, hp, hd, dt)
+        D, Hh, Ww = hp.dhw
+        meta = dict(N=B, dhw=(D, 1, 1), cin=hp.C, cout=self.num_classes, k=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), transposed=False,
+                    out_pad=(0, 0, 0), dtype=dt, act=_lib.ACT_NONE, out_f32=True, src=None)
+        wfc = self.fc.weight.view(self.num_classes, hp.C, 1, 1, 1)
+        outs = []
+        for h in (hp, hd):
+            pooled = _AvgPoolRowsFn.apply(h.t, B * D, Hh * Ww, h.C, dt)
+            rows = T._ConvFn.apply(pooled, wfc, None, dict(meta))
+            outs.append(rows[:, :self.num_classes].float().reshape(B, D * self.num_classes))
+        return outs[0], outs[1]
+
+    def gp2(self, x):
+        """Gradient penalty of patchgan_3d.py:285-294 on the clip ``x``: a scalar whose value is mean_b |d sum(pred)/dx|_b^2 and
+        whose gradient w.r.t. the parameters is that of the penalty (forward-over-reverse, see the module docstring).  Unlike
+        the reference's ``gp2(pred, x)`` it runs its own forward passes (the current spectral-norm buffers, no iteration)."""
+        xg = x.detach().float().requires_grad_(True)
+        pred, _ = self.forward(xg, power_iteration=False)
+        (g,) = torch.autograd.grad(pred.sum(), xg)
+        B = x.shape[0]
+        reg = g.pow(2).reshape(B, -1).sum(1).mean()
+        _, pdot = self.forward_with_tangent(x.detach(), (2.0 / B) * g)
+        tsum = pdot.sum()
+        return tsum + (reg - tsum).detach()
 
 
 class PatchDiscriminator(nn.Module):
