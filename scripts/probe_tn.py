@@ -6,6 +6,7 @@ from ipoke_amd import _lib
 from ipoke_amd._lib import check, WgradDesc
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+PAD = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # extra elements of row pitch on both operands
 hid = 2048
 dev = "cuda"; M = B * 64
 lib = _lib.lib(); s = _lib.current_stream()
@@ -13,14 +14,14 @@ NW = 8
 def mk(k, pad, Kc, Nout, ldy, w_sn, w_sc, w_st):
     ds = []
     for i in range(NW):
-        A = torch.randn(M, Kc, device=dev).to(torch.bfloat16)
-        dY = torch.randn(M, ldy, device=dev).to(torch.bfloat16)
+        A = torch.randn(M, Kc + PAD, device=dev).to(torch.bfloat16)
+        dY = torch.randn(M, ldy + PAD, device=dev).to(torch.bfloat16)
         dW = torch.empty(Nout * w_sn + 16, device=dev)
         w = WgradDesc()
         w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = w.kw = k
         w.sd = w.sh = w.sw = 1; w.ph = w.pw = pad
-        w.A = A.data_ptr(); w.a_sn = 64 * Kc; w.a_sh = 8 * Kc; w.a_sw = Kc; w.a_sc = 1; w.Kc_real = Kc; w.Kc = Kc
-        w.dY = dY.data_ptr(); w.ldy = ldy; w.Nout = Nout
+        w.A = A.data_ptr(); w.a_sn = 64 * (Kc + PAD); w.a_sh = 8 * (Kc + PAD); w.a_sw = Kc + PAD; w.a_sc = 1; w.Kc_real = Kc; w.Kc = Kc
+        w.dY = dY.data_ptr(); w.ldy = ldy + PAD; w.Nout = Nout
         w.dW = dW.data_ptr(); w.w_sn = w_sn; w.w_sc = w_sc; w.w_st = w_st
         ds.append((w, A, dY, dW))
     return ds
@@ -35,4 +36,4 @@ def run(ds, n=200):
 c2 = mk(1, 0, hid, hid, hid, hid, 1, 0)
 c3 = mk(3, 1, hid, 64, 64, hid * 9, 9, 1)
 c1 = mk(3, 1, 32, hid, hid, 32 * 9, 9, 1)
-print(f"B={B}: conv2 {run(c2):.1f} us  conv3 {run(c3):.1f} us  conv1 {run(c1):.1f} us")
+print(f"B={B} pad={PAD}: conv2 {run(c2):.1f} us  conv3 {run(c3):.1f} us  conv1 {run(c1):.1f} us")
