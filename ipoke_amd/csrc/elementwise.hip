@@ -5,6 +5,9 @@
 // major").  A layer acting on the first C channels leaves columns >= C untouched (they are the
 // channels the multi-scale architecture has already split off, reference macow2.py:888-899).
 #include "common.h"
+#ifndef IPK_CHAIN_PRIO
+#define IPK_CHAIN_PRIO 1      // the chain's elementwise kernels raise their wave priority like its GEMMs (gemm.hip)
+#endif
 
 namespace ipoke {
 
@@ -46,6 +49,7 @@ __global__ void cond_prepare_kernel(const float* __restrict__ h, T* __restrict__
 template <typename T>
 __global__ void extract_cols_kernel(const float* __restrict__ s, int ld, int off, int stride, int C, T* __restrict__ out, int ldo,
                                     long M) {
+  if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   const long total = M * ldo;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / ldo; const int j = (int)(i - m * ldo);
@@ -59,6 +63,7 @@ __global__ void extract_cols_kernel(const float* __restrict__ s, int ld, int off
 __global__ void actnorm_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int ld, int c0, int C,
                                    const float* __restrict__ ls, const float* __restrict__ bias,
                                    const int* __restrict__ idx) {
+  if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   const long total = (long)M * ld;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int col = (int)(i % ld);
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(1024) void actnorm_bwd_kernel(const float* __restri
                                                            float* __restrict__ dx, int P, int ld, int c0, int C,
                                                            const float* __restrict__ ls, const int* __restrict__ idx,
                                                            const float* __restrict__ dld, float* __restrict__ part) {
+  if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   extern __shared__ float sm[];   // [2][rows_par][C]
   const int tid = threadIdx.x, b = blockIdx.x;
   const long row0 = (long)b * P;
@@ -234,6 +240,7 @@ __device__ __forceinline__ void affine_copy_rest(const AffineArgs& a, long row0,
 // grid = B * Q: Q slices of P/Q positions per sample (Q = 4 when the log-det slot is 4 wide, like the MCF kernels)
 __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out,
                                   float* __restrict__ scale_out, float* __restrict__ logdet_slot, int slot_stride, int Q) {
+  if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   extern __shared__ float raw_s[];
   __shared__ float red[8];
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
@@ -278,6 +285,7 @@ __global__ __launch_bounds__(1024) void affine_bwd_kernel(int Cp, int t_off, int
                                                           const float* __restrict__ scale, const float* __restrict__ dld,
                                                           float* __restrict__ dx, T* __restrict__ dparams, int ldp,
                                                           float* __restrict__ dbias_part) {
+  if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   extern __shared__ float sm[];      // [2*Cp] column sums
   const int b = blockIdx.x;
   const long row0 = (long)b * P;

@@ -34,6 +34,7 @@ struct NtParams {
   void* C; int c_f32, c_acc; long ldc; int c_coff, c_cstride;
   int splitk, kb_per_split, n_pad;
   int tiles_m, tiles_n, xa, xb;
+  int prio;            // != 0: raise the waves' issue priority (s_setprio)
 #ifdef IPOKE_GEMM_STAMPS
   long long* stamps = nullptr;   // probe build only (scripts/probe_gemm_stamps.py): 4 wall-clock stamps per workgroup
 #endif
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
   unsigned char* dummy = smem + NSTAGE * STAGE;                         // 1 KB per wave: landing zone of padding DMAs
   int* taptab = reinterpret_cast<int*>(smem + NSTAGE * STAGE + NTHR * 16);
   GEMM_STAMP(0);
+  if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);     // chain kernels win the SIMD's issue arbitration against co-resident side-stream waves
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WM * WN), wr = wave % (WM * WN);
@@ -1031,6 +1033,7 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const NtParams p) {
   unsigned char* ring = zrow + 256;                        // R filter K-blocks
   unsigned char* dummy = ring + R * WSLOT;                 // landing zone of padding DMAs, 1 KB per wave
   GEMM_STAMP(0);
+  if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mh = wave & 1, kq = wave >> 1;
@@ -1557,9 +1560,12 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
       (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && ((p.a_sn | p.a_sd | p.a_sh | p.a_sw) & 7) == 0 &&
       (p.batch ? ((reinterpret_cast<uintptr_t>(p.a_base) | reinterpret_cast<uintptr_t>(p.y_base)) & 15) == 0
                : ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.dY)) & 15) == 0)) {
-    constexpr int NST = 4;
+    // ring depth: 2 slots (64 KB of LDS) let a weight-gradient workgroup share a CU with a chain GEMM workgroup (89 KB): the
+    // same 29 us alone, 39 instead of 55 us inside the train step
+    static const int nst = getenv("IPOKE_TN_STAGES") ? atoi(getenv("IPOKE_TN_STAGES")) : 2;      // developer A/B: ring depth 2 / 3 / 4
+    const int NST = nst == 2 || nst == 3 ? nst : 4;
     const size_t lds2 = (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
-    auto kern = igemm_tn_glds_kernel<NST>;
+    auto kern = NST == 2 ? igemm_tn_glds_kernel<2> : NST == 3 ? igemm_tn_glds_kernel<3> : igemm_tn_glds_kernel<4>;
     static bool attr_done2 = false;
     if (!attr_done2) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2 = true; }
     const int ntiles = p.tiles_n * p.tiles_k;
@@ -1637,6 +1643,12 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
     IPK_REQUIRE(p.c_cstride == 1 && !d->c_accumulate, "dtype outputs are dense, non-accumulating");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    // s_setprio(2) in the chain's GEMMs: their waves win the issue arbitration against the co-resident weight-gradient /
+    // optimizer waves of the side streams (64.6 -> 63.3 ms per step; levels 1 / 2 / 3 measure the same)
+    static const int prio = getenv("IPOKE_NT_PRIO") ? atoi(getenv("IPOKE_NT_PRIO")) : 2;
+    p.prio = prio;
+  }
 #ifdef IPOKE_GEMM_STAMPS
   p.stamps = g_gemm_stamps;
   if (g_gemm_stamps) g_gemm_stamps += 4 * 4096;                // one slab of 4096 workgroups per launch
