@@ -483,8 +483,10 @@ class _L1TanhFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss, d_frame):
         grad, frame = ctx.saved_tensors
-        g = grad * (1.0 - frame * frame) * d_loss
-        return g, None, None
+        d = grad * d_loss
+        if d_frame is not None:              # the reconstruction also feeds the discriminators (GAN terms)
+            d = d + d_frame
+        return d * (1.0 - frame * frame), None, None
 
 
 # ------------------------------------------------------------------------------------------------ model pieces
@@ -604,24 +606,24 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
     return loss, torch.stack(frames, dim=1), mu4, lv4
 
 
-class FirstStageTrainer:
-    """Minimal training harness of c4: ``step(X)`` = forward, L1 + KL loss, backward, Adam step (the reference's
-    first-stage optimiser is ``Adam(lr, betas=(0.5, 0.9))`` over encoder + GRU + decoder, first_stage_motion_model.py:283-300)."""
+class MultiTensorAdam:
+    """torch.optim.Adam(lr, betas, weight_decay) semantics over a parameter list, one ``ipoke_adam_multi`` launch per 48
+    tensors; parameters without a gradient are skipped like torch does."""
 
-    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8):
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8):
         import ctypes
-        self.model = model
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        self._ct = ctypes
+        self.params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.weight_decay, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(weight_decay), float(eps)
         self.exp_avg = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.steps = 0
-        self._ct = ctypes
-        self.grad_hook = None           # data parallel: all-reduce of the gradients between backward and the update
 
-    def _adam(self):
-        """torch.optim.Adam(lr, betas, weight_decay) over every parameter that received a gradient: one multi-tensor launch
-        per 48 tensors (ipoke_adam_multi)."""
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
         ct = self._ct
         idx = [i for i, p in enumerate(self.params) if p.grad is not None]
         if not idx:
@@ -635,6 +637,17 @@ class FirstStageTrainer:
                                           arr([self.exp_avg_sq[i] for i in idx]), sizes, n, self.lr, self.betas[0], self.betas[1],
                                           self.eps, self.weight_decay, self.steps, 1.0, _lib.current_stream()))
 
+
+class FirstStageTrainer:
+    """Minimal training harness of c4: ``step(X)`` = forward, L1 + KL loss, backward, Adam step (the reference's
+    first-stage optimiser is ``Adam(lr, betas=(0.5, 0.9))`` over encoder + GRU + decoder, first_stage_motion_model.py:283-300)."""
+
+    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8):
+        self.model = model
+        self.opt = MultiTensorAdam(model.parameters(), lr, betas, weight_decay, eps)
+        self.params = self.opt.params
+        self.grad_hook = None           # data parallel: all-reduce of the gradients between backward and the update
+
     def step(self, X, eps=None):
         m = self.model
         m.train()
@@ -642,12 +655,11 @@ class FirstStageTrainer:
             Z = m.enc_motion.z_dim
             s = m.enc_motion.min_ssize
             eps = torch.FloatTensor(X.shape[0], Z, s, s).normal_().to(X.device)      # CPU generator, motion_encoder.py:220
-        for p in self.params:
-            p.grad = None
+        self.opt.zero_grad()
         loss, X_hat, mu, lv = first_stage_forward_loss(m, X, eps)
         loss.backward()
         if self.grad_hook is not None:
             self.grad_hook()
-        self._adam()
+        self.opt.step()
         m.invalidate_operands()
         return loss.detach(), X_hat.detach()
