@@ -35,26 +35,31 @@ __device__ __forceinline__ float sn_at(const SnView& V, int r, int c) {
   const int c1 = c / V.n2, c2 = c - c1 * V.n2;
   return V.w[(long)r * V.s_r + (long)c1 * V.s_1 + c2];
 }
-// tv[c] = sum_r W[r][c] u[r];  acc[0] += sum_c tv[c]^2
-__global__ __launch_bounds__(256) void sn_cols_kernel(SnView V, const float* __restrict__ u, float* __restrict__ tv, float* __restrict__ acc) {
-  __shared__ float red[4];
+// tv[c] += sum_{r in this block's row chunk} W[r][c] u[r]   (tv zeroed by the previous call's final kernel; fp32 atomics: the
+// row chunks give the launch (C / 256) x (R / 32) workgroups instead of C / 256 -- 18 for a 512 x 4608 matrix)
+constexpr int kSnRowChunk = 32;
+__global__ __launch_bounds__(256) void sn_cols_kernel(SnView V, const float* __restrict__ u, float* __restrict__ tv) {
   const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * kSnRowChunk, r1 = min(V.R, r0 + kSnRowChunk);
+  if (c >= V.C) return;
+  const int c1 = c / V.n2, c2 = c - c1 * V.n2;
+  const float* col = V.w + (long)c1 * V.s_1 + c2;
   float s = 0.f;
-  if (c < V.C) {
-    const int c1 = c / V.n2, c2 = c - c1 * V.n2;
-    const float* col = V.w + (long)c1 * V.s_1 + c2;
-    for (int r = 0; r < V.R; ++r) s = fmaf(col[(long)r * V.s_r], u[r], s);
-    tv[c] = s;
-  }
-  const float sq = block_sum(s * s, red);
-  if (threadIdx.x == 0) atomicAdd(acc, sq);
+  for (int r = r0; r < r1; ++r) s = fmaf(col[(long)r * V.s_r], u[r], s);
+  atomicAdd(tv + c, s);
 }
 // one wave per row: tu[r] = sum_c W[r][c] vhat[c], vhat = iterate ? tv / max(||tv||, eps) : v;  acc[1] += tu[r]^2
-// (iterate: block 0 also stores vhat into v)
+// (iterate: every block derives ||tv|| itself; block 0 also stores vhat into v)
 __global__ __launch_bounds__(256) void sn_rows_kernel(SnView V, const float* __restrict__ tv, float* __restrict__ v, float* __restrict__ tu,
                                                       float* __restrict__ acc, int iterate, float eps) {
+  __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float inv = iterate ? 1.f / fmaxf(sqrtf(acc[0]), eps) : 1.f;
+  float inv = 1.f;
+  if (iterate) {
+    float sq = 0.f;
+    for (int c = threadIdx.x; c < V.C; c += 256) sq = fmaf(tv[c], tv[c], sq);
+    inv = 1.f / fmaxf(sqrtf(block_sum(sq, red)), eps);
+  }
   const float* src = iterate ? tv : v;
   const int r = blockIdx.x * 4 + wave;
   if (r < V.R) {
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void sn_rows_kernel(SnView V, const float* __r
 // u = iterate ? tu / max(||tu||, eps) : u;  sigma = sum_r u[r] tu[r];  out = {sigma, 1/sigma};  snapshot = [u | v];  acc reset
 __global__ __launch_bounds__(256) void sn_final_kernel(int R, int C, float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ tu,
                                                        float* __restrict__ acc, float* __restrict__ out, float* __restrict__ snap, int iterate,
-                                                       float eps) {
+                                                       float eps, float* __restrict__ tv) {
   __shared__ float red[4];
   const float inv = iterate ? 1.f / fmaxf(sqrtf(acc[1]), eps) : 1.f;
   float s = 0.f;
@@ -80,6 +85,7 @@ __global__ __launch_bounds__(256) void sn_final_kernel(int R, int C, float* __re
     s = fmaf(ur, tu[r], s);
   }
   if (snap) for (int c = threadIdx.x; c < C; c += 256) snap[R + c] = v[c];
+  if (iterate) for (int c = threadIdx.x; c < C; c += 256) tv[c] = 0.f;          // clean accumulator for the next call
   s = block_sum(s, red);
   if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; acc[0] = 0.f; acc[1] = 0.f; }
 }
@@ -340,12 +346,12 @@ extern "C" int ipoke_spectral_sigma(const float* w, int cout, int cin, int taps,
   const SnView V = sn_view(w, cout, cin, taps, transposed);
   float* acc = workspace; float* tu = workspace + 4; float* tv = tu + cout;
   if (iterate) {
-    hipLaunchKernelGGL(sn_cols_kernel, dim3((V.C + 255) / 256), dim3(256), 0, STREAM(stream), V, u, tv, acc);
+    hipLaunchKernelGGL(sn_cols_kernel, dim3((V.C + 255) / 256, (V.R + kSnRowChunk - 1) / kSnRowChunk), dim3(256), 0, STREAM(stream), V, u, tv);
     IPK_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(sn_rows_kernel, dim3((V.R + 3) / 4), dim3(256), 0, STREAM(stream), V, tv, v, tu, acc, iterate, eps);
   IPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sn_final_kernel, dim3(1), dim3(256), 0, STREAM(stream), V.R, V.C, u, v, tu, acc, out, snapshot, iterate, eps);
+  hipLaunchKernelGGL(sn_final_kernel, dim3(1), dim3(256), 0, STREAM(stream), V.R, V.C, u, v, tu, acc, out, snapshot, iterate, eps, tv);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
