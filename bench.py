@@ -238,7 +238,31 @@ def secondary(args, cfg, rank, world, device):
     """c4: first-stage VAE train step; c5: sampling.  Same timing contract as the headline run."""
     B, T, size, z = cfg["batch_size"], cfg["n_frames"], cfg["spatial_size"], cfg["z_dim"]
     batch = synthetic_batch(B, T, size, seed=1 + rank, device=device)
-    if args.config == "c4":
+    if args.config == "c4gan":
+        # the reference's real first-stage step (first_stage_motion_model.py:160-277, config/first_stage.yaml d_t / d_s) without
+        # the VGG term: L1 + KL + temporal discriminator (hinge + gradient penalty) + spatial discriminator + generator terms
+        import numpy as np
+        from ipoke_amd.discriminator import PatchDiscriminator, TemporalDiscriminator
+        from ipoke_amd.first_stage import SpadeCondMotionModel
+        from ipoke_amd.first_stage_gan import FirstStageGANTrainer
+        if world > 1:
+            raise SystemExit("c4gan is a single-GPU measurement")
+        torch.manual_seed(0)
+        model = SpadeCondMotionModel(configs.first_stage_config(size, z, T), dirs={}, dtype=args.dtype).to(device)
+        d_t = {"bce_loss": False, "gp_weight": 1.0, "num_classes": 1, "patch_temp_disc": False, "fmap_weight": 1.0, "gen_weight": 1.0,
+               "max_frames": 12}
+        d_s = {"bce_loss": False, "gp_weight": 0.0, "fmap_weight": 1.0, "gen_weight": 1.0, "n_examples": 16}
+        disc_t = TemporalDiscriminator(size, d_t, dtype=args.dtype).to(device)
+        disc_s = PatchDiscriminator(d_s, dtype=args.dtype).to(device)
+        gan = FirstStageGANTrainer(model, disc_t, disc_s, {"training": {"lr": 2e-4, "weight_decay": 1e-5, "w_l1": 10.0, "w_kl": 1e-7, "w_vgg": 0.0},
+                                                            "d_t": d_t, "d_s": d_s, "data": {"max_frames": T - 1}})
+        eps = torch.randn(B, z, 8, 8, generator=torch.Generator().manual_seed(7 + rank)).to(device)
+        rng = np.random.RandomState(3)
+        step = lambda i: gan.step(batch["images"], eps, *gan.draw(batch["images"], rng))["loss"]
+        metric, frames = "video-frames/sec (first-stage adversarial train step: L1 + KL + d_t hinge/GP + d_s + generator terms)", world * B * T
+        workload = (f"first_stage {T}x3x{size}x{size} clips, z={z}, generator fwd+bwd, 3-D ResNet-18 discriminator on {d_t['max_frames']} frames "
+                    f"(4 forward + tangent pass + backward), PatchGAN on {d_s['n_examples']} frames, three Adam steps; no VGG term; per-GPU batch {B}")
+    elif args.config == "c4":
         from ipoke_amd.first_stage import SpadeCondMotionModel
         from ipoke_amd.first_stage_train import FirstStageTrainer
         torch.manual_seed(0)
@@ -298,7 +322,7 @@ def secondary(args, cfg, rank, world, device):
                 "config": {"workload": workload, "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
                            "weights": "random init of the named architecture (no checkpoints offline)"},
                 "roofline": kernel_roofline(B, args.dtype)}
-        if args.config == "c4":
+        if args.config in ("c4", "c4gan"):
             line["loss"] = round(float(out.item()), 4)
         if graph:
             line["hipgraph"] = graph
@@ -313,7 +337,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c4gan", "c5"],
                     help="c2 (default) is the configuration BASELINE.json's metric is quoted on; c4 = first-stage VAE train step "
                          "(L1 + KL), c5 = sampling (reverse flow + 15-frame decode): secondary workloads of SURVEY.md §8d")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -338,7 +362,7 @@ def main():
         cfg["batch_size"] = args.batch
     B, T, size, z = cfg["batch_size"], cfg["n_frames"], cfg["spatial_size"], cfg["z_dim"]
 
-    if args.config in ("c4", "c5"):
+    if args.config in ("c4", "c4gan", "c5"):
         secondary(args, cfg, rank, world, device)
         return
 

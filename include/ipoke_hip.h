@@ -469,10 +469,12 @@ int ipoke_avgpool_rows_bwd(const void* dy, int ldy, void* dx, int ldx, int64_t G
  * returns the gradients on xdot, on the PRIMAL input x (the second-order term, through the statistics), on resdot and on
  * gamma (fp32 [C], atomically accumulated).  x, xdot, y, q, ... are channels-last rows of the compute dtype. */
 int ipoke_groupnorm_jvp(const void* x, int ldx, const void* xdot, int ldxd, const void* y, int ldy, const void* resdot, int ldres,
-                        void* ydot, int ldyd, const float* gamma, int N, int S, int C, int G, int act, float eps, int dtype, void* stream);
+                        void* ydot, int ldyd, const float* gamma, int N, int S, int C, int G, int act, float eps, float* workspace, int dtype,
+                        void* stream);
 int ipoke_groupnorm_jvp_bwd(const void* x, int ldx, const void* xdot, int ldxd, const void* y, int ldy, const void* q, int ldq,
                             void* dxdot, int lddxd, void* dx, int lddx, void* dresdot, int lddres, float* dgamma, const float* gamma,
-                            int N, int S, int C, int G, int act, float eps, int dtype, void* stream);
+                            int N, int S, int C, int G, int act, float eps, float* workspace, int dtype, void* stream);
+long ipoke_groupnorm_jvp_workspace_floats(int N, int G);     /* workspace of the two calls above */
 /* y[o][c] = x[idx[o][c]][c]: the tangent of MaxPool3d under the primal pass's selection (idx of ipoke_maxpool3d_fwd). */
 int ipoke_gather_rows(const void* x, int ldx, const int* idx, void* y, int ldy, int64_t Mo, int C, int dtype, void* stream);
 

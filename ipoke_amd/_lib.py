@@ -156,9 +156,10 @@ SIGNATURES = {
     "ipoke_avgpool_rows": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, _P]),
     "ipoke_avgpool_rows_bwd": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, _P]),
     "ipoke_groupnorm_jvp": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float,
-                                    c_int, _P]),
+                                    _P, c_int, _P]),
     "ipoke_groupnorm_jvp_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P,
-                                        c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+                                        c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
+    "ipoke_groupnorm_jvp_workspace_floats": (ctypes.c_long, [c_int, c_int]),
     "ipoke_gather_rows": (c_int, [_P, c_int, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_kl_loss": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),

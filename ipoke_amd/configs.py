@@ -101,5 +101,6 @@ BENCH_CONFIGS = {
     "c2": dict(name="plants_128", spatial_size=128, z_dim=64, n_frames=16, batch_size=20),
     "c3": dict(name="iper_128", spatial_size=128, z_dim=32, n_frames=16, batch_size=40),
     "c4": dict(name="first_stage_128", spatial_size=128, z_dim=32, n_frames=16, batch_size=20),
+    "c4gan": dict(name="first_stage_128_gan", spatial_size=128, z_dim=32, n_frames=16, batch_size=20),
     "c5": dict(name="h36m_128", spatial_size=128, z_dim=64, n_frames=16, batch_size=32),
 }

@@ -243,56 +243,143 @@ struct GnJvp {
   const void* q; int ldq; void* dxd; int lddxd; void* dx; int lddx; void* dresd; int lddresd; float* dgamma;   // backward
   const float* gamma; int N, S, C, G, act; float eps;
 };
-template <typename T>
-__device__ __forceinline__ float gj_ld(const void* p, long m, int ld, int c) { return ET<T>::to_f32(reinterpret_cast<const T*>(p)[m * ld + c]); }
+// Two launches per direction, both on a (position chunk, sample) grid with 16-byte loads (thread (rr, cg) owns the E16 channels
+// of column group cg over rows rr, rr + rp, ...): (1) per-channel sums over the chunk -> per-group sums, added atomically
+// into gsum[n][g][.]: sum x, x^2, u, x u (+ w, w x, w u in the backward); (2) the element-wise pass with the group scalars
+// derived from those sums (xhat sums follow from raw ones: <xhat u> = r (<x u> - mu <u>)).
+constexpr int kGjPos = 128;          // positions per block
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void gn_jvp_kernel(const GnJvp a) {
-  __shared__ float red[4];
-  const int n = blockIdx.x / a.G, g = blockIdx.x % a.G, cpg = a.C / a.G;
-  const long cnt = (long)a.S * cpg;
-  const float inv = 1.f / (float)cnt;
-  float s1 = 0.f, s2 = 0.f;
-  for (long e = threadIdx.x; e < cnt; e += 256) {
-    const long m = (long)n * a.S + e / cpg; const int c = g * cpg + (int)(e % cpg);
-    const float xv = gj_ld<T>(a.x, m, a.ldx, c);
-    s1 += xv; s2 += xv * xv;
+__global__ __launch_bounds__(256) void gn_jvp_sums_kernel(const GnJvp a, float* __restrict__ gsum) {
+  constexpr int E16 = ET<T>::E16, NK = BWD ? 7 : 4;
+  typedef typename ET<T>::frag frag_t;
+  const int n = blockIdx.y, p0 = blockIdx.x * kGjPos, p1 = min(a.S, p0 + kGjPos);
+  const int cpg = a.C / a.G, cvec = a.C / E16;
+  for (int g0 = 0; g0 < cvec; g0 += 256) {
+    const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
+    const int rp = 256 / groups;
+    const int cg = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
+    float acc[NK][E16];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int e = 0; e < E16; ++e) acc[k][e] = 0.f;
+    if (rr < rp) {
+      for (int p = p0 + rr; p < p1; p += rp) {
+        const long m = (long)n * a.S + p;
+        const frag_t xv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
+        const frag_t uv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.xd) + m * a.ldxd + cg * E16);
+        frag_t qv, yv;
+        if (BWD) {
+          qv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.q) + m * a.ldq + cg * E16);
+          if (a.act != IPOKE_ACT_NONE) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
+        }
+#pragma unroll
+        for (int e = 0; e < E16; ++e) {
+          const float x = ET<T>::to_f32(xv[e]), u = ET<T>::to_f32(uv[e]);
+          acc[0][e] += x; acc[1][e] += x * x; acc[2][e] += u; acc[3][e] += x * u;
+          if constexpr (BWD) {
+            float w = ET<T>::to_f32(qv[e]) * (a.gamma ? a.gamma[cg * E16 + e] : 1.f);
+            if (a.act != IPOKE_ACT_NONE) w *= act_grad_from_out(a.act, ET<T>::to_f32(yv[e]));
+            acc[4][e] += w; acc[5][e] += w * x; acc[6][e] += w * u;
+          }
+        }
+      }
+    }
+    // per-thread sums -> per-group sums: a thread's E16 channels lie in at most two groups when cpg < E16, in one otherwise
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      if (rr < rp) {
+        if (cpg >= E16) {
+          float t = 0.f;
+#pragma unroll
+          for (int e = 0; e < E16; ++e) t += acc[k][e];
+          atomicAdd(gsum + ((long)n * a.G + (cg * E16) / cpg) * 8 + k, t);
+        } else {
+          for (int e0 = 0; e0 < E16; e0 += cpg) {
+            float t = 0.f;
+            for (int e = e0; e < e0 + cpg; ++e) t += acc[k][e];
+            atomicAdd(gsum + ((long)n * a.G + (cg * E16 + e0) / cpg) * 8 + k, t);
+          }
+        }
+      }
+    }
   }
-  const float mu = block_sum(s1, red) * inv;
-  const float var = fmaxf(block_sum(s2, red) * inv - mu * mu, 0.f);
-  const float r = rsqrtf(var + a.eps);
-  float su = 0.f, sxu = 0.f, sw = 0.f, swx = 0.f, swu = 0.f;
-  for (long e = threadIdx.x; e < cnt; e += 256) {
-    const long m = (long)n * a.S + e / cpg; const int c = g * cpg + (int)(e % cpg);
-    const float xh = (gj_ld<T>(a.x, m, a.ldx, c) - mu) * r, u = gj_ld<T>(a.xd, m, a.ldxd, c);
-    su += u; sxu += xh * u;
+}
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gn_jvp_apply_kernel(const GnJvp a, const float* __restrict__ gsum) {
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  extern __shared__ float lds[];            // [8][G]: mu, r, ub, mm, aa, bb, k0, -  per group of this sample; then [C] dgamma partials
+  const int n = blockIdx.y, p0 = blockIdx.x * kGjPos, p1 = min(a.S, p0 + kGjPos);
+  const int cpg = a.C / a.G, cvec = a.C / E16, G = a.G;
+  const float inv = 1.f / ((float)a.S * cpg);
+  for (int g = threadIdx.x; g < G; g += 256) {
+    const float* s = gsum + ((long)n * G + g) * 8;
+    const float mu = s[0] * inv, var = fmaxf(s[1] * inv - mu * mu, 0.f), r = rsqrtf(var + a.eps);
+    const float ub = s[2] * inv, mm = r * (s[3] * inv - mu * ub);
+    lds[g] = mu; lds[G + g] = r; lds[2 * G + g] = ub; lds[3 * G + g] = mm;
     if (BWD) {
-      float w = gj_ld<T>(a.q, m, a.ldq, c) * (a.gamma ? a.gamma[c] : 1.f);
-      if (a.act != IPOKE_ACT_NONE) w *= act_grad_from_out(a.act, gj_ld<T>(a.y, m, a.ldy, c));
-      sw += w; swx += w * xh; swu += w * u;
+      const float aa = s[4] * inv, bb = r * (s[5] * inv - mu * aa), cc = s[6] * inv;
+      lds[4 * G + g] = aa; lds[5 * G + g] = bb; lds[6 * G + g] = cc - aa * ub - 3.f * bb * mm;
     }
   }
-  const float ub = block_sum(su, red) * inv, mm = block_sum(sxu, red) * inv;
-  float aa = 0.f, bb = 0.f, cc = 0.f;
-  if (BWD) { aa = block_sum(sw, red) * inv; bb = block_sum(swx, red) * inv; cc = block_sum(swu, red) * inv; }
-  const float k0 = cc - aa * ub - 3.f * bb * mm;
-  for (long e = threadIdx.x; e < cnt; e += 256) {
-    const long m = (long)n * a.S + e / cpg; const int c = g * cpg + (int)(e % cpg);
-    const float xh = (gj_ld<T>(a.x, m, a.ldx, c) - mu) * r, u = gj_ld<T>(a.xd, m, a.ldxd, c);
-    const float gm = a.gamma ? a.gamma[c] : 1.f;
-    const float da = a.act != IPOKE_ACT_NONE ? act_grad_from_out(a.act, gj_ld<T>(a.y, m, a.ldy, c)) : 1.f;
-    const float proj = r * (u - ub - xh * mm);                    // d xhat along u
-    if (!BWD) {
-      float yd = gm * proj;
-      if (a.resd) yd += gj_ld<T>(a.resd, m, a.ldres, c);
-      reinterpret_cast<T*>(a.yd)[m * a.ldyd + c] = ET<T>::from_f32(yd * da);
-    } else {
-      const float qd = gj_ld<T>(a.q, m, a.ldq, c) * da;           // act'(y) q
-      const float w = qd * gm;
-      reinterpret_cast<T*>(a.dxd)[m * a.lddxd + c] = ET<T>::from_f32(r * (w - aa - xh * bb));
-      reinterpret_cast<T*>(a.dx)[m * a.lddx + c] = ET<T>::from_f32(-r * r * (xh * k0 + mm * (w - aa) + bb * (u - ub)));
-      if (a.dresd) reinterpret_cast<T*>(a.dresd)[m * a.lddresd + c] = ET<T>::from_f32(qd);
-      if (a.dgamma) atomicAdd(a.dgamma + c, qd * proj);
+  float* dg = lds + 8 * G;
+  if (BWD && a.dgamma) for (int c = threadIdx.x; c < a.C; c += 256) dg[c] = 0.f;
+  __syncthreads();
+  for (int g0 = 0; g0 < cvec; g0 += 256) {
+    const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
+    const int rp = 256 / groups;
+    const int cg = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
+    float dgl[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) dgl[e] = 0.f;
+    if (rr < rp) {
+      for (int p = p0 + rr; p < p1; p += rp) {
+        const long m = (long)n * a.S + p;
+        const frag_t xv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
+        const frag_t uv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.xd) + m * a.ldxd + cg * E16);
+        frag_t yv, rv, qv, o1, o2, o3;
+        if (a.act != IPOKE_ACT_NONE) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
+        if (!BWD && a.resd) rv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.resd) + m * a.ldres + cg * E16);
+        if (BWD) qv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.q) + m * a.ldq + cg * E16);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) {
+          const int c = cg * E16 + e, g = c / cpg;
+          const float mu = lds[g], r = lds[G + g], ub = lds[2 * G + g], mm = lds[3 * G + g];
+          const float xh = (ET<T>::to_f32(xv[e]) - mu) * r, u = ET<T>::to_f32(uv[e]);
+          const float gm = a.gamma ? a.gamma[c] : 1.f;
+          const float da = a.act != IPOKE_ACT_NONE ? act_grad_from_out(a.act, ET<T>::to_f32(yv[e])) : 1.f;
+          const float proj = r * (u - ub - xh * mm);
+          if (!BWD) {
+            float yd = gm * proj;
+            if (a.resd) yd += ET<T>::to_f32(rv[e]);
+            o1[e] = ET<T>::from_f32(yd * da);
+          } else {
+            const float qd = ET<T>::to_f32(qv[e]) * da, w = qd * gm;
+            const float aa = lds[4 * G + g], bb = lds[5 * G + g], k0 = lds[6 * G + g];
+            o1[e] = ET<T>::from_f32(r * (w - aa - xh * bb));
+            o2[e] = ET<T>::from_f32(-r * r * (xh * k0 + mm * (w - aa) + bb * (u - ub)));
+            o3[e] = ET<T>::from_f32(qd);
+            dgl[e] += qd * proj;
+          }
+        }
+        if (!BWD) {
+          *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.yd) + m * a.ldyd + cg * E16) = o1;
+        } else {
+          *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dxd) + m * a.lddxd + cg * E16) = o1;
+          *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dx) + m * a.lddx + cg * E16) = o2;
+          if (a.dresd) *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dresd) + m * a.lddresd + cg * E16) = o3;
+        }
+      }
+      if (BWD && a.dgamma) {
+#pragma unroll
+        for (int e = 0; e < E16; ++e) atomicAdd(dg + cg * E16 + e, dgl[e]);
+      }
     }
+  }
+  if (BWD && a.dgamma) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += 256) atomicAdd(a.dgamma + c, dg[c]);
   }
 }
 // y[o][c] = x[idx[o][c]][c]: the tangent of max-pooling (the primal pass's selection); its backward is ipoke_maxpool3d_bwd
@@ -456,7 +543,7 @@ extern "C" int ipoke_avgpool_rows_bwd(const void* dy, int ldy, void* dx, int ldx
   return IPOKE_OK;
 }
 
-/* GroupNorm tangent (see the comment at gn_jvp_kernel).  desc: the GnJvp fields as a flat argument list. */
+/* GroupNorm tangent (see the comment above gn_jvp_sums_kernel). */
 static int gn_jvp_fill(GnJvp& a, const void* x, int ldx, const void* xd, int ldxd, const void* y, int ldy, const float* gamma, int N, int S,
                        int C, int G, int act, float eps) {
   IPK_REQUIRE(x && xd && N >= 1 && S >= 1 && C >= 1 && G >= 1 && C % G == 0, "bad GroupNorm tangent arguments");
@@ -465,28 +552,47 @@ static int gn_jvp_fill(GnJvp& a, const void* x, int ldx, const void* xd, int ldx
   a.x = x; a.ldx = ldx; a.xd = xd; a.ldxd = ldxd; a.y = y; a.ldy = ldy; a.gamma = gamma; a.N = N; a.S = S; a.C = C; a.G = G; a.act = act; a.eps = eps;
   return IPOKE_OK;
 }
+
+template <bool BWD>
+static int gn_jvp_launch(const GnJvp& a, float* gsum, int dtype, void* stream) {
+  const int e16 = dtype == IPOKE_BF16 ? 8 : 4, cpg = a.C / a.G;
+  IPK_REQUIRE(a.C % e16 == 0 && (cpg % e16 == 0 || e16 % cpg == 0) && a.ldx % e16 == 0 && a.ldxd % e16 == 0, "channels / pitches: multiples of 16 bytes");
+  const int nch = (a.S + kGjPos - 1) / kGjPos;
+  const size_t lds = ((size_t)8 * a.G + a.C) * sizeof(float);
+  IPK_HIP(hipMemsetAsync(gsum, 0, (size_t)a.N * a.G * 8 * sizeof(float), STREAM(stream)));
+  if (dtype == IPOKE_BF16) {
+    hipLaunchKernelGGL((gn_jvp_sums_kernel<bf16_t, BWD>), dim3(nch, a.N), dim3(256), 0, STREAM(stream), a, gsum);
+    hipLaunchKernelGGL((gn_jvp_apply_kernel<bf16_t, BWD>), dim3(nch, a.N), dim3(256), lds, STREAM(stream), a, gsum);
+  } else {
+    hipLaunchKernelGGL((gn_jvp_sums_kernel<float, BWD>), dim3(nch, a.N), dim3(256), 0, STREAM(stream), a, gsum);
+    hipLaunchKernelGGL((gn_jvp_apply_kernel<float, BWD>), dim3(nch, a.N), dim3(256), lds, STREAM(stream), a, gsum);
+  }
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+/* workspace of ipoke_groupnorm_jvp / _bwd: N * G * 8 floats */
+extern "C" long ipoke_groupnorm_jvp_workspace_floats(int N, int G) { return (long)N * G * 8; }
 extern "C" int ipoke_groupnorm_jvp(const void* x, int ldx, const void* xdot, int ldxd, const void* y, int ldy, const void* resdot, int ldres,
-                                   void* ydot, int ldyd, const float* gamma, int N, int S, int C, int G, int act, float eps, int dtype,
-                                   void* stream) {
+                                   void* ydot, int ldyd, const float* gamma, int N, int S, int C, int G, int act, float eps, float* workspace,
+                                   int dtype, void* stream) {
   GnJvp a; int rc = gn_jvp_fill(a, x, ldx, xdot, ldxd, y, ldy, gamma, N, S, C, G, act, eps); if (rc) return rc;
   IPK_REQUIRE(ydot, "null output");
   a.resd = resdot; a.ldres = ldres; a.yd = ydot; a.ldyd = ldyd;
-  if (dtype == IPOKE_BF16) hipLaunchKernelGGL((gn_jvp_kernel<bf16_t, false>), dim3(N * G), dim3(256), 0, STREAM(stream), a);
-  else hipLaunchKernelGGL((gn_jvp_kernel<float, false>), dim3(N * G), dim3(256), 0, STREAM(stream), a);
-  IPK_LAUNCH_CHECK();
+  IPK_REQUIRE(workspace, "null workspace");
+  rc = gn_jvp_launch<false>(a, workspace, dtype, stream); if (rc) return rc;
   return IPOKE_OK;
 }
 /* q: gradient on ydot.  Outputs: dxdot, dx (gradient on the PRIMAL input, through the statistics), dresdot (optional), dgamma
  * (optional, fp32 [C], accumulated atomically: zero it first). */
 extern "C" int ipoke_groupnorm_jvp_bwd(const void* x, int ldx, const void* xdot, int ldxd, const void* y, int ldy, const void* q, int ldq,
                                        void* dxdot, int lddxd, void* dx, int lddx, void* dresdot, int lddres, float* dgamma,
-                                       const float* gamma, int N, int S, int C, int G, int act, float eps, int dtype, void* stream) {
+                                       const float* gamma, int N, int S, int C, int G, int act, float eps, float* workspace, int dtype,
+                                       void* stream) {
   GnJvp a; int rc = gn_jvp_fill(a, x, ldx, xdot, ldxd, y, ldy, gamma, N, S, C, G, act, eps); if (rc) return rc;
   IPK_REQUIRE(q && dxdot && dx, "null tensor");
   a.q = q; a.ldq = ldq; a.dxd = dxdot; a.lddxd = lddxd; a.dx = dx; a.lddx = lddx; a.dresd = dresdot; a.lddresd = lddres; a.dgamma = dgamma;
-  if (dtype == IPOKE_BF16) hipLaunchKernelGGL((gn_jvp_kernel<bf16_t, true>), dim3(N * G), dim3(256), 0, STREAM(stream), a);
-  else hipLaunchKernelGGL((gn_jvp_kernel<float, true>), dim3(N * G), dim3(256), 0, STREAM(stream), a);
-  IPK_LAUNCH_CHECK();
+  IPK_REQUIRE(workspace, "null workspace");
+  rc = gn_jvp_launch<true>(a, workspace, dtype, stream); if (rc) return rc;
   return IPOKE_OK;
 }
 /* y[o][c] = x[idx[o][c]][c] for c < C (zero beyond): the tangent of MaxPool3d given the primal pass's selection. */

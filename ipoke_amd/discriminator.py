@@ -83,10 +83,11 @@ class _NormJvpFn(torch.autograd.Function):
         dt = meta["dtype"]
         yd = torch.zeros_like(xd_t) if xd_t.shape[1] > meta["C"] else torch.empty_like(xd_t)
         g32 = None if gamma is None else gamma.detach().float().contiguous()
+        ws = torch.empty(meta["N"] * meta["G"] * 8, dtype=torch.float32, device=x_t.device)
         check(_lib.lib().ipoke_groupnorm_jvp(ptr(x_t), x_t.shape[1], ptr(xd_t), xd_t.shape[1], ptr(y_t), y_t.shape[1],
                                              None if resd_t is None else ptr(resd_t), 0 if resd_t is None else resd_t.shape[1],
                                              ptr(yd), yd.shape[1], None if g32 is None else ptr(g32), meta["N"], meta["S"], meta["C"],
-                                             meta["G"], meta["act"], 1e-5, ops._dt(dt), _lib.current_stream()))
+                                             meta["G"], meta["act"], 1e-5, ptr(ws), ops._dt(dt), _lib.current_stream()))
         ctx.save_for_backward(x_t, xd_t, y_t, g32)
         ctx.meta, ctx.has_res = meta, resd_t is not None
         return yd
@@ -100,10 +101,11 @@ class _NormJvpFn(torch.autograd.Function):
         dx = torch.zeros_like(x_t) if x_t.shape[1] > m["C"] else torch.empty_like(x_t)
         dres = (torch.zeros_like(xd_t) if xd_t.shape[1] > m["C"] else torch.empty_like(xd_t)) if ctx.has_res else None
         dgamma = None if g32 is None else torch.zeros(m["C"], dtype=torch.float32, device=q.device)
+        ws = torch.empty(m["N"] * m["G"] * 8, dtype=torch.float32, device=q.device)
         check(_lib.lib().ipoke_groupnorm_jvp_bwd(ptr(x_t), x_t.shape[1], ptr(xd_t), xd_t.shape[1], ptr(y_t), y_t.shape[1], ptr(q), q.shape[1],
                                                  ptr(dxd), dxd.shape[1], ptr(dx), dx.shape[1], None if dres is None else ptr(dres),
                                                  0 if dres is None else dres.shape[1], None if dgamma is None else ptr(dgamma),
-                                                 None if g32 is None else ptr(g32), m["N"], m["S"], m["C"], m["G"], m["act"], 1e-5,
+                                                 None if g32 is None else ptr(g32), m["N"], m["S"], m["C"], m["G"], m["act"], 1e-5, ptr(ws),
                                                  ops._dt(m["dtype"]), _lib.current_stream()))
         return dx, dxd, None, dres, dgamma, None
 
