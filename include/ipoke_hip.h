@@ -478,6 +478,11 @@ long ipoke_groupnorm_jvp_workspace_floats(int N, int G);     /* workspace of the
 /* y[o][c] = x[idx[o][c]][c]: the tangent of MaxPool3d under the primal pass's selection (idx of ipoke_maxpool3d_fwd). */
 int ipoke_gather_rows(const void* x, int ldx, const int* idx, void* y, int ldy, int64_t Mo, int C, int dtype, void* stream);
 
+/* Feature-matching term of the discriminators (patchgan_3d.py:297-304, patchgan.py:449-457): loss[0] += scale * sum |a - b| over
+ * two channels-last maps of the compute dtype; grad [M][ldg] = scale * sign(a - b), the gradient w.r.t. a. */
+int ipoke_l1_pair(const void* a, int lda, const void* b, int ldb, int64_t M, int C, float scale, float* loss, void* grad, int ldg, int dtype,
+                  void* stream);
+
 /* reparameterize backward: dmulv = [dz + dmu | dz*eps*exp(lv/2)/2 + dlv]  (any of dz/dmu/dlv may be NULL) */
 int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, const float* dz, const float* dmu, const float* dlv, void* dmulv,
                       int ldo, int64_t M, int Z, int dtype, void* stream);

@@ -161,6 +161,7 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
     "ipoke_groupnorm_jvp_workspace_floats": (ctypes.c_long, [c_int, c_int]),
     "ipoke_gather_rows": (c_int, [_P, c_int, _P, _P, c_int, c_int64, c_int, c_int, _P]),
+    "ipoke_l1_pair": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_float, _P, _P, c_int, c_int, _P]),
     "ipoke_kl_loss": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P]),

@@ -392,6 +392,29 @@ __global__ void gather_rows_kernel(const T* __restrict__ x, int ldx, const int* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- feature matching
+// loss += scale * sum |a - b|,  grad = scale * sign(a - b)   (fmap_loss of the discriminators, patchgan_3d.py:297-304) on two
+// channels-last maps of the compute dtype
+template <typename T>
+__global__ __launch_bounds__(256) void l1_pair_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb, long M, int C, float scale,
+                                                      float* __restrict__ loss, T* __restrict__ grad, int ldg) {
+  __shared__ float red[4];
+  const long total = M * ldg;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % ldg); const long m = i / ldg;
+    float g = 0.f;
+    if (c < C) {
+      const float d = ET<T>::to_f32(a[m * lda + c]) - ET<T>::to_f32(b[m * ldb + c]);
+      s += fabsf(d);
+      g = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+    }
+    grad[i] = ET<T>::from_f32(g);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(loss, scale * s);
+}
+
 static int grid1(long n, int cap = 2048) { long g = (n + 255) / 256; if (g < 1) g = 1; if (g > cap) g = cap; return (int)g; }
 
 }  // namespace ipoke
@@ -602,6 +625,20 @@ extern "C" int ipoke_gather_rows(const void* x, int ldx, const int* idx, void* y
     hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(grid1(Mo * ldy, 4096)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx, idx, (bf16_t*)y, ldy, (long)Mo, C);
   else
     hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid1(Mo * ldy, 4096)), dim3(256), 0, STREAM(stream), (const float*)x, ldx, idx, (float*)y, ldy, (long)Mo, C);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* loss[0] += scale * sum_{m, c < C} |a - b|; grad [M][ldg] = scale * sign(a - b) (zero beyond C). */
+extern "C" int ipoke_l1_pair(const void* a, int lda, const void* b, int ldb, int64_t M, int C, float scale, float* loss, void* grad, int ldg,
+                             int dtype, void* stream) {
+  IPK_REQUIRE(a && b && loss && grad && M >= 1 && C >= 1 && lda >= C && ldb >= C && ldg >= C, "bad arguments");
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(l1_pair_kernel<bf16_t>, dim3(grid1(M * ldg, 1024)), dim3(256), 0, STREAM(stream), (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
+                       (long)M, C, scale, loss, (bf16_t*)grad, ldg);
+  else
+    hipLaunchKernelGGL(l1_pair_kernel<float>, dim3(grid1(M * ldg, 1024)), dim3(256), 0, STREAM(stream), (const float*)a, lda, (const float*)b, ldb,
+                       (long)M, C, scale, loss, (float*)grad, ldg);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

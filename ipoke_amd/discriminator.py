@@ -69,6 +69,26 @@ class _AvgPoolRowsFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class _L1MeanFn(torch.autograd.Function):
+    """mean |a - b| over the real channels of two channels-last maps; the gradient flows into ``a`` only (``b`` = the true
+    clip's map, which the generator step does not differentiate)."""
+
+    @staticmethod
+    def forward(ctx, a_t, b_t, C, dtype):
+        M = a_t.shape[0]
+        loss = torch.zeros(1, device=a_t.device)
+        grad = torch.empty_like(a_t)
+        check(_lib.lib().ipoke_l1_pair(ptr(a_t), a_t.shape[1], ptr(b_t), b_t.shape[1], M, C, 1.0 / (M * C), ptr(loss), ptr(grad), grad.shape[1],
+                                       ops._dt(dtype), _lib.current_stream()))
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, d):
+        (grad,) = ctx.saved_tensors
+        return grad * d.to(grad.dtype), None, None, None
+
+
 def max_pool3d(x, k, s, p, dtype):
     y, _ = _MaxPool3dFn.apply(x.t, x.N, x.C, tuple(x.dhw), tuple(k), tuple(s), tuple(p), dtype)
     odhw = tuple((i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip(x.dhw, k, s, p))
@@ -238,11 +258,12 @@ class TemporalDiscriminator(nn.Module):
     def loss(pred, real):
         return torch.relu(1.0 - pred).mean() if real else torch.relu(1.0 + pred).mean()
 
-    @staticmethod
-    def fmap_loss(fmap1, fmap2):
+    def fmap_loss(self, fmap1, fmap2):
+        """mean over the maps of mean |f1 - f2| (:297-304); differentiated w.r.t. ``fmap1`` (the fake clip's maps) only, as the
+        generator step uses it (the discriminator gradients of that step are discarded by the next ``zero_grad``)."""
         tot = 0.0
         for a, b in zip(fmap1, fmap2):
-            tot = tot + (a.t[:, :a.C].float() - b.t[:, :b.C].float()).abs().mean()
+            tot = tot + _L1MeanFn.apply(a.t, b.t.detach(), a.C, self.dtype)
         return tot / len(fmap1)
 
     def forward_with_tangent(self, x, v):
@@ -342,7 +363,7 @@ class PatchDiscriminator(nn.Module):
         return pred, fmap
 
     loss = staticmethod(TemporalDiscriminator.loss)
-    fmap_loss = staticmethod(TemporalDiscriminator.fmap_loss)
+    fmap_loss = TemporalDiscriminator.fmap_loss
 
     def gp(self, pred, x):
         raise NotImplementedError("gradient penalty (patchgan.py:438-447) needs double backward: not built (DESIGN.md section 9); "
