@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 from ipoke_amd import _lib, configs, dist as D, ops                      # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3       # f32-input matrix cores (v_mfma_f32_16x16x4_f32): 1/16 of the bf16 rate, same guide
 FLOW_GFLOP = {32: 134.95304192, 64: 158.35070464}      # per sample forward
 ENC_GFLOP = {128: 82.96, 64: 20.52}
 
@@ -238,7 +239,26 @@ def secondary(args, cfg, rank, world, device):
     """c4: first-stage VAE train step; c5: sampling.  Same timing contract as the headline run."""
     B, T, size, z = cfg["batch_size"], cfg["n_frames"], cfg["spatial_size"], cfg["z_dim"]
     batch = synthetic_batch(B, T, size, seed=1 + rank, device=device)
-    if args.config == "c4gan":
+    if args.config == "fvd":
+        # the FVD evaluation's device work per I3D batch (utils/metrics.py:679-731, 787-800): 224x224 bilinear resize + de-normalisation
+        # + the I3D trunk to 400 logits; fp32 arithmetic as in the reference unless --dtype bf16 is forced with --fvd-dtype
+        from ipoke_amd import fvd
+        from ipoke_amd.utils.detfill import deterministic_fill_
+        net = fvd.I3D(400, "rgb", dtype=args.fvd_dtype, device="cpu")
+        deterministic_fill_(net, prefix="i3d.")
+        net.to(device)
+        vids = batch["images"]
+        minval = fvd._resized_min(vids)
+        net.logits_of_videos(vids, (224, 224), minval)
+        net.gflop = 0.0
+        net.logits_of_videos(vids, (224, 224), minval)
+        gflop = net.gflop
+        step = lambda i: net.logits_of_videos(vids, (224, 224), minval)
+        metric, frames = "video-frames/sec (FVD evaluation: 224x224 resize + I3D logits)", world * B * T
+        workload = (f"I3D (Kinetics RGB, 12.7 M parameters, 58 convolutions) on {T}x3x{size}x{size} clips resized to 224x224, batch {B} "
+                    f"(bs_i3d), {args.fvd_dtype} arithmetic, {gflop / B:.1f} GFLOP per clip")
+        args.dtype = args.fvd_dtype
+    elif args.config == "c4gan":
         # the reference's real first-stage step (first_stage_motion_model.py:160-277, config/first_stage.yaml d_t / d_s) without
         # the VGG term: L1 + KL + temporal discriminator (hinge + gradient penalty) + spatial discriminator + generator terms
         import numpy as np
@@ -321,9 +341,16 @@ def secondary(args, cfg, rank, world, device):
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": workload, "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
                            "weights": "random init of the named architecture (no checkpoints offline)"},
-                "roofline": kernel_roofline(B, args.dtype)}
+                "roofline": kernel_roofline(B, args.dtype) if args.config != "fvd" else None}
         if args.config in ("c4", "c4gan"):
             line["loss"] = round(float(out.item()), 4)
+        if args.config == "fvd":
+            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            line["algorithmic_tflop_per_step_per_gpu"] = round(gflop / 1e3, 3)
+            line["step_mfma_frac"] = round(gflop / 1e3 / (ms * 1e-3) / peak, 4)
+            line["roofline"] = {"bound": "mfma", "achieved": round(gflop / 1e3 / (ms * 1e-3), 2), "peak": peak, "unit": "TFLOP/s",
+                                "frac": line["step_mfma_frac"], "traffic": None,
+                                "kernel": "whole I3D batch (58 implicit-GEMM launches + 13 pools + resize), wall clock of the step"}
         if graph:
             line["hipgraph"] = graph
             line["algorithmic_tflop_per_step_per_gpu"] = round(B * (FLOW_GFLOP[z] + 244.3) / 1e3, 2)     # un-hoisted
@@ -337,11 +364,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c4gan", "c5"],
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c4gan", "c5", "fvd"],
                     help="c2 (default) is the configuration BASELINE.json's metric is quoted on; c4 = first-stage VAE train step "
                          "(L1 + KL), c5 = sampling (reverse flow + 15-frame decode): secondary workloads of SURVEY.md §8d")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--fvd-dtype", default="f32", choices=["bf16", "f32"], help="arithmetic of --config fvd (the reference's I3D runs fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=1)
     ap.add_argument("--cpu-timeout", type=int, default=420)
@@ -362,7 +390,7 @@ def main():
         cfg["batch_size"] = args.batch
     B, T, size, z = cfg["batch_size"], cfg["n_frames"], cfg["spatial_size"], cfg["z_dim"]
 
-    if args.config in ("c4", "c4gan", "c5"):
+    if args.config in ("c4", "c4gan", "c5", "fvd"):
         secondary(args, cfg, rank, world, device)
         return
 

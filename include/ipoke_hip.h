@@ -491,6 +491,31 @@ int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, const float* d
 int ipoke_l1_loss(const float* yhat_cl, int ldy, const float* x_nchw, int N, int C, int S, int64_t x_sn, float scale,
                   float* loss_accum, float* grad_cl, int ldg, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * FVD evaluation (reference utils/metrics.py; host side in ipoke_amd/fvd.py).  The I3D convolutions are ipoke_conv_forward
+ * with the eval-mode BatchNorm folded into weight and bias; these are the element-wise / window kernels around them.
+ * ------------------------------------------------------------------------------------------- */
+/* metrics.py:787-792 (F.interpolate(..., mode='bilinear', size=(224, 224), align_corners=True) of every frame): frame f of clip n
+ * of a strided fp32 tensor (element strides s_n, s_f, s_c, s_h, s_w) -> channels-last fp32 rows dst[(frame*Ho + y)*Wp + pad_l + x][C],
+ * Wp = pad_l + Wo + pad_r, border columns zero (the stem convolution's TF-SAME padding along W is stored so that it can read a
+ * 7-pixel window as one tap).  minval (may be NULL) receives the running minimum of the produced values (start it with
+ * ipoke_min_reset); dst == NULL takes the minimum only.  With Ho == Hi, Wo == Wi the copy is exact. */
+int ipoke_video_to_cl(const float* src, int64_t s_n, int64_t s_f, int64_t s_c, int64_t s_h, int64_t s_w, int N, int T, int C, int Hi,
+                      int Wi, float* dst, int Ho, int Wo, int pad_l, int pad_r, float* minval, void* stream);
+int ipoke_min_reset(float* minval, void* stream);
+/* metrics.py:794-798: x = (x + 1) / 2 on the interior columns of `rows` padded rows when *minval < 0 (decided on the device) */
+int ipoke_denorm_if_negative(float* x, int64_t rows, int Wo, int pad_l, int pad_r, int C, const float* minval, void* stream);
+/* metrics.py:939-960 MaxPool3dTFPadding: ZERO padding, then MaxPool3d(ceil_mode=True), on channels-last rows of the compute dtype.
+ * dims = {N, C, Di, Hi, Wi, Do, Ho, Wo, kd, kh, kw, sd, sh, sw, pd, ph, pw, ed, eh, ew}: p* = front padding, e* = input extent +
+ * back padding (window positions in the zero border count as 0, positions beyond it are ignored). */
+int ipoke_pool3d_same(const int* dims, const void* x, int ldx, void* y, int ldy, int dtype, void* stream);
+/* y[g][c] = sum_k w[k] x[g*S + k][c] (w: device fp32 [S]): metrics.py:1085, 1091 -- AvgPool3d((2, 7, 7), 1) and the mean over the
+ * remaining time steps as one weighted mean over a clip's rows, taken before the (linear) logits convolution. */
+int ipoke_pool_rows_weighted(const void* x, int ldx, void* y, int ldy, int64_t G, int S, int C, const float* w, int dtype, void* stream);
+/* metrics.py:733-771 (calculate_moments / calculate_activation_statistics): rows of act fp32 [n][D] without any non-NaN entry are
+ * dropped, mu = mean, sigma = np.cov(rowvar=False), both float64.  workspace: (n + 1) int32. */
+int ipoke_activation_moments(const float* act, int n, int D, double* mu, double* sigma, int* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

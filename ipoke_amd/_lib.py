@@ -170,6 +170,13 @@ SIGNATURES = {
     "ipoke_flow_prepare_weights_range": (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
     "ipoke_wn_bwd_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_flow_backward_pieces": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, GRAD_READY_FN, _P, _P]),
+    "ipoke_video_to_cl": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int,
+                                  c_int, _P, _P]),
+    "ipoke_min_reset": (c_int, [_P, _P]),
+    "ipoke_denorm_if_negative": (c_int, [_P, c_int64, c_int, c_int, c_int, c_int, _P, _P]),
+    "ipoke_pool3d_same": (c_int, [_P, _P, c_int, _P, c_int, c_int, _P]),
+    "ipoke_pool_rows_weighted": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, _P, c_int, _P]),
+    "ipoke_activation_moments": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "ipoke_timing_start": (c_int, []),
     "ipoke_timing_stop": (c_int, [POINTER(c_int), c_int, POINTER(c_int), POINTER(ctypes.c_double)]),
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),

@@ -60,6 +60,7 @@ def first_stage_config(spatial_size=128, z_dim=32, n_frames=16):
     return {
         "data": {"spatial_size": (spatial_size, spatial_size), "max_frames": n_frames - 1, "batch_size": 20},
         "training": {"lr": 2e-4, "weight_decay": 1e-5, "w_kl": 1e-7, "w_l1": 10, "w_vgg": 10, "full_sequence": True},
+        "logging": {"bs_i3d": 8},
         "architecture": {
             "ENC_M_channels": enc, "decoder_factor": 32, "z_dim": z_dim, "norm": "group", "CN_content": "spade",
             "CN_motion": "ADAIN", "spectral_norm": True, "running_stats": False, "n_gru_layers": 4,
@@ -87,7 +88,7 @@ def second_stage_config(spatial_size=128, z_dim=64, n_frames=16, batch_size=20, 
                      "lr_scaling": True, "lr_scaling_max_it": 500, "custom_lr_decrease": True, "mixed_prec": False,
                      "full_seq": True, "spatial_mean": False, "use_adabelief": False},
         "testing": {"n_samples_per_data_point": 5},
-        "logging": {"log_train_prog_at": 200, "n_samples": 4, "n_log_images": 8},
+        "logging": {"log_train_prog_at": 200, "n_samples": 4, "n_log_images": 8, "n_fvd_samples": 1000},
         "conditioner": {"use": True},
         "first_stage": first_stage_config(spatial_size, z_dim, n_frames),
         "poke_embedder": encoder2d_config(spatial_size, 2),
@@ -103,4 +104,5 @@ BENCH_CONFIGS = {
     "c4": dict(name="first_stage_128", spatial_size=128, z_dim=32, n_frames=16, batch_size=20),
     "c4gan": dict(name="first_stage_128_gan", spatial_size=128, z_dim=32, n_frames=16, batch_size=20),
     "c5": dict(name="h36m_128", spatial_size=128, z_dim=64, n_frames=16, batch_size=32),
+    "fvd": dict(name="fvd_i3d", spatial_size=128, z_dim=64, n_frames=16, batch_size=8),      # first_stage.yaml:92 bs_i3d
 }

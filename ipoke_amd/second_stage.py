@@ -253,6 +253,45 @@ class PokeMotionModel(nn.Module):
             self.log("learning_rate", self._optimizer.param_groups[0]["lr"])
         return loss
 
+    # ---- validation loop (second_stage_video.py:490-584) --------------------------------------------------
+    def attach_fvd(self, i3d=None, dtype="f32"):
+        """The reference builds ``self.FVD = FVD(n_samples=...)`` with the Kinetics I3D weights in __init__ (:66); here the metric
+        is attached explicitly (the I3D checkpoint is not part of the second-stage checkpoint)."""
+        from .fvd import FVD
+        self.FVD = FVD(n_samples=self.config["logging"]["n_fvd_samples"], i3d=i3d, dtype=dtype)
+        self._fvd_fake, self._fvd_true, self._fvd_fake_x0, self._fvd_true_x0 = [], [], [], []
+        return self.FVD
+
+    def validation_step(self, batch, batch_id):
+        """NLL terms of the batch, and (for the first n_fvd_samples clips) one sampled video per clip kept for the FVD of the
+        epoch; generated and true clips stay on the device.  ssim / psnr / lpips of the reference's logging (:510-514) come
+        from pytorch_lightning.metrics / the lpips package and are not part of this path."""
+        with torch.no_grad():
+            out, logdet = self.forward_density(batch)
+            loss, loss_dict = self.loss_func(out, logdet)
+        self.log_dict({"val/" + key: loss_dict[key] for key in loss_dict})
+        X = batch["images"]
+        if getattr(self, "FVD", None) is not None and batch_id <= int(self.config["logging"]["n_fvd_samples"] / X.size(0)):
+            X_hat = self.forward_sample(batch, n_logged_vids=X.size(0))[0].to(X.device)
+            self._fvd_fake.append(X_hat)
+            self._fvd_true.append(X[:, 1:])
+            self._fvd_fake_x0.append(torch.cat([X[:, 0].unsqueeze(1), X_hat], dim=1))
+            self._fvd_true_x0.append(X)
+        self.log("d_ref_nll-val", torch.abs(loss_dict["reference_nll_loss"] - loss_dict["nll_loss"]))
+        self.log("loss-val", loss)
+        return {"loss": loss, "batch_idx": batch_id, "loss_dict": loss_dict}
+
+    def validation_epoch_end(self, outputs=None):
+        from .fvd import calculate_FVD
+        bs = self.first_stage_config["logging"]["bs_i3d"]
+        fvd_score = calculate_FVD(self.FVD.i3d, torch.cat(self._fvd_fake), torch.cat(self._fvd_true), batch_size=bs)
+        self.log("FVD-val", fvd_score)
+        fvd_x0 = calculate_FVD(self.FVD.i3d, torch.cat(self._fvd_fake_x0), torch.cat(self._fvd_true_x0), batch_size=bs)
+        self.log("FVD-val-x0", fvd_x0)
+        for lst in (self._fvd_fake, self._fvd_true, self._fvd_fake_x0, self._fvd_true_x0):
+            lst.clear()
+        return fvd_score, fvd_x0
+
     def configure_optimizers(self):
         tr = self.config["training"]
         self._optimizer = FusedAdamAmsgrad(self.flow, lr=tr["lr"], betas=(0.9, 0.999), weight_decay=tr["weight_decay"], amsgrad=True)

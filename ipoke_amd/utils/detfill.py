@@ -48,6 +48,8 @@ def fill_value(key, ref):
         return 0.03 * _randn(shape, g)
     if leaf == "motion_bias":
         return _randn(shape, g)
+    if leaf == "running_var":                        # BatchNorm statistics of the I3D network: positive variances
+        return 0.5 + torch.rand(shape, generator=g)
     if leaf in ("gamma",):
         return 1.0 + 0.1 * _randn(shape, g)
     squeezed = [s for s in shape if s != 1]

@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 from ipoke_amd import configs                                    # noqa: E402
 from ipoke_amd.utils.detfill import deterministic_fill_          # noqa: E402
-from oracle import disc_ref, flow_ref, ref_import, vae_ref       # noqa: E402
+from oracle import disc_ref, flow_ref, fvd_ref, ref_import, vae_ref      # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -792,12 +792,62 @@ def g9_patch_disc():
     npz("g9_patch_disc_64", **arrs)
 
 
+def g10_fvd():
+    """G10: the FVD evaluation (utils/metrics.py:679-800, 813-1099): I3D logits of 64x64 clips after the 224x224 bilinear
+    preprocess, for 16-frame (FVD-val-x0) and 15-frame (FVD-val) clips, named intermediate maps of the first clip, the
+    activation moments and the Frechet distance of N = 6 generated against 6 original clips (I3D batch 3)."""
+    mt = ref_import.ref("utils.metrics")
+    m = mt.I3D(400, "rgb")
+    deterministic_fill_(m, prefix="i3d.")
+    m.eval()
+    o = fvd_ref.I3D(400)
+    assert set(m.state_dict()) == set(o.state_dict()), set(m.state_dict()) ^ set(o.state_dict())
+    o.load_state_dict(m.state_dict())
+    o.eval()
+    N = 6
+    orig = torch.rand(N, 16, 3, 64, 64, generator=gen(101)) * 2 - 1
+    gen_ = (orig + 0.35 * torch.randn(N, 16, 3, 64, 64, generator=gen(102))).clamp(-1, 1)
+    arrs = dict(videos_orig=orig.half(), videos_gen=gen_.half())
+    orig, gen_ = orig.half().float(), gen_.half().float()          # the fixture stores fp16: use exactly those values
+    for T in (16, 15):
+        vo, vg = orig[:, 16 - T:], gen_[:, 16 - T:]
+        pg, po = mt.preprocess(vg, vo)
+        close(fvd_ref.preprocess(vg), pg, 1e-6, "G10 preprocess"); close(fvd_ref.preprocess(vo), po, 1e-6, "G10 preprocess")
+        a_ref = mt.get_activations(po, m, 3)
+        a_or = fvd_ref.activations(o, po, 3)
+        close(torch.from_numpy(a_or), torch.from_numpy(a_ref), 2e-5, f"G10 logits T={T}")
+        f_ref = mt.calculate_FVD(m, vg, vo, batch_size=3, cuda=False)
+        f_or = fvd_ref.fvd(o, vg, vo, 3)
+        assert abs(f_ref - f_or) <= 1e-3 * abs(f_ref) + 1e-3, (f_ref, f_or)
+        print(f"  T={T}: FVD reference {f_ref:.6f} oracle {f_or:.6f}; logits |max| {np.abs(a_ref).max():.3f}")
+        mu, sg = mt.calculate_activation_statistics(pg, m, 3, cuda=False)
+        arrs[f"logits_orig_T{T}"] = a_ref
+        arrs[f"logits_gen_T{T}"] = mt.get_activations(pg, m, 3)
+        arrs[f"mu_gen_T{T}"] = mu
+        arrs[f"sigma_gen_checksum_T{T}"] = checksum(torch.from_numpy(sg), "sigma")
+        arrs[f"fvd_T{T}"] = np.float64(f_ref)
+        if T == 16:
+            taps = {}
+            with torch.no_grad():
+                x = po[:1].permute(0, 2, 1, 3, 4)
+                lo = o(x, taps)
+                # the same maps from the reference's sub-modules
+                r = m.maxPool3d_2a_3x3(m.conv3d_1a_7x7(x)); close(taps["pool2a"], r, 2e-5, "G10 pool2a")
+                r = m.maxPool3d_3a_3x3(m.conv3d_2c_3x3(m.conv3d_2b_1x1(r))); close(taps["pool3a"], r, 2e-5, "G10 pool3a")
+                r = m.mixed_3b(r); close(taps["mixed_3b"], r, 2e-5, "G10 mixed_3b")
+                r = m.maxPool3d_4a_3x3(m.mixed_3c(r)); close(taps["pool4a"], r, 2e-5, "G10 pool4a")
+            for k, t in taps.items():
+                arrs[f"tap_{k}_checksum"] = checksum(t, k)
+                arrs[f"tap_{k}_slice"] = t[0, :6, :2, :5, :5]
+    npz("g10_fvd", **arrs)
+
+
 def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
             "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
-            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc}
+            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd}
     for name in (which or list(jobs)):
         print(f"[{name}]")
         t = time.time()

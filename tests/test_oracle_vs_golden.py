@@ -243,3 +243,31 @@ def test_patch_discriminator(golden):
     for k, want in zip(g["grad_names"], g["grad_checksums"]):
         got = _checksum(grads[str(k)].grad, str(k))
         assert np.allclose(got, want, rtol=2e-3, atol=1e-5 * max(1.0, abs(want[1]))), k
+
+
+def test_fvd_oracle(golden):
+    """G10: oracle/fvd_ref (I3D, preprocess, moments, Frechet distance) against the reference's logits, moments and FVD value."""
+    from oracle import fvd_ref
+    g = golden("g10_fvd")
+    o = fvd_ref.I3D(400)
+    deterministic_fill_(o, prefix="i3d.")
+    o.eval()
+    vo, vg = t(g["videos_orig"]).float()[:, 1:], t(g["videos_gen"]).float()[:, 1:]
+    a = fvd_ref.activations(o, fvd_ref.preprocess(vg), 3)
+    assert np.abs(a - g["logits_gen_T15"]).max() <= 5e-5
+    mu, sigma = fvd_ref.moments(a)
+    assert np.abs(mu - g["mu_gen_T15"]).max() <= 5e-5
+    assert np.allclose(_checksum(torch.from_numpy(sigma), "sigma"), g["sigma_gen_checksum_T15"], rtol=1e-4, atol=1e-4)
+    mo, so = fvd_ref.moments(g["logits_orig_T15"])
+    assert abs(fvd_ref.frechet_distance(mu, sigma, mo, so) - float(g["fvd_T15"])) <= 1e-3 * float(g["fvd_T15"])
+    del vo
+
+
+def test_fvd_state_dict_keys():
+    """The product I3D (parameter container only on CPU) and the oracle share the reference's state-dict keys and shapes."""
+    from ipoke_amd import fvd
+    from oracle import fvd_ref
+    a = fvd.I3D(400, "rgb", device="cpu").state_dict()
+    b = fvd_ref.I3D(400).state_dict()
+    assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
+    assert "mixed_3b.branch_3.1.conv3d.weight" in a and "conv3d_0c_1x1.conv3d.bias" in a and len(a) == 344
