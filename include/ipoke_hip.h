@@ -516,6 +516,25 @@ int ipoke_pool_rows_weighted(const void* x, int ldx, void* y, int ldy, int64_t G
  * dropped, mu = mean, sigma = np.cov(rowvar=False), both float64.  workspace: (n + 1) int32. */
 int ipoke_activation_moments(const float* act, int n, int D, double* mu, double* sigma, int* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input pipeline on the device (reference data/base_dataset.py; host side in ipoke_amd/data.py).
+ * ------------------------------------------------------------------------------------------- */
+/* _get_flow (:651-693): dst [B][C][Ho][Wo] = bilinear, align_corners=True, of src [B][C][Hi][Wi] / divide_by (the division is applied
+ * to the source values first, as the reference does for scale_poke_to_res: divide_by = Hi / Ho; pass 1 otherwise). */
+int ipoke_flow_resize(const float* src, float* dst, int B, int C, int Hi, int Wi, int Ho, int Wo, float divide_by, void* stream);
+/* _get_poke (:507-648) for a batch of flows [B][2][H][W]: candidate positions from the normalised flow amplitude on the window
+ * [poke_size, size - poke_size)^2 (amplitude > mean + 2 std, fallbacks > mean + std, > mean; zero-poke samples: centres below the
+ * 5th percentile, values from positions > mean + std / > mean), the number of pokes and the picks from the caller's uniforms
+ * u [B][1 + 2 n_pokes] in [0, 1): u[0] -> count = 1 + floor(u min(n_pokes, #candidates)) unless fix_n_pokes, u[1 .. n_pokes] -> value
+ * sources (zero-poke samples), u[1 + n_pokes ..] -> centres, each as floor(u * #set) in row-major order of the set.
+ * Outputs: poke [B][2][H][W] (later pokes overwrite earlier ones), centers int64 [B][n_pokes][2] = (row, col), -1 padded,
+ * flow_out (optional) = flow, zeroed for zero-poke samples (:680-681), status [B] (1: no candidate -- the reference raises FlowError
+ * and resamples).  zero_poke: int32 [B] or NULL.  workspace: ipoke_poke_workspace_bytes. */
+int64_t ipoke_poke_workspace_bytes(int B, int H, int W, int poke_size, int n_pokes);
+int ipoke_poke_simulate(const float* flow, int B, int H, int W, int poke_size, int n_pokes, int fix_n_pokes, int equal_poke_val,
+                        const int* zero_poke, const float* u, float* poke, int64_t* centers, float* flow_out, int* status, void* workspace,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

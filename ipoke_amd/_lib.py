@@ -177,6 +177,9 @@ SIGNATURES = {
     "ipoke_pool3d_same": (c_int, [_P, _P, c_int, _P, c_int, c_int, _P]),
     "ipoke_pool_rows_weighted": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, _P, c_int, _P]),
     "ipoke_activation_moments": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
+    "ipoke_flow_resize": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "ipoke_poke_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "ipoke_poke_simulate": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ipoke_timing_start": (c_int, []),
     "ipoke_timing_stop": (c_int, [POINTER(c_int), c_int, POINTER(c_int), POINTER(ctypes.c_double)]),
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),

@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 from ipoke_amd import configs                                    # noqa: E402
 from ipoke_amd.utils.detfill import deterministic_fill_          # noqa: E402
-from oracle import disc_ref, flow_ref, fvd_ref, ref_import, vae_ref      # noqa: E402
+from oracle import data_ref, disc_ref, flow_ref, fvd_ref, ref_import, vae_ref      # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -842,12 +842,79 @@ def g10_fvd():
     npz("g10_fvd", **arrs)
 
 
+def _synthetic_raw_flow(seed, hs, kind):
+    """Smooth synthetic optical flow [2, hs, hs]: a few moving blobs on a still background ("blobs"), a nearly uniform field whose
+    amplitude has no outliers beyond two standard deviations ("flat"), or a dense random field ("dense")."""
+    g = gen(seed)
+    if kind == "flat":
+        yy, xx = torch.meshgrid(torch.linspace(-1, 1, hs), torch.linspace(-1, 1, hs), indexing="ij")
+        return torch.stack([1.0 + 0.5 * xx, 0.3 * yy]).numpy().astype(np.float32) * 6
+    coarse = torch.randn(1, 2, 6, 6, generator=g)
+    if kind == "blobs":
+        coarse = coarse * (torch.rand(1, 1, 6, 6, generator=g) < 0.2)
+    f = torch.nn.functional.interpolate(coarse, size=(hs, hs), mode="bicubic", align_corners=False)[0] * 12
+    return (f + 0.05 * torch.randn(2, hs, hs, generator=g)).numpy().astype(np.float32)
+
+
+def g11_data():
+    """G11: the data path (data/base_dataset.py: _get_flow :651-693, _get_poke :507-648) run through the reference's own methods on
+    synthetic raw flows: resized flows, pokes and poke centres for ordinary and zero-poke samples, equal_poke_val on and off, fixed
+    and drawn poke counts, and a flat field that exercises the threshold fallbacks.  np.random.randint is replaced by
+    oracle.data_ref.UniformDraws fed with the stored uniforms while the reference runs."""
+    import tempfile
+    import types
+    np.int = int                                            # the reference predates numpy 1.24
+    bd = ref_import.ref("data.base_dataset")
+    tmp = tempfile.mkdtemp()
+    cases = []
+    for size, hs, poke_size in ((64, 96, 5), (128, 160, 5), (128, 160, 10)):
+        for j, kind in enumerate(("blobs", "dense", "flat", "blobs")):
+            for zero in (False, True):
+                cases.append(dict(size=size, hs=hs, poke_size=poke_size, kind=kind, zero=zero, seed=1000 * size + 10 * j + int(zero) + poke_size,
+                                  equal=(j != 3), fix=(j == 1 and poke_size == 10)))
+    arrs = {"n_cases": np.int64(len(cases))}
+    for ci, c in enumerate(cases):
+        raw = _synthetic_raw_flow(c["seed"], c["hs"], c["kind"])
+        path = os.path.join(tmp, f"flow{ci}.npy")
+        np.save(path, raw)
+        size = c["size"]
+        cfg = {"spatial_size": (size, size), "n_pokes": 5, "poke_size": c["poke_size"]}
+        fake = types.SimpleNamespace(config=cfg, datadict={"flow_paths": np.array([[path]])}, valid_lags=[0], scale_poke_to_res=True, geom_transfs=None,
+                                     poke_size=c["poke_size"], valid_h=[c["poke_size"], size - c["poke_size"]], valid_w=[c["poke_size"], size - c["poke_size"]],
+                                     filter_flow=False, fix_n_pokes=c["fix"], equal_poke_val=c["equal"])
+        fake._get_flow = lambda ids, _f=fake, **kw: bd.BaseDataset._get_flow(_f, ids, **kw)
+        ids = (0, -1 if c["zero"] else 3)
+        flow = bd.BaseDataset._get_flow(fake, (0, 3))
+        u = torch.rand(11, generator=gen(c["seed"] + 7)).numpy().astype(np.float32)
+        keep = np.random.randint
+        np.random.randint = data_ref.UniformDraws(u, 5, c["fix"], c["zero"])
+        try:
+            poke, centers = bd.BaseDataset._get_poke(fake, ids)
+        finally:
+            np.random.randint = keep
+        flow_ret = bd.BaseDataset._get_flow(fake, ids)             # what the sample's "flow" entry holds (zeros for zero pokes)
+        of = data_ref.get_flow(raw, (size, size), True)
+        close(of, flow, 0.0, f"G11 flow {ci}")
+        op, oc = data_ref.get_poke(of, c["poke_size"], 5, data_ref.UniformDraws(u, 5, c["fix"], c["zero"]), zero=c["zero"], fix_n_pokes=c["fix"],
+                                   equal_poke_val=c["equal"])
+        close(op, poke, 0.0, f"G11 poke {ci}")
+        assert torch.equal(oc, centers), (ci, oc, centers)
+        n = int((centers[:, 0] >= 0).sum())
+        print(f"  case {ci}: {c['kind']:5s} {size}px poke_size {c['poke_size']} zero={int(c['zero'])} equal={int(c['equal'])} fix={int(c['fix'])}: "
+              f"{n} pokes, |poke| {poke.abs().sum().item():.2f}")
+        arrs.update({f"raw{ci}": raw, f"u{ci}": u, f"flow{ci}": flow, f"flow_ret_abs{ci}": np.float64(flow_ret.abs().sum().item()),
+                     f"centers{ci}": centers.numpy(), f"poke_abs{ci}": np.float64(poke.abs().sum().item()),
+                     f"poke_nz{ci}": poke.nonzero().numpy().astype(np.int16), f"poke_val{ci}": poke[poke != 0].numpy(),
+                     f"meta{ci}": np.array([size, c["poke_size"], int(c["zero"]), int(c["equal"]), int(c["fix"])])})
+    npz("g11_data_path", **arrs)
+
+
 def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
             "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
-            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd}
+            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd, "g11": g11_data}
     for name in (which or list(jobs)):
         print(f"[{name}]")
         t = time.time()

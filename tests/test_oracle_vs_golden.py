@@ -271,3 +271,18 @@ def test_fvd_state_dict_keys():
     b = fvd_ref.I3D(400).state_dict()
     assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
     assert "mixed_3b.branch_3.1.conv3d.weight" in a and "conv3d_0c_1x1.conv3d.bias" in a and len(a) == 344
+
+
+def test_data_path_oracle(golden):
+    """G11: oracle/data_ref (flow resize, poke simulation with injected draws) against the reference's _get_flow / _get_poke."""
+    from oracle import data_ref
+    g = golden("g11_data_path")
+    for ci in range(int(g["n_cases"])):
+        size, poke_size, zero, equal, fix = (int(v) for v in g[f"meta{ci}"])
+        flow = data_ref.get_flow(g[f"raw{ci}"], (size, size), True)
+        assert torch.equal(flow, t(g[f"flow{ci}"]))
+        poke, centers = data_ref.get_poke(flow, poke_size, 5, data_ref.UniformDraws(g[f"u{ci}"], 5, bool(fix), bool(zero)), zero=bool(zero),
+                                          fix_n_pokes=bool(fix), equal_poke_val=bool(equal))
+        assert np.array_equal(centers.numpy(), g[f"centers{ci}"])
+        assert np.array_equal(poke.nonzero().numpy().astype(np.int16), g[f"poke_nz{ci}"])
+        assert np.array_equal(poke[poke != 0].numpy(), g[f"poke_val{ci}"])
