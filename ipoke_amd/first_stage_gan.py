@@ -12,9 +12,10 @@ with three ``Adam(lr, betas=(0.5, 0.9), weight_decay)`` optimisers (:376-386).  
 HIP ops of ``first_stage_train`` / ``discriminator`` and ``ipoke_adam_multi``; the gradient penalty is evaluated
 forward-over-reverse (``TemporalDiscriminator.gp2``).
 
-Deviations, both deliberate: the VGG perceptual term (``w_vgg``, utils/losses.py:67-82) needs the pretrained torchvision VGG-19
-weights, which are not available offline -- it is omitted (``w_vgg`` must be 0); the random choices of the reference's step
-(clip offset, frame examples; numpy's global RNG) are arguments, so that the caller owns the random stream.
+The VGG perceptual term (``w_vgg``, utils/losses.py:67-82) is ``ipoke_amd.vgg.VGGLoss``, passed in by the caller with the
+torchvision VGG-19 weights loaded (they are not available offline; bench and tests use random-init weights of that
+architecture).  One deliberate deviation: the random choices of the reference's step (clip offset, frame examples; numpy's
+global RNG) are arguments, so that the caller owns the random stream.
 """
 import numpy as np
 import torch
@@ -23,13 +24,14 @@ from . import first_stage_train as T
 
 
 class FirstStageGANTrainer:
-    def __init__(self, model, disc_t, disc_s, cfg):
+    def __init__(self, model, disc_t, disc_s, cfg, vgg_loss=None):
         """``cfg``: the reference's config sections -- cfg["training"] (lr, weight_decay, w_l1, w_kl, w_vgg), cfg["d_t"]
         (gp_weight, fmap_weight, gen_weight, max_frames), cfg["d_s"] (n_examples, gen_weight, fmap_weight),
         cfg["data"]["max_frames"]."""
         tr = cfg["training"]
-        if float(tr.get("w_vgg", 0.0)) != 0.0:
-            raise NotImplementedError("the VGG perceptual loss needs pretrained VGG-19 weights (not available offline): set w_vgg = 0")
+        self.w_vgg, self.vgg_loss = float(tr.get("w_vgg", 0.0)), vgg_loss
+        if self.w_vgg != 0.0 and vgg_loss is None:
+            raise ValueError("w_vgg != 0 needs vgg_loss=ipoke_amd.vgg.VGGLoss(...) (load the torchvision VGG-19 weights into it)")
         self.model, self.disc_t, self.disc_s, self.cfg = model, disc_t, disc_s, cfg
         self.w_l1, self.w_kl = float(tr["w_l1"]), float(tr["w_kl"])
         self.mf_dt = min(int(cfg["d_t"]["max_frames"]), int(cfg["data"]["max_frames"]))
@@ -79,6 +81,10 @@ class FirstStageGANTrainer:
             log.update(loss_d_ds=loss_ds.detach())
         self.opt_g.zero_grad()
         total = loss_rec
+        if self.w_vgg != 0.0:                                        # (:263, :271)
+            loss_vgg = self.vgg_loss(X[:, 1:].reshape(-1, *X.shape[2:]), X_hat.reshape(-1, *X_hat.shape[2:]))
+            total = total + self.w_vgg * loss_vgg
+            log.update(loss_vgg=loss_vgg.detach())
         if ds_ is not None:
             pg, _ = ds_(x_fake, pit)
             loss_gen_ds = -pg.mean()

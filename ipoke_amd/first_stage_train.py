@@ -121,69 +121,71 @@ class _ConvFn(torch.autograd.Function):
         else:
             g = _pad_cols(dy, ldg, dt) if (dy.dtype != _tdt(dt) or dy.shape[1] != ldg) else dy.contiguous()
         d_bias = None
-        if ctx.has_bias:
+        if ctx.has_bias and ctx.needs_input_grad[2]:
             d_bias = torch.empty(cout, dtype=torch.float32, device=dy.device)
             ws = _workspace(lib.ipoke_colsum_workspace_floats(M, cout), dy.device, "colsum")
             check(lib.ipoke_colsum(ptr(g), ldg, M, cout, 0, ptr(d_bias), 0, ptr(ws), ops._dt(dt), s))
         # ---- weight gradient, PyTorch layout
-        taps = k[0] * k[1] * k[2]
-        d_w = torch.empty(w.shape, dtype=torch.float32, device=dy.device)
-        wd = WgradDesc()
-        wd.kd, wd.kh, wd.kw = k
-        wd.sd, wd.sh, wd.sw = st
-        wd.pd, wd.ph, wd.pw = pd
-        wd.NB = N
-        src = m.get("src")
-        if not m["transposed"]:
-            wd.Di, wd.Hi, wd.Wi = idhw
-            wd.Do, wd.Ho, wd.Wo = odhw
-            if src is not None:
-                t_src, _, _, _, sst = src
-                wd.A = t_src.data_ptr(); wd.a_f32 = 1
-                wd.a_sn, wd.a_sc, wd.a_sd, wd.a_sh, wd.a_sw = sst
-                wd.Kc_real = cin; wd.Kc = K.round_up(cin, e16)
-            else:
-                ld = x_t.shape[1]
-                wd.A = x_t.data_ptr(); wd.a_f32 = 0
-                wd.a_sn = idhw[0] * idhw[1] * idhw[2] * ld; wd.a_sd = idhw[1] * idhw[2] * ld; wd.a_sh = idhw[2] * ld
-                wd.a_sw = ld; wd.a_sc = 1
-                wd.Kc_real = K.round_up(cin, e16); wd.Kc = wd.Kc_real
-            wd.Kc_store = cin
-            wd.dY = g.data_ptr(); wd.ldy = ldg; wd.Nout = cout
-            wd.w_sn = cin * taps; wd.w_sc = taps; wd.w_st = 1
-        else:
-            # ConvTranspose y = C_W^T x: dW[in][out][tap] is the weight gradient of the direct conv with "input" dy, "output" x
-            ld = x_t.shape[1]
-            wd.Di, wd.Hi, wd.Wi = odhw
-            wd.Do, wd.Ho, wd.Wo = idhw
-            wd.A = g.data_ptr(); wd.a_f32 = 0
-            wd.a_sn = odhw[0] * odhw[1] * odhw[2] * ldg; wd.a_sd = odhw[1] * odhw[2] * ldg; wd.a_sh = odhw[2] * ldg
-            wd.a_sw = ldg; wd.a_sc = 1
-            wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = cout
-            wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
-            wd.w_sn = cout * taps; wd.w_sc = taps; wd.w_st = 1
-        # the reduction runs over every output position (up to B*128*128 rows) while dW has only a handful of 128x128
-        # tiles: split the rows over enough workgroups to fill the chip; every split stores its own slab, summed below
-        # (deterministic, and ~10x cheaper than fp32 atomics into the few thousand addresses of dW)
-        tiles = -(-wd.Nout // 128) * -(-(taps * wd.Kc) // 128)
-        rows = N * wd.Do * wd.Ho * wd.Wo
-        splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), 1024 // tiles))
-        if splitm > 1:
-            slabs = torch.empty(splitm, d_w.numel(), dtype=torch.float32, device=dy.device)
-            wd.splitm = splitm; wd.split_stride = d_w.numel(); wd.dW = slabs.data_ptr()
-            check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
-            check(lib.ipoke_reduce_rows(ptr(slabs), ptr(d_w), splitm, d_w.numel(), s))
-        else:
-            wd.dW = d_w.data_ptr()
-            check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+        d_w = None
         sn = m.get("sn")
-        if sn is not None:                        # d_w is the gradient w.r.t. weight_orig / sigma: fold sigma's own gradient in
-            sig, snap, bws = sn
-            t_w = 1
-            for kk in w.shape[2:]:
-                t_w *= int(kk)
-            r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
-            check(lib.ipoke_spectral_bwd(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snap), ptr(sig), ptr(bws), s))
+        if ctx.needs_input_grad[1]:                 # frozen weights (the VGG feature extractor) skip this half
+            taps = k[0] * k[1] * k[2]
+            d_w = torch.empty(w.shape, dtype=torch.float32, device=dy.device)
+            wd = WgradDesc()
+            wd.kd, wd.kh, wd.kw = k
+            wd.sd, wd.sh, wd.sw = st
+            wd.pd, wd.ph, wd.pw = pd
+            wd.NB = N
+            src = m.get("src")
+            if not m["transposed"]:
+                wd.Di, wd.Hi, wd.Wi = idhw
+                wd.Do, wd.Ho, wd.Wo = odhw
+                if src is not None:
+                    t_src, _, _, _, sst = src
+                    wd.A = t_src.data_ptr(); wd.a_f32 = 1
+                    wd.a_sn, wd.a_sc, wd.a_sd, wd.a_sh, wd.a_sw = sst
+                    wd.Kc_real = cin; wd.Kc = K.round_up(cin, e16)
+                else:
+                    ld = x_t.shape[1]
+                    wd.A = x_t.data_ptr(); wd.a_f32 = 0
+                    wd.a_sn = idhw[0] * idhw[1] * idhw[2] * ld; wd.a_sd = idhw[1] * idhw[2] * ld; wd.a_sh = idhw[2] * ld
+                    wd.a_sw = ld; wd.a_sc = 1
+                    wd.Kc_real = K.round_up(cin, e16); wd.Kc = wd.Kc_real
+                wd.Kc_store = cin
+                wd.dY = g.data_ptr(); wd.ldy = ldg; wd.Nout = cout
+                wd.w_sn = cin * taps; wd.w_sc = taps; wd.w_st = 1
+            else:
+                # ConvTranspose y = C_W^T x: dW[in][out][tap] is the weight gradient of the direct conv with "input" dy, "output" x
+                ld = x_t.shape[1]
+                wd.Di, wd.Hi, wd.Wi = odhw
+                wd.Do, wd.Ho, wd.Wo = idhw
+                wd.A = g.data_ptr(); wd.a_f32 = 0
+                wd.a_sn = odhw[0] * odhw[1] * odhw[2] * ldg; wd.a_sd = odhw[1] * odhw[2] * ldg; wd.a_sh = odhw[2] * ldg
+                wd.a_sw = ldg; wd.a_sc = 1
+                wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = cout
+                wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
+                wd.w_sn = cout * taps; wd.w_sc = taps; wd.w_st = 1
+            # the reduction runs over every output position (up to B*128*128 rows) while dW has only a handful of 128x128
+            # tiles: split the rows over enough workgroups to fill the chip; every split stores its own slab, summed below
+            # (deterministic, and ~10x cheaper than fp32 atomics into the few thousand addresses of dW)
+            tiles = -(-wd.Nout // 128) * -(-(taps * wd.Kc) // 128)
+            rows = N * wd.Do * wd.Ho * wd.Wo
+            splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), 1024 // tiles))
+            if splitm > 1:
+                slabs = torch.empty(splitm, d_w.numel(), dtype=torch.float32, device=dy.device)
+                wd.splitm = splitm; wd.split_stride = d_w.numel(); wd.dW = slabs.data_ptr()
+                check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+                check(lib.ipoke_reduce_rows(ptr(slabs), ptr(d_w), splitm, d_w.numel(), s))
+            else:
+                wd.dW = d_w.data_ptr()
+                check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+            if sn is not None:                        # d_w is the gradient w.r.t. weight_orig / sigma: fold sigma's own gradient in
+                sig, snap, bws = sn
+                t_w = 1
+                for kk in w.shape[2:]:
+                    t_w *= int(kk)
+                r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
+                check(lib.ipoke_spectral_bwd(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snap), ptr(sig), ptr(bws), s))
         # ---- data gradient: the adjoint convolution with the same weights
         d_x = None
         if x_t is not None and ctx.needs_input_grad[0]:
@@ -642,8 +644,12 @@ class FirstStageTrainer:
     """Minimal training harness of c4: ``step(X)`` = forward, L1 + KL loss, backward, Adam step (the reference's
     first-stage optimiser is ``Adam(lr, betas=(0.5, 0.9))`` over encoder + GRU + decoder, first_stage_motion_model.py:283-300)."""
 
-    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8):
+    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8, vgg_loss=None, w_vgg=0.0):
+        """``vgg_loss`` (ipoke_amd.vgg.VGGLoss) with ``w_vgg`` adds the perceptual term of first_stage_motion_model.py:263-271."""
         self.model = model
+        self.vgg_loss, self.w_vgg = vgg_loss, float(w_vgg)
+        if self.w_vgg != 0.0 and vgg_loss is None:
+            raise ValueError("w_vgg != 0 needs vgg_loss=ipoke_amd.vgg.VGGLoss(...) (load the torchvision VGG-19 weights into it)")
         self.opt = MultiTensorAdam(model.parameters(), lr, betas, weight_decay, eps)
         self.params = self.opt.params
         self.grad_hook = None           # data parallel: all-reduce of the gradients between backward and the update
@@ -657,6 +663,8 @@ class FirstStageTrainer:
             eps = torch.FloatTensor(X.shape[0], Z, s, s).normal_().to(X.device)      # CPU generator, motion_encoder.py:220
         self.opt.zero_grad()
         loss, X_hat, mu, lv = first_stage_forward_loss(m, X, eps)
+        if self.w_vgg != 0.0:
+            loss = loss + self.w_vgg * self.vgg_loss(X[:, 1:].reshape(-1, *X.shape[2:]).float(), X_hat.reshape(-1, *X_hat.shape[2:]))
         loss.backward()
         if self.grad_hook is not None:
             self.grad_hook()

@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 from ipoke_amd import configs                                    # noqa: E402
 from ipoke_amd.utils.detfill import deterministic_fill_          # noqa: E402
-from oracle import data_ref, disc_ref, flow_ref, fvd_ref, ref_import, vae_ref      # noqa: E402
+from oracle import data_ref, disc_ref, flow_ref, fvd_ref, ref_import, vae_ref, vgg_ref      # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -909,12 +909,50 @@ def g11_data():
     npz("g11_data_path", **arrs)
 
 
+def g12_vgg():
+    """G12: the VGG perceptual loss (utils/losses.py:6-82) as the first stage calls it (first_stage_motion_model.py:263) on 64x64
+    frames: the reference's own VGGLoss / VGG classes run with ``torchvision.models.vgg19`` resolved to the restated feature stack
+    (torchvision itself is absent); loss value, the five feature maps of the generated frames and the gradient w.r.t. them."""
+    import types
+    ls = ref_import.ref("utils.losses")
+    feats = vgg_ref.vgg19_features()
+    deterministic_fill_(feats, prefix="vgg19.features.")
+    ls.torchvision.models.vgg19 = lambda pretrained=True: types.SimpleNamespace(features=feats)
+    m = ls.VGGLoss()
+    o = vgg_ref.VGGLoss()
+    deterministic_fill_(o.vgg, prefix="unused.")
+    o.vgg.load_state_dict(m.vgg.state_dict())
+    assert list(m.vgg.state_dict()) == list(o.vgg.state_dict())
+    x = torch.rand(6, 3, 64, 64, generator=gen(121)) * 2 - 1
+    y = (x + 0.4 * torch.randn(6, 3, 64, 64, generator=gen(122))).clamp(-1, 1)
+    arrs = dict(x_true=x, x_hat=y, keys=np.array(list(m.vgg.state_dict())))
+
+    def run(net):
+        yy = y.clone().requires_grad_(True)
+        loss = net(x, yy).mean()
+        loss.backward()
+        with torch.no_grad():
+            fm = net.vgg(y)
+        return loss.detach(), yy.grad, fm
+
+    loss, dy, fm = run(m)
+    losso, dyo, fmo = run(o)
+    close(losso, loss, 1e-6, "G12 loss"); close(dyo, dy, 1e-7, "G12 dy")
+    for i, (a, b) in enumerate(zip(fmo, fm)):
+        close(a, b, 1e-5, f"G12 fmap{i}")
+        arrs[f"fmap{i}_checksum"] = checksum(b, f"vgg{i}")
+        arrs[f"fmap{i}_slice"] = b[:2, :4, :4, :4]
+    print(f"  loss {loss.item():.6f}; |dy| max {dy.abs().max().item():.3e}")
+    arrs.update(loss=loss, dy=dy)
+    npz("g12_vgg_loss", **arrs)
+
+
 def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
             "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
-            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd, "g11": g11_data}
+            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd, "g11": g11_data, "g12": g12_vgg}
     for name in (which or list(jobs)):
         print(f"[{name}]")
         t = time.time()
