@@ -31,7 +31,7 @@ class FlowEngine:
     """Owner of the native handle and of the flat device buffers."""
 
     def __init__(self, arch, dtype="bf16", max_batch=64, device=None):
-        for key in ("attention", "condition_nice", "cond_conv", "multistack", "augmented_input"):
+        for key in ("attention", "condition_nice", "cond_conv", "multistack"):       # augmented_input only widens flow_in_channels (second_stage.py)
             if arch.get(key, False):
                 raise NotImplementedError(f"architecture option {key}=True is outside the shipped iPOKE configs")
         if float(arch.get("p_dropout", 0.0)) > 0.0:

@@ -33,25 +33,26 @@ class _NllFunction(torch.autograd.Function):
 
 
 def nll(sample, spatial_mean=False):
-    if spatial_mean:
-        raise NotImplementedError("spatial_mean=True is not used by the shipped configs")
+    """mean over the batch of loss.py:75-79 ``nll``; with spatial_mean the sum over positions becomes their mean (a 1 / (h w) factor)."""
     z = torch.zeros(sample.shape[0], device=sample.device)
-    return _NllFunction.apply(sample, z, 0.0)[1]
+    v = _NllFunction.apply(sample, z, 0.0)[1]
+    return v / (sample.shape[-2] * sample.shape[-1]) if spatial_mean else v
 
 
 class FlowLoss(nn.Module):
     def __init__(self, spatial_mean=False, logdet_weight=1.0):
         super().__init__()
-        if spatial_mean:
-            raise NotImplementedError("spatial_mean=True is not used by the shipped configs")
         self.spatial_mean = spatial_mean
         self.logdet_weight = logdet_weight
 
     def forward(self, sample, logdet):
         assert len(logdet.shape) == 1
         loss, nll_loss, nlogdet_loss = _NllFunction.apply(sample, logdet, self.logdet_weight)
+        if self.spatial_mean:       # loss.py:14-20: both terms carry 1 / (h w); the gradient scales with the loss
+            hw = float(sample.shape[-2] * sample.shape[-1])
+            loss, nll_loss, nlogdet_loss = loss / hw, nll_loss / hw, nlogdet_loss / hw
         with torch.no_grad():       # logged only; consumes the device RNG like the reference's randn_like
-            reference_nll_loss = nll(torch.randn_like(sample))
+            reference_nll_loss = nll(torch.randn_like(sample), self.spatial_mean)
         log = {"flow_loss": loss, "reference_nll_loss": reference_nll_loss, "nlogdet_loss": nlogdet_loss,
                "nll_loss": nll_loss, "logdet_weight": self.logdet_weight}
         return loss, log

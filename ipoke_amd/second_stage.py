@@ -70,9 +70,20 @@ class PokeMotionModel(nn.Module):
             self.conditioner = FirstStageWrapper(self.conditioner_config, dtype=dtype)
         arch = config["architecture"]
         self.augment_input = bool(arch.get("augmented_input", False))
-        if self.augment_input:
-            raise NotImplementedError("augmented_input is off in every shipped config")
         arch["flow_in_channels"] = self.first_stage_config["architecture"]["z_dim"]
+        if self.augment_input:
+            # noise channels appended to the latent (:66-79, :304-308).  The flow input is detached (:348), so the "trainable"
+            # scale / shift never receive a gradient in the reference either: they are kept as parameters for the state dict only
+            n_aug = int(arch["augment_channels"])
+            arch["flow_in_channels"] += n_aug
+            if arch.get("scale_augmentation", False):
+                self.scale_augment = torch.nn.Parameter(torch.ones(n_aug), requires_grad=False)
+            else:
+                self.register_buffer("scale_augment", torch.ones(n_aug))
+            if arch.get("shift_augmentation", False):
+                self.shift_augment = torch.nn.Parameter(torch.zeros(n_aug), requires_grad=False)
+            else:
+                self.register_buffer("shift_augment", torch.zeros(n_aug))
         pe_arch = self.poke_emb_config["architecture"]
         self.embed_poke_and_image = bool(pe_arch.get("poke_and_image", False))
         self.poke_key = "flow" if pe_arch.get("flow_ae", False) else "poke"
@@ -177,6 +188,11 @@ class PokeMotionModel(nn.Module):
         else:
             with torch.no_grad():
                 flow_input, *_ = self.encode_first_stage(X)
+                if self.augment_input:
+                    n_aug = self.config["architecture"]["augment_channels"]
+                    noise = torch.randn((flow_input.size(0), n_aug, *flow_input.shape[-2:])).type_as(X)
+                    noise = self.scale_augment.to(X.device)[None, :, None, None] * noise + self.shift_augment.to(X.device)[None, :, None, None]
+                    flow_input = torch.cat([flow_input, noise], dim=1)
         cond = torch.cat([cond, poke_emb], dim=1) if self.use_cond else poke_emb
         return flow_input, cond
 
@@ -238,6 +254,8 @@ class PokeMotionModel(nn.Module):
             for _ in range(n_samples):
                 flow_input, cond = self.make_flow_input(batch, reverse=True, use_kp_poke=use_keypoint_pokes)
                 out_motion = self.flow(flow_input, cond, reverse=True)
+                if self.augment_input:
+                    out_motion = out_motion[:, :-self.config["architecture"]["augment_channels"]].contiguous()
                 out_video = self.decode_first_stage(out_motion, X)
                 if add_first_frame:
                     out_video = torch.cat([X[:, 0].unsqueeze(1), out_video], dim=1)

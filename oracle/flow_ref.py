@@ -515,15 +515,16 @@ class FlowLoss(nn.Module):
 
     def __init__(self, spatial_mean=False, logdet_weight=1.0):
         super().__init__()
-        assert not spatial_mean
+        self.spatial_mean = spatial_mean
         self.logdet_weight = logdet_weight
 
     def forward(self, sample, logdet):
         assert logdet.dim() == 1
-        nll_loss = nll(sample).mean()
-        nlogdet = -logdet.mean()
+        hw = float(sample.shape[-2] * sample.shape[-1]) if self.spatial_mean else 1.0      # loss.py:14-20, 75-77
+        nll_loss = nll(sample).mean() / hw
+        nlogdet = -logdet.mean() / hw
         loss = nll_loss + self.logdet_weight * nlogdet
-        ref = nll(torch.randn_like(sample)).mean()
+        ref = nll(torch.randn_like(sample)).mean() / hw
         return loss, {"flow_loss": loss, "reference_nll_loss": ref, "nlogdet_loss": nlogdet,
                       "nll_loss": nll_loss, "logdet_weight": self.logdet_weight}
 

@@ -194,3 +194,22 @@ def test_hipgraph_replay_is_bit_identical_to_eager(golden, dtype):
             assert torch.equal(rev, ref_rev) and torch.equal(out, ref_out) and torch.equal(ld, ref_ld), it
         m.set_graph_mode(False)
         assert torch.equal(m(z, cond, reverse=True), ref_rev)
+
+
+@pytest.mark.parametrize("spatial_mean", [False, True])
+def test_flow_loss_value_and_gradient(spatial_mean):
+    """FlowLoss (loss.py:6-31, 75-79) incl. the spatial_mean form: value and both gradients against the oracle's autograd."""
+    from ipoke_amd.loss import FlowLoss
+    from oracle import flow_ref
+    g = torch.Generator().manual_seed(2)
+    x, ld = torch.randn(5, 32, 8, 8, generator=g), torch.randn(5, generator=g) * 30
+    xo, ldo = x.clone().requires_grad_(True), ld.clone().requires_grad_(True)
+    lo, _ = flow_ref.FlowLoss(spatial_mean=spatial_mean, logdet_weight=0.7)(xo, ldo)
+    lo.backward()
+    xg, ldg = x.cuda().requires_grad_(True), ld.cuda().requires_grad_(True)
+    lg, log = FlowLoss(spatial_mean=spatial_mean, logdet_weight=0.7)(xg, ldg)
+    lg.backward()
+    assert abs(lg.item() - lo.item()) <= 2e-6 * abs(lo.item())
+    assert (xg.grad.cpu() - xo.grad).abs().max().item() <= 1e-7 and (ldg.grad.cpu() - ldo.grad).abs().max().item() <= 1e-8
+    ref_scale = 0.5 * 32 * (1 if spatial_mean else 64)             # E[reference_nll_loss] of a standard normal sample
+    assert 0.7 * ref_scale < log["reference_nll_loss"].item() < 1.3 * ref_scale

@@ -147,6 +147,9 @@ def test_flow_loss_known_answers():
     assert abs(fl(torch.ones(3, 4, 8, 8), torch.zeros(3))[0].item() - 0.5 * 4 * 64) < 1e-4
     with pytest.raises(AssertionError):
         fl(z, torch.zeros(3, 1))                       # reference asserts len(logdet.shape) == 1 (loss.py:15)
+    # spatial_mean (loss.py:14-20, 75-77): both terms divided by h * w; known answers from the reference's FlowLoss
+    sm = flow_ref.FlowLoss(spatial_mean=True, logdet_weight=0.5)
+    assert abs(sm(torch.ones(3, 4, 8, 8), torch.full((3,), 6.4))[0].item() - (0.5 * 4 - 0.5 * 6.4 / 64)) < 1e-5
 
 
 def test_lr_schedule(golden):

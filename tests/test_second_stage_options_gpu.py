@@ -1,0 +1,52 @@
+"""Optional branches of the second stage that the shipped configs leave off: augmented_input (second_stage_video.py:66-79, 304-308,
+335-336) -- noise channels appended to the latent before the flow and stripped after sampling."""
+import copy
+
+import pytest
+import torch
+
+from ipoke_amd import configs
+from ipoke_amd.second_stage import PokeMotionModel
+from ipoke_amd.utils.detfill import deterministic_fill_
+from oracle import flow_ref
+from tests.helpers import synthetic_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_augmented_input():
+    arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+    arch["flow_mid_channels_factor"] = 2
+    arch.update(augmented_input=True, augment_channels=16, scale_augmentation=True)
+    conf = configs.second_stage_config(64, 32, 16, batch_size=2, arch=arch)
+    model = PokeMotionModel(conf, dirs={}, dtype="f32", device=DEV, max_batch=2)
+    assert model.config["architecture"]["flow_in_channels"] == 48
+    assert "scale_augment" in dict(model.named_parameters()) and "shift_augment" in dict(model.named_buffers())
+    for name in ("first_stage_model", "poke_embedder", "conditioner", "flow"):
+        deterministic_fill_(getattr(model, name), prefix=name + ".")
+    model.flow.sync_buffers()
+    with torch.no_grad():
+        model.scale_augment.fill_(2.0); model.shift_augment.fill_(0.5)
+    batch = synthetic_batch(2, 16, 64, seed=4, device=DEV)
+    torch.manual_seed(11)
+    flow_input, cond = model.make_flow_input(batch)
+    torch.manual_seed(11)                                             # same CPU draws in the same order: the encoder's reparameterisation
+    latent, _ = model.encode_first_stage(batch["images"])             # noise first, then the augmentation noise
+    noise = torch.randn(2, 16, 8, 8)
+    assert flow_input.shape == (2, 48, 8, 8) and torch.equal(flow_input[:, :32], latent)
+    assert torch.allclose(flow_input[:, 32:].cpu(), 2.0 * noise + 0.5, atol=1e-6)
+    # the 48-channel flow against the oracle on that input
+    with torch.no_grad():
+        out, logdet = model.flow(flow_input, cond)
+    o = flow_ref.SupervisedMacowTransformer(copy.deepcopy(model.config["architecture"]))
+    deterministic_fill_(o, prefix="flow.")
+    with torch.no_grad():
+        oo, old = o(flow_input.cpu(), cond.cpu())
+    assert (out.cpu() - oo).abs().max().item() < 2e-4 and (logdet.cpu() - old).abs().max().item() < 2e-2
+    # training step and sampling run; sampled motion is cut back to z_dim channels before decoding
+    from ipoke_amd.trainer import SecondStageTrainer
+    tr = SecondStageTrainer(model)
+    l0 = tr.train_step(batch).item()
+    vids = model.forward_sample(batch, n_samples=1, n_logged_vids=2)
+    assert vids[0].shape == (2, 15, 3, 64, 64) and torch.isfinite(vids[0]).all() and l0 == l0
