@@ -259,8 +259,8 @@ def secondary(args, cfg, rank, world, device):
                     f"(bs_i3d), {args.fvd_dtype} arithmetic, {gflop / B:.1f} GFLOP per clip")
         args.dtype = args.fvd_dtype
     elif args.config == "c4gan":
-        # the reference's real first-stage step (first_stage_motion_model.py:160-277, config/first_stage.yaml d_t / d_s) without
-        # the VGG term: L1 + KL + temporal discriminator (hinge + gradient penalty) + spatial discriminator + generator terms
+        # the reference's real first-stage step (first_stage_motion_model.py:160-277, config/first_stage.yaml d_t / d_s, w_vgg = 10):
+        # L1 + KL + VGG perceptual loss + temporal discriminator (hinge + gradient penalty) + spatial discriminator + generator terms
         import numpy as np
         from ipoke_amd.discriminator import PatchDiscriminator, TemporalDiscriminator
         from ipoke_amd.first_stage import SpadeCondMotionModel
@@ -274,14 +274,19 @@ def secondary(args, cfg, rank, world, device):
         d_s = {"bce_loss": False, "gp_weight": 0.0, "fmap_weight": 1.0, "gen_weight": 1.0, "n_examples": 16}
         disc_t = TemporalDiscriminator(size, d_t, dtype=args.dtype).to(device)
         disc_s = PatchDiscriminator(d_s, dtype=args.dtype).to(device)
-        gan = FirstStageGANTrainer(model, disc_t, disc_s, {"training": {"lr": 2e-4, "weight_decay": 1e-5, "w_l1": 10.0, "w_kl": 1e-7, "w_vgg": 0.0},
-                                                            "d_t": d_t, "d_s": d_s, "data": {"max_frames": T - 1}})
+        from ipoke_amd.utils.detfill import deterministic_fill_
+        from ipoke_amd.vgg import VGGLoss
+        vgg = VGGLoss(dtype=args.dtype)
+        deterministic_fill_(vgg.vgg, prefix="vgg19.")          # random-init weights of the VGG-19 architecture (no pretrained weights offline)
+        vgg.to(device)
+        gan = FirstStageGANTrainer(model, disc_t, disc_s, {"training": {"lr": 2e-4, "weight_decay": 1e-5, "w_l1": 10.0, "w_kl": 1e-7, "w_vgg": 10.0},
+                                                            "d_t": d_t, "d_s": d_s, "data": {"max_frames": T - 1}}, vgg_loss=vgg)
         eps = torch.randn(B, z, 8, 8, generator=torch.Generator().manual_seed(7 + rank)).to(device)
         rng = np.random.RandomState(3)
         step = lambda i: gan.step(batch["images"], eps, *gan.draw(batch["images"], rng))["loss"]
-        metric, frames = "video-frames/sec (first-stage adversarial train step: L1 + KL + d_t hinge/GP + d_s + generator terms)", world * B * T
+        metric, frames = "video-frames/sec (first-stage adversarial train step: L1 + KL + VGG + d_t hinge/GP + d_s + generator terms)", world * B * T
         workload = (f"first_stage {T}x3x{size}x{size} clips, z={z}, generator fwd+bwd, 3-D ResNet-18 discriminator on {d_t['max_frames']} frames "
-                    f"(4 forward + tangent pass + backward), PatchGAN on {d_s['n_examples']} frames, three Adam steps; no VGG term; per-GPU batch {B}")
+                    f"(4 forward + tangent pass + backward), PatchGAN on {d_s['n_examples']} frames, VGG-19 perceptual loss on {B * (T - 1)} frame pairs, three Adam steps; per-GPU batch {B}")
     elif args.config == "c4":
         from ipoke_amd.first_stage import SpadeCondMotionModel
         from ipoke_amd.first_stage_train import FirstStageTrainer

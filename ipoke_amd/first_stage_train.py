@@ -25,6 +25,8 @@ evaluated frame by frame.
 """
 from ctypes import byref
 
+import os
+
 import torch
 
 from . import _lib, nn as K, ops
@@ -69,6 +71,9 @@ def _weight_operand(w, dtype, transposed_conv, inv_scale=None):
                                                None if inv_scale is None else ptr(inv_scale), ptr(out), kc, ops._dt(dtype),
                                                _lib.current_stream()))
     return out, kc
+
+
+_WGRAD_WGS = int(os.environ.get("IPOKE_WGRAD_WGS", "512"))       # workgroups a split-M weight gradient aims for (c4: 256 / 512 / 1024 / 2048 -> 156.5 / 151.0 / 156.5 / 160.6 ms: more slabs = more fp32 partial traffic)
 
 
 class _SnWeight:
@@ -170,7 +175,7 @@ class _ConvFn(torch.autograd.Function):
             # (deterministic, and ~10x cheaper than fp32 atomics into the few thousand addresses of dW)
             tiles = -(-wd.Nout // 128) * -(-(taps * wd.Kc) // 128)
             rows = N * wd.Do * wd.Ho * wd.Wo
-            splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), 1024 // tiles))
+            splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), _WGRAD_WGS // tiles))
             if splitm > 1:
                 slabs = torch.empty(splitm, d_w.numel(), dtype=torch.float32, device=dy.device)
                 wd.splitm = splitm; wd.split_stride = d_w.numel(); wd.dW = slabs.data_ptr()
