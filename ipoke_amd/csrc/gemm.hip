@@ -1205,6 +1205,244 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const NtParams p) {
   GEMM_STAMP(3);
 }
 
+// =============================================================================================
+// 3x3 convolution (stride 1, pad 1, one depth slice) on maps of any size with >= 64 dense input channels: the 2-D convolutions
+// of the SPADE decoder, the VGG feature stack and their data gradients.  As an implicit GEMM every tap re-fetches the input
+// rows of its tile from L2 (nine passes of global_load_lds over the same pixels: at 128 x 128 x 64 channels the A stream is
+// 600 MB per launch for 67 MB of input, and the launch runs at the L2 -> LDS rate, 6x off the HBM and the matrix-core time).
+// Here a workgroup owns an 8 x 16 patch of output pixels of one image and stages the patch's INPUT with its one-pixel halo
+// (10 x 18 pixels, zero outside the image) in LDS once per 64-channel chunk; the nine taps read it through shifted row
+// addresses -- the same chunk-major reduction, filter ring, 2 x 4 wave arrangement and K-group hand-over as conv3x3_s8 above,
+// minus the "outside the map" masks (the zero border is materialised by the staging DMA).  Output channels are tiled by 64
+// over blockIdx.y.  transposed (data gradient): the taps are mirrored, the caller supplies the transposed filter operand.
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
+  typedef bf16_t T;
+  typedef typename ET<T>::frag frag_t;
+  typedef typename Pack4<T>::type pack_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int BM = 128, BN = 64, NTHR = 512, R = 12;
+  constexpr int TH = 8, TW = 16, HW = TW + 2, HROWS = (TH + 2) * HW;       // 180 halo pixels
+  constexpr int A_IT = 3;                                                   // 24 DMA slots of 8 pixel rows >= 180 rows
+  constexpr int ABUF = 8 * A_IT * 1024, WSLOT = BN * 128;
+  constexpr int MREP = 4, NREP = 4;
+  constexpr int EP = BN * 4 + 16;
+  constexpr unsigned kInvalid = 0xffffffffu;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* abuf = smem;                              // 2 x ABUF: the halo image of a chunk, double-buffered
+  unsigned char* ring = smem + 2 * ABUF;                   // R filter K-blocks
+  unsigned char* dummy = ring + R * WSLOT;                 // landing zone of padding DMAs, 1 KB per wave
+  if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mh = wave & 1, kq = wave >> 1;
+  const GeomDev& g = p.g;
+  const int tiles_x = g.Wo / TW, tiles_y = g.Ho / TH;
+  const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
+  const int nch = p.Kc >> 6, nkb = nch * 9, nrounds = (nkb + 3) >> 2;
+  const int sgn = g.transposed ? -1 : 1;
+
+  const T* Abase = reinterpret_cast<const T*>(p.A);
+  const T* Wbase = reinterpret_cast<const T*>(p.W);
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+  unsigned a_src[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int row = (wave + 8 * i) * 8 + (lane >> 3), pos = lane & 7;
+    const int py = row / HW, px = row - py * HW, y = y0 - 1 + py, x = x0 - 1 + px;
+    a_src[i] = kInvalid;
+    if (row < HROWS && (unsigned)y < (unsigned)g.Hi && (unsigned)x < (unsigned)g.Wi)
+      a_src[i] = (unsigned)((long)img * p.a_sn + (long)y * p.a_sh + (long)x * p.a_sw + p.a_coff + ((pos ^ ((row >> 1) & 7)) * 8));
+  }
+  unsigned w_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int nl = 32 * (wave >> 2) + 8 * j + (lane >> 3), n = n0 + nl, pos = lane & 7;
+    w_src[j] = n < p.Nout ? (unsigned)((long)n * p.ldw + ((pos ^ ((nl >> 1) & 7)) * 8)) : kInvalid;
+  }
+  int wi_g = wave & 3, wi_c = 0, wi_t = wave & 3;
+  auto issue_w = [&]() {
+    const bool in = wi_g < nkb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool real = in && w_src[j] != kInvalid;
+      const T* src = real ? Wbase + w_src[j] + (long)wi_t * p.Kc + wi_c * 64 : zero;
+      unsigned char* dst = in ? ring + (wi_g % R) * WSLOT + (4 * (wave >> 2) + j) * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+    wi_g += 4; wi_t += 4;
+    if (wi_t >= 9) { wi_t -= 9; ++wi_c; }
+  };
+  int a_next = 0;
+  auto issue_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bool real = a_next < nch && a_src[i] != kInvalid;
+      const T* src = real ? Abase + a_src[i] + a_next * 64 : zero;
+      unsigned char* dst = a_next < nch ? abuf + (a_next & 1) * ABUF + (wave + 8 * i) * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+    ++a_next;
+  };
+  issue_a();
+  issue_w(); issue_w();
+
+  const int qlo = lane >> 4;
+  int b_rd[NREP];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int n = j * 16 + (lane & 15);
+    b_rd[j] = n * 128 + ((qlo ^ ((n >> 1) & 7)) * 16);
+  }
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int gk = kq, ci = 0, t = kq;
+  for (int r = 0; r < nrounds; ++r) {
+    wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    if (a_next <= (4 * r) / 9 + 1) issue_a();
+    issue_w();
+    if (gk < nkb) {
+      const unsigned char* ab = abuf + (ci & 1) * ABUF;
+      const unsigned char* wb = ring + (gk % R) * WSLOT;
+      const int th = t / 3, tw = t - 3 * th;
+      // halo row of output pixel (mh*4 + i, lane & 15) under this tap
+      const int sr0 = (mh * 4 + 1 + sgn * (th - 1)) * HW + (lane & 15) + 1 + sgn * (tw - 1);
+      frag_t fa[2][MREP], fb[2][NREP];
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+          const int sr = sr0 + i * HW;
+          fa[hs][i] = *reinterpret_cast<const frag_t*>(ab + sr * 128 + (((hs * 4 + qlo) ^ ((sr >> 1) & 7)) * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) fb[hs][j] = *reinterpret_cast<const frag_t*>(wb + (b_rd[j] ^ (hs * 64)));
+      }
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[hs][i], fb[hs][j], acc[i][j]);
+    }
+    gk += 4; t += 4;
+    if (t >= 9) { t -= 9; ++ci; }
+  }
+  wait_vmcnt<0>();
+  // the four K groups meet (as in conv3x3_s8), then group 0 parks the sums for the sweep
+  unsigned char* st = smem + (mh * MREP * 16 + (lane & 15)) * EP + (lane >> 4) * 16;
+  __syncthreads();
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const int give_lo = round == 0 ? 2 : 1, take_hi = round == 0 ? 2 : 1;
+    if (kq >= give_lo && kq < 2 * give_lo) {
+      unsigned char* d = st + (kq - give_lo) * BM * EP;
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(d + i * 16 * EP + j * 64) = acc[i][j];
+    }
+    __syncthreads();
+    if (kq < take_hi) {
+      const unsigned char* d = st + kq * BM * EP;
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(d + i * 16 * EP + j * 64);
+    }
+    __syncthreads();
+  }
+  if (kq == 0) {
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(st + i * 16 * EP + j * 64) = acc[i][j];
+  }
+  __syncthreads();
+  // sweep: tile row `row` is output pixel (y0 + row / 16, x0 + row % 16) of image img
+  const long mbase = ((long)img * g.Ho + y0) * g.Wo + x0;
+  const bool vec_ok = (p.Nout & 3) == 0;
+  constexpr int G4 = BN / 4;
+  for (int idx = tid; idx < BM * G4; idx += NTHR) {
+    const int row = idx / G4, c4 = idx - row * G4;
+    const long m = mbase + (long)(row >> 4) * g.Wo + (row & 15);
+    const int n = n0 + 4 * c4;
+    if (n >= p.n_pad) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * EP + c4 * 16);
+    const bool full = vec_ok && n + 3 < p.Nout;
+    if (p.bias) {
+      if (full) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      else for (int r = 0; r < 4; ++r) if (n + r < p.Nout) v[r] += p.bias[n + r];
+    }
+    if (p.act != IPOKE_ACT_NONE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fast_act<T>(p.act, v[r]);
+    }
+    if (p.dact) {
+      const T* dp = reinterpret_cast<const T*>(p.dact) + m * p.ld_dact + n;
+      if (full && (p.ld_dact & 3) == 0) {
+        const pack_t y = *reinterpret_cast<const pack_t*>(dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(p.dact_act, ET<T>::to_f32(y[r]));
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.Nout) v[r] *= act_grad_from_out(p.dact_act, ET<T>::to_f32(dp[r]));
+      }
+    }
+    if (!full) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n + r >= p.Nout) v[r] = 0.f;
+    }
+    if (p.c_f32) {
+      float* Cp = reinterpret_cast<float*>(p.C) + m * p.ldc + p.c_coff;
+      if (full && p.c_cstride == 1 && ((p.ldc | p.c_coff) & 3) == 0) *reinterpret_cast<f32x4*>(Cp + n) = v;
+      else for (int r = 0; r < 4; ++r) if (n + r < p.Nout) Cp[(long)(n + r) * p.c_cstride] = v[r];
+    } else {
+      T* Cp = reinterpret_cast<T*>(p.C) + m * p.ldc + p.c_coff + n;
+      if (n + 3 < p.n_pad && ((p.ldc | p.c_coff) & 3) == 0) {
+        pack_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = ET<T>::from_f32(v[r]);
+        *reinterpret_cast<pack_t*>(Cp) = o;
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.n_pad) Cp[r] = ET<T>::from_f32(v[r]);
+      }
+    }
+  }
+}
+
+static bool halo_applicable(const NtParams& p) {
+  static const int on = getenv("IPOKE_HALO") ? atoi(getenv("IPOKE_HALO")) : 1;         // developer A/B: IPOKE_HALO=0 turns the kernel off
+  const GeomDev& g = p.g;
+  return on && !p.a_f32 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Do == 1 && g.Hi == g.Ho && g.Wi == g.Wo &&
+         g.Ho % 8 == 0 && g.Wo % 16 == 0 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 1 && g.pw == 1 &&
+         p.Kc % 64 == 0 && p.Kc_real == p.Kc && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot && p.splitk == 1 && !p.c_acc &&
+         ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && (long)(g.M / g.S) * p.a_sn + (long)g.Hi * p.a_sh + p.Kc < (1L << 31) &&
+         (long)p.Nout * p.ldw < (1L << 31) && g.M >= 4096 &&
+         // measured against the implicit-GEMM kernel (scripts/probe_halo.py, B = 32): 64 channels at 128 x 128: 139 vs 181 us,
+         // 64 -> 3: 129 vs 168, 256 channels at 16 x 16: 18 vs 32 us, 512 at 16 x 16 (N = 300): 486 vs 682; but 128 channels at
+         // 64 x 64: 91 vs 86 and 256 at 32 x 32: 68 vs 67 -- there the nine-tap re-fetch is hidden and the generic tile map wins
+         (p.Kc <= 64 || g.Ho * g.Wo <= 256);
+}
+static int launch_conv3x3_halo(NtParams& p, hipStream_t s) {
+  const size_t lds = 2 * 24 * 1024 + 12 * 64 * 128 + 8 * 1024;
+  auto kern = conv3x3_halo_kernel;
+  static bool attr_done = false;
+  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  p.tiles_m = p.g.M / 128; p.tiles_n = ceil_div(p.Nout, 64); p.xa = p.xb = 0;
+  dim3 grid((unsigned)p.tiles_m, (unsigned)p.tiles_n);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
 // chunks of 64 input channels per split such that (row tiles) x (splits) stays within one round of workgroups
 static int conv3x3_s8_splits(int M, int Kc, int TS) {
   const int tiles = ceil_div(M, 64 * TS), nchunks = Kc / 64;
@@ -1305,6 +1543,7 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
   const int M = p.g.M, N = p.Nout;
   if constexpr (sizeof(T) == 2) {
     if (s8_applicable(p)) return launch_conv3x3_s8(p, s);
+    if (halo_applicable(p)) return launch_conv3x3_halo(p, s);
   }
   static const int forced = getenv("IPOKE_NT_TILE") ? atoi(getenv("IPOKE_NT_TILE")) : 0;     // developer override
   switch (forced) {

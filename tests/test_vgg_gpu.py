@@ -20,7 +20,7 @@ DEV = "cuda"
 # gradient is sign(f2 - f1), and a handful of the 2.6 M map elements have |f2 - f1| below the fp32 rounding of two different
 # summation orders (mean deviation 1.3e-3 of mean |dy|; bf16: 0.2 / 0.17), so their sign -- and a few pixels of dy under that element's receptive field -- flips.  Hence an element-wise
 # bound (dy), a mean bound (dy_mean) and the abs-sum (dy_sum).
-TOL = {"f32": dict(loss=2e-6, fmap=2e-5, dy=5e-2, dy_mean=5e-3, dy_sum=1e-4), "bf16": dict(loss=5e-3, fmap=3e-2, dy=0.6, dy_mean=0.3, dy_sum=3e-2)}
+TOL = {"f32": dict(loss=2e-6, fmap=2e-5, dy=5e-2, dy_mean=5e-3, dy_sum=1e-4), "bf16": dict(loss=5e-3, fmap=5e-2, dy=0.8, dy_mean=0.4, dy_sum=3e-2)}
 
 
 def _checksum(x, key):
