@@ -60,7 +60,7 @@ def first_stage_config(spatial_size=128, z_dim=32, n_frames=16):
     return {
         "data": {"spatial_size": (spatial_size, spatial_size), "max_frames": n_frames - 1, "batch_size": 20},
         "training": {"lr": 2e-4, "weight_decay": 1e-5, "w_kl": 1e-7, "w_l1": 10, "w_vgg": 10, "full_sequence": True},
-        "logging": {"bs_i3d": 8},
+        "logging": {"bs_i3d": 8, "n_samples_fvd": 1000},
         "architecture": {
             "ENC_M_channels": enc, "decoder_factor": 32, "z_dim": z_dim, "norm": "group", "CN_content": "spade",
             "CN_motion": "ADAIN", "spectral_norm": True, "running_stats": False, "n_gru_layers": 4,

@@ -476,6 +476,51 @@ class SpadeCondMotionModel(nn.Module):
         motion, mu, logvar = self.enc_motion(X_in.transpose(1, 2), eps=eps)
         return self.decode(motion, X[:, 0], X.shape[1] - 1), mu, logvar
 
+    # ---- validation loop (first_stage_motion_model.py:303-367) -------------------------------------------
+    def attach_fvd(self, i3d=None, dtype="f32", vgg_loss=None):
+        """The reference builds ``self.FVD`` / ``self.vgg_loss`` in __init__ when ``train=True`` (:52-63); here they are attached
+        explicitly (their checkpoints are separate files)."""
+        from .fvd import FVD
+        self.FVD = FVD(n_samples=self.config["logging"]["n_samples_fvd"], i3d=i3d, dtype=dtype)
+        self.vgg_loss = vgg_loss
+        self.features_fvd_fake, self.features_fvd_true, self.fvd_features_fake_x0, self.fvd_features_true_x0 = [], [], [], []
+        self.logged = {}
+        return self.FVD
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_id):
+        """Reconstruction, ``val/rec_loss`` (mean |X[:, 1:] - X_hat|, ``ipoke_l1_pair``), ``val/vgg_loss`` when a VGGLoss is attached, and
+        the clips kept (on the device) for the epoch's FVD.  ssim / psnr / lpips (third-party metric packages) are not part of this path."""
+        from ._lib import check, ptr
+        X = batch["images"].float()
+        X_hat, mu, logvar = self(X)
+        tgt = X[:, 1:].contiguous()
+        W = X.shape[-1]
+        M = tgt.numel() // W
+        loss = torch.zeros(1, device=X.device)
+        scratch = torch.empty(M, W, device=X.device)
+        check(_lib.lib().ipoke_l1_pair(ptr(X_hat.contiguous()), W, ptr(tgt), W, M, W, 1.0 / tgt.numel(), ptr(loss), ptr(scratch), W, _lib.F32,
+                                       _lib.current_stream()))
+        self.logged["val/rec_loss"] = loss[0]
+        if getattr(self, "vgg_loss", None) is not None:
+            self.logged["val/vgg_loss"] = self.vgg_loss(tgt.reshape(-1, *X.shape[2:]), X_hat.reshape(-1, *X_hat.shape[2:]))
+        if getattr(self, "FVD", None) is not None and batch_id <= int(self.config["logging"]["n_samples_fvd"] / X_hat.size(0)):
+            self.features_fvd_fake.append(X_hat)
+            self.features_fvd_true.append(tgt)
+            self.fvd_features_fake_x0.append(torch.cat([X[:, 0].unsqueeze(1), X_hat], dim=1))
+            self.fvd_features_true_x0.append(X)
+        return X_hat
+
+    def validation_epoch_end(self, outputs=None):
+        from .fvd import calculate_FVD
+        bs = self.config["logging"]["bs_i3d"]
+        fvd = calculate_FVD(self.FVD.i3d, torch.cat(self.features_fvd_fake), torch.cat(self.features_fvd_true), batch_size=bs)
+        fvd_x0 = calculate_FVD(self.FVD.i3d, torch.cat(self.fvd_features_fake_x0), torch.cat(self.fvd_features_true_x0), batch_size=bs)
+        self.logged["FVD-val"], self.logged["FVD-val-x0"] = fvd, fvd_x0
+        for lst in (self.features_fvd_fake, self.features_fvd_true, self.fvd_features_fake_x0, self.fvd_features_true_x0):
+            lst.clear()
+        return fvd, fvd_x0
+
     def training_loss(self, X, eps, w_l1=10.0, w_kl=1e-7, power_iteration=None):
         """Differentiable forward + ``w_l1 * L1 + w_kl * KL`` (first_stage_motion_model.py:263-276 without the GAN / VGG
         terms).  Returns (loss, X_hat, mu, logvar); ``loss.backward()`` fills ``.grad`` of every parameter."""

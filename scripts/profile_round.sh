@@ -18,7 +18,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- python $R/b
 cp $(find /tmp/p_c4 -name "*kernel_stats.csv" | head -1) $O/r02_c4_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4gan -- python $R/bench.py --config c4gan --steps 3 --warmup 1 --no-cpu-baseline > $O/c4gan_trace_run.log 2>&1
 cp $(find /tmp/p_c4gan -name "*kernel_stats.csv" | head -1) $O/r02_c4gan_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_fvd -- python $R/bench.py --config fvd --steps 5 --warmup 3 --no-cpu-baseline > $O/fvd_trace_run.log 2>&1
+cp $(find /tmp/p_fvd -name "*kernel_stats.csv" | head -1) $O/r02_fvd_kernel_stats.csv
 # un-profiled bench lines
+python $R/bench.py --config fvd --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_fvd_bench_line.json
+python $R/bench.py --config fvd --fvd-dtype bf16 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/r02_fvd_bench_line.json
 python $R/bench.py --config c4gan --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_c4gan_bench_line.json
 python $R/bench.py --config c5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_c5_bench_line.json
 python $R/bench.py --config c4 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_c4_bench_line.json

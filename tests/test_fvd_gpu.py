@@ -172,3 +172,30 @@ def test_validation_loop_fvd():
     print(f"FVD-val {fvd_val:.5f} (oracle {want:.5f}); FVD-val-x0 {fvd_x0:.5f} (oracle {want_x0:.5f})")
     assert abs(fvd_val - want) <= 2e-3 * abs(want) and abs(fvd_x0 - want_x0) <= 2e-3 * abs(want_x0)
     assert model.logged["FVD-val"] == fvd_val and not model._fvd_fake
+
+
+def test_first_stage_validation_loop():
+    """SpadeCondMotionModel.validation_step / validation_epoch_end (first_stage_motion_model.py:303-367): rec_loss and the two FVDs
+    of the reconstructions against the oracle's values for the same clips."""
+    from ipoke_amd import configs
+    from ipoke_amd.first_stage import SpadeCondMotionModel
+    conf = configs.first_stage_config(64, 32, 16)
+    conf["logging"].update(bs_i3d=3, n_samples_fvd=6)
+    model = SpadeCondMotionModel(conf, dirs={}, dtype="f32").to(DEV).eval()
+    deterministic_fill_(model, prefix="first_stage.")
+    model.attach_fvd(i3d=_model("f32"))
+    kept_hat, kept_x = [], []
+    for i in range(2):
+        X = (torch.rand(3, 16, 3, 64, 64, generator=torch.Generator().manual_seed(40 + i)) * 2 - 1).to(DEV)
+        X_hat = model.validation_step({"images": X}, i)
+        want = (X[:, 1:] - X_hat).abs().mean().item()
+        assert abs(model.logged["val/rec_loss"].item() - want) <= 1e-5 * max(1.0, want)
+        kept_hat.append(X_hat.cpu()); kept_x.append(X.cpu())
+    fvd_val, fvd_x0 = model.validation_epoch_end()
+    o = fvd_ref.I3D(400)
+    deterministic_fill_(o, prefix="i3d.")
+    o.eval()
+    Xh, Xt = torch.cat(kept_hat), torch.cat(kept_x)
+    want, want_x0 = fvd_ref.fvd(o, Xh, Xt[:, 1:], 3), fvd_ref.fvd(o, torch.cat([Xt[:, :1], Xh], 1), Xt, 3)
+    print(f"first stage: FVD-val {fvd_val:.5f} (oracle {want:.5f}); FVD-val-x0 {fvd_x0:.5f} (oracle {want_x0:.5f})")
+    assert abs(fvd_val - want) <= 2e-3 * abs(want) and abs(fvd_x0 - want_x0) <= 2e-3 * abs(want_x0)
