@@ -369,6 +369,9 @@ typedef struct {
   const void* res; int32_t ld_res;
   int32_t act;
   float* workspace;                                      /* ipoke_groupnorm_workspace_floats(N, S, G) floats */
+  int32_t mod_samples;                                   /* > 0: mod_gamma / mod_beta hold mod_samples samples and sample n reads those of
+                                                            sample n % mod_samples (all generated frames of a clip share the SPADE maps of
+                                                            its start frame: the frames are decoded as ONE batch ordered (frame, clip)) */
 } ipoke_norm_desc;
 int64_t ipoke_groupnorm_workspace_floats(int N, int S, int G);
 int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream);

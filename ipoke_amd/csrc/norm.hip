@@ -138,6 +138,7 @@ struct NormApply {
   const float* stats;              // [N][G][2]
   const float* gamma; const float* beta;      // [C] affine or NULL
   const void* mod_gamma; const void* mod_beta; int ld_mod;   // SPADE: T [N*S][ld_mod]; y = xhat*(1+mg)+mb
+  int mod_N;                       // > 0: the modulation maps hold mod_N samples, sample n reads those of n % mod_N
   const void* res; int ld_res;     // optional residual added before the activation
   int act;
   int pos_per_block;
@@ -174,8 +175,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
       frag_t r, mg, mb;
       if (a.res) r = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.res) + m * a.ld_res + cc * E16);
       if (a.mod_gamma) {
-        mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + m * a.ld_mod + cc * E16);
-        mb = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_beta) + m * a.ld_mod + cc * E16);
+        const long mm = a.mod_N > 0 ? (long)(n % a.mod_N) * a.S + p : m;
+        mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + mm * a.ld_mod + cc * E16);
+        mb = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_beta) + mm * a.ld_mod + cc * E16);
       }
       float o[E16];
 #pragma unroll
@@ -373,6 +375,7 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
   a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.y_f32 = d->y_f32; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
   a.stats = stats; a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = d->mod_gamma; a.mod_beta = d->mod_beta; a.ld_mod = d->ld_mod;
   a.res = d->res; a.ld_res = d->ld_res; a.act = d->act;
+  a.mod_N = d->mod_samples > 0 && d->mod_samples < d->N ? d->mod_samples : 0;
   a.pos_per_block = 256;
   const int achunks = (d->S + a.pos_per_block - 1) / a.pos_per_block;
   DISPATCH_T(dtype,

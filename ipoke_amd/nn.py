@@ -122,6 +122,9 @@ def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=N
     d.gamma = 0 if gamma is None else gamma.data_ptr(); d.beta = 0 if beta is None else beta.data_ptr()
     if mod is not None:
         d.mod_gamma = mod[0].t.data_ptr(); d.mod_beta = mod[1].t.data_ptr(); d.ld_mod = mod[0].t.shape[1]
+        if mod[0].N != x.N:                     # frames of a clip decoded as one batch ordered (frame, clip): shared SPADE maps
+            assert x.N % mod[0].N == 0 and mod[0].S == x.S
+            d.mod_samples = mod[0].N
     if res is not None:
         d.res = res.t.data_ptr(); d.ld_res = res.t.shape[1]
     d.act = act
