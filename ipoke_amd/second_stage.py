@@ -233,12 +233,17 @@ class PokeMotionModel(nn.Module):
                 if torch.is_tensor(t_) and t_.is_cuda:
                     t_.record_stream(stream)
         flow_input.record_stream(cur); cond.record_stream(cur)
-        self._prefetched = (batch, flow_input, cond, ev)
+        if not isinstance(getattr(self, "_prefetched", None), dict):
+            self._prefetched = {}
+        # keyed FIFO: the next batch may be prefetched before this one is consumed (and a loop may feed the same object twice)
+        self._prefetched.setdefault(id(batch), []).append((batch, flow_input, cond, ev))
 
     def forward_density(self, batch):
-        pf = getattr(self, "_prefetched", None)
+        queue = (getattr(self, "_prefetched", None) or {}).get(id(batch))
+        pf = queue.pop(0) if queue else None
+        if queue is not None and not queue:
+            del self._prefetched[id(batch)]
         if pf is not None and pf[0] is batch:
-            self._prefetched = None
             torch.cuda.current_stream().wait_event(pf[3])
             flow_input, cond = pf[1], pf[2]
         else:

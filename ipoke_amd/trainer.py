@@ -42,6 +42,7 @@ class SecondStageTrainer:
         self.prefetch_stream = None
         if os.environ.get("IPOKE_NO_PREFETCH", "0") != "1" and torch.cuda.is_available():
             self.prefetch_stream = torch.cuda.Stream()
+        self.prefetch_at_start = os.environ.get("IPOKE_PREFETCH_AT", "after_bwd") == "start"
         model.flow.train()
 
     def _optimizer_step(self, fn):
@@ -98,8 +99,18 @@ class SecondStageTrainer:
     def train_step(self, batch, batch_idx=0, next_batch=None):
         m = self.model
         m.on_train_batch_start(batch, batch_idx, 0)
-        loss = m.training_step(batch, batch_idx)
         prefetch = next_batch is not None and self.prefetch_stream is not None
+        if prefetch and self.prefetch_at_start:
+            # developer switch IPOKE_PREFETCH_AT=start (measured, NOT adopted: 69.7 vs 63.7 ms): the next batch's frozen encoders
+            # queued BEFORE this step's forward, to run underneath it (no weight gradients / optimizer there) instead of behind
+            # the backward pass.  The forward chain is latency-bound; full-chip encoder kernels beside it slow it by more
+            # than the hole they leave (scripts/probe_host.py: the host needs 29 ms per step and is throttled by the queue depth,
+            # so the ~7 ms of queueing are not what costs).
+            step_start = torch.cuda.Event()
+            step_start.record()
+            m.prefetch_flow_input(next_batch, self.prefetch_stream, after=step_start)
+            prefetch = False
+        loss = m.training_step(batch, batch_idx)
         if prefetch:
             fwd_done = torch.cuda.Event()
             fwd_done.record()                 # the encoders of the next batch may start behind the forward pass ...
