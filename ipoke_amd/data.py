@@ -74,5 +74,7 @@ class PokeSimulator:
         """The ``batch`` dict the second stage consumes (images, flow, poke = [poke, poke_centers]) from frames already on the device
         and raw flows: the part of BaseDataset.__getitem__ that follows the file reads."""
         flow = self.get_flow(raw_flow)
-        poke, centers, flow_out, _ = self.get_poke(flow, zero_poke, u, generator)
-        return {"images": images, "flow": flow_out, "poke": [poke, centers]}
+        # no host synchronisation on the loader path: samples without a candidate (the reference's FlowError) are flagged in
+        # ``poke_status`` (int32 [B], 1 = resample), for the caller to inspect when it chooses to
+        poke, centers, flow_out, status = self.get_poke(flow, zero_poke, u, generator, strict=False)
+        return {"images": images, "flow": flow_out, "poke": [poke, centers], "poke_status": status}
