@@ -1,6 +1,6 @@
 """The assembled first-stage adversarial training step (ipoke_amd/first_stage_gan.py, reference
-first_stage_motion_model.py:160-277 without the VGG term) against the same step composed from the oracle's modules on the CPU
-(oracle/vae_ref.py, oracle/disc_ref.py -- each pinned to the reference by its own golden): loss values and the gradients
+first_stage_motion_model.py:160-277, with and without the VGG term) against the same step composed from the oracle's modules on
+the CPU (oracle/vae_ref.py, oracle/disc_ref.py, oracle/vgg_ref.py -- each pinned to the reference by its own golden): loss values and the gradients
 every optimiser sees, with frozen spectral-norm buffers and given random choices."""
 import copy
 import zlib
@@ -15,7 +15,7 @@ from ipoke_amd.first_stage import SpadeCondMotionModel
 from ipoke_amd.first_stage_gan import FirstStageGANTrainer
 from ipoke_amd.first_stage_train import MultiTensorAdam
 from ipoke_amd.utils.detfill import deterministic_fill_
-from oracle import disc_ref, vae_ref
+from oracle import disc_ref, vae_ref, vgg_ref
 
 pytestmark = pytest.mark.gpu
 DT_CFG = {"bce_loss": False, "gp_weight": 1.0, "num_classes": 1, "patch_temp_disc": False, "fmap_weight": 1.0, "gen_weight": 1.0,
@@ -32,7 +32,10 @@ def _abs_sum(d):
     return {k: v.detach().double().abs().sum().item() for k, v in d.items()}
 
 
-def test_gan_step_matches_oracle_composition(monkeypatch):
+@pytest.mark.parametrize("w_vgg", [0.0, 10.0])
+def test_gan_step_matches_oracle_composition(monkeypatch, w_vgg):
+    from ipoke_amd.vgg import VGGLoss
+    TRAIN = dict(globals()["TRAIN"], w_vgg=w_vgg)
     size, z, T_ = 64, 32, 5
     cfg = configs.first_stage_config(size, z, T_)
     gen = torch.Generator().manual_seed(11)
@@ -65,8 +68,11 @@ def test_gan_step_matches_oracle_composition(monkeypatch):
     pg, _ = os_(x_fake); l_gs = -pg.mean()
     pg, ff = ot(X_fake); _, ft = ot(X_true.detach()); l_gt = -pg.mean(); l_fm = ot.fmap_loss(ff, ft)
     l_rec = vae_ref.first_stage_loss(X, Xh, mu, lv, TRAIN["w_l1"], TRAIN["w_kl"])
+    ovgg = vgg_ref.VGGLoss()
+    deterministic_fill_(ovgg.vgg, prefix="vgg19.")
+    l_vgg = ovgg(X[:, 1:].reshape(-1, 3, size, size), Xh.reshape(-1, 3, size, size)) if w_vgg else torch.zeros(())
     og.zero_grad()
-    (l_rec + l_gs + DT_CFG["gen_weight"] * l_gt + DT_CFG["fmap_weight"] * l_fm).backward()
+    (l_rec + w_vgg * l_vgg + l_gs + DT_CFG["gen_weight"] * l_gt + DT_CFG["fmap_weight"] * l_fm).backward()
     ref.update(loss_g_s=l_gs.item(), loss_g_t=l_gt.item(), loss_fmap_t=l_fm.item(), loss=l_rec.item(),
                g_gen=_abs_sum({k: p.grad for k, p in og.named_parameters() if p.grad is not None}))
 
@@ -74,7 +80,10 @@ def test_gan_step_matches_oracle_composition(monkeypatch):
     m = SpadeCondMotionModel(copy.deepcopy(cfg), dirs={}, dtype="f32"); deterministic_fill_(m, prefix="first_stage."); m = m.cuda()
     dt_ = TemporalDiscriminator(size, DT_CFG, dtype="f32"); deterministic_fill_(dt_, prefix="disc_t."); dt_ = dt_.cuda()
     ds_ = PatchDiscriminator(DS_CFG, dtype="f32"); deterministic_fill_(ds_, prefix="disc_s."); ds_ = ds_.cuda()
-    tr = FirstStageGANTrainer(m, dt_, ds_, {"training": TRAIN, "d_t": DT_CFG, "d_s": DS_CFG, "data": {"max_frames": T_ - 1}})
+    vgg = VGGLoss(dtype="f32")
+    deterministic_fill_(vgg.vgg, prefix="vgg19.")
+    tr = FirstStageGANTrainer(m, dt_, ds_, {"training": TRAIN, "d_t": DT_CFG, "d_s": DS_CFG, "data": {"max_frames": T_ - 1}},
+                              vgg_loss=vgg.cuda() if w_vgg else None)
     seen = {}
     names = {id(tr.opt_dt): ("g_dt", dt_), id(tr.opt_ds): ("g_ds", ds_), id(tr.opt_g): ("g_gen", m)}
     orig = MultiTensorAdam.step
@@ -91,6 +100,9 @@ def test_gan_step_matches_oracle_composition(monkeypatch):
         print(f"{k}: {got:.6f} vs {want:.6f}")
         assert abs(got - want) <= 2e-4 * max(1.0, abs(want)), k
     assert abs(log["loss_gp_dt"].item() - ref["gp"]) <= 1e-3 * ref["gp"]
+    if w_vgg:
+        print(f"loss_vgg: {log['loss_vgg'].item():.6f} vs {l_vgg.item():.6f}")
+        assert abs(log["loss_vgg"].item() - l_vgg.item()) <= 2e-4 * max(1.0, abs(l_vgg.item()))
     for tag in ("g_dt", "g_ds", "g_gen"):
         worst = ("", 0.0)
         big = max(ref[tag].values())
