@@ -158,6 +158,12 @@ typedef struct {
 int ipoke_affine_fwd(const ipoke_affine_desc* d, const float* in, float* out, float* scale_out /* [M][Cp] or NULL */,
                      float* logdet_slot /* [B*slot_stride] or NULL */, int slot_stride, int B, void* stream);
 int ipoke_affine_inv(const ipoke_affine_desc* d, const float* in, float* out, int B, void* stream);
+/* The same with one more output: the channels the coupling just wrote, again as a dense zero-padded [M][ext_ld] operand of `dtype` --
+ * the conditioning input of the next coupling's first convolution when that coupling conditions on exactly these channels
+ * (coupling*_up followed by coupling*_dn, macow2.py:364-375, 397-448), which then needs no extract_cols launch.  ext may be NULL. */
+int ipoke_affine_fwd_ext(const ipoke_affine_desc* d, const float* in, float* out, float* scale_out, float* logdet_slot, int slot_stride,
+                         int B, void* ext, int ext_ld, int dtype, void* stream);
+int ipoke_affine_inv_ext(const ipoke_affine_desc* d, const float* in, float* out, int B, void* ext, int ext_ld, int dtype, void* stream);
 int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, const float* dy, const float* x,
                      const float* scale, const float* dld, float* dx, void* dparams /* dtype [M][ldp] */, int ldp,
                      float* dbias_part /* [B][2Cp] or NULL */, int B, int dtype, void* stream);

@@ -238,8 +238,23 @@ __device__ __forceinline__ void affine_copy_rest(const AffineArgs& a, long row0,
   }
 }
 // grid = B * Q: Q slices of P/Q positions per sample (Q = 4 when the log-det slot is 4 wide, like the MCF kernels)
+// ext (optional): the transformed channels once more as a dense, zero-padded [M][ext_ld] operand of the compute dtype -- the
+// conditioning input of the NEXT coupling when that one conditions on exactly these channels (coupling*_up -> coupling*_dn),
+// which saves its extract_cols launch
+template <typename T>
+__device__ __forceinline__ void affine_ext_store(void* ext, int ext_ld, long row, int i, float v) {
+  reinterpret_cast<T*>(ext)[row * ext_ld + i] = ET<T>::from_f32(v);
+}
+__device__ __forceinline__ void affine_ext_pad(const AffineArgs& a, void* ext, int ext_ld, int ext_bf16, long row0, int rows) {
+  const int pad = ext_ld - a.Cp;
+  for (int e = threadIdx.x; e < rows * pad; e += blockDim.x) {
+    const int p = e / pad, i = a.Cp + (e - p * pad);
+    if (ext_bf16) affine_ext_store<bf16_t>(ext, ext_ld, row0 + p, i, 0.f); else affine_ext_store<float>(ext, ext_ld, row0 + p, i, 0.f);
+  }
+}
 __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out,
-                                  float* __restrict__ scale_out, float* __restrict__ logdet_slot, int slot_stride, int Q) {
+                                  float* __restrict__ scale_out, float* __restrict__ logdet_slot, int slot_stride, int Q,
+                                  void* __restrict__ ext, int ext_ld, int ext_bf16) {
   if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   extern __shared__ float raw_s[];
   __shared__ float red[8];
@@ -254,14 +269,18 @@ __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, fl
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
-    out[off] = sc * in[off] + mu;
+    const float y = sc * in[off] + mu;
+    out[off] = y;
+    if (ext) { if (ext_bf16) affine_ext_store<bf16_t>(ext, ext_ld, row0 + p, i, y); else affine_ext_store<float>(ext, ext_ld, row0 + p, i, y); }
     if (scale_out) scale_out[(row0 + p) * a.Cp + i] = sc;
     ld_acc += logf(sc);
   }
+  if (ext && ext_ld > a.Cp) affine_ext_pad(a, ext, ext_ld, ext_bf16, row0, rows);
   const float tot = block_sum(ld_acc, red);
   if (threadIdx.x == 0 && logdet_slot) logdet_slot[(long)b * slot_stride + q] = tot;
 }
-__global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out, int Q) {
+__global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out, int Q,
+                                  void* __restrict__ ext, int ext_ld, int ext_bf16) {
   extern __shared__ float raw_s[];
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int rows = a.P / Q;
@@ -273,8 +292,11 @@ __global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, fl
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
-    out[off] = (in[off] - mu) / (sc + 1e-12f);      // macow_utils.py:64
+    const float y = (in[off] - mu) / (sc + 1e-12f);      // macow_utils.py:64
+    out[off] = y;
+    if (ext) { if (ext_bf16) affine_ext_store<bf16_t>(ext, ext_ld, row0 + p, i, y); else affine_ext_store<float>(ext, ext_ld, row0 + p, i, y); }
   }
+  if (ext && ext_ld > a.Cp) affine_ext_pad(a, ext, ext_ld, ext_bf16, row0, rows);
 }
 // backward.  x = saved layer input, scale = saved scales.  Produces
 //   dx (zp channels: dy*scale, others: dy copied),  dparams T [m][ldp] = [dmu | ds | 0 pad],
@@ -551,23 +573,34 @@ static AffineArgs to_args(const ipoke_affine_desc* d) {
   a.Cp = d->Cp; a.t_off = d->t_off; a.t_stride = d->t_stride; a.P = d->P; a.ld = d->ld;
   return a;
 }
-extern "C" int ipoke_affine_fwd(const ipoke_affine_desc* d, const float* in, float* out, float* scale_out,
-                                float* logdet_slot, int slot_stride, int B, void* stream) {
+extern "C" int ipoke_affine_fwd_ext(const ipoke_affine_desc* d, const float* in, float* out, float* scale_out,
+                                    float* logdet_slot, int slot_stride, int B, void* ext, int ext_ld, int dtype, void* stream) {
   int rc = check_affine(d); if (rc) return rc;
   IPK_REQUIRE(in && out, "null state");
+  IPK_REQUIRE(!ext || (ext_ld >= d->Cp && (dtype == IPOKE_BF16 || dtype == IPOKE_F32)), "bad extra operand output");
   const int Q = (slot_stride >= 4 || !logdet_slot) && d->P % 4 == 0 ? 4 : 1;
   hipLaunchKernelGGL(affine_fwd_kernel, dim3(B * Q), dim3(256), (size_t)(d->P / Q) * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d),
-                     in, out, scale_out, logdet_slot, slot_stride < 1 ? 1 : slot_stride, Q);
+                     in, out, scale_out, logdet_slot, slot_stride < 1 ? 1 : slot_stride, Q, ext, ext_ld, dtype == IPOKE_BF16 ? 1 : 0);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_affine_fwd(const ipoke_affine_desc* d, const float* in, float* out, float* scale_out,
+                                float* logdet_slot, int slot_stride, int B, void* stream) {
+  return ipoke_affine_fwd_ext(d, in, out, scale_out, logdet_slot, slot_stride, B, nullptr, 0, IPOKE_F32, stream);
+}
+extern "C" int ipoke_affine_inv_ext(const ipoke_affine_desc* d, const float* in, float* out, int B, void* ext, int ext_ld, int dtype,
+                                    void* stream) {
+  int rc = check_affine(d); if (rc) return rc;
+  IPK_REQUIRE(in && out, "null state");
+  IPK_REQUIRE(!ext || (ext_ld >= d->Cp && (dtype == IPOKE_BF16 || dtype == IPOKE_F32)), "bad extra operand output");
+  const int Q = d->P % 4 == 0 ? 4 : 1;
+  hipLaunchKernelGGL(affine_inv_kernel, dim3(B * Q), dim3(256), (size_t)(d->P / Q) * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d), in, out, Q,
+                     ext, ext_ld, dtype == IPOKE_BF16 ? 1 : 0);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
 extern "C" int ipoke_affine_inv(const ipoke_affine_desc* d, const float* in, float* out, int B, void* stream) {
-  int rc = check_affine(d); if (rc) return rc;
-  IPK_REQUIRE(in && out, "null state");
-  const int Q = d->P % 4 == 0 ? 4 : 1;
-  hipLaunchKernelGGL(affine_inv_kernel, dim3(B * Q), dim3(256), (size_t)(d->P / Q) * 2 * d->Cp * sizeof(float), STREAM(stream), to_args(d), in, out, Q);
-  IPK_LAUNCH_CHECK();
-  return IPOKE_OK;
+  return ipoke_affine_inv_ext(d, in, out, B, nullptr, 0, IPOKE_F32, stream);
 }
 extern "C" int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, const float* dy, const float* x,
                                 const float* scale, const float* dld, float* dx, void* dparams, int ldp,

@@ -477,13 +477,21 @@ void set_a_dense(ipoke_conv_desc& d, const void* act, int ld, int kc) {
 }
 
 int nice_splitk(const Ctx& c) { return max_splitk(*c.f, c.B); }
+// coupling `a` transforms exactly the channels coupling `b` conditions on (up -> dn pairs): a's transform also writes b's operand
+bool nice_feeds(const Op& a, const Op& b) {
+  static const int on = getenv("IPOKE_NO_EXTRACT_FUSION") ? 0 : 1;
+  return on && a.type == OP_NICE && b.type == OP_NICE && b.z_off == a.t_off && b.z_stride == a.t_stride && b.cin == a.cout;
+}
 
 // coupling net forward: conv1 -> ELU -> conv2 -> ELU -> conv3 (split-K partials)
-int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2, void* zc) {
+// `zc_ready`: the conditioning operand was already written by the preceding coupling's transform (ipoke_affine_*_ext)
+int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2, void* zc, bool zc_ready = false) {
   const int hid = c.f->cfg.hidden;
   ipoke_conv_desc d;
-  int rc0 = ipoke_extract_cols(in, c.ld, op.z_off, op.z_stride, op.cin, zc, op.Kc1, c.M, c.dtype, c.stream());
-  if (rc0) return rc0;
+  if (!zc_ready) {
+    int rc0 = ipoke_extract_cols(in, c.ld, op.z_off, op.z_stride, op.cin, zc, op.Kc1, c.M, c.dtype, c.stream());
+    if (rc0) return rc0;
+  }
   set_conv8(d, c.B, 3, 1);
   set_a_dense(d, zc, op.Kc1, op.Kc1);
   d.W = c.sh(op.sh_c1); d.ldw = 9 * op.Kc1; d.Nout = hid; d.act = IPOKE_ACT_ELU; d.C = h1; d.ldc = hid;
@@ -936,9 +944,17 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
         void* h1 = l.rows(save ? op.ws_a : l.plan.tmp_h1, hb);
         void* h2 = l.rows(save ? op.ws_b : l.plan.tmp_h2, hb);
         void* zc = save ? l.rows(op.ws_g, (int64_t)op.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
-        rc = nice_net(l, op, in, h1, h2, zc); if (rc) return rc;
+        const bool have_zc = i > 0 && nice_feeds(f->ops[i - 1], op);
+        rc = nice_net(l, op, in, h1, h2, zc, have_zc); if (rc) return rc;
         ipoke_affine_desc a; nice_affine_desc(l, op, a);
-        rc = ipoke_affine_fwd(&a, in, out, save ? l.rowsf(op.ws_c, op.cout) : nullptr, l.slot(op.slot), 4, l.B, l.stream());
+        void* ext = nullptr; int ext_ld = 0;
+        if (i + 1 < f->ops.size() && nice_feeds(op, f->ops[i + 1])) {
+          const Op& nx = f->ops[i + 1];
+          ext = save ? l.rows(nx.ws_g, (int64_t)nx.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
+          ext_ld = nx.Kc1;
+        }
+        rc = ipoke_affine_fwd_ext(&a, in, out, save ? l.rowsf(op.ws_c, op.cout) : nullptr, l.slot(op.slot), 4, l.B, ext, ext_ld, l.dtype,
+                                  l.stream());
       }
       if (rc) return rc;
     }
@@ -1036,10 +1052,13 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
         rc = ipoke_mcf_inv(&d, l.dtype, l.stream());
       } else {
         // the conditioning channels are untouched by the coupling, so the net sees the same input as in forward
-        rc = nice_net(l, op, in, l.rows(l.plan.tmp_h1, hb), l.rows(l.plan.tmp_h2, hb), l.rows(l.plan.tmp_zc, 64L * f->esz));
+        const bool have_zc = i + 1 < (int)f->ops.size() && nice_feeds(f->ops[i + 1], op);     // the coupling inverted just before this one
+        rc = nice_net(l, op, in, l.rows(l.plan.tmp_h1, hb), l.rows(l.plan.tmp_h2, hb), l.rows(l.plan.tmp_zc, 64L * f->esz), have_zc);
         if (rc) return rc;
         ipoke_affine_desc a; nice_affine_desc(l, op, a);
-        rc = ipoke_affine_inv(&a, in, out, l.B, l.stream());
+        const bool feed = i > 0 && nice_feeds(op, f->ops[i - 1]);
+        rc = ipoke_affine_inv_ext(&a, in, out, l.B, feed ? l.rows(l.plan.tmp_zc, 64L * f->esz) : nullptr, feed ? f->ops[i - 1].Kc1 : 0, l.dtype,
+                                  l.stream());
       }
       if (rc) return rc;
     }
