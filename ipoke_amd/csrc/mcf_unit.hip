@@ -105,6 +105,15 @@ __device__ __forceinline__ void unit_load_w2(McfW<T>& w, const void* W2, const U
     w.w2[st][0] = buf_frag<T>(rs, voff, st < n2 ? st * 1024 : kOob);   // unused K steps: out of range, zeros, no traffic
 }
 
+// Row pitch (floats) of the backward kernel's fp32 gradient tile: C rounded up to 4, plus 4 -- and 4 more when that is an EVEN
+// number of 16-byte units.  Fragment-shaped f32x4 accesses put the 16 lanes of a group on 16 consecutive rows; with an even pitch
+// (C = 60, 52, 44, ... : every second level of the flow) those rows fall on 8 or fewer of the 16 bank groups.
+__host__ __device__ inline int unit_gb_pitch(int C) {
+  int cp = ((C + 3) & ~3) + 4;
+  if (((cp >> 2) & 1) == 0) cp += 4;
+  return cp;
+}
+
 // fp32 transforms of the bf16-net mode: hardware exp / log / rcp (1-2 ulp) instead of the libm-grade tanhf / logf / expm1f
 // of the per-layer (parity-mode) kernels.  tanh(s/2) + 1 == 2 / (1 + exp(-s)); the ELU output is rounded to bf16 anyway.
 __device__ __forceinline__ float fast_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
   unsigned char* dp = smem;                                       // T [64][K3p]  (later: fp32 [64][C] tap-half partials)
   unsigned char* dc = dp + 64 * dp_pitch;                         // T [64 + zero row][Hq]
   float* gb = reinterpret_cast<float*>(dc + 65 * dc_pitch);       // [64][C] running gradient / dy*scale
-  const int CP = ((C + 3) & ~3) + 4;                              // row pitch of gb / part: 16-byte rows + 4 floats, so that the
+  const int CP = unit_gb_pitch(C);                                // row pitch of gb / part: an ODD number of 16-byte units, so that the
                                                                   // fragment-shaped accesses of phase (c) are bank-conflict free
   float* psum = gb + 64 * CP;                                     // [2][rows_par <= 64][2C] per-thread partial column sums
   float* red2 = psum + 2 * 4096;                                  // [2][Q][2C]
@@ -941,7 +950,7 @@ extern "C" int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* s
 #endif
   const bool wide = U.Cp > 32;
   const size_t dp_bytes = (size_t)64 * ((wide ? 128 : 64) * 2 + 16);
-  const size_t CP = ((U.C + 3) & ~3) + 4;
+  const size_t CP = unit_gb_pitch(U.C);
   const size_t lds = dp_bytes + (size_t)65 * ((wide ? 256 : 128) * 2 + 16) + (size_t)64 * CP * 4 + (2 * 4096 + 2 * 512) * 4;
   IPK_REQUIRE((size_t)64 * CP * 4 <= dp_bytes, "tap-half partials must fit the dparams tile");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
