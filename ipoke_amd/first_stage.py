@@ -34,6 +34,8 @@ class _Cached(nn.Module):
     def invalidate(self):
         for m in self.modules():
             m.__dict__.pop("_opcache", None)
+        from . import first_stage_train
+        first_stage_train.clear_operand_cache()
 
     def _load_from_state_dict(self, *a, **k):
         self.__dict__.pop("_opcache", None)
@@ -547,3 +549,5 @@ class SpadeCondMotionModel(nn.Module):
         """Drop the cached inference weight operands (after an optimiser step or a state-dict load)."""
         for m in self.modules():
             m.__dict__.pop("_opcache", None)
+        from . import first_stage_train
+        first_stage_train.clear_operand_cache()

@@ -57,9 +57,32 @@ def _pad_cols(t, ld, dtype):
     return out
 
 
-def _weight_operand(w, dtype, transposed_conv, inv_scale=None):
+_OPCACHE = {}
+
+
+def clear_operand_cache():
+    """Called whenever parameters change behind autograd's back (MultiTensorAdam writes through raw pointers)."""
+    _OPCACHE.clear()
+
+
+def _weight_operand(w, dtype, transposed_conv, inv_scale=None, cacheable=False):
     """fp32 conv weight in PyTorch layout -> ([rows][taps*kc] operand of the compute dtype, kc); ``transposed_conv`` reads
-    ConvTranspose storage [in][out][k] as the conv weight [out][in][k]; ``inv_scale``: device scalar (1/sigma)."""
+    ConvTranspose storage [in][out][k] as the conv weight [out][in][k]; ``inv_scale``: device scalar (1/sigma).
+    ``cacheable`` (module parameters without spectral norm: GRU, SPADE, VGG convolutions): the operand of a weight version is
+    built once and reused by the 15 per-frame calls of a step and by the backward pass."""
+    key = None
+    if cacheable and inv_scale is None:
+        key = (w.data_ptr(), w._version, tuple(w.shape), bool(transposed_conv), str(dtype), torch.cuda.current_stream().cuda_stream)
+        hit = _OPCACHE.get(key)
+        if hit is not None:
+            return hit
+    res = _build_weight_operand(w, dtype, transposed_conv, inv_scale)
+    if key is not None:
+        _OPCACHE[key] = res
+    return res
+
+
+def _build_weight_operand(w, dtype, transposed_conv, inv_scale=None):
     w = w.contiguous()
     taps = 1
     for k in w.shape[2:]:
@@ -92,7 +115,8 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x_t, w, bias, meta):
         dt = meta["dtype"]
         sn = meta.get("sn")                       # (sig, snap): w is weight_orig, the operand carries 1/sigma
-        wop, kc = _weight_operand(w.detach(), dt, meta["transposed"], None if sn is None else sn[0][1:])
+        meta["w_param"] = isinstance(w, torch.nn.Parameter) and sn is None
+        wop, kc = _weight_operand(w.detach(), dt, meta["transposed"], None if sn is None else sn[0][1:], cacheable=meta["w_param"])
         b = None if bias is None else bias.detach().float().contiguous()
         src = meta.get("src")
         x = None if src is not None else K.CL(x_t, meta["N"], meta["dhw"], meta["cin"])
@@ -198,11 +222,11 @@ class _ConvFn(torch.autograd.Function):
             gcl = K.CL(g, N, odhw, cout)
             if not m["transposed"]:
                 # conv weight [cout, cin, k] read as a ConvTranspose weight [in=cout, out=cin, k]
-                wop, kc = _weight_operand(w.detach(), dt, True, inv)
+                wop, kc = _weight_operand(w.detach(), dt, True, inv, cacheable=m.get("w_param", False))
                 opad = tuple(i - ((o - 1) * s_ - 2 * p + kk) for i, o, s_, p, kk in zip(idhw, odhw, st, pd, k))
                 dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt, transposed=True, out_pad=opad)
             else:
-                wop, kc = _weight_operand(w.detach(), dt, False, inv)         # [in, out, k] read as conv weight [cout'=in]
+                wop, kc = _weight_operand(w.detach(), dt, False, inv, cacheable=m.get("w_param", False))         # [in, out, k] read as conv weight [cout'=in]
                 dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt)
             assert dx.dhw == tuple(idhw), (dx.dhw, idhw)
             d_x = dx.t
@@ -640,6 +664,7 @@ class MultiTensorAdam:
         grads = [self.params[i].grad.contiguous() for i in idx]
         arr = lambda ts: (ct.c_void_p * n)(*[t.data_ptr() for t in ts])
         sizes = (ct.c_int64 * n)(*[self.params[i].numel() for i in idx])
+        clear_operand_cache()                      # the update writes through raw pointers: no version bump tells the cache
         check(_lib.lib().ipoke_adam_multi(arr([self.params[i].data for i in idx]), arr(grads), arr([self.exp_avg[i] for i in idx]),
                                           arr([self.exp_avg_sq[i] for i in idx]), sizes, n, self.lr, self.betas[0], self.betas[1],
                                           self.eps, self.weight_decay, self.steps, 1.0, _lib.current_stream()))
