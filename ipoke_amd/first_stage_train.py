@@ -65,14 +65,14 @@ def clear_operand_cache():
     _OPCACHE.clear()
 
 
-def _weight_operand(w, dtype, transposed_conv, inv_scale=None, cacheable=False):
+def _weight_operand(w, dtype, transposed_conv, inv_scale=None, cacheable=False, scope=None):
     """fp32 conv weight in PyTorch layout -> ([rows][taps*kc] operand of the compute dtype, kc); ``transposed_conv`` reads
     ConvTranspose storage [in][out][k] as the conv weight [out][in][k]; ``inv_scale``: device scalar (1/sigma).
     ``cacheable`` (module parameters without spectral norm: GRU, SPADE, VGG convolutions): the operand of a weight version is
     built once and reused by the 15 per-frame calls of a step and by the backward pass."""
     key = None
     if cacheable and inv_scale is None:
-        key = (w.data_ptr(), w._version, tuple(w.shape), bool(transposed_conv), str(dtype), torch.cuda.current_stream().cuda_stream)
+        key = (w.data_ptr(), w._version, tuple(w.shape), bool(transposed_conv), str(dtype), torch.cuda.current_stream().cuda_stream, scope)
         hit = _OPCACHE.get(key)
         if hit is not None:
             return hit
@@ -115,8 +115,9 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x_t, w, bias, meta):
         dt = meta["dtype"]
         sn = meta.get("sn")                       # (sig, snap): w is weight_orig, the operand carries 1/sigma
-        meta["w_param"] = isinstance(w, torch.nn.Parameter) and sn is None
-        wop, kc = _weight_operand(w.detach(), dt, meta["transposed"], None if sn is None else sn[0][1:], cacheable=meta["w_param"])
+        meta["w_param"] = (isinstance(w, torch.nn.Parameter) or meta.get("w_scope") is not None) and sn is None
+        wop, kc = _weight_operand(w.detach(), dt, meta["transposed"], None if sn is None else sn[0][1:], cacheable=meta["w_param"],
+                                  scope=meta.get("w_scope"))
         b = None if bias is None else bias.detach().float().contiguous()
         src = meta.get("src")
         x = None if src is not None else K.CL(x_t, meta["N"], meta["dhw"], meta["cin"])
@@ -222,11 +223,11 @@ class _ConvFn(torch.autograd.Function):
             gcl = K.CL(g, N, odhw, cout)
             if not m["transposed"]:
                 # conv weight [cout, cin, k] read as a ConvTranspose weight [in=cout, out=cin, k]
-                wop, kc = _weight_operand(w.detach(), dt, True, inv, cacheable=m.get("w_param", False))
+                wop, kc = _weight_operand(w.detach(), dt, True, inv, cacheable=m.get("w_param", False), scope=m.get("w_scope"))
                 opad = tuple(i - ((o - 1) * s_ - 2 * p + kk) for i, o, s_, p, kk in zip(idhw, odhw, st, pd, k))
                 dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt, transposed=True, out_pad=opad)
             else:
-                wop, kc = _weight_operand(w.detach(), dt, False, inv, cacheable=m.get("w_param", False))         # [in, out, k] read as conv weight [cout'=in]
+                wop, kc = _weight_operand(w.detach(), dt, False, inv, cacheable=m.get("w_param", False), scope=m.get("w_scope"))   # [in, out, k] read as conv weight [cout'=in]
                 dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt)
             assert dx.dhw == tuple(idhw), (dx.dhw, idhw)
             d_x = dx.t
@@ -434,16 +435,25 @@ class _GruUpdateFn(torch.autograd.Function):
         return d_o, d_u, d_h, None, None
 
 
-def gru_cell(cell, x, h, dtype):
+_FWD_EPOCH = [0]      # forward passes so far: scopes cached operands of per-pass temporaries (the concatenated GRU gate weights)
+
+
+def gru_gate_weights(cell):
+    """update | reset gate weights and biases as one convolution (built once per forward pass, shared by its time steps)."""
+    return (torch.cat([cell.update_gate.weight, cell.reset_gate.weight], 0), torch.cat([cell.update_gate.bias, cell.reset_gate.bias]))
+
+
+def gru_cell(cell, x, h, dtype, gate_w=None):
     """ConvGRUCell.run with gradients (rnn.py:48-56)."""
     Ch = cell.hidden
     xh = torch.cat([x.t[:, :x.C], h.t[:, :Ch]], dim=1)
     xh_cl = K.CL(xh, x.N, x.dhw, x.C + Ch)
     # update and reset gates share their input: one GEMM with the concatenated weights (update first)
-    w_ur = torch.cat([cell.update_gate.weight, cell.reset_gate.weight], 0)
-    b_ur = torch.cat([cell.update_gate.bias, cell.reset_gate.bias])
+    w_ur, b_ur = gru_gate_weights(cell) if gate_w is None else gate_w
     meta = dict(N=x.N, dhw=tuple(x.dhw), cin=x.C + Ch, cout=2 * Ch, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), transposed=False,
                 out_pad=(0, 0, 0), dtype=dtype, act=_lib.ACT_NONE, out_f32=False, src=None)
+    if gate_w is not None:
+        meta["w_scope"] = _FWD_EPOCH[0]           # the same tensor for every time step of this pass: its operand is built once
     ur = _ConvFn.apply(xh, w_ur, b_ur, meta)
     hr, u = _GruGatesFn.apply(ur[:, :2 * Ch].contiguous(), h.t, Ch, dtype)
     xhr = torch.cat([x.t[:, :x.C], hr], dim=1)
@@ -619,11 +629,15 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
     n_out = B * (T - 1) * 3 * X.shape[-1] * X.shape[-2]
     l1 = 0.0
     frames = []
+    _FWD_EPOCH[0] += 1
+    if len(_OPCACHE) > 4096:
+        clear_operand_cache()                      # scoped entries of passes whose backward never ran
+    gate_w = [gru_gate_weights(cell) for cell in model.rnn.cells]
     for t in range(T - 1):
         xin = in_rnn
         new_hidden = []
-        for cell, h in zip(model.rnn.cells, hidden):
-            xin = gru_cell(cell, xin, h, dt)
+        for cell, gw, h in zip(model.rnn.cells, gate_w, hidden):
+            xin = gru_cell(cell, xin, h, dt, gw)
             new_hidden.append(xin)
         hidden = new_hidden
         pre = decode_frame(model.gen, hidden[-1], x0, dt, pit)
