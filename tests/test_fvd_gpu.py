@@ -199,3 +199,20 @@ def test_first_stage_validation_loop():
     want, want_x0 = fvd_ref.fvd(o, Xh, Xt[:, 1:], 3), fvd_ref.fvd(o, torch.cat([Xt[:, :1], Xh], 1), Xt, 3)
     print(f"first stage: FVD-val {fvd_val:.5f} (oracle {want:.5f}); FVD-val-x0 {fvd_x0:.5f} (oracle {want_x0:.5f})")
     assert abs(fvd_val - want) <= 2e-3 * abs(want) and abs(fvd_x0 - want_x0) <= 2e-3 * abs(want_x0)
+
+
+@pytest.mark.parametrize("T", [9, 32])
+def test_i3d_other_clip_lengths(T):
+    """Clip lengths the goldens do not hold: 9 frames (odd remainders on the time axis at every strided layer) and 32 frames (three
+    windows of the (2, 7, 7) average pool, i.e. the head's weighted time mean with unequal frame weights) against the oracle's I3D."""
+    m = _model("f32")
+    o = fvd_ref.I3D(400)
+    deterministic_fill_(o, prefix="i3d.")
+    o.eval()
+    vids = torch.rand(2, T, 3, 48, 48, generator=torch.Generator().manual_seed(T)) * 2 - 1
+    with torch.no_grad():
+        want = o(fvd_ref.preprocess(vids).permute(0, 2, 1, 3, 4))
+    got = fvd._activations(m, vids.to(DEV), 2, fvd._resized_min(vids.to(DEV)), resize=(224, 224)).cpu()
+    err = (got - want).abs().max().item()
+    print(f"T={T}: logits err {err:.2e} (|logits| <= {want.abs().max():.2f})")
+    assert err <= 1e-4
