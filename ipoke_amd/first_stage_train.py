@@ -58,6 +58,7 @@ def _pad_cols(t, ld, dtype):
 
 
 _OPCACHE = {}
+_HOIST_SPADE = os.environ.get("IPOKE_NO_SPADE_HOIST", "0") != "1"      # developer A/B: per-frame SPADE maps as the reference computes them
 
 
 def clear_operand_cache():
@@ -596,14 +597,26 @@ def spade_modulation(sp, y_nchw, size, dtype):
     return conv(sp.conv_gamma, h, dtype), conv(sp.conv_beta, h, dtype)
 
 
-def decode_frame(gen, h, start_frame, dtype, pit):
+def spade_modulations(gen, start_frame, dtype):
+    """(gamma, beta) maps of every SPADE block for a clip's start frame.  util.py:494-500 recomputes them in every decoder call; they
+    are a function of the start frame and of three plain (not spectral-normalised) convolutions only, so the frames of a clip share
+    them: computed once per pass, every frame's GroupNorm reads the same maps, autograd sums the frames' gradients into them and the
+    three convolutions are differentiated once -- the same values, (T - 2) / (T - 1) fewer SPADE convolutions in both directions."""
+    size, mods = 8, []
+    for sp in gen.spade_blocks:
+        size *= 2
+        mods.append(spade_modulation(sp, start_frame, (size, size), dtype))
+    return mods
+
+
+def decode_frame(gen, h, start_frame, dtype, pit, mods=None):
     """SpadeCondConvDecoder.forward for one frame; returns the pre-tanh output [M, 3] fp32 (CL)."""
     x = res_block(gen.in_block, h, dtype, pit=pit)
     size = 8
-    for blk, sp in zip(gen.blocks, gen.spade_blocks):
+    for i, (blk, sp) in enumerate(zip(gen.blocks, gen.spade_blocks)):
         x = res_block(blk, x, dtype, pit=pit)
         size *= 2
-        mod = spade_modulation(sp, start_frame, (size, size), dtype)       # recomputed per frame as in the reference
+        mod = mods[i] if mods is not None else spade_modulation(sp, start_frame, (size, size), dtype)
         x = group_norm(x, sp.groups, dtype, mod=mod)
     return conv_block(gen.out_conv, x, dtype, out_f32=True)
 
@@ -633,6 +646,7 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
     if len(_OPCACHE) > 4096:
         clear_operand_cache()                      # scoped entries of passes whose backward never ran
     gate_w = [gru_gate_weights(cell) for cell in model.rnn.cells]
+    mods = spade_modulations(model.gen, x0, dt) if _HOIST_SPADE else None
     for t in range(T - 1):
         xin = in_rnn
         new_hidden = []
@@ -640,7 +654,7 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
             xin = gru_cell(cell, xin, h, dt, gw)
             new_hidden.append(xin)
         hidden = new_hidden
-        pre = decode_frame(model.gen, hidden[-1], x0, dt, pit)
+        pre = decode_frame(model.gen, hidden[-1], x0, dt, pit, mods)
         lt, frame = _L1TanhFn.apply(pre.t, X[:, t + 1], 1.0 / n_out)
         l1 = l1 + lt
         frames.append(frame.view(B, pre.dhw[1], pre.dhw[2], 3).permute(0, 3, 1, 2))
