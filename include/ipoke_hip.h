@@ -452,6 +452,22 @@ int ipoke_conv_weight_operand(const float* w, int cout, int cin, int taps, int t
 long ipoke_spectral_workspace_floats(int cout, int cin, int taps);
 int ipoke_spectral_sigma(const float* w, int cout, int cin, int taps, int transposed, float* u, float* v, int iterate, float eps,
                          float* out, float* snapshot, float* workspace, void* stream);
+/* Several power iterations of several weights ahead of time: torch's spectral_norm iterates once per forward call of the wrapped
+ * module (first_stage_motion_model.py decodes T - 1 frames per pass through the same decoder convolutions); the iterations depend on
+ * the weight and its own u / v only, so the T - 1 {sigma, 1/sigma} pairs and u | v snapshots of every decoder weight are produced by
+ * 3 launches per iteration instead of 3 per call.  Same arithmetic as ipoke_spectral_sigma(iterate = 1), call by call. */
+typedef struct {
+  const float* w; int32_t cout, cin, taps, transposed;
+  float* u; float* v;                    /* updated in place, as after `iterations` calls                                  */
+  float* out; int64_t out_stride;        /* iteration k: {sigma, 1/sigma} at out + k * out_stride                            */
+  float* snap; int64_t snap_stride;      /* iteration k: u | v snapshot (cout + cin*taps floats) at snap + k * snap_stride    */
+  float* workspace;                      /* ipoke_spectral_workspace_floats floats, zeroed once (shared with ipoke_spectral_sigma) */
+} ipoke_sn_job;
+int ipoke_sn_job_size(void);             /* bytes per job of the device-side table the caller provides */
+/* host jobs -> device table (synchronises; once per model: the pointers stay valid across steps) */
+int ipoke_sn_jobs_upload(const ipoke_sn_job* jobs, int njobs, void* jobs_dev, void* stream);
+/* `iterations` power iterations of every job, 3 launches per iteration; max_rows / max_cols: largest cout / cin*taps of the table */
+int ipoke_spectral_sigma_multi(const void* jobs_dev, int njobs, int max_rows, int max_cols, int iterations, float eps, void* stream);
 /* in place: gradient w.r.t. w_orig / sigma -> gradient w.r.t. w_orig:  (G - <G, W/sigma> u v^T) / sigma.
  * workspace: 2 floats, zeroed once by the caller. */
 int ipoke_spectral_bwd(const float* w, int cout, int cin, int taps, int transposed, float* grad, const float* snapshot,

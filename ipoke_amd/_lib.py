@@ -74,6 +74,12 @@ class NormDesc(Structure):
                 ("res", c_void_p), ("ld_res", c_int32), ("act", c_int32), ("workspace", c_void_p), ("mod_samples", c_int32)]
 
 
+class SnJob(Structure):
+    _fields_ = [("w", c_void_p), ("cout", c_int32), ("cin", c_int32), ("taps", c_int32), ("transposed", c_int32),
+                ("u", c_void_p), ("v", c_void_p), ("out", c_void_p), ("out_stride", c_int64), ("snap", c_void_p), ("snap_stride", c_int64),
+                ("workspace", c_void_p)]
+
+
 class FlowConfig(Structure):
     _fields_ = [("z_channels", c_int32), ("hidden", c_int32), ("cond_channels", c_int32), ("factor", c_int32),
                 ("n_levels", c_int32), ("num_steps", c_int32 * 32), ("kernel_h", c_int32), ("kernel_w", c_int32),
@@ -151,6 +157,9 @@ SIGNATURES = {
     "ipoke_spectral_workspace_floats": (ctypes.c_long, [c_int, c_int, c_int]),
     "ipoke_spectral_sigma": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, ctypes.c_float, _P, _P, _P, _P]),
     "ipoke_spectral_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "ipoke_sn_job_size": (c_int, []),
+    "ipoke_sn_jobs_upload": (c_int, [_P, c_int, _P, _P]),
+    "ipoke_spectral_sigma_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P]),
     "ipoke_adam_multi": (c_int, [_P, _P, _P, _P, _P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, c_int, ctypes.c_float, _P]),
     "ipoke_maxpool3d_fwd": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P]),

@@ -8,6 +8,8 @@
 //   * KL(q || N(0,1)) value and gradient in one pass (utils/losses.py:47-48).
 // All of it is HBM-bound streaming work: every weight element is read once per pass (twice per power iteration).
 #include "common.h"
+
+#include <vector>
 #include <cstring>
 
 namespace ipoke {
@@ -89,6 +91,61 @@ __global__ __launch_bounds__(256) void sn_final_kernel(int R, int C, float* __re
   s = block_sum(s, red);
   if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; acc[0] = 0.f; acc[1] = 0.f; }
 }
+// ---- the same three kernels over MANY weights per launch (blockIdx.z = job) and a given iteration index: a decoder weight is
+// normalised once per generated frame, i.e. T - 1 power iterations per training pass whose inputs are the weight and its own
+// u / v only -- they are run ahead of the time loop, one launch triple per iteration for all weights instead of one per call.
+struct SnJob { SnView V; float* u; float* v; float* out; float* snap; float* ws; long out_stride, snap_stride; };
+__global__ __launch_bounds__(256) void sn_cols_multi_kernel(const SnJob* __restrict__ jobs) {
+  const SnJob J = jobs[blockIdx.z];
+  const SnView& V = J.V;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * kSnRowChunk, r1 = min(V.R, r0 + kSnRowChunk);
+  if (c >= V.C || r0 >= V.R) return;
+  float* tv = J.ws + 4 + V.R;
+  const int c1 = c / V.n2, c2 = c - c1 * V.n2;
+  const float* col = V.w + (long)c1 * V.s_1 + c2;
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s = fmaf(col[(long)r * V.s_r], J.u[r], s);
+  atomicAdd(tv + c, s);
+}
+__global__ __launch_bounds__(256) void sn_rows_multi_kernel(const SnJob* __restrict__ jobs, float eps) {
+  __shared__ float red[4];
+  const SnJob J = jobs[blockIdx.z];
+  const SnView& V = J.V;
+  if ((int)blockIdx.x * 4 >= V.R) return;
+  float* acc = J.ws; float* tu = J.ws + 4; float* tv = tu + V.R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sq = 0.f;
+  for (int c = threadIdx.x; c < V.C; c += 256) sq = fmaf(tv[c], tv[c], sq);
+  const float inv = 1.f / fmaxf(sqrtf(block_sum(sq, red)), eps);
+  const int r = blockIdx.x * 4 + wave;
+  if (r < V.R) {
+    float s = 0.f;
+    for (int c = lane; c < V.C; c += 64) s = fmaf(sn_at(V, r, c), tv[c] * inv, s);
+    s = wave_sum(s);
+    if (lane == 0) { tu[r] = s; atomicAdd(acc + 1, s * s); }
+  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < V.C; c += 256) J.v[c] = tv[c] * inv;
+}
+__global__ __launch_bounds__(256) void sn_final_multi_kernel(const SnJob* __restrict__ jobs, int it, float eps) {
+  __shared__ float red[4];
+  const SnJob J = jobs[blockIdx.z];
+  const int R = J.V.R, C = J.V.C;
+  float* acc = J.ws; float* tu = J.ws + 4; float* tv = tu + R;
+  float* out = J.out + (long)it * J.out_stride; float* snap = J.snap + (long)it * J.snap_stride;
+  const float inv = 1.f / fmaxf(sqrtf(acc[1]), eps);
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float ur = tu[r] * inv;
+    J.u[r] = ur; snap[r] = ur;
+    s = fmaf(ur, tu[r], s);
+  }
+  for (int c = threadIdx.x; c < C; c += 256) { snap[R + c] = J.v[c]; tv[c] = 0.f; }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; acc[0] = 0.f; acc[1] = 0.f; }
+}
+
 // backward of w_eff = w / sigma with sigma = u^T W v (u, v constants):  dW = (G - <G, W_eff> u v^T) / sigma
 __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(SnView V, const float* __restrict__ g, float* __restrict__ acc) {
   __shared__ float red[4];
@@ -462,6 +519,40 @@ extern "C" int ipoke_spectral_sigma(const float* w, int cout, int cin, int taps,
   hipLaunchKernelGGL(sn_rows_kernel, dim3((V.R + 3) / 4), dim3(256), 0, STREAM(stream), V, tv, v, tu, acc, iterate, eps);
   IPK_LAUNCH_CHECK();
   hipLaunchKernelGGL(sn_final_kernel, dim3(1), dim3(256), 0, STREAM(stream), V.R, V.C, u, v, tu, acc, out, snapshot, iterate, eps, tv);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* Device-side job table of ipoke_spectral_sigma_multi: jobs (HOST array) -> jobs_dev (njobs * ipoke_sn_job_size() bytes owned by the
+ * caller).  Synchronises the stream (done once per model, the table holds pointers that stay valid across steps). */
+extern "C" int ipoke_sn_job_size(void) { return (int)sizeof(SnJob); }
+extern "C" int ipoke_sn_jobs_upload(const ipoke_sn_job* jobs, int njobs, void* jobs_dev, void* stream) {
+  IPK_REQUIRE(jobs && jobs_dev && njobs >= 1, "bad arguments");
+  std::vector<SnJob> h(njobs);
+  for (int i = 0; i < njobs; ++i) {
+    const ipoke_sn_job& j = jobs[i];
+    IPK_REQUIRE(j.w && j.u && j.v && j.out && j.snap && j.workspace && j.cout >= 1 && j.cin >= 1 && j.taps >= 1, "bad spectral-norm job");
+    h[i].V = sn_view(j.w, j.cout, j.cin, j.taps, j.transposed);
+    h[i].u = j.u; h[i].v = j.v; h[i].out = j.out; h[i].snap = j.snap; h[i].ws = j.workspace;
+    h[i].out_stride = j.out_stride; h[i].snap_stride = j.snap_stride;
+  }
+  hipStream_t s = STREAM(stream);
+  IPK_HIP(hipMemcpyAsync(jobs_dev, h.data(), (size_t)njobs * sizeof(SnJob), hipMemcpyHostToDevice, s));
+  IPK_HIP(hipStreamSynchronize(s));
+  return IPOKE_OK;
+}
+/* `iterations` successive power iterations of the `njobs` weights of an uploaded table, three launches per iteration for all of them
+ * (max_rows / max_cols: the largest cout / cin*taps among the jobs); iteration k writes {sigma, 1/sigma} to out + k*out_stride and the
+ * u | v snapshot to snap + k*snap_stride; u, v end as after the last iteration.  No host synchronisation. */
+extern "C" int ipoke_spectral_sigma_multi(const void* jobs_dev, int njobs, int max_rows, int max_cols, int iterations, float eps, void* stream) {
+  IPK_REQUIRE(jobs_dev && njobs >= 1 && iterations >= 1 && max_rows >= 1 && max_cols >= 1, "bad arguments");
+  hipStream_t s = STREAM(stream);
+  const SnJob* jd = reinterpret_cast<const SnJob*>(jobs_dev);
+  for (int it = 0; it < iterations; ++it) {
+    hipLaunchKernelGGL(sn_cols_multi_kernel, dim3((max_cols + 255) / 256, (max_rows + kSnRowChunk - 1) / kSnRowChunk, njobs), dim3(256), 0, s, jd);
+    hipLaunchKernelGGL(sn_rows_multi_kernel, dim3((max_rows + 3) / 4, 1, njobs), dim3(256), 0, s, jd, eps);
+    hipLaunchKernelGGL(sn_final_multi_kernel, dim3(1, 1, njobs), dim3(256), 0, s, jd, it, eps);
+  }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -58,6 +58,7 @@ def _pad_cols(t, ld, dtype):
 
 
 _OPCACHE = {}
+_SN_AHEAD = os.environ.get("IPOKE_NO_SN_AHEAD", "0") != "1"            # developer A/B: one power iteration per decoder call, at the call
 _HOIST_SPADE = os.environ.get("IPOKE_NO_SPADE_HOIST", "0") != "1"      # developer A/B: per-frame SPADE maps as the reference computes them
 
 
@@ -262,6 +263,10 @@ def effective_weight(mod, power_iteration=False):
     if not mod.snorm:
         return mod.weight
     w = mod.weight_orig
+    pre = mod.__dict__.get("_sn_pre")
+    if power_iteration and pre:                   # this call's iteration was run ahead of the time loop (precompute_power_iterations)
+        sig, snap = pre.pop(0)
+        return _SnWeight(w, sig, snap, mod.transposed, mod)
     taps = 1
     for k in w.shape[2:]:
         taps *= int(k)
@@ -275,6 +280,60 @@ def effective_weight(mod, power_iteration=False):
     check(lib.ipoke_spectral_sigma(ptr(w), rows, cols, taps, int(mod.transposed), ptr(mod.weight_u), ptr(mod.weight_v),
                                    int(bool(power_iteration)), 1e-12, ptr(sig), ptr(snap), ptr(ws), _lib.current_stream()))
     return _SnWeight(w, sig, snap, mod.transposed, mod)
+
+
+def _sn_geometry(mod):
+    w = mod.weight_orig
+    taps = 1
+    for k in w.shape[2:]:
+        taps *= int(k)
+    rows, cols = (w.shape[1], w.shape[0]) if mod.transposed else (w.shape[0], w.shape[1])
+    return rows, cols, taps
+
+
+def precompute_power_iterations(root, calls):
+    """Run the ``calls`` power iterations that the next ``calls`` forward calls of every spectral-normalised convolution under
+    ``root`` would perform (torch's spectral_norm iterates once per call; the decoder is called once per generated frame), three
+    launches per iteration for ALL weights (ipoke_spectral_sigma_multi) instead of three per call.  Each module's queue ``_sn_pre``
+    then hands the (sigma, snapshot) pairs to ``effective_weight`` call by call -- the same arithmetic in the same order per weight."""
+    import ctypes
+    mods = [m for m in root.modules() if isinstance(m, FS._Conv) and m.snorm]
+    if not mods or calls < 1:
+        return []
+    lib = _lib.lib()
+    dev = mods[0].weight_orig.device
+    geo = [_sn_geometry(m) for m in mods]
+    for m, (r, c, t) in zip(mods, geo):
+        ws = getattr(m, "_sn_ws", None)
+        if ws is None or ws.device != dev:
+            m._sn_ws = torch.zeros(int(lib.ipoke_spectral_workspace_floats(r, c, t)), dtype=torch.float32, device=dev)
+    key = (calls,) + tuple((m.weight_orig.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(), m._sn_ws.data_ptr()) for m in mods)
+    cache = root.__dict__.get("_sn_multi")
+    if cache is None or cache["key"] != key:
+        sizes = [r + c * t for r, c, t in geo]
+        sig_all = torch.empty(len(mods), calls, 2, dtype=torch.float32, device=dev)
+        snap_all = torch.empty(calls * sum(sizes), dtype=torch.float32, device=dev)
+        jobs = (_lib.SnJob * len(mods))()
+        snaps, off = [], 0
+        for i, (m, (r, c, t), n) in enumerate(zip(mods, geo, sizes)):
+            sv = snap_all[off:off + calls * n].view(calls, n)
+            off += calls * n
+            snaps.append(sv)
+            j = jobs[i]
+            j.w = m.weight_orig.data_ptr(); j.cout, j.cin, j.taps, j.transposed = r, c, t, int(m.transposed)
+            j.u = m.weight_u.data_ptr(); j.v = m.weight_v.data_ptr()
+            j.out = sig_all[i].data_ptr(); j.out_stride = 2
+            j.snap = sv.data_ptr(); j.snap_stride = n
+            j.workspace = m._sn_ws.data_ptr()
+        jobs_dev = torch.empty(len(mods) * int(lib.ipoke_sn_job_size()), dtype=torch.uint8, device=dev)
+        check(lib.ipoke_sn_jobs_upload(ctypes.byref(jobs), len(mods), ptr(jobs_dev), _lib.current_stream()))
+        cache = dict(key=key, sig=sig_all, snap_all=snap_all, snaps=snaps, jobs_dev=jobs_dev, max_r=max(g[0] for g in geo),
+                     max_c=max(g[1] * g[2] for g in geo))
+        root.__dict__["_sn_multi"] = cache
+    check(lib.ipoke_spectral_sigma_multi(ptr(cache["jobs_dev"]), len(mods), cache["max_r"], cache["max_c"], calls, 1e-12, _lib.current_stream()))
+    for i, m in enumerate(mods):
+        m.__dict__["_sn_pre"] = [(cache["sig"][i, k], cache["snaps"][i][k]) for k in range(calls)]
+    return mods
 
 
 # ------------------------------------------------------------------------------------------------ norms
@@ -647,6 +706,7 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
         clear_operand_cache()                      # scoped entries of passes whose backward never ran
     gate_w = [gru_gate_weights(cell) for cell in model.rnn.cells]
     mods = spade_modulations(model.gen, x0, dt) if _HOIST_SPADE else None
+    sn_pre = precompute_power_iterations(model.gen, T - 1) if (pit and _SN_AHEAD) else []
     for t in range(T - 1):
         xin = in_rnn
         new_hidden = []
@@ -658,6 +718,10 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
         lt, frame = _L1TanhFn.apply(pre.t, X[:, t + 1], 1.0 / n_out)
         l1 = l1 + lt
         frames.append(frame.view(B, pre.dhw[1], pre.dhw[2], 3).permute(0, 3, 1, 2))
+    for m_sn in sn_pre:                               # every decoder convolution consumed exactly its T - 1 iterations
+        left = m_sn.__dict__.pop("_sn_pre", [])
+        if left:
+            raise RuntimeError(f"spectral-norm bookkeeping: {len(left)} precomputed power iterations were not consumed")
     mu4 = mu.view(B, dhw[1], dhw[2], Z).permute(0, 3, 1, 2)
     lv4 = lv.view(B, dhw[1], dhw[2], Z).permute(0, 3, 1, 2)
     kl = _KLFn.apply(mu, lv)                                                             # utils/losses.py:47-48
