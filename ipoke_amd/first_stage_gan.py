@@ -80,6 +80,27 @@ class FirstStageGANTrainer:
             self.opt_ds.step()
             log.update(loss_d_ds=loss_ds.detach())
         self.opt_g.zero_grad()
+        # The generator step differentiates the discriminators w.r.t. their INPUT only: their parameter gradients would be thrown
+        # away (the next discriminator step starts with zero_grad), and the true clip's feature maps carry no gradient at all.  The
+        # reference lets autograd compute both; here the discriminator parameters are frozen for the duration (no weight-gradient
+        # GEMMs, no spectral-norm backward) and the true clip runs without a graph.  Losses and generator gradients are unchanged.
+        frozen = [p for d in (dt_, ds_) if d is not None for p in d.parameters() if p.requires_grad]
+        for p in frozen:
+            p.requires_grad_(False)
+        try:
+            total = self._generator_loss(loss_rec, X, X_hat, X_fake if dt_ is not None else None, X_true if dt_ is not None else None,
+                                         x_fake if ds_ is not None else None, pit, log)
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+        total.backward()                                             # one backward = the reference's three accumulating ones
+        self.opt_g.step()
+        m.invalidate_operands()
+        log.update(loss=loss_rec.detach(), X_hat=X_hat.detach())
+        return log
+
+    def _generator_loss(self, loss_rec, X, X_hat, X_fake, X_true, x_fake, pit, log):
+        dt_, ds_, cdt = self.disc_t, self.disc_s, self.cfg["d_t"]
         total = loss_rec
         if self.w_vgg != 0.0:                                        # (:263, :271)
             loss_vgg = self.vgg_loss(X[:, 1:].reshape(-1, *X.shape[2:]), X_hat.reshape(-1, *X_hat.shape[2:]))
@@ -92,13 +113,10 @@ class FirstStageGANTrainer:
             log.update(loss_g_s=loss_gen_ds.detach())
         if dt_ is not None:
             pg, fmap_fake = dt_(X_fake, pit)
-            _, fmap_true = dt_(X_true, pit)
+            with torch.no_grad():
+                _, fmap_true = dt_(X_true, pit)
             loss_gen_dt = -pg.mean()
             loss_fmap = dt_.fmap_loss(fmap_fake, fmap_true)
             total = total + float(cdt["gen_weight"]) * loss_gen_dt + float(cdt["fmap_weight"]) * loss_fmap
             log.update(loss_g_t=loss_gen_dt.detach(), loss_fmap_t=loss_fmap.detach())
-        total.backward()                                             # one backward = the reference's three accumulating ones
-        self.opt_g.step()
-        m.invalidate_operands()
-        log.update(loss=loss_rec.detach(), X_hat=X_hat.detach())
-        return log
+        return total
