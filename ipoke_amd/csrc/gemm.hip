@@ -1238,9 +1238,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
   const int mh = wave & 1, kq = wave >> 1;
   const GeomDev& g = p.g;
   const int tiles_x = g.Wo / TW, tiles_y = g.Ho / TH;
-  const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
+  const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, slice = tile / (tiles_x * tiles_y);
+  const int img = slice / g.Do, dz = slice - img * g.Do;       // 3 x 3 x 3 (kdn = 3): the tile lies in depth slice dz of sample img
   const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
-  const int nch = p.Kc >> 6, nkb = nch * 9, nrounds = (nkb + 3) >> 2;
+  const int kdn = g.taps / 9;                                  // depth taps: "virtual chunks" v = chunk * kdn + kd, nine K-blocks each
+  const int nch = (p.Kc >> 6) * kdn, nkb = nch * 9, nrounds = (nkb + 3) >> 2;
   const int sgn = g.transposed ? -1 : 1;
 
   const T* Abase = reinterpret_cast<const T*>(p.A);
@@ -1267,7 +1269,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool real = in && w_src[j] != kInvalid;
-      const T* src = real ? Wbase + w_src[j] + (long)wi_t * p.Kc + wi_c * 64 : zero;
+      const T* src = real ? Wbase + w_src[j] + (long)((wi_c % kdn) * 9 + wi_t) * p.Kc + (wi_c / kdn) * 64 : zero;
       unsigned char* dst = in ? ring + (wi_g % R) * WSLOT + (4 * (wave >> 2) + j) * 1024 : dummy + wave * 1024;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
     }
@@ -1278,8 +1280,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
   auto issue_a = [&]() {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const bool real = a_next < nch && a_src[i] != kInvalid;
-      const T* src = real ? Abase + a_src[i] + a_next * 64 : zero;
+      const int dd = dz + (kdn == 3 ? sgn * (a_next % kdn - 1) : 0);                 // depth slice this virtual chunk reads
+      const bool real = a_next < nch && a_src[i] != kInvalid && (unsigned)dd < (unsigned)g.Di;
+      const T* src = real ? Abase + a_src[i] + (long)dd * p.a_sd + (a_next / kdn) * 64 : zero;
       unsigned char* dst = a_next < nch ? abuf + (a_next & 1) * ABUF + (wave + 8 * i) * 1024 : dummy + wave * 1024;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
     }
@@ -1366,7 +1369,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
   }
   __syncthreads();
   // sweep: tile row `row` is output pixel (y0 + row / 16, x0 + row % 16) of image img
-  const long mbase = ((long)img * g.Ho + y0) * g.Wo + x0;
+  const long mbase = ((long)slice * g.Ho + y0) * g.Wo + x0;
   const bool vec_ok = (p.Nout & 3) == 0;
   constexpr int G4 = BN / 4;
   for (int idx = tid; idx < BM * G4; idx += NTHR) {
@@ -1421,6 +1424,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
 static bool halo_applicable(const NtParams& p) {
   static const int on = getenv("IPOKE_HALO") ? atoi(getenv("IPOKE_HALO")) : 1;         // developer A/B: IPOKE_HALO=0 turns the kernel off
   const GeomDev& g = p.g;
+  static const int on3 = getenv("IPOKE_HALO3D") ? atoi(getenv("IPOKE_HALO3D")) : 1;    // the 3 x 3 x 3 form alone
+  const bool flat = g.taps == 9 && g.Di == 1 && g.Do == 1 && g.pd == 0;
+  const bool deep = on3 && g.taps == 27 && g.Di == g.Do && g.pd == 1 && (p.a_sd & 7) == 0;
+  if (!(flat || deep)) return false;
+  if (deep) {     // measured (scripts/probe_halo3d.py, B = 20): 64 channels 16x64x64: 670 vs 997 us, 12x32x32: 126 vs 185 us; but 128
+                  // channels 8x32x32: 271 vs 230, 256 channels 4x16x16: 141 vs 101, 512 channels: 255 vs 177 -> 64 input channels only
+    if (p.Kc > 64) return false;
+    return on && !p.a_f32 && g.khw == 9 && g.kw == 3 && g.Hi == g.Ho && g.Wi == g.Wo && g.Ho % 8 == 0 && g.Wo % 16 == 0 &&
+           g.sd == 1 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && p.Kc % 64 == 0 && p.Kc_real == p.Kc && (p.a_coff & 7) == 0 &&
+           p.ldw >= p.Ktot && p.splitk == 1 && !p.c_acc && ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 &&
+           (long)(g.M / g.S) * p.a_sn + (long)g.Di * p.a_sd + p.Kc < (1L << 31) && (long)p.Nout * p.ldw < (1L << 31) && g.M >= 4096;
+  }
   return on && !p.a_f32 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Do == 1 && g.Hi == g.Ho && g.Wi == g.Wo &&
          g.Ho % 8 == 0 && g.Wo % 16 == 0 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 1 && g.pw == 1 &&
          p.Kc % 64 == 0 && p.Kc_real == p.Kc && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot && p.splitk == 1 && !p.c_acc &&

@@ -78,3 +78,27 @@ def test_halo_conv_data_gradient():
     dx = K.conv(g_cl, wop, kc, cin, (1, 3, 3), (1, 1, 1), (0, 1, 1), "bf16", transposed=True)
     got = _nchw(dx.t, N, H, W, cin).cpu()
     assert (got - x.grad).abs().max().item() <= 2e-2 * x.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("N,D,H,W,cin,cout", [(2, 4, 32, 32, 64, 64), (1, 8, 16, 32, 128, 192), (2, 3, 16, 16, 256, 64)])
+def test_halo_conv3d_forward_and_data_gradient(N, D, H, W, cin, cout):
+    """The 3 x 3 x 3 form (depth halo by "virtual chunks": one staged input image per (channel chunk, depth tap)): forward with
+    bias + ReLU, and the data gradient (all three tap axes mirrored), against torch's fp32 conv3d on the same bf16-rounded operands."""
+    g = torch.Generator().manual_seed(D * H + cin)
+    x = torch.randn(N, cin, D, H, W, generator=g).to(torch.bfloat16).float().requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (5.2 * cin ** 0.5)).to(torch.bfloat16).float()
+    b = torch.randn(cout, generator=g) * 0.1
+    pre = F.conv3d(x, w, b, padding=1)
+    ref = F.relu(pre)
+    dy = torch.randn(N, cout, D, H, W, generator=g).to(torch.bfloat16).float()
+    pre.backward(dy)
+    rows = x.detach().permute(0, 2, 3, 4, 1).reshape(-1, cin).to(torch.bfloat16).contiguous().to(DEV)
+    wop, kc = K.weight_operand(w.to(DEV), "bf16")
+    y = K.conv(K.CL(rows, N, (D, H, W), cin), wop, kc, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1), "bf16", bias=b.to(DEV), act=_lib.ACT_RELU)
+    got = y.t[:, :cout].float().reshape(N, D, H, W, cout).permute(0, 4, 1, 2, 3).cpu()
+    assert (got - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    wop_t, kc_t = K.weight_operand(w.to(DEV), "bf16", transposed_conv=True)
+    g_rows = dy.permute(0, 2, 3, 4, 1).reshape(-1, cout).to(torch.bfloat16).contiguous().to(DEV)
+    dx = K.conv(K.CL(g_rows, N, (D, H, W), cout), wop_t, kc_t, cin, (3, 3, 3), (1, 1, 1), (1, 1, 1), "bf16", transposed=True)
+    got_dx = dx.t[:, :cin].float().reshape(N, D, H, W, cin).permute(0, 4, 1, 2, 3).cpu()
+    assert (got_dx - x.grad).abs().max().item() <= 2e-2 * x.grad.abs().max().item()
