@@ -278,8 +278,10 @@ int ipoke_timing_start(void);
 int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us);
 
 /* LU-parametrised invertible 1x1 convolution (macow2.py:596-649), used by the flow engine when use1x1 is set: prepare builds
- * [W | W^-1 | wl | wu] (C*C floats each) per job in the workspace; apply: out[:, :C] = in[:, :C] mat^T (or mat), rest copied;
- * wgrad writes dl, du, dlog_s of one layer into the flat gradient buffer. */
+ * [W | W^-1 | wl | wu] (C*C floats each) per job in the workspace; apply: out[:, :C] = in[:, :C] mat^T (or mat), rest copied,
+ * over 64 * B rows (the 1x1 convolution is row-wise: one workgroup per block of 64 rows = one sample of the 8x8 latent; B counts
+ * those blocks, so any row count that is a multiple of 64 is valid);
+ * wgrad writes dl, du, dlog_s of one layer into the flat gradient buffer (B samples of P8 positions each). */
 int ipoke_lu_job_size(void);
 int ipoke_lu_prepare(const float* params, const float* fbuf, float* workspace, const void* jobs_dev, int njobs, void* stream);
 int ipoke_lu_apply(const float* in, float* out, int B, int ld, int C, const float* mat, int transposed, void* stream);

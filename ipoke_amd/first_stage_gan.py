@@ -39,6 +39,26 @@ class FirstStageGANTrainer:
         self.opt_g = T.MultiTensorAdam(model.parameters(), **kw)
         self.opt_dt = T.MultiTensorAdam(disc_t.parameters(), **kw) if disc_t is not None else None
         self.opt_ds = T.MultiTensorAdam(disc_s.parameters(), **kw) if disc_s is not None else None
+        self.gamma = float(tr.get("gamma", 0.98))                    # first_stage.yaml:45
+
+    def optimizers(self):
+        return [o for o in (self.opt_g, self.opt_ds, self.opt_dt) if o is not None]
+
+    def on_epoch_end(self):
+        """The three ExponentialLR(gamma) schedulers of first_stage_motion_model.py:383-388, stepped once per epoch."""
+        for o in self.optimizers():
+            o.exponential_lr_step(self.gamma)
+
+    def state_dict(self):
+        return {"opt_g": self.opt_g.state_dict(), "opt_ds": None if self.opt_ds is None else self.opt_ds.state_dict(),
+                "opt_dt": None if self.opt_dt is None else self.opt_dt.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.opt_g.load_state_dict(sd["opt_g"])
+        if self.opt_ds is not None and sd.get("opt_ds") is not None:
+            self.opt_ds.load_state_dict(sd["opt_ds"])
+        if self.opt_dt is not None and sd.get("opt_dt") is not None:
+            self.opt_dt.load_state_dict(sd["opt_dt"])
 
     def draw(self, X, rng=np.random):
         """The random choices of one step, as the reference draws them (:175, :204-205)."""

@@ -731,16 +731,51 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
 
 class MultiTensorAdam:
     """torch.optim.Adam(lr, betas, weight_decay) semantics over a parameter list, one ``ipoke_adam_multi`` launch per 48
-    tensors; parameters without a gradient are skipped like torch does."""
+    tensors; parameters without a gradient are skipped like torch does.  ``param_groups[0]['lr']`` is the live learning rate
+    (schedulers write it, as with a torch optimizer); ``exponential_lr_step(gamma)`` is the reference's per-epoch
+    ``ExponentialLR`` (first_stage_motion_model.py:383-386).  One step counter for all tensors: identical to torch's
+    per-parameter counters as long as every parameter receives a gradient in every step it takes part in (true for the three
+    first-stage optimisers: each owns one network that is always differentiated as a whole)."""
 
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8):
         import ctypes
         self._ct = ctypes
         self.params = [p for p in params if p.requires_grad]
-        self.lr, self.betas, self.weight_decay, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(weight_decay), float(eps)
+        self.betas, self.weight_decay, self.eps = (float(betas[0]), float(betas[1])), float(weight_decay), float(eps)
+        self.param_groups = [{"params": self.params, "lr": float(lr), "initial_lr": float(lr)}]
         self.exp_avg = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.steps = 0
+
+    @property
+    def lr(self):
+        return float(self.param_groups[0]["lr"])
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]["lr"] = float(value)
+
+    def exponential_lr_step(self, gamma):
+        """One epoch of torch.optim.lr_scheduler.ExponentialLR(self, gamma)."""
+        self.lr = self.lr * float(gamma)
+
+    def state_dict(self):
+        return {"steps": self.steps, "lr": self.lr, "initial_lr": self.param_groups[0]["initial_lr"], "betas": self.betas,
+                "weight_decay": self.weight_decay, "eps": self.eps, "exp_avg": [t.clone() for t in self.exp_avg],
+                "exp_avg_sq": [t.clone() for t in self.exp_avg_sq]}
+
+    def load_state_dict(self, sd):
+        if len(sd["exp_avg"]) != len(self.params) or any(a.shape != p.shape for a, p in zip(sd["exp_avg"], self.params)):
+            raise ValueError("optimizer state does not match this parameter list")
+        with torch.no_grad():
+            for dst, src in zip(self.exp_avg, sd["exp_avg"]):
+                dst.copy_(src)                      # lands on the parameters' device whatever map_location loaded the file
+            for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+                dst.copy_(src)
+        self.steps = int(sd["steps"])
+        self.lr = float(sd["lr"])
+        self.param_groups[0]["initial_lr"] = float(sd.get("initial_lr", sd["lr"]))
+        self.betas, self.weight_decay, self.eps = tuple(sd["betas"]), float(sd["weight_decay"]), float(sd["eps"])
 
     def zero_grad(self):
         for p in self.params:
@@ -766,15 +801,29 @@ class FirstStageTrainer:
     """Minimal training harness of c4: ``step(X)`` = forward, L1 + KL loss, backward, Adam step (the reference's
     first-stage optimiser is ``Adam(lr, betas=(0.5, 0.9))`` over encoder + GRU + decoder, first_stage_motion_model.py:283-300)."""
 
-    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8, vgg_loss=None, w_vgg=0.0):
-        """``vgg_loss`` (ipoke_amd.vgg.VGGLoss) with ``w_vgg`` adds the perceptual term of first_stage_motion_model.py:263-271."""
+    def __init__(self, model, lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-5, eps=1e-8, vgg_loss=None, w_vgg=0.0, gamma=0.98):
+        """``vgg_loss`` (ipoke_amd.vgg.VGGLoss) with ``w_vgg`` adds the perceptual term of first_stage_motion_model.py:263-271;
+        ``gamma``: per-epoch learning-rate decay (first_stage.yaml:45), applied by ``on_epoch_end``."""
         self.model = model
+        self.gamma = float(gamma)
         self.vgg_loss, self.w_vgg = vgg_loss, float(w_vgg)
         if self.w_vgg != 0.0 and vgg_loss is None:
             raise ValueError("w_vgg != 0 needs vgg_loss=ipoke_amd.vgg.VGGLoss(...) (load the torchvision VGG-19 weights into it)")
         self.opt = MultiTensorAdam(model.parameters(), lr, betas, weight_decay, eps)
         self.params = self.opt.params
         self.grad_hook = None           # data parallel: all-reduce of the gradients between backward and the update
+
+    def on_epoch_end(self):
+        """Lightning steps the ExponentialLR scheduler once per epoch (first_stage_motion_model.py:383-388)."""
+        self.opt.exponential_lr_step(self.gamma)
+
+    def state_dict(self):
+        return {"model": self.model.state_dict(), "opt": self.opt.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.model.load_state_dict(sd["model"])
+        self.model.invalidate_operands()
+        self.opt.load_state_dict(sd["opt"])
 
     def step(self, X, eps=None):
         m = self.model

@@ -65,14 +65,26 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         self._covered += end - begin
 
     # ---- ZeRO-1 over the flat buffer: reduce-scatter -> update of this rank's shard -> all-gather of the parameters ----
-    def _shard_state(self, begin, n):
-        """Adam state of this rank's shard of the slice starting at ``begin`` (allocated on first use: 3 P / world in total;
-        the replicated ``exp_avg*`` buffers of the constructor are released by ``enable_sharding``)."""
-        st = self._shards.get(begin)
-        if st is None or st[0].numel() != n:
-            dev = self.flow.flat_params.device
+    def _shard_state(self, key, lo, n):
+        """Adam state (m, v, v_max) of flat[lo:lo+n] held by THIS rank under ``key`` (a slice's begin for its 1/world shard,
+        -(begin+1) for its replicated trailing elements).  Allocated on first use -- 3 P / world in total -- as zeros, or cut
+        out of a replicated checkpoint that ``load_state_dict`` parked in ``_full_state``.  A stored shard of another size
+        means the slice layout (IPOKE_PIECES, bucket count, world size) changed since the state was saved: that is an error,
+        never a silent reset of the moments."""
+        st = self._shards.get(key)
+        if st is not None:
+            if st[0].numel() != n or self._layout.get(key) != (lo, n):
+                raise RuntimeError(f"optimizer shard {key}: stored layout {self._layout.get(key)} / {st[0].numel()} elements, requested "
+                                   f"({lo}, {n}) -- the gradient-slice layout or world size differs from the one the state was saved with")
+            return st
+        dev = self.flow.flat_params.device
+        full = getattr(self, "_full_state", None)
+        if full is not None:
+            st = tuple(f[lo:lo + n].to(dev, torch.float32).clone() for f in full)
+        else:
             st = tuple(torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(3))
-            self._shards[begin] = st
+        self._shards[key] = st
+        self._layout[key] = (lo, n)
         return st
 
     def enable_sharding(self, world, rank, grad_dtype=torch.float32):
@@ -81,7 +93,7 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         if self.steps != 0:
             raise RuntimeError("enable_sharding must be called before the first optimizer step")
         self.world, self.rank, self.grad_dtype = int(world), int(rank), grad_dtype
-        self._shards = {}
+        self._shards, self._layout, self._full_state = {}, {}, None
         self.exp_avg = self.exp_avg_sq = self.max_exp_avg_sq = None      # replicated state is not kept
 
     @torch.no_grad()
@@ -108,7 +120,7 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
             if red.dtype != torch.float32:
                 red = red.float()
             lo = begin + self.rank * sh
-            m, v, vmax = self._shard_state(begin, sh)
+            m, v, vmax = self._shard_state(begin, lo, sh)
             check(L.ipoke_adam_amsgrad_step_grid(ptr(flat[lo:lo + sh]), ptr(red), ptr(m), ptr(v), ptr(vmax), sh, *hyper, 128,
                                                  _lib.current_stream()))
             own = flat[lo:lo + sh].clone()                 # out-of-place input: valid for every backend
@@ -116,7 +128,7 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         if main < n:
             tail = grads[begin + main:end]
             D.allreduce_async(tail).wait()
-            m, v, vmax = self._shard_state(-(begin + 1), n - main)       # replicated state of the few trailing elements
+            m, v, vmax = self._shard_state(-(begin + 1), begin + main, n - main)       # replicated state of the few trailing elements
             # the trailing slice starts 16-byte aligned (begin and main are multiples of 4 floats)
             check(L.ipoke_adam_amsgrad_step_grid(ptr(flat[begin + main:end]), ptr(tail), ptr(m), ptr(v), ptr(vmax), n - main, *hyper, 1,
                                                  _lib.current_stream()))
@@ -128,25 +140,82 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
             raise RuntimeError(f"piecewise optimizer step covered {self._covered} of {self.flow.flat_params.numel()} parameters")
         self.flow.engine.shadow_stale = False       # every slice refreshed its shadows right after its update
 
+    def _groups(self):
+        return [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+
     def state_dict(self):
+        """Replicated mode: the full m / v / v_max.  Sharded (ZeRO-1) mode: THIS RANK's shards only, with their (offset, length)
+        layout -- every rank has to save its own (``torch.save(opt.state_dict(), f"opt_rank{rank}.pt")``), or call the collective
+        ``full_state_dict()`` and save its result on rank 0."""
         if getattr(self, "_shards", None) is not None:
             return {"steps": self.steps, "sharded": True, "world": self.world, "rank": self.rank,
-                    "shards": {k: tuple(t.clone() for t in v) for k, v in self._shards.items()},
-                    "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+                    "shards": {k: tuple(t.clone() for t in v) for k, v in self._shards.items()}, "layout": dict(self._layout),
+                    "param_groups": self._groups()}
         return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "max_exp_avg_sq": self.max_exp_avg_sq, "param_groups": [{k: v for k, v in g.items() if k != "params"}
-                                                                         for g in self.param_groups]}
+                "max_exp_avg_sq": self.max_exp_avg_sq, "param_groups": self._groups()}
+
+    @staticmethod
+    def merge_sharded(states, numel):
+        """Per-rank sharded state dicts (all ranks of one run) -> a replicated state dict."""
+        full = [torch.zeros(numel, dtype=torch.float32) for _ in range(3)]
+        covered = torch.zeros(numel, dtype=torch.bool)
+        for sd in states:
+            for key, (lo, n) in sd["layout"].items():
+                for f, t_ in zip(full, sd["shards"][key]):
+                    f[lo:lo + n] = t_.detach().to("cpu", torch.float32)
+                covered[lo:lo + n] = True
+        if not bool(covered.all()):
+            raise ValueError(f"sharded optimizer states cover {int(covered.sum())} of {numel} elements (a rank's file is missing)")
+        return {"steps": states[0]["steps"], "exp_avg": full[0], "exp_avg_sq": full[1], "max_exp_avg_sq": full[2],
+                "param_groups": states[0]["param_groups"]}
+
+    def full_state_dict(self):
+        """Collective in sharded mode: gathers every rank's shards into the replicated layout (on the parameters' device)."""
+        if getattr(self, "_shards", None) is None:
+            return self.state_dict()
+        import torch.distributed as td
+        numel, dev = self.flow.flat_params.numel(), self.flow.flat_params.device
+        full = [torch.zeros(numel, dtype=torch.float32, device=dev) for _ in range(3)]
+        for key, (lo, n) in self._layout.items():
+            if key < 0 and self.rank != 0:
+                continue                                    # trailing elements are replicated: rank 0 contributes them
+            for f, t_ in zip(full, self._shards[key]):
+                f[lo:lo + n] = t_
+        if self.world > 1:
+            for f in full:
+                td.all_reduce(f)                            # every element is owned by exactly one contributing rank
+        return {"steps": self.steps, "exp_avg": full[0], "exp_avg_sq": full[1], "max_exp_avg_sq": full[2], "param_groups": self._groups()}
 
     def load_state_dict(self, sd):
-        self.steps = int(sd["steps"])
+        """Accepts both layouts in both modes: a replicated checkpoint loaded into a sharded optimizer is cut into this rank's
+        shards when the slices are first touched; a sharded per-rank checkpoint loads into the same (world, rank) only (merge the
+        ranks' files with ``merge_sharded`` for anything else).  State lands on the parameters' device whatever ``map_location``
+        the checkpoint was read with."""
+        dev = self.flow.flat_params.device
+        sharded_opt = getattr(self, "_shards", None) is not None
         if sd.get("sharded"):
+            if not sharded_opt:
+                raise ValueError("per-rank sharded optimizer state cannot be loaded into a replicated optimizer: merge the ranks' "
+                                 "files with FusedAdamAmsgrad.merge_sharded(states, numel) (or save full_state_dict()) first")
             if (sd["world"], sd["rank"]) != (self.world, self.rank):
-                raise ValueError("sharded optimizer state belongs to another (world, rank)")
-            self._shards = {k: tuple(t.clone() for t in v) for k, v in sd["shards"].items()}
-            for g, s_ in zip(self.param_groups, sd["param_groups"]):
-                g.update(s_)
-            return
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.max_exp_avg_sq.copy_(sd["max_exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+                raise ValueError(f"sharded optimizer state belongs to (world, rank) = ({sd['world']}, {sd['rank']}), this is "
+                                 f"({self.world}, {self.rank})")
+            for key, (lo, n) in sd["layout"].items():
+                if any(t_.numel() != n for t_ in sd["shards"][key]):
+                    raise ValueError(f"optimizer shard {key}: tensors do not match the stored layout ({lo}, {n})")
+            self._shards = {k: tuple(t_.detach().to(dev, torch.float32).clone() for t_ in v) for k, v in sd["shards"].items()}
+            self._layout = {k: tuple(v) for k, v in sd["layout"].items()}
+            self._full_state = None
+        elif sharded_opt:
+            n = self.flow.flat_params.numel()
+            full = (sd["exp_avg"], sd["exp_avg_sq"], sd["max_exp_avg_sq"])
+            if any(f.numel() != n for f in full):
+                raise ValueError("replicated optimizer state does not match the flat parameter buffer")
+            self._shards, self._layout = {}, {}
+            self._full_state = tuple(f.detach() for f in full)          # shards are cut out on first use (_shard_state)
+        else:
+            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.max_exp_avg_sq.copy_(sd["max_exp_avg_sq"])
+        self.steps = int(sd["steps"])
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update(s_)

@@ -947,12 +947,115 @@ def g12_vgg():
     npz("g12_vgg_loss", **arrs)
 
 
+def g13_train_mode():
+    """G13: the first-stage training step exactly as c4 runs it -- ``SpadeCondMotionModel`` at 128x128, z = 32, T = 16 in
+    ``.train()`` mode, so that every spectral-normalised decoder convolution runs one power iteration per ``gen`` CALL
+    (old-style torch.nn.utils.spectral_norm hook, models/modules/autoencoders/util.py:52, 252): 15 different sigma per weight per
+    step (models/first_stage_motion_model.py:498-522).  X_hat (three frames verbatim + per-frame checksums), L1 + KL loss, the
+    checksum of every parameter gradient, and ``weight_u`` / ``weight_v`` of every decoder convolution after the step."""
+    T = 16
+    cfg = configs.first_stage_config(128, 32, T)
+    fsm = ref_import.ref("models.first_stage_motion_model")
+    # ``train=False`` only keeps the constructor from building discriminators / metric nets (first_stage_motion_model.py:51-69);
+    # the module's mode is what the spectral-norm hook looks at
+    m = fsm.SpadeCondMotionModel(copy.deepcopy(cfg), dirs={}, train=False)
+    deterministic_fill_(m, prefix="first_stage.")
+    m.train()
+    o = vae_ref.SpadeCondMotionModel(copy.deepcopy(cfg)); o.load_state_dict(m.state_dict()); o.train()
+    X = torch.rand(1, T, 3, 128, 128, generator=gen(131)) * 2 - 1
+    torch.manual_seed(79)
+    eps = torch.FloatTensor(1, 32, 8, 8).normal_()
+    torch.manual_seed(79)
+    Xh, mu, lv = m(X)
+    losses = ref_import.ref("utils.losses")
+    loss = 10 * (X[:, 1:] - Xh).abs().mean() + 1e-7 * losses.KL(mu, lv)
+    loss.backward()
+    Xo, muo, lvo = o(X, eps=eps)
+    lo = vae_ref.first_stage_loss(X, Xo, muo, lvo)
+    e1 = close(Xo, Xh, 1e-4, "G13 X_hat"); close(lo, loss, 1e-4, "G13 loss")
+    lo.backward()
+    arrs = dict(X_seed=131, eps=eps, mu=mu, logvar=lv, loss=loss, X_hat_frames=Xh[:, [0, 7, 14]],
+                X_hat_checksums=np.stack([checksum(Xh[:, i], f"frame{i}") for i in range(T - 1)]))
+    names, sums, worst = [], [], 0.0
+    for (k, p), (k2, q) in zip(m.named_parameters(), o.named_parameters()):
+        assert k == k2
+        if p.grad is None:
+            continue
+        names.append(k); sums.append(checksum(p.grad, k))
+        e_ = (p.grad - q.grad).abs().max().item() / (p.grad.abs().max().item() + 1e-6)
+        if e_ > 2e-3:
+            print(f"    {k}: rel {e_:.2e} (|grad| max {p.grad.abs().max().item():.2e})")
+        worst = max(worst, e_)
+    assert worst <= 3e-2, worst           # L1 sub-gradient sign flips below the oracle-vs-reference forward difference (see g_128)
+    arrs["grad_names"], arrs["grad_checksums"] = np.array(names), np.stack(sums)
+    un, worst_u = [], 0.0
+    sdm, sdo = m.state_dict(), o.state_dict()
+    for k in sdm:
+        if k.startswith("gen.") and k.endswith("weight_u"):
+            un.append(k)
+            arrs["u." + k] = sdm[k]
+            arrs["v_checksum." + k] = checksum(sdm[k[:-1] + "v"], k[:-1] + "v")
+            worst_u = max(worst_u, (sdm[k] - sdo[k]).abs().max().item())
+    assert worst_u <= 1e-5, worst_u
+    arrs["u_names"] = np.array(un)
+    print(f"  G13 oracle-vs-reference: X_hat {e1:.2e}, worst relative grad error {worst:.2e}, u after {T - 1} iterations {worst_u:.2e} "
+          f"({len(un)} spectral-normalised decoder convolutions)")
+    npz("g13_first_stage_train_mode_128", **arrs)
+
+
+def g7_sample_128():
+    """G7-128: ``forward_sample`` of the c5 model -- 128x128, the FULL z = 64 flow (1.237 B parameters, the weights and the
+    data-initialised ActNorm parameters of golden ``g3_full_flow_z64``), 15 generated frames -- with an injected latent
+    (models/second_stage_video.py:326-382).  Stored: the conditioning, the sampled motion latent, frames 0 / 7 / 14 of both videos
+    and per-frame checksums."""
+    g3 = np.load(os.path.join(OUT, "g3_full_flow_z64.npz"))
+    arch = configs.flow_arch(64)
+    t0 = time.time()
+    M, cfg = build_reference_poke_model(128, 64, 16, arch)
+    # a reverse pass from z ~ N(0, 1) through 800 randomly filled autoregressive inverses overflows in the reference itself
+    # at g3's gain scale 0.3 (NaN; |motion| 20 at 0.2); at 0.15 it is well conditioned: |motion| <= 11.5, forward(reverse(z)) - z = 1.5e-5
+    g_scale = 0.15
+    with torch.no_grad():
+        sd = M.flow.state_dict()
+        for k, v in sd.items():
+            if k.endswith("weight_g"):
+                v.mul_(g_scale)
+        for k in g3.files:
+            if k.startswith("actnorm."):
+                sd[k[len("actnorm."):]].copy_(torch.from_numpy(g3[k]))
+    print(f"  built the reference c5 model in {time.time() - t0:.0f}s")
+    batch = synthetic_batch(2, 16, 128, seed=5)
+    zs = rn((2, 64, 8, 8), 56)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: zs.clone()
+    try:
+        vids = M.forward_sample(batch, n_samples=1, n_logged_vids=2)
+    finally:
+        torch.randn = real_randn
+    with torch.no_grad():
+        _, cond = M.make_flow_input(batch, reverse=True)
+        motion = M.flow(zs, cond, reverse=True)
+    v = vids[0]
+    assert torch.isfinite(motion).all() and torch.isfinite(v).all() and tuple(v.shape) == (2, 15, 3, 128, 128)
+    O7 = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch)); O7.load_state_dict(M.flow.state_dict())
+    with torch.no_grad():
+        e = close(O7(zs, cond, reverse=True), motion, 5e-4, "G7-128 reverse")
+    ofs = vae_ref.SpadeCondMotionModel(copy.deepcopy(cfg["first_stage"])).eval(); ofs.load_state_dict(M.first_stage_model.state_dict())
+    with torch.no_grad():
+        e2 = close(ofs.decode(motion, batch["images"][:, 0], 15), v, 2e-4, "G7-128 decode")
+    print(f"  G7-128 oracle-vs-reference: motion {e:.2e} (|motion| max {motion.abs().max().item():.2f}), video {e2:.2e}")
+    npz("g7_sample_128", batch_seed=5, z=zs, cond=cond, motion=motion, video_frames=v[:, [0, 7, 14]],
+        video_checksums=np.stack([checksum(v[:, i], f"frame{i}") for i in range(15)]), video_shape=np.array(v.shape),
+        g_scale=g_scale)
+
+
 def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
             "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
-            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd, "g11": g11_data, "g12": g12_vgg}
+            "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd, "g11": g11_data, "g12": g12_vgg, "g13": g13_train_mode,
+            "g7_128": g7_sample_128}
     for name in (which or list(jobs)):
         print(f"[{name}]")
         t = time.time()

@@ -6,10 +6,14 @@ reference's state-dict keys.  Pinned against golden vectors generated from the
 reference's own modules (``oracle/make_goldens.py``).  Imported only by tests,
 ``__graft_entry__.smoke`` and ``bench.py``'s cpu_baseline leg.
 
-Reference sites are cited per class.  Spectral-normalised convolutions are
-restated in *eval* mode (frozen u, v; weight = weight_orig / sigma), which is
-how the second stage uses them (models/second_stage_video.py:269-272); the
-train-mode power iteration is provided separately by ``spectral_power_iter``.
+Reference sites are cited per class.  Spectral-normalised convolutions follow
+torch.nn.utils.spectral_norm (old-style forward-pre-hook, util.py:52, 252): in
+*eval* mode u, v are frozen (weight = weight_orig / sigma), which is how the
+second stage uses them (models/second_stage_video.py:269-272); in *train* mode
+every forward CALL first runs one power iteration on the buffers
+(``spectral_power_iter``) and sigma is taken with clones of the updated u, v --
+the decoder is called once per generated frame, so a first-stage training step
+sees T - 1 different sigma per weight (pinned by golden ``g13_first_stage_train_mode_128``).
 """
 import math
 
@@ -166,7 +170,13 @@ class _SNConv(nn.Module):
         return w.reshape(w.shape[0], -1)
 
     def weight(self):
-        sigma = torch.dot(self.weight_u, torch.mv(self.matrix(), self.weight_v))
+        u, v = self.weight_u, self.weight_v
+        if self.training:
+            # torch's hook: iterate in place without grad, then clone so that later calls' in-place updates do not
+            # invalidate what this call's backward needs
+            self.spectral_power_iter()
+            u, v = u.clone(), v.clone()
+        sigma = torch.dot(u, torch.mv(self.matrix(), v))
         return self.weight_orig / sigma
 
     @torch.no_grad()

@@ -103,33 +103,40 @@ def test_full_size_flow(golden, z, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_flow_z64_batch20_properties(golden, dtype):
-    """The benchmarked batch size (B = 20 -> M = 1280 GEMM rows) through size-independent properties: (i) samples are
-    independent, so a batch of 10 copies of the golden pair reproduces the golden outputs in every slot; (ii) the
-    mean-loss gradients of that batch equal the gradients of the pair (checked against the golden checksums of every
-    tensor); (iii) reverse(forward(x)) = x."""
-    g = golden("g3_full_flow_z64")
-    m = full_flow(g, 64, dtype, 20)
+@pytest.mark.parametrize("z,B", [(64, 20), (64, 32), (64, 40), (32, 32), (32, 40)])
+def test_flow_benchmarked_batch_properties(golden, z, B, dtype):
+    """The benchmarked batch sizes -- c2: z = 64, B = 20 (M = 1280 GEMM rows); c5: z = 64, B = 32 (M = 2048; sampling, 16
+    two-sample inverse workgroups); c3: z = 32, B = 40 (M = 2560) and the cross pairs -- through size-independent properties:
+    (i) samples are independent, so a batch of B / 2 copies of the golden pair reproduces the golden outputs in every slot
+    (other GEMM tile maps, split-K counts and conv3x3_s8 sample tilings than the B = 2 run of the same golden);
+    (ii) the mean-loss gradients of that batch equal the gradients of the pair (checked against the golden checksums of
+    every tensor); (iii) the reverse pass of the golden output reproduces the golden reverse in every slot;
+    (iv) reverse(forward(x)) = x."""
+    g = golden(f"g3_full_flow_z{z}")
+    m = full_flow(g, z, dtype, B)
     tol = FULL_TOL[dtype]
-    x = t(g["x"], DEV).repeat(10, 1, 1, 1)
-    cond = t(g["cond"], DEV).repeat(10, 1, 1, 1)
+    n = B // 2
+    x = t(g["x"], DEV).repeat(n, 1, 1, 1)
+    cond = t(g["cond"], DEV).repeat(n, 1, 1, 1)
     out, logdet = m(x, cond)
-    ref_out, ref_ld = t(g["out"]).repeat(10, 1, 1, 1), t(g["logdet"]).repeat(10)
+    ref_out, ref_ld = t(g["out"]).repeat(n, 1, 1, 1), t(g["logdet"]).repeat(n)
     d_out = (out.detach().cpu() - ref_out).abs()
     e_out, e_mean = d_out.max().item(), d_out.mean().item()
     e_ld = ((logdet.detach().cpu() - ref_ld).abs() / ref_ld.abs()).max().item()
-    print(f"[{dtype}] z64 B=20: out err max {e_out:.3e} mean {e_mean:.3e}, logdet rel err {e_ld:.3e}")
+    print(f"[{dtype}] z{z} B={B}: out err max {e_out:.3e} mean {e_mean:.3e}, logdet rel err {e_ld:.3e}")
     assert e_out <= tol["out"] and e_mean <= tol["out_mean"] and e_ld <= tol["logdet"]
     loss = (0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()
     loss.backward()
     worst, key = grad_errors(m, g, every=1)
-    print(f"[{dtype}] z64 B=20: worst gradient checksum error {worst:.3e} at {key}")
+    print(f"[{dtype}] z{z} B={B}: worst gradient checksum error {worst:.3e} at {key}")
     assert worst <= tol["grad"]
     with torch.no_grad():
+        rev_g = m(t(g["out"], DEV).repeat(n, 1, 1, 1), cond, reverse=True)
         rev = m(out.detach(), cond, reverse=True)
+    e_rev = (rev_g.cpu() - t(g["reverse"]).repeat(n, 1, 1, 1)).abs().max().item()
     e_rt = (rev - x).abs().max().item()
-    print(f"[{dtype}] z64 B=20: round trip err {e_rt:.3e}")
-    assert e_rt <= tol["rt"]
+    print(f"[{dtype}] z{z} B={B}: reverse of the golden output err {e_rev:.3e}, round trip err {e_rt:.3e}")
+    assert e_rev <= tol["rev"] and e_rt <= tol["rt"]
 
 
 # ------------------------------------------------------------------------------------------------ MCF units, C = 60 / 64
@@ -404,3 +411,73 @@ def test_first_stage_train_slice_128(golden, dtype):
     for b in bad:
         print("   BAD", b)
     assert not bad
+
+
+# ------------------------------------------------------------------------------------------------ c5: sampling at 128 x 128, z = 64
+def _c5_model(g, dtype, max_batch):
+    from ipoke_amd.second_stage import PokeMotionModel
+    conf = configs.second_stage_config(128, 64, 16, batch_size=max_batch)
+    m = PokeMotionModel(conf, dirs={}, dtype=dtype, device=DEV, max_batch=max_batch)
+    deterministic_fill_(m.first_stage_model, prefix="first_stage.")
+    deterministic_fill_(m.poke_embedder, prefix="poke_embedder.")
+    deterministic_fill_(m.conditioner, prefix="conditioner.")
+    deterministic_fill_(m.flow, prefix="flow.")
+    g3 = g("g3_full_flow_z64")
+    with torch.no_grad():
+        for k, p in m.flow.named_parameters():
+            if k.endswith("weight_g"):
+                p.mul_(float(g("g7_sample_128")["g_scale"]))
+        sd = m.flow.state_dict()
+        for k in g3:
+            if k.startswith("actnorm."):
+                sd[k[len("actnorm."):]].copy_(t(g3[k], DEV))
+    m.flow.sync_buffers()
+    return m
+
+
+SAMPLE_TOL = {"f32": dict(motion=2e-3, v_max=2e-3, v_mean=5e-5), "bf16": dict(motion=0.15, v_max=0.25, v_mean=2e-2)}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B", [2, 32])
+def test_forward_sample_128_z64(golden, B, dtype):
+    """c5 as benchmarked: ``forward_sample`` of the h36m_128 / plants_128 model -- 2-D encoders, the FULL z = 64 flow in
+    reverse (1.237 B parameters), ConvGRU + frame-batched SPADE decode of 15 frames at 128x128 -- with an injected latent,
+    against golden ``g7_sample_128`` (the reference's own PokeMotionModel.forward_sample, second_stage_video.py:326-382).
+    B = 32 (the c5 batch: M = 2048 reverse GEMMs, 16 two-sample inverse workgroups, 480-image decoder batch) repeats the
+    golden pair 16 times: every slot must reproduce it."""
+    from tests.helpers import synthetic_batch
+    g7 = golden("g7_sample_128")
+    m = _c5_model(golden, dtype, B)
+    n = B // 2
+    pair = synthetic_batch(2, 16, 128, seed=int(g7["batch_seed"]), device=DEV)
+    batch = {k: ([p.repeat(n, *([1] * (p.dim() - 1))) for p in v] if isinstance(v, list) else v.repeat(n, *([1] * (v.dim() - 1))))
+             for k, v in pair.items()}
+    z = t(g7["z"]).repeat(n, 1, 1, 1)
+    real = torch.randn
+    torch.randn = lambda *a, **k: z.clone()
+    try:
+        vids = m.forward_sample(batch, n_samples=1, n_logged_vids=B)
+        _, cond = m.make_flow_input(batch, reverse=True)
+    finally:
+        torch.randn = real
+    v = vids[0]
+    assert tuple(v.shape) == (B, 15, 3, 128, 128) and v.device.type == "cpu"
+    tol = SAMPLE_TOL[dtype]
+    e_c = (cond[:2].cpu() - t(g7["cond"])).abs().max().item()
+    with torch.no_grad():
+        motion = m.flow(z.to(DEV), t(g7["cond"], DEV).repeat(n, 1, 1, 1), reverse=True)
+    e_m = (motion.cpu() - t(g7["motion"]).repeat(n, 1, 1, 1)).abs().max().item()
+    ref = t(g7["video_frames"])
+    e_max = e_mean = 0.0
+    for b in range(0, B, 2):
+        d = (v[b:b + 2, [0, 7, 14]] - ref).abs()
+        e_max, e_mean = max(e_max, d.max().item()), max(e_mean, d.mean().item())
+    e_cs = 0.0
+    for i in range(15):
+        cs = checksum(v[:2, i], f"frame{i}")
+        e_cs = max(e_cs, abs(cs[0] - g7["video_checksums"][i][0]) / v[:2, i].numel(), abs(cs[1] - g7["video_checksums"][i][1]) / v[:2, i].numel())
+    print(f"[{dtype}] c5 sample B={B}: cond err {e_c:.3e}, motion err {e_m:.3e} (|motion| max {np.abs(g7['motion']).max():.1f}), "
+          f"video err max {e_max:.3e} mean {e_mean:.3e}, per-frame mean-pixel checksum err {e_cs:.3e}")
+    assert e_c <= VAE_TOL[dtype] * 2 and e_m <= tol["motion"]
+    assert e_max <= tol["v_max"] and e_mean <= tol["v_mean"] and e_cs <= tol["v_mean"]

@@ -79,3 +79,83 @@ def test_single_process_is_a_noop():
     from ipoke_amd import dist as D
     t = torch.ones(5)
     assert D.allreduce_flat_(t) is t and D.world_size() == 1 and D.max_over_ranks(3.5, torch.device("cpu")) == 3.5
+
+
+def _fake_opt(numel, world=None, rank=0):
+    """FusedAdamAmsgrad over a stand-in flow (host tensors; only the state bookkeeping is exercised, no kernel runs)."""
+    import types
+    from ipoke_amd.optim import FusedAdamAmsgrad
+    flow = types.SimpleNamespace(flat_params=torch.zeros(numel, requires_grad=True))
+    opt = FusedAdamAmsgrad(flow, lr=1e-3, weight_decay=1e-5)
+    if world is not None:
+        opt.enable_sharding(world, rank)
+    return opt
+
+
+def test_sharded_optimizer_state_roundtrip_and_conversion():
+    """ZeRO-1 optimizer state: per-rank save / load round trip, layout validation (a changed slice layout raises instead of
+    zeroing the moments), replicated -> sharded (shards cut out of the full tensors) and sharded -> replicated (merge of the
+    ranks' files)."""
+    import pytest
+    from ipoke_amd import dist as D
+    from ipoke_amd.optim import FusedAdamAmsgrad
+    numel, world = 1003, 2
+    pieces = [(600, 1003), (0, 600)]
+    full = [torch.arange(numel, dtype=torch.float32) + 1000 * k for k in range(3)]
+    states = []
+    for rank in range(world):
+        opt = _fake_opt(numel, world, rank)
+        for b, e in pieces:                                     # what step_range_sharded touches
+            sh, main = D.shard_layout(e - b, world)
+            lo = b + rank * sh
+            for st, f in zip(opt._shard_state(b, lo, sh), full):
+                st.copy_(f[lo:lo + sh])
+            if main < e - b:
+                for st, f in zip(opt._shard_state(-(b + 1), b + main, e - b - main), full):
+                    st.copy_(f[b + main:e])
+        opt.steps = 7
+        sd = opt.state_dict()
+        assert sd["sharded"] and sd["layout"][0][0] == rank * D.shard_layout(600, world)[0]
+        states.append(sd)
+        # round trip into a fresh optimizer of the same (world, rank)
+        opt2 = _fake_opt(numel, world, rank)
+        opt2.load_state_dict(sd)
+        assert opt2.steps == 7
+        b, e = pieces[0]
+        sh, _ = D.shard_layout(e - b, world)
+        got = opt2._shard_state(b, b + rank * sh, sh)
+        assert torch.equal(got[1], full[1][b + rank * sh:b + rank * sh + sh])
+        with pytest.raises(RuntimeError):                       # other slice layout: must not silently reset the moments
+            opt2._shard_state(b, b + rank * sh, sh - 4)
+        with pytest.raises(ValueError):                         # other rank
+            _fake_opt(numel, world, 1 - rank).load_state_dict(sd)
+    # sharded -> replicated
+    merged = FusedAdamAmsgrad.merge_sharded(states, numel)
+    for k, f in zip(("exp_avg", "exp_avg_sq", "max_exp_avg_sq"), full):
+        assert torch.equal(merged[k], f)
+    rep = _fake_opt(numel)
+    rep.load_state_dict(merged)
+    assert rep.steps == 7 and torch.equal(rep.max_exp_avg_sq, full[2])
+    with pytest.raises(ValueError):
+        rep.load_state_dict(states[0])
+    with pytest.raises(ValueError):
+        FusedAdamAmsgrad.merge_sharded(states[:1], numel)        # a rank's file is missing
+    # replicated -> sharded: the shards are cut out of the full tensors on first use
+    for rank in range(world):
+        opt = _fake_opt(numel, world, rank)
+        opt.load_state_dict(rep.state_dict())
+        b, e = pieces[1]
+        sh, main = D.shard_layout(e - b, world)
+        lo = b + rank * sh
+        m, v, vmax = opt._shard_state(b, lo, sh)
+        assert torch.equal(m, full[0][lo:lo + sh]) and torch.equal(vmax, full[2][lo:lo + sh])
+    # single-process full_state_dict of a sharded optimizer (world 1) equals the replicated layout
+    one = _fake_opt(numel, 1, 0)
+    one.load_state_dict(merged)
+    for b, e in pieces:
+        sh, main = D.shard_layout(e - b, 1)
+        one._shard_state(b, b, sh)
+        if main < e - b:
+            one._shard_state(-(b + 1), b + main, e - b - main)
+    fsd = one.full_state_dict()
+    assert torch.equal(fsd["exp_avg_sq"], full[1])

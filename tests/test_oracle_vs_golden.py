@@ -193,6 +193,28 @@ def test_first_stage_l1_kl_training_slice(golden):
     assert (Xh - t(g["X_hat"])).abs().max() <= 5e-5 and abs(loss.item() - float(g["loss"])) <= 1e-4
 
 
+def test_first_stage_train_mode_step_128(golden):
+    """The oracle in TRAIN mode (one power iteration per decoder call: 15 sigma per weight per step) against the reference's own
+    train-mode step at the c4 size (golden g13: 128x128, z = 32, T = 16): reconstruction, loss, u buffers after the step, and the
+    checksums of a few gradient tensors."""
+    g = golden("g13_first_stage_train_mode_128")
+    m = vae_ref.SpadeCondMotionModel(configs.first_stage_config(128, 32, 16)).train()
+    deterministic_fill_(m, prefix="first_stage.")
+    X = torch.rand(1, 16, 3, 128, 128, generator=torch.Generator().manual_seed(int(g["X_seed"]))) * 2 - 1
+    Xh, mu, lv = m(X, eps=t(g["eps"]))
+    loss = vae_ref.first_stage_loss(X, Xh, mu, lv)
+    assert (Xh[:, [0, 7, 14]] - t(g["X_hat_frames"])).abs().max() <= 1e-4 and abs(loss.item() - float(g["loss"])) <= 1e-4
+    sd = m.state_dict()
+    for k in g["u_names"].tolist():
+        assert (sd[k] - t(g["u." + k])).abs().max() <= 1e-5, k
+    loss.backward()
+    names = g["grad_names"].tolist()
+    grads = dict(m.named_parameters())
+    for k in ("gen.out_conv.conv.weight", "gen.in_block.conv1.conv.weight_orig", "rnn.cells.0.out_gate.weight", "enc_motion.conv1.weight"):
+        cs, ref = _checksum(grads[k].grad, k), g["grad_checksums"][names.index(k)]
+        assert abs(cs[0] - ref[0]) <= 1e-2 * ref[1] and abs(cs[1] - ref[1]) <= 1e-2 * ref[1], (k, cs, ref)
+
+
 def _checksum(x, key):
     import zlib
     x = x.detach().double().flatten().cpu()
