@@ -344,6 +344,23 @@ int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
 /* refresh only the shadows derived from the parameters in params[begin, end) (a range announced by
  * ipoke_flow_backward_pieces, i.e. whole levels): lets the weight preparation follow the per-group optimizer update */
 int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* params, void* shadow, int64_t begin, int64_t end, void* stream);
+/* torch.optim.Adam(amsgrad=True) over params[begin, end) (second_stage_video.py:648-650) fused with the refresh of the weight shadows
+ * derived from that range: the plain 1x1 weights (conv2 of every coupling net, macow_utils.py:274) are updated tile by tile and their
+ * two operands written from the registers that hold the new values; the rest is updated linearly and laid out as by
+ * ipoke_flow_prepare_weights_range.  Equivalent to ipoke_adam_amsgrad_step_grid on the range + ipoke_flow_prepare_weights_range.
+ * m, v, vmax: optimizer state with the layout of params.  [begin, end) covers whole tensors. */
+int ipoke_flow_adam_range(ipoke_flow* f, float* params, const float* grads, float* m, float* v, float* vmax, void* shadow, int64_t begin,
+                          int64_t end, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                          int max_blocks, void* stream);
+/* its two kernels on their own (job / segment tables as the engine builds them; sizes for layout checks) */
+int ipoke_adam_tile_job_size(void);
+int ipoke_adam_seg_size(void);
+int ipoke_adam_amsgrad_shadow_tiles(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, const void* jobs_dev, int njobs,
+                                    int tile_begin, int ntiles, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                    float grad_scale, int max_blocks, int dtype, void* stream);
+int ipoke_adam_amsgrad_segments(float* p, const float* g, float* m, float* v, float* vmax, const void* segs_dev, int seg_begin, int nsegs,
+                                int64_t begin, int64_t end, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                float grad_scale, int blocks_per_segment, void* stream);
 /* parameter gradients (written, not accumulated) and optionally d/dx, given d/d_out and d/d_logdet */
 int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
                         const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,

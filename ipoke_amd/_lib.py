@@ -179,6 +179,14 @@ SIGNATURES = {
     "ipoke_relayout_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "ipoke_wn_scale_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_flow_prepare_weights_range": (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
+    "ipoke_flow_adam_range": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
+                                      c_float, c_int, _P]),
+    "ipoke_adam_tile_job_size": (c_int, []),
+    "ipoke_adam_seg_size": (c_int, []),
+    "ipoke_adam_amsgrad_shadow_tiles": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                                                c_int, c_float, c_int, c_int, _P]),
+    "ipoke_adam_amsgrad_segments": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_float, c_float, c_float, c_float,
+                                            c_float, c_int, c_float, c_int, _P]),
     "ipoke_wn_bwd_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_flow_backward_pieces": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, GRAD_READY_FN, _P, _P]),
     "ipoke_video_to_cl": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int,

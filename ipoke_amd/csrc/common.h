@@ -113,6 +113,25 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// ---- Adam with amsgrad (torch.optim.Adam semantics), one element; shared by every kernel that applies the update
+struct AdamHyper { float lr_bc1, beta1, beta2, eps, wd, bc2_sqrt, grad_scale; };     // lr_bc1 = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t)
+__device__ __forceinline__ void adam_amsgrad_update(float& p, float g, float& m, float& v, float& vx, const AdamHyper& h) {
+  const float gr = g * h.grad_scale + h.wd * p;
+  m = h.beta1 * m + (1.f - h.beta1) * gr;
+  v = h.beta2 * v + (1.f - h.beta2) * gr * gr;
+  vx = fmaxf(vx, v);
+  const float denom = sqrtf(vx) / h.bc2_sqrt + h.eps;
+  p -= h.lr_bc1 * (m / denom);
+}
+__device__ __forceinline__ void adam_amsgrad_update4(f32x4& p, const f32x4& g, f32x4& m, f32x4& v, f32x4& vx, const AdamHyper& h) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float pk = p[k], mk = m[k], vk = v[k], xk = vx[k];
+    adam_amsgrad_update(pk, g[k], mk, vk, xk, h);
+    p[k] = pk; m[k] = mk; v[k] = vk; vx[k] = xk;
+  }
+}
+
 struct McfGeom { int kh, kw, oy, ox; };
 __host__ __device__ inline McfGeom mcf_geom(int order) {
   // input(y + ky + oy, x + kx + ox) feeds output (y, x): strictly above / below / left / right

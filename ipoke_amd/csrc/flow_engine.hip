@@ -61,6 +61,8 @@ struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
   int taps, n_real, k_real, A_rows_pad, A_inner_pad, B_rows_pad, B_inner_pad, B_rows_real, tile, tiles_k, block_start, frag_tiled;
 };
 struct WnJobH { long v_off, g_off, out_off; int rows, K, row_start; };
+struct AdamTileJobH { long src_off, dstA, dstB; int N, K, tile_start, pad; };     // mirrors AdamTileJob of prep.hip
+struct AdamSegH { long off, len; };                                               // mirrors AdamSeg of prep.hip
 struct LsRefH { long off; int C; };
 struct LuJobH { long p_l, p_u, p_logs, b_perm, b_sign, b_lmask, b_umask, b_eye, w_off; int C, pad; };   // mirrors LuJob of lu.hip
 
@@ -84,6 +86,12 @@ struct ipoke_flow {
   void* d_ntab[3] = {nullptr, nullptr, nullptr};   // NICE conv1 / conv2 / conv3 weight-gradient batch entries, by nice_idx
   int n_nice = 0;
   std::vector<RelayoutJobH> rjobs; int rblocks = 0;
+  // Optimizer-fused shadows (ipoke_flow_adam_range): plain 1x1 weights whose operands the Adam kernel writes itself (ajobs, in
+  // tiles of 64 x 64), the relayout table WITHOUT them (rjobs2, own block numbering), and the gaps between them in the flat buffer
+  std::vector<AdamTileJobH> ajobs; int atiles = 0;
+  std::vector<RelayoutJobH> rjobs2; int rblocks2 = 0;
+  std::vector<AdamSegH> asegs;
+  void* d_ajobs = nullptr; void* d_rjobs2 = nullptr; void* d_rblockjob2 = nullptr; void* d_asegs = nullptr;
   std::vector<WnJobH> wjobs;
   std::vector<LsRefH> lsrefs;
   void* d_rjobs = nullptr; void* d_wjobs = nullptr; void* d_lsrefs = nullptr; void* d_rblockjob = nullptr;
@@ -162,6 +170,18 @@ struct Builder {
                    B_rows_real, tile, tiles_k, f.rblocks, frag_tiled};
     f.rjobs.push_back(j);
     f.rblocks += tiles_n * tiles_k;
+    // a dense, unpadded, un-normalised [n][k] matrix in whole 64 x 64 tiles: its operands are the tensor's cast and its transpose
+    const bool fusable = taps == 1 && scale < 0 && !frag_tiled && s_k == 1 && s_n == k_real && n_real % 64 == 0 && k_real % 64 == 0 &&
+                         A_rows_pad == n_real && A_inner_pad == k_real && B_rows_pad == k_real && B_inner_pad == n_real &&
+                         B_rows_real == k_real;
+    if (fusable) {
+      f.ajobs.push_back({src, dstA, dstB, n_real, k_real, f.atiles, 0});
+      f.atiles += (n_real / 64) * (k_real / 64);
+    } else {
+      j.block_start = f.rblocks2;
+      f.rjobs2.push_back(j);
+      f.rblocks2 += tiles_n * tiles_k;
+    }
   }
 
   void actnorm(const std::string& pfx, int C_active, int c0, int Cn, const std::string* shuffle_pfx) {
@@ -616,6 +636,16 @@ extern "C" int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out)
   f->cfg = *cfg;
   f->esz = cfg->dtype == IPOKE_BF16 ? 2 : 4; f->e16 = 16 / f->esz; f->ks = 64 / f->esz;
   int rc = build(*f); if (rc) return rc;
+  {   // gaps between the optimizer-fused tensors (both tables are in parameter order)
+    int64_t pos = 0;
+    for (size_t k = 0; k < f->ajobs.size(); ++k) {
+      IPK_REQUIRE(f->ajobs[k].src_off >= pos, "fused tensors must be in parameter order");
+      if (f->ajobs[k].src_off > pos) f->asegs.push_back({(long)pos, (long)(f->ajobs[k].src_off - pos)});
+      pos = f->ajobs[k].src_off + (int64_t)f->ajobs[k].N * f->ajobs[k].K;
+    }
+    if (pos < f->n_params) f->asegs.push_back({(long)pos, (long)(f->n_params - pos)});
+    for (size_t k = 1; k < f->rjobs.size(); ++k) IPK_REQUIRE(f->rjobs[k].src_off > f->rjobs[k - 1].src_off, "relayout jobs must be in parameter order");
+  }
   const char* env = getenv("IPOKE_NO_SIDE_STREAM");
   f->use_side = !(env && env[0] == '1');
   const char* gr = getenv("IPOKE_GRAPH");
@@ -644,6 +674,26 @@ static int ensure_device(ipoke_flow* f) {
     }
     IPK_HIP(hipMalloc(&f->d_rblockjob, bj.size() * sizeof(int32_t)));
     IPK_HIP(hipMemcpy(f->d_rblockjob, bj.data(), bj.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  IPK_REQUIRE((int)sizeof(AdamTileJobH) == ipoke_adam_tile_job_size() && (int)sizeof(AdamSegH) == ipoke_adam_seg_size(), "Adam table layout mismatch");
+  if (!f->ajobs.empty()) {
+    IPK_HIP(hipMalloc(&f->d_ajobs, f->ajobs.size() * sizeof(AdamTileJobH)));
+    IPK_HIP(hipMemcpy(f->d_ajobs, f->ajobs.data(), f->ajobs.size() * sizeof(AdamTileJobH), hipMemcpyHostToDevice));
+  }
+  if (!f->asegs.empty()) {
+    IPK_HIP(hipMalloc(&f->d_asegs, f->asegs.size() * sizeof(AdamSegH)));
+    IPK_HIP(hipMemcpy(f->d_asegs, f->asegs.data(), f->asegs.size() * sizeof(AdamSegH), hipMemcpyHostToDevice));
+  }
+  if (!f->rjobs2.empty()) {
+    IPK_HIP(hipMalloc(&f->d_rjobs2, f->rjobs2.size() * sizeof(RelayoutJobH)));
+    IPK_HIP(hipMemcpy(f->d_rjobs2, f->rjobs2.data(), f->rjobs2.size() * sizeof(RelayoutJobH), hipMemcpyHostToDevice));
+    std::vector<int32_t> bj((size_t)f->rblocks2);
+    for (size_t k = 0; k < f->rjobs2.size(); ++k) {
+      const int b0 = f->rjobs2[k].block_start, b1 = k + 1 < f->rjobs2.size() ? f->rjobs2[k + 1].block_start : f->rblocks2;
+      for (int b = b0; b < b1; ++b) bj[b] = (int32_t)k;
+    }
+    IPK_HIP(hipMalloc(&f->d_rblockjob2, bj.size() * sizeof(int32_t)));
+    IPK_HIP(hipMemcpy(f->d_rblockjob2, bj.data(), bj.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   IPK_HIP(hipMalloc(&f->d_wjobs, f->wjobs.size() * sizeof(WnJobH)));
   IPK_HIP(hipMemcpy(f->d_wjobs, f->wjobs.data(), f->wjobs.size() * sizeof(WnJobH), hipMemcpyHostToDevice));
@@ -675,6 +725,10 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   if (f->d_lsrefs) (void)hipFree(f->d_lsrefs);
   if (f->d_lujobs) (void)hipFree(f->d_lujobs);
   if (f->d_rblockjob) (void)hipFree(f->d_rblockjob);
+  if (f->d_ajobs) (void)hipFree(f->d_ajobs);
+  if (f->d_asegs) (void)hipFree(f->d_asegs);
+  if (f->d_rjobs2) (void)hipFree(f->d_rjobs2);
+  if (f->d_rblockjob2) (void)hipFree(f->d_rblockjob2);
   if (f->d_w1tab) (void)hipFree(f->d_w1tab);
   for (int k = 0; k < 3; ++k) if (f->d_ntab[k]) (void)hipFree(f->d_ntab[k]);
   if (f->d_w2tab) (void)hipFree(f->d_w2tab);
@@ -747,10 +801,7 @@ extern "C" int ipoke_flow_prepare_weights(ipoke_flow* f, const float* params, vo
                               reinterpret_cast<const int32_t*>(f->d_rblockjob), f->cfg.dtype, stream);
 }
 
-extern "C" int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* params, void* shadow, int64_t begin, int64_t end,
-                                                void* stream) {
-  IPK_REQUIRE(f && params && shadow && begin >= 0 && end >= begin, "bad arguments");
-  { int rc0 = ensure_device(f); if (rc0) return rc0; }
+static int prepare_range(ipoke_flow* f, const float* params, void* shadow, int64_t begin, int64_t end, bool skip_fused, void* stream) {
   float* wn_scale = reinterpret_cast<float*>(shadow);
   float* wn_inv = wn_scale + align_up(f->wn_rows, 64);
   // job tables are in parameter order: the jobs whose source tensor starts inside [begin, end) are contiguous
@@ -764,18 +815,64 @@ extern "C" int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* para
     int rc = ipoke_wn_scale_multi_range(params, wn_scale, wn_inv, f->d_wjobs, w0, w1 - w0, row0, row1 - row0, stream);
     if (rc) return rc;
   }
+  const std::vector<RelayoutJobH>& jobs = skip_fused ? f->rjobs2 : f->rjobs;
+  const int nblocks = skip_fused ? f->rblocks2 : f->rblocks;
   int j0 = 0, j1 = 0;
-  while (j0 < (int)f->rjobs.size() && f->rjobs[j0].src_off < begin) ++j0;
+  while (j0 < (int)jobs.size() && jobs[j0].src_off < begin) ++j0;
   j1 = j0;
-  while (j1 < (int)f->rjobs.size() && f->rjobs[j1].src_off < end) ++j1;
+  while (j1 < (int)jobs.size() && jobs[j1].src_off < end) ++j1;
   if (j1 > j0) {
-    const int b0 = f->rjobs[j0].block_start;
-    const int b1 = j1 < (int)f->rjobs.size() ? f->rjobs[j1].block_start : f->rblocks;
+    const int b0 = jobs[j0].block_start;
+    const int b1 = j1 < (int)jobs.size() ? jobs[j1].block_start : nblocks;
     void* sh = reinterpret_cast<unsigned char*>(shadow) + 2 * align_up(f->wn_rows, 64) * 4;
-    return ipoke_relayout_multi_range(params, sh, wn_scale, f->d_rjobs, (int)f->rjobs.size(), b0, b1 - b0,
-                                      reinterpret_cast<const int32_t*>(f->d_rblockjob), f->cfg.dtype, stream);
+    return ipoke_relayout_multi_range(params, sh, wn_scale, skip_fused ? f->d_rjobs2 : f->d_rjobs, (int)jobs.size(), b0, b1 - b0,
+                                      reinterpret_cast<const int32_t*>(skip_fused ? f->d_rblockjob2 : f->d_rblockjob), f->cfg.dtype, stream);
   }
   return IPOKE_OK;
+}
+
+extern "C" int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* params, void* shadow, int64_t begin, int64_t end,
+                                                void* stream) {
+  IPK_REQUIRE(f && params && shadow && begin >= 0 && end >= begin, "bad arguments");
+  { int rc0 = ensure_device(f); if (rc0) return rc0; }
+  return prepare_range(f, params, shadow, begin, end, false, stream);
+}
+
+/* Adam-amsgrad update of params[begin, end) AND the refresh of every weight shadow derived from it, on `stream`:
+ *   1. the plain 1x1 weights (conv2 of the coupling nets) by ipoke_adam_amsgrad_shadow_tiles -- update + both operands in one pass,
+ *   2. everything between them by ipoke_adam_amsgrad_segments,
+ *   3. weight-norm scales and the relayout of the remaining (3x3, masked, weight-normed) tensors.
+ * [begin, end) must cover whole tensors (the ranges ipoke_flow_backward_pieces announces, or [0, param_count)). */
+extern "C" int ipoke_flow_adam_range(ipoke_flow* f, float* params, const float* grads, float* m, float* v, float* vmax, void* shadow,
+                                     int64_t begin, int64_t end, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     int step, float grad_scale, int max_blocks, void* stream) {
+  IPK_REQUIRE(f && params && grads && m && v && vmax && shadow && begin >= 0 && end >= begin && end <= f->n_params, "bad arguments");
+  { int rc0 = ensure_device(f); if (rc0) return rc0; }
+  if (end == begin) return IPOKE_OK;
+  int a0 = 0, a1 = 0;
+  while (a0 < (int)f->ajobs.size() && f->ajobs[a0].src_off < begin) ++a0;
+  a1 = a0;
+  while (a1 < (int)f->ajobs.size() && f->ajobs[a1].src_off < end) ++a1;
+  if (a1 > a0) {
+    IPK_REQUIRE(f->ajobs[a1 - 1].src_off + (int64_t)f->ajobs[a1 - 1].N * f->ajobs[a1 - 1].K <= end, "range must cover whole tensors");
+    const int t0 = f->ajobs[a0].tile_start, t1 = a1 < (int)f->ajobs.size() ? f->ajobs[a1].tile_start : f->atiles;
+    void* sh = reinterpret_cast<unsigned char*>(shadow) + 2 * align_up(f->wn_rows, 64) * 4;
+    int rc = ipoke_adam_amsgrad_shadow_tiles(params, grads, m, v, vmax, sh, f->d_ajobs, (int)f->ajobs.size(), t0, t1 - t0, lr, beta1, beta2,
+                                             eps, weight_decay, step, grad_scale, max_blocks, f->cfg.dtype, stream);
+    if (rc) return rc;
+  }
+  int s0 = 0, s1 = 0;
+  while (s0 < (int)f->asegs.size() && f->asegs[s0].off + f->asegs[s0].len <= begin) ++s0;
+  s1 = s0;
+  while (s1 < (int)f->asegs.size() && f->asegs[s1].off < end) ++s1;
+  if (s1 > s0) {
+    int per = max_blocks > 0 ? max_blocks / (s1 - s0) : 16;
+    if (per < 2) per = 2; if (per > 32) per = 32;
+    int rc = ipoke_adam_amsgrad_segments(params, grads, m, v, vmax, f->d_asegs, s0, s1 - s0, begin, end, lr, beta1, beta2, eps, weight_decay,
+                                         step, grad_scale, per, stream);
+    if (rc) return rc;
+  }
+  return prepare_range(f, params, shadow, begin, end, true, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -62,6 +62,7 @@ struct TnParams {
   float* dW; long w_sn, w_sc, w_st; int accumulate;
   int splitm, mb_per_split, rows_fixed, Kc_store;
   int tiles_n, tiles_k;
+  int xa, xb;          // LDS-DMA kernel: XCD-aware tile map (xa x xb = 8 sub-grids), 0: plain row-major order
   long split_stride;   // > 0: split z stores its slab at dW + z*split_stride instead of atomics
   int tile0, max_wgs;  // first output tile of this launch / cap on workgroups per launch (0: none)
 };
@@ -1646,8 +1647,19 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn2 = wave >> 2, wk = wave & 3;     // wave tile: 64 (n) x 32 (k)
   const GeomDev& g = p.g;
-  const int tile = (int)blockIdx.x + p.tile0;
-  const int tn = tile % p.tiles_n, tk = tile / p.tiles_n;
+  int tn, tk;
+  if (p.xa > 0) {
+    // XCD-aware tile map (blocks are dealt round-robin over the 8 XCDs, each with its own L2): XCD x owns a
+    // (tiles_n / xa) x (tiles_k / xb) sub-grid, so that its L2 fetches 1/xa of dY and 1/xb of A instead of (with the plain
+    // row-major order and tiles_n = 16) 1/8 of dY and ALL of A -- conv2 shape: 47 -> 31 MB of fabric reads per problem
+    const int bid = (int)blockIdx.x, xcd = bid & 7, q = bid >> 3;
+    const int sub_n = p.tiles_n / p.xa, sub_k = p.tiles_k / p.xb;
+    tn = (xcd % p.xa) * sub_n + q % sub_n;
+    tk = (xcd / p.xa) * sub_k + q / sub_n;
+  } else {
+    const int tile = (int)blockIdx.x + p.tile0;
+    tn = tile % p.tiles_n; tk = tile / p.tiles_n;
+  }
   const int n0 = tn * 128, k0 = tk * 128;
   const int z = blockIdx.y;
   const int nmb_total = (g.M + RM - 1) / RM;
@@ -1824,6 +1836,17 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     if (!attr_done2) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2 = true; }
     const int ntiles = p.tiles_n * p.tiles_k;
     const int cap = p.max_wgs > 0 ? p.max_wgs : ntiles;
+    p.xa = p.xb = 0;
+    static const bool xcd_map = !(getenv("IPOKE_TN_XCD") && atoi(getenv("IPOKE_TN_XCD")) == 0);      // developer A/B
+    if (xcd_map && cap >= ntiles && ntiles % 8 == 0) {     // whole problem in one launch, blockIdx.x % 8 = XCD for every (y, z)
+      double best = -1;
+      for (int xa = 1; xa <= 8; xa *= 2) {
+        const int xb = 8 / xa;
+        if (p.tiles_n % xa || p.tiles_k % xb) continue;
+        const double cost = (double)p.tiles_n / xa + (double)p.tiles_k / xb;       // operand columns an XCD's L2 has to hold
+        if (best < 0 || cost < best) { best = cost; p.xa = xa; p.xb = xb; }
+      }
+    }
     for (int t0 = 0; t0 < ntiles; t0 += cap) {
       p.tile0 = t0;
       dim3 grid2((unsigned)std::min(cap, ntiles - t0), (unsigned)p.splitm, (unsigned)nbatch);

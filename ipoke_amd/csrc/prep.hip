@@ -226,9 +226,159 @@ __global__ void wn_bwd_kernel(const float* __restrict__ params, float* __restric
   if (lane == 0) grads[j.g_off + row] = dot * inv;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Adam-amsgrad fused with the shadow refresh of plain 1x1 weights (conv2 of every coupling net: [hidden][hidden], 73 % of the
+// flow's parameters).  These tensors need no weight norm, their forward operand is the bf16 cast of the tensor in place and
+// their data-gradient operand its transpose -- so the optimizer, which holds the updated p in registers, writes both and
+// `relayout` never re-reads them (per step at z = 64: 3.6 GB less HBM read, 215 relayout jobs less).  One 64 x 64 tile per
+// iteration of a persistent workgroup: a thread owns 8 consecutive k of two rows (two 16-byte loads per array, all 20 issued
+// before the arithmetic), stores p / m / v / v_max and the straight operand row segment, and the tile meets in LDS once for
+// the transposed operand.  Same arithmetic as adam_amsgrad_kernel (adam_amsgrad_update).
+struct AdamTileJob { long src_off, dstA, dstB; int N, K, tile_start, pad; };
+
+template <typename T> struct Out8;
+template <> struct Out8<bf16_t> {
+  static __device__ __forceinline__ void store(bf16_t* dst, const float* x) {
+    bf16x8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)x[q];
+    *reinterpret_cast<bf16x8*>(dst) = o;
+  }
+};
+template <> struct Out8<float> {
+  static __device__ __forceinline__ void store(float* dst, const float* x) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{x[0], x[1], x[2], x[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{x[4], x[5], x[6], x[7]};
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void adam_shadow_tile_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                               float* __restrict__ v, float* __restrict__ vmax, T* __restrict__ shadow,
+                                                               const AdamTileJob* __restrict__ jobs, int njobs, int tile_begin,
+                                                               int ntiles, AdamHyper h) {
+  constexpr int TP = 65;
+  __shared__ float tile[64 * TP];
+  const int tid = threadIdx.x;
+  for (int t = tile_begin + (int)blockIdx.x; t < tile_begin + ntiles; t += (int)gridDim.x) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].tile_start <= t) lo = mid; else hi = mid - 1;
+    }
+    const AdamTileJob j = jobs[lo];
+    const int lt = t - j.tile_start, tiles_k = j.K >> 6;
+    const int n0 = (lt / tiles_k) << 6, k0 = (lt % tiles_k) << 6;
+    f32x4 pp[4], gg[4], mm[4], vv[4], vx[4];
+    long off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, r = u >> 3, c = (u & 7) * 8;
+      off[i] = j.src_off + (long)(n0 + r) * j.K + k0 + c;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        pp[2 * i + q] = *reinterpret_cast<const f32x4*>(p + off[i] + 4 * q);
+        gg[2 * i + q] = *reinterpret_cast<const f32x4*>(g + off[i] + 4 * q);
+        mm[2 * i + q] = *reinterpret_cast<const f32x4*>(m + off[i] + 4 * q);
+        vv[2 * i + q] = *reinterpret_cast<const f32x4*>(v + off[i] + 4 * q);
+        vx[2 * i + q] = *reinterpret_cast<const f32x4*>(vmax + off[i] + 4 * q);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) adam_amsgrad_update4(pp[e], gg[e], mm[e], vv[e], vx[e], h);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, r = u >> 3, c = (u & 7) * 8;
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<f32x4*>(p + off[i] + 4 * q) = pp[2 * i + q];
+        *reinterpret_cast<f32x4*>(m + off[i] + 4 * q) = mm[2 * i + q];
+        *reinterpret_cast<f32x4*>(v + off[i] + 4 * q) = vv[2 * i + q];
+        *reinterpret_cast<f32x4*>(vmax + off[i] + 4 * q) = vx[2 * i + q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[4 * q + k] = pp[2 * i + q][k]; tile[r * TP + c + 4 * q + k] = pp[2 * i + q][k]; }
+      }
+      Out8<T>::store(shadow + j.dstA + (long)(n0 + r) * j.K + k0 + c, x);      // forward operand: [n][k], the tensor's own order
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, kl = u >> 3, nl = (u & 7) * 8;
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = tile[(nl + q) * TP + kl];
+      Out8<T>::store(shadow + j.dstB + (long)(k0 + kl) * j.N + n0 + nl, x);     // data-gradient operand: [k][n]
+    }
+    __syncthreads();
+  }
+}
+
+// the same update over the gaps between those tensors: segment s0 + blockIdx.y of a table, clipped to [begin, end)
+struct AdamSeg { long off, len; };
+__global__ void adam_amsgrad_seg_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                        float* __restrict__ vmax, const AdamSeg* __restrict__ segs, int s0, long begin, long end,
+                                        AdamHyper h) {
+  const AdamSeg sg = segs[s0 + blockIdx.y];
+  const long lo = sg.off > begin ? sg.off : begin, hi = sg.off + sg.len < end ? sg.off + sg.len : end;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = lo + ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < hi; i += stride) {
+    if (i + 3 < hi) {
+      f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+      f32x4 vx = *reinterpret_cast<f32x4*>(vmax + i);
+      adam_amsgrad_update4(pp, gg, mm, vv, vx, h);
+      *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm;
+      *reinterpret_cast<f32x4*>(v + i) = vv; *reinterpret_cast<f32x4*>(vmax + i) = vx;
+    } else {
+      for (long k = i; k < hi; ++k) adam_amsgrad_update(p[k], g[k], m[k], v[k], vmax[k], h);
+    }
+  }
+}
+
 }  // namespace ipoke
 
 using namespace ipoke;
+
+extern "C" int ipoke_adam_tile_job_size(void) { return (int)sizeof(AdamTileJob); }
+extern "C" int ipoke_adam_seg_size(void) { return (int)sizeof(AdamSeg); }
+
+static AdamHyper make_hyper(float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale) {
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  return AdamHyper{lr / (float)bc1, beta1, beta2, eps, wd, (float)sqrt(bc2), grad_scale};
+}
+
+extern "C" int ipoke_adam_amsgrad_shadow_tiles(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, const void* jobs_dev,
+                                               int njobs, int tile_begin, int ntiles, float lr, float beta1, float beta2, float eps,
+                                               float weight_decay, int step, float grad_scale, int max_blocks, int dtype, void* stream) {
+  IPK_REQUIRE(p && g && m && v && vmax && shadow && jobs_dev && njobs >= 1 && ntiles >= 0 && step >= 1, "bad arguments");
+  IPK_REQUIRE(dtype == IPOKE_BF16 || dtype == IPOKE_F32, "bad dtype");
+  if (ntiles == 0) return IPOKE_OK;
+  const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+  const int grid = max_blocks > 0 && max_blocks < ntiles ? max_blocks : ntiles;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(adam_shadow_tile_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, p, g, m, v, vmax, (bf16_t*)shadow,
+                       (const AdamTileJob*)jobs_dev, njobs, tile_begin, ntiles, h);
+  else
+    hipLaunchKernelGGL(adam_shadow_tile_kernel<float>, dim3(grid), dim3(256), 0, s, p, g, m, v, vmax, (float*)shadow,
+                       (const AdamTileJob*)jobs_dev, njobs, tile_begin, ntiles, h);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+extern "C" int ipoke_adam_amsgrad_segments(float* p, const float* g, float* m, float* v, float* vmax, const void* segs_dev, int seg_begin,
+                                           int nsegs, int64_t begin, int64_t end, float lr, float beta1, float beta2, float eps,
+                                           float weight_decay, int step, float grad_scale, int blocks_per_segment, void* stream) {
+  IPK_REQUIRE(p && g && m && v && vmax && segs_dev && nsegs >= 0 && seg_begin >= 0 && end >= begin && step >= 1, "bad arguments");
+  if (nsegs == 0) return IPOKE_OK;
+  const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+  hipLaunchKernelGGL(adam_amsgrad_seg_kernel, dim3(blocks_per_segment > 0 ? blocks_per_segment : 8, nsegs), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), p, g, m, v, vmax, (const AdamSeg*)segs_dev, seg_begin, (long)begin, (long)end, h);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
 
 extern "C" int ipoke_relayout_job_size(void) { return (int)sizeof(RelayoutJob); }
 extern "C" int ipoke_wn_job_size(void) { return (int)sizeof(WnJob); }

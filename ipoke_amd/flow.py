@@ -146,7 +146,7 @@ class FlowEngine:
         """Refresh the matrix-core weight shadows from the master weights (after every update)."""
         self._need_gpu()
         if self.shadow is None:
-            self.shadow = torch.empty(self.lib.ipoke_flow_shadow_bytes(self.handle), dtype=torch.uint8, device=self.device)
+            self.shadow = torch.zeros(self.lib.ipoke_flow_shadow_bytes(self.handle), dtype=torch.uint8, device=self.device)
         check(self.lib.ipoke_flow_prepare_weights(self.handle, ptr(self.params), ptr(self.shadow), _lib.current_stream()))
         self.shadow_stale = False
 
@@ -154,9 +154,20 @@ class FlowEngine:
         """Refresh the shadows of the parameters in flat[begin:end] (whole levels) on the current stream."""
         self._need_gpu()
         if self.shadow is None:
-            self.shadow = torch.empty(self.lib.ipoke_flow_shadow_bytes(self.handle), dtype=torch.uint8, device=self.device)
+            self.shadow = torch.zeros(self.lib.ipoke_flow_shadow_bytes(self.handle), dtype=torch.uint8, device=self.device)
         check(self.lib.ipoke_flow_prepare_weights_range(self.handle, ptr(self.params), ptr(self.shadow), int(begin), int(end),
                                                         _lib.current_stream()))
+
+    def adam_range(self, begin, end, m, v, vmax, lr, betas, eps, weight_decay, step, grad_scale=1.0, max_blocks=0):
+        """Adam-amsgrad update of flat[begin:end] fused with the refresh of its weight shadows (ipoke_flow_adam_range): the plain
+        1x1 weights get their operands written by the optimizer kernel itself.  Current stream."""
+        self._need_gpu()
+        if self.shadow is None:
+            self.shadow = torch.zeros(self.lib.ipoke_flow_shadow_bytes(self.handle), dtype=torch.uint8, device=self.device)
+        check(self.lib.ipoke_flow_adam_range(self.handle, ptr(self.params), ptr(self.ensure_grads()), ptr(m), ptr(v), ptr(vmax),
+                                             ptr(self.shadow), int(begin), int(end), float(lr), float(betas[0]), float(betas[1]),
+                                             float(eps), float(weight_decay), int(step), float(grad_scale), int(max_blocks),
+                                             _lib.current_stream()))
 
     # ---- compute -------------------------------------------------------------------------
     def _prep_inputs(self, x, cond):

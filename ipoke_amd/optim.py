@@ -7,10 +7,15 @@ layout) instead of ~3000 per-tensor updates; afterwards the matrix-core weight s
 It is a ``torch.optim.Optimizer`` so LR schedules that write ``param_groups[i]['lr']`` (the reference's
 ``on_train_batch_start``) work unchanged.
 """
+import os
+
 import torch
 
 from . import _lib
 from ._lib import check, ptr
+
+# developer A/B: IPOKE_NO_ADAM_FUSION=1 -> linear Adam kernel + relayout of every tensor (round-2 path)
+_FUSE_SHADOWS = os.environ.get("IPOKE_NO_ADAM_FUSION", "0") != "1"
 
 
 class FusedAdamAmsgrad(torch.optim.Optimizer):
@@ -37,6 +42,11 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.steps += 1
         flat, grads = self.flow.flat_params, self.flow.flat_grads
+        if _FUSE_SHADOWS and not self.flow.engine.shadow_stale:
+            # update + shadow refresh in one pass (the conv2 operands leave the optimizer kernel's registers)
+            self.flow.engine.adam_range(0, flat.numel(), self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, g["lr"], g["betas"], g["eps"],
+                                        g["weight_decay"], self.steps, grad_scale)
+            return loss
         check(_lib.lib().ipoke_adam_amsgrad_step(
             ptr(flat), ptr(grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.max_exp_avg_sq), flat.numel(),
             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
@@ -54,6 +64,11 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         """Adam-amsgrad update of flat[begin:end] on the current stream (same kernel, same step count for every slice)."""
         g = self.param_groups[0]
         flat, grads = self.flow.flat_params, self.flow.flat_grads
+        if _FUSE_SHADOWS and not self.flow.engine.shadow_stale:
+            self.flow.engine.adam_range(begin, end, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, g["lr"], g["betas"], g["eps"],
+                                        g["weight_decay"], self.steps, grad_scale, max_blocks=128)
+            self._covered += end - begin
+            return
         sl = slice(begin, end)
         check(_lib.lib().ipoke_adam_amsgrad_step_grid(
             ptr(flat[sl]), ptr(grads[sl]), ptr(self.exp_avg[sl]), ptr(self.exp_avg_sq[sl]), ptr(self.max_exp_avg_sq[sl]), end - begin,

@@ -213,3 +213,50 @@ def test_flow_loss_value_and_gradient(spatial_mean):
     assert (xg.grad.cpu() - xo.grad).abs().max().item() <= 1e-7 and (ldg.grad.cpu() - ldo.grad).abs().max().item() <= 1e-8
     ref_scale = 0.5 * 32 * (1 if spatial_mean else 64)             # E[reference_nll_loss] of a standard normal sample
     assert 0.7 * ref_scale < log["reference_nll_loss"].item() < 1.3 * ref_scale
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("hidden", [64, 192])
+def test_fused_adam_shadow_refresh_is_bit_identical(dtype, hidden):
+    """ipoke_flow_adam_range (Adam-amsgrad with the conv2 operands written by the optimizer kernel, the gaps updated by the
+    segment kernel, the rest laid out by relayout) against the plain path (linear ipoke_adam_amsgrad_step over the flat buffer +
+    ipoke_flow_prepare_weights): parameters, m, v, v_max and EVERY byte of the shadow buffer, over the whole buffer in one
+    call and over the ranges a piecewise backward announces, three steps."""
+    from ipoke_amd import optim as O
+    arch = configs.flow_arch(16, hidden=hidden, num_steps=[2, 1, 1], factor=4)
+
+    def run(fused, pieces):
+        m = build(arch, dtype).train()
+        eng = m.engine
+        x = torch.randn(3, 16, 8, 8, generator=torch.Generator().manual_seed(1)).cuda()
+        cond = torch.randn(3, 128, 8, 8, generator=torch.Generator().manual_seed(2)).cuda()
+        opt = O.FusedAdamAmsgrad(m, lr=1e-3, weight_decay=1e-5)
+        n = eng.params.numel()
+        O._FUSE_SHADOWS = fused
+        try:
+            for step in range(3):
+                out, logdet = m(x, cond)
+                ((0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()).backward()
+                if pieces is None:
+                    opt.step()
+                else:
+                    opt.begin_step()
+                    for b, e in pieces(eng, n):
+                        opt.step_range(b, e)
+                    opt.finish_step()
+            torch.cuda.synchronize()
+        finally:
+            O._FUSE_SHADOWS = True
+        return (eng.params.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.max_exp_avg_sq.clone(), eng.shadow.clone())
+
+    def cut(eng, n):
+        # tensor-aligned ranges: cut the flat buffer at three tensor starts (as the engine's level groups are)
+        offs = sorted({off for name, off, shape, kind in eng.tensors if kind == 0})
+        cuts = [0, offs[len(offs) // 4], offs[len(offs) // 2], offs[3 * len(offs) // 4], n]
+        return [(cuts[i], cuts[i + 1]) for i in range(4)][::-1]
+
+    ref = run(False, None)
+    for pieces in (None, cut):
+        got = run(True, pieces)
+        for name, a, b in zip(("params", "exp_avg", "exp_avg_sq", "max_exp_avg_sq", "shadow"), ref, got):
+            assert torch.equal(a, b), (name, "whole" if pieces is None else "pieces", (a.float() - b.float()).abs().max().item())

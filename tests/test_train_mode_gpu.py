@@ -20,11 +20,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 T = 16
 
-# f32 (exact-f32 matrix cores): the bounds of the eval-mode slices (tests/test_vae_gpu.py).  bf16: see grad_report() -- the
-# sum / abs-sum of a tensor's gradient and the MEAN sampled-element error are bounded tightly, the MAX over sampled elements
-# separately (a single element of a bf16 weight gradient that sits on a ReLU kink or an L1 sign flip moves by its own size).
+# f32 (exact-f32 matrix cores): the bounds of the eval-mode slices (tests/test_vae_gpu.py); measured on MI355X: X_hat 6.6e-5, u / v
+# 1.2e-7, gradient sums 1.4e-3, sampled elements 3.0e-3 (max) / 6e-4 (mean) -- the L1 sub-gradient sign(x_hat - x) flips for pixels
+# whose residual is below the forward difference, which perturbs every upstream gradient at the 1e-3 level.
+# bf16: the max and the mean over the sampled elements are bounded separately.  The yardstick is the REFERENCE ITSELF with its
+# convolutions in bf16 (scripts/ref_bf16_autocast.py: the reference's SpadeCondMotionModel, train mode, under
+# torch.autocast(bfloat16) against its own fp32 run, 64x64, T = 4): X_hat moves by 0.17 (max) / 9.7e-3 (mean) and, in the metrics
+# of grad_report, the gradients by 0.148 (worst sum / abs-sum), 0.33 (worst sampled element), 0.086 (mean sampled element) -- the
+# same tensors that are worst here (bias and norm-affine vectors of the encoder, the GRU gate biases: sums of the loss gradient over
+# all positions, where the sign flips of the L1 term do not average out), the same magnitudes (measured here, T = 16, 128x128:
+# 0.17 / 0.32 / 0.075).  A bf16 run cannot be closer to the fp32 reference than bf16 arithmetic lets the reference be to itself;
+# the bounds are 1.5x the reference's own deviation.  f32 mode is the tight check of the same code path.
 TOL = {"f32": dict(x_max=2e-4, x_mean=1e-5, loss=2e-4, mu=2e-4, sum=5e-3, smp_max=3e-2, smp_mean=5e-3, u=2e-5),
-       "bf16": dict(x_max=0.2, x_mean=1.5e-2, loss=5e-2, mu=6e-2, sum=0.1, smp_max=0.2, smp_mean=4e-2, u=2e-5)}
+       "bf16": dict(x_max=0.25, x_mean=1.5e-2, loss=5e-2, mu=6e-2, sum=0.25, smp_max=0.5, smp_mean=0.13, u=2e-5)}
 
 
 def train_model(dtype):
