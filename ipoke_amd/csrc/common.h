@@ -115,13 +115,16 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // ---- Adam with amsgrad (torch.optim.Adam semantics), one element; shared by every kernel that applies the update
 struct AdamHyper { float lr_bc1, beta1, beta2, eps, wd, bc2_sqrt, grad_scale; };     // lr_bc1 = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t)
+// Every product-sum is an explicit fmaf and contraction is off inside the function, so that each kernel that applies the update
+// (linear, per segment, tile-wise with the shadow writes) produces bit-identical parameters whatever the compiler would have fused.
 __device__ __forceinline__ void adam_amsgrad_update(float& p, float g, float& m, float& v, float& vx, const AdamHyper& h) {
-  const float gr = g * h.grad_scale + h.wd * p;
-  m = h.beta1 * m + (1.f - h.beta1) * gr;
-  v = h.beta2 * v + (1.f - h.beta2) * gr * gr;
+#pragma clang fp contract(off)
+  const float gr = fmaf(h.wd, p, g * h.grad_scale);
+  m = fmaf(h.beta1, m, (1.f - h.beta1) * gr);
+  v = fmaf(h.beta2, v, ((1.f - h.beta2) * gr) * gr);
   vx = fmaxf(vx, v);
   const float denom = sqrtf(vx) / h.bc2_sqrt + h.eps;
-  p -= h.lr_bc1 * (m / denom);
+  p = fmaf(-h.lr_bc1, m / denom, p);
 }
 __device__ __forceinline__ void adam_amsgrad_update4(f32x4& p, const f32x4& g, f32x4& m, f32x4& v, f32x4& vx, const AdamHyper& h) {
 #pragma unroll

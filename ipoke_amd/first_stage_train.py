@@ -26,6 +26,7 @@ evaluated frame by frame.
 from ctypes import byref
 
 import os
+import weakref
 
 import torch
 
@@ -67,20 +68,25 @@ def clear_operand_cache():
     _OPCACHE.clear()
 
 
-def _weight_operand(w, dtype, transposed_conv, inv_scale=None, cacheable=False, scope=None):
+def _weight_operand(w, dtype, transposed_conv, inv_scale=None, cacheable=False, scope=None, owner=None):
     """fp32 conv weight in PyTorch layout -> ([rows][taps*kc] operand of the compute dtype, kc); ``transposed_conv`` reads
     ConvTranspose storage [in][out][k] as the conv weight [out][in][k]; ``inv_scale``: device scalar (1/sigma).
     ``cacheable`` (module parameters without spectral norm: GRU, SPADE, VGG convolutions): the operand of a weight version is
-    built once and reused by the 15 per-frame calls of a step and by the backward pass."""
+    built once and reused by the 15 per-frame calls of a step and by the backward pass.  ``owner``: the tensor object the caller
+    holds (``w`` itself may be a fresh ``detach()`` view); an entry is only valid while THAT object is alive -- a key made of the
+    device address alone would hand a freed model's operand to whichever new tensor the allocator places there."""
     key = None
+    owner = w if owner is None else owner
     if cacheable and inv_scale is None:
-        key = (w.data_ptr(), w._version, tuple(w.shape), bool(transposed_conv), str(dtype), torch.cuda.current_stream().cuda_stream, scope)
+        key = (owner.data_ptr(), owner._version, tuple(w.shape), bool(transposed_conv), str(dtype), torch.cuda.current_stream().cuda_stream, scope)
         hit = _OPCACHE.get(key)
         if hit is not None:
-            return hit
+            if hit[0]() is owner:
+                return hit[1]
+            del _OPCACHE[key]                      # the address was recycled by another tensor
     res = _build_weight_operand(w, dtype, transposed_conv, inv_scale)
     if key is not None:
-        _OPCACHE[key] = res
+        _OPCACHE[key] = (weakref.ref(owner), res)
     return res
 
 
@@ -119,7 +125,7 @@ class _ConvFn(torch.autograd.Function):
         sn = meta.get("sn")                       # (sig, snap): w is weight_orig, the operand carries 1/sigma
         meta["w_param"] = (isinstance(w, torch.nn.Parameter) or meta.get("w_scope") is not None) and sn is None
         wop, kc = _weight_operand(w.detach(), dt, meta["transposed"], None if sn is None else sn[0][1:], cacheable=meta["w_param"],
-                                  scope=meta.get("w_scope"))
+                                  scope=meta.get("w_scope"), owner=w)
         b = None if bias is None else bias.detach().float().contiguous()
         src = meta.get("src")
         x = None if src is not None else K.CL(x_t, meta["N"], meta["dhw"], meta["cin"])
@@ -225,11 +231,11 @@ class _ConvFn(torch.autograd.Function):
             gcl = K.CL(g, N, odhw, cout)
             if not m["transposed"]:
                 # conv weight [cout, cin, k] read as a ConvTranspose weight [in=cout, out=cin, k]
-                wop, kc = _weight_operand(w.detach(), dt, True, inv, cacheable=m.get("w_param", False), scope=m.get("w_scope"))
+                wop, kc = _weight_operand(w.detach(), dt, True, inv, cacheable=m.get("w_param", False), scope=m.get("w_scope"), owner=w)
                 opad = tuple(i - ((o - 1) * s_ - 2 * p + kk) for i, o, s_, p, kk in zip(idhw, odhw, st, pd, k))
                 dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt, transposed=True, out_pad=opad)
             else:
-                wop, kc = _weight_operand(w.detach(), dt, False, inv, cacheable=m.get("w_param", False), scope=m.get("w_scope"))   # [in, out, k] read as conv weight [cout'=in]
+                wop, kc = _weight_operand(w.detach(), dt, False, inv, cacheable=m.get("w_param", False), scope=m.get("w_scope"), owner=w)   # [in, out, k] read as conv weight [cout'=in]
                 dx = K.conv(gcl, wop, kc, cin, k, st, pd, dt)
             assert dx.dhw == tuple(idhw), (dx.dhw, idhw)
             d_x = dx.t

@@ -14,8 +14,14 @@ import torch
 from . import _lib
 from ._lib import check, ptr
 
-# developer A/B: IPOKE_NO_ADAM_FUSION=1 -> linear Adam kernel + relayout of every tensor (round-2 path)
-_FUSE_SHADOWS = os.environ.get("IPOKE_NO_ADAM_FUSION", "0") != "1"
+# IPOKE_ADAM_FUSION=1: Adam-amsgrad fused with the shadow refresh of the plain 1x1 weights (ipoke_flow_adam_range).  Built, bit-identical
+# to the plain path (tests/test_flow_gpu.py) and measured on MI355X (round 3, c2): it saves 3.6 GB of HBM reads per step, but its
+# 64 x 64-tile access pattern streams at ~3.2 TB/s against the linear kernel's 5.7 TB/s -- optimizer + refresh of the whole buffer
+# 14.3 ms against 11.9 ms alone, 20.0 against 15.1 ms in twelve pieces on 128-workgroup grids, and the train step 65.7-66.9 ms
+# against 63.3-63.7 ms (scripts/probe_adam.py).  Off by default.
+_FUSE_DEFAULT = os.environ.get("IPOKE_ADAM_FUSION", "0") == "1"
+_FUSE_SHADOWS = _FUSE_DEFAULT
+_TILE_BLOCKS = int(os.environ.get("IPOKE_ADAM_TILE_BLOCKS", "128"))     # developer A/B: persistent grid of the fused tile kernel underneath backward
 
 
 class FusedAdamAmsgrad(torch.optim.Optimizer):
@@ -66,7 +72,7 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         flat, grads = self.flow.flat_params, self.flow.flat_grads
         if _FUSE_SHADOWS and not self.flow.engine.shadow_stale:
             self.flow.engine.adam_range(begin, end, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, g["lr"], g["betas"], g["eps"],
-                                        g["weight_decay"], self.steps, grad_scale, max_blocks=128)
+                                        g["weight_decay"], self.steps, grad_scale, max_blocks=_TILE_BLOCKS)
             self._covered += end - begin
             return
         sl = slice(begin, end)
