@@ -65,13 +65,16 @@ def randomise_couplings(model, seed=0):
     model.flow.mark_weights_updated()
 
 
+PMC_ROUND = "r03"          # the committed PMC passes roofline.traffic is read from (NOT measured by this run: see traffic_source)
+
+
 def pmc_traffic(kernel_substr, grid_size):
     """HBM-side bytes per launch from the committed in-situ PMC passes (separate rocprofv3 --pmc runs of this bench, summarised
     by scripts/pmc_summary.py): 2 x FETCH_SIZE (the gfx950 correction for 16-byte-per-lane streaming reads) + WRITE_SIZE, KB."""
     try:
         tot = 0.0
         for counter, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-            rows = json.load(open(os.path.join(ROOT, "profiles", f"r02_bench_pmc_{counter}.json")))
+            rows = json.load(open(os.path.join(ROOT, "profiles", f"{PMC_ROUND}_bench_pmc_{counter}.json")))
             hit = [r for r in rows if kernel_substr in r["kernel"] and r["grid_size"] == grid_size and r["counter"] == counter]
             if not hit:
                 return None
@@ -110,7 +113,8 @@ def kernel_roofline(B, dtype, iters=50):
     if M == 1280 and dtype == "bf16":
         traffic = pmc_traffic("igemm_nt_glds_kernel<bool _Accum, int, E, 4, 5, 2, 3, 1, true, 2>", str(256 * 512))
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch: 2 x FETCH_SIZE + WRITE_SIZE of this kernel's dispatches INSIDE the train step (rocprofv3 --pmc, profiles/r02_bench_pmc_*.json)",
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch: 2 x FETCH_SIZE + WRITE_SIZE of this kernel's dispatches INSIDE the train step",
+            "traffic_source": f"profiles/{PMC_ROUND}_bench_pmc_*.json: separate rocprofv3 --pmc passes of this command (not this run; PMC collection and timing cannot share a run)",
             "algorithmic_bytes_per_launch": int(2 * (M * hid + hid * hid + M * hid)),
             "kernel": "igemm_nt (NICE conv2 1x1, M=%d N=K=2048, %s)" % (M, dtype), "avg_launch_us": round(avg_s * 1e6, 2),
             "algorithmic_gflop_per_launch": round(flops / 1e9, 3)}
@@ -164,7 +168,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, clips=1, seed=1):
+def cpu_baseline(cfg, clips=2, seed=1, timed_steps=3):
     """The CPU oracle doing the same optimisation step on `clips` clips of the same workload (bounded sample)."""
     from oracle import flow_ref, vae_ref
     from ipoke_amd.utils.detfill import deterministic_fill_
@@ -209,11 +213,15 @@ def cpu_baseline(cfg, clips=1, seed=1):
         opt.step()
 
     t0 = time.time(); step(); t_warm = time.time() - t0            # warm-up (allocator, thread pools, first-touch of 15 GB)
-    t0 = time.time(); step(); dt = time.time() - t0
+    times = []
+    for _ in range(timed_steps):
+        t0 = time.time(); step(); times.append(time.time() - t0)
+    times.sort()
+    dt = times[len(times) // 2]
     return {"value": round(clips * T / dt, 4), "unit": "video-frames/sec", "cores": ncores, "kind": "port",
-            "sample": f"{clips} clip(s) of the same workload (16x3x{size}x{size}, z={z}), same coupling initialisation as the GPU leg: "
+            "sample": f"{clips} clip(s) per step of the same workload (16x3x{size}x{size}, z={z}), same coupling initialisation as the GPU leg: "
                       f"encoders + flow fwd + FlowLoss + bwd + Adam-amsgrad, oracle/ PyTorch fp32 CPU; 1 warm-up step ({t_warm:.1f}s), "
-                      f"1 timed step = {dt:.1f}s (model build {t_build:.0f}s untimed)"}
+                      f"median of {timed_steps} timed steps = {dt:.1f}s (min {times[0]:.1f}s, max {times[-1]:.1f}s; model build {t_build:.0f}s untimed)"}
 
 
 def cpu_baseline_subprocess(config, clips, timeout_s):
@@ -233,6 +241,28 @@ def cpu_baseline_subprocess(config, clips, timeout_s):
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "video-frames/sec", "cores": usable_cores(), "kind": "port",
                 "sample": f"cpu leg exceeded {timeout_s}s for {clips} clip(s); lower bound {clips * 16 / timeout_s:.4f} frames/s not reached"}
+
+
+def secondary_subprocess(config, steps, warmup, timeout_s=600):
+    """Time a secondary workload (c4: first-stage train step, c5: sampling) with this same script in a child process -- same timing
+    contract, fresh HIP context -- and return the fields of its JSON line that matter beside the headline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                d = json.loads(ln)
+                keep = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "algorithmic_tflop_per_step_per_gpu",
+                                          "step_mfma_frac", "hipgraph", "loss") if k in d}
+                keep["workload"] = d["config"]["workload"]
+                return keep
+        return {"error": (out.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"exceeded {timeout_s}s"}
 
 
 def secondary(args, cfg, rank, world, device):
@@ -326,19 +356,29 @@ def secondary(args, cfg, rank, world, device):
     torch.cuda.synchronize(); D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     graph = None
-    if args.config == "c5":        # the same K steps with the reverse flow replayed from a captured hipGraph (configs[4])
+    if args.config == "c5":
+        def timed_again():
+            for i in range(3):
+                step(i)
+            D.barrier(); torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for i in range(args.steps):
+                step(args.warmup + i)
+            torch.cuda.synchronize(); D.barrier()
+            return D.max_over_ranks(time.perf_counter() - tg, device)
+        # configs[4] "hipGraph-captured": (a) the reverse flow replayed from the engine's own captured graph, decoder eager;
+        # (b) the WHOLE device side of forward_sample (encoders + reverse flow + ConvGRU + batched decode) as one captured graph
         model.flow.set_graph_mode(True)
-        for i in range(3):
-            step(i)
-        D.barrier(); torch.cuda.synchronize()
-        tg = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        torch.cuda.synchronize(); D.barrier()
-        eg = D.max_over_ranks(time.perf_counter() - tg, device)
+        eg = timed_again()
         model.flow.set_graph_mode(False)
-        graph = {"ms_per_step": round(eg / args.steps * 1e3, 3), "value": round(frames / (eg / args.steps), 2),
-                 "what": "reverse flow replayed as a captured hipGraph, decoder eager"}
+        model.set_sample_graph(True)
+        ef = timed_again()
+        model.set_sample_graph(False)
+        graph = {"flow_graph_ms_per_step": round(eg / args.steps * 1e3, 3), "flow_graph_value": round(frames / (eg / args.steps), 2),
+                 "full_graph_ms_per_step": round(ef / args.steps * 1e3, 3), "full_graph_value": round(frames / (ef / args.steps), 2),
+                 "what": "same K steps; flow_graph: reverse flow replayed as a captured hipGraph, decoder eager; full_graph: conditioning "
+                         "encoders + reverse flow + ConvGRU + frame-batched decode replayed as ONE captured hipGraph (PokeMotionModel.set_sample_graph); "
+                         "the headline value of this line is the eager path"}
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {"metric": metric, "value": round(frames / (elapsed / args.steps), 2), "unit": "video-frames/sec", "n_gpus": world,
@@ -376,8 +416,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--fvd-dtype", default="f32", choices=["bf16", "f32"], help="arithmetic of --config fvd (the reference's I3D runs fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=1)
-    ap.add_argument("--cpu-timeout", type=int, default=420)
+    ap.add_argument("--cpu-clips", type=int, default=2, help="clips per CPU-baseline step (the per-step Adam / weight stream is amortised over them)")
+    ap.add_argument("--cpu-timeout", type=int, default=600)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c4 / c5 lines attached to the default c2 line")
+    ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -429,7 +471,7 @@ def main():
         roof = kernel_roofline(B, args.dtype)
         if insitu:                       # the dominant kernel as it runs INSIDE the step; the isolated figure is kept beside it
             iso = roof
-            roof = dict(insitu[0]); roof["traffic"] = iso["traffic"]; roof["traffic_unit"] = iso["traffic_unit"]
+            roof = dict(insitu[0]); roof["traffic"] = iso["traffic"]; roof["traffic_unit"] = iso["traffic_unit"]; roof["traffic_source"] = iso["traffic_source"]
             roof["algorithmic_bytes_per_launch"] = iso["algorithmic_bytes_per_launch"]
             roof["isolated_avg_launch_us"] = iso["avg_launch_us"]; roof["isolated_frac"] = iso["frac"]
         P_bytes = model.flow.engine.n_params * 4
@@ -451,6 +493,11 @@ def main():
         }
         if insitu:
             line["roofline_other_kernels"] = insitu[1:]
+        if not args.no_secondary and world == 1 and args.config == "c2":
+            # BASELINE configs[3] / configs[4], timed by the same driver invocation (their own lines: --config c4 / c5)
+            del model, trainer, batch
+            torch.cuda.empty_cache()
+            line["secondary"] = {c: secondary_subprocess(c, args.secondary_steps, 3) for c in ("c4", "c5")}
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_clips, args.cpu_timeout)
         print(json.dumps(line), flush=True)

@@ -211,6 +211,9 @@ typedef struct {
    * post_part[b] = [d_log_scale(C) | d_bias(C)] in the layout of ipoke_actnorm_bwd.  Requires C % 4 == 0, ld % 4 == 0. */
   const float* post_log_scale; const float* post_bias;
   const float* y_post; float* post_part;
+  /* ipoke_macow_unit_bwd only, optional: dtype [B*64][round_up(C, 32)] copy of this layer's input state (columns >= C zero) --
+   * the A operand of the shifted-conv weight gradient in the matrix cores' own dtype, so that gradient runs on the LDS-DMA GEMM */
+  void* x_op_save;
 } ipoke_mcf_desc;
 int ipoke_mcf_shadow_dims(int C, int Cc, int dtype, int32_t* dims8);
 int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream);

@@ -63,7 +63,8 @@ class McfDesc(Structure):
                 ("a2_save", c_void_p), ("scale_save", c_void_p), ("logdet_slot", c_void_p),
                 ("W2T", c_void_p), ("W1T", c_void_p), ("dy", c_void_p), ("dld", c_void_p), ("dx", c_void_p),
                 ("dparams_save", c_void_p), ("dc_save", c_void_p), ("dbias_part", c_void_p),
-                ("post_log_scale", c_void_p), ("post_bias", c_void_p), ("y_post", c_void_p), ("post_part", c_void_p)]
+                ("post_log_scale", c_void_p), ("post_bias", c_void_p), ("y_post", c_void_p), ("post_part", c_void_p),
+                ("x_op_save", c_void_p)]
 
 
 class NormDesc(Structure):

@@ -112,6 +112,9 @@ struct ipoke_flow {
   std::vector<int> red_first;          // first reduction-table entry of op i (size nops + 1)
   int last_fwd_B = 0; bool have_saved = false;
   int P = 64;
+  // every masked-conv layer is differentiated inside a fused MaCowUnit launch, which also writes the layer's input in the matrix
+  // cores' dtype: the shifted-conv weight gradients then read that copy through the LDS-DMA GEMM instead of the fp32 state
+  bool mcf_xop = false;
 };
 
 namespace {
@@ -379,6 +382,9 @@ int build(ipoke_flow& f) {
       i += 5;
     }
   }
+  static const bool noxop = getenv("IPOKE_NO_MCF_XOP") != nullptr;      // developer A/B
+  f.mcf_xop = c.dtype == IPOKE_BF16 && !noxop;
+  for (const Op& op : f.ops) if (op.type == OP_MCF && op.unit_of < 0) f.mcf_xop = false;
   return IPOKE_OK;
 }
 
@@ -441,6 +447,7 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
       op.ws_b = take(cur, M * op.C * 4);              // scale
       op.ws_c = take(cur, M * op.K3p * f.esz);        // dparams
       op.ws_d = take(cur, M * op.Hq * f.esz);         // dc
+      if (f.mcf_xop) op.ws_e = take(cur, M * op.Cp * f.esz);      // x in the compute dtype (written by the unit's backward kernel)
     } else if (op.type == OP_NICE) {
       op.ws_a = take(cur, M * hid * f.esz);           // h1
       op.ws_b = take(cur, M * hid * f.esz);           // h2
@@ -583,7 +590,8 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
     const long dbp = (long)(plan.dbias_part / 4) + (long)i * (B + 1) * 128;
     if (op.type == OP_MCF) {
       const McfGeom g = mcf_geom(op.order);
-      w1[op.mcf_idx] = {(long)(plan.state0 + (int64_t)i * plan.state_stride), (long)op.ws_d, (long)op.p_w1, g.kh, g.kw, -g.oy, -g.ox};
+      w1[op.mcf_idx] = {f->mcf_xop ? (long)op.ws_e : (long)(plan.state0 + (int64_t)i * plan.state_stride), (long)op.ws_d, (long)op.p_w1, g.kh,
+                        g.kw, -g.oy, -g.ox};
       w2[op.mcf_idx] = {(long)op.ws_a, (long)op.ws_c, (long)op.p_v, 1, 1, 0, 0};
       red.push_back({dbp, (long)op.p_b, 2 * op.C, 2 * op.C});
     } else if (op.type == OP_NICE) {
@@ -1221,7 +1229,11 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     if (r) return r;
     std::memset(&w, 0, sizeof(w));
     w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = 2; w.kw = 3; w.sd = w.sh = w.sw = 1;
-    w.a_f32 = 1; w.a_sn = 64L * c.ld; w.a_sh = 8L * c.ld; w.a_sw = c.ld; w.a_sc = 1; w.Kc_real = op.C; w.Kc = op.Cp;
+    if (f->mcf_xop) {   // dtype copy [M][Cp] of every layer input, zero padded: the LDS-DMA weight-gradient GEMM
+      w.a_f32 = 0; w.a_sn = 64L * op.Cp; w.a_sh = 8L * op.Cp; w.a_sw = op.Cp; w.a_sc = 1; w.Kc_real = op.Cp; w.Kc = op.Cp; w.Kc_store = op.C;
+    } else {
+      w.a_f32 = 1; w.a_sn = 64L * c.ld; w.a_sh = 8L * c.ld; w.a_sw = c.ld; w.a_sc = 1; w.Kc_real = op.C; w.Kc = op.Cp;
+    }
     w.ldy = op.Hq; w.Nout = op.H; w.w_sn = (int64_t)op.C * 6; w.w_sc = 6; w.w_st = 1;
     r = ipoke_conv_wgrad_batched(&w, reinterpret_cast<const unsigned char*>(f->d_w1tab) + (size_t)pend_lo * ipoke_wgrad_batch_entry_size(),
                                  nb, c.ws, c.ws, grads, c.dtype, wstream);
@@ -1367,6 +1379,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
           d4[k].x = l.state(j);
           d4[k].a2_save = l.rows(mk.ws_a, (int64_t)mk.K2p * f->esz); d4[k].scale_save = l.rowsf(mk.ws_b, mk.C);
           d4[k].dparams_save = l.rows(mk.ws_c, (int64_t)mk.K3p * f->esz); d4[k].dc_save = l.rows(mk.ws_d, (int64_t)mk.Hq * f->esz);
+          if (f->mcf_xop) d4[k].x_op_save = l.rows(mk.ws_e, (int64_t)mk.Cp * f->esz);
           d4[k].dbias_part = l.dbp(j, 2 * mk.C);
           if (mk.fuse_act >= 0) {
             const Op& an = f->ops[mk.fuse_act];

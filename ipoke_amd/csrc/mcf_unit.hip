@@ -24,6 +24,7 @@ struct UnitLayer {
   const float* x;                                           // bwd / inverse: saved input state of this layer
   const float* y_post; float* post_part;                    // bwd of the ActNorm: its saved output, [B][2C] partial sums
   void* dparams_save; void* dc_save; float* dbias_part;
+  void* x_op;                                               // bwd: dtype [B*64][Cp] copy of x for the shifted-conv weight gradient (NULL: none)
   int order;
 };
 struct UnitParams {
@@ -511,6 +512,11 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
           *reinterpret_cast<bf16x2*>(dp + p * dp_pitch + (C + c2) * (int)sizeof(T)) = ts;
           *reinterpret_cast<bf16x2*>(dps + (row0 + p) * U.K3p + c2) = tm;
           *reinterpret_cast<bf16x2*>(dps + (row0 + p) * U.K3p + C + c2) = ts;
+          if (Lk.x_op) {        // the layer input in the matrix cores' dtype: A operand of the shifted-conv weight gradient
+            bf16x2 xo;
+            xo[0] = ET<T>::from_f32(xv[i][0]); xo[1] = ET<T>::from_f32(xv[i][1]);
+            *reinterpret_cast<bf16x2*>(reinterpret_cast<T*>(Lk.x_op) + (row0 + p) * U.Cp + c2) = xo;
+          }
         }
       }
       *reinterpret_cast<f32x2*>(psum + r0 * N2 + c2) = sg;
@@ -526,6 +532,14 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_kernel(const UnitP
       for (int e = tid; e < 64 * padc; e += kMcfThreads) {
         const int p = e / padc, j = N2 + e - p * padc;
         dps[(row0 + p) * U.K3p + j] = (T)0.f;
+      }
+      if (Lk.x_op) {
+        T* xo = reinterpret_cast<T*>(Lk.x_op);
+        const int padx = U.Cp - C;
+        for (int e = tid; e < 64 * padx; e += kMcfThreads) {
+          const int p = e / padx, j = C + e - p * padx;
+          xo[(row0 + p) * U.Cp + j] = (T)0.f;
+        }
       }
     }
     UNIT_STAMP(2 + 6 * (3 - k));
@@ -893,7 +907,7 @@ static int unit_params(UnitParams& U, const ipoke_mcf_desc* d, int dtype, bool b
     L.W1 = s.W1; L.W2 = s.W2; L.bias2 = s.bias2; L.W1T = s.W1T; L.W2T = s.W2T; L.y = s.y; L.a2_save = s.a2_save;
     L.scale_save = s.scale_save; L.ld_slot = s.logdet_slot; L.post_ls = s.post_log_scale; L.post_bias = s.post_bias;
     L.x = s.x; L.y_post = s.y_post; L.post_part = s.post_part; L.dparams_save = s.dparams_save; L.dc_save = s.dc_save;
-    L.dbias_part = s.dbias_part; L.order = s.order;
+    L.dbias_part = s.dbias_part; L.order = s.order; L.x_op = bwd ? s.x_op_save : nullptr;
     if (!bwd) IPK_REQUIRE(s.W1 && s.W2 && s.bias2, "null forward operand");
     else {
       IPK_REQUIRE(s.W1T && s.W2T && s.x && s.a2_save && s.scale_save && s.dparams_save && s.dc_save, "null backward operand");

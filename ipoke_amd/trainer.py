@@ -16,10 +16,14 @@ class SecondStageTrainer:
     def __init__(self, model, n_grad_buckets=12, overlap=None):
         self.model = model
         tr, bs = model.config["training"], model.config["data"]["batch_size"]
-        if tr.get("min_acc_batch_size", 0) > bs:
-            # experiments/experiment.py:83-88 turns this into Lightning's accumulate_grad_batches; the engine writes (not
-            # accumulates) the flat gradient buffer on every backward pass
-            raise NotImplementedError("gradient accumulation (training.min_acc_batch_size > data.batch_size) is not implemented")
+        # experiments/experiment.py:81-88: accumulate_grad_batches = ceil(min_acc_batch_size / batch_size) when that is larger than the
+        # batch (1 for every shipped config: 3 < 20).  Lightning 1.1.7 divides each micro-batch loss by the count and steps the
+        # optimizer on every k-th batch; global_step counts optimizer steps.  The engine WRITES the flat gradient buffer on every
+        # backward pass, so the first k - 1 micro-batches are summed into a second flat buffer and the k-th pass adds it slice by slice
+        # right before the slice's exchange / update; the 1 / k is folded into the fused update's grad_scale.
+        mab = int(tr.get("min_acc_batch_size", 0) or 0)
+        self.accumulate_grad_batches = -(-mab // bs) if mab > bs else 1
+        self._acc, self._acc_count = None, 0
         self.opt = model.configure_optimizers()[0]
         self.world = D.world_size()
         self.n_grad_buckets = n_grad_buckets = int(os.environ.get("IPOKE_PIECES", n_grad_buckets))
@@ -54,13 +58,16 @@ class SecondStageTrainer:
         """grads[begin:end] is final at the current point of ``ready_stream``: all-reduce it there (data parallel) and
         apply the optimizer update to that slice, all without blocking the backward chain."""
         flat = self.model.flow.flat_grads
+        scale = 1.0 / (self.world * self.accumulate_grad_batches)
         with torch.cuda.stream(self.ready_stream):
+            if self._acc_count:                                  # gradients of the earlier micro-batches of this optimizer step
+                flat[begin:end].add_(self._acc[begin:end])
             if self.zero1:
-                self.opt.step_range_sharded(begin, end, grad_scale=1.0 / self.world)
+                self.opt.step_range_sharded(begin, end, grad_scale=scale)
                 return
             if self.world > 1:
                 D.allreduce_async(flat[begin:end]).wait()        # orders ready_stream after the collective, host does not block
-            self.opt.step_range(begin, end, grad_scale=1.0 / self.world)
+            self.opt.step_range(begin, end, grad_scale=scale)
 
     def sync_initial_state(self, batch):
         """Data-dependent ActNorm init happens on the first forward (macow2.py:503-505).  Under DDP the reference lets
@@ -114,6 +121,21 @@ class SecondStageTrainer:
         if prefetch:
             fwd_done = torch.cuda.Event()
             fwd_done.record()                 # the encoders of the next batch may start behind the forward pass ...
+        k = self.accumulate_grad_batches
+        if k > 1 and self._acc_count < k - 1:
+            # a micro-batch that does not end the optimizer step: plain backward, gradients summed aside
+            loss.backward()
+            if prefetch:
+                m.prefetch_flow_input(next_batch, self.prefetch_stream, after=fwd_done)
+            flat = m.flow.flat_grads
+            if self._acc is None:
+                self._acc = torch.empty_like(flat)
+            if self._acc_count == 0:
+                self._acc.copy_(flat)
+            else:
+                self._acc.add_(flat)
+            self._acc_count += 1
+            return loss
         if self.overlap:
             self.opt.begin_step()
             eng = m.flow.engine
@@ -129,8 +151,11 @@ class SecondStageTrainer:
             loss.backward()
             if prefetch:
                 m.prefetch_flow_input(next_batch, self.prefetch_stream, after=fwd_done)
+            if self._acc_count:
+                m.flow.flat_grads.add_(self._acc)
             if self.world > 1:
                 D.allreduce_flat_(m.flow.flat_grads, self.n_grad_buckets)
-            self._optimizer_step(lambda: self.opt.step(grad_scale=1.0 / self.world))
+            self._optimizer_step(lambda: self.opt.step(grad_scale=1.0 / (self.world * k)))
+        self._acc_count = 0
         m.global_step += 1
         return loss

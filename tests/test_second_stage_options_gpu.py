@@ -50,3 +50,51 @@ def test_augmented_input():
     l0 = tr.train_step(batch).item()
     vids = model.forward_sample(batch, n_samples=1, n_logged_vids=2)
     assert vids[0].shape == (2, 15, 3, 64, 64) and torch.isfinite(vids[0]).all() and l0 == l0
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_gradient_accumulation_matches_the_large_batch_step(overlap):
+    """training.min_acc_batch_size > data.batch_size (experiments/experiment.py:81-88 -> Lightning's accumulate_grad_batches = k):
+    k = 2 micro-batches of 2 clips, each loss divided by k, one optimizer step -- against the CPU oracle + torch.optim.Adam(amsgrad)
+    doing ONE step on the 4 clips at once (the mean loss of 4 = the mean of the two micro-batch means): parameters after the step,
+    and a second optimizer step to check that the accumulation buffer is reset."""
+    from ipoke_amd.trainer import SecondStageTrainer
+    arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+    arch["flow_mid_channels_factor"] = 2
+    conf = configs.second_stage_config(64, 32, 16, batch_size=2, arch=arch)
+    conf["training"]["min_acc_batch_size"] = 4
+    conf["training"]["lr_scaling"] = False                      # constant lr 1e-3 from the first step (the warm-up starts at 0)
+    model = PokeMotionModel(conf, dirs={}, dtype="f32", device=DEV, max_batch=2)
+    deterministic_fill_(model.flow, prefix="flow.")
+    model.flow.sync_buffers()
+    tr = SecondStageTrainer(model, n_grad_buckets=3, overlap=overlap)
+    assert tr.accumulate_grad_batches == 2
+    gen = torch.Generator().manual_seed(3)
+    inputs = [(torch.randn(2, 32, 8, 8, generator=gen), torch.randn(2, 128, 8, 8, generator=gen)) for _ in range(4)]
+    batches = [{"images": torch.zeros(2, 16, 3, 64, 64, device=DEV), "tag": i} for i in range(4)]
+    model.make_flow_input = lambda batch, **kw: tuple(x.to(DEV) for x in inputs[batch["tag"]])      # frozen encoders bypassed
+    # oracle: two optimizer steps on the concatenated micro-batches
+    o = flow_ref.SupervisedMacowTransformer(copy.deepcopy(model.config["architecture"]))
+    deterministic_fill_(o, prefix="flow.")
+    opt = torch.optim.Adam(o.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5, amsgrad=True)
+    loss_fn = flow_ref.FlowLoss()
+    ref_losses = []
+    for s in range(2):
+        x = torch.cat([inputs[2 * s][0], inputs[2 * s + 1][0]]); c = torch.cat([inputs[2 * s][1], inputs[2 * s + 1][1]])
+        opt.zero_grad()
+        out, ld = o(x, c)
+        loss, _ = loss_fn(out, ld)
+        loss.backward(); opt.step()
+        ref_losses.append(loss.item())
+    losses = [tr.train_step(batches[i], i).item() for i in range(4)]
+    torch.cuda.synchronize()
+    assert model.global_step == 2                                                      # optimizer steps, not batches
+    for s in range(2):
+        assert abs(0.5 * (losses[2 * s] + losses[2 * s + 1]) - ref_losses[s]) <= 2e-3 * max(1.0, abs(ref_losses[s]))
+    worst = 0.0
+    got = dict(model.flow.named_parameters())
+    for k, p in o.named_parameters():
+        d = (got[k].detach().cpu() - p.detach()).abs().max().item() / max(p.detach().abs().max().item(), 1e-3)
+        worst = max(worst, d)
+    print(f"gradient accumulation (overlap={overlap}): worst relative parameter deviation after 2 optimizer steps {worst:.2e}")
+    assert worst <= 5e-4
