@@ -1623,7 +1623,9 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
 // rows one LDS cycle touches fall into different bank groups.
 __device__ __forceinline__ int tn_swz(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
-template <int NSTAGE>
+// RM = reduction rows per ring slot: 64 (default, 2 slots) or 32 (4 slots in the same 64 KB: three in flight instead of one, but 40
+// instead of 20 barriers per flow-sized problem -- slower, see launch_tn).
+template <int NSTAGE, int RM>
 __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) {
   typedef bf16_t T;
   TnParams p = pin;
@@ -1636,10 +1638,11 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
   typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tr4_t;
-  constexpr int RM = 64;                        // reduction rows per stage
+  static_assert(RM == 64 || RM == 32, "stage height");
+  constexpr int NI = RM / 32;                   // DMA instructions per thread, operand and stage
   constexpr int TILE = RM * 256;                // one operand image: 64 rows x 128 columns of bf16
   constexpr int STAGE = 2 * TILE;
-  constexpr int L = 4;                          // DMA instructions per thread and stage (2 per operand)
+  constexpr int L = 2 * NI;                     // DMA instructions per thread and stage
   static_assert((NSTAGE - 2) * L <= 63, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* taptab = reinterpret_cast<int*>(smem + NSTAGE * STAGE);
@@ -1699,19 +1702,23 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     unsigned char* sy = smem + slot * STAGE;
     unsigned char* sx = sy + TILE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int m = mb * RM + rl0 + 32 * i;
       const T* src = zero;
       if (real && y_ok && m < g.M) src = dY + (long)m * p.ldy + p.y_coff + ncol;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sy + (wave + 8 * i) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int m = mb * RM + rl0 + 32 * i;
       const T* src = zero;
       if (real && x_ok && m < g.M) {
         if (p.rows_fixed) {
-          if (x_fix[i] != kBad) src = A + (long)(mb * (RM / S)) * p.a_sn + x_fix[i];
+          // rows_fixed: S = 64 (the 8x8 latent).  RM = 64: a stage is one sample, x_fix[i] its rows rl0 + 32 i;
+          // RM = 32: stage mb is half (mb & 1) of sample mb >> 1
+          const int half = RM == 64 ? i : (mb & 1);
+          const long smp = RM == 64 ? (long)mb : (long)(mb >> 1);
+          if (x_fix[half] != kBad) src = A + smp * p.a_sn + x_fix[half];
         } else {
           const RowPos r = decode_row(g, m, p.a_sn);
           int id, ih, iw;
@@ -1763,7 +1770,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     const unsigned char* base = smem + slot * STAGE;
     slot = (slot + 1) % NSTAGE;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < NI; ++ks) {
       frag_t fy[4], fx[2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) fy[i] = tr_frag(base, y_rd[i] + ks * 32 * 256);
@@ -1828,12 +1835,23 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
                : ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.dY)) & 15) == 0)) {
     // ring depth: 2 slots (64 KB of LDS) let a weight-gradient workgroup share a CU with a chain GEMM workgroup (89 KB): the
     // same 29 us alone, 39 instead of 55 us inside the train step
-    static const int nst = getenv("IPOKE_TN_STAGES") ? atoi(getenv("IPOKE_TN_STAGES")) : 2;      // developer A/B: ring depth 2 / 3 / 4
-    const int NST = nst == 2 || nst == 3 ? nst : 4;
-    const size_t lds2 = (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
-    auto kern = NST == 2 ? igemm_tn_glds_kernel<2> : NST == 3 ? igemm_tn_glds_kernel<3> : igemm_tn_glds_kernel<4>;
-    static bool attr_done2 = false;
-    if (!attr_done2) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2 = true; }
+    // IPOKE_TN_STAGES (developer A/B): 2 (default) / 3 = 64-row stages, that many slots; 4 = four slots of 32 rows (measured, round 3:
+    // conv2 35.5 us against 29.7 us alone, 63.3 against 62.0 ms per step -- twice the barriers cost more than the deeper ring hides)
+    static const int nst = getenv("IPOKE_TN_STAGES") ? atoi(getenv("IPOKE_TN_STAGES")) : 2;
+    const bool r32 = nst != 2 && nst != 3 && p.g.S == 64;           // half-sample stages need the 8x8 latent's fixed row pattern
+    const int NST = r32 ? 4 : (nst == 3 ? 3 : 2);
+    const int RMv = r32 ? 32 : 64;
+    const size_t lds2 = (size_t)NST * 2 * RMv * 256 + 256 * sizeof(int);
+    auto kern = r32 ? igemm_tn_glds_kernel<4, 32> : NST == 2 ? igemm_tn_glds_kernel<2, 64> : igemm_tn_glds_kernel<3, 64>;
+    static bool attr_done2[3] = {false, false, false};
+    const int ai = r32 ? 0 : NST - 1;
+    if (!attr_done2[ai]) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2[ai] = true; }
+    if (r32) {                                                       // reduction blocks of 32 rows
+      const int nmb32 = ceil_div(p.g.M, 32);
+      if (p.splitm > nmb32) p.splitm = nmb32;
+      p.mb_per_split = ceil_div(nmb32, p.splitm);
+      p.rows_fixed = 1;
+    }
     const int ntiles = p.tiles_n * p.tiles_k;
     const int cap = p.max_wgs > 0 ? p.max_wgs : ntiles;
     p.xa = p.xb = 0;

@@ -113,25 +113,32 @@ __device__ __forceinline__ void relayout_tile(const RelayoutJob& j, const float*
 template <typename T>
 __global__ __launch_bounds__(256) void relayout_kernel(const float* __restrict__ params, T* __restrict__ shadow,
                                                        const float* __restrict__ wn_scale, const RelayoutJob* __restrict__ jobs,
-                                                       int njobs, const int* __restrict__ block_job, int block_base) {
+                                                       int njobs, const int* __restrict__ block_job, int block_base, int nblocks) {
   __shared__ __attribute__((aligned(16))) float tile[32 * 33 * 9];   // [n_l][tap][k_l], k pitch TE+1 (>= 64*65)
-  const int bid = (int)blockIdx.x + block_base;          // global block id (a launch may cover a sub-range of the jobs)
-  int lo = 0;
-  if (block_job) {
-    lo = block_job[bid];
-  } else {                     // locate the job of this block (block_start is ascending)
-    int hi = njobs - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (jobs[mid].block_start <= bid) lo = mid; else hi = mid - 1;
+  // Grid-stride over the tiles [block_base, block_base + nblocks) so that the grid can be capped (IPOKE_RELAYOUT_BLOCKS).  Measured,
+  // round 3: the refresh of a slice is the worst neighbour a chain kernel can have -- a conv2 GEMM that overlaps it takes 72-170 us
+  // instead of 24, a fused MaCowUnit backward 193 instead of 59 (profiles/r03_overlap_before.txt: one workgroup per tile, four per CU
+  // by LDS, keeps every CU full for the ~300 us of a slice) -- and yet capping it LOSES: 62.3 ms per step uncapped against 62.8 / 63.7 /
+  // 65.3 / 65.0 / 76.9 at 1024 / 512 / 256 / 128 / 64 workgroups.  Short and brutal beats long and mild; the default stays uncapped.
+  for (int bid = (int)blockIdx.x + block_base; bid < block_base + nblocks; bid += (int)gridDim.x) {
+    int lo = 0;
+    if (block_job) {
+      lo = block_job[bid];
+    } else {                     // locate the job of this block (block_start is ascending)
+      int hi = njobs - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block_start <= bid) lo = mid; else hi = mid - 1;
+      }
     }
+    const RelayoutJob j = jobs[lo];
+    const int t_id = bid - j.block_start;
+    const int n0 = (t_id / j.tiles_k) * j.tile, k0 = (t_id % j.tiles_k) * j.tile;
+    if (j.taps == 1) relayout_tile<T, 1, 64>(j, params, shadow, wn_scale, n0, k0, tile);
+    else if (j.taps == 9) relayout_tile<T, 9, 32>(j, params, shadow, wn_scale, n0, k0, tile);
+    else relayout_tile<T, 6, 32>(j, params, shadow, wn_scale, n0, k0, tile);
+    __syncthreads();             // the tile is reused by the next iteration
   }
-  const RelayoutJob j = jobs[lo];
-  const int t_id = bid - j.block_start;
-  const int n0 = (t_id / j.tiles_k) * j.tile, k0 = (t_id % j.tiles_k) * j.tile;
-  if (j.taps == 1) relayout_tile<T, 1, 64>(j, params, shadow, wn_scale, n0, k0, tile);
-  else if (j.taps == 9) relayout_tile<T, 9, 32>(j, params, shadow, wn_scale, n0, k0, tile);
-  else relayout_tile<T, 6, 32>(j, params, shadow, wn_scale, n0, k0, tile);
 }
 
 // weight-norm rows: scale[n] = g[n] / ||v[n]||, inv_norm[n] = 1/||v[n]||.  One wave per row.
@@ -393,12 +400,16 @@ extern "C" int ipoke_relayout_multi_range(const float* params, void* shadow, con
   IPK_REQUIRE(params && shadow && jobs_dev && njobs > 0 && nblocks >= 0 && block_begin >= 0, "bad arguments");
   if (nblocks == 0) return IPOKE_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // optional grid cap (developer A/B, see relayout_kernel); one workgroup per tile otherwise
+  static const int cap_env = getenv("IPOKE_RELAYOUT_BLOCKS") ? atoi(getenv("IPOKE_RELAYOUT_BLOCKS")) : 0;
+  const int cap = block_begin == 0 && nblocks > 100000 ? 65536 : (cap_env > 0 ? cap_env : nblocks);
+  const int grid = nblocks < cap ? nblocks : cap;
   if (dtype == IPOKE_BF16)
-    hipLaunchKernelGGL(relayout_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, s, params, (bf16_t*)shadow, wn_scale,
-                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev, block_begin);
+    hipLaunchKernelGGL(relayout_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, params, (bf16_t*)shadow, wn_scale,
+                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev, block_begin, nblocks);
   else
-    hipLaunchKernelGGL(relayout_kernel<float>, dim3(nblocks), dim3(256), 0, s, params, (float*)shadow, wn_scale,
-                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev, block_begin);
+    hipLaunchKernelGGL(relayout_kernel<float>, dim3(grid), dim3(256), 0, s, params, (float*)shadow, wn_scale,
+                       (const RelayoutJob*)jobs_dev, njobs, block_job_dev, block_begin, nblocks);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
