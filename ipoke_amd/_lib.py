@@ -9,7 +9,7 @@ import os
 from ctypes import CFUNCTYPE, POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libipoke_hip.so")
+LIB_PATH = os.environ.get("IPOKE_LIB_PATH") or os.path.join(_HERE, "libipoke_hip.so")     # IPOKE_LIB_PATH: developer A/B of two builds in one GPU call
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_ELU, ACT_RELU, ACT_LRELU02, ACT_TANH, ACT_SIGMOID = range(6)
