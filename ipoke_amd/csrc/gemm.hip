@@ -1581,6 +1581,8 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
     }
     if (glds_mode == 16) return launch_nt_glds<T, 1, 8, 5, 1, 3, 1>(p, s);         // developer A/B: 80 x 128, 8 waves of 80 x 16, 3 slots
     if (glds_mode == 17) return launch_nt_glds<T, 1, 4, 5, 2, 2, 2, 2>(p, s);      // developer A/B: 2 K-halves x 4 waves of 80 x 32, 2 slots x 2
+    if (glds_mode == 18 && M % 80 == 0) return launch_nt_glds<T, 1, 4, 5, 2, 4, 1, 2>(p, s);      // developer A/B: the default 80 x 128 tile with 4 ring slots
+    if (glds_mode == 19 && M % 80 == 0) return launch_nt_glds<T, 1, 4, 5, 2, 5, 1, 2>(p, s);      // ... 5 slots
     {
       // Row-tile height: the flow's GEMMs have M = 64*B rows (1280 at B = 20) and N = 2048, i.e. 160 tiles of 128 x 128 on
       // 256 CUs.  80- or 160-row tiles give exactly 256 workgroups at B = 20 / 40; pick the height with the least
