@@ -167,6 +167,15 @@ int ipoke_affine_inv_ext(const ipoke_affine_desc* d, const float* in, float* out
 int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, const float* dy, const float* x,
                      const float* scale, const float* dld, float* dx, void* dparams /* dtype [M][ldp] */, int ldp,
                      float* dbias_part /* [B][2Cp] or NULL */, int B, int dtype, void* stream);
+/* A coupling followed by an ActNorm2dFlow (+ Shuffle) -- MaCowStep's coupling1_dn -> actnorm2, coupling2_dn -> the next step's actnorm1,
+ * MultiScalePrior's coupling -> actnorm (macow2.py:1066-1117, 569-593) -- as ONE launch per direction.  Forward: ipoke_affine_fwd followed by
+ * ipoke_actnorm_fwd on its output; `out` (the coupling's output, the ActNorm's saved input; NULL when nothing is saved) and `out2` are both
+ * written.  Backward: ipoke_actnorm_bwd (dy2, x1 = out, part) followed by ipoke_affine_bwd on the gradient it passes on. */
+int ipoke_affine_actnorm_fwd(const ipoke_affine_desc* d, const float* in, float* out, float* out2, float* scale_out, float* logdet_slot,
+                             int slot_stride, int B, int c0, int C, const float* log_scale, const float* bias, const int32_t* idx, void* stream);
+int ipoke_actnorm_affine_bwd(int c0, int C, const float* log_scale, const int32_t* idx, const float* dy2, const float* x1, float* part,
+                             int Cp, int t_off, int t_stride, int P, int ld, const float* x0, const float* scale, const float* dld, float* dx,
+                             void* dparams, int ldp, float* dbias_part, int B, int dtype, void* stream);
 int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream);
 /* multi-tensor form: entries_dev[i] = {int64 src, int64 dst (float offsets), int32 ld, int32 ncols}; R rows each */
 int ipoke_reduce_entry_size(void);

@@ -115,6 +115,9 @@ SIGNATURES = {
     "ipoke_affine_fwd_ext": (c_int, [POINTER(AffineDesc), _P, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "ipoke_affine_inv_ext": (c_int, [POINTER(AffineDesc), _P, _P, c_int, _P, c_int, c_int, _P]),
     "ipoke_affine_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P]),
+    "ipoke_affine_actnorm_fwd": (c_int, [POINTER(AffineDesc), _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "ipoke_actnorm_affine_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P,
+                                         c_int, c_int, _P]),
     "ipoke_reduce_rows": (c_int, [_P, _P, c_int, c_int, _P]),
     "ipoke_logdet_finalize": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "ipoke_actnorm_logdet": (c_int, [_P, _P, c_int, c_int, _P, _P]),

@@ -379,6 +379,191 @@ __global__ __launch_bounds__(1024) void affine_bwd_kernel(int Cp, int t_off, int
     dbias_part[(long)b * 2 * Cp + tid] = t;
   }
 }
+// ------------------------------------------------------------------ affine coupling + the ActNorm (+ Shuffle) that follows it
+// MaCowStep / MultiScalePrior put an ActNorm2dFlow (optionally with a channel shuffle) right behind a coupling (macow2.py:1066-1117,
+// 569-593).  Both are row-wise maps of the [M][ld] state; as two launches they cost two dependent kernel boundaries and two round trips
+// through memory for 330 KB of state.  Fused: the block keeps its rows of the coupling's output in LDS (the shuffle needs whole rows)
+// and writes BOTH states -- `out` (the coupling's output = the ActNorm's saved input, may be NULL when nothing is saved) and `out2`.
+struct ActNormArgs { int c0, C; const float* ls; const float* bias; const int* idx; };
+__global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const float* __restrict__ in, float* __restrict__ out,
+                                          float* __restrict__ out2, float* __restrict__ scale_out, float* __restrict__ logdet_slot,
+                                          int slot_stride, int Q) {
+  if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
+  extern __shared__ float raw_s[];                 // [rows][2Cp] raw (mu, s), then [rows][ld] the coupling's output rows
+  __shared__ float red[8];
+  const int b = blockIdx.x / Q, q = blockIdx.x % Q;
+  const int rows = a.P / Q;
+  const long row0 = (long)b * a.P + (long)q * rows;
+  float* tile = raw_s + rows * 2 * a.Cp;
+  {   // untouched channels -> tile (and `out`)
+    const int total = rows * a.ld;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4 * blockDim.x) {
+      float v[4]; bool w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * blockDim.x;
+        const int col = i % a.ld;
+        const int rel = col - a.t_off;
+        const bool transformed = rel >= 0 && rel % a.t_stride == 0 && rel / a.t_stride < a.Cp;
+        w[u] = i < total && !transformed;
+        if (w[u]) v[u] = in[row0 * a.ld + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (w[u]) { tile[i0 + u * blockDim.x] = v[u]; if (out) out[row0 * a.ld + i0 + u * blockDim.x] = v[u]; }
+    }
+  }
+  affine_stage_raw(a, row0, rows, raw_s);
+  float ld_acc = 0.f;
+  for (int e = threadIdx.x; e < rows * a.Cp; e += blockDim.x) {
+    const int p = e / a.Cp, i = e - p * a.Cp;
+    const float mu = raw_s[p * 2 * a.Cp + i];
+    const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
+    const int col = a.t_off + i * a.t_stride;
+    const long off = (row0 + p) * a.ld + col;
+    const float y = sc * in[off] + mu;
+    tile[p * a.ld + col] = y;
+    if (out) out[off] = y;
+    if (scale_out) scale_out[(row0 + p) * a.Cp + i] = sc;
+    ld_acc += logf(sc);
+  }
+  const float tot = block_sum(ld_acc, red);          // (its barriers also publish the tile)
+  if (threadIdx.x == 0 && logdet_slot) logdet_slot[(long)b * slot_stride + q] = tot;
+  for (int e = threadIdx.x; e < rows * a.ld; e += blockDim.x) {
+    const int p = e / a.ld, col = e - p * a.ld;
+    const int j = col - n.c0;
+    float v;
+    if (j >= 0 && j < n.C) {
+      const int src = n.idx ? n.idx[j] : j;
+      v = tile[p * a.ld + n.c0 + src];
+      if (n.ls) v = v * expf(n.ls[src]) + n.bias[src];
+    } else {
+      v = tile[e];
+    }
+    out2[(row0 + p) * a.ld + col] = v;
+  }
+}
+
+// backward of that pair in one launch: dy2 = gradient w.r.t. the ActNorm's output, x1 = its saved input (the coupling's output), x0 = the
+// coupling's saved input.  Phase A is actnorm_bwd_kernel with the gradient it passes on kept in LDS ([P][ld]), phase B affine_bwd_kernel
+// reading it from there.  part: [B][2 C] ActNorm partials (NULL without parameters), dbias_part: [B][2 Cp] coupling-bias partials.
+template <typename T>
+__global__ __launch_bounds__(1024) void actnorm_affine_bwd_kernel(ActNormArgs n, int Cp, int t_off, int t_stride, int P, int ld,
+                                                                  const float* __restrict__ dy2, const float* __restrict__ x1,
+                                                                  const float* __restrict__ x0, const float* __restrict__ scale,
+                                                                  const float* __restrict__ dld, float* __restrict__ dx,
+                                                                  T* __restrict__ dparams, int ldp, float* __restrict__ part,
+                                                                  float* __restrict__ dbias_part) {
+  if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
+  extern __shared__ float sm[];                    // [P][ld] gradient w.r.t. the coupling's output, then the partial-sum area
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const long row0 = (long)b * P;
+  float* g1 = sm;
+  float* ps = sm + P * ld;                         // max(2 * rows_par_n * C, rows_par_a * 2 * Cp) floats
+  const float g_ld = dld[b];
+  // ---- phase A: ActNorm (+ shuffle) backward into the LDS tile
+  {
+    const int C = n.C, c0 = n.c0;
+    const int rows_par = blockDim.x / C;
+    const int j = tid % C, r0 = tid / C;
+    float a_ls = 0.f, a_b = 0.f;
+    if (r0 < rows_par) {
+      const int src = n.idx ? n.idx[j] : j;
+      const float e = n.ls ? expf(n.ls[src]) : 1.f;
+      for (int m0 = r0; m0 < P; m0 += 4 * rows_par) {
+        float g[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u * rows_par;
+          g[u] = 0.f; xv[u] = 0.f;
+          if (m < P) {
+            g[u] = dy2[(row0 + m) * ld + c0 + j];
+            if (n.ls) xv[u] = x1[(row0 + m) * ld + c0 + src];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u * rows_par;
+          if (m < P) {
+            g1[m * ld + c0 + src] = g[u] * e;
+            a_ls += g[u] * xv[u] * e;
+            a_b += g[u];
+          }
+        }
+      }
+    }
+    if (C < ld) {        // columns outside the ActNorm window pass through
+      const int rest = ld - C;
+      for (int e = tid; e < P * rest; e += blockDim.x) {
+        const int m = e / rest, k = e - m * rest;
+        const int col = k < c0 ? k : k + C;
+        g1[m * ld + col] = dy2[(row0 + m) * ld + col];
+      }
+    }
+    if (n.ls && r0 < rows_par) { ps[r0 * C + j] = a_ls; ps[(rows_par + r0) * C + j] = a_b; }
+    __syncthreads();
+    if (n.ls && tid < C) {
+      const int s_ = n.idx ? n.idx[tid] : tid;     // thread tid accumulated channel s_
+      float t_ls = 0.f, t_b = 0.f;
+      for (int r = 0; r < rows_par; ++r) { t_ls += ps[r * C + tid]; t_b += ps[(rows_par + r) * C + tid]; }
+      part[(long)b * 2 * C + s_] = t_ls + (float)P * g_ld;
+      part[(long)b * 2 * C + C + s_] = t_b;
+    }
+    __syncthreads();                                // ps is reused below
+  }
+  // ---- phase B: the coupling's backward, its incoming gradient read from the tile
+  const int rows_par = blockDim.x / Cp;
+  const int i = tid % Cp, r0 = tid / Cp;
+  float a_mu = 0.f, a_s = 0.f;
+  const bool act = r0 < rows_par;
+  for (int m0 = r0; act && m0 < P; m0 += 4 * rows_par) {
+    float g[4], sc[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + u * rows_par;
+      g[u] = 0.f; sc[u] = 1.f; xv[u] = 0.f;
+      if (m < P) {
+        const int col = t_off + i * t_stride;
+        g[u] = g1[m * ld + col]; xv[u] = x0[(row0 + m) * ld + col];
+        sc[u] = scale[(row0 + m) * Cp + i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + u * rows_par;
+      if (m < P) {
+        const float t = sc[u] - 1.f;
+        const float ds = (g[u] * xv[u] + g_ld / sc[u]) * 0.5f * (1.f - t * t);
+        dx[(row0 + m) * ld + t_off + (long)i * t_stride] = g[u] * sc[u];
+        dparams[(row0 + m) * ldp + i] = ET<T>::from_f32(g[u]);
+        dparams[(row0 + m) * ldp + Cp + i] = ET<T>::from_f32(ds);
+        a_mu += g[u]; a_s += ds;
+      }
+    }
+  }
+  if (act) { ps[r0 * 2 * Cp + i] = a_mu; ps[r0 * 2 * Cp + Cp + i] = a_s; }
+  for (int e = tid; e < P * ld; e += blockDim.x) {      // untouched channels
+    const int col = e % ld;
+    const int rel = col - t_off;
+    const bool transformed = rel >= 0 && rel % t_stride == 0 && rel / t_stride < Cp;
+    if (!transformed) dx[row0 * ld + e] = g1[e];
+  }
+  {
+    const int pad = ldp - 2 * Cp;
+    for (int e = tid; e < P * pad; e += blockDim.x) {
+      const int p = e / pad, j = 2 * Cp + (e - p * pad);
+      dparams[(row0 + p) * ldp + j] = ET<T>::from_f32(0.f);
+    }
+  }
+  __syncthreads();
+  if (dbias_part && tid < 2 * Cp) {
+    const int used = rows_par < P ? rows_par : P;
+    float t = 0.f;
+    for (int r = 0; r < used; ++r) t += ps[r * 2 * Cp + tid];
+    dbias_part[(long)b * 2 * Cp + tid] = t;
+  }
+}
+
 // dst[c] = sum_r src[r][c]
 __global__ void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int ncols) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) {
@@ -606,6 +791,39 @@ extern "C" int ipoke_affine_bwd(int Cp, int t_off, int t_stride, int P, int ld, 
   else
     hipLaunchKernelGGL(affine_bwd_kernel<float>, dim3(B), dim3(1024), sm, STREAM(stream), Cp, t_off, t_stride, P, ld, dy, x,
                        scale, dld, dx, (float*)dparams, ldp, dbias_part);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_affine_actnorm_fwd(const ipoke_affine_desc* d, const float* in, float* out, float* out2, float* scale_out,
+                                        float* logdet_slot, int slot_stride, int B, int c0, int C, const float* log_scale, const float* bias,
+                                        const int32_t* idx, void* stream) {
+  int rc = check_affine(d); if (rc) return rc;
+  IPK_REQUIRE(in && out2 && in != out2 && C >= 1 && c0 >= 0 && c0 + C <= d->ld, "bad arguments");
+  IPK_REQUIRE((log_scale == nullptr) == (bias == nullptr), "log_scale and bias come together");
+  const int Q = (slot_stride >= 4 || !logdet_slot) && d->P % 4 == 0 ? 4 : 1;
+  const ActNormArgs n{c0, C, log_scale, bias, idx};
+  const size_t lds = (size_t)(d->P / Q) * (2 * d->Cp + d->ld) * sizeof(float);
+  hipLaunchKernelGGL(affine_actnorm_fwd_kernel, dim3(B * Q), dim3(256), lds, STREAM(stream), to_args(d), n, in, out, out2, scale_out,
+                     logdet_slot, slot_stride < 1 ? 1 : slot_stride, Q);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_actnorm_affine_bwd(int c0, int C, const float* log_scale, const int32_t* idx, const float* dy2, const float* x1,
+                                        float* part, int Cp, int t_off, int t_stride, int P, int ld, const float* x0, const float* scale,
+                                        const float* dld, float* dx, void* dparams, int ldp, float* dbias_part, int B, int dtype,
+                                        void* stream) {
+  IPK_REQUIRE(dy2 && x0 && scale && dld && dx && dparams && ldp >= 2 * Cp && Cp >= 1 && 2 * Cp <= 1024, "bad arguments");
+  IPK_REQUIRE(C >= 1 && C <= 256 && c0 >= 0 && c0 + C <= ld && P * ld <= 8192, "bad ActNorm window / state tile");
+  IPK_REQUIRE(!log_scale || (x1 && part), "parameter gradients need the saved input and the partial-sum buffer");
+  const ActNormArgs n{c0, C, log_scale, nullptr, idx};
+  const size_t psn = (size_t)2 * (1024 / C) * C, psa = (size_t)(1024 / Cp) * 2 * Cp;
+  const size_t lds = ((size_t)P * ld + (psn > psa ? psn : psa)) * sizeof(float);
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(actnorm_affine_bwd_kernel<bf16_t>, dim3(B), dim3(1024), lds, STREAM(stream), n, Cp, t_off, t_stride, P, ld, dy2, x1,
+                       x0, scale, dld, dx, (bf16_t*)dparams, ldp, part, dbias_part);
+  else
+    hipLaunchKernelGGL(actnorm_affine_bwd_kernel<float>, dim3(B), dim3(1024), lds, STREAM(stream), n, Cp, t_off, t_stride, P, ld, dy2, x1,
+                       x0, scale, dld, dx, (float*)dparams, ldp, part, dbias_part);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

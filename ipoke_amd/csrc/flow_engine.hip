@@ -54,6 +54,8 @@ struct Op {
   bool unit_head = false;                      // MCF: first of the six ops of a MaCowUnit that one fused launch executes
   int unit_of = -1;                            // index of the unit's first op for every op inside such a unit
   int lu_idx = -1;                             // OP_LU: index into the LU job table
+  int an_next = -1;                            // NICE: index of the stand-alone ActNorm (+ Shuffle) right behind it, run in the same launches
+  int an_prev = -1;                            // ActNorm: index of the coupling whose launches execute it
 };
 
 struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
@@ -381,6 +383,12 @@ int build(ipoke_flow& f) {
       for (int k = 0; k < 6; ++k) f.ops[i + k].unit_of = (int)i;
       i += 5;
     }
+  }
+  // coupling -> ActNorm (+ Shuffle) pairs: one launch per direction (ipoke_affine_actnorm_fwd / ipoke_actnorm_affine_bwd)
+  static const bool noan = getenv("IPOKE_NO_AN_FUSION") != nullptr;     // developer A/B
+  for (size_t i = 0; !noan && i + 1 < f.ops.size(); ++i) {
+    Op& a = f.ops[i]; Op& b2 = f.ops[i + 1];
+    if (a.type == OP_NICE && b2.type == OP_ACTNORM && !b2.fused && b2.unit_of < 0 && b2.Cn <= 256) { a.an_next = (int)i + 1; b2.an_prev = (int)i; }
   }
   static const bool noxop = getenv("IPOKE_NO_MCF_XOP") != nullptr;      // developer A/B
   f.mcf_xop = c.dtype == IPOKE_BF16 && !noxop;
@@ -1022,7 +1030,8 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
     }
     if (!init && op.fused) continue;               // done by the preceding MCF launch, which wrote this op's output state
     const bool fuse = !init && op.type == OP_MCF && op.fuse_act >= 0;
-    const int nxt = save ? (int)i + (fuse ? 2 : 1) : (cur ^ 1);
+    const bool with_an = !init && op.type == OP_NICE && op.an_next >= 0;       // the ActNorm behind this coupling runs in its affine launch
+    const int nxt = save ? (int)i + (fuse || with_an ? 2 : 1) : (cur ^ 1);
     for (const Ctx& l : lanes) {
       const float* in = l.state(cur); float* out = l.state(nxt);
       if (op.type == OP_LU) {
@@ -1058,12 +1067,21 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
           ext = save ? l.rows(nx.ws_g, (int64_t)nx.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
           ext_ld = nx.Kc1;
         }
-        rc = ipoke_affine_fwd_ext(&a, in, out, save ? l.rowsf(op.ws_c, op.cout) : nullptr, l.slot(op.slot), 4, l.B, ext, ext_ld, l.dtype,
-                                  l.stream());
+        if (with_an) {
+          const Op& an = f->ops[op.an_next];
+          rc = ipoke_affine_actnorm_fwd(&a, in, save ? l.state((int)i + 1) : nullptr, out, save ? l.rowsf(op.ws_c, op.cout) : nullptr,
+                                        l.slot(op.slot), 4, l.B, an.c0, an.Cn, an.p_ls >= 0 ? params + an.p_ls : nullptr,
+                                        an.p_bias >= 0 ? params + an.p_bias : nullptr, an.idx_fwd >= 0 ? perm + an.idx_fwd : nullptr,
+                                        l.stream());
+        } else {
+          rc = ipoke_affine_fwd_ext(&a, in, out, save ? l.rowsf(op.ws_c, op.cout) : nullptr, l.slot(op.slot), 4, l.B, ext, ext_ld, l.dtype,
+                                    l.stream());
+        }
       }
       if (rc) return rc;
     }
     cur = nxt;
+    if (with_an) ++i;                              // the ActNorm op has been executed
   }
   rc = join_lanes(f, lanes, c.s); if (rc) return rc;
   rc = ipoke_state_to_nchw(c.state(cur), out_nchw, B, z, f->P, c.ld, stream); if (rc) return rc;
@@ -1363,6 +1381,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   flush_nice_fn = flush_nice;
   size_t pk = 0;
   int cur = 0;
+  int pending_an = -1;              // ActNorm op whose backward is carried by the next (lower) coupling's launch
   const int64_t goff[2] = {c.plan.g0, c.plan.g1};
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
     const Op& op = f->ops[i];
@@ -1406,6 +1425,9 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       if (i == f->units[pieces[pk].first].op_lo) { rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc; ++pk; }
       continue;
     }
+    // An ActNorm right behind a coupling is differentiated by the coupling's launch (ipoke_actnorm_affine_bwd), unless it is the
+    // lowest op of the current piece: its parameter-gradient partials must exist when the piece is finished right after this op.
+    if (op.type == OP_ACTNORM && op.an_prev >= 0 && i != f->units[pieces[pk].first].op_lo) { pending_an = i; continue; }
     if (op.type != OP_NICE) { rc = flush_nice(); if (rc) return rc; }
     for (const Ctx& l : lanes) {
       const float* gin = l.rowsf(goff[cur], l.ld); float* gout = l.rowsf(goff[cur ^ 1], l.ld);
@@ -1439,8 +1461,16 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       } else {
         const void* h1 = l.rows(op.ws_a, hb); const void* h2 = l.rows(op.ws_b, hb);
         void* dprm = l.rows(op.ws_d, (int64_t)op.Kc3 * f->esz); void* dp2 = l.rows(op.ws_e, hb); void* dp1 = l.rows(op.ws_f, hb);
-        rc = ipoke_affine_bwd(op.cout, op.t_off, op.t_stride, f->P, l.ld, gin, xin, l.rowsf(op.ws_c, op.cout), l.dld(), gout, dprm,
-                              op.Kc3, l.dbp(i, 2 * op.cout), l.B, l.dtype, l.stream());
+        if (pending_an == i + 1) {
+          const Op& an = f->ops[i + 1];
+          rc = ipoke_actnorm_affine_bwd(an.c0, an.Cn, an.p_ls >= 0 ? params + an.p_ls : nullptr, an.idx_fwd >= 0 ? perm + an.idx_fwd : nullptr,
+                                        gin, l.state(i + 1), an.p_ls >= 0 ? l.dbp(i + 1, 2 * an.Cn) : nullptr, op.cout, op.t_off, op.t_stride,
+                                        f->P, l.ld, xin, l.rowsf(op.ws_c, op.cout), l.dld(), gout, dprm, op.Kc3, l.dbp(i, 2 * op.cout), l.B,
+                                        l.dtype, l.stream());
+        } else {
+          rc = ipoke_affine_bwd(op.cout, op.t_off, op.t_stride, f->P, l.ld, gin, xin, l.rowsf(op.ws_c, op.cout), l.dld(), gout, dprm,
+                                op.Kc3, l.dbp(i, 2 * op.cout), l.B, l.dtype, l.stream());
+        }
         if (rc) return rc;
         ipoke_conv_desc d;
         // conv3 data gradient, times ELU'(h2)
@@ -1470,6 +1500,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       pend_lo = op.mcf_idx;
     } else if (op.type == OP_NICE) {
       pend_nice.push_back(i);      // weight gradients: launched when the chain leaves this group of couplings
+      if (pending_an == i + 1) pending_an = -1;
     }
     cur ^= 1;
     if (i == f->units[pieces[pk].first].op_lo) {        // the lowest op of the current piece has been queued
