@@ -338,3 +338,73 @@ def test_nice_coupling_composed(golden, C, variant, dtype):
     assert e_y <= TOLS[dtype] * 4 and e_ld <= TOLS[dtype] * 200
     xi = ops.affine_inv(y, part, sd["net.conv3.conv.bias"].float().contiguous(), cout, t_off, stride, B)
     assert (ops.from_state(xi, B, C).cpu() - x.cpu()).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("C,c0,Cn,stride,shuffle,params", [(64, 0, 64, 2, True, True), (60, 0, 60, 1, False, True), (32, 28, 4, 1, False, True),
+                                                           (8, 0, 8, 2, True, False)])
+def test_coupling_actnorm_pair_kernels(C, c0, Cn, stride, shuffle, params, dtype):
+    """ipoke_affine_actnorm_fwd / ipoke_actnorm_affine_bwd (a coupling and the ActNorm (+ Shuffle) behind it in one launch per
+    direction: MaCowStep's coupling -> actnorm, MultiScalePrior's coupling -> actnorm on a channel window) against the two separate
+    launches they replace: both states, scales, log-det slots; gradient passed on, coupling-parameter gradients, bias and ActNorm
+    partial sums."""
+    from ctypes import byref
+    from ipoke_amd import _lib, ops
+    from ipoke_amd._lib import check, ptr
+    from tests.helpers import tdt
+    dev = "cuda"
+    B, ld, P = 3, 64, 64
+    Cp = C // 2
+    t_off = 1 if stride == 2 else C - Cp
+    gen = torch.Generator().manual_seed(C + c0 + Cn)
+    x = torch.randn(B * P, ld, generator=gen).to(dev)
+    raw = (torch.randn(2, B * P, 2 * Cp, generator=gen) * 0.5).to(dev)          # two split-K partial slabs
+    bias = (torch.randn(2 * Cp, generator=gen) * 0.1).to(dev)
+    ls = (torch.randn(Cn, generator=gen) * 0.2).to(dev) if params else None
+    ab = torch.randn(Cn, generator=gen).to(dev) if params else None
+    idx = torch.randperm(Cn, generator=gen).to(dev) if shuffle else None
+    L = _lib.lib()
+    # ---- forward: separate launches
+    y1, ldet1, sc1 = ops.affine_fwd(x, raw, bias, Cp, t_off, stride, B)
+    y2 = ops.actnorm_fwd(y1, c0, Cn, ls, ab, idx)
+    # ---- forward: one launch
+    d, keep = ops._affine_desc(raw, bias, Cp, t_off, stride, ld)
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    sc = torch.empty(B * P, Cp, device=dev); slots = torch.zeros(B, device=dev)
+    i32 = None if idx is None else idx.to(torch.int32).contiguous()
+    check(L.ipoke_affine_actnorm_fwd(byref(d), ptr(x), ptr(o1), ptr(o2), ptr(sc), ptr(slots), 1, B, c0, Cn, ptr(ls), ptr(ab), ptr(i32),
+                                     _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(o1, y1) and torch.equal(sc, sc1)
+    assert (o2 - y2).abs().max().item() <= 1e-6 * max(1.0, y2.abs().max().item())
+    assert (slots - ldet1).abs().max().item() <= 1e-4
+    # the saved-nothing form (out == NULL) writes the same second state
+    o2b = torch.empty_like(x)
+    check(L.ipoke_affine_actnorm_fwd(byref(d), ptr(x), None, ptr(o2b), None, None, 1, B, c0, Cn, ptr(ls), ptr(ab), ptr(i32), _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(o2b, o2)
+    # ---- backward: separate launches
+    dy2 = torch.randn(B * P, ld, generator=gen).to(dev)
+    dld = torch.randn(B, generator=gen).to(dev)
+    e16 = 8 if dtype == "bf16" else 4
+    ldp = -(-2 * Cp // e16) * e16 + e16                              # one extra chunk of K padding
+    dx_a = torch.empty_like(x)
+    part_a = torch.zeros(B, 2 * Cn, device=dev) if params else None
+    check(L.ipoke_actnorm_bwd(ptr(dy2), ptr(y1), ptr(dx_a), B * P, ld, c0, Cn, ptr(ls), ptr(i32), ptr(dld), B, P, ptr(part_a),
+                              _lib.current_stream()))
+    g_ref = torch.empty_like(x)
+    dprm_ref = torch.full((B * P, ldp), 7.0, device=dev, dtype=tdt(dtype))
+    dbp_ref = torch.zeros(B, 2 * Cp, device=dev)
+    check(L.ipoke_affine_bwd(Cp, t_off, stride, P, ld, ptr(dx_a), ptr(x), ptr(sc1), ptr(dld), ptr(g_ref), ptr(dprm_ref), ldp, ptr(dbp_ref), B,
+                             _lib.DTYPES[dtype], _lib.current_stream()))
+    # ---- backward: one launch
+    g, dprm = torch.empty_like(x), torch.full((B * P, ldp), 7.0, device=dev, dtype=tdt(dtype))
+    dbp = torch.zeros(B, 2 * Cp, device=dev)
+    part = torch.zeros(B, 2 * Cn, device=dev) if params else None
+    check(L.ipoke_actnorm_affine_bwd(c0, Cn, ptr(ls), ptr(i32), ptr(dy2), ptr(y1), ptr(part), Cp, t_off, stride, P, ld, ptr(x), ptr(sc1),
+                                     ptr(dld), ptr(g), ptr(dprm), ldp, ptr(dbp), B, _lib.DTYPES[dtype], _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(g, g_ref) and torch.equal(dprm, dprm_ref)
+    assert (dbp - dbp_ref).abs().max().item() <= 1e-5 * max(1.0, dbp_ref.abs().max().item())
+    if params:
+        assert (part - part_a).abs().max().item() <= 1e-5 * max(1.0, part_a.abs().max().item())
