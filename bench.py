@@ -349,6 +349,8 @@ def secondary(args, cfg, rank, world, device):
         workload = f"{cfg['name']} forward_sample, z={z}, reverse flow + {T - 1}-frame decode at {size}x{size}, per-GPU batch {B}"
     for i in range(args.warmup):
         out = step(i)
+    import gc
+    gc.collect(); gc.freeze()                     # see main(): no generation-2 collection inside the timed loop
     D.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -449,6 +451,10 @@ def main():
     randomise_couplings(model)
     for i in range(args.warmup):
         trainer.train_step(batch, i, next_batch=batch)
+    # the model is ~7 000 parameter objects plus their modules: a generation-2 collection of Python's cycle GC inside the timed loop
+    # stalls the host for > 100 ms (seen as one 185 ms step in 30): collect now and move the survivors out of the collector's sight
+    import gc
+    gc.collect(); gc.freeze()
     D.barrier(); torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()

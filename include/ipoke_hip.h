@@ -385,6 +385,13 @@ int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm,
  * on (a stream ordered after) `ready_stream` overlaps the remaining pieces.  On return `stream` is ordered after
  * `ready_stream`.  npieces = 1, ready_stream = stream, ready = NULL is ipoke_flow_backward. */
 typedef void (*ipoke_grad_ready_fn)(void* user, int piece, int64_t begin, int64_t end);
+/* Single-process training: let the engine apply torch.optim.Adam(amsgrad=True) (second_stage_video.py:648-650) itself.  While set
+ * (m != NULL; m, v, vmax: optimizer state in the layout of params), ipoke_flow_backward_pieces queues -- on `ready_stream`, right
+ * behind a piece's last gradient kernel -- ipoke_adam_amsgrad_step_grid over the piece's parameter ranges and the refresh of their
+ * weight shadows, i.e. what a `ready` callback would launch from the host, without the host round trip (params and shadow are
+ * written: pass buffers the caller owns mutably).  `step` is the 1-based optimizer step the bias corrections use. */
+int ipoke_flow_set_native_adam(ipoke_flow* f, float* m, float* v, float* vmax, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, float grad_scale, int max_blocks);
 int ipoke_flow_backward_pieces(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
                                const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
                                void* workspace, int npieces, void* ready_stream, ipoke_grad_ready_fn ready, void* user,

@@ -183,6 +183,7 @@ SIGNATURES = {
     "ipoke_relayout_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "ipoke_wn_scale_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_flow_prepare_weights_range": (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
+    "ipoke_flow_set_native_adam": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_int]),
     "ipoke_flow_adam_range": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
                                       c_float, c_int, _P]),
     "ipoke_adam_tile_job_size": (c_int, []),

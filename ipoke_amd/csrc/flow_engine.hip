@@ -117,6 +117,11 @@ struct ipoke_flow {
   // every masked-conv layer is differentiated inside a fused MaCowUnit launch, which also writes the layer's input in the matrix
   // cores' dtype: the shifted-conv weight gradients then read that copy through the LDS-DMA GEMM instead of the fp32 state
   bool mcf_xop = false;
+  // Optimizer applied by the engine itself as soon as a piece of the backward pass is final (ipoke_flow_set_native_adam): the
+  // Adam-amsgrad update and the shadow refresh of the piece's parameter ranges are queued on the ready stream by finish_piece
+  // without a round trip through the host callback.
+  struct NativeAdam { bool on = false; float* m = nullptr; float* v = nullptr; float* vmax = nullptr; float lr = 0, beta1 = 0, beta2 = 0, eps = 0, wd = 0,
+                      grad_scale = 1; int step = 0, max_blocks = 0; } nadam;
 };
 
 namespace {
@@ -847,6 +852,21 @@ static int prepare_range(ipoke_flow* f, const float* params, void* shadow, int64
   return IPOKE_OK;
 }
 
+/* Optimizer inside the piecewise backward pass (single process): after ipoke_flow_set_native_adam(..., step >= 1) every
+ * ipoke_flow_backward_pieces applies Adam-amsgrad to the ranges of a piece and refreshes their shadows on the ready stream as soon as the
+ * piece is final -- what the `ready` callback of a data-parallel run does after its gradient exchange.  m = NULL switches it off. */
+extern "C" int ipoke_flow_set_native_adam(ipoke_flow* f, float* m, float* v, float* vmax, float lr, float beta1, float beta2, float eps,
+                                          float weight_decay, int step, float grad_scale, int max_blocks) {
+  IPK_REQUIRE(f != nullptr, "null flow handle");
+  ipoke_flow::NativeAdam& A = f->nadam;
+  A.on = m != nullptr;
+  if (!A.on) return IPOKE_OK;
+  IPK_REQUIRE(v && vmax && step >= 1, "bad optimizer state");
+  A.m = m; A.v = v; A.vmax = vmax; A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.wd = weight_decay; A.step = step;
+  A.grad_scale = grad_scale; A.max_blocks = max_blocks;
+  return IPOKE_OK;
+}
+
 extern "C" int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* params, void* shadow, int64_t begin, int64_t end,
                                                 void* stream) {
   IPK_REQUIRE(f && params && shadow && begin >= 0 && end >= begin, "bad arguments");
@@ -1314,6 +1334,19 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       r = ipoke_wn_bwd_multi_range(params, grads, c.wn_inv(), f->d_wjobs, wj0[kind], wj1[kind] - wj0[kind], rw0[kind],
                                    rw1[kind] - rw0[kind], rstream);
       if (r) return r;
+    }
+    if (f->nadam.on) {
+      // single-GPU training: the update of the piece's ranges and the refresh of their shadows, natively, on the ready stream
+      const ipoke_flow::NativeAdam& A = f->nadam;
+      float* pm = const_cast<float*>(params);
+      for (int kind = 0; kind < 3; ++kind) {
+        if (p0[kind] < 0 || p1[kind] <= p0[kind]) continue;
+        const int64_t b0 = p0[kind], n = p1[kind] - p0[kind];
+        r = ipoke_adam_amsgrad_step_grid(pm + b0, grads + b0, A.m + b0, A.v + b0, A.vmax + b0, n, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
+                                         A.grad_scale, A.max_blocks, rstream);
+        if (r) return r;
+        r = prepare_range(f, params, const_cast<void*>(shadow), b0, b0 + n, false, rstream); if (r) return r;
+      }
     }
     if (ready)
       for (int kind = 0; kind < 3; ++kind)

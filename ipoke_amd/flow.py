@@ -235,6 +235,12 @@ class FlowEngine:
                                                _lib.current_stream()))
         else:
             npieces, ready_stream, fn = self.grad_ready_hook
+            if fn is None:        # the engine applies the optimizer itself (ipoke_flow_set_native_adam): no host callback
+                check(self.lib.ipoke_flow_backward_pieces(self.handle, ptr(self.params), ptr(self.perm), ptr(self.shadow),
+                                                          ptr(st["d_out"]), ptr(st["d_logdet"]), B, ptr(grads),
+                                                          ptr(st["dx"]) if need_dx else None, ptr(ws), int(npieces),
+                                                          c_void_p(ready_stream.cuda_stream), _lib.GRAD_READY_FN(), None, _lib.current_stream()))
+                return st["dx"].clone() if need_dx else None
             failure = []
 
             def _ready(user, piece, begin, end):

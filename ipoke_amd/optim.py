@@ -156,6 +156,25 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         self.flow.engine.prepare_weights_range(begin, end)
         self._covered += n
 
+    # ---- native piecewise step: the engine applies the update of every piece itself (single process) ------------------
+    def arm_native(self, grad_scale=1.0, max_blocks=128):
+        """Hand this step's update to the engine: ``ipoke_flow_backward_pieces`` then queues the Adam-amsgrad update and the shadow
+        refresh of every piece on the ready stream as soon as the piece is final (ipoke_flow_set_native_adam) -- the launches of
+        ``step_range`` without the host callback between the chain's kernels.  Call after ``begin_step``; ``finish_native`` after
+        the backward pass."""
+        g = self.param_groups[0]
+        check(_lib.lib().ipoke_flow_set_native_adam(self.flow.engine.handle, ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.max_exp_avg_sq),
+                                                    float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                                    float(g["weight_decay"]), int(self.steps), float(grad_scale), int(max_blocks)))
+
+    def disarm_native(self):
+        check(_lib.lib().ipoke_flow_set_native_adam(self.flow.engine.handle, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 1.0, 0))
+
+    def finish_native(self):
+        self.disarm_native()
+        self._covered = self.flow.flat_params.numel()          # every piece was updated and refreshed by the engine
+        self.finish_step()
+
     def finish_step(self):
         if self._covered != self.flow.flat_params.numel():
             raise RuntimeError(f"piecewise optimizer step covered {self._covered} of {self.flow.flat_params.numel()} parameters")

@@ -94,14 +94,31 @@ class PokeMotionModel(nn.Module):
         fs_min = self.first_stage_config["architecture"]["min_spatial_size"]
         self.adapt_poke_emb_ssize = pe_arch["min_spatial_size"] != fs_min
         self.adapt_cond_ssize = self.use_cond and self.conditioner_config["architecture"]["min_spatial_size"] != fs_min
-        if self.adapt_poke_emb_ssize or self.adapt_cond_ssize:
-            raise NotImplementedError("adapt_*_ssize convolutions are off in every shipped config (all latents are 8x8)")
+        if self.adapt_poke_emb_ssize:
+            # second_stage_video.py:114-118 builds a stride-`factor` Conv2d when the poke latent is SMALLER than the first stage's
+            # (factor > 1: 4x4 -> 2x2) and a stride-1/factor transposed block when it is LARGER (16x16 -> 32x32): both move the map AWAY
+            # from the first-stage size, and the torch.cat of :311 fails in the reference itself.  Nothing to be compatible with.
+            raise NotImplementedError("adapt_poke_emb_ssize: the reference's own adapter resizes in the wrong direction for either ratio "
+                                      "(second_stage_video.py:114-118) and cannot run; use a poke embedder with the first stage's latent size")
+        if self.adapt_cond_ssize:
+            from .first_stage import Conv2dTransposeBlock
+            factor = float(fs_min) / self.conditioner_config["architecture"]["min_spatial_size"]
+            if factor < 1 or factor != int(factor):
+                # :123-126: `nn.Conv2d(..., stride=int(factor))` with factor < 1 is a stride-0 convolution ("non-positive stride")
+                raise NotImplementedError("adapt_cond_ssize with a conditioner latent larger than the first stage's builds a stride-0 "
+                                          "Conv2d in the reference (second_stage_video.py:123-126): no behaviour to reproduce")
+            nf = self.conditioner_config["architecture"]["nf_max"]
+            # Conv2dTransposeBlock(nf, nf, st=factor, ks=3, padding=1): ConvTranspose2d + ("elu" -> ReLU); trainable in name only --
+            # it is applied under torch.no_grad (:268-290) and so never receives a gradient in the reference either
+            self.conv_adapt_cond = Conv2dTransposeBlock(nf, nf, 3, int(factor), 1, norm="none", activation="elu", snorm=False)
         if arch.get("multistack", False):
             raise NotImplementedError("multistack flows are outside the shipped configs")
         mb = max_batch if max_batch is not None else max(config["data"]["batch_size"], 1)
         self.first_stage_model.to(self.device_); self.poke_embedder.to(self.device_)
         if self.use_cond:
             self.conditioner.to(self.device_)
+        if self.adapt_cond_ssize:
+            self.conv_adapt_cond.to(self.device_)
         self.flow = SupervisedMacowTransformer(arch, dtype=dtype, max_batch=mb, device=self.device_)
         self.loss_func = FlowLoss(spatial_mean=self.spatial_mean_for_loss, logdet_weight=logdet_weight)
         self.logged = {}
@@ -181,6 +198,8 @@ class PokeMotionModel(nn.Module):
             poke_emb, *_ = self.poke_embedder.encoder(poke)
             if self.use_cond:
                 cond, *_ = self.conditioner.encoder(X[:, 0])
+                if self.adapt_cond_ssize:
+                    cond = self._adapt_cond(cond)
         if reverse:
             spatial = self.first_stage_config["architecture"]["min_spatial_size"]
             # CPU generator, then moved: torch.randn(...).type_as(X) (:296-300)
@@ -195,6 +214,12 @@ class PokeMotionModel(nn.Module):
                     flow_input = torch.cat([flow_input, noise], dim=1)
         cond = torch.cat([cond, poke_emb], dim=1) if self.use_cond else poke_emb
         return flow_input, cond
+
+    def _adapt_cond(self, cond):
+        """conv_adapt_cond (second_stage_video.py:120-129, 286-287): the conditioner's 4x4 (...) latent brought to the first stage's size."""
+        from . import nn as K
+        y = self.conv_adapt_cond.run(K.from_nchw(cond.float(), self.dtype), self.dtype)
+        return K.to_nchw(y, self.dtype)
 
     def encode_first_stage(self, X):
         with torch.no_grad():
@@ -267,6 +292,8 @@ class PokeMotionModel(nn.Module):
         poke_emb, *_ = self.poke_embedder.encoder(poke)
         if self.use_cond:
             cond, *_ = self.conditioner.encoder(X[:, 0])
+            if self.adapt_cond_ssize:
+                cond = self._adapt_cond(cond)
             cond = torch.cat([cond, poke_emb], dim=1)
         else:
             cond = poke_emb

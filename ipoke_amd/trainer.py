@@ -38,6 +38,8 @@ class SecondStageTrainer:
         if self.zero1:
             gd = torch.bfloat16 if os.environ.get("IPOKE_GRAD_EXCHANGE", "f32") == "bf16" else torch.float32
             self.opt.enable_sharding(self.world, D.rank(), gd)
+        # one process, no accumulation: the engine queues every piece's update itself (no host callback inside the backward pass)
+        self.native_opt = self.overlap and self.world == 1 and os.environ.get("IPOKE_NO_NATIVE_ADAM", "0") != "1"
         if self.overlap:
             self.ready_stream = torch.cuda.Stream()      # the hook itself is installed around the backward of train_step only
         # train_step(batch, next_batch=...): the frozen encoders (first stage, poke, image) of the NEXT batch do not depend on the
@@ -139,14 +141,21 @@ class SecondStageTrainer:
         if self.overlap:
             self.opt.begin_step()
             eng = m.flow.engine
-            eng.grad_ready_hook = (self.n_grad_buckets, self.ready_stream, self._grads_ready)
+            native = self.native_opt and self._acc_count == 0 and not eng.shadow_stale
+            if native:
+                self.opt.arm_native(grad_scale=1.0 / (self.world * self.accumulate_grad_batches))
+            eng.grad_ready_hook = (self.n_grad_buckets, self.ready_stream, None if native else self._grads_ready)
+            ok = False
             try:
                 loss.backward()               # exchanges and updates every slice from the engine's callbacks; on return the
-            finally:                          # current stream is ordered after the ready stream
+                ok = True                     # current stream is ordered after the ready stream
+            finally:
                 eng.grad_ready_hook = None    # a backward outside train_step must not apply optimizer updates
+                if native and not ok:
+                    self.opt.disarm_native()
             if prefetch:                      # ... but are queued after the backward pass (host order = GPU start order)
                 m.prefetch_flow_input(next_batch, self.prefetch_stream, after=fwd_done)
-            self._optimizer_step(self.opt.finish_step)
+            self._optimizer_step(self.opt.finish_native if native else self.opt.finish_step)
         else:
             loss.backward()
             if prefetch:

@@ -1049,13 +1049,45 @@ def g7_sample_128():
         g_scale=g_scale)
 
 
+def g14_adapt_cond():
+    """G14: ``adapt_cond_ssize`` (models/second_stage_video.py:120-129, 286-287): a conditioner whose latent is 4x4 and the transposed
+    adapter block that brings it to the first stage's 8x8 -- the one adapter variant of the reference that can run (the poke adapter
+    resizes away from the target for either ratio, the conditioner adapter for larger latents is a stride-0 Conv2d).  64x64, z = 32."""
+    util = ref_import.ref("models.modules.autoencoders.util")
+    arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+    M, cfg = build_reference_poke_model(64, 32, 16, arch)
+    fcm = ref_import.ref("models.modules.autoencoders.fully_conv_models")
+    ccfg = configs.encoder2d_config(64, 3)
+    ccfg["architecture"]["min_spatial_size"] = 4
+    M.conditioner = fcm.FirstStageWrapper(copy.deepcopy(ccfg))
+    deterministic_fill_(M.conditioner, prefix="conditioner.")
+    M.adapt_cond_ssize = True
+    M.conv_adapt_cond = util.Conv2dTransposeBlock(64, 64, st=2, ks=3, padding=1)          # as __init__ builds it for factor = 8 / 4 (:127-129)
+    deterministic_fill_(M.conv_adapt_cond, prefix="conv_adapt_cond.")
+    batch = synthetic_batch(2, 16, 64, seed=6)
+    torch.manual_seed(97)
+    eps = torch.FloatTensor(2, 32, 8, 8).normal_()
+    torch.manual_seed(97)
+    flow_input, cond = M.make_flow_input(batch)
+    assert tuple(cond.shape) == (2, 128, 8, 8)
+    with torch.no_grad():
+        raw, *_ = M.conditioner.encoder(batch["images"][:, 0])
+    assert tuple(raw.shape) == (2, 64, 4, 4)
+    # oracle: the same from the restated blocks
+    oc = vae_ref.FirstStageWrapper(copy.deepcopy(ccfg)).eval(); oc.load_state_dict(M.conditioner.state_dict(), strict=False)
+    ob = vae_ref.Conv2dTransposeBlock(64, 64, 3, 2, 1, norm="none", activation="elu", snorm=False); ob.load_state_dict(M.conv_adapt_cond.state_dict())
+    with torch.no_grad():
+        close(ob(oc.encoder(batch["images"][:, 0])[0]), cond[:, :64], 2e-5, "G14 adapted cond")
+    npz("g14_adapt_cond_64", batch_seed=6, eps=eps, flow_input=flow_input, cond=cond, cond_latent_4x4=raw)
+
+
 def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
             "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
             "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd, "g11": g11_data, "g12": g12_vgg, "g13": g13_train_mode,
-            "g7_128": g7_sample_128}
+            "g7_128": g7_sample_128, "g14": g14_adapt_cond}
     for name in (which or list(jobs)):
         print(f"[{name}]")
         t = time.time()

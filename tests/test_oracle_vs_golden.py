@@ -215,6 +215,22 @@ def test_first_stage_train_mode_step_128(golden):
         assert abs(cs[0] - ref[0]) <= 1e-2 * ref[1] and abs(cs[1] - ref[1]) <= 1e-2 * ref[1], (k, cs, ref)
 
 
+def test_adapt_cond_oracle(golden):
+    """The conditioner with a 4x4 latent + the transposed adapter block (second_stage_video.py:120-129) from the oracle's blocks
+    against the reference's make_flow_input (golden g14)."""
+    g = golden("g14_adapt_cond_64")
+    ccfg = configs.encoder2d_config(64, 3)
+    ccfg["architecture"]["min_spatial_size"] = 4
+    oc = vae_ref.FirstStageWrapper(ccfg).eval()
+    ob = vae_ref.Conv2dTransposeBlock(64, 64, 3, 2, 1, norm="none", activation="elu", snorm=False)
+    deterministic_fill_(oc, prefix="conditioner."); deterministic_fill_(ob, prefix="conv_adapt_cond.")
+    X0 = torch.rand(2, 16, 3, 64, 64, generator=torch.Generator().manual_seed(int(g["batch_seed"])))[:, 0] * 2 - 1
+    with torch.no_grad():
+        lat = oc.encoder(X0)[0]
+        cond = ob(lat)
+    assert (lat - t(g["cond_latent_4x4"])).abs().max() <= 2e-5 and (cond - t(g["cond"])[:, :64]).abs().max() <= 2e-5
+
+
 def _checksum(x, key):
     import zlib
     x = x.detach().double().flatten().cpu()

@@ -98,3 +98,43 @@ def test_gradient_accumulation_matches_the_large_batch_step(overlap):
         worst = max(worst, d)
     print(f"gradient accumulation (overlap={overlap}): worst relative parameter deviation after 2 optimizer steps {worst:.2e}")
     assert worst <= 5e-4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_adapt_cond_ssize(golden, dtype):
+    """adapt_cond_ssize (second_stage_video.py:120-129, 286-287): a conditioner with a 4x4 latent and the transposed adapter block
+    (ConvTranspose2d k3 s2 + the "elu" -> ReLU quirk) that brings it to the first stage's 8x8, against the reference's own
+    make_flow_input (golden g14).  The two adapter variants that cannot run in the reference raise with the reason."""
+    from tests.conftest import t
+    g = golden("g14_adapt_cond_64")
+    arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+    arch["flow_mid_channels_factor"] = 2
+    conf = configs.second_stage_config(64, 32, 16, batch_size=2, arch=arch)
+    conf["conditioner_model"]["architecture"]["min_spatial_size"] = 4
+    model = PokeMotionModel(conf, dirs={}, dtype=dtype, device=DEV, max_batch=2)
+    assert model.adapt_cond_ssize and not model.adapt_poke_emb_ssize
+    assert {"conv_adapt_cond.conv.weight", "conv_adapt_cond.conv.bias"} <= set(model.state_dict())
+    for name in ("first_stage_model", "poke_embedder", "conditioner", "flow"):
+        deterministic_fill_(getattr(model, name), prefix=("first_stage" if name == "first_stage_model" else name) + ".")
+    deterministic_fill_(model.conv_adapt_cond, prefix="conv_adapt_cond.")
+    model.flow.sync_buffers()
+    batch = synthetic_batch(2, 16, 64, seed=int(g["batch_seed"]), device=DEV)
+    torch.manual_seed(97)
+    flow_input, cond = model.make_flow_input(batch)
+    e_c = (cond.cpu() - t(g["cond"])).abs().max().item()
+    e_z = (flow_input.cpu() - t(g["flow_input"])).abs().max().item()
+    print(f"adapt_cond_ssize[{dtype}]: cond err {e_c:.3e} (|cond| max {abs(g['cond']).max():.2f}), flow_input err {e_z:.3e}")
+    assert cond.shape == (2, 128, 8, 8)
+    assert e_c <= (4e-4 if dtype == "f32" else 0.12) and e_z <= (2e-4 if dtype == "f32" else 6e-2)
+    # sampling runs through the adapter too
+    vids = model.forward_sample(batch, n_samples=1, n_logged_vids=1)
+    assert vids[0].shape == (1, 15, 3, 64, 64)
+    bad = configs.second_stage_config(64, 32, 16, batch_size=2, arch=configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4))
+    bad["architecture"]["flow_mid_channels_factor"] = 2
+    bad["conditioner_model"]["architecture"]["min_spatial_size"] = 16
+    with pytest.raises(NotImplementedError, match="stride-0"):
+        PokeMotionModel(bad, dirs={}, dtype=dtype, device=DEV, max_batch=2)
+    bad["conditioner_model"]["architecture"]["min_spatial_size"] = 8
+    bad["poke_embedder"]["architecture"]["min_spatial_size"] = 4
+    with pytest.raises(NotImplementedError, match="wrong direction"):
+        PokeMotionModel(bad, dirs={}, dtype=dtype, device=DEV, max_batch=2)
