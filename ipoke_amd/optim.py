@@ -15,10 +15,10 @@ from . import _lib
 from ._lib import check, ptr
 
 # IPOKE_ADAM_FUSION=1: Adam-amsgrad fused with the shadow refresh of the plain 1x1 weights (ipoke_flow_adam_range).  Built, bit-identical
-# to the plain path (tests/test_flow_gpu.py) and measured on MI355X (round 3, c2): it saves 3.6 GB of HBM reads per step, but its
-# 64 x 64-tile access pattern streams at ~3.2 TB/s against the linear kernel's 5.7 TB/s -- optimizer + refresh of the whole buffer
-# 14.3 ms against 11.9 ms alone, 20.0 against 15.1 ms in twelve pieces on 128-workgroup grids, and the train step 65.7-66.9 ms
-# against 63.3-63.7 ms (scripts/probe_adam.py).  Off by default.
+# to the plain path (tests/test_flow_gpu.py) and measured on MI355X (round 3, c2): it saves 3.6 GB of HBM reads per step and 73 % of the
+# relayout work, but its 64 x 64-tile access pattern streams HBM worse than the linear kernel -- optimizer + refresh of the whole buffer
+# 14.4 ms against 12.6 ms alone, 17.5 against 15.2 ms in twelve pieces on 128-workgroup grids (with the loads of the next tile issued ahead
+# of the arithmetic; 20.0 ms without), and the train step 62.1-62.2 ms against 61.8 ms (scripts/probe_adam.py).  Off by default.
 _FUSE_DEFAULT = os.environ.get("IPOKE_ADAM_FUSION", "0") == "1"
 _FUSE_SHADOWS = _FUSE_DEFAULT
 _TILE_BLOCKS = int(os.environ.get("IPOKE_ADAM_TILE_BLOCKS", "128"))     # developer A/B: persistent grid of the fused tile kernel underneath backward
