@@ -177,6 +177,8 @@ int ipoke_actnorm_affine_bwd(int c0, int C, const float* log_scale, const int32_
                              int Cp, int t_off, int t_stride, int P, int ld, const float* x0, const float* scale, const float* dld, float* dx,
                              void* dparams, int ldp, float* dbias_part, int B, int dtype, void* stream);
 int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream);
+/* developer probe (IPOKE_SIDE_DELAY_US): one wave spinning for about `us` microseconds on `stream` */
+int ipoke_spin_delay(int us, void* stream);
 /* multi-tensor form: entries_dev[i] = {int64 src, int64 dst (float offsets), int32 ld, int32 ncols}; R rows each */
 int ipoke_reduce_entry_size(void);
 int ipoke_reduce_rows_multi(const float* src, float* dst, const void* entries_dev, int nentries, int R, void* stream);

@@ -119,6 +119,7 @@ SIGNATURES = {
     "ipoke_actnorm_affine_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P,
                                          c_int, c_int, _P]),
     "ipoke_reduce_rows": (c_int, [_P, _P, c_int, c_int, _P]),
+    "ipoke_spin_delay": (c_int, [c_int, _P]),
     "ipoke_logdet_finalize": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "ipoke_actnorm_logdet": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "ipoke_flow_nll": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),

@@ -827,6 +827,17 @@ extern "C" int ipoke_actnorm_affine_bwd(int c0, int C, const float* log_scale, c
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
+__global__ void spin_delay_kernel(long ticks) {
+  const long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+/* developer probe: occupy `stream` with one wave for about `us` microseconds (constant 100 MHz counter) */
+extern "C" int ipoke_spin_delay(int us, void* stream) {
+  IPK_REQUIRE(us >= 0 && us <= 1000, "bad delay");
+  hipLaunchKernelGGL(spin_delay_kernel, dim3(1), dim3(64), 0, STREAM(stream), (long)us * 100);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
 extern "C" int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream) {
   IPK_REQUIRE(src && dst, "null tensor");
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(grid_for(ncols, 128)), dim3(128), 0, STREAM(stream), src, dst, R, ncols);

@@ -1246,7 +1246,15 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   // after every lane has produced the operands of that layer.
   hipStream_t ws_stream = f->use_side ? f->side : s;
   void* wstream = reinterpret_cast<void*>(ws_stream);
-  auto wgrads_wait_lanes = [&]() -> int { return join_lanes(f, lanes, ws_stream); };
+  // IPOKE_SIDE_DELAY_US (developer A/B): a one-wave spin of that many microseconds at the head of every side-stream batch, so that
+  // the chain's next kernel (a fused MaCowUnit needs whole CUs: 8 waves x 240 registers) takes its CUs before the batch's
+  // hundreds of weight-gradient workgroups are dealt onto every CU
+  static const int side_delay = getenv("IPOKE_SIDE_DELAY_US") ? atoi(getenv("IPOKE_SIDE_DELAY_US")) : 0;
+  auto wgrads_wait_lanes = [&]() -> int {
+    int r0 = join_lanes(f, lanes, ws_stream); if (r0) return r0;
+    if (side_delay > 0 && f->use_side) return ipoke_spin_delay(side_delay, wstream);
+    return IPOKE_OK;
+  };
   // Every parameter gradient is written exactly once per backward (no accumulation, no memset).  The weight gradients
   // of the MCF layers are tiny GEMMs (a handful of output tiles): they are deferred and issued as batched launches,
   // one per run of same-shape layers (= one level), using the per-layer saved operands that stay in the workspace.
@@ -1257,8 +1265,10 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     const Op& op = f->ops[pend_op];
     const int nb = pend_hi - pend_lo + 1;
     int r = wgrads_wait_lanes(); if (r) return r;
+    static const int mcf_cap = getenv("IPOKE_TN_MAX_WGS") ? atoi(getenv("IPOKE_TN_MAX_WGS")) : 0;
     ipoke_wgrad_desc w; std::memset(&w, 0, sizeof(w));
     w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = w.kh = w.kw = 1; w.sd = w.sh = w.sw = 1;
+    w.max_workgroups = f->use_side ? mcf_cap : 0;
     const int K2 = op.H + f->cfg.cond_channels;
     w.a_f32 = 0; w.a_sn = 64L * op.K2p; w.a_sh = 8L * op.K2p; w.a_sw = op.K2p; w.a_sc = 1; w.Kc_real = K2; w.Kc = op.K2p;
     w.ldy = op.K3p; w.Nout = 2 * op.C; w.w_sn = K2; w.w_sc = 1; w.w_st = 0;
@@ -1267,6 +1277,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     if (r) return r;
     std::memset(&w, 0, sizeof(w));
     w.NB = B; w.Di = 1; w.Hi = 8; w.Wi = 8; w.Do = 1; w.Ho = 8; w.Wo = 8; w.kd = 1; w.kh = 2; w.kw = 3; w.sd = w.sh = w.sw = 1;
+    w.max_workgroups = f->use_side ? mcf_cap : 0;
     if (f->mcf_xop) {   // dtype copy [M][Cp] of every layer input, zero padded: the LDS-DMA weight-gradient GEMM
       w.a_f32 = 0; w.a_sn = 64L * op.Cp; w.a_sh = 8L * op.Cp; w.a_sw = op.Cp; w.a_sc = 1; w.Kc_real = op.Cp; w.Kc = op.Cp; w.Kc_store = op.C;
     } else {

@@ -65,6 +65,7 @@ struct TnParams {
   int xa, xb;          // LDS-DMA kernel: XCD-aware tile map (xa x xb = 8 sub-grids), 0: plain row-major order
   long split_stride;   // > 0: split z stores its slab at dW + z*split_stride instead of atomics
   int tile0, max_wgs;  // first output tile of this launch / cap on workgroups per launch (0: none)
+  int z0;              // first problem (batch entry) of this launch
 };
 
 // decode output row m -> input base coordinates
@@ -729,7 +730,7 @@ template <typename T, int NR>
 __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
   TnParams p = pin;
   if (pin.batch) {                       // batched launch: blockIdx.z selects operands and the 2-D tap geometry
-    const TnBatchEntry e = pin.batch[blockIdx.z];
+    const TnBatchEntry e = pin.batch[blockIdx.z + pin.z0];
     p.A = pin.a_base + e.a_off; p.dY = pin.y_base + e.y_off; p.dW = pin.w_base + e.w_off;
     p.g.khw = e.kh * e.kw; p.g.kw = e.kw; p.g.taps = e.kh * e.kw; p.g.ph = e.ph; p.g.pw = e.pw;
   }
@@ -1632,7 +1633,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   typedef bf16_t T;
   TnParams p = pin;
   if (pin.batch) {                       // batched launch: blockIdx.z selects operands and the 2-D tap geometry
-    const TnBatchEntry e = pin.batch[blockIdx.z];
+    const TnBatchEntry e = pin.batch[blockIdx.z + pin.z0];
     p.A = pin.a_base + e.a_off; p.dY = pin.y_base + e.y_off; p.dW = pin.w_base + e.w_off;
     p.g.khw = e.kh * e.kw; p.g.kw = e.kw; p.g.taps = e.kh * e.kw; p.g.ph = e.ph; p.g.pw = e.pw;
   }
@@ -1869,9 +1870,15 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     }
     for (int t0 = 0; t0 < ntiles; t0 += cap) {
       p.tile0 = t0;
-      dim3 grid2((unsigned)std::min(cap, ntiles - t0), (unsigned)p.splitm, (unsigned)nbatch);
-      hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, s, p);
-      IPK_LAUNCH_CHECK();
+      const int nt = std::min(cap, ntiles - t0);
+      // the cap counts the problems of a batched launch too: as many whole problems per launch as fit under it
+      const int zper = p.max_wgs > 0 ? std::max(1, p.max_wgs / std::max(1, nt * p.splitm)) : nbatch;
+      for (int z0 = 0; z0 < nbatch; z0 += zper) {
+        p.z0 = z0;
+        dim3 grid2((unsigned)nt, (unsigned)p.splitm, (unsigned)std::min(zper, nbatch - z0));
+        hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, s, p);
+        IPK_LAUNCH_CHECK();
+      }
     }
     return IPOKE_OK;
   }
@@ -1976,7 +1983,7 @@ static int fill_tn(TnParams& p, const ipoke_wgrad_desc* d, int dtype, bool batch
   p.dW = d->dW; p.w_sn = d->w_sn; p.w_sc = d->w_sc; p.w_st = d->w_st; p.accumulate = d->accumulate;
   p.splitm = d->splitm < 1 ? 1 : d->splitm;
   p.split_stride = d->split_stride;
-  p.tile0 = 0; p.max_wgs = d->max_workgroups;
+  p.tile0 = 0; p.z0 = 0; p.max_wgs = d->max_workgroups;
   IPK_REQUIRE(p.split_stride >= 0 && !(p.split_stride > 0 && d->accumulate), "split slabs are stored, not accumulated");
   p.Kc_store = d->Kc_store > 0 ? d->Kc_store : d->Kc_real;
   IPK_REQUIRE(p.Kc_store <= d->Kc_real, "Kc_store exceeds Kc_real");
