@@ -51,6 +51,12 @@ struct NtParams {
 #define GEMM_STAMP(i) do {} while (0)
 #endif
 
+// Probe builds of the LDS-DMA weight-gradient kernel (scripts/probe_tn_phases.sh; never in the shipped library):
+// -DIPOKE_TN_ABL=1 matrix cores idle, 2 neither fragment reads nor matrix cores, 3 no DMA, 4 no epilogue stores
+#ifndef IPOKE_TN_ABL
+#define IPOKE_TN_ABL 0
+#endif
+
 // one problem of a batched weight-gradient launch (blockIdx.z): byte/float offsets against the launch's bases
 struct TnBatchEntry { long a_off, y_off, w_off; int kh, kw, ph, pw; };
 
@@ -1769,9 +1775,13 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   for (int it = 0; it < nst; ++it) {
     wait_vmcnt<(NSTAGE - 2) * L>();               // this wave's share of the oldest slot has landed
     __builtin_amdgcn_s_barrier();                 // ... and everybody else's; the slot refilled below is no longer read
-    issue((slot + NSTAGE - 1) % NSTAGE, mb_begin + issued, issued < nst); ++issued;
+#if IPOKE_TN_ABL != 3
+    issue((slot + NSTAGE - 1) % NSTAGE, mb_begin + issued, issued < nst);
+#endif
+    ++issued;
     const unsigned char* base = smem + slot * STAGE;
     slot = (slot + 1) % NSTAGE;
+#if IPOKE_TN_ABL != 2
 #pragma unroll
     for (int ks = 0; ks < NI; ++ks) {
       frag_t fy[4], fx[2];
@@ -1779,13 +1789,28 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
       for (int i = 0; i < 4; ++i) fy[i] = tr_frag(base, y_rd[i] + ks * 32 * 256);
 #pragma unroll
       for (int j = 0; j < 2; ++j) fx[j] = tr_frag(base, x_rd[j] + ks * 32 * 256);
+#if IPOKE_TN_ABL == 1
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fy[i]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(fx[j]));
+#else
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) mma64(fy[i], fx[j], acc[i][j]);
+#endif
     }
+#endif
   }
   wait_vmcnt<0>();
+#if IPOKE_TN_ABL == 4
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+  return;
+#endif
 
   // epilogue: acc[i][j][r] = dW[n = n0 + wn2*64 + 16i + (lane&15)][k = k0 + wk*32 + 16j + 4*(lane>>4) + r]
   const bool vec4 = p.w_sc == 1 && !p.accumulate && !(p.splitm > 1 && p.split_stride == 0) && ((p.w_sn | p.w_st | p.split_stride) & 3) == 0 &&

@@ -1,1 +1,7 @@
-for v in "X=1" "IPOKE_TN_MAX_WGS=256" "IPOKE_TN_MAX_WGS=512" "IPOKE_SIDE_DELAY_US=3" "IPOKE_SIDE_DELAY_US=8" "IPOKE_SIDE_DELAY_US=8 IPOKE_TN_MAX_WGS=256" "X=1" "IPOKE_TN_MAX_WGS=256" "IPOKE_SIDE_DELAY_US=8"; do echo "== ${v:0:50}"; env $v python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d[\"ms_per_step\"], d[\"ms_per_step_median\"], d[\"roofline\"][\"avg_launch_us\"], [ (k[\"kernel\"][:14], k[\"avg_launch_us\"]) for k in d[\"roofline_other_kernels\"]])"; done
+set -x
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/final_tests.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 > gpurun_out/final_smoke.txt
+timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
+cat gpurun_out/final_tests.txt gpurun_out/final_smoke.txt
+tail -c 3000 gpurun_out/final_bench.json
