@@ -10,6 +10,7 @@
 // the TN kernel, 8x8 (bf16) / 4x4 (f32) blocks are transposed in registers before they reach LDS.
 // 256 threads = 4 wave64; each wave owns MREP x NREP 16x16 accumulator fragments.
 #include "common.h"
+#include <type_traits>
 
 namespace ipoke {
 
@@ -1632,8 +1633,23 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
 // rows one LDS cycle touches fall into different bank groups.
 __device__ __forceinline__ int tn_swz(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
-// RM = reduction rows per ring slot: 64 (default, 2 slots) or 32 (4 slots in the same 64 KB: three in flight instead of one, but 40
-// instead of 20 barriers per flow-sized problem -- slower, see launch_tn).
+// The transposing reads are inline assembly, not __builtin_amdgcn_ds_read_tr16_b64: hipcc's wait-count insertion treats every
+// LDS read with a memory operand as a possible reader of ALL LDS-DMA writes in flight and puts `s_waitcnt vmcnt(0)` in front of the
+// first fragment read of an iteration -- the stage issued a few instructions earlier had to land before the stage already in
+// LDS could be read, i.e. DMA and math ran one after the other (conv2 shape, phase-ablation builds -DIPOKE_TN_ABL: DMA alone
+// 11.9 us, reads + matrix cores alone 13.2 us, epilogue 4.1 us, whole kernel 29.2 us = their sum).  The assembly reads carry no
+// memory operand; the kernel waits for them itself (tn_wait_frags ties the registers to the s_waitcnt).
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tn_tr4_t;
+template <int IMM> __device__ __forceinline__ tn_tr4_t tn_ds_tr(unsigned addr) {
+  tn_tr4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
+template <typename F> __device__ __forceinline__ void tn_wait_frags(F (&f)[6]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5])::"memory");
+}
+
+// RM = reduction rows per ring slot (64).
 template <int NSTAGE, int RM>
 __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) {
   typedef bf16_t T;
@@ -1646,8 +1662,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   typedef typename ET<T>::frag frag_t;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
-  typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tr4_t;
-  static_assert(RM == 64 || RM == 32, "stage height");
+  static_assert(RM == 64, "stage height: two 32-row reduction steps, read and multiplied in a two-phase software pipeline");
   constexpr int NI = RM / 32;                   // DMA instructions per thread, operand and stage
   constexpr int TILE = RM * 256;                // one operand image: 64 rows x 128 columns of bf16
   constexpr int STAGE = 2 * TILE;
@@ -1748,61 +1763,87 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     const int col = colbase + 4 * (i16 & 3);
     return rrow * 256 + (((col >> 3) ^ hsw) * 16) + ((col >> 2) & 1) * 8;
   };
-  int y_rd[4], x_rd[2];
+  // LDS byte addresses of this lane's fragment reads in slot 0, reduction step 0
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned y_rd[4], x_rd[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) y_rd[i] = frag_off(wn2 * 64 + 16 * i);
+  for (int i = 0; i < 4; ++i) y_rd[i] = lds0 + (unsigned)frag_off(wn2 * 64 + 16 * i);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) x_rd[j] = TILE + frag_off(wk * 32 + 16 * j);
-  auto tr_frag = [&](const unsigned char* base, int off) -> frag_t {
-    const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) tr4_t*)(base + off));
-    const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) tr4_t*)(base + off + 4 * 256));
-    frag_t f;
+  for (int j = 0; j < 2; ++j) x_rd[j] = lds0 + (unsigned)(TILE + frag_off(wk * 32 + 16 * j));
+  // the six operand fragments of reduction step KS (rows 32 KS .. 32 KS + 31) of the stage at byte offset sb: twelve reads in flight
+  auto read_frags = [&](frag_t (&f)[6], unsigned sb, auto ks_tag) {
+    constexpr int KS = decltype(ks_tag)::value;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
-    return f;
+    for (int q = 0; q < 6; ++q) {
+      const unsigned a = (q < 4 ? y_rd[q & 3] : x_rd[q & 1]) + sb;
+      const tn_tr4_t lo = tn_ds_tr<KS * 32 * 256>(a), hi = tn_ds_tr<KS * 32 * 256 + 4 * 256>(a);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f[q][e] = lo[e]; f[q][4 + e] = hi[e]; }
+    }
   };
+  typedef std::integral_constant<int, 0> K0;
+  typedef std::integral_constant<int, 1> K1;
 
   f32x4 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  int issued = 0;
-#pragma unroll
-  for (int s2 = 0; s2 < NSTAGE - 1; ++s2) { issue(s2, mb_begin + issued, issued < nst); ++issued; }
-  int slot = 0;
-  for (int it = 0; it < nst; ++it) {
-    wait_vmcnt<(NSTAGE - 2) * L>();               // this wave's share of the oldest slot has landed
-    __builtin_amdgcn_s_barrier();                 // ... and everybody else's; the slot refilled below is no longer read
-#if IPOKE_TN_ABL != 3
-    issue((slot + NSTAGE - 1) % NSTAGE, mb_begin + issued, issued < nst);
-#endif
-    ++issued;
-    const unsigned char* base = smem + slot * STAGE;
-    slot = (slot + 1) % NSTAGE;
-#if IPOKE_TN_ABL != 2
-#pragma unroll
-    for (int ks = 0; ks < NI; ++ks) {
-      frag_t fy[4], fx[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fy[i] = tr_frag(base, y_rd[i] + ks * 32 * 256);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fx[j] = tr_frag(base, x_rd[j] + ks * 32 * 256);
+  auto mma_frags = [&](frag_t (&f)[6]) {
 #if IPOKE_TN_ABL == 1
 #pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fy[i]));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(fx[j]));
+    for (int q = 0; q < 6; ++q) asm volatile("" :: "v"(f[q]));
 #else
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma64(fy[i], fx[j], acc[i][j]);
+      for (int j = 0; j < 2; ++j) mma64(f[i], f[4 + j], acc[i][j]);
 #endif
-    }
+  };
+
+  // Two-phase pipeline, one barrier per stage: while the matrix cores work on one 32-row step, the fragment reads of the next step
+  // (and, in the second phase, the DMA of the stage NSTAGE ahead) are in flight:
+  //   [wait FA] read FB = (it, 1) | mma FA | [stage it+1 landed, wait FB] barrier | DMA stage it+NSTAGE -> slot of it | read FA = (it+1, 0) | mma FB
+  int issued = 0;
+#pragma unroll
+  for (int s2 = 0; s2 < NSTAGE; ++s2) { issue(s2, mb_begin + issued, issued < nst); ++issued; }
+  wait_vmcnt<(NSTAGE - 1) * L>();                 // this wave's share of stage 0 has landed
+  __builtin_amdgcn_s_barrier();                   // ... and everybody else's
+  frag_t FA[6], FB[6];
+#if IPOKE_TN_ABL != 2
+  read_frags(FA, 0u, K0{});
 #endif
+  int slot = 0;
+  for (int it = 0; it < nst; ++it) {
+    const unsigned sb = (unsigned)(slot * STAGE);
+    const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+#if IPOKE_TN_ABL != 2
+    tn_wait_frags(FA);
+    read_frags(FB, sb, K1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(FA);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    wait_vmcnt<(NSTAGE - 2) * L>();               // this wave's share of stage it + 1 has landed
+#if IPOKE_TN_ABL != 2
+    tn_wait_frags(FB);                            // ... and its reads of stage it are complete: the slot may be refilled
+#endif
+    __builtin_amdgcn_s_barrier();
+#if IPOKE_TN_ABL != 3
+    issue(slot, mb_begin + issued, issued < nst);
+#endif
+    ++issued;
+#if IPOKE_TN_ABL != 2
+    read_frags(FA, (unsigned)(nslot * STAGE), K0{});     // (past the last stage: a padding slot, never multiplied)
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(FB);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    slot = nslot;
   }
+#if IPOKE_TN_ABL != 2
+  tn_wait_frags(FA);
+#endif
   wait_vmcnt<0>();
 #if IPOKE_TN_ABL == 4
 #pragma unroll
@@ -1863,23 +1904,14 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
                : ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.dY)) & 15) == 0)) {
     // ring depth: 2 slots (64 KB of LDS) let a weight-gradient workgroup share a CU with a chain GEMM workgroup (89 KB): the
     // same 29 us alone, 39 instead of 55 us inside the train step
-    // IPOKE_TN_STAGES (developer A/B): 2 (default) / 3 = 64-row stages, that many slots; 4 = four slots of 32 rows (measured, round 3:
-    // conv2 35.5 us against 29.7 us alone, 63.3 against 62.0 ms per step -- twice the barriers cost more than the deeper ring hides)
+    // IPOKE_TN_STAGES (developer A/B): 2 (default) or 3 ring slots.  (Four slots of 32 rows in the same 64 KB -- three stages in
+    // flight, twice the barriers -- measured 35.5 against 29.7 us alone and 63.3 against 62.0 ms per step in round 3; removed.)
     static const int nst = getenv("IPOKE_TN_STAGES") ? atoi(getenv("IPOKE_TN_STAGES")) : 2;
-    const bool r32 = nst != 2 && nst != 3 && p.g.S == 64;           // half-sample stages need the 8x8 latent's fixed row pattern
-    const int NST = r32 ? 4 : (nst == 3 ? 3 : 2);
-    const int RMv = r32 ? 32 : 64;
-    const size_t lds2 = (size_t)NST * 2 * RMv * 256 + 256 * sizeof(int);
-    auto kern = r32 ? igemm_tn_glds_kernel<4, 32> : NST == 2 ? igemm_tn_glds_kernel<2, 64> : igemm_tn_glds_kernel<3, 64>;
-    static bool attr_done2[3] = {false, false, false};
-    const int ai = r32 ? 0 : NST - 1;
-    if (!attr_done2[ai]) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2[ai] = true; }
-    if (r32) {                                                       // reduction blocks of 32 rows
-      const int nmb32 = ceil_div(p.g.M, 32);
-      if (p.splitm > nmb32) p.splitm = nmb32;
-      p.mb_per_split = ceil_div(nmb32, p.splitm);
-      p.rows_fixed = 1;
-    }
+    const int NST = nst == 3 ? 3 : 2;
+    const size_t lds2 = (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
+    auto kern = NST == 2 ? igemm_tn_glds_kernel<2, 64> : igemm_tn_glds_kernel<3, 64>;
+    static bool attr_done2[2] = {false, false};
+    if (!attr_done2[NST - 2]) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2[NST - 2] = true; }
     const int ntiles = p.tiles_n * p.tiles_k;
     const int cap = p.max_wgs > 0 ? p.max_wgs : ntiles;
     p.xa = p.xb = 0;
