@@ -560,6 +560,12 @@ int ipoke_l1_loss(const float* yhat_cl, int ldy, const float* x_nchw, int N, int
  * FVD evaluation (reference utils/metrics.py; host side in ipoke_amd/fvd.py).  The I3D convolutions are ipoke_conv_forward
  * with the eval-mode BatchNorm folded into weight and bias; these are the element-wise / window kernels around them.
  * ------------------------------------------------------------------------------------------- */
+/* motion_encoder.py:161 (ResNetMotionEncoder.conv1 = nn.Conv3d(3, 64, (3, 7, 7), 2, (1, 3, 3)) on the fp32 clip): the clip
+ * src[n][c][t][y][x] (element strides s_*, 3 channels) as channels-last pixels of FOUR channels of the compute dtype (the fourth 0),
+ * rows dst[((n*T + t)*H + y)*(pad_l + W + pad_r) + pad_l + x][4] with zero columns left and right -- a 7-tap window along x is
+ * then one 16-byte aligned run of 8 pixels and the stem runs as 21 taps of 32 channels through ipoke_conv_forward. */
+int ipoke_clip_to_cl4(const float* src, int64_t s_n, int64_t s_c, int64_t s_t, int64_t s_h, int64_t s_w, int N, int T, int H, int W,
+                      int pad_l, int pad_r, void* dst, int dtype, void* stream);
 /* metrics.py:787-792 (F.interpolate(..., mode='bilinear', size=(224, 224), align_corners=True) of every frame): frame f of clip n
  * of a strided fp32 tensor (element strides s_n, s_f, s_c, s_h, s_w) -> channels-last fp32 rows dst[(frame*Ho + y)*Wp + pad_l + x][C],
  * Wp = pad_l + Wo + pad_r, border columns zero (the stem convolution's TF-SAME padding along W is stored so that it can read a

@@ -149,6 +149,7 @@ SIGNATURES = {
     "ipoke_bilinear_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_cl_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_nchw_to_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_clip_to_cl4": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "ipoke_groupnorm_stats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
     "ipoke_groupnorm_stats_offset": (c_int64, [c_int, c_int, c_int]),
     "ipoke_groupnorm_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),

@@ -6,6 +6,7 @@
 // Statistics are fp32 and numerically robust: every block reduces a chunk of positions to
 // (count, mean, M2) per group and a finalize kernel merges chunks with Chan's parallel update.
 #include "common.h"
+#include "mcf_dev.h"
 
 namespace ipoke {
 
@@ -142,6 +143,7 @@ struct NormApply {
   const void* res; int ld_res;     // optional residual added before the activation
   int act;
   int pos_per_block;
+  float* stats_out = nullptr;      // gn_fused_kernel: [N][G][2] (mean, rstd), kept for the backward pass
 };
 // grid (chunks, N): a block normalises pos_per_block positions of ONE sample, so the per-channel scale / shift
 // (rstd*gamma, beta - mean*rstd*gamma) are built once in LDS and the inner loop is one FMA per element, no divisions.
@@ -198,6 +200,107 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
         *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.y) + m * a.ldy + cc * E16) = w;
       }
     }
+  }
+}
+
+// Small maps (the 16 x 16 ... 8 x 8 stages of the encoders): statistics, normalisation, affine, residual and activation of one
+// (sample, channel slab) in ONE launch instead of stats -> finalize -> apply.  Those three launches had 20 ... 160 workgroups
+// to work with (6 + 5 + 30 us for 256 positions x 256 channels x 20 samples); a slab of CS channels (whole groups) gives
+// N * C / CS workgroups, is read from memory once into LDS, and the exact two-pass variance (mean first, then the squared
+// deviations) is taken from there.  grid (C / CS, N), dynamic LDS = S * CS * sizeof(T).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const NormApply a, int CS, float eps) {
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  __shared__ float red[256 * E16];
+  __shared__ float chan[2][2048];            // per channel of the slab: totals, then (scale, shift)
+  T* tile = reinterpret_cast<T*>(gsm);
+  const int n = blockIdx.y, c0 = blockIdx.x * CS;
+  const int cvec = CS / E16, rp = 256 / cvec;
+  const int cc = threadIdx.x % cvec, rr = threadIdx.x / cvec;
+  const bool on = rr < rp;
+  const int cpg = a.C / a.G, ngl = CS / cpg;
+  const T* xb = reinterpret_cast<const T*>(a.x) + ((long)n * a.S) * a.ldx + c0 + cc * E16;
+  // ---- pass 1: memory -> LDS, per-channel sums
+  float s[E16];
+#pragma unroll
+  for (int e = 0; e < E16; ++e) s[e] = 0.f;
+  if (on) {
+    for (int p = rr; p < a.S; p += rp) {
+      const frag_t v = *reinterpret_cast<const frag_t*>(xb + (long)p * a.ldx);
+      *reinterpret_cast<frag_t*>(tile + (long)p * CS + cc * E16) = v;
+#pragma unroll
+      for (int e = 0; e < E16; ++e) s[e] += ET<T>::to_f32(v[e]);
+    }
+  }
+  auto channel_totals = [&](const float (&v)[E16]) {      // chan[0][c] = sum over the row lanes, fixed order
+#pragma unroll
+    for (int e = 0; e < E16; ++e) red[threadIdx.x * E16 + e] = on ? v[e] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CS; i += 256) {
+      const int cgi = i / E16, e = i - cgi * E16;
+      float t = 0.f;
+      for (int k = 0; k < rp; ++k) t += red[(k * cvec + cgi) * E16 + e];
+      chan[0][i] = t;
+    }
+    __syncthreads();
+  };
+  channel_totals(s);
+  const float inv_cnt = 1.f / ((float)a.S * (float)cpg);
+  for (int g = threadIdx.x; g < ngl; g += 256) {
+    float t = 0.f;
+    for (int c = 0; c < cpg; ++c) t += chan[0][g * cpg + c];
+    const float mean = t * inv_cnt;
+    for (int c = 0; c < cpg; ++c) chan[1][g * cpg + c] = mean;
+    if (a.stats_out) a.stats_out[((long)n * a.G + c0 / cpg + g) * 2] = mean;
+  }
+  __syncthreads();
+  // ---- pass 2 (LDS): squared deviations from the group mean
+  float mu[E16], q[E16];
+#pragma unroll
+  for (int e = 0; e < E16; ++e) { mu[e] = chan[1][cc * E16 + e]; q[e] = 0.f; }
+  if (on) {
+    for (int p = rr; p < a.S; p += rp) {
+      const frag_t v = *reinterpret_cast<const frag_t*>(tile + (long)p * CS + cc * E16);
+#pragma unroll
+      for (int e = 0; e < E16; ++e) { const float d = ET<T>::to_f32(v[e]) - mu[e]; q[e] += d * d; }
+    }
+  }
+  channel_totals(q);
+  for (int g = threadIdx.x; g < ngl; g += 256) {
+    float t = 0.f;
+    for (int c = 0; c < cpg; ++c) t += chan[0][g * cpg + c];
+    const float rstd = rsqrtf(t * inv_cnt + eps);                     // biased variance, as torch group_norm
+    for (int c = 0; c < cpg; ++c) chan[0][g * cpg + c] = rstd;
+    if (a.stats_out) a.stats_out[((long)n * a.G + c0 / cpg + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  // scale -> chan[0], shift -> chan[1] (a thread rewrites only the channels it has just read)
+  for (int i = threadIdx.x; i < CS; i += 256) {
+    const float mean = chan[1][i], rstd = chan[0][i];
+    const float gm = a.gamma ? a.gamma[c0 + i] : 1.f, bt = a.beta ? a.beta[c0 + i] : 0.f;
+    chan[0][i] = rstd * gm; chan[1][i] = bt - mean * rstd * gm;
+  }
+  __syncthreads();
+  // ---- pass 3 (LDS -> memory)
+  if (!on) return;
+  float sc[E16], sh[E16];
+#pragma unroll
+  for (int e = 0; e < E16; ++e) { sc[e] = chan[0][cc * E16 + e]; sh[e] = chan[1][cc * E16 + e]; }
+  for (int p = rr; p < a.S; p += rp) {
+    const long m = (long)n * a.S + p;
+    const frag_t v = *reinterpret_cast<const frag_t*>(tile + (long)p * CS + cc * E16);
+    frag_t r;
+    if (a.res) r = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.res) + m * a.ld_res + c0 + cc * E16);
+    frag_t w;
+#pragma unroll
+    for (int e = 0; e < E16; ++e) {
+      float f = ET<T>::to_f32(v[e]) * sc[e] + sh[e];
+      if (a.res) f += ET<T>::to_f32(r[e]);
+      w[e] = ET<T>::from_f32(act_apply(a.act, f));
+    }
+    *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.y) + m * a.ldy + c0 + cc * E16) = w;
   }
 }
 
@@ -313,6 +416,32 @@ __global__ void nchw_to_cl_kernel(const float* __restrict__ x, T* __restrict__ y
   }
 }
 
+// fp32 clip src[n][c][t][y][x] (element strides s_*; 3 channels) -> channels-last pixels of FOUR channels of T (the fourth is 0),
+// rows dst[((n*Tn + t)*H + y)*Wp + pad_l + x][4], zero columns left and right: with 8- / 16-byte pixels a 7-tap window along x is
+// one contiguous, 16-byte aligned run of 8 pixels, so the encoder's (3, 7, 7) stem runs as 21 taps of 32 channels on the LDS-DMA
+// GEMM (motion_encoder.py:161; the reference reads the same pixels through nn.Conv3d(3, 64, (3, 7, 7), 2, (1, 3, 3))).
+template <typename T>
+__global__ void clip_to_cl4_kernel(const float* __restrict__ src, long s_n, long s_c, long s_t, long s_h, long s_w, int Tn, int H, int W,
+                                   int pad_l, int Wp, long rows, T* __restrict__ dst) {
+  typedef typename Pack4<T>::type pack_t;
+  const long total = rows * Wp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xp = (int)(i % Wp); long r = i / Wp;
+    const int y = (int)(r % H); r /= H;
+    const int t = (int)(r % Tn); const long n = r / Tn;
+    const int x = xp - pad_l;
+    pack_t o;
+    if (x >= 0 && x < W) {
+      const float* q = src + n * s_n + t * s_t + y * s_h + x * s_w;
+      o[0] = ET<T>::from_f32(q[0]); o[1] = ET<T>::from_f32(q[s_c]); o[2] = ET<T>::from_f32(q[2 * s_c]);
+    } else {
+      o[0] = ET<T>::from_f32(0.f); o[1] = o[0]; o[2] = o[0];
+    }
+    o[3] = ET<T>::from_f32(0.f);
+    *reinterpret_cast<pack_t*>(dst + i * 4) = o;
+  }
+}
+
 static inline int grid1d(long n, int block = 256, int cap = 4096) {
   long g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -365,6 +494,34 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
   float* part = d->workspace;
   float* stats = part + (int64_t)d->N * nchunks * d->G * 3;
   hipStream_t s = STREAM(stream);
+  {
+    // small maps: one launch per norm (gn_fused_kernel).  Slab = the smallest run of whole groups that is a multiple of 16 bytes
+    // and at least 32 channels wide (64-byte rows), as long as the S x CS tile fits in LDS.  IPOKE_GN_FUSED=0: developer A/B.
+    static const bool fused_on = !(getenv("IPOKE_GN_FUSED") && atoi(getenv("IPOKE_GN_FUSED")) == 0);
+    const int cpg = d->C / d->G, esz = dtype == IPOKE_BF16 ? 2 : 4;
+    int unit = cpg; while (unit % e16) unit += cpg;                    // lcm(cpg, e16)
+    int CS = unit; while (CS < 32 && d->C % (CS + unit) == 0 && CS + unit <= d->C) CS += unit;
+    while (d->C % CS) CS += unit;
+    const size_t tile = (size_t)d->S * CS * esz;
+    if (fused_on && !d->y_f32 && !d->mod_gamma && CS <= 2048 && CS / e16 <= 256 && tile <= 128 * 1024 && d->ldy % e16 == 0 &&
+        (!d->res || d->ld_res % e16 == 0)) {
+      NormApply a;
+      a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.y_f32 = 0; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
+      a.stats = nullptr; a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = nullptr; a.mod_beta = nullptr; a.ld_mod = 0; a.mod_N = 0;
+      a.res = d->res; a.ld_res = d->ld_res; a.act = d->act; a.pos_per_block = 0; a.stats_out = stats;
+      if (dtype == IPOKE_BF16) {
+        static bool attr_bf = false;
+        if (!attr_bf) { IPK_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_bf = true; }
+        hipLaunchKernelGGL(gn_fused_kernel<bf16_t>, dim3(d->C / CS, d->N), dim3(256), tile, s, a, CS, d->eps);
+      } else {
+        static bool attr_f = false;
+        if (!attr_f) { IPK_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_f = true; }
+        hipLaunchKernelGGL(gn_fused_kernel<float>, dim3(d->C / CS, d->N), dim3(256), tile, s, a, CS, d->eps);
+      }
+      IPK_LAUNCH_CHECK();
+      return IPOKE_OK;
+    }
+  }
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, d->N), dim3(256), 0, s, (const bf16_t*)d->x, d->S, d->ldx, d->C, d->G, ppb, part),
     hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, d->N), dim3(256), 0, s, (const float*)d->x, d->S, d->ldx, d->C, d->G, ppb, part));
@@ -437,6 +594,22 @@ extern "C" int ipoke_bilinear_cl(const float* x_nchw, float* y_cl, int N, int C,
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
+extern "C" int ipoke_clip_to_cl4(const float* src, int64_t s_n, int64_t s_c, int64_t s_t, int64_t s_h, int64_t s_w, int N, int T, int H,
+                                 int W, int pad_l, int pad_r, void* dst, int dtype, void* stream) {
+  IPK_REQUIRE(src && dst && N >= 1 && T >= 1 && H >= 1 && W >= 1 && pad_l >= 0 && pad_r >= 0, "bad arguments");
+  IPK_REQUIRE(dtype == IPOKE_BF16 || dtype == IPOKE_F32, "bad dtype");
+  const int Wp = pad_l + W + pad_r;
+  const long rows = (long)N * T * H;
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(clip_to_cl4_kernel<bf16_t>, dim3(grid1d(rows * Wp, 256, 16384)), dim3(256), 0, STREAM(stream), src, (long)s_n, (long)s_c,
+                       (long)s_t, (long)s_h, (long)s_w, T, H, W, pad_l, Wp, rows, (bf16_t*)dst);
+  else
+    hipLaunchKernelGGL(clip_to_cl4_kernel<float>, dim3(grid1d(rows * Wp, 256, 16384)), dim3(256), 0, STREAM(stream), src, (long)s_n, (long)s_c,
+                       (long)s_t, (long)s_h, (long)s_w, T, H, W, pad_l, Wp, rows, (float*)dst);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
 extern "C" int ipoke_cl_to_nchw(const void* x_cl, int ld, float* y, int N, int C, int S, int dtype, void* stream) {
   IPK_REQUIRE(x_cl && y, "null tensor");
   DISPATCH_T(dtype,

@@ -11,6 +11,7 @@ first-stage training (L1 + KL) lives in ``ipoke_amd.first_stage_train`` and is r
 ``SpadeCondMotionModel.training_loss``.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -107,6 +108,9 @@ class _Norm(nn.Module):
         return K.group_norm(x, self.groups, dtype, act=act, res=res)
 
 
+_STEM_FOLD = os.environ.get("IPOKE_NO_STEM_FOLD", "0") != "1"      # developer A/B: conv1 of the 3-D encoder read in place
+
+
 # ---------------------------------------------------------------------------------------------- 3-D encoder
 class BasicBlock(nn.Module):
     """motion_encoder.py:45-74."""
@@ -177,14 +181,54 @@ class ResNetMotionEncoder(nn.Module):
             c[key] = (wop, kc, b)
         return c[key]
 
+    def _stem_operand(self):
+        """conv1 as 21 taps (kd, kh) of 32 channels: channel 4*kw + c of a tap is weight[:, c, kd, kh, kw] (kw < 7, c < 3), the rest 0."""
+        c = self.conv1._cache()
+        key = ("stem", self.dtype)
+        if key not in c:
+            with torch.no_grad():
+                w = self.conv1.weight.detach().float()                       # [64][3][3][7][7]
+                buf = torch.zeros(w.shape[0], 3, 7, 8, 4, dtype=torch.float32, device=w.device)
+                buf[:, :, :, :7, :3] = w.permute(0, 2, 3, 4, 1)
+                c[key] = buf.reshape(w.shape[0], 21 * 32).to(ops.torch_dtype(self.dtype)).contiguous()
+        return c[key]
+
+    def _stem(self, x):
+        """conv1 on the fp32 clip.  A (3, 7, 7) window over 3 channels read in place is 147 taps of 3 strided floats (653 us at
+        B = 20, 16 x 128 x 128 through the register-staged kernel); with the clip rewritten once as padded channels-last pixels of four
+        channels (ipoke_clip_to_cl4) a 7-tap run along x is one aligned 8-pixel read and the convolution 21 taps of 32 channels on
+        the LDS-DMA kernel.  Descriptor: 'double pixels' of 8 channels along x (stride 1) so that every tap start is 16-byte aligned."""
+        dt = self.dtype
+        B, C, T, H, W = x.shape
+        conv = self.conv1
+        if (not _STEM_FOLD or C != 3 or conv.k != (3, 7, 7) or conv.stride != (2, 2, 2) or conv.pad != (1, 3, 3) or W % 2
+                or conv.bias is not None):
+            st = (x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4))
+            return conv.run(None, dt, src_f32=(x, B, C, (T, H, W), st))
+        Wp = W + 6
+        clip = torch.empty(B * T * H * Wp, 4, dtype=ops.torch_dtype(dt), device=x.device)
+        check(_lib.lib().ipoke_clip_to_cl4(ptr(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4), B, T, H, W, 3, 3,
+                                           ptr(clip), ops._dt(dt), _lib.current_stream()))
+        odhw = ((T + 2 - 3) // 2 + 1, (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1)
+        wop = self._stem_operand()
+        d = ops.conv_desc(B, (T, H, odhw[2]), odhw, (3, 7, 1), (2, 2, 1), (1, 3, 0))
+        d.A = clip.data_ptr(); d.a_f32 = 0
+        d.a_sn, d.a_sd, d.a_sh, d.a_sw, d.a_sc = T * H * Wp * 4, H * Wp * 4, Wp * 4, 8, 1
+        d.a_coff = 0; d.Kc_real = 32; d.Kc = 32
+        d.W = wop.data_ptr(); d.ldw = wop.shape[1]; d.Nout = conv.cout
+        d.bias = 0; d.act = _lib.ACT_NONE
+        y = torch.empty(B * odhw[0] * odhw[1] * odhw[2], K.round_up(conv.cout, K.e16(dt)), dtype=ops.torch_dtype(dt), device=x.device)
+        d.C = y.data_ptr(); d.ldc = y.shape[1]
+        ops.conv_forward(d, dt)
+        return K.CL(y, B, odhw, conv.cout)
+
     @torch.no_grad()
     def forward(self, x, eps=None):
         _lib.require_gpu()
         dt = self.dtype
         B, C, T, H, W = x.shape
         x = x.float()
-        st = (x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4))
-        h = self.conv1.run(None, dt, src_f32=(x, B, C, (T, H, W), st))
+        h = self._stem(x)
         h = self.bn1.run(h, dt, act=_lib.ACT_RELU)
         layers = [self.layer1, self.layer2, self.layer3] + ([self.layer4] if self.stride4 is not None else []) + (
             [self.layer5] if self.has5 else [])

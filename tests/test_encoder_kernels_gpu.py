@@ -1,0 +1,90 @@
+"""GPU parity of the kernels of the frozen-encoder phase: the one-launch GroupNorm of small maps (csrc/norm.hip gn_fused_kernel)
+against torch.nn.functional.group_norm, the four-channel clip rewrite (ipoke_clip_to_cl4) and the folded (3, 7, 7) stem of the 3-D
+encoder (motion_encoder.py:161) against the same convolution read in place and against torch's conv3d."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ipoke_amd import _lib, configs, nn as K, ops
+from ipoke_amd import first_stage as FS
+from ipoke_amd._lib import check, ptr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# N, C, H, W, groups (0: InstanceNorm), affine, residual, act -- the shapes of the encoders' 32 x 32 ... 8 x 8 stages and ragged ones
+GN_CASES = [
+    (20, 256, 16, 16, 16, True, True, "relu"),
+    (4, 256, 8, 8, 16, True, True, "relu"),
+    (3, 128, 32, 64, 16, True, False, "relu"),       # S = 2048, 8 channels per group
+    (2, 64, 32, 32, 16, True, True, "none"),         # 4 channels per group: a slab spans several groups
+    (2, 64, 16, 16, 0, False, False, "elu"),         # InstanceNorm
+    (2, 48, 5, 7, 16, True, False, "none"),          # 3 channels per group, ragged position count
+    (1, 512, 8, 8, 16, True, False, "relu"),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", GN_CASES, ids=[f"n{c[0]}c{c[1]}s{c[2] * c[3]}g{c[4]}" for c in GN_CASES])
+def test_groupnorm_small_maps_vs_torch(case, dtype):
+    N, C, H, W, G, affine, use_res, act = case
+    gen = torch.Generator().manual_seed(C + H)
+    x = 2.0 * torch.randn(N, C, H, W, generator=gen) + 0.7          # a mean far from 0: the variance must not cancel
+    gamma = 1 + 0.3 * torch.randn(C, generator=gen) if affine else None
+    beta = 0.2 * torch.randn(C, generator=gen) if affine else None
+    res = torch.randn(N, C, H, W, generator=gen) if use_res else None
+    groups = C if G == 0 else G
+    xc = K.from_nchw(x.to(DEV), dtype)
+    rc = K.from_nchw(res.to(DEV), dtype) if use_res else None
+    xr = K.to_nchw(xc, dtype).cpu()                                   # the (bf16-rounded) values the kernel sees
+    rr = K.to_nchw(rc, dtype).cpu() if use_res else None
+    y = F.group_norm(xr, groups, gamma, beta, eps=1e-5)
+    if use_res:
+        y = y + rr
+    y = {"relu": torch.relu, "elu": F.elu, "none": lambda v: v}[act](y)
+    actc = {"relu": _lib.ACT_RELU, "elu": _lib.ACT_ELU, "none": _lib.ACT_NONE}[act]
+    out = K.group_norm(xc, groups, dtype, None if gamma is None else gamma.to(DEV), None if beta is None else beta.to(DEV), act=actc, res=rc)
+    got = K.to_nchw(out, dtype).cpu()
+    err = (got - y).abs().max().item()
+    assert err <= (2e-5 if dtype == "f32" else 4e-2) * max(1.0, y.abs().max().item()), err
+
+
+def test_clip_to_cl4():
+    gen = torch.Generator().manual_seed(3)
+    B, T, H, W = 2, 3, 6, 10
+    x = torch.randn(B, T + 1, 3, H, W, generator=gen).to(DEV)[:, 1:].transpose(1, 2)       # strided [B, 3, T, H, W] view, as the model passes it
+    assert not x.is_contiguous()
+    for dtype in ("f32", "bf16"):
+        Wp = W + 6
+        dst = torch.full((B * T * H * Wp, 4), 7.0, dtype=ops.torch_dtype(dtype), device=DEV)
+        check(_lib.lib().ipoke_clip_to_cl4(ptr(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4), B, T, H, W, 3, 3,
+                                           ptr(dst), ops._dt(dtype), _lib.current_stream()))
+        want = torch.zeros(B, T, H, Wp, 4, device=DEV)
+        want[:, :, :, 3:3 + W, :3] = x.permute(0, 2, 3, 4, 1)
+        assert torch.equal(dst.float().view(B, T, H, Wp, 4), want.to(ops.torch_dtype(dtype)).float())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_folded_stem_matches_conv3d(dtype, monkeypatch):
+    cfg = configs.first_stage_config(64, 32, 16)["architecture"]
+    dic = dict(cfg); dic.update(img_size=64, max_frames=15, full_seq=True)
+    torch.manual_seed(11)
+    enc = FS.ResNetMotionEncoder(dic, dtype=dtype).to(DEV)
+    x = torch.randn(2, 16, 3, 64, 64, device=DEV)[:, 1:].transpose(1, 2)                  # [2, 3, 15, 64, 64], strided
+    w = enc.conv1.weight.detach()
+    if dtype == "bf16":
+        ref = F.conv3d(x.bfloat16().float().cpu(), w.bfloat16().float().cpu(), None, 2, (1, 3, 3))
+    else:
+        ref = F.conv3d(x.cpu(), w.cpu(), None, 2, (1, 3, 3))
+    monkeypatch.setattr(FS, "_STEM_FOLD", True)
+    folded = enc._stem(x.float())
+    monkeypatch.setattr(FS, "_STEM_FOLD", False)
+    plain = enc._stem(x.float())
+    assert folded.dhw == plain.dhw == tuple(ref.shape[2:]) and folded.C == plain.C == 64
+    a, b = K.to_nchw(folded, dtype).cpu(), K.to_nchw(plain, dtype).cpu()
+    r = ref
+    assert a.shape == r.shape
+    tol = 2e-5 if dtype == "f32" else 2e-2
+    scale = r.abs().max().item()
+    assert (a - r).abs().max().item() <= tol * scale, ((a - r).abs().max().item(), scale)
+    assert (a - b).abs().max().item() <= tol * scale
