@@ -57,6 +57,9 @@ struct NtParams {
 #ifndef IPOKE_TN_ABL
 #define IPOKE_TN_ABL 0
 #endif
+#ifndef IPOKE_H16_ABL         // the same for conv3x3_halo16_kernel: 1 matrix cores idle, 2 DMA and barriers only, 3 no DMA
+#define IPOKE_H16_ABL 0
+#endif
 
 // one problem of a batched weight-gradient launch (blockIdx.z): byte/float offsets against the launch's bases
 struct TnBatchEntry { long a_off, y_off, w_off; int kh, kw, ph, pw; };
@@ -1430,6 +1433,294 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
   }
 }
 
+// =============================================================================================
+// The same convolution for WIDE layers (>= 128 input channels, output channels in tiles of 128): the 3 x 3 x 3 stages of the 3-D
+// encoder at 128 / 256 channels, the 3 x 3 layers of the decoder, discriminators and VGG stack on 16 x 16 and larger maps.
+// As implicit GEMMs those launches stream (taps) x (input tile) + (output tiles) x (whole filter) through L2 -> LDS:
+// 128 -> 128 channels on 4 x 64 x 64 x 20 positions moves 2.3 GB of re-fetched input rows and 1.8 GB of filter per launch and runs
+// at the DMA rate (455 us, 26 % of the matrix peak).  Here a workgroup owns a 16 x 16 pixel patch of one depth slice and ALL 128
+// output channels of a tile: the patch's input with its halo (18 x 18 pixels, zero outside the map) is staged once per
+// (64-channel chunk, depth tap) and serves nine taps; the filter K-blocks (one tap x 64 channels x 128 outputs, 16 KB) stream
+// through a three-slot ring.  Per output the DMA traffic is a third of the implicit GEMM's and the loop is bound by the matrix
+// cores: 8 waves = 4 pixel-row groups x 2 channel halves, 64 x 64 outputs each, 32 MFMAs per wave and barrier.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo16_kernel(const NtParams p) {
+  typedef bf16_t T;
+  typedef typename ET<T>::frag frag_t;
+  typedef typename Pack4<T>::type pack_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int BM = 256, BN = 128, NTHR = 512, R = 4;
+  constexpr int TH = 16, TW = 16, HW = TW + 2, HROWS = (TH + 2) * HW;       // 324 halo pixels
+  constexpr int A_IT = 6;                                                   // 48 DMA pieces of 8 pixel rows >= 324 rows ...
+  constexpr int A_PIECES = (HROWS + 7) / 8;                                 // ... of which 41 hold pixels: the image buffer is 41 KB
+  constexpr int ABUF = A_PIECES * 1024, WSLOT = BN * 128, W_IT = WSLOT / (8 * 1024);
+  constexpr int MREP = 4, NREP = 4;
+  constexpr int EP = BN * 4 + 16;
+  constexpr unsigned kInvalid = 0xffffffffu;
+  static_assert(W_IT == 2 && 2 * ABUF + R * WSLOT >= BM * EP, "layout");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* abuf = smem;                              // 2 x ABUF: the halo image of a (chunk, depth tap), double-buffered
+  unsigned char* ring = smem + 2 * ABUF;                   // R filter K-blocks
+  unsigned char* dummy = ring + R * WSLOT;                 // landing zone of padding DMAs, 1 KB per wave
+  if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const GeomDev& g = p.g;
+  const int tiles_x = g.Wo / TW, tiles_y = g.Ho / TH;
+  const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, slice = tile / (tiles_x * tiles_y);
+  const int img = slice / g.Do, dz = slice - img * g.Do;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
+  const int kdn = g.taps / 9;                                  // depth taps: "virtual chunks" v = chunk * kdn + kd, nine K-blocks each
+  const int nch = (p.Kc >> 6) * kdn, nkb = nch * 9;
+  const int sgn = g.transposed ? -1 : 1;
+
+  const T* Abase = reinterpret_cast<const T*>(p.A);
+  const T* Wbase = reinterpret_cast<const T*>(p.W);
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+  unsigned a_src[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int row = (wave + 8 * i) * 8 + (lane >> 3), pos = lane & 7;
+    const int py = row / HW, px = row - py * HW, y = y0 - 1 + py, x = x0 - 1 + px;
+    a_src[i] = kInvalid;
+    if (row < HROWS && (unsigned)y < (unsigned)g.Hi && (unsigned)x < (unsigned)g.Wi)
+      a_src[i] = (unsigned)((long)img * p.a_sn + (long)y * p.a_sh + (long)x * p.a_sw + p.a_coff + ((pos ^ ((row >> 1) & 7)) * 8));
+  }
+  unsigned w_src[W_IT];
+#pragma unroll
+  for (int j = 0; j < W_IT; ++j) {
+    const int nl = (wave * W_IT + j) * 8 + (lane >> 3), n = n0 + nl, pos = lane & 7;
+    w_src[j] = n < p.Nout ? (unsigned)((long)n * p.ldw + ((pos ^ ((nl >> 1) & 7)) * 8)) : kInvalid;
+  }
+  // filter K-block wi_g = (virtual chunk, tap): element offset w_off = (kd * 9 + tap) * Kc + chunk * 64, kept incrementally
+  int wi_g = 0, wi_t = 0, wi_kd = 0, wi_ch = 0;
+  long w_off = 0;
+  auto issue_w = [&]() {
+    const bool in = wi_g < nkb;
+#pragma unroll
+    for (int j = 0; j < W_IT; ++j) {
+      const bool real = in && w_src[j] != kInvalid;
+      const T* src = real ? Wbase + w_src[j] + w_off : zero;
+      unsigned char* dst = in ? ring + (wi_g % R) * WSLOT + (wave * W_IT + j) * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+    ++wi_g;
+    const bool tap_wrap = wi_t == 8, kd_wrap = tap_wrap && wi_kd + 1 == kdn;
+    wi_t = tap_wrap ? 0 : wi_t + 1;
+    wi_kd = kd_wrap ? 0 : (tap_wrap ? wi_kd + 1 : wi_kd);
+    wi_ch = kd_wrap ? wi_ch + 1 : wi_ch;
+    w_off = kd_wrap ? (long)wi_ch * 64 : w_off + p.Kc;
+  };
+  int a_next = 0;
+  auto issue_a = [&]() {
+    // depth slice this virtual chunk reads: forward dz * sd - 1 + kd; data gradient (sd = 1, mirrored taps) dz + 1 - kd
+    const int kd = a_next % kdn;
+    const int dd = kdn == 3 ? (g.transposed ? dz + 1 - kd : dz * g.sd - 1 + kd) : dz;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bool real = a_next < nch && a_src[i] != kInvalid && (unsigned)dd < (unsigned)g.Di;
+      const T* src = real ? Abase + a_src[i] + (long)dd * p.a_sd + (a_next / kdn) * 64 : zero;
+      unsigned char* dst = a_next < nch && wave + 8 * i < A_PIECES ? abuf + (a_next & 1) * ABUF + (wave + 8 * i) * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+    ++a_next;
+  };
+  issue_a();
+  issue_w(); issue_w(); issue_w();
+
+  const int qlo = lane >> 4;
+  int b_rd[NREP];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int n = wn * 64 + j * 16 + (lane & 15);
+    b_rd[j] = n * 128 + ((qlo ^ ((n >> 1) & 7)) * 16);
+  }
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragments of K-block kb (tap t of the image in buffer ci & 1, filter slot kb % R)
+  auto read_frags = [&](frag_t (&fa)[2][MREP], frag_t (&fb)[2][NREP], int kb, int ci_, int t_) {
+    const unsigned char* ab = abuf + (ci_ & 1) * ABUF;
+    const unsigned char* wb = ring + (kb % R) * WSLOT;
+    const int th = t_ / 3, tw = t_ - 3 * th;
+    // halo row of output pixel (wm*4 + i, lane & 15) under this tap
+    const int sr0 = (wm * 4 + 1 + sgn * (th - 1)) * HW + (lane & 15) + 1 + sgn * (tw - 1);
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) {
+        const int sr = sr0 + i * HW;
+        fa[hs][i] = *reinterpret_cast<const frag_t*>(ab + sr * 128 + (((hs * 4 + qlo) ^ ((sr >> 1) & 7)) * 16));
+      }
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) fb[hs][j] = *reinterpret_cast<const frag_t*>(wb + (b_rd[j] ^ (hs * 64)));
+    }
+  };
+  auto mma_frags = [&](frag_t (&fa)[2][MREP], frag_t (&fb)[2][NREP]) {
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[hs][i], fb[hs][j], acc[i][j]);
+  };
+  // Round r: [K-block r + 1 has landed] barrier | DMA of K-block r + 3 (and, every ninth round, of the next halo image) | fragment
+  // reads of K-block r + 1 into the other register set | 32 MFMAs on K-block r, two MFMAs per read in issue order.  The LDS latency
+  // of a round's reads is covered by the previous round's matrix work; a filter block has two rounds to land.  DMA order inside a
+  // round is filter first, image second, so that the image (needed nine rounds later) is not the newest transfer when the next
+  // rounds wait for their filter block: vmcnt counts 8, 8, 2, 2, ... over a nine-round period.  (Measured and dropped: one image
+  // piece per round with a constant vmcnt -- the per-round address arithmetic costs more than the uniform rounds gain, 349 vs 319 us.)
+  frag_t fa0[2][MREP], fb0[2][NREP], fa1[2][MREP], fb1[2][NREP];
+  wait_vmcnt<2 * W_IT>();                        // image 0 and K-block 0
+  __builtin_amdgcn_s_barrier();
+  read_frags(fa0, fb0, 0, 0, 0);
+  int ci = 0, t = 0;                             // image / tap of K-block r
+  auto round = [&](int r, frag_t (&fa_cur)[2][MREP], frag_t (&fb_cur)[2][NREP], frag_t (&fa_nxt)[2][MREP], frag_t (&fb_nxt)[2][NREP]) {
+    if (t == 1 || t == 2) wait_vmcnt<A_IT + W_IT>(); else wait_vmcnt<W_IT>();
+    __builtin_amdgcn_s_barrier();
+    const int tn = t == 8 ? 0 : t + 1, cn = t == 8 ? ci + 1 : ci;
+#if IPOKE_H16_ABL != 2
+    read_frags(fa_nxt, fb_nxt, r + 1, cn, tn);      // (past the last K-block: stale LDS contents, never multiplied)
+#if IPOKE_H16_ABL == 1
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(fa_cur[hs][i])); asm volatile("" :: "v"(fb_cur[hs][i])); }
+#else
+    // first half of the matrix work, one fragment read per MFMA in issue order: with the sixteen reads in front, eight waves queue
+    // 128 ds_read_b128 on the LDS pipe after every barrier before any of them reaches its first MFMA (no-DMA build: 0.95 -> 0.79 us
+    // per round, against 0.54 of MFMA time)
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) GEMM_MMA(fa_cur[0][i], fb_cur[0][j], acc[i][j]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#endif
+#endif
+#if IPOKE_H16_ABL != 3
+    // the round's transfers are issued between the two halves: behind the barrier they would keep every wave off the matrix cores
+    issue_w();                                   // K-block r + 3 -> the slot of K-block r - 1
+    if (t == 0) issue_a();                       // image ci + 1 -> the buffer of image ci - 1 (a padding transfer past the end)
+#endif
+#if IPOKE_H16_ABL == 0
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) GEMM_MMA(fa_cur[1][i], fb_cur[1][j], acc[i][j]);
+#endif
+    t = tn; ci = cn;
+  };
+  for (int r = 0; r < nkb; r += 2) {
+    round(r, fa0, fb0, fa1, fb1);
+    if (r + 1 < nkb) round(r + 1, fa1, fb1, fa0, fb0);
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+  // park the sums for the sweep: tile row = pixel (wm*4 + i, lane & 15), column = wn*64 + 16 j + 4 (lane >> 4) + e
+  {
+    unsigned char* st = smem + ((wm * 4) * 16 + (lane & 15)) * EP + (wn * 64 + (lane >> 4) * 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(st + i * 16 * EP + j * 64) = acc[i][j];
+  }
+  __syncthreads();
+  const long mbase = ((long)slice * g.Ho + y0) * g.Wo + x0;
+  const bool vec_ok = (p.Nout & 3) == 0;
+  constexpr int G4 = BN / 4;
+  for (int idx = tid; idx < BM * G4; idx += NTHR) {
+    const int row = idx / G4, c4 = idx - row * G4;
+    const long m = mbase + (long)(row >> 4) * g.Wo + (row & 15);
+    const int n = n0 + 4 * c4;
+    if (n >= p.n_pad) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * EP + c4 * 16);
+    const bool full = vec_ok && n + 3 < p.Nout;
+    if (p.bias) {
+      if (full) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      else for (int e = 0; e < 4; ++e) if (n + e < p.Nout) v[e] += p.bias[n + e];
+    }
+    if (p.act != IPOKE_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fast_act<T>(p.act, v[e]);
+    }
+    if (p.dact) {
+      const T* dp = reinterpret_cast<const T*>(p.dact) + m * p.ld_dact + n;
+      if (full && (p.ld_dact & 3) == 0) {
+        const pack_t y = *reinterpret_cast<const pack_t*>(dp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_out(p.dact_act, ET<T>::to_f32(y[e]));
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.Nout) v[e] *= act_grad_from_out(p.dact_act, ET<T>::to_f32(dp[e]));
+      }
+    }
+    if (!full) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e >= p.Nout) v[e] = 0.f;
+    }
+    if (p.c_f32) {
+      float* Cp = reinterpret_cast<float*>(p.C) + m * p.ldc + p.c_coff;
+      if (full && p.c_cstride == 1 && ((p.ldc | p.c_coff) & 3) == 0) *reinterpret_cast<f32x4*>(Cp + n) = v;
+      else for (int e = 0; e < 4; ++e) if (n + e < p.Nout) Cp[(long)(n + e) * p.c_cstride] = v[e];
+    } else {
+      T* Cp = reinterpret_cast<T*>(p.C) + m * p.ldc + p.c_coff + n;
+      if (n + 3 < p.n_pad && ((p.ldc | p.c_coff) & 3) == 0) {
+        pack_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ET<T>::from_f32(v[e]);
+        *reinterpret_cast<pack_t*>(Cp) = o;
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.n_pad) Cp[e] = ET<T>::from_f32(v[e]);
+      }
+    }
+  }
+}
+
+static bool halo16_applicable(const NtParams& p) {
+  // IPOKE_HALO16 (developer A/B): 0 off, 1 (default) where measured faster, 2 wherever the kernel can run
+  // (read on every call -- a launch is tens of microseconds -- so that the parity tests can force the kernel onto small shapes)
+  const char* mode_s = getenv("IPOKE_HALO16");
+  const int mode = mode_s ? atoi(mode_s) : 1;
+  const GeomDev& g = p.g;
+  if (!mode || p.a_f32 || !(g.taps == 9 || g.taps == 27) || g.khw != 9 || g.kw != 3) return false;
+  const bool flat = g.taps == 9 && g.Di == 1 && g.Do == 1 && g.pd == 0 && g.sd == 1;
+  const bool deep = g.taps == 27 && g.pd == 1 && (p.a_sd & 7) == 0 && (g.sd == 1 ? g.Di == g.Do : (!g.transposed && g.sd == 2));
+  if (!(flat || deep)) return false;
+  const bool can = g.Hi == g.Ho && g.Wi == g.Wo && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
+                   p.Kc % 64 == 0 && p.Kc_real == p.Kc && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot && p.splitk == 1 && !p.c_acc &&
+                   ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 &&
+                   (long)(g.M / g.S) * p.a_sn + (long)g.Di * p.a_sd + (long)g.Hi * p.a_sh + p.Kc < (1L << 31) && (long)p.Nout * p.ldw < (1L << 31);
+  if (!can) return false;
+  if (mode == 2) return true;
+  // Measured (scripts/probe_halo16.py, B = 20, against the kernels used before): 128 -> 128 channels on 4 x 64 x 64: 304 vs 485 us;
+  // 64 -> 128, depth stride 2, 8 x 64 x 64: 175 vs 302; 2-D 128 -> 128 on 64 x 64 at B = 32: 52 vs 73 -- but 256 -> 256 on
+  // 2 x 32 x 32 (320 workgroups = 1.25 rounds of the chip): 207 vs 201, 2-D 64 x 64 at B = 20 (320): 47 vs 45, 16 x 16 maps (40 - 80
+  // workgroups): 39 vs 19.  The kernel holds one workgroup per CU, so it is taken when the grid fills whole rounds of 256 to >= 80 %
+  // and the 128-wide output tile is not mostly padding; 64-channel 2-D layers stay with conv3x3_halo_kernel.
+  const long wgs = (long)(g.M / 256) * ceil_div(p.Nout, 128), rounds = (wgs + 255) / 256;
+  return (deep ? p.Kc >= 64 : p.Kc >= 128) && p.Nout >= 96 && wgs >= 256 && wgs * 10 >= rounds * 256 * 8;
+}
+static int launch_conv3x3_halo16(NtParams& p, hipStream_t s) {
+  const size_t lds = 2 * 41 * 1024 + 4 * 128 * 128 + 8 * 1024;
+  auto kern = conv3x3_halo16_kernel;
+  static bool attr_done = false;
+  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  p.tiles_m = p.g.M / 256; p.tiles_n = ceil_div(p.Nout, 128); p.xa = p.xb = 0;
+  dim3 grid((unsigned)p.tiles_m, (unsigned)p.tiles_n);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
 static bool halo_applicable(const NtParams& p) {
   static const int on = getenv("IPOKE_HALO") ? atoi(getenv("IPOKE_HALO")) : 1;         // developer A/B: IPOKE_HALO=0 turns the kernel off
   const GeomDev& g = p.g;
@@ -1567,6 +1858,7 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
   const int M = p.g.M, N = p.Nout;
   if constexpr (sizeof(T) == 2) {
     if (s8_applicable(p)) return launch_conv3x3_s8(p, s);
+    if (halo16_applicable(p)) return launch_conv3x3_halo16(p, s);
     if (halo_applicable(p)) return launch_conv3x3_halo(p, s);
   }
   static const int forced = getenv("IPOKE_NT_TILE") ? atoi(getenv("IPOKE_NT_TILE")) : 0;     // developer override

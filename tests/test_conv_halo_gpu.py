@@ -1,4 +1,6 @@
-"""The halo-staged 3x3 convolution kernel (csrc/gemm.hip: conv3x3_halo_kernel -- 2-D 3x3 / stride 1 / pad 1 convolutions with
+"""The halo-staged 3x3 convolution kernels (csrc/gemm.hip: conv3x3_halo_kernel, and conv3x3_halo16_kernel for wide layers -- every
+test runs twice: with the dispatcher's own choice and with IPOKE_HALO16=2, which sends every shape the wide kernel can run to it)
+-- conv3x3_halo_kernel -- 2-D 3x3 / stride 1 / pad 1 convolutions with
 >= 64 dense input channels on maps of 16 x 16 and larger) through ipoke_conv_forward, against torch's fp32 convolution of the
 same bf16-rounded operands: forward with bias + activation, narrow fp32 outputs (the decoder's 3-channel head), several output
 tiles, channel offsets into a wider output, and the data-gradient form (mirrored taps, activation-derivative mask).  The
@@ -12,6 +14,15 @@ from ipoke_amd import _lib, nn as K, ops
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+
+@pytest.fixture(autouse=True, params=["dispatch", "halo16"])
+def _kernel_choice(request, monkeypatch):
+    if request.param == "halo16":
+        monkeypatch.setenv("IPOKE_HALO16", "2")
+    else:
+        monkeypatch.delenv("IPOKE_HALO16", raising=False)
+    yield
 
 
 def _rows(x):          # [N, C, H, W] -> channels-last bf16 rows
@@ -102,3 +113,19 @@ def test_halo_conv3d_forward_and_data_gradient(N, D, H, W, cin, cout):
     dx = K.conv(K.CL(g_rows, N, (D, H, W), cout), wop_t, kc_t, cin, (3, 3, 3), (1, 1, 1), (1, 1, 1), "bf16", transposed=True)
     got_dx = dx.t[:, :cin].float().reshape(N, D, H, W, cin).permute(0, 4, 1, 2, 3).cpu()
     assert (got_dx - x.grad).abs().max().item() <= 2e-2 * x.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("N,D,H,W,cin,cout", [(2, 6, 16, 32, 64, 128), (1, 5, 32, 16, 128, 96)])
+def test_halo_conv3d_depth_stride_2(N, D, H, W, cin, cout):
+    """layer1[0].conv1 of the 3-D encoder (motion_encoder.py:165: stride (2, 1, 1)): the depth halo reads slices 2 dz - 1 + kd."""
+    g = torch.Generator().manual_seed(D + cin)
+    x = torch.randn(N, cin, D, H, W, generator=g).to(torch.bfloat16).float()
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (5.2 * cin ** 0.5)).to(torch.bfloat16).float()
+    ref = F.conv3d(x, w, None, stride=(2, 1, 1), padding=1)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, cin).to(torch.bfloat16).contiguous().to(DEV)
+    wop, kc = K.weight_operand(w.to(DEV), "bf16")
+    y = K.conv(K.CL(rows, N, (D, H, W), cin), wop, kc, cout, (3, 3, 3), (2, 1, 1), (1, 1, 1), "bf16")
+    Do = ref.shape[2]
+    assert y.dhw == (Do, H, W)
+    got = y.t[:, :cout].float().reshape(N, Do, H, W, cout).permute(0, 4, 1, 2, 3).cpu()
+    assert (got - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
