@@ -1471,7 +1471,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, slice = tile / (tiles_x * tiles_y);
   const int img = slice / g.Do, dz = slice - img * g.Do;
   const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
-  const int kdn = g.taps / 9;                                  // depth taps: "virtual chunks" v = chunk * kdn + kd, nine K-blocks each
+  // Depth taps: "virtual chunks" v = chunk * kdn + (kd - kd_lo), nine K-blocks each.  Taps whose input slice lies outside the clip
+  // (the first / last output slices of a 3 x 3 x 3 convolution) contribute zeros: they are left out of the list -- a sixth of the
+  // work at depth 4, a third at depth 2.  Input slice of tap kd: forward dz * sd - 1 + kd; data gradient (sd = 1, mirrored) dz + 1 - kd.
+  int kd_lo = 0, kd_hi = 0;
+  if (g.taps == 27) {
+    if (g.transposed) { kd_lo = max(0, dz + 2 - g.Di); kd_hi = min(2, dz + 1); }
+    else { kd_lo = max(0, 1 - dz * g.sd); kd_hi = min(2, g.Di - dz * g.sd); }
+  }
+  const int kdn = kd_hi - kd_lo + 1;
   const int nch = (p.Kc >> 6) * kdn, nkb = nch * 9;
   const int sgn = g.transposed ? -1 : 1;
 
@@ -1495,7 +1503,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // filter K-block wi_g = (virtual chunk, tap): element offset w_off = (kd * 9 + tap) * Kc + chunk * 64, kept incrementally
   int wi_g = 0, wi_t = 0, wi_kd = 0, wi_ch = 0;
-  long w_off = 0;
+  const long w_off0 = (long)kd_lo * 9 * p.Kc;
+  long w_off = w_off0;
   auto issue_w = [&]() {
     const bool in = wi_g < nkb;
 #pragma unroll
@@ -1510,13 +1519,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     wi_t = tap_wrap ? 0 : wi_t + 1;
     wi_kd = kd_wrap ? 0 : (tap_wrap ? wi_kd + 1 : wi_kd);
     wi_ch = kd_wrap ? wi_ch + 1 : wi_ch;
-    w_off = kd_wrap ? (long)wi_ch * 64 : w_off + p.Kc;
+    w_off = kd_wrap ? w_off0 + (long)wi_ch * 64 : w_off + p.Kc;
   };
   int a_next = 0;
   auto issue_a = [&]() {
-    // depth slice this virtual chunk reads: forward dz * sd - 1 + kd; data gradient (sd = 1, mirrored taps) dz + 1 - kd
-    const int kd = a_next % kdn;
-    const int dd = kdn == 3 ? (g.transposed ? dz + 1 - kd : dz * g.sd - 1 + kd) : dz;
+    const int kd = kd_lo + a_next % kdn;
+    const int dd = g.taps == 27 ? (g.transposed ? dz + 1 - kd : dz * g.sd - 1 + kd) : dz;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const bool real = a_next < nch && a_src[i] != kInvalid && (unsigned)dd < (unsigned)g.Di;
@@ -1706,8 +1714,10 @@ static bool halo16_applicable(const NtParams& p) {
   // 2 x 32 x 32 (320 workgroups = 1.25 rounds of the chip): 207 vs 201, 2-D 64 x 64 at B = 20 (320): 47 vs 45, 16 x 16 maps (40 - 80
   // workgroups): 39 vs 19.  The kernel holds one workgroup per CU, so it is taken when the grid fills whole rounds of 256 to >= 80 %
   // and the 128-wide output tile is not mostly padding; 64-channel 2-D layers stay with conv3x3_halo_kernel.
+  // (a deep layer of depth <= 2 skips a third of its taps here and not in the implicit GEMM: that outweighs a ragged last round)
   const long wgs = (long)(g.M / 256) * ceil_div(p.Nout, 128), rounds = (wgs + 255) / 256;
-  return (deep ? p.Kc >= 64 : p.Kc >= 128) && p.Nout >= 96 && wgs >= 256 && wgs * 10 >= rounds * 256 * 8;
+  const bool shallow = deep && g.Do <= 2 && g.Di <= 2 * g.sd;
+  return (deep ? p.Kc >= 64 : p.Kc >= 128) && p.Nout >= 96 && wgs >= 256 && (wgs * 10 >= rounds * 256 * 8 || (shallow && wgs * 10 >= rounds * 256 * 6));
 }
 static int launch_conv3x3_halo16(NtParams& p, hipStream_t s) {
   const size_t lds = 2 * 41 * 1024 + 4 * 128 * 128 + 8 * 1024;

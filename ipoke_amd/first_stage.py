@@ -82,7 +82,24 @@ class _Conv(_Cached):
                 c[dtype] = (wop, kc, None if self.bias is None else self.bias.detach().float().contiguous())
         return c[dtype]
 
+    def _mid_operand(self, dtype):
+        """The kd = 1 slice of a (3, k, k) filter as a 2-D operand: on an input of depth 1 (pad 1) the other two depth taps only
+        ever see the zero padding -- two thirds of the multiplications of layer3 / layer4 of the 3-D encoder."""
+        c = self._cache()
+        key = ("mid", dtype)
+        if key not in c:
+            with torch.no_grad():
+                wop, kc = K.weight_operand(self.weight[:, :, 1:2].contiguous(), dtype, self.transposed)
+                c[key] = (wop, kc, None if self.bias is None else self.bias.detach().float().contiguous())
+        return c[key]
+
     def run(self, x, dtype, act=_lib.ACT_NONE, out_f32=False, src_f32=None):
+        if (_DEPTH1_SLICE and self.dims == 3 and x is not None and x.dhw[0] == 1 and self.k[0] == 3 and self.pad[0] == 1
+                and not self.transposed and not self.snorm):
+            wop, kc, b = self._mid_operand(dtype)
+            y = K.conv(x, wop, kc, self.cout, (1, self.k[1], self.k[2]), (1, self.stride[1], self.stride[2]), (0, self.pad[1], self.pad[2]),
+                       dtype, bias=b, act=act, out_f32=out_f32)
+            return y
         wop, kc, b = self.operand(dtype)
         out_pad = (0, self.pad[1], self.pad[2]) if self.transposed else (0, 0, 0)     # util.py:52 output_padding=padding
         return K.conv(x, wop, kc, self.cout, self.k, self.stride, self.pad, dtype, bias=b, act=act, transposed=self.transposed,
@@ -109,6 +126,7 @@ class _Norm(nn.Module):
 
 
 _STEM_FOLD = os.environ.get("IPOKE_NO_STEM_FOLD", "0") != "1"      # developer A/B: conv1 of the 3-D encoder read in place
+_DEPTH1_SLICE = os.environ.get("IPOKE_NO_DEPTH1_SLICE", "0") != "1"  # developer A/B: 3 x 3 x 3 filters on depth-1 inputs run all 27 taps
 
 
 # ---------------------------------------------------------------------------------------------- 3-D encoder
