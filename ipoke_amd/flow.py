@@ -249,7 +249,10 @@ class FlowEngine:
                 if failure:
                     return
                 try:
-                    fn(int(begin), int(end))
+                    if getattr(fn, "wants_piece", False):
+                        fn(int(begin), int(end), int(piece))
+                    else:
+                        fn(int(begin), int(end))
                 except BaseException as exc:          # noqa: BLE001
                     failure.append(exc)
             cb = _lib.GRAD_READY_FN(_ready)

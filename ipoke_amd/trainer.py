@@ -49,6 +49,10 @@ class SecondStageTrainer:
         if os.environ.get("IPOKE_NO_PREFETCH", "0") != "1" and torch.cuda.is_available():
             self.prefetch_stream = torch.cuda.Stream()
         self.prefetch_at_start = os.environ.get("IPOKE_PREFETCH_AT", "after_bwd") == "start"
+        # IPOKE_PREFETCH_AT=piece<k> (developer A/B): the next batch's encoders are queued when the backward pass has issued its
+        # k-th piece (of IPOKE_PIECES), ordered after that point of the chain -- their tail overlaps the rest of the backward pass
+        at = os.environ.get("IPOKE_PREFETCH_AT", "")
+        self.prefetch_piece = int(at[5:]) if at.startswith("piece") else None
         model.flow.train()
 
     def _optimizer_step(self, fn):
@@ -144,7 +148,18 @@ class SecondStageTrainer:
             native = self.native_opt and self._acc_count == 0 and not eng.shadow_stale
             if native:
                 self.opt.arm_native(grad_scale=1.0 / (self.world * self.accumulate_grad_batches))
-            eng.grad_ready_hook = (self.n_grad_buckets, self.ready_stream, None if native else self._grads_ready)
+            hook_fn = None if native else self._grads_ready
+            if native and prefetch and self.prefetch_piece is not None:
+                state = {"done": False}
+
+                def hook_fn(begin, end, piece, _state=state):
+                    if not _state["done"] and piece >= self.prefetch_piece:
+                        _state["done"] = True
+                        here = torch.cuda.Event()
+                        here.record()
+                        m.prefetch_flow_input(next_batch, self.prefetch_stream, after=here)
+                hook_fn.wants_piece = True
+            eng.grad_ready_hook = (self.n_grad_buckets, self.ready_stream, hook_fn)
             ok = False
             try:
                 loss.backward()               # exchanges and updates every slice from the engine's callbacks; on return the
@@ -153,8 +168,8 @@ class SecondStageTrainer:
                 eng.grad_ready_hook = None    # a backward outside train_step must not apply optimizer updates
                 if native and not ok:
                     self.opt.disarm_native()
-            if prefetch:                      # ... but are queued after the backward pass (host order = GPU start order)
-                m.prefetch_flow_input(next_batch, self.prefetch_stream, after=fwd_done)
+            if prefetch and not (native and self.prefetch_piece is not None and state["done"]):
+                m.prefetch_flow_input(next_batch, self.prefetch_stream, after=fwd_done)      # queued after the backward pass (host order = GPU start order)
             self._optimizer_step(self.opt.finish_native if native else self.opt.finish_step)
         else:
             loss.backward()
