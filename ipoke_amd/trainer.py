@@ -49,8 +49,10 @@ class SecondStageTrainer:
         if os.environ.get("IPOKE_NO_PREFETCH", "0") != "1" and torch.cuda.is_available():
             self.prefetch_stream = torch.cuda.Stream()
         self.prefetch_at_start = os.environ.get("IPOKE_PREFETCH_AT", "after_bwd") == "start"
-        # IPOKE_PREFETCH_AT=piece<k> (developer A/B): the next batch's encoders are queued when the backward pass has issued its
-        # k-th piece (of IPOKE_PIECES), ordered after that point of the chain -- their tail overlaps the rest of the backward pass
+        # IPOKE_PREFETCH_AT=piece<k> (developer A/B, measured round 3, NOT adopted): the next batch's encoders are queued when the
+        # backward pass has issued its k-th piece (of IPOKE_PIECES), ordered after that point of the chain, so that they overlap the rest
+        # of the backward pass instead of following it: 60.7 (k = 11) / 61.4 (k = 6 .. 10) against 59.1 ms -- beside the backward chain and
+        # its side streams the full-chip encoder kernels cost more than the 4 ms hole they fill (the same verdict as =start)
         at = os.environ.get("IPOKE_PREFETCH_AT", "")
         self.prefetch_piece = int(at[5:]) if at.startswith("piece") else None
         model.flow.train()
