@@ -225,6 +225,10 @@ typedef struct {
   /* ipoke_macow_unit_bwd only, optional: dtype [B*64][round_up(C, 32)] copy of this layer's input state (columns >= C zero) --
    * the A operand of the shifted-conv weight gradient in the matrix cores' own dtype, so that gradient runs on the LDS-DMA GEMM */
   void* x_op_save;
+  /* ipoke_macow_unit_fwd only, optional (layer 3 of the unit): the conditioning operand of the NICE coupling that follows the unit
+   * (NICE2d.forward, macow2.py:397-448: the net reads the channels zc_off + k * zc_stride, k < zc_cin, of the unit's output) as a
+   * dtype [B*64][zc_ld] matrix, columns zc_cin .. zc_ld - 1 zero -- what ipoke_extract_cols would produce in a launch of its own */
+  void* zc_out; int32_t zc_off, zc_stride, zc_cin, zc_ld;
 } ipoke_mcf_desc;
 int ipoke_mcf_shadow_dims(int C, int Cc, int dtype, int32_t* dims8);
 int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream);

@@ -64,7 +64,8 @@ class McfDesc(Structure):
                 ("W2T", c_void_p), ("W1T", c_void_p), ("dy", c_void_p), ("dld", c_void_p), ("dx", c_void_p),
                 ("dparams_save", c_void_p), ("dc_save", c_void_p), ("dbias_part", c_void_p),
                 ("post_log_scale", c_void_p), ("post_bias", c_void_p), ("y_post", c_void_p), ("post_part", c_void_p),
-                ("x_op_save", c_void_p)]
+                ("x_op_save", c_void_p),
+                ("zc_out", c_void_p), ("zc_off", c_int32), ("zc_stride", c_int32), ("zc_cin", c_int32), ("zc_ld", c_int32)]
 
 
 class NormDesc(Structure):

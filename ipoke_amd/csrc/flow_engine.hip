@@ -518,6 +518,12 @@ void set_a_dense(ipoke_conv_desc& d, const void* act, int ld, int kc) {
 
 int nice_splitk(const Ctx& c) { return max_splitk(*c.f, c.B); }
 // coupling `a` transforms exactly the channels coupling `b` conditions on (up -> dn pairs): a's transform also writes b's operand
+// coupling op `i` follows a fused MaCowUnit (ops i-6 .. i-1): the unit's forward kernel writes the coupling's conditioning operand
+// (IPOKE_NO_UNIT_ZC=1: a launch of ipoke_extract_cols instead, as in rounds 1-2)
+bool unit_feeds(const ipoke_flow* f, size_t i) {
+  static const int on = getenv("IPOKE_NO_UNIT_ZC") ? 0 : 1;
+  return on && i >= 6 && i < f->ops.size() && f->ops[i].type == OP_NICE && f->ops[i - 6].unit_head;
+}
 bool nice_feeds(const Op& a, const Op& b) {
   static const int on = getenv("IPOKE_NO_EXTRACT_FUSION") ? 0 : 1;
   return on && a.type == OP_NICE && b.type == OP_NICE && b.z_off == a.t_off && b.z_stride == a.t_stride && b.cin == a.cout;
@@ -1042,6 +1048,11 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
           if (mk.fuse_act >= 0) { d4[k].post_log_scale = params + f->ops[mk.fuse_act].p_ls; d4[k].post_bias = params + f->ops[mk.fuse_act].p_bias; }
           if (save) { d4[k].a2_save = l.rows(mk.ws_a, (int64_t)mk.K2p * f->esz); d4[k].scale_save = l.rowsf(mk.ws_b, mk.C); }
         }
+        if (unit_feeds(f, i + 6)) {
+          const Op& nx = f->ops[i + 6];
+          d4[3].zc_out = save ? l.rows(nx.ws_g, (int64_t)nx.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
+          d4[3].zc_off = nx.z_off; d4[3].zc_stride = nx.z_stride; d4[3].zc_cin = nx.cin; d4[3].zc_ld = nx.Kc1;
+        }
         rc = ipoke_macow_unit_fwd(d4, l.dtype, l.stream()); if (rc) return rc;
       }
       cur = nxt;
@@ -1078,7 +1089,7 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
         void* h1 = l.rows(save ? op.ws_a : l.plan.tmp_h1, hb);
         void* h2 = l.rows(save ? op.ws_b : l.plan.tmp_h2, hb);
         void* zc = save ? l.rows(op.ws_g, (int64_t)op.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
-        const bool have_zc = i > 0 && nice_feeds(f->ops[i - 1], op);
+        const bool have_zc = (i > 0 && nice_feeds(f->ops[i - 1], op)) || (!init && unit_feeds(f, i));
         rc = nice_net(l, op, in, h1, h2, zc, have_zc); if (rc) return rc;
         ipoke_affine_desc a; nice_affine_desc(l, op, a);
         void* ext = nullptr; int ext_ld = 0;

@@ -25,6 +25,7 @@ struct UnitLayer {
   const float* y_post; float* post_part;                    // bwd of the ActNorm: its saved output, [B][2C] partial sums
   void* dparams_save; void* dc_save; float* dbias_part;
   void* x_op;                                               // bwd: dtype [B*64][Cp] copy of x for the shifted-conv weight gradient (NULL: none)
+  void* zc; int zc_off, zc_stride, zc_cin, zc_ld;           // fwd: conditioning operand of the coupling behind the unit (NULL: none)
   int order;
 };
 struct UnitParams {
@@ -348,7 +349,20 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitP
           bf16x2 tv; tv[0] = ET<T>::from_f32(yv[0]); tv[1] = ET<T>::from_f32(yv[1]);
           *reinterpret_cast<bf16x2*>(xs + p * xs_pitch + c * (int)sizeof(T)) = tv;
           if (Lk.y) *reinterpret_cast<f32x2*>(Lk.y + (row0 + p) * ld + c) = yv;
+          if (Lk.zc) {                                        // (the rounded values just stored in xs)
+            T* zr = reinterpret_cast<T*>(Lk.zc) + (row0 + p) * Lk.zc_ld;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int rel = c + q - Lk.zc_off, kz = Lk.zc_stride == 2 ? rel >> 1 : rel;
+              if (rel >= 0 && kz < Lk.zc_cin && (Lk.zc_stride != 2 || !(rel & 1))) zr[kz] = tv[q];
+            }
+          }
         }
+      }
+      if (Lk.zc) {                                            // zero padding of the operand rows
+        const int npad = Lk.zc_ld - Lk.zc_cin;
+        T* zr = reinterpret_cast<T*>(Lk.zc) + row0 * Lk.zc_ld + Lk.zc_cin;
+        for (int i = tid; i < 64 * npad; i += kMcfThreads) { const int r = i / npad; zr[r * Lk.zc_ld + (i - r * npad)] = ET<T>::from_f32(0.f); }
       }
     }
     const float tot = block_sum(ld_acc, red);       // two barriers: the state update above is complete behind them
@@ -912,6 +926,9 @@ static int unit_params(UnitParams& U, const ipoke_mcf_desc* d, int dtype, bool b
     L.scale_save = s.scale_save; L.ld_slot = s.logdet_slot; L.post_ls = s.post_log_scale; L.post_bias = s.post_bias;
     L.x = s.x; L.y_post = s.y_post; L.post_part = s.post_part; L.dparams_save = s.dparams_save; L.dc_save = s.dc_save;
     L.dbias_part = s.dbias_part; L.order = s.order; L.x_op = bwd ? s.x_op_save : nullptr;
+    L.zc = bwd ? nullptr : s.zc_out; L.zc_off = s.zc_off; L.zc_stride = s.zc_stride; L.zc_cin = s.zc_cin; L.zc_ld = s.zc_ld;
+    if (L.zc) IPK_REQUIRE(k == 3 && (s.zc_stride == 1 || s.zc_stride == 2) && s.zc_cin >= 1 && s.zc_ld >= s.zc_cin && s.zc_off >= 0 &&
+                          s.zc_off + (s.zc_cin - 1) * s.zc_stride < C, "conditioning operand: layer 3 only, stride 1 or 2, columns inside the state");
     if (!bwd) IPK_REQUIRE(s.W1 && s.W2 && s.bias2, "null forward operand");
     else {
       IPK_REQUIRE(s.W1T && s.W2T && s.x && s.a2_save && s.scale_save && s.dparams_save && s.dc_save, "null backward operand");
