@@ -81,6 +81,13 @@ typedef struct {
   int32_t c_coff, c_cstride; /* column n is stored at c_coff + n*c_cstride                          */
   int32_t splitk;          /* >1: fp32 partials C[z][M][ldc], epilogue skipped (bias/act by consumer);
                               with c_accumulate: the K slices are atomically added into C instead      */
+  /* optional output scatter (c_scatter = 1; dtype or fp32 outputs, splitk = 1, no dact): output position (n, od = 0, oh, ow) is
+   * stored at row c_row0 + n*c_sn + oh*c_sh + ow*c_sw of C instead of row m -- the four sub-pixel phases of a stride-2
+   * ConvTranspose2d (util.py:52-55: 3 x 3, padding 1, output_padding 1) run as four stride-1 convolutions with 1 / 2 / 2 / 4 taps
+   * that write every second row and column of the up-sampled map, instead of one launch that multiplies 9 taps of which 2.25
+   * fall on input pixels. */
+  int32_t c_scatter;
+  int64_t c_sn, c_sh, c_sw, c_row0;
 } ipoke_conv_desc;
 
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);

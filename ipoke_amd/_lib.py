@@ -26,7 +26,8 @@ class ConvDesc(Structure):
         ("W", c_void_p), ("ldw", c_int32), ("Nout", c_int32),
         ("bias", c_void_p), ("act", c_int32), ("dact", c_void_p), ("ld_dact", c_int32), ("dact_act", c_int32),
         ("C", c_void_p), ("c_f32", c_int32), ("c_accumulate", c_int32), ("ldc", c_int64),
-        ("c_coff", c_int32), ("c_cstride", c_int32), ("splitk", c_int32)]
+        ("c_coff", c_int32), ("c_cstride", c_int32), ("splitk", c_int32),
+        ("c_scatter", c_int32), ("c_sn", c_int64), ("c_sh", c_int64), ("c_sw", c_int64), ("c_row0", c_int64)]
 
 
 class WgradDesc(Structure):

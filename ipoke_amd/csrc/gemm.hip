@@ -36,6 +36,7 @@ struct NtParams {
   int splitk, kb_per_split, n_pad;
   int tiles_m, tiles_n, xa, xb;
   int prio;            // != 0: raise the waves' issue priority (s_setprio)
+  int c_scatter; long c_sn, c_sh, c_sw, c_row0;      // output row of position (n, oh, ow) when c_scatter (ipoke_conv_desc)
 #ifdef IPOKE_GEMM_STAMPS
   long long* stamps = nullptr;   // probe build only (scripts/probe_gemm_stamps.py): 4 wall-clock stamps per workgroup
 #endif
@@ -177,6 +178,24 @@ __device__ __forceinline__ float fast_act(int act, float x) {
 // iteration's stores; measured 3.2-3.7 us per launch at the 80 x 128 tile.  The fast path is branch-free: a thread owns ONE
 // 4-column group (so its bias is loaded once) in ITER rows, the derivative-mask loads of all rows are issued before the
 // accumulators are parked, and ELU / mask are applied by select.
+// row of C that holds output position m (dense, or scattered: ipoke_conv_desc.c_scatter)
+__device__ __forceinline__ long out_row(const NtParams& p, int m) {
+  if (!p.c_scatter) return m;
+  const GeomDev& g = p.g;
+  int ow, oh, n;
+  if (g.pow2) {
+    ow = m & ((1 << g.lWo) - 1);
+    const int t1 = m >> g.lWo;
+    oh = t1 & ((1 << g.lHo) - 1);
+    n = t1 >> (g.lHo + g.lDo);
+  } else {
+    const int t1 = m / g.Wo; ow = m - t1 * g.Wo;
+    const int t2 = t1 / g.Ho; oh = t1 - t2 * g.Ho;
+    n = t2 / g.Do;
+  }
+  return p.c_row0 + (long)n * p.c_sn + (long)oh * p.c_sh + (long)ow * p.c_sw;
+}
+
 template <typename T, int WM, int WN, int MREP, int NREP, int NTHR = WM * WN * 64>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP][NREP], unsigned char* smem, int m0, int n0,
                                             int wm, int wn, int z, bool writer = true) {
@@ -188,7 +207,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP
   constexpr int G4F = BN / 4;
   if constexpr ((BM * G4F) % NTHR == 0 && NTHR % G4F == 0) {
     constexpr int ITER = BM * G4F / NTHR, RSTEP = NTHR / G4F;
-    const bool fast = p.splitk == 1 && !p.c_f32 && (p.Nout & 3) == 0 && m0 + BM <= g.M && n0 + BN <= p.Nout &&
+    const bool fast = p.splitk == 1 && !p.c_scatter && !p.c_f32 && (p.Nout & 3) == 0 && m0 + BM <= g.M && n0 + BN <= p.Nout &&
                       ((p.ldc | p.c_coff) & 3) == 0 && (p.act == IPOKE_ACT_NONE || p.act == IPOKE_ACT_ELU) &&
                       (!p.dact || ((p.ld_dact & 3) == 0 && p.dact_act == IPOKE_ACT_ELU));
     if (fast) {
@@ -305,7 +324,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP
       for (int r = 0; r < 4; ++r) if (n + r >= p.Nout) v[r] = 0.f;
     }
     if (p.c_f32) {
-      float* Cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + p.c_coff;
+      float* Cp = reinterpret_cast<float*>(p.C) + out_row(p, m) * p.ldc + p.c_coff;
       if (full && p.c_cstride == 1 && !p.c_acc && ((p.ldc | p.c_coff) & 3) == 0) {
         *reinterpret_cast<f32x4*>(Cp + n) = v;
       } else {
@@ -317,7 +336,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP
         }
       }
     } else {
-      T* Cp = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + p.c_coff + n;
+      T* Cp = reinterpret_cast<T*>(p.C) + out_row(p, m) * p.ldc + p.c_coff + n;
       // columns up to n_pad are written (zero beyond Nout) so that consumers can read a padded K
       if (n + 3 < p.n_pad && ((p.ldc | p.c_coff) & 3) == 0) {
         pack_t o;
@@ -1699,7 +1718,7 @@ static bool halo16_applicable(const NtParams& p) {
   const char* mode_s = getenv("IPOKE_HALO16");
   const int mode = mode_s ? atoi(mode_s) : 1;
   const GeomDev& g = p.g;
-  if (!mode || p.a_f32 || !(g.taps == 9 || g.taps == 27) || g.khw != 9 || g.kw != 3) return false;
+  if (!mode || p.a_f32 || p.c_scatter || !(g.taps == 9 || g.taps == 27) || g.khw != 9 || g.kw != 3) return false;
   const bool flat = g.taps == 9 && g.Di == 1 && g.Do == 1 && g.pd == 0 && g.sd == 1;
   const bool deep = g.taps == 27 && g.pd == 1 && (p.a_sd & 7) == 0 && (g.sd == 1 ? g.Di == g.Do : (!g.transposed && g.sd == 2));
   if (!(flat || deep)) return false;
@@ -1737,7 +1756,7 @@ static bool halo_applicable(const NtParams& p) {
   static const int on3 = getenv("IPOKE_HALO3D") ? atoi(getenv("IPOKE_HALO3D")) : 1;    // the 3 x 3 x 3 form alone
   const bool flat = g.taps == 9 && g.Di == 1 && g.Do == 1 && g.pd == 0;
   const bool deep = on3 && g.taps == 27 && g.Di == g.Do && g.pd == 1 && (p.a_sd & 7) == 0;
-  if (!(flat || deep)) return false;
+  if (!(flat || deep) || p.c_scatter) return false;
   if (deep) {     // measured (scripts/probe_halo3d.py, B = 20): 64 channels 16x64x64: 670 vs 997 us, 12x32x32: 126 vs 185 us; but 128
                   // channels 8x32x32: 271 vs 230, 256 channels 4x16x16: 141 vs 101, 512 channels: 255 vs 177 -> 64 input channels only
     if (p.Kc > 64) return false;
@@ -1834,7 +1853,7 @@ static int s8_samples_per_tile() {
 }
 static bool s8_applicable(const NtParams& p) {
   const GeomDev& g = p.g;
-  return s8_samples_per_tile() > 0 && !p.a_f32 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Hi == 8 && g.Wi == 8 &&
+  return s8_samples_per_tile() > 0 && !p.c_scatter && !p.a_f32 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Hi == 8 && g.Wi == 8 &&
          g.lDo == 0 && g.lHo == 3 && g.lWo == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 1 && g.pw == 1 &&
          p.Kc % 64 == 0 && p.Kc_real == p.Kc && p.Kc >= 256 && p.Nout <= 64 && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot &&
          ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && (long)(g.M >> 6) * p.a_sn + 7 * p.a_sh + 7 * p.a_sw + p.Kc < (1L << 31) &&
@@ -2293,6 +2312,8 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   p.C = d->C; p.c_f32 = d->c_f32; p.c_acc = d->c_accumulate; p.ldc = d->ldc; p.c_coff = d->c_coff;
   p.c_cstride = d->c_cstride <= 0 ? 1 : d->c_cstride;
   p.splitk = d->splitk < 1 ? 1 : d->splitk;
+  p.c_scatter = d->c_scatter; p.c_sn = d->c_sn; p.c_sh = d->c_sh; p.c_sw = d->c_sw; p.c_row0 = d->c_row0;
+  if (d->c_scatter) IPK_REQUIRE(p.splitk == 1 && !d->dact && !d->c_accumulate && p.g.Do == 1 && d->c_row0 >= 0, "output scatter: plain stores of a 2-D map");
   p.n_pad = d->Nout;
   if (!d->c_f32 && p.splitk == 1) {
     const long lim = d->ldc - d->c_coff;

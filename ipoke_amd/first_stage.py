@@ -93,7 +93,40 @@ class _Conv(_Cached):
                 c[key] = (wop, kc, None if self.bias is None else self.bias.detach().float().contiguous())
         return c[key]
 
+    _PHASE_TAPS = ((1,), (2, 0))      # output parity 0: tap 1 on input pixel i; parity 1: tap 2 on pixel i, tap 0 on pixel i + 1
+
+    def _phase_operands(self, dtype):
+        """The four sub-pixel phases of a 3 x 3 / stride 2 / padding 1 / output_padding 1 ConvTranspose2d (util.py:52-55) as
+        stride-1 convolutions: output pixel (2 i + a, 2 j + b) = sum over the taps of parity (a, b) -- 1, 2, 2, 4 of the 9."""
+        c = self._cache()
+        key = ("phases", dtype)
+        if key not in c:
+            with torch.no_grad():
+                w = self.weight_orig / K.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, True) if self.snorm else self.weight
+                wr = w.detach().transpose(0, 1)                                  # [cout, cin, kh, kw]
+                ops_ = {}
+                for a in (0, 1):
+                    for b in (0, 1):
+                        wp = wr[:, :, list(self._PHASE_TAPS[a])][:, :, :, list(self._PHASE_TAPS[b])].contiguous()
+                        ops_[(a, b)] = K.weight_operand(wp.unsqueeze(2), dtype)
+                c[key] = (ops_, None if self.bias is None else self.bias.detach().float().contiguous())
+        return c[key]
+
+    def _run_phases(self, x, dtype, act, out_f32):
+        ops_, b = self._phase_operands(dtype)
+        N, (_, Hi, Wi) = x.N, x.dhw
+        Ho, Wo = 2 * Hi, 2 * Wi
+        ldc = self.cout if out_f32 else K.round_up(self.cout, K.e16(dtype))
+        y = torch.empty(N * Ho * Wo, ldc, dtype=torch.float32 if out_f32 else ops.torch_dtype(dtype), device=x.t.device)
+        for (a, bb), (wop, kc) in ops_.items():
+            K.conv(x, wop, kc, self.cout, (1, 1 + a, 1 + bb), (1, 1, 1), (0, 0, 0), dtype, bias=b, act=act, out_f32=out_f32, out=y,
+                   odhw=(1, Hi, Wi), scatter=(Ho * Wo, 2 * Wo, 2, a * Wo + bb))
+        return K.CL(y, N, (1, Ho, Wo), self.cout)
+
     def run(self, x, dtype, act=_lib.ACT_NONE, out_f32=False, src_f32=None):
+        if (_CT_PHASES and self.transposed and self.dims == 2 and x is not None and self.k == (1, 3, 3) and self.stride == (1, 2, 2)
+                and self.pad == (0, 1, 1)):
+            return self._run_phases(x, dtype, act, out_f32)
         if (_DEPTH1_SLICE and self.dims == 3 and x is not None and x.dhw[0] == 1 and self.k[0] == 3 and self.pad[0] == 1
                 and not self.transposed and not self.snorm):
             wop, kc, b = self._mid_operand(dtype)
@@ -126,6 +159,7 @@ class _Norm(nn.Module):
 
 
 _STEM_FOLD = os.environ.get("IPOKE_NO_STEM_FOLD", "0") != "1"      # developer A/B: conv1 of the 3-D encoder read in place
+_CT_PHASES = os.environ.get("IPOKE_NO_CT_PHASES", "0") != "1"       # developer A/B: stride-2 ConvTranspose2d as one 9-tap launch
 _DEPTH1_SLICE = os.environ.get("IPOKE_NO_DEPTH1_SLICE", "0") != "1"  # developer A/B: 3 x 3 x 3 filters on depth-1 inputs run all 27 taps
 
 

@@ -67,14 +67,17 @@ def out_extent(i, k, s, p, transposed, out_pad=0):
 
 
 def conv(x, w_op, kc, cout, k, stride, pad, dtype, bias=None, act=_lib.ACT_NONE, transposed=False, out_pad=(0, 0, 0),
-         out_f32=False, src_f32=None, out=None):
+         out_f32=False, src_f32=None, out=None, odhw=None, scatter=None):
     """Implicit-GEMM convolution.  ``x`` is a CL, or ``src_f32`` = (tensor, N, C, dhw, strides(n,c,d,h,w)) for an
-    fp32 source read in place (input images)."""
+    fp32 source read in place (input images).  ``odhw``: output extent when it is not the symmetric-padding formula's (windows
+    that overhang the input read zeros).  ``scatter`` = (c_sn, c_sh, c_sw, c_row0): rows of ``out`` the positions are written to
+    (ipoke_conv_desc.c_scatter); the returned CL then describes this launch's positions only."""
     if src_f32 is not None:
         src, N, cin, dhw, st = src_f32
     else:
         N, cin, dhw = x.N, x.C, x.dhw
-    odhw = tuple(out_extent(i, kk, s, p, transposed, op) for i, kk, s, p, op in zip(dhw, k, stride, pad, out_pad))
+    if odhw is None:
+        odhw = tuple(out_extent(i, kk, s, p, transposed, op) for i, kk, s, p, op in zip(dhw, k, stride, pad, out_pad))
     M = N * odhw[0] * odhw[1] * odhw[2]
     d = ops.conv_desc(N, dhw, odhw, k, stride, pad, transposed)
     if src_f32 is not None:
@@ -96,6 +99,9 @@ def conv(x, w_op, kc, cout, k, stride, pad, dtype, bias=None, act=_lib.ACT_NONE,
         ldc = round_up(cout, e16(dtype))
         y = torch.empty(M, ldc, dtype=ops.torch_dtype(dtype), device=w_op.device) if out is None else out
     d.C = y.data_ptr(); d.ldc = y.shape[1]
+    if scatter is not None:
+        assert out is not None
+        d.c_scatter = 1; d.c_sn, d.c_sh, d.c_sw, d.c_row0 = scatter
     ops.conv_forward(d, dtype)
     return CL(y, N, odhw, cout)
 

@@ -1,5 +1,4 @@
-J='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d.get("ms_per_step_median"), d.get("loss"))'
-timeout 1500 python -m pytest tests/test_flow_gpu.py tests/test_units_gpu.py tests/test_bench_configs_gpu.py -m gpu -x -q 2>&1 | tail -3
-for i in 1 2; do for v in 0 1; do
-echo -n "NO_UNIT_ZC=$v  "; if [ $v = 1 ]; then export IPOKE_NO_UNIT_ZC=1; else unset IPOKE_NO_UNIT_ZC; fi; python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "$J"
-done; done
+J='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d.get("ms_per_step_median"))'
+timeout 900 python -m pytest tests/test_encoder_kernels_gpu.py tests/test_capi_cpu.py -x -q 2>&1 | tail -3
+for v in 0 1; do echo -n "c5 NO_CT_PHASES=$v "; IPOKE_NO_CT_PHASES=$v python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "$J"; done
+timeout 900 python -m pytest tests/test_vae_gpu.py tests/test_full_gpu.py -m gpu -x -q 2>&1 | tail -3

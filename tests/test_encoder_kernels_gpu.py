@@ -88,3 +88,32 @@ def test_folded_stem_matches_conv3d(dtype, monkeypatch):
     scale = r.abs().max().item()
     assert (a - r).abs().max().item() <= tol * scale, ((a - r).abs().max().item(), scale)
     assert (a - b).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,cin,cout,snorm", [(2, 8, 8, 32, 24, False), (3, 16, 32, 64, 64, True), (1, 5, 7, 16, 40, False)])
+def test_conv_transpose_phases(N, H, W, cin, cout, snorm, dtype, monkeypatch):
+    """Stride-2 ConvTranspose2d (util.py:52-55) as four sub-pixel stride-1 convolutions with scattered output rows
+    (ipoke_conv_desc.c_scatter) against torch.nn.functional.conv_transpose2d and against the one-launch 9-tap form."""
+    torch.manual_seed(H * W + cin)
+    mod = FS._Conv(cin, cout, 3, 2, 1, transposed=True, snorm=snorm).to(DEV)
+    with torch.no_grad():
+        mod.bias.copy_(0.1 * torch.randn(cout))
+    x = torch.randn(N, cin, H, W)
+    xc = K.from_nchw(x.to(DEV), dtype)
+    xr = K.to_nchw(xc, dtype).cpu()
+    w = (mod.weight_orig / K.spectral_sigma(mod.weight_orig, mod.weight_u, mod.weight_v, True) if snorm else mod.weight).detach().cpu()
+    if dtype == "bf16":
+        w = w.bfloat16().float()
+    ref = F.elu(F.conv_transpose2d(xr, w, mod.bias.detach().cpu(), stride=2, padding=1, output_padding=1))
+    monkeypatch.setattr(FS, "_CT_PHASES", True)
+    got = mod.run(xc, dtype, act=_lib.ACT_ELU)
+    monkeypatch.setattr(FS, "_CT_PHASES", False)
+    one = mod.run(xc, dtype, act=_lib.ACT_ELU)
+    assert got.dhw == one.dhw == (1, 2 * H, 2 * W)
+    a, b = K.to_nchw(got, dtype).cpu(), K.to_nchw(one, dtype).cpu()
+    tol = (2e-5 if dtype == "f32" else 2e-2) * max(1.0, ref.abs().max().item())
+    assert (a - ref).abs().max().item() <= tol
+    assert (a - b).abs().max().item() <= tol
+    if got.t.shape[1] > cout:                                  # padded columns are written as zeros by every phase
+        assert float(got.t[:, cout:].float().abs().max()) == 0.0

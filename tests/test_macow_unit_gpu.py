@@ -69,8 +69,19 @@ def test_macow_unit_forward_backward(C, ld):
     for k in range(4):
         d4[k].y = ys[k].data_ptr(); d4[k].a2_save = a2[k].data_ptr(); d4[k].scale_save = sc[k].data_ptr()
         d4[k].logdet_slot = slots[k].data_ptr()
-    _lib.check(L.ipoke_macow_unit_fwd(d4, _lib.DTYPES[DT], _lib.current_stream()))
+    # the coupling behind the unit conditions on every other channel ("skip") / on a contiguous half: the unit writes that operand
+    zc_cases = []
+    for (off, stride, cin) in [(1, 2, C // 2), (C // 2, 1, C - C // 2)]:
+        zld = -(-cin // 8) * 8 + 8
+        zc_cases.append((off, stride, cin, zld, torch.full((M, zld), 3.0, device=DEV, dtype=tdt(DT))))
+    for off, stride, cin, zld, buf in zc_cases:
+        d4[3].zc_out, d4[3].zc_off, d4[3].zc_stride, d4[3].zc_cin, d4[3].zc_ld = buf.data_ptr(), off, stride, cin, zld
+        _lib.check(L.ipoke_macow_unit_fwd(d4, _lib.DTYPES[DT], _lib.current_stream()))
     torch.cuda.synchronize()
+    for off, stride, cin, zld, buf in zc_cases:          # bit-identical to the rounded output state, zero padding
+        want = ys[3][:, off:off + (cin - 1) * stride + 1:stride].to(tdt(DT))
+        assert torch.equal(buf[:, :cin], want), (off, stride)
+        assert float(buf[:, cin:].float().abs().max()) == 0.0
     # ---------------- per-layer chain (the ActNorms as their own launches)
     cur = xs
     ref_states, ref_a2, ref_sc, ref_ld = [], [], [], []
