@@ -115,6 +115,31 @@ class _SnWeight:
         self.w_orig, self.sig, self.snap, self.transposed, self.mod = w_orig, sig, snap, transposed, mod
 
 
+_CT_PHASES = os.environ.get("IPOKE_NO_CT_PHASES", "0") != "1"        # developer A/B: stride-2 ConvTranspose2d forward as one 9-tap launch
+# taps (kh * 3 + kw) of the four sub-pixel phases (output parity (a, b): rows 2 i + a, columns 2 j + b), in the tap order of the
+# stride-1 convolution that computes the phase (first_stage._Conv._phase_operands); the phases' first blocks are 0, 1, 3, 5
+_CT_PERM = (4, 5, 3, 7, 1, 8, 6, 2, 0)
+_CT_PHASE = {(0, 0): (0, 1), (0, 1): (1, 2), (1, 0): (3, 2), (1, 1): (5, 4)}
+_ct_index = {}
+
+
+def _conv_transpose_phases(x, wop, kc, cout, dt, bias, act, out_f32):
+    """Forward of a 3 x 3 / stride 2 / padding 1 / output_padding 1 ConvTranspose2d (util.py:52-55) from its [cout][9 * kc] operand:
+    one gather puts the tap blocks in phase order, four stride-1 convolutions (1, 2, 2, 4 taps) write the four pixel parities."""
+    idx = _ct_index.get(x.t.device)
+    if idx is None:
+        idx = _ct_index[x.t.device] = torch.tensor(_CT_PERM, device=x.t.device)
+    wperm = wop.view(cout, 9, kc).index_select(1, idx).view(cout, 9 * kc)
+    N, (_, Hi, Wi) = x.N, x.dhw
+    Ho, Wo = 2 * Hi, 2 * Wi
+    ldc = cout if out_f32 else K.round_up(cout, K.e16(dt))
+    y = torch.empty(N * Ho * Wo, ldc, dtype=torch.float32 if out_f32 else _tdt(dt), device=x.t.device)
+    for (a, b), (first, ntap) in _CT_PHASE.items():
+        K.conv(x, wperm[:, first * kc:(first + ntap) * kc], kc, cout, (1, 1 + a, 1 + b), (1, 1, 1), (0, 0, 0), dt, bias=bias, act=act,
+               out_f32=out_f32, out=y, odhw=(1, Hi, Wi), scatter=(Ho * Wo, 2 * Wo, 2, a * Wo + b))
+    return K.CL(y, N, (1, Ho, Wo), cout)
+
+
 # ------------------------------------------------------------------------------------------------ convolution
 class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, w) + bias).  ``x`` is the CL tensor [M, ld] (or None with ``meta['src']`` an fp32 image)."""
@@ -129,8 +154,12 @@ class _ConvFn(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         src = meta.get("src")
         x = None if src is not None else K.CL(x_t, meta["N"], meta["dhw"], meta["cin"])
-        y = K.conv(x, wop, kc, meta["cout"], meta["k"], meta["stride"], meta["pad"], dt, bias=b, act=meta["act"],
-                   transposed=meta["transposed"], out_pad=meta["out_pad"], out_f32=meta.get("out_f32", False), src_f32=src)
+        if (_CT_PHASES and meta["transposed"] and x is not None and tuple(meta["k"]) == (1, 3, 3) and tuple(meta["stride"]) == (1, 2, 2)
+                and tuple(meta["pad"]) == (0, 1, 1) and tuple(meta["out_pad"]) == (0, 1, 1)):
+            y = _conv_transpose_phases(x, wop, kc, meta["cout"], dt, b, meta["act"], meta.get("out_f32", False))
+        else:
+            y = K.conv(x, wop, kc, meta["cout"], meta["k"], meta["stride"], meta["pad"], dt, bias=b, act=meta["act"],
+                       transposed=meta["transposed"], out_pad=meta["out_pad"], out_f32=meta.get("out_f32", False), src_f32=src)
         meta["odhw"] = y.dhw
         ctx.meta = meta
         ctx.save_for_backward(x_t, w, y.t if meta["act"] != _lib.ACT_NONE else None)

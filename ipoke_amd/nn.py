@@ -90,7 +90,7 @@ def conv(x, w_op, kc, cout, k, stride, pad, dtype, bias=None, act=_lib.ACT_NONE,
         d.a_sn = dhw[0] * dhw[1] * dhw[2] * ld; d.a_sd = dhw[1] * dhw[2] * ld; d.a_sh = dhw[2] * ld; d.a_sw = ld; d.a_sc = 1
         d.Kc_real = kc; d.Kc = kc
         assert ld >= kc, "activation pitch must cover the padded channel count"
-    d.W = w_op.data_ptr(); d.ldw = w_op.shape[1]; d.Nout = cout
+    d.W = w_op.data_ptr(); d.ldw = w_op.stride(0); d.Nout = cout      # (a column range of a wider operand keeps its pitch)
     d.bias = 0 if bias is None else bias.data_ptr(); d.act = act
     if out_f32:
         y = torch.empty(M, cout, dtype=torch.float32, device=w_op.device) if out is None else out
