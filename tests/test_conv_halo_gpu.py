@@ -16,12 +16,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True, params=["dispatch", "halo16"])
+@pytest.fixture(autouse=True, params=["dispatch", "halo16", "c64"])
 def _kernel_choice(request, monkeypatch):
+    """halo16 / c64: IPOKE_HALO16=2 / IPOKE_C64=2 send every shape conv3x3_halo16_kernel / conv3x3_c64_kernel (persistent workgroups,
+    filter resident in LDS: 64 -> <= 64 channels) can run to it; the dispatcher's own rule needs maps far larger than a test's."""
+    monkeypatch.delenv("IPOKE_HALO16", raising=False)
+    monkeypatch.delenv("IPOKE_C64", raising=False)
     if request.param == "halo16":
         monkeypatch.setenv("IPOKE_HALO16", "2")
-    else:
-        monkeypatch.delenv("IPOKE_HALO16", raising=False)
+    elif request.param == "c64":
+        monkeypatch.setenv("IPOKE_C64", "2")
     yield
 
 
@@ -36,7 +40,8 @@ def _nchw(t, N, H, W, C):
 @pytest.mark.parametrize("N,H,W,cin,cout,act,out_f32", [(4, 32, 32, 64, 64, _lib.ACT_ELU, False), (2, 64, 48, 128, 128, _lib.ACT_NONE, False),
                                                       (3, 16, 32, 256, 72, _lib.ACT_RELU, False), (2, 128, 128, 64, 3, _lib.ACT_TANH, True),
                                                       (1, 64, 64, 192, 320, _lib.ACT_LRELU02, False), (16, 16, 16, 256, 256, _lib.ACT_ELU, False),
-                                                      (4, 16, 16, 512, 200, _lib.ACT_NONE, False)])
+                                                      (4, 16, 16, 512, 200, _lib.ACT_NONE, False), (3, 48, 16, 64, 20, _lib.ACT_RELU, False),
+                                                      (2, 16, 32, 64, 40, _lib.ACT_NONE, True)])
 def test_halo_conv_forward(N, H, W, cin, cout, act, out_f32):
     g = torch.Generator().manual_seed(H * W + cin)
     x = torch.randn(N, cin, H, W, generator=g).to(torch.bfloat16).float()
@@ -76,10 +81,10 @@ def test_halo_conv_into_channel_range():
     assert float((out[:, :32].float() - 7).abs().max()) == 0 and float((out[:, 96:].float() - 7).abs().max()) == 0
 
 
-def test_halo_conv_data_gradient():
+@pytest.mark.parametrize("N,H,W,cin,cout", [(2, 32, 64, 128, 64), (3, 16, 48, 64, 64), (2, 32, 32, 40, 64)])
+def test_halo_conv_data_gradient(N, H, W, cin, cout):
     """transposed = 1 (the adjoint of a stride-1 3x3 convolution) with the activation-derivative mask of the saved output."""
-    g = torch.Generator().manual_seed(9)
-    N, H, W, cin, cout = 2, 32, 64, 128, 64                   # forward conv: cin -> cout; its data gradient: cout -> cin
+    g = torch.Generator().manual_seed(9)                      # forward conv: cin -> cout; its data gradient: cout -> cin
     x = torch.randn(N, cin, H, W, generator=g, requires_grad=True)
     w = (torch.randn(cout, cin, 3, 3, generator=g) / 34).to(torch.bfloat16).float()
     dy = torch.randn(N, cout, H, W, generator=g).to(torch.bfloat16).float()
