@@ -349,25 +349,27 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_kernel(const UnitP
           bf16x2 tv; tv[0] = ET<T>::from_f32(yv[0]); tv[1] = ET<T>::from_f32(yv[1]);
           *reinterpret_cast<bf16x2*>(xs + p * xs_pitch + c * (int)sizeof(T)) = tv;
           if (Lk.y) *reinterpret_cast<f32x2*>(Lk.y + (row0 + p) * ld + c) = yv;
-          if (Lk.zc) {                                        // (the rounded values just stored in xs)
-            T* zr = reinterpret_cast<T*>(Lk.zc) + (row0 + p) * Lk.zc_ld;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const int rel = c + q - Lk.zc_off, kz = Lk.zc_stride == 2 ? rel >> 1 : rel;
-              if (rel >= 0 && kz < Lk.zc_cin && (Lk.zc_stride != 2 || !(rel & 1))) zr[kz] = tv[q];
-            }
-          }
         }
-      }
-      if (Lk.zc) {                                            // zero padding of the operand rows
-        const int npad = Lk.zc_ld - Lk.zc_cin;
-        T* zr = reinterpret_cast<T*>(Lk.zc) + row0 * Lk.zc_ld + Lk.zc_cin;
-        for (int i = tid; i < 64 * npad; i += kMcfThreads) { const int r = i / npad; zr[r * Lk.zc_ld + (i - r * npad)] = ET<T>::from_f32(0.f); }
       }
     }
     const float tot = block_sum(ld_acc, red);       // two barriers: the state update above is complete behind them
     UNIT_STAMP(7 + 6 * k);
     if (tid == 0 && Lk.ld_slot) Lk.ld_slot[(long)b * U.slot_w] = tot;
+    if (Lk.zc) {
+      // conditioning operand of the coupling behind the unit: the selected columns of the (rounded) state tile in LDS, two per
+      // 4-byte store, zero beyond zc_cin (scattered 2-byte stores from the update loop above cost 1.5 us per launch)
+      const int half = Lk.zc_ld >> 1;
+      T* zb = reinterpret_cast<T*>(Lk.zc) + row0 * Lk.zc_ld;
+      const T z0 = ET<T>::from_f32(0.f);
+      for (int i = tid; i < 64 * half; i += kMcfThreads) {
+        const int r = i / half, k2 = (i - r * half) * 2;
+        const unsigned char* xr = xs + r * xs_pitch;
+        bf16x2 v;
+        v[0] = k2 < Lk.zc_cin ? *reinterpret_cast<const T*>(xr + (Lk.zc_off + k2 * Lk.zc_stride) * (int)sizeof(T)) : z0;
+        v[1] = k2 + 1 < Lk.zc_cin ? *reinterpret_cast<const T*>(xr + (Lk.zc_off + (k2 + 1) * Lk.zc_stride) * (int)sizeof(T)) : z0;
+        *reinterpret_cast<bf16x2*>(zb + (long)r * Lk.zc_ld + k2) = v;
+      }
+    }
     // the 1x1 weights of the next layer are not needed before its second contraction: requested here, they land
     // underneath its first one (and do not add to the register pressure of the epilogue above)
     if (k < 3) unit_load_w2<T, WIDE>(wr, U.L[k + 1].W2, U);
@@ -927,7 +929,7 @@ static int unit_params(UnitParams& U, const ipoke_mcf_desc* d, int dtype, bool b
     L.x = s.x; L.y_post = s.y_post; L.post_part = s.post_part; L.dparams_save = s.dparams_save; L.dc_save = s.dc_save;
     L.dbias_part = s.dbias_part; L.order = s.order; L.x_op = bwd ? s.x_op_save : nullptr;
     L.zc = bwd ? nullptr : s.zc_out; L.zc_off = s.zc_off; L.zc_stride = s.zc_stride; L.zc_cin = s.zc_cin; L.zc_ld = s.zc_ld;
-    if (L.zc) IPK_REQUIRE(k == 3 && (s.zc_stride == 1 || s.zc_stride == 2) && s.zc_cin >= 1 && s.zc_ld >= s.zc_cin && s.zc_off >= 0 &&
+    if (L.zc) IPK_REQUIRE(k == 3 && (s.zc_stride == 1 || s.zc_stride == 2) && s.zc_cin >= 1 && s.zc_ld >= s.zc_cin && s.zc_ld % 2 == 0 && s.zc_off >= 0 &&
                           s.zc_off + (s.zc_cin - 1) * s.zc_stride < C, "conditioning operand: layer 3 only, stride 1 or 2, columns inside the state");
     if (!bwd) IPK_REQUIRE(s.W1 && s.W2 && s.bias2, "null forward operand");
     else {
