@@ -2300,6 +2300,29 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
 #endif
   };
 
+  // reads of the next step's fragments (into fn) interleaved with the MFMAs of this step's (fc): three reads behind every second
+  // MFMA in issue order -- with the twelve reads in front, eight waves queue 96 transposing reads on the LDS pipe before any of
+  // them reaches its first MFMA (the same finding as in conv3x3_halo16)
+  auto read_mma = [&](frag_t (&fn)[6], unsigned sb, auto ks_tag, frag_t (&fc)[6]) {
+    constexpr int KS = decltype(ks_tag)::value;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = q >> 1, j = q & 1;
+#if IPOKE_TN_ABL == 1
+      asm volatile("" :: "v"(fc[i]), "v"(fc[4 + j]));
+#else
+      mma64(fc[i], fc[4 + j], acc[i][j]);
+#endif
+      if (q < 6) {                                   // fragment q of the next step: two transposing reads
+        const unsigned a = (q < 4 ? y_rd[q & 3] : x_rd[q & 1]) + sb;
+        const tn_tr4_t lo = tn_ds_tr<KS * 32 * 256>(a), hi = tn_ds_tr<KS * 32 * 256 + 4 * 256>(a);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { fn[q][e] = lo[e]; fn[q][4 + e] = hi[e]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   // Two-phase pipeline, one barrier per stage: while the matrix cores work on one 32-row step, the fragment reads of the next step
   // (and, in the second phase, the DMA of the stage NSTAGE ahead) are in flight:
   //   [wait FA] read FB = (it, 1) | mma FA | [stage it+1 landed, wait FB] barrier | DMA stage it+NSTAGE -> slot of it | read FA = (it+1, 0) | mma FB
@@ -2318,10 +2341,8 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
 #if IPOKE_TN_ABL != 2
     tn_wait_frags(FA);
-    read_frags(FB, sb, K1{});
     __builtin_amdgcn_sched_barrier(0);
-    mma_frags(FA);
-    __builtin_amdgcn_sched_barrier(0);
+    read_mma(FB, sb, K1{}, FA);
 #endif
     wait_vmcnt<(NSTAGE - 2) * L>();               // this wave's share of stage it + 1 has landed
 #if IPOKE_TN_ABL != 2
@@ -2333,10 +2354,8 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
 #endif
     ++issued;
 #if IPOKE_TN_ABL != 2
-    read_frags(FA, (unsigned)(nslot * STAGE), K0{});     // (past the last stage: a padding slot, never multiplied)
     __builtin_amdgcn_sched_barrier(0);
-    mma_frags(FB);
-    __builtin_amdgcn_sched_barrier(0);
+    read_mma(FA, (unsigned)(nslot * STAGE), K0{}, FB);      // (past the last stage: a padding slot, never multiplied)
 #endif
     slot = nslot;
   }
