@@ -1,8 +1,2 @@
-J='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d.get("ms_per_step_median"), [k["avg_launch_us"] for k in d["roofline_other_kernels"]])'
-echo -n "new  "; python scripts/probe_tn.py 20 2>/dev/null | tail -1
-echo -n "prev "; IPOKE_LIB_PATH=$PWD/scripts/exp/libipoke_prev.so python scripts/probe_tn.py 20 2>/dev/null | tail -1
-timeout 900 python -m pytest tests/test_units_gpu.py tests/test_vae_bwd_units_gpu.py tests/test_flow_gpu.py -m gpu -x -q 2>&1 | tail -2
-for r in 1 2; do
-echo -n "new  "; python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "$J"
-echo -n "prev "; IPOKE_LIB_PATH=$PWD/scripts/exp/libipoke_prev.so python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "$J"
-done
+bash scripts/profile_round.sh r03c > /dev/null 2>&1
+ls gpurun_out/r03c | head -30
