@@ -1713,13 +1713,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // =============================================================================================
-// 3 x 3 convolution (stride 1, pad 1) of 64 -> <= 64 channels on large maps: the 128 x 128 layers of the decoder (64 -> 64 and the
-// 64 -> 3 image head over all frames of a batch of clips: 7.9 M pixels in sampling).  With one 64-channel chunk the reduction is nine
-// K-blocks deep, and conv3x3_halo_kernel spends its 8 us per 128-pixel workgroup on prologue, filter stream and the K-group hand-over
-// (2.0 ms for 580 GFLOP and 1 GB of input).  Here the WHOLE filter (9 x 64 x 64 = 72 KB) is loaded once per workgroup and stays in
-// LDS; persistent workgroups (one per CU) walk over 16 x 16-pixel patches whose halo images (18 x 18 x 64 channels = 41 KB) are
-// double-buffered -- the only stream -- and there is one barrier per patch.  8 waves = 4 pixel-row groups x 2 halves of 32 output
-// channels; halves / fragments beyond Nout are skipped (the image head computes 16 of 64 columns).
+// Stride-1 convolutions with <= 64 output channels and a filter that FITS IN LDS, on large maps: the 128 x 128 layers of the decoder
+// (3 x 3, 64 -> 64 and the 64 -> 3 image head over all frames of a batch of clips: 7.9 M pixels in sampling) and the four sub-pixel
+// phases of its last up-convolution (1 / 2 / 2 / 4 taps of 128 -> 64 channels, scattered output rows).  Their reductions are 2 - 9
+// K-blocks deep: conv3x3_halo_kernel / the implicit GEMM spend ~8 us per 64 - 128-pixel workgroup on prologue, filter stream and
+// epilogue (2.0 ms for 580 GFLOP and 1 GB of input; 0.6 ms per phase).  Here the WHOLE filter (taps x chunks x 8 KB <= 72 KB) is loaded
+// once per workgroup and stays in LDS; persistent workgroups (one per CU) walk over 16 x 16-pixel patches, one 64-channel chunk of the
+// patch's halo image (18 x 18 pixels = 41 KB, zero outside the map) per buffer, double-buffered -- the only stream --, one barrier
+// per image.  Taps are the kh x kw window at offsets a - ph (ph - a for the data gradient), all within the one-pixel halo.
+// 8 waves = 4 pixel-row groups x 2 halves of 32 output channels; fragments beyond Nout are skipped (the image head computes 16 of
+// 64 columns); the epilogue runs from the accumulators.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(const NtParams p) {
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
@@ -1732,7 +1735,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int MREP = 4, NREP = 2;
   static_assert(W_IT == 9, "filter pieces per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* wbuf = smem;                              // [tap][64 output channels][64 input channels], rows swizzled
+  unsigned char* wbuf = smem;                              // [tap][chunk][64 output channels][64 input channels], rows swizzled
   unsigned char* abuf = smem + WBYTES;                     // 2 x ABUF halo images
   unsigned char* dummy = abuf + 2 * ABUF;                  // landing zone of padding DMAs (1 KB, shared)
   if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -1741,22 +1744,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wm = wave & 3, wn = wave >> 2;
   const GeomDev& g = p.g;
   const int tiles_x = g.Wo / TW, tiles_y = g.Ho / TH, ntiles = (g.M / (g.Ho * g.Wo)) * tiles_x * tiles_y;
-  const int sgn = g.transposed ? -1 : 1;
+  const int ntaps = g.khw, nch = p.Kc >> 6, nimg = ntiles * nch;          // virtual images: (patch, chunk)
   const T* Abase = reinterpret_cast<const T*>(p.A);
   const T* Wbase = reinterpret_cast<const T*>(p.W);
   const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
   const int lrow = lane >> 3, lpos = lane & 7;
 
-  // ---- the filter, once
+  // ---- the filter, once: piece = ((tap * nch + chunk) * 8 + row group)
+  {
+    const int npieces = ntaps * nch * 8;
 #pragma unroll
-  for (int j = 0; j < W_IT; ++j) {
-    const int piece = wave * W_IT + j;                     // 8 rows of tap piece / 8
-    const int tap = piece >> 3, nl = (piece & 7) * 8 + lrow;
-    const T* src = nl < p.Nout ? Wbase + (long)nl * p.ldw + tap * 64 + ((lpos ^ ((nl >> 1) & 7)) * 8) : zero;
-    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(wbuf + piece * 1024), 16, 0, 0);
+    for (int j = 0; j < W_IT; ++j) {
+      const int piece = wave * W_IT + j;
+      const int tc = piece >> 3, tap = tc / nch, ch = tc - tap * nch, nl = (piece & 7) * 8 + lrow;
+      const bool real = piece < npieces && nl < p.Nout;
+      const T* src = real ? Wbase + (long)nl * p.ldw + tap * p.Kc + ch * 64 + ((lpos ^ ((nl >> 1) & 7)) * 8) : zero;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(piece < npieces ? wbuf + piece * 1024 : dummy), 16, 0, 0);
+    }
   }
-  auto issue_image = [&](int tile, int buf) {
-    const bool have = tile < ntiles;
+  auto issue_image = [&](int v, int buf) {                 // v = tile * nch + chunk
+    const bool have = v < nimg;
+    const int tile = v / nch, ch = v - tile * nch;
     const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, img = t2 / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
 #pragma unroll
@@ -1764,13 +1772,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int pi = wave + 8 * i, row = pi * 8 + lrow;
       const int py = row / HW, px = row - py * HW, y = y0 - 1 + py, x = x0 - 1 + px;
       const bool real = have && row < HROWS && (unsigned)y < (unsigned)g.Hi && (unsigned)x < (unsigned)g.Wi;
-      const T* src = real ? Abase + (long)img * p.a_sn + (long)y * p.a_sh + (long)x * p.a_sw + p.a_coff + ((lpos ^ ((row >> 1) & 7)) * 8) : zero;
+      const T* src = real ? Abase + (long)img * p.a_sn + (long)y * p.a_sh + (long)x * p.a_sw + p.a_coff + ch * 64 + ((lpos ^ ((row >> 1) & 7)) * 8) : zero;
       unsigned char* dst = have && pi < A_PIECES ? abuf + buf * ABUF + pi * 1024 : dummy;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
     }
   };
-  int tile = blockIdx.x;
-  issue_image(tile, 0);
+  const int vstep = (int)gridDim.x * nch;                  // a workgroup's patches: blockIdx.x, blockIdx.x + gridDim.x, ...
+  int v = (int)blockIdx.x * nch;                           // its images in order: the chunks of a patch, then the next patch
+  auto next_image = [&](int vv) { return (vv % nch) + 1 < nch ? vv + 1 : vv - (nch - 1) + vstep; };
+  issue_image(v, 0);
 
   const int qlo = lane >> 4;
   const int nfrag = min(NREP, max(0, (p.Nout - wn * 32 + 15) >> 4));      // 16-column fragments of this wave that hold outputs
@@ -1782,79 +1792,84 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const bool vec_ok = (p.Nout & 3) == 0;
   int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-    wait_vmcnt<0>();                               // this patch's image (and, the first time, the filter) has landed
+  f32x4 acc[MREP][NREP];
+  for (; v < nimg; v = next_image(v), buf ^= 1) {
+    const int ch = v % nch;
+    wait_vmcnt<0>();                               // this image (and, the first time, the filter) has landed
     __builtin_amdgcn_s_barrier();                  // ... everybody's share of it; the other buffer is no longer read
-    issue_image(tile + gridDim.x, buf ^ 1);
-    f32x4 acc[MREP][NREP];
+    issue_image(next_image(v), buf ^ 1);
+    if (ch == 0) {
 #pragma unroll
-    for (int i = 0; i < MREP; ++i)
+      for (int i = 0; i < MREP; ++i)
 #pragma unroll
-      for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nfrag > 0) {
-      const unsigned char* ab = abuf + buf * ABUF;
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (nfrag == 0) continue;
+    const unsigned char* ab = abuf + buf * ABUF;
+    for (int t = 0; t < ntaps; ++t) {
+      const int ta = t / g.kw, tb = t - ta * g.kw;
+      const int dy = g.transposed ? g.ph - ta : ta - g.ph, dx = g.transposed ? g.pw - tb : tb - g.pw;
+      const int sr0 = (wm * 4 + 1 + dy) * HW + (lane & 15) + 1 + dx;
+      const unsigned char* wb = wbuf + (t * nch + ch) * 64 * 128;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int th = t / 3, tw = t - 3 * th;
-        const int sr0 = (wm * 4 + 1 + sgn * (th - 1)) * HW + (lane & 15) + 1 + sgn * (tw - 1);
-        const unsigned char* wb = wbuf + t * 64 * 128;
-#pragma unroll
-        for (int hs = 0; hs < 2; ++hs) {
-          frag_t fa[MREP], fb[NREP];
-#pragma unroll
-          for (int i = 0; i < MREP; ++i) {
-            const int sr = sr0 + i * HW;
-            fa[i] = *reinterpret_cast<const frag_t*>(ab + sr * 128 + (((hs * 4 + qlo) ^ ((sr >> 1) & 7)) * 16));
-          }
-#pragma unroll
-          for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(wb + (b_rd[j] ^ (hs * 64)));
-#pragma unroll
-          for (int i = 0; i < MREP; ++i) {
-            GEMM_MMA(fa[i], fb[0], acc[i][0]);
-            if (nfrag > 1) GEMM_MMA(fa[i], fb[1], acc[i][1]);
-          }
-        }
-      }
-      // ---- epilogue straight from the accumulators: acc[i][j][e] = pixel (wm*4 + i, lane & 15), channel wn*32 + 16 j + 4 (lane >> 4) + e
-      const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, img = t2 / tiles_y;
-      const long mrow = ((long)img * g.Ho + ty * TH + wm * 4) * g.Wo + tx * TW + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) {
-        const int n = wn * 32 + j * 16 + qlo * 4;
-        if (j >= nfrag || n >= p.n_pad) continue;
-        const bool full = vec_ok && n + 3 < p.Nout;
-        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-          if (full) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-          else for (int e = 0; e < 4; ++e) if (n + e < p.Nout) b4[e] = p.bias[n + e];
-        }
+      for (int hs = 0; hs < 2; ++hs) {
+        frag_t fa[MREP], fb[NREP];
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
-          const long m = mrow + (long)i * g.Wo;
-          f32x4 v = acc[i][j] + b4;
-          if (p.act != IPOKE_ACT_NONE) {
+          const int sr = sr0 + i * HW;
+          fa[i] = *reinterpret_cast<const frag_t*>(ab + sr * 128 + (((hs * 4 + qlo) ^ ((sr >> 1) & 7)) * 16));
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fast_act<T>(p.act, v[e]);
-          }
-          if (!full) {
+        for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(wb + (b_rd[j] ^ (hs * 64)));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (n + e >= p.Nout) v[e] = 0.f;
-          }
-          if (p.c_f32) {
-            float* Cp = reinterpret_cast<float*>(p.C) + m * p.ldc + p.c_coff;
-            if (full && p.c_cstride == 1 && ((p.ldc | p.c_coff) & 3) == 0) *reinterpret_cast<f32x4*>(Cp + n) = v;
-            else for (int e = 0; e < 4; ++e) if (n + e < p.Nout) Cp[(long)(n + e) * p.c_cstride] = v[e];
+        for (int i = 0; i < MREP; ++i) {
+          GEMM_MMA(fa[i], fb[0], acc[i][0]);
+          if (nfrag > 1) GEMM_MMA(fa[i], fb[1], acc[i][1]);
+        }
+      }
+    }
+    if (ch + 1 < nch) continue;
+    // ---- epilogue straight from the accumulators: acc[i][j][e] = pixel (wm*4 + i, lane & 15), channel wn*32 + 16 j + 4 (lane >> 4) + e
+    const int tile = v / nch;
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, img = t2 / tiles_y;
+    const int oy = ty * TH + wm * 4, ox = tx * TW + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int n = wn * 32 + j * 16 + qlo * 4;
+      if (j >= nfrag || n >= p.n_pad) continue;
+      const bool full = vec_ok && n + 3 < p.Nout;
+      f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        if (full) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+        else for (int e = 0; e < 4; ++e) if (n + e < p.Nout) b4[e] = p.bias[n + e];
+      }
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) {
+        const long m = p.c_scatter ? p.c_row0 + (long)img * p.c_sn + (long)(oy + i) * p.c_sh + (long)ox * p.c_sw
+                                   : ((long)img * g.Ho + oy + i) * g.Wo + ox;
+        f32x4 v4 = acc[i][j] + b4;
+        if (p.act != IPOKE_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = fast_act<T>(p.act, v4[e]);
+        }
+        if (!full) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e >= p.Nout) v4[e] = 0.f;
+        }
+        if (p.c_f32) {
+          float* Cp = reinterpret_cast<float*>(p.C) + m * p.ldc + p.c_coff;
+          if (full && p.c_cstride == 1 && ((p.ldc | p.c_coff) & 3) == 0) *reinterpret_cast<f32x4*>(Cp + n) = v4;
+          else for (int e = 0; e < 4; ++e) if (n + e < p.Nout) Cp[(long)(n + e) * p.c_cstride] = v4[e];
+        } else {
+          T* Cp = reinterpret_cast<T*>(p.C) + m * p.ldc + p.c_coff + n;
+          if (n + 3 < p.n_pad && ((p.ldc | p.c_coff) & 3) == 0) {
+            pack_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ET<T>::from_f32(v4[e]);
+            *reinterpret_cast<pack_t*>(Cp) = o;
           } else {
-            T* Cp = reinterpret_cast<T*>(p.C) + m * p.ldc + p.c_coff + n;
-            if (n + 3 < p.n_pad && ((p.ldc | p.c_coff) & 3) == 0) {
-              pack_t o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = ET<T>::from_f32(v[e]);
-              *reinterpret_cast<pack_t*>(Cp) = o;
-            } else {
-              for (int e = 0; e < 4; ++e)
-                if (n + e < p.n_pad) Cp[e] = ET<T>::from_f32(v[e]);
-            }
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.n_pad) Cp[e] = ET<T>::from_f32(v4[e]);
           }
         }
       }
@@ -1870,10 +1885,17 @@ static bool c64_applicable(const NtParams& p) {
   const int mode = mode_s ? atoi(mode_s) : 1;
   const GeomDev& g = p.g;
   if (!mode) return false;
-  const bool can = !p.a_f32 && !p.c_scatter && !p.dact && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Do == 1 && g.pd == 0 &&
-                   g.Hi == g.Ho && g.Wi == g.Wo && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
-                   p.Kc == 64 && p.Kc_real == 64 && p.Nout <= 64 && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot && (p.ldw & 7) == 0 && p.splitk == 1 && !p.c_acc &&
-                   ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && p.n_pad <= 64;
+  // window offsets a - ph (forward) / ph - a (data gradient) must lie within the one-pixel halo
+  const int kh = g.kw > 0 ? g.khw / g.kw : 0;
+  const int lo_y = g.transposed ? g.ph - (kh - 1) : -g.ph, hi_y = g.transposed ? g.ph : kh - 1 - g.ph;
+  const int lo_x = g.transposed ? g.pw - (g.kw - 1) : -g.pw, hi_x = g.transposed ? g.pw : g.kw - 1 - g.pw;
+  const int nch = p.Kc / 64;
+  const bool can = !p.a_f32 && !p.dact && g.taps == g.khw && kh >= 1 && g.khw == kh * g.kw && g.Di == 1 && g.Do == 1 && g.pd == 0 &&
+                   g.Hi == g.Ho && g.Wi == g.Wo && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.sd == 1 && g.sh == 1 && g.sw == 1 &&
+                   lo_y >= -1 && hi_y <= 1 && lo_x >= -1 && hi_x <= 1 && (!g.transposed || (kh == 3 && g.kw == 3)) &&
+                   (p.Kc == 64 || p.Kc == 128) && p.Kc_real == p.Kc && g.khw * nch <= 9 && (g.khw > 1 || p.c_scatter) && p.Nout <= 64 && (p.a_coff & 7) == 0 &&
+                   p.ldw >= p.Ktot && (p.ldw & 7) == 0 && p.splitk == 1 && !p.c_acc && ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && p.n_pad <= 64 &&
+                   (reinterpret_cast<uintptr_t>(p.W) & 15) == 0;
   if (!can) return false;
   return mode == 2 || g.M / 256 >= 512;
 }
