@@ -336,6 +336,25 @@ def test_motion_encoder_128_z64(golden, dtype):
         assert err <= VAE_TOL[dtype]
 
 
+def test_motion_encoder_128_z64_benchmarked_batch(golden):
+    """The c2 batch: 20 clips (copies of the golden clip).  At this size the dispatcher sends the 128-channel 3 x 3 x 3 stages and
+    the stride-(2, 1, 1) convolution to conv3x3_halo16_kernel (1 280 workgroups; at B = 1 they run as implicit GEMMs) and the stem runs
+    folded: every slot must reproduce the reference's mu / logvar / z, and all slots must agree with each other to the bit."""
+    g = golden("g4_encoder_128_z64")
+    m = first_stage(128, 64, 16, "bf16")
+    X = torch.rand(1, 16, 3, 128, 128, generator=torch.Generator().manual_seed(int(g["X_seed"]))) * 2 - 1
+    B = 20
+    Xb = X.to(DEV).expand(B, -1, -1, -1, -1).contiguous()
+    eps = t(g["eps"], DEV).expand(B, -1, -1, -1).contiguous()
+    z, mu, lv = m.enc_motion(Xb.transpose(1, 2), eps=eps)
+    for name, got in (("mu", mu), ("logvar", lv), ("z", z)):
+        ref = t(g[name])
+        err = (got.cpu() - ref).abs().max().item()
+        print(f"encoder128/z64[bf16, B = {B}] {name} err {err:.3e}")
+        assert got.shape[0] == B and err <= VAE_TOL["bf16"]
+        assert torch.equal(got[:1].expand_as(got), got), name
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_gru_and_spade_decoder_128_z64(golden, dtype):
     """c5 decoder: 4-layer ConvGRU on the 8x8x64 latent + the 5-entry dec_channels SPADE decoder up to 128x128."""
