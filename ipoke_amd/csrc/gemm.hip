@@ -1047,7 +1047,7 @@ static void pick_xcd_map(NtParams& p) {
 // every fourth K-block (tap), four K-blocks are consumed per barrier, and the four groups' accumulators meet in LDS
 // (two hand-over rounds) before the epilogue.
 // Split-K is over channel chunks (blockIdx.y); the epilogue is nt_epilogue (partials / atomics / dense outputs).
-__global__ __launch_bounds__(512) void conv3x3_s8_kernel(const NtParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s8_kernel(const NtParams p) {
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
   typedef __attribute__((address_space(3))) void lds_void;
@@ -1201,6 +1201,15 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const NtParams p) {
         for (int i = 0; i < MREP; ++i)
 #pragma unroll
           for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[hs][i], fb[hs][j], acc[i][j]);
+      // issue order: the eight fragments of the first half-step, then the second half-step's reads one per two MFMAs of the first.
+      // (hipcc's own schedule reads just in time, four MFMAs per s_waitcnt lgkmcnt(0): eight exposed LDS latencies per K-block.)
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     }
     gk += 4; t += 4;
     if (t >= 9) { t -= 9; ++ci; }
@@ -1246,7 +1255,7 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const NtParams p) {
 // addresses -- the same chunk-major reduction, filter ring, 2 x 4 wave arrangement and K-group hand-over as conv3x3_s8 above,
 // minus the "outside the map" masks (the zero border is materialised by the staging DMA).  Output channels are tiled by 64
 // over blockIdx.y.  transposed (data gradient): the taps are mirrored, the caller supplies the transposed filter operand.
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const NtParams p) {
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
   typedef typename Pack4<T>::type pack_t;
@@ -1364,6 +1373,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const NtParams p) {
         for (int i = 0; i < MREP; ++i)
 #pragma unroll
           for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[hs][i], fb[hs][j], acc[i][j]);
+      // issue order as in conv3x3_s8_kernel: first half-step's fragments, then one read of the second per two MFMAs of the first
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     }
     gk += 4; t += 4;
     if (t >= 9) { t -= 9; ++ci; }
