@@ -587,6 +587,13 @@ int ipoke_video_to_cl(const float* src, int64_t s_n, int64_t s_f, int64_t s_c, i
 int ipoke_min_reset(float* minval, void* stream);
 /* metrics.py:794-798: x = (x + 1) / 2 on the interior columns of `rows` padded rows when *minval < 0 (decided on the device) */
 int ipoke_denorm_if_negative(float* x, int64_t rows, int Wo, int pad_l, int pad_r, int C, const float* minval, void* stream);
+/* metrics.py:450-481 (SSIM_custom / PSNR_custom = pytorch_lightning.metrics.functional.ssim / psnr with their defaults; logged per
+ * validation batch, second_stage_video.py:511-512): out[0] = 10 log10((max(target) - min(target))^2 / mse), out[1] = mean SSIM map
+ * (11 x 11 Gaussian window, sigma 1.5, k1 = 0.01, k2 = 0.03, data range = the larger of the two tensors' ranges) over the positions
+ * whose windows lie inside the image, of `planes` fp32 planes [planes][H][W] (N * C planes of NCHW tensors); H, W >= 11.
+ * workspace: ipoke_image_metrics_workspace_bytes(planes, H, W) bytes. */
+int64_t ipoke_image_metrics_workspace_bytes(int64_t planes, int H, int W);
+int ipoke_psnr_ssim(const float* preds, const float* target, int64_t planes, int H, int W, void* workspace, float* out, void* stream);
 /* metrics.py:939-960 MaxPool3dTFPadding: ZERO padding, then MaxPool3d(ceil_mode=True), on channels-last rows of the compute dtype.
  * dims = {N, C, Di, Hi, Wi, Do, Ho, Wo, kd, kh, kw, sd, sh, sw, pd, ph, pw, ed, eh, ew}: p* = front padding, e* = input extent +
  * back padding (window positions in the zero border count as 0, positions beyond it are ignored). */

@@ -151,6 +151,8 @@ SIGNATURES = {
     "ipoke_bilinear_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_cl_to_nchw": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_nchw_to_cl": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ipoke_image_metrics_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "ipoke_psnr_ssim": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "ipoke_clip_to_cl4": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "ipoke_groupnorm_stats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
     "ipoke_groupnorm_stats_offset": (c_int64, [c_int, c_int, c_int]),

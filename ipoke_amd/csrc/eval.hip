@@ -148,6 +148,114 @@ __global__ void moments_cov_kernel(const float* __restrict__ a, int n, int D, co
   for (int r = 0; r < n; ++r) if (valid[r]) s += ((double)a[(long)r * D + i] - mi) * ((double)a[(long)r * D + j] - mj);
   sigma[(long)i * D + j] = s / (double)(*count - 1);
 }
+// ------------------------------------------------------------------------------------------------ image metrics
+// pytorch_lightning.metrics.functional.psnr / ssim as the reference's validation logging calls them (second_stage_video.py:511-512,
+// metrics.py:450-481: defaults -- 11 x 11 Gaussian window of sigma 1.5, k1 = 0.01, k2 = 0.03, data ranges taken from the tensors).
+// mm[0..3] = {-min(a), max(a), -min(b), max(b)} (one atomic flavour); sums in double.
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__global__ void pair_stats_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ mm, double* __restrict__ sse) {
+  float amin = INFINITY, amax = -INFINITY, bmin = INFINITY, bmax = -INFINITY;
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = a[i], y = b[i], d = x - y;
+    amin = fminf(amin, x); amax = fmaxf(amax, x); bmin = fminf(bmin, y); bmax = fmaxf(bmax, y);
+    acc += (double)d * (double)d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    amin = fminf(amin, __shfl_xor(amin, o, 64)); amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    bmin = fminf(bmin, __shfl_xor(bmin, o, 64)); bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
+    acc += __shfl_xor(acc, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomic_max_f32(mm + 0, -amin); atomic_max_f32(mm + 1, amax); atomic_max_f32(mm + 2, -bmin); atomic_max_f32(mm + 3, bmax);
+    atomicAdd(sse, acc);
+  }
+}
+__global__ void psnr_final_kernel(const float* __restrict__ mm, const double* __restrict__ sse, long n, float* __restrict__ out) {
+  // psnr = 10 log10(range^2 / mse), range = max(target) - min(target)   (functional/psnr.py: data_range=None, base 10)
+  const double range = (double)mm[3] + (double)mm[2];
+  const double mse = sse[0] / (double)n;
+  out[0] = (float)(10.0 * (2.0 * log(range) - log(mse)) / log(10.0));
+}
+// SSIM map of one plane tile: 32 x 32 output positions whose 11 x 11 windows lie inside the image (the reference pads by reflection and
+// crops the padded border away again, functional/ssim.py), separable Gaussian of the five moments, per-block partial sum in double.
+__global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, const float* __restrict__ b, int H, int W, const float* __restrict__ mm,
+                                                   double* __restrict__ part) {
+  constexpr int TS = 32, K = 11, IN = TS + K - 1;           // 42 x 42 inputs per tile
+  __shared__ float sa[IN][IN + 1], sb[IN][IN + 1];
+  __shared__ float hz[5][IN][TS + 1];                       // horizontally filtered moments
+  __shared__ float gw[K];
+  __shared__ double red[4];
+  const int Ho = H - (K - 1), Wo = W - (K - 1);
+  const int tiles_x = (Wo + TS - 1) / TS;
+  const int plane = blockIdx.y, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * TS, x0 = tx * TS;
+  const float* pa = a + (long)plane * H * W;
+  const float* pb = b + (long)plane * H * W;
+  if (threadIdx.x < K) {
+    float sum = 0.f, mine = 0.f;
+    for (int i = 0; i < K; ++i) {
+      const float d = (float)(i - K / 2) / 1.5f, gi = expf(-d * d / 2.f);
+      sum += gi;
+      if (i == (int)threadIdx.x) mine = gi;
+    }
+    gw[threadIdx.x] = mine / sum;
+  }
+  for (int i = threadIdx.x; i < IN * IN; i += 256) {
+    const int r = i / IN, c = i - r * IN, y = y0 + r, x = x0 + c;
+    const bool in = y < H && x < W;
+    sa[r][c] = in ? pa[(long)y * W + x] : 0.f;
+    sb[r][c] = in ? pb[(long)y * W + x] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < IN * TS; i += 256) {
+    const int r = i / TS, c = i - r * TS;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float w = gw[k], x = sa[r][c + k], y = sb[r][c + k];
+      m0 += w * x; m1 += w * y; m2 += w * x * x; m3 += w * y * y; m4 += w * x * y;
+    }
+    hz[0][r][c] = m0; hz[1][r][c] = m1; hz[2][r][c] = m2; hz[3][r][c] = m3; hz[4][r][c] = m4;
+  }
+  __syncthreads();
+  const float range = fmaxf(mm[1] + mm[0], mm[3] + mm[2]);   // max(preds.max() - preds.min(), target.max() - target.min())
+  const float c1 = (0.01f * range) * (0.01f * range), c2 = (0.03f * range) * (0.03f * range);
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < TS * TS; i += 256) {
+    const int r = i / TS, c = i - r * TS;
+    if (y0 + r >= Ho || x0 + c >= Wo) continue;
+    float mu_a = 0.f, mu_b = 0.f, e_aa = 0.f, e_bb = 0.f, e_ab = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float w = gw[k];
+      mu_a += w * hz[0][r + k][c]; mu_b += w * hz[1][r + k][c]; e_aa += w * hz[2][r + k][c]; e_bb += w * hz[3][r + k][c]; e_ab += w * hz[4][r + k][c];
+    }
+    const float maa = mu_a * mu_a, mbb = mu_b * mu_b, mab = mu_a * mu_b;
+    const float upper = 2.f * (e_ab - mab) + c2, lower = (e_aa - maa) + (e_bb - mbb) + c2;
+    acc += (double)(((2.f * mab + c1) * upper) / ((maa + mbb + c1) * lower));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(long)plane * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void ssim_final_kernel(const double* __restrict__ part, long nparts, double count, float* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < nparts; i += 256) acc += part[i];      // fixed order: reproducible
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] / count);
+}
+
+
 
 // ==============================================================================================
 extern "C" int ipoke_video_to_cl(const float* src, int64_t s_n, int64_t s_f, int64_t s_c, int64_t s_h, int64_t s_w, int N, int T, int C, int Hi,
@@ -211,6 +319,35 @@ extern "C" int ipoke_activation_moments(const float* act, int n, int D, double* 
   hipLaunchKernelGGL(moments_valid_kernel, dim3((n + 255) / 256), dim3(256), 0, STREAM(stream), act, n, D, valid, count);
   hipLaunchKernelGGL(moments_mean_kernel, dim3((D + 63) / 64), dim3(64), 0, STREAM(stream), act, n, D, valid, count, mu);
   hipLaunchKernelGGL(moments_cov_kernel, dim3((D + 63) / 64, D), dim3(64), 0, STREAM(stream), act, n, D, valid, count, mu, sigma);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* Workspace of ipoke_psnr_ssim in bytes (planes of H x W fp32 pixels). */
+extern "C" int64_t ipoke_image_metrics_workspace_bytes(int64_t planes, int H, int W) {
+  const int64_t Ho = H > 10 ? H - 10 : 0, Wo = W > 10 ? W - 10 : 0;
+  return 64 + 8 * (planes * ((Ho + 31) / 32) * ((Wo + 31) / 32) + 1);
+}
+/* out[0] = psnr(preds, target), out[1] = ssim(preds, target) of `planes` fp32 image planes [planes][H][W] (the N * C planes of NCHW
+ * tensors): pytorch_lightning.metrics.functional.psnr / ssim with their defaults, as SSIM_custom / PSNR_custom call them
+ * (metrics.py:450-481). */
+extern "C" int ipoke_psnr_ssim(const float* preds, const float* target, int64_t planes, int H, int W, void* workspace, float* out, void* stream) {
+  IPK_REQUIRE(preds && target && workspace && out && planes >= 1 && H >= 11 && W >= 11, "bad arguments (images must be at least 11 x 11)");
+  hipStream_t s = STREAM(stream);
+  float* mm = reinterpret_cast<float*>(workspace);
+  double* sse = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(workspace) + 32);
+  double* part = sse + 4;
+  const long n = (long)planes * H * W;
+  IPK_HIP(hipMemsetAsync(mm, 0xff, 4 * sizeof(float), s));       // 0xffffffff: below every float in the order of atomic_max_f32
+  IPK_HIP(hipMemsetAsync(sse, 0, sizeof(double), s));
+  hipLaunchKernelGGL(pair_stats_kernel, dim3(grid1(n, 2048)), dim3(256), 0, s, preds, target, n, mm, sse);
+  IPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(psnr_final_kernel, dim3(1), dim3(1), 0, s, mm, sse, n, out);
+  IPK_LAUNCH_CHECK();
+  const int Ho = H - 10, Wo = W - 10, tiles = ((Ho + 31) / 32) * ((Wo + 31) / 32);
+  hipLaunchKernelGGL(ssim_kernel, dim3(tiles, (unsigned)planes), dim3(256), 0, s, preds, target, H, W, mm, part);
+  IPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(256), 0, s, part, (long)planes * tiles, (double)planes * Ho * Wo, out + 1);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -371,8 +371,8 @@ class PokeMotionModel(nn.Module):
 
     def validation_step(self, batch, batch_id):
         """NLL terms of the batch, and (for the first n_fvd_samples clips) one sampled video per clip kept for the FVD of the
-        epoch; generated and true clips stay on the device.  ssim / psnr / lpips of the reference's logging (:510-514) come
-        from pytorch_lightning.metrics / the lpips package and are not part of this path."""
+        epoch; generated and true clips stay on the device.  ssim-val / psnr-val (:511-512) are computed on the device
+        (ipoke_amd/metrics.py); lpips-val (:513) needs the lpips package's pretrained network and is not part of this path."""
         with torch.no_grad():
             out, logdet = self.forward_density(batch)
             loss, loss_dict = self.loss_func(out, logdet)
@@ -384,6 +384,12 @@ class PokeMotionModel(nn.Module):
             self._fvd_true.append(X[:, 1:])
             self._fvd_fake_x0.append(torch.cat([X[:, 0].unsqueeze(1), X_hat], dim=1))
             self._fvd_true_x0.append(X)
+            from . import metrics
+            X_hat_log = X_hat.reshape(-1, *X_hat.shape[2:]).type_as(X)
+            X_log = X[:, 1:].reshape(-1, *X_hat.shape[2:])
+            both = metrics.psnr_ssim(X_hat_log, X_log)
+            self.log("ssim-val", both[1])
+            self.log("psnr-val", both[0])
         self.log("d_ref_nll-val", torch.abs(loss_dict["reference_nll_loss"] - loss_dict["nll_loss"]))
         self.log("loss-val", loss)
         return {"loss": loss, "batch_idx": batch_id, "loss_dict": loss_dict}

@@ -1,8 +1,11 @@
-J='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d.get("ms_per_step_median"))'
-timeout 900 python -m pytest tests/test_conv_halo_gpu.py tests/test_flow_gpu.py tests/test_units_gpu.py -m gpu -x -q 2>&1 | tail -2
-for r in 1 2; do
-echo -n "new  "; python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "$J"
-echo -n "prev "; IPOKE_LIB_PATH=$PWD/scripts/exp/libipoke_prev.so python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "$J"
-done
-echo -n "c5 new  "; python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "$J"
-echo -n "c5 prev "; IPOKE_LIB_PATH=$PWD/scripts/exp/libipoke_prev.so python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "$J"
+timeout 900 python -m pytest tests/test_metrics_gpu.py tests/test_fvd_gpu.py -m gpu -x -q -s 2>&1 | grep -v amdgpu | tail -14
+python - <<'PY'
+import torch, time
+from ipoke_amd import metrics
+x=torch.rand(480,3,128,128,device='cuda'); y=(x+0.1*torch.randn_like(x)).clamp(0,1)
+for _ in range(3): metrics.psnr_ssim(y,x)
+torch.cuda.synchronize(); e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): metrics.psnr_ssim(y,x)
+e1.record(); torch.cuda.synchronize(); print("psnr+ssim of 480 frames 3x128x128:", e0.elapsed_time(e1)/10, "ms")
+PY

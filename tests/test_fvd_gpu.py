@@ -162,6 +162,12 @@ def test_validation_loop_fvd():
         batch = synthetic_batch(3, 16, 64, seed=20 + i, device=DEV)
         out = model.validation_step(batch, i)
         assert torch.isfinite(out["loss"]).all() and "val/nll_loss" in model.logged
+        # ssim-val / psnr-val of this batch (second_stage_video.py:511-512) against the oracle on the clips the step kept
+        from oracle import metrics_ref
+        fake, true = model._fvd_fake[-1].cpu(), model._fvd_true[-1].cpu()
+        fake, true = fake.reshape(-1, *fake.shape[2:]), true.reshape(-1, *true.shape[2:])
+        assert abs(float(model.logged["ssim-val"]) - metrics_ref.ssim(fake, true).item()) <= 2e-5
+        assert abs(float(model.logged["psnr-val"]) - metrics_ref.psnr(fake, true).item()) <= 1e-3
     kept = [torch.cat(x).cpu() for x in (model._fvd_fake, model._fvd_true, model._fvd_fake_x0, model._fvd_true_x0)]
     assert kept[0].shape == (6, 15, 3, 64, 64) and kept[3].shape == (6, 16, 3, 64, 64)
     fvd_val, fvd_x0 = model.validation_epoch_end()
