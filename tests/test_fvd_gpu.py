@@ -196,6 +196,10 @@ def test_first_stage_validation_loop():
         X_hat = model.validation_step({"images": X}, i)
         want = (X[:, 1:] - X_hat).abs().mean().item()
         assert abs(model.logged["val/rec_loss"].item() - want) <= 1e-5 * max(1.0, want)
+        from oracle import metrics_ref
+        fake, true = X_hat.cpu().reshape(-1, *X_hat.shape[2:]), X[:, 1:].cpu().reshape(-1, *X_hat.shape[2:])
+        assert abs(float(model.logged["ssim-val"]) - metrics_ref.ssim(fake, true).item()) <= 2e-5
+        assert abs(float(model.logged["psnr-val"]) - metrics_ref.psnr(fake, true).item()) <= 1e-3
         kept_hat.append(X_hat.cpu()); kept_x.append(X.cpu())
     fvd_val, fvd_x0 = model.validation_epoch_end()
     o = fvd_ref.I3D(400)
