@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Benchmark of the iPOKE second-stage train step on MI355X (BASELINE.json metric: video-frames/sec).
 
-    python bench.py --gpus 1 --steps K --warmup W            # one GPU
-    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...   # data parallel, one rank per GPU
+    python bench.py --gpus N --steps K --warmup W            # N = 1: in process; N > 1: re-executes itself under torch.distributed.run
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+                                                             # the same job launched by hand: one rank per GPU over RCCL
 
 One *step* = the reference's second-stage optimisation step on one synthetic batch that is
 already resident in HBM: frozen poke/image/motion encoders (no grad) -> flow forward -> FlowLoss -> flow backward ->
@@ -326,16 +327,7 @@ def secondary(args, cfg, rank, world, device):
             D.broadcast_(p.data, src=0)
         trainer = FirstStageTrainer(model)
         eps = torch.randn(B, z, 8, 8, generator=torch.Generator().manual_seed(7 + rank)).to(device)
-        if world > 1:
-            params = [p for p in model.parameters() if p.requires_grad]
-
-            def sync_grads():
-                flat = torch._utils._flatten_dense_tensors([p.grad for p in params])
-                D.allreduce_flat_(flat, 4)
-                flat.div_(world)
-                for p, g in zip(params, torch._utils._unflatten_dense_tensors(flat, [p.grad for p in params])):
-                    p.grad.copy_(g)
-            trainer.grad_hook = sync_grads
+        trainer.enable_data_parallel()             # N > 1: flat-buffer all-reduce of the gradients, mean folded into the Adam update
         step = lambda i: trainer.step(batch["images"], eps)[0]
         metric, frames = "video-frames/sec (first-stage VAE train step, L1 + KL)", world * B * T
         workload = f"first_stage {T}x3x{size}x{size} clips, z={z}, encoder + ConvGRU + SPADE decoder fwd+bwd, per-GPU batch {B}"
@@ -406,6 +398,21 @@ def secondary(args, cfg, rank, world, device):
     D.barrier()
 
 
+def self_launch_command(argv, gpus, environ, script=None, port=None):
+    """``python bench.py --gpus N`` (N > 1) without a torchrun environment: the command that re-runs this script as N ranks, one per GPU
+    -- exactly the launch line of the driver's contract -- or None when this process is already a rank (WORLD_SIZE set), N = 1, or this
+    is the CPU-baseline child.  Rank 0 of the relaunched job prints the one JSON line."""
+    if gpus <= 1 or "WORLD_SIZE" in environ or "--cpu-baseline-only" in argv:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -428,10 +435,19 @@ def main():
         print(json.dumps(cpu_baseline(dict(configs.BENCH_CONFIGS[args.config]), clips=args.cpu_clips)), flush=True)
         return
 
+    relaunch = self_launch_command(sys.argv[1:], args.gpus, os.environ)
+    if relaunch is not None:                 # plain `python bench.py --gpus N`: become the N-rank job (same stdout, same exit code)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+        sys.stdout.flush()
+        os.execv(sys.executable, relaunch)
+
     _lib.require_gpu()
     rank, world, local = D.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if os.environ.get("IPOKE_DIST_SINGLE_GPU") != "1" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} GPU(s) visible (one rank per GPU over RCCL; the single-GPU test "
+                         "mode is IPOKE_DIST_BACKEND=gloo IPOKE_DIST_SINGLE_GPU=1)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     cfg = dict(configs.BENCH_CONFIGS[args.config])

@@ -93,6 +93,10 @@ typedef struct {
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
 /* n back-to-back native launches of the same convolution (kernel timing without host round trips) */
 int ipoke_conv_forward_repeat(const ipoke_conv_desc* d, int dtype, int n, void* stream);
+/* Test hook: kernel-dispatch switch `name` ("c64": conv3x3_c64, "halo16": conv3x3_halo16) <- value (0 off, 1 the measured default
+ * rule, 2 wherever the kernel can run; < 0: back to the environment default IPOKE_C64 / IPOKE_HALO16).  The switches are read from the
+ * environment once per process -- no getenv on the launch path. */
+int ipoke_set_dispatch_override(const char* name, int value);
 
 /* Split count the library wants for the skinny 3x3 convolutions of the coupling nets (conv3 forward: split-K partial
  * slabs; conv1 data gradient: atomic accumulation) at M = 64*B output rows and Kc input channels -- callers size their
@@ -309,7 +313,8 @@ int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us);
  * wgrad writes dl, du, dlog_s of one layer into the flat gradient buffer (B samples of P8 positions each). */
 int ipoke_lu_job_size(void);
 int ipoke_lu_prepare(const float* params, const float* fbuf, float* workspace, const void* jobs_dev, int njobs, void* stream);
-int ipoke_lu_apply(const float* in, float* out, int B, int ld, int C, const float* mat, int transposed, void* stream);
+/* out[m][:C] = mat (or mat^T) in[m][:C] on M state rows of pitch ld (M = B * positions per sample); columns >= C are copied */
+int ipoke_lu_apply(const float* in, float* out, int64_t M, int ld, int C, const float* mat, int transposed, void* stream);
 int ipoke_lu_wgrad(const float* dy, const float* x, int B, int P8, int ld, const float* params, const float* fbuf,
                    const float* workspace, const void* job_dev, const float* dld, float* grads, void* stream);
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ipoke_dtype_size": (c_int, [c_int]),
     "ipoke_conv_forward": (c_int, [POINTER(ConvDesc), c_int, _P]),
     "ipoke_conv_forward_repeat": (c_int, [POINTER(ConvDesc), c_int, c_int, _P]),
+    "ipoke_set_dispatch_override": (c_int, [c_char_p, c_int]),
     "ipoke_conv3x3_skinny_splitk": (c_int, [c_int, c_int, c_int]),
     "ipoke_conv_wgrad": (c_int, [POINTER(WgradDesc), c_int, _P]),
     "ipoke_wgrad_batch_entry_size": (c_int, []),
@@ -226,7 +227,7 @@ SIGNATURES = {
     "ipoke_flow_set_float_buffers": (c_int, [_P, _P]),
     "ipoke_lu_job_size": (c_int, []),
     "ipoke_lu_prepare": (c_int, [_P, _P, _P, _P, c_int, _P]),
-    "ipoke_lu_apply": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "ipoke_lu_apply": (c_int, [_P, _P, c_int64, c_int, c_int, _P, c_int, _P]),
     "ipoke_lu_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "ipoke_flow_op_info": (c_int, [_P, c_int, POINTER(c_int64)]),
     "ipoke_flow_shadow_base": (c_int64, [_P]),
@@ -284,3 +285,17 @@ def require_gpu():
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("ipoke_amd needs an MI355X (gfx950) GPU: no HIP device is visible and there is no CPU path")
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def dispatch_override(name, value):
+    """Test hook: run a block with the kernel-dispatch switch ``name`` ("c64" | "halo16") at ``value`` (0 off, 1 the measured default
+    rule, 2 wherever the kernel can run), then return it to the process default (ipoke_set_dispatch_override)."""
+    check(lib().ipoke_set_dispatch_override(name.encode(), int(value)))
+    try:
+        yield
+    finally:
+        check(lib().ipoke_set_dispatch_override(name.encode(), -1))

@@ -152,8 +152,10 @@ __global__ void moments_cov_kernel(const float* __restrict__ a, int n, int D, co
 // pytorch_lightning.metrics.functional.psnr / ssim as the reference's validation logging calls them (second_stage_video.py:511-512,
 // metrics.py:450-481: defaults -- 11 x 11 Gaussian window of sigma 1.5, k1 = 0.01, k2 = 0.03, data ranges taken from the tensors).
 // mm[0..3] = {-min(a), max(a), -min(b), max(b)} (one atomic flavour); sums in double.
+// Chosen by the SIGN BIT, not by `v >= 0`: -0.0f (the negated minimum of an image whose darkest pixel is exactly 0) compares >= 0 but its
+// bit pattern is INT_MIN, which as a signed integer never beats the 0xffffffff initial value.
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
-  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  if (__float_as_int(v) >= 0) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 __global__ void pair_stats_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ mm, double* __restrict__ sse) {

@@ -1066,7 +1066,7 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
     for (const Ctx& l : lanes) {
       const float* in = l.state(cur); float* out = l.state(nxt);
       if (op.type == OP_LU) {
-        rc = ipoke_lu_apply(in, out, l.B, l.ld, op.C, lu_mat(l, op, 0), 0, l.stream());
+        rc = ipoke_lu_apply(in, out, (int64_t)l.B * l.f->P, l.ld, op.C, lu_mat(l, op, 0), 0, l.stream());
       } else if (op.type == OP_ACTNORM) {
         const float* ls = op.p_ls >= 0 ? params + op.p_ls : nullptr;
         const float* bs = op.p_bias >= 0 ? params + op.p_bias : nullptr;
@@ -1195,7 +1195,7 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
     for (const Ctx& l : lanes) {
       const float* in = l.state(cur); float* out = l.state(cur ^ 1);
       if (op.type == OP_LU) {
-        rc = ipoke_lu_apply(in, out, l.B, l.ld, op.C, lu_mat(l, op, 1), 0, l.stream());
+        rc = ipoke_lu_apply(in, out, (int64_t)l.B * l.f->P, l.ld, op.C, lu_mat(l, op, 1), 0, l.stream());
       } else if (op.type == OP_ACTNORM) {
         rc = ipoke_actnorm_inv(in, out, (int)l.M, l.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
                                op.p_bias >= 0 ? params + op.p_bias : nullptr, op.idx_bwd >= 0 ? perm + op.idx_bwd : nullptr,
@@ -1490,7 +1490,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       if (op.type == OP_LU) {
         // dx = dy W (W^T applied per position); parameter gradients straight into the flat buffer (the forward pass of
         // this step left [W | W^-1 | wl | wu] in the workspace)
-        rc = ipoke_lu_apply(gin, gout, l.B, l.ld, op.C, lu_mat(l, op, 0), 1, l.stream()); if (rc) return rc;
+        rc = ipoke_lu_apply(gin, gout, (int64_t)l.B * l.f->P, l.ld, op.C, lu_mat(l, op, 0), 1, l.stream()); if (rc) return rc;
         rc = ipoke_lu_wgrad(gin, xin, l.B, f->P, l.ld, params, f->fbuf, l.at<float>(l.plan.lu),
                             reinterpret_cast<const unsigned char*>(f->d_lujobs) + (size_t)op.lu_idx * sizeof(LuJobH), l.dld(), grads,
                             l.stream());

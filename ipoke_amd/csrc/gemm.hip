@@ -10,6 +10,9 @@
 // the TN kernel, 8x8 (bf16) / 4x4 (f32) blocks are transposed in registers before they reach LDS.
 // 256 threads = 4 wave64; each wave owns MREP x NREP 16x16 accumulator fragments.
 #include "common.h"
+#include <atomic>
+#include <cstring>
+#include <mutex>
 #include <type_traits>
 
 namespace ipoke {
@@ -1013,6 +1016,13 @@ static int set_lds(KernelT k, size_t bytes) {
   IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return IPOKE_OK;
 }
+// The dynamic-LDS attribute of a kernel is set once per process, race-free (the header promises thread safety for launches on
+// distinct streams): one std::once_flag + result per expansion site, i.e. per kernel (template instantiation).
+#define IPK_SET_LDS_ONCE(kern, bytes) do {                                              \
+    static std::once_flag ipk_once; static int ipk_rc = IPOKE_OK;                       \
+    std::call_once(ipk_once, [&]() { ipk_rc = set_lds(kern, bytes); });                 \
+    if (ipk_rc) return ipk_rc;                                                          \
+  } while (0)
 
 // XCD-aware tile -> block mapping: XCD x (= blockIdx % 8) owns a (tiles_m/xa) x (tiles_n/xb) sub-grid so
 // that its private L2 holds one slab of A rows and one slab of W rows; (xa, xb) minimises L2 fill bytes.
@@ -1895,11 +1905,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   wait_vmcnt<0>();
 }
 
+// Dispatch switches of the two persistent / wide 3 x 3 kernels: 0 off, 1 (default) where measured faster, 2 wherever the kernel can run.
+// Read from the environment ONCE (IPOKE_C64 / IPOKE_HALO16, developer A/B); the parity tests move them at run time through
+// ipoke_set_dispatch_override (no getenv on the launch path, atomics because launches on distinct streams may come from distinct threads).
+static std::atomic<int> g_c64_mode{-1}, g_halo16_mode{-1};
+static int dispatch_mode(std::atomic<int>& slot, const char* env_name) {
+  int m = slot.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv(env_name);
+    m = e ? atoi(e) : 1;
+    if (m < 0 || m > 2) m = 1;
+    int expect = -1;
+    if (!slot.compare_exchange_strong(expect, m)) m = expect;      // somebody else (or the override hook) was first
+  }
+  return m;
+}
+
 static bool c64_applicable(const NtParams& p) {
-  // IPOKE_C64 (developer A/B; read per call so that the parity tests can force the kernel onto small maps): 0 off, 1 (default)
-  // at >= 512 patches (two per CU), 2 wherever it can run
-  const char* mode_s = getenv("IPOKE_C64");
-  const int mode = mode_s ? atoi(mode_s) : 1;
+  // mode 1 (default): at >= 512 patches (two per CU)
+  const int mode = dispatch_mode(g_c64_mode, "IPOKE_C64");
   const GeomDev& g = p.g;
   if (!mode) return false;
   // window offsets a - ph (forward) / ph - a (data gradient) must lie within the one-pixel halo
@@ -1919,8 +1943,7 @@ static bool c64_applicable(const NtParams& p) {
 static int launch_conv3x3_c64(NtParams& p, hipStream_t s) {
   const size_t lds = 9 * 64 * 128 + 2 * 41 * 1024 + 1024;
   auto kern = conv3x3_c64_kernel;
-  static bool attr_done = false;
-  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  IPK_SET_LDS_ONCE(kern, lds);
   const int ntiles = p.g.M / 256;
   p.tiles_m = ntiles; p.tiles_n = 1; p.xa = p.xb = 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min(ntiles, 256)), dim3(512), lds, s, p);
@@ -1929,10 +1952,7 @@ static int launch_conv3x3_c64(NtParams& p, hipStream_t s) {
 }
 
 static bool halo16_applicable(const NtParams& p) {
-  // IPOKE_HALO16 (developer A/B): 0 off, 1 (default) where measured faster, 2 wherever the kernel can run
-  // (read on every call -- a launch is tens of microseconds -- so that the parity tests can force the kernel onto small shapes)
-  const char* mode_s = getenv("IPOKE_HALO16");
-  const int mode = mode_s ? atoi(mode_s) : 1;
+  const int mode = dispatch_mode(g_halo16_mode, "IPOKE_HALO16");
   const GeomDev& g = p.g;
   if (!mode || p.a_f32 || p.c_scatter || !(g.taps == 9 || g.taps == 27) || g.khw != 9 || g.kw != 3) return false;
   const bool flat = g.taps == 9 && g.Di == 1 && g.Do == 1 && g.pd == 0 && g.sd == 1;
@@ -1957,8 +1977,7 @@ static bool halo16_applicable(const NtParams& p) {
 static int launch_conv3x3_halo16(NtParams& p, hipStream_t s) {
   const size_t lds = 2 * 41 * 1024 + 4 * 128 * 128 + 8 * 1024;
   auto kern = conv3x3_halo16_kernel;
-  static bool attr_done = false;
-  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  IPK_SET_LDS_ONCE(kern, lds);
   p.tiles_m = p.g.M / 256; p.tiles_n = ceil_div(p.Nout, 128); p.xa = p.xb = 0;
   dim3 grid((unsigned)p.tiles_m, (unsigned)p.tiles_n);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
@@ -1994,8 +2013,7 @@ static bool halo_applicable(const NtParams& p) {
 static int launch_conv3x3_halo(NtParams& p, hipStream_t s) {
   const size_t lds = 2 * 24 * 1024 + 12 * 64 * 128 + 8 * 1024;
   auto kern = conv3x3_halo_kernel;
-  static bool attr_done = false;
-  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  IPK_SET_LDS_ONCE(kern, lds);
   p.tiles_m = p.g.M / 128; p.tiles_n = ceil_div(p.Nout, 64); p.xa = p.xb = 0;
   dim3 grid((unsigned)p.tiles_m, (unsigned)p.tiles_n);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
@@ -2024,8 +2042,7 @@ static int launch_nt_glds_impl(NtParams& p, hipStream_t s) {
   size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * 128 + WM * WN * WK * 64 * 16 + 256 * sizeof(int);
   if (lds < (size_t)WK * BM * (BN * 4 + 16)) lds = (size_t)WK * BM * (BN * 4 + 16);      // epilogue staging (+ the K halves' hand-over)
   auto kern = igemm_nt_glds_kernel<T, WM, WN, MREP, NREP, NSTAGE, KPB, SIMPLE, WK>;
-  static bool attr_done = false;
-  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  IPK_SET_LDS_ONCE(kern, lds);
   dim3 grid((unsigned)((long)p.tiles_m * p.tiles_n), (unsigned)p.splitk);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * WK * 64), lds, s, p);
   IPK_LAUNCH_CHECK();
@@ -2055,8 +2072,7 @@ static int launch_nt(NtParams& p, hipStream_t s) {
   if (lds < (size_t)BM * (BN * 4 + 16)) lds = (size_t)BM * (BN * 4 + 16);
   lds += 256 * sizeof(int);
   auto kern = igemm_nt_kernel<T, WM, WN, MREP, NREP>;
-  static bool attr_done = false;     // one flag per template instantiation
-  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  IPK_SET_LDS_ONCE(kern, lds);     // one flag per template instantiation
   dim3 grid((unsigned)nt, (unsigned)p.splitk);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
   IPK_LAUNCH_CHECK();
@@ -2079,8 +2095,7 @@ static int launch_conv3x3_s8(NtParams& p, hipStream_t s) {
   constexpr int BM = 128;
   const size_t lds = 2 * BM * 128 + 256 + 12 * 64 * 128 + 512 * 16;
   auto kern = conv3x3_s8_kernel;
-  static bool attr_done = false;
-  if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+  IPK_SET_LDS_ONCE(kern, lds);
   p.tiles_m = ceil_div(p.g.M, BM); p.tiles_n = 1; p.xa = p.xb = 0;
   p.kb_per_split = ceil_div(p.Kc / 64, p.splitk);
   dim3 grid((unsigned)p.tiles_m, (unsigned)p.splitk);
@@ -2467,8 +2482,7 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     const int NST = nst == 3 ? 3 : 2;
     const size_t lds2 = (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
     auto kern = NST == 2 ? igemm_tn_glds_kernel<2, 64> : igemm_tn_glds_kernel<3, 64>;
-    static bool attr_done2[2] = {false, false};
-    if (!attr_done2[NST - 2]) { int rc = set_lds(kern, lds2); if (rc) return rc; attr_done2[NST - 2] = true; }
+    if (NST == 2) { IPK_SET_LDS_ONCE(kern, lds2); } else { IPK_SET_LDS_ONCE(kern, lds2); }      // one flag per ring depth
     const int ntiles = p.tiles_n * p.tiles_k;
     const int cap = p.max_wgs > 0 ? p.max_wgs : ntiles;
     p.xa = p.xb = 0;
@@ -2500,13 +2514,11 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, (unsigned)nbatch);
   if (nr == 2) {
     auto kern = igemm_tn_kernel<T, 2>;
-    static bool attr_done = false;
-    if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+    IPK_SET_LDS_ONCE(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
   } else {
     auto kern = igemm_tn_kernel<T, 4>;
-    static bool attr_done = false;
-    if (!attr_done) { int rc = set_lds(kern, lds); if (rc) return rc; attr_done = true; }
+    IPK_SET_LDS_ONCE(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
   }
   IPK_LAUNCH_CHECK();
@@ -2521,6 +2533,16 @@ using namespace ipoke;
 static long long* g_gemm_stamps = nullptr;
 extern "C" void ipoke_gemm_set_stamps(long long* base) { g_gemm_stamps = base; }
 #endif
+
+/* Test hook: moves a kernel-dispatch switch at run time ("c64" / "halo16": 0 off, 1 default rule, 2 wherever the kernel can run;
+ * value < 0 re-reads the environment default at the next launch). */
+extern "C" int ipoke_set_dispatch_override(const char* name, int value) {
+  IPK_REQUIRE(name != nullptr && value <= 2, "bad arguments");
+  std::atomic<int>* slot = !strcmp(name, "c64") ? &g_c64_mode : (!strcmp(name, "halo16") ? &g_halo16_mode : nullptr);
+  IPK_REQUIRE(slot != nullptr, "unknown dispatch switch (c64 | halo16)");
+  slot->store(value < 0 ? -1 : value, std::memory_order_relaxed);
+  return IPOKE_OK;
+}
 
 extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream) {
   IPK_REQUIRE(d != nullptr, "null descriptor");

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void lu_prepare_kernel(const float* __restrict
 }
 
 // out[m][i] = sum_j mat[i][j] in[m][j]  (transposed: mat[j][i]) on the first C columns of one sample; the rest is copied
-__global__ __launch_bounds__(256) void lu_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int ld, int C,
+__global__ __launch_bounds__(256) void lu_apply_kernel(const float* __restrict__ in, float* __restrict__ out, long M, int ld, int C,
                                                        const float* __restrict__ mat, int transposed) {
   __shared__ float Ws[kLuMax * kLuP], X[64 * kLuP];
   const int tid = threadIdx.x;
@@ -96,13 +96,14 @@ __global__ __launch_bounds__(256) void lu_apply_kernel(const float* __restrict__
     const int r = e / C, c = e - r * C;
     Ws[(transposed ? c : r) * kLuP + (transposed ? r : c)] = mat[e];
   }
-  for (int e = tid; e < 64 * ld; e += 256) {
+  const int rows = (int)(M - row0 < 64 ? M - row0 : 64);        // the last workgroup of a row count that is not a multiple of 64
+  for (int e = tid; e < rows * ld; e += 256) {
     const int m = e / ld, c = e - m * ld;
     const float v = in[(row0 + m) * ld + c];
     if (c < C) X[m * kLuP + c] = v; else out[(row0 + m) * ld + c] = v;
   }
   __syncthreads();
-  for (int e = tid; e < 64 * C; e += 256) {
+  for (int e = tid; e < rows * C; e += 256) {
     const int m = e / C, i = e - m * C;
     float s = 0.f;
     for (int k = 0; k < C; ++k) s = fmaf(Ws[i * kLuP + k], X[m * kLuP + k], s);
@@ -194,9 +195,10 @@ extern "C" int ipoke_lu_prepare(const float* params, const float* fbuf, float* w
   return IPOKE_OK;
 }
 
-extern "C" int ipoke_lu_apply(const float* in, float* out, int B, int ld, int C, const float* mat, int transposed, void* stream) {
-  IPK_REQUIRE(in && out && mat && B >= 1 && C >= 1 && C <= kLuMax && ld >= C && in != out, "bad arguments");
-  hipLaunchKernelGGL(lu_apply_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, ld, C, mat, transposed);
+extern "C" int ipoke_lu_apply(const float* in, float* out, int64_t M, int ld, int C, const float* mat, int transposed, void* stream) {
+  IPK_REQUIRE(in && out && mat && M >= 1 && M < (1L << 37) && C >= 1 && C <= kLuMax && ld >= C && in != out, "bad arguments");
+  hipLaunchKernelGGL(lu_apply_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, (long)M, ld, C,
+                     mat, transposed);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

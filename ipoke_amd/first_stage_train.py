@@ -781,6 +781,7 @@ class MultiTensorAdam:
         self.exp_avg = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.steps = 0
+        self.grad_scale = 1.0           # folded into the update: 1 / world for gradients summed over data-parallel ranks
 
     @property
     def lr(self):
@@ -829,7 +830,7 @@ class MultiTensorAdam:
         clear_operand_cache()                      # the update writes through raw pointers: no version bump tells the cache
         check(_lib.lib().ipoke_adam_multi(arr([self.params[i].data for i in idx]), arr(grads), arr([self.exp_avg[i] for i in idx]),
                                           arr([self.exp_avg_sq[i] for i in idx]), sizes, n, self.lr, self.betas[0], self.betas[1],
-                                          self.eps, self.weight_decay, self.steps, 1.0, _lib.current_stream()))
+                                          self.eps, self.weight_decay, self.steps, float(self.grad_scale), _lib.current_stream()))
 
 
 class FirstStageTrainer:
@@ -846,8 +847,34 @@ class FirstStageTrainer:
             raise ValueError("w_vgg != 0 needs vgg_loss=ipoke_amd.vgg.VGGLoss(...) (load the torchvision VGG-19 weights into it)")
         self.opt = MultiTensorAdam(model.parameters(), lr, betas, weight_decay, eps)
         self.params = self.opt.params
-        self.grad_hook = None           # data parallel: all-reduce of the gradients between backward and the update
+        self.grad_hook = None           # called between backward and the update (data parallel: enable_data_parallel)
+        self._dp_flat = None
 
+    def enable_data_parallel(self, n_buckets=4):
+        """One process per GPU (experiments/experiment.py:86-89 runs the first stage under DDP): after the backward pass the gradients
+        are gathered into ONE persistent flat buffer (a multi-tensor copy), summed over the ranks in ``n_buckets`` large slices
+        (``dist.allreduce_flat_``: xGMI is point-to-point, large messages keep every link busy) and handed to the optimizer as views
+        of that buffer -- no copy back; the mean's 1 / world is folded into the fused Adam update."""
+        from . import dist as D
+        world = D.world_size()
+        if world == 1:
+            return
+        sizes = [p.numel() for p in self.params]
+        offs, n = [], 0
+        for k in sizes:
+            offs.append(n)
+            n += -(-k // 4) * 4                       # 16-byte aligned views
+        self._dp_flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        views = [self._dp_flat[o:o + k].view(p.shape) for o, k, p in zip(offs, sizes, self.params)]
+        self.opt.grad_scale = 1.0 / world
+
+        def sync_grads():
+            have = [(v, p) for v, p in zip(views, self.params) if p.grad is not None]
+            torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
+            D.allreduce_flat_(self._dp_flat, n_buckets)
+            for v, p in have:
+                p.grad = v
+        self.grad_hook = sync_grads
     def on_epoch_end(self):
         """Lightning steps the ExponentialLR scheduler once per epoch (first_stage_motion_model.py:383-388)."""
         self.opt.exponential_lr_step(self.gamma)

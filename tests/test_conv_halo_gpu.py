@@ -1,5 +1,5 @@
 """The halo-staged 3x3 convolution kernels (csrc/gemm.hip: conv3x3_halo_kernel, and conv3x3_halo16_kernel for wide layers -- every
-test runs twice: with the dispatcher's own choice and with IPOKE_HALO16=2, which sends every shape the wide kernel can run to it)
+test runs twice: with the dispatcher's own choice and with the halo16 dispatch switch at 2, which sends every shape the wide kernel can run to it)
 -- conv3x3_halo_kernel -- 2-D 3x3 / stride 1 / pad 1 convolutions with
 >= 64 dense input channels on maps of 16 x 16 and larger) through ipoke_conv_forward, against torch's fp32 convolution of the
 same bf16-rounded operands: forward with bias + activation, narrow fp32 outputs (the decoder's 3-channel head), several output
@@ -17,16 +17,15 @@ DEV = "cuda"
 
 
 @pytest.fixture(autouse=True, params=["dispatch", "halo16", "c64"])
-def _kernel_choice(request, monkeypatch):
-    """halo16 / c64: IPOKE_HALO16=2 / IPOKE_C64=2 send every shape conv3x3_halo16_kernel / conv3x3_c64_kernel (persistent workgroups,
-    filter resident in LDS: 64 -> <= 64 channels) can run to it; the dispatcher's own rule needs maps far larger than a test's."""
-    monkeypatch.delenv("IPOKE_HALO16", raising=False)
-    monkeypatch.delenv("IPOKE_C64", raising=False)
-    if request.param == "halo16":
-        monkeypatch.setenv("IPOKE_HALO16", "2")
-    elif request.param == "c64":
-        monkeypatch.setenv("IPOKE_C64", "2")
-    yield
+def _kernel_choice(request):
+    """halo16 / c64: the dispatch switches at 2 (ipoke_set_dispatch_override) send every shape conv3x3_halo16_kernel / conv3x3_c64_kernel
+    (persistent workgroups, filter resident in LDS: 64 -> <= 64 channels) can run to it; the dispatcher's own rule needs maps far larger
+    than most of this file's (tests/test_c4_dispatch_gpu.py covers the default rule at the benchmarked sizes)."""
+    if request.param == "dispatch":
+        yield
+    else:
+        with _lib.dispatch_override(request.param, 2):
+            yield
 
 
 def _rows(x):          # [N, C, H, W] -> channels-last bf16 rows

@@ -159,3 +159,22 @@ def test_sharded_optimizer_state_roundtrip_and_conversion():
             one._shard_state(-(b + 1), b + main, e - b - main)
     fsd = one.full_state_dict()
     assert torch.equal(fsd["exp_avg_sq"], full[1])
+
+
+def test_bench_self_launch_decision():
+    """`python bench.py --gpus N` as the driver runs it (no torchrun environment) must turn itself into the N-rank job of the contract;
+    a process that already is a rank, N = 1 and the CPU-baseline child must not relaunch."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = bench.self_launch_command(argv, 8, {}, script="/x/bench.py", port=29123)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29123"
+    assert cmd[-len(argv) - 1:] == ["/x/bench.py"] + argv                       # the script and ITS arguments, unchanged, last
+    auto = bench.self_launch_command(argv, 2, {})
+    assert 1024 <= int(auto[auto.index("--master-port") + 1]) < 65536 and auto[-len(argv) - 1].endswith("bench.py")
+    assert bench.self_launch_command(argv, 8, {"WORLD_SIZE": "8", "RANK": "3"}) is None      # already a rank of a launched job
+    assert bench.self_launch_command(["--gpus", "1"], 1, {}) is None
+    assert bench.self_launch_command(["--cpu-baseline-only", "--gpus", "2"], 2, {}) is None

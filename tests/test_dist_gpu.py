@@ -92,3 +92,24 @@ def test_bf16_gradient_exchange_stays_close():
     assert torch.equal(b0[3], b1[3])
     assert all(abs(x - y) <= 1e-3 * max(1.0, abs(x)) for x, y in zip(a0[0], b0[0])), (a0[0], b0[0])
     assert (a0[3] - b0[3]).abs().max().item() <= 3 * 3 * 1e-3      # at most lr per step and parameter
+
+
+def test_bench_gpus2_self_launches_over_gloo():
+    """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself under torch.distributed.run, two ranks share
+    this box's one GPU over gloo (IPOKE_DIST_BACKEND / IPOKE_DIST_SINGLE_GPU: the only difference to the RCCL run is the backend string
+    and the device index), rank 0 prints ONE JSON line whose value is the whole job's.  c1 = BASELINE configs[0] (plants_64, z = 32)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IPOKE_DIST_BACKEND="gloo", IPOKE_DIST_SINGLE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "c1",
+                          "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 16 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]

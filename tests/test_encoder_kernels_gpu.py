@@ -94,13 +94,12 @@ def test_folded_stem_matches_conv3d(dtype, monkeypatch):
 @pytest.mark.parametrize("N,H,W,cin,cout,snorm", [(2, 8, 8, 32, 24, False), (3, 16, 32, 64, 64, True), (1, 5, 7, 16, 40, False),
                                                   (2, 16, 48, 128, 64, True), (1, 32, 16, 128, 20, False)])
 @pytest.mark.parametrize("c64", [False, True], ids=["dispatch", "c64"])
-def test_conv_transpose_phases(N, H, W, cin, cout, snorm, dtype, c64, monkeypatch):
+def test_conv_transpose_phases(N, H, W, cin, cout, snorm, dtype, c64, monkeypatch, request):
     """Stride-2 ConvTranspose2d (util.py:52-55) as four sub-pixel stride-1 convolutions with scattered output rows
     (ipoke_conv_desc.c_scatter) against torch.nn.functional.conv_transpose2d and against the one-launch 9-tap form."""
-    if c64:                 # the phases of 64- / 128-channel inputs on 16-aligned maps through conv3x3_c64_kernel (filter resident in LDS)
-        monkeypatch.setenv("IPOKE_C64", "2")
-    else:
-        monkeypatch.delenv("IPOKE_C64", raising=False)
+    # c64: the phases of 64- / 128-channel inputs on 16-aligned maps through conv3x3_c64_kernel (filter resident in LDS)
+    _lib.check(_lib.lib().ipoke_set_dispatch_override(b"c64", 2 if c64 else -1))
+    request.addfinalizer(lambda: _lib.lib().ipoke_set_dispatch_override(b"c64", -1))
     torch.manual_seed(H * W + cin)
     mod = FS._Conv(cin, cout, 3, 2, 1, transposed=True, snorm=snorm).to(DEV)
     with torch.no_grad():

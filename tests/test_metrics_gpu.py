@@ -35,3 +35,25 @@ def test_identical_images_and_running_means():
     assert abs(s.compute().item() - sum(v[1] for v in vals) / 3) <= 1e-6
     with pytest.raises(ValueError):
         metrics.psnr_ssim(x, x[:, :2])
+
+
+@pytest.mark.parametrize("zeros_everywhere", [True, False])
+def test_exact_zero_minimum(zeros_everywhere):
+    """Images in [0, 1] whose darkest pixels are exactly 0: the negated minimum is -0.0f, whose bit pattern is INT_MIN (ADVICE r3:
+    the integer-atomic float maximum must pick its flavour by the sign bit).  ``zeros_everywhere``: every wavefront sees a zero (the range
+    table stayed at its NaN initial value before the fix); otherwise only a few do (the minimum was silently over-estimated)."""
+    g = torch.Generator().manual_seed(5)
+    shape = (3, 3, 48, 64)
+    target = torch.rand(shape, generator=g) * 0.9 + 0.1
+    preds = (target + 0.1 * torch.randn(shape, generator=g)).clamp(0.05, 1)
+    if zeros_everywhere:
+        target[..., ::2] = 0.0
+        preds[..., 1::3] = 0.0
+    else:
+        target[1, 2, 17, 5] = 0.0
+        preds[2, 0, 40, 63] = 0.0
+    both = metrics.psnr_ssim(preds.to(DEV), target.to(DEV)).cpu()
+    want_p, want_s = metrics_ref.psnr(preds, target).item(), metrics_ref.ssim(preds, target).item()
+    assert torch.isfinite(both).all()
+    assert abs(both[0].item() - want_p) <= 1e-4 * max(1.0, abs(want_p))
+    assert abs(both[1].item() - want_s) <= 2e-5
