@@ -88,6 +88,13 @@ typedef struct {
    * fall on input pixels. */
   int32_t c_scatter;
   int64_t c_sn, c_sh, c_sw, c_row0;
+  /* optional per-image-group scale of the accumulators, applied before the bias (splitk = 1): the outputs of image n are multiplied by
+   * row_scale[(n / rs_images) * rs_stride].  First-stage training decodes the T - 1 generated frames of a batch of clips as ONE batch
+   * ordered (frame, clip); torch's spectral_norm runs one power iteration per decoder call, i.e. frame t uses W / sigma_t (util.py:52,
+   * 252) -- conv(x, W / sigma_t) = conv(x, W) / sigma_t, so one operand of W_orig serves every frame and 1 / sigma_t is this scale
+   * (rs_images = clips per batch, row_scale = the {sigma, 1/sigma} table of ipoke_spectral_sigma_multi + 1, rs_stride = 2). */
+  const float* row_scale;
+  int32_t rs_images, rs_stride;
 } ipoke_conv_desc;
 
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
@@ -97,6 +104,9 @@ int ipoke_conv_forward_repeat(const ipoke_conv_desc* d, int dtype, int n, void* 
  * rule, 2 wherever the kernel can run; < 0: back to the environment default IPOKE_C64 / IPOKE_HALO16).  The switches are read from the
  * environment once per process -- no getenv on the launch path. */
 int ipoke_set_dispatch_override(const char* name, int value);
+/* Test hook: the kernel family the calling thread's last ipoke_conv_forward was dispatched to */
+enum { IPOKE_KERNEL_NONE = 0, IPOKE_KERNEL_IGEMM = 1, IPOKE_KERNEL_S8 = 2, IPOKE_KERNEL_HALO = 3, IPOKE_KERNEL_HALO16 = 4, IPOKE_KERNEL_C64 = 5 };
+int ipoke_last_conv_kernel(void);
 
 /* Split count the library wants for the skinny 3x3 convolutions of the coupling nets (conv3 forward: split-K partial
  * slabs; conv1 data gradient: atomic accumulation) at M = 64*B output rows and Kc input channels -- callers size their
@@ -477,6 +487,8 @@ typedef struct {
   float* workspace;                      /* ipoke_groupnorm_bwd_workspace_floats(N, S, C, G) floats  */
   const float* stats;                    /* optional [N][G][2] (mean, rstd) kept from the forward pass (the tail of the forward
                                             workspace, see ipoke_groupnorm_stats_offset); NULL: recomputed from x */
+  int32_t mod_samples;                   /* as ipoke_norm_desc.mod_samples: sample n read the modulation of sample n % mod_samples;
+                                            dmod_gamma / dmod_beta are still written per sample (sum the frames: ipoke_sum_frames) */
 } ipoke_norm_bwd_desc;
 /* float offset of the (mean, rstd) table inside the workspace ipoke_groupnorm / ipoke_groupnorm_stats just filled */
 int64_t ipoke_groupnorm_stats_offset(int N, int S, int G);
@@ -500,6 +512,36 @@ int ipoke_gru_gates_bwd(const void* ur_pre, const void* h, int ldh, const void* 
  * 1/sigma of spectral norm).  Replaces the reshape/permute/pad/cast chain of nn.Conv2d's weight on every call. */
 int ipoke_conv_weight_operand(const float* w, int cout, int cin, int taps, int transposed, const float* inv_scale, void* out, int kc,
                               int dtype, void* stream);
+/* ---- frames of a batch of clips decoded as ONE batch (first-stage training, ipoke_conv_desc.row_scale) ----------------------------
+ * Backward pass over (dy, y) of a layer  y = act(conv(x, W) * scale[group] + bias)  whose rows are grouped by frame (group of row m =
+ * m / rows_per_group; scale[group * scale_stride] = 1 / sigma_t of torch's spectral_norm, util.py:52, 252):
+ *   gs[m][c]    = dy * act'(y) * scale[group]      (dtype, columns C .. Cpad zero): rows of the data- and weight-gradient GEMMs
+ *   dots[group] = sum over the group's rows and channels of dy * act'(y) * (pre(y) - bias[c])  = <dW_eff_t, W / sigma_t>
+ *   dbias[c]    = column sums of dy * act'(y)      (optional)
+ * pre(y) is the pre-activation recovered from the saved output (act: NONE, RELU, ELU, LRELU02).  Deterministic (per-block partial
+ * sums reduced in a fixed order).  Replaces, for all T - 1 decoder calls of a training pass at once, autograd's backward of
+ * `weight_orig / sigma` in torch.nn.utils.spectral_norm's compute_weight. */
+typedef struct {
+  const void* dy; int32_t lddy;
+  const void* y; int32_t ldy;            /* saved layer output (post-activation)                     */
+  int64_t M; int32_t C, Cpad; int32_t act;
+  const float* bias;                     /* [C] or NULL                                              */
+  const float* scale; int32_t scale_stride; int64_t rows_per_group;
+  void* gs; int32_t ldgs;
+  float* dots;                           /* [M / rows_per_group]                                     */
+  float* dbias;                          /* [C] or NULL                                              */
+  float* workspace;                      /* ipoke_rowscale_bwd_workspace_floats(M, C, rows_per_group) floats */
+} ipoke_rowscale_bwd_desc;
+int64_t ipoke_rowscale_bwd_workspace_floats(int64_t M, int C, int64_t rows_per_group);
+int ipoke_rowscale_bwd(const ipoke_rowscale_bwd_desc* d, int dtype, void* stream);
+/* In place: grad (gradient of W_orig in PyTorch weight layout, holding sum_t dW_eff_t / sigma_t: the weight gradient of the rows
+ * scaled by 1 / sigma_t) -= sum_t dots[t] / sigma_t * u_t v_t^T -- the part that reaches W_orig through sigma_t = u_t^T W v_t.
+ * snapshots[t * snap_stride ..] = u_t | v_t and sig[t * sig_stride ..] = {sigma_t, 1 / sigma_t} as ipoke_spectral_sigma_multi wrote them. */
+int ipoke_spectral_bwd_frames(const float* w, int cout, int cin, int taps, int transposed, float* grad, const float* snapshots,
+                              int64_t snap_stride, const float* sig, int64_t sig_stride, const float* dots, int frames, void* stream);
+/* dst[i] = sum_{f < frames} src[f * n + i] (dtype in and out, fp32 accumulation; n a multiple of 16 bytes): gradients of maps shared by
+ * the frames of a clip -- the SPADE modulation of util.py:494-500, which autograd sums over the reference's T - 1 decoder calls */
+int ipoke_sum_frames(const void* src, void* dst, int frames, int64_t n, int dtype, void* stream);
 /* torch.nn.utils.spectral_norm (reference: models/modules/autoencoders/util.py:52,252): one power iteration
  * v = normalize(W^T u), u = normalize(W v) (iterate != 0; u, v updated in place, eps as in F.normalize) and
  * sigma = u^T W v with W = weight.reshape(cout, -1) (weight.transpose(0,1).reshape(cout, -1) when transposed).

@@ -27,7 +27,8 @@ class ConvDesc(Structure):
         ("bias", c_void_p), ("act", c_int32), ("dact", c_void_p), ("ld_dact", c_int32), ("dact_act", c_int32),
         ("C", c_void_p), ("c_f32", c_int32), ("c_accumulate", c_int32), ("ldc", c_int64),
         ("c_coff", c_int32), ("c_cstride", c_int32), ("splitk", c_int32),
-        ("c_scatter", c_int32), ("c_sn", c_int64), ("c_sh", c_int64), ("c_sw", c_int64), ("c_row0", c_int64)]
+        ("c_scatter", c_int32), ("c_sn", c_int64), ("c_sh", c_int64), ("c_sw", c_int64), ("c_row0", c_int64),
+        ("row_scale", c_void_p), ("rs_images", c_int32), ("rs_stride", c_int32)]
 
 
 class WgradDesc(Structure):
@@ -53,7 +54,14 @@ class NormBwdDesc(Structure):
                 ("dmod_gamma", c_void_p), ("dmod_beta", c_void_p), ("ld_dmod", c_int32),
                 ("N", c_int32), ("S", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
                 ("gamma", c_void_p), ("beta", c_void_p), ("mod_gamma", c_void_p), ("ld_mod", c_int32),
-                ("dgamma", c_void_p), ("dbeta", c_void_p), ("act", c_int32), ("workspace", c_void_p), ("stats", c_void_p)]
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("act", c_int32), ("workspace", c_void_p), ("stats", c_void_p),
+                ("mod_samples", c_int32)]
+
+
+class RowScaleBwdDesc(Structure):
+    _fields_ = [("dy", c_void_p), ("lddy", c_int32), ("y", c_void_p), ("ldy", c_int32), ("M", c_int64), ("C", c_int32), ("Cpad", c_int32),
+                ("act", c_int32), ("bias", c_void_p), ("scale", c_void_p), ("scale_stride", c_int32), ("rows_per_group", c_int64),
+                ("gs", c_void_p), ("ldgs", c_int32), ("dots", c_void_p), ("dbias", c_void_p), ("workspace", c_void_p)]
 
 
 class McfDesc(Structure):
@@ -99,6 +107,11 @@ SIGNATURES = {
     "ipoke_conv_forward": (c_int, [POINTER(ConvDesc), c_int, _P]),
     "ipoke_conv_forward_repeat": (c_int, [POINTER(ConvDesc), c_int, c_int, _P]),
     "ipoke_set_dispatch_override": (c_int, [c_char_p, c_int]),
+    "ipoke_last_conv_kernel": (c_int, []),
+    "ipoke_rowscale_bwd_workspace_floats": (c_int64, [c_int64, c_int, c_int64]),
+    "ipoke_rowscale_bwd": (c_int, [POINTER(RowScaleBwdDesc), c_int, _P]),
+    "ipoke_spectral_bwd_frames": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int64, _P, c_int64, _P, c_int, _P]),
+    "ipoke_sum_frames": (c_int, [_P, _P, c_int, c_int64, c_int, _P]),
     "ipoke_conv3x3_skinny_splitk": (c_int, [c_int, c_int, c_int]),
     "ipoke_conv_wgrad": (c_int, [POINTER(WgradDesc), c_int, _P]),
     "ipoke_wgrad_batch_entry_size": (c_int, []),
@@ -288,6 +301,9 @@ def require_gpu():
 
 
 import contextlib
+
+
+KERNEL_NONE, KERNEL_IGEMM, KERNEL_S8, KERNEL_HALO, KERNEL_HALO16, KERNEL_C64 = range(6)       # ipoke_last_conv_kernel
 
 
 @contextlib.contextmanager

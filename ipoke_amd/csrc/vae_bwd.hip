@@ -103,7 +103,7 @@ struct NormBwd {
   int N, S, C, G;
   const float* stats;                  // [N][G][2] mean, rstd (recomputed)
   const float* gamma; const float* beta;
-  const void* mod_gamma; int ld_mod;
+  const void* mod_gamma; int ld_mod; int mod_N;     // mod_N > 0: sample n reads the modulation rows of sample n % mod_N
   int act;
   float* part;                         // [N][nchunks][2][C]  (sum du, sum du*xhat)
   float* gsum;                         // [N][G][2]           (S1 = sum dxhat, S2 = sum dxhat*xhat)
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const NormBwd a) {
   typedef typename ET<T>::frag frag_t;
   __shared__ float sm[2][256 * E16];
   const int n = blockIdx.y, chunk = blockIdx.x;
+  const long mod_row0 = (long)(a.mod_N > 0 ? n % a.mod_N : n) * a.S;
   const int p0 = chunk * a.pos_per_block, p1 = min(a.S, p0 + a.pos_per_block);
   const int cpg = a.C / a.G;
   const int cvec = a.C / E16;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const NormBwd a) {
         const frag_t xv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
         frag_t yv, mg;
         if (a.act != IPOKE_ACT_NONE) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
-        if (a.mod_gamma) mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + m * a.ld_mod + cg * E16);
+        if (a.mod_gamma) mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + (mod_row0 + p) * a.ld_mod + cg * E16);
 #pragma unroll
         for (int e = 0; e < E16; ++e) {
           float du = ET<T>::to_f32(gy[e]);
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
   typedef typename ET<T>::frag frag_t;
   extern __shared__ float lds[];            // [6][C]: mean, rstd, gamma, beta, S1/cnt, S2/cnt
   const int n = blockIdx.y, cpg = a.C / a.G, C = a.C;
+  const long mod_row0 = (long)(a.mod_N > 0 ? n % a.mod_N : n) * a.S;
   const float inv_cnt = 1.f / ((float)a.S * cpg);
   for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cpg;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
       const frag_t xv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
       frag_t yv, mg;
       if (a.act != IPOKE_ACT_NONE) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
-      if (a.mod_gamma) mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + m * a.ld_mod + cg * E16);
+      if (a.mod_gamma) mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + (mod_row0 + p) * a.ld_mod + cg * E16);
       frag_t odx, odw, odmg;
 #pragma unroll
       for (int e = 0; e < E16; ++e) {
@@ -422,6 +424,7 @@ extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void
   a.dx = d->dx; a.lddx = d->lddx; a.dres = d->dres; a.lddres = d->lddres; a.dmg = d->dmod_gamma; a.dmb = d->dmod_beta;
   a.ld_dmod = d->ld_dmod; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
   a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = d->mod_gamma; a.ld_mod = d->ld_mod; a.act = d->act;
+  a.mod_N = d->mod_samples > 0 && d->mod_samples < d->N ? d->mod_samples : 0;
   a.nchunks = (d->S + kNormBwdPos - 1) / kNormBwdPos; a.pos_per_block = kNormBwdPos;
   a.part = d->workspace + ipoke_groupnorm_workspace_floats(d->N, d->S, d->G);
   a.gsum = a.part + (int64_t)d->N * a.nchunks * 2 * d->C;

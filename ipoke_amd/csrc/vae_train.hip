@@ -178,6 +178,146 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(SnView V, float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------- frames decoded as one batch
+// First-stage training decodes the T - 1 generated frames of a batch of clips as ONE batch ordered (frame, clip) with one operand of
+// W_orig and 1 / sigma_t (torch's spectral_norm iterates once per decoder call, util.py:52, 252) applied per image group in the GEMM
+// epilogue (ipoke_conv_desc.row_scale):  y = act(conv(x, W) / sigma_t + b).  Backward of that layer needs, in one pass over (dy, y):
+//   gs    = dy * act'(y) / sigma_t                    the gradient of conv(x, W): rows of the data- and weight-gradient GEMMs
+//   dot_t = sum_{rows of frame t} dy * act'(y) * (pre(y) - b)  = <dW_eff_t, W / sigma_t>     (sigma_t's own gradient, below)
+//   dbias = column sums of dy * act'(y)
+// pre(y): the pre-activation recovered from the saved output (where it cannot be recovered -- ReLU's zeros -- act'(y) is zero).
+// Grid (row blocks of a group, groups); per-block partials, reduced in a fixed order by rowscale_final_kernel (deterministic).
+struct RowScaleBwd {
+  const void* dy; int lddy; const void* y; int ldy; long M; int C, Cpad, act;
+  const float* bias; const float* scale; int scale_stride; long rows_per_group;
+  void* gs; int ldgs; float* dots; float* dbias; float* dot_part; float* col_part; int nbx, ngroups, rows_per_block;
+};
+__device__ __forceinline__ float pre_from_out(int act, float y) {
+  switch (act) {
+    case IPOKE_ACT_ELU: return y > 0.f ? y : log1pf(fmaxf(y, -0.99999994f));
+    case IPOKE_ACT_LRELU02: return y > 0.f ? y : 5.f * y;
+    default: return y;          // NONE; RELU (the gradient is zero where the output was clipped)
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void rowscale_bwd_kernel(const RowScaleBwd a) {
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  __shared__ float sm[256 * E16];
+  __shared__ float red[4];
+  const int grp = blockIdx.y;
+  const long r0 = (long)grp * a.rows_per_group + (long)blockIdx.x * a.rows_per_block;
+  const long r1 = min((long)(grp + 1) * a.rows_per_group, min(a.M, r0 + a.rows_per_block));
+  const float sc = a.scale[(long)grp * a.scale_stride];
+  const int cvec = a.Cpad / E16;
+  float dot = 0.f;
+  float* cpart = a.col_part ? a.col_part + ((long)grp * a.nbx + blockIdx.x) * a.C : nullptr;
+  for (int g0 = 0; g0 < cvec; g0 += 256) {
+    const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
+    const int rp = 256 / groups;
+    const int cg = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
+    float cs[E16], bb[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) { cs[e] = 0.f; const int c = cg * E16 + e; bb[e] = (a.bias && c < a.C) ? a.bias[c] : 0.f; }
+    if (rr < rp) {
+      for (long m = r0 + rr; m < r1; m += rp) {
+        const frag_t gy = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.dy) + m * a.lddy + cg * E16);
+        const frag_t yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
+        frag_t o;
+#pragma unroll
+        for (int e = 0; e < E16; ++e) {
+          const int c = cg * E16 + e;
+          float g = 0.f;
+          if (c < a.C) {
+            const float yy = ET<T>::to_f32(yv[e]);
+            g = ET<T>::to_f32(gy[e]) * act_grad_from_out(a.act, yy);
+            if (g != 0.f) dot = fmaf(g, pre_from_out(a.act, yy) - bb[e], dot);
+            cs[e] += g;
+          }
+          o[e] = ET<T>::from_f32(g * sc);
+        }
+        *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.gs) + m * a.ldgs + cg * E16) = o;
+      }
+    }
+    if (cpart) {
+#pragma unroll
+      for (int e = 0; e < E16; ++e) sm[threadIdx.x * E16 + e] = rr < rp ? cs[e] : 0.f;
+      __syncthreads();
+      for (int i = threadIdx.x; i < groups * E16; i += 256) {
+        const int cgi = i / E16, e = i - cgi * E16, c = (g0 + cgi) * E16 + e;
+        float t = 0.f;
+        for (int k = 0; k < rp; ++k) t += sm[(k * groups + cgi) * E16 + e];
+        if (c < a.C) cpart[c] = t;
+      }
+      __syncthreads();
+    }
+  }
+  dot = block_sum(dot, red);
+  if (threadIdx.x == 0) a.dot_part[(long)grp * a.nbx + blockIdx.x] = dot;
+}
+// blocks 0 .. ngroups-1: dots[group]; blocks ngroups ..: 16 channels of dbias each (16 row lanes, fixed order)
+__global__ __launch_bounds__(256) void rowscale_final_kernel(const RowScaleBwd a) {
+  __shared__ float red[256];
+  if ((int)blockIdx.x < a.ngroups) {
+    float t = 0.f;
+    for (int k = threadIdx.x; k < a.nbx; k += 256) t += a.dot_part[(long)blockIdx.x * a.nbx + k];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) a.dots[blockIdx.x] = red[0];
+    return;
+  }
+  const int cl = threadIdx.x % 16, rl = threadIdx.x / 16, c = ((int)blockIdx.x - a.ngroups) * 16 + cl;
+  const long nblk = (long)a.ngroups * a.nbx;
+  float t = 0.f;
+  if (c < a.C) for (long k = rl; k < nblk; k += 16) t += a.col_part[k * a.C + c];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  if (rl == 0 && c < a.C) {
+    float u = 0.f;
+    for (int k = 0; k < 16; ++k) u += red[k * 16 + cl];
+    a.dbias[c] = u;
+  }
+}
+// grad[r][c] -= sum_t dots[t] / sigma_t * u_t[r] v_t[c]: the gradient that reaches W_orig through sigma_t = u_t^T W v_t, summed over
+// the frames (grad already holds sum_t dW_eff_t / sigma_t -- the weight gradient of the rows scaled by 1 / sigma_t)
+__global__ __launch_bounds__(256) void sn_bwd_frames_kernel(SnView V, float* __restrict__ g, const float* __restrict__ snap, long snap_stride,
+                                                            const float* __restrict__ sig, long sig_stride, const float* __restrict__ dots, int frames) {
+  const long total = (long)V.R * V.C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / V.C), c = (int)(i - (long)r * V.C);
+    const int c1 = c / V.n2, c2 = c - c1 * V.n2;
+    const long off = (long)r * V.s_r + (long)c1 * V.s_1 + c2;
+    float t = 0.f;
+    for (int f = 0; f < frames; ++f) {
+      const float* sp = snap + (long)f * snap_stride;
+      t = fmaf(dots[f] * sig[(long)f * sig_stride + 1], sp[r] * sp[V.R + c], t);
+    }
+    g[off] -= t;
+  }
+}
+// dst[i] = sum_f src[f][i] (fp32 accumulation): per-position gradients of maps shared by the frames of a clip (the SPADE modulation)
+template <typename T>
+__global__ __launch_bounds__(256) void sum_frames_kernel(const T* __restrict__ src, T* __restrict__ dst, int frames, long n) {
+  constexpr int E16 = ET<T>::E16;
+  typedef typename ET<T>::frag frag_t;
+  const long nv = n / E16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    float acc[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) acc[e] = 0.f;
+    for (int f = 0; f < frames; ++f) {
+      const frag_t v = *reinterpret_cast<const frag_t*>(src + (long)f * n + i * E16);
+#pragma unroll
+      for (int e = 0; e < E16; ++e) acc[e] += ET<T>::to_f32(v[e]);
+    }
+    frag_t o;
+#pragma unroll
+    for (int e = 0; e < E16; ++e) o[e] = ET<T>::from_f32(acc[e]);
+    *reinterpret_cast<frag_t*>(dst + i * E16) = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- multi-tensor Adam
 constexpr int kAdamMax = 48;
 struct AdamPack { float* p[kAdamMax]; const float* g[kAdamMax]; float* m[kAdamMax]; float* v[kAdamMax]; long n[kAdamMax]; };
@@ -616,6 +756,64 @@ extern "C" int ipoke_spectral_bwd(const float* w, int cout, int cin, int taps, i
   IPK_LAUNCH_CHECK();
   hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(g), dim3(256), 0, STREAM(stream), V, grad, snapshot, sig, workspace,
                      reinterpret_cast<unsigned*>(workspace + 1));
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+static const int kRowScaleRows = 512;
+extern "C" int64_t ipoke_rowscale_bwd_workspace_floats(int64_t M, int C, int64_t rows_per_group) {
+  if (rows_per_group < 1 || M < 1) return 0;
+  const int64_t ngroups = (M + rows_per_group - 1) / rows_per_group, nbx = (rows_per_group + kRowScaleRows - 1) / kRowScaleRows;
+  return ngroups * nbx * (int64_t)(C + 1);
+}
+/* see ipoke_rowscale_bwd_desc (include/ipoke_hip.h) */
+extern "C" int ipoke_rowscale_bwd(const ipoke_rowscale_bwd_desc* d, int dtype, void* stream) {
+  IPK_REQUIRE(d && d->dy && d->y && d->gs && d->scale && d->dots && d->workspace, "null tensor");
+  IPK_REQUIRE(dtype == IPOKE_F32 || dtype == IPOKE_BF16, "bad dtype");
+  const int e16 = dtype == IPOKE_BF16 ? 8 : 4;
+  IPK_REQUIRE(d->M >= 1 && d->C >= 1 && d->Cpad >= d->C && d->Cpad % e16 == 0 && d->lddy % e16 == 0 && d->ldy % e16 == 0 && d->ldgs % e16 == 0 &&
+              d->lddy >= d->Cpad && d->ldy >= d->Cpad && d->ldgs >= d->Cpad && d->Cpad <= 4096, "pitches must cover the padded channel count in 16-byte steps");
+  IPK_REQUIRE(d->rows_per_group >= 1 && d->M % d->rows_per_group == 0 && d->M / d->rows_per_group <= 65535, "rows must divide into the image groups");
+  IPK_REQUIRE(d->act == IPOKE_ACT_NONE || d->act == IPOKE_ACT_RELU || d->act == IPOKE_ACT_ELU || d->act == IPOKE_ACT_LRELU02,
+              "the pre-activation must be recoverable from the saved output");
+  RowScaleBwd a;
+  a.dy = d->dy; a.lddy = d->lddy; a.y = d->y; a.ldy = d->ldy; a.M = d->M; a.C = d->C; a.Cpad = d->Cpad; a.act = d->act;
+  a.bias = d->bias; a.scale = d->scale; a.scale_stride = d->scale_stride < 1 ? 1 : d->scale_stride; a.rows_per_group = d->rows_per_group;
+  a.gs = d->gs; a.ldgs = d->ldgs; a.dots = d->dots; a.dbias = d->dbias;
+  a.ngroups = (int)(d->M / d->rows_per_group); a.rows_per_block = kRowScaleRows;
+  a.nbx = (int)((d->rows_per_group + kRowScaleRows - 1) / kRowScaleRows);
+  a.dot_part = d->workspace; a.col_part = d->dbias ? d->workspace + (int64_t)a.ngroups * a.nbx : nullptr;
+  hipStream_t s = STREAM(stream);
+  if (dtype == IPOKE_BF16) hipLaunchKernelGGL(rowscale_bwd_kernel<bf16_t>, dim3(a.nbx, a.ngroups), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(rowscale_bwd_kernel<float>, dim3(a.nbx, a.ngroups), dim3(256), 0, s, a);
+  IPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rowscale_final_kernel, dim3(a.ngroups + (d->dbias ? (d->C + 15) / 16 : 0)), dim3(256), 0, s, a);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* In place: grad (PyTorch weight layout; holds sum_t dW_eff_t / sigma_t) -= sum_t dots[t] / sigma_t * u_t v_t^T.  snapshots[t] = u_t | v_t and
+ * sig[t] = {sigma_t, 1 / sigma_t} as written by ipoke_spectral_sigma_multi (strides in floats); dots from ipoke_rowscale_bwd. */
+extern "C" int ipoke_spectral_bwd_frames(const float* w, int cout, int cin, int taps, int transposed, float* grad, const float* snapshots,
+                                         int64_t snap_stride, const float* sig, int64_t sig_stride, const float* dots, int frames, void* stream) {
+  IPK_REQUIRE(w && grad && snapshots && sig && dots && frames >= 1 && sig_stride >= 2, "bad arguments");
+  const SnView V = sn_view(w, cout, cin, taps, transposed);
+  const long total = (long)V.R * V.C;
+  hipLaunchKernelGGL(sn_bwd_frames_kernel, dim3(grid1(total, 2048)), dim3(256), 0, STREAM(stream), V, grad, snapshots, (long)snap_stride, sig,
+                     (long)sig_stride, dots, frames);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* dst[i] = sum_{f < frames} src[f * n + i], dtype in and out, fp32 accumulation; n a multiple of 16 bytes */
+extern "C" int ipoke_sum_frames(const void* src, void* dst, int frames, int64_t n, int dtype, void* stream) {
+  IPK_REQUIRE(src && dst && frames >= 1 && n >= 1, "bad arguments");
+  const int e16 = dtype == IPOKE_BF16 ? 8 : 4;
+  IPK_REQUIRE(n % e16 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "16-byte aligned rows");
+  hipStream_t s = STREAM(stream);
+  const int g = grid1(n / e16, 4096);
+  if (dtype == IPOKE_BF16) hipLaunchKernelGGL(sum_frames_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, frames, (long)n);
+  else hipLaunchKernelGGL(sum_frames_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, frames, (long)n);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -20,8 +20,12 @@ libipoke_hip on channels-last activations --
     Adam                 ipoke_adam_multi (multi-tensor, torch.optim.Adam semantics)
 
 PyTorch autograd only records the graph.  In train mode every spectral-normalised conv runs one power iteration per
-forward *call*, i.e. T-1 times per step for the decoder (util.py:52, 252) -- kept, which is why the decoder is
-evaluated frame by frame.
+forward *call*, i.e. T-1 times per step for the decoder (util.py:52, 252): frame t is decoded with W / sigma_t.  Kept -- but
+conv(x, W / sigma_t) = conv(x, W) / sigma_t and sigma_t is a per-frame SCALAR, so the T - 1 ConvGRU steps run first (sequential, 8 x 8)
+and the decoder runs ONCE over the (frame, clip)-ordered batch of all frames with one operand of W_orig and 1 / sigma_t as a per-image
+scale of the GEMM epilogue (ipoke_conv_desc.row_scale); the backward pass needs one weight gradient per convolution (rows pre-scaled
+by 1 / sigma_t) plus the scalars <dY_t, Y_t> for sigma_t's own gradient (ipoke_rowscale_bwd, ipoke_spectral_bwd_frames).
+IPOKE_C4_PER_FRAME=1 keeps the frame-by-frame evaluation of rounds 2-3 (same mathematics, 15 x the decoder launches).
 """
 from ctypes import byref
 
@@ -61,6 +65,7 @@ def _pad_cols(t, ld, dtype):
 _OPCACHE = {}
 _SN_AHEAD = os.environ.get("IPOKE_NO_SN_AHEAD", "0") != "1"            # developer A/B: one power iteration per decoder call, at the call
 _HOIST_SPADE = os.environ.get("IPOKE_NO_SPADE_HOIST", "0") != "1"      # developer A/B: per-frame SPADE maps as the reference computes them
+_FRAME_BATCH = os.environ.get("IPOKE_C4_PER_FRAME", "0") != "1"         # all generated frames decoded as ONE batch (module docstring); 0: frame by frame
 
 
 def clear_operand_cache():
@@ -115,6 +120,16 @@ class _SnWeight:
         self.w_orig, self.sig, self.snap, self.transposed, self.mod = w_orig, sig, snap, transposed, mod
 
 
+class _SnFrames:
+    """A spectral-normalised weight for a batch of ``frames`` image groups ordered (frame, clip): ``weight_orig`` plus the tables of the
+    frames' power iterations -- ``sig`` [frames, 2] = {sigma_t, 1 / sigma_t} and ``snaps`` [frames, rows + cols] = u_t | v_t
+    (ipoke_spectral_sigma_multi).  frames = 1: one sigma for the whole batch (evaluation mode)."""
+
+    def __init__(self, w_orig, sig, snaps, transposed, mod):
+        self.w_orig, self.sig, self.snaps, self.transposed, self.mod = w_orig, sig, snaps, transposed, mod
+        self.frames = int(sig.shape[0])
+
+
 _CT_PHASES = os.environ.get("IPOKE_NO_CT_PHASES", "0") != "1"        # developer A/B: stride-2 ConvTranspose2d forward as one 9-tap launch
 # taps (kh * 3 + kw) of the four sub-pixel phases (output parity (a, b): rows 2 i + a, columns 2 j + b), in the tap order of the
 # stride-1 convolution that computes the phase (first_stage._Conv._phase_operands); the phases' first blocks are 0, 1, 3, 5
@@ -123,7 +138,7 @@ _CT_PHASE = {(0, 0): (0, 1), (0, 1): (1, 2), (1, 0): (3, 2), (1, 1): (5, 4)}
 _ct_index = {}
 
 
-def _conv_transpose_phases(x, wop, kc, cout, dt, bias, act, out_f32):
+def _conv_transpose_phases(x, wop, kc, cout, dt, bias, act, out_f32, row_scale=None):
     """Forward of a 3 x 3 / stride 2 / padding 1 / output_padding 1 ConvTranspose2d (util.py:52-55) from its [cout][9 * kc] operand:
     one gather puts the tap blocks in phase order, four stride-1 convolutions (1, 2, 2, 4 taps) write the four pixel parities."""
     idx = _ct_index.get(x.t.device)
@@ -136,7 +151,7 @@ def _conv_transpose_phases(x, wop, kc, cout, dt, bias, act, out_f32):
     y = torch.empty(N * Ho * Wo, ldc, dtype=torch.float32 if out_f32 else _tdt(dt), device=x.t.device)
     for (a, b), (first, ntap) in _CT_PHASE.items():
         K.conv(x, wperm[:, first * kc:(first + ntap) * kc], kc, cout, (1, 1 + a, 1 + b), (1, 1, 1), (0, 0, 0), dt, bias=bias, act=act,
-               out_f32=out_f32, out=y, odhw=(1, Hi, Wi), scatter=(Ho * Wo, 2 * Wo, 2, a * Wo + b))
+               out_f32=out_f32, out=y, odhw=(1, Hi, Wi), scatter=(Ho * Wo, 2 * Wo, 2, a * Wo + b), row_scale=row_scale)
     return K.CL(y, N, (1, Ho, Wo), cout)
 
 
@@ -148,21 +163,29 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x_t, w, bias, meta):
         dt = meta["dtype"]
         sn = meta.get("sn")                       # (sig, snap): w is weight_orig, the operand carries 1/sigma
+        snf = meta.get("sn_frames")               # (sig [F, 2], snaps [F, n]): w is weight_orig, ONE operand, 1/sigma_t in the epilogue
         meta["w_param"] = (isinstance(w, torch.nn.Parameter) or meta.get("w_scope") is not None) and sn is None
         wop, kc = _weight_operand(w.detach(), dt, meta["transposed"], None if sn is None else sn[0][1:], cacheable=meta["w_param"],
                                   scope=meta.get("w_scope"), owner=w)
         b = None if bias is None else bias.detach().float().contiguous()
         src = meta.get("src")
         x = None if src is not None else K.CL(x_t, meta["N"], meta["dhw"], meta["cin"])
+        rs = None
+        if snf is not None:
+            frames = int(snf[0].shape[0])
+            if meta["N"] % frames or meta.get("out_f32", False):
+                raise RuntimeError("frame-batched spectral norm: the batch must hold whole frames and a dtype output")
+            rs = (snf[0].view(-1)[1:], meta["N"] // frames, 2)
         if (_CT_PHASES and meta["transposed"] and x is not None and tuple(meta["k"]) == (1, 3, 3) and tuple(meta["stride"]) == (1, 2, 2)
                 and tuple(meta["pad"]) == (0, 1, 1) and tuple(meta["out_pad"]) == (0, 1, 1)):
-            y = _conv_transpose_phases(x, wop, kc, meta["cout"], dt, b, meta["act"], meta.get("out_f32", False))
+            y = _conv_transpose_phases(x, wop, kc, meta["cout"], dt, b, meta["act"], meta.get("out_f32", False), row_scale=rs)
         else:
             y = K.conv(x, wop, kc, meta["cout"], meta["k"], meta["stride"], meta["pad"], dt, bias=b, act=meta["act"],
-                       transposed=meta["transposed"], out_pad=meta["out_pad"], out_f32=meta.get("out_f32", False), src_f32=src)
+                       transposed=meta["transposed"], out_pad=meta["out_pad"], out_f32=meta.get("out_f32", False), src_f32=src, row_scale=rs)
         meta["odhw"] = y.dhw
         ctx.meta = meta
-        ctx.save_for_backward(x_t, w, y.t if meta["act"] != _lib.ACT_NONE else None)
+        ctx.bias32 = b if snf is not None else None
+        ctx.save_for_backward(x_t, w, y.t if (meta["act"] != _lib.ACT_NONE or snf is not None) else None)
         ctx.has_bias = bias is not None
         return y.t
 
@@ -178,7 +201,32 @@ class _ConvFn(torch.autograd.Function):
         ldg = K.round_up(cout, e16)
         lib = _lib.lib()
         s = _lib.current_stream()
-        if m["act"] != _lib.ACT_NONE:
+        snf = m.get("sn_frames")
+        d_bias = None
+        if snf is not None:
+            # one pass over (dy, y): g = dy * act'(y) / sigma_t (the rows of both gradient GEMMs), the frames' <dY_t, Y_t - b> for sigma_t's
+            # own gradient, and the bias gradient
+            sig, snaps = snf
+            frames = int(sig.shape[0])
+            dyc = dy.contiguous()
+            if dyc.dtype != _tdt(dt) or dyc.shape[1] < ldg:
+                dyc = _pad_cols(dyc, ldg, dt)
+            g = torch.empty(M, ldg, dtype=_tdt(dt), device=dy.device)
+            dots = torch.empty(frames, dtype=torch.float32, device=dy.device)
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            if want_b:
+                d_bias = torch.empty(cout, dtype=torch.float32, device=dy.device)
+            rd = _lib.RowScaleBwdDesc()
+            rd.dy = dyc.data_ptr(); rd.lddy = dyc.shape[1]; rd.y = y_t.data_ptr(); rd.ldy = y_t.shape[1]
+            rd.M, rd.C, rd.Cpad, rd.act = M, cout, ldg, m["act"]
+            rd.bias = 0 if ctx.bias32 is None else ctx.bias32.data_ptr()
+            sc = sig.view(-1)[1:]
+            rd.scale = sc.data_ptr(); rd.scale_stride = 2; rd.rows_per_group = M // frames
+            rd.gs = g.data_ptr(); rd.ldgs = ldg; rd.dots = dots.data_ptr(); rd.dbias = 0 if d_bias is None else d_bias.data_ptr()
+            ws = _workspace(lib.ipoke_rowscale_bwd_workspace_floats(M, cout, M // frames), dy.device, "rowscale")
+            rd.workspace = ws.data_ptr()
+            check(lib.ipoke_rowscale_bwd(byref(rd), ops._dt(dt), s))
+        elif m["act"] != _lib.ACT_NONE:
             if m.get("out_f32", False):
                 raise RuntimeError("fused activation on an fp32 output has no backward here (the loss kernel owns tanh)")
             g = torch.empty(M, ldg, dtype=_tdt(dt), device=dy.device)
@@ -187,8 +235,7 @@ class _ConvFn(torch.autograd.Function):
                                     ops._dt(dt), s))
         else:
             g = _pad_cols(dy, ldg, dt) if (dy.dtype != _tdt(dt) or dy.shape[1] != ldg) else dy.contiguous()
-        d_bias = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if snf is None and ctx.has_bias and ctx.needs_input_grad[2]:
             d_bias = torch.empty(cout, dtype=torch.float32, device=dy.device)
             ws = _workspace(lib.ipoke_colsum_workspace_floats(M, cout), dy.device, "colsum")
             check(lib.ipoke_colsum(ptr(g), ldg, M, cout, 0, ptr(d_bias), 0, ptr(ws), ops._dt(dt), s))
@@ -253,6 +300,13 @@ class _ConvFn(torch.autograd.Function):
                     t_w *= int(kk)
                 r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
                 check(lib.ipoke_spectral_bwd(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snap), ptr(sig), ptr(bws), s))
+            if snf is not None:                       # d_w holds sum_t dW_eff_t / sigma_t; sigma_t's own gradients are rank-1 terms
+                t_w = 1
+                for kk in w.shape[2:]:
+                    t_w *= int(kk)
+                r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
+                check(lib.ipoke_spectral_bwd_frames(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snaps), snaps.stride(0),
+                                                    ptr(sig), sig.stride(0), ptr(dots), frames, s))
         # ---- data gradient: the adjoint convolution with the same weights
         d_x = None
         if x_t is not None and ctx.needs_input_grad[0]:
@@ -286,19 +340,33 @@ def conv(mod, x, dtype, act=_lib.ACT_NONE, out_f32=False, src=None, w=None):
             bws = w.mod._sn_bwd_ws = torch.zeros(2, dtype=torch.float32, device=w.w_orig.device)
         meta["sn"] = (w.sig, w.snap, bws)
         w = w.w_orig
+    elif isinstance(w, _SnFrames):
+        meta["sn_frames"] = (w.sig, w.snaps)
+        w = w.w_orig
     y = _ConvFn.apply(None if src is not None else x.t, w, mod.bias, meta)
     return K.CL(y, N, meta["odhw"], mod.cout)
 
 
-def effective_weight(mod, power_iteration=False):
+def effective_weight(mod, power_iteration=False, frames=None):
     """The conv weight as ``conv`` takes it: the plain ``weight`` parameter, or for spectral norm a ``_SnWeight`` --
     torch spectral_norm semantics: u, v are buffers updated without grad by one power iteration per call in train mode;
     sigma = u^T W v carries grad (ipoke_spectral_sigma / ipoke_spectral_bwd), the division by sigma happens while the
-    matrix-core operand is written."""
+    matrix-core operand is written.  ``frames``: the input is the batch of all ``frames`` decoder calls of this pass ordered
+    (frame, clip) -> a ``_SnFrames`` with the whole table of the calls' sigmas (run ahead by ``precompute_power_iterations``); without
+    power iteration one sigma serves the whole batch."""
     if not mod.snorm:
         return mod.weight
     w = mod.weight_orig
     pre = mod.__dict__.get("_sn_pre")
+    if frames is not None:
+        if power_iteration:
+            tab = mod.__dict__.pop("_sn_tab", None)
+            if tab is None or tab[0].shape[0] != frames or not pre or len(pre) != frames:
+                raise RuntimeError("frame-batched spectral norm needs precompute_power_iterations(root, frames) before the decoder pass")
+            pre.clear()                           # this ONE batched call consumes the module's T - 1 iterations
+            return _SnFrames(w, tab[0], tab[1], mod.transposed, mod)
+        one = effective_weight(mod, False)
+        return _SnFrames(w, one.sig.view(1, 2), one.snap.view(1, -1), mod.transposed, mod)
     if power_iteration and pre:                   # this call's iteration was run ahead of the time loop (precompute_power_iterations)
         sig, snap = pre.pop(0)
         return _SnWeight(w, sig, snap, mod.transposed, mod)
@@ -368,6 +436,7 @@ def precompute_power_iterations(root, calls):
     check(lib.ipoke_spectral_sigma_multi(ptr(cache["jobs_dev"]), len(mods), cache["max_r"], cache["max_c"], calls, 1e-12, _lib.current_stream()))
     for i, m in enumerate(mods):
         m.__dict__["_sn_pre"] = [(cache["sig"][i, k], cache["snaps"][i][k]) for k in range(calls)]
+        m.__dict__["_sn_tab"] = (cache["sig"][i], cache["snaps"][i])             # the same iterations as whole tables (frame-batched decoding)
     return mods
 
 
@@ -387,6 +456,7 @@ class _NormFn(torch.autograd.Function):
             d.gamma = g32.data_ptr(); d.beta = b32.data_ptr()
         if mg_t is not None:
             d.mod_gamma = mg_t.data_ptr(); d.mod_beta = mb_t.data_ptr(); d.ld_mod = mg_t.shape[1]
+            d.mod_samples = int(meta.get("mod_samples", 0))        # > 0: the frames of a clip share its SPADE maps (batch ordered (frame, clip))
         if res_t is not None:
             d.res = res_t.data_ptr(); d.ld_res = res_t.shape[1]
         d.act = meta["act"]
@@ -420,10 +490,14 @@ class _NormFn(torch.autograd.Function):
         if has_res:
             dres = torch.zeros_like(x_t) if x_t.shape[1] > C else torch.empty_like(x_t)
             d.dres = dres.data_ptr(); d.lddres = dres.shape[1]
+        mod_n = int(m.get("mod_samples", 0)) if has_mod else 0
         if has_mod:
-            dmg = torch.zeros_like(mg_t); dmb = torch.zeros_like(mg_t)
+            if mod_n:                  # per-frame modulation gradients [frames][clips * S][ld], summed over the frames below
+                dmg = torch.zeros(x_t.shape[0], mg_t.shape[1], dtype=mg_t.dtype, device=mg_t.device); dmb = torch.zeros_like(dmg)
+            else:
+                dmg = torch.zeros_like(mg_t); dmb = torch.zeros_like(mg_t)
             d.dmod_gamma = dmg.data_ptr(); d.dmod_beta = dmb.data_ptr(); d.ld_dmod = dmg.shape[1]
-            d.mod_gamma = mg_t.data_ptr(); d.ld_mod = mg_t.shape[1]
+            d.mod_gamma = mg_t.data_ptr(); d.ld_mod = mg_t.shape[1]; d.mod_samples = mod_n
         if has_affine:
             dgamma = torch.empty(C, dtype=torch.float32, device=dy.device); dbeta = torch.empty_like(dgamma)
             d.gamma = g32.data_ptr(); d.beta = b32.data_ptr(); d.dgamma = dgamma.data_ptr(); d.dbeta = dbeta.data_ptr()
@@ -431,11 +505,22 @@ class _NormFn(torch.autograd.Function):
         d.workspace = ws.data_ptr()
         d.stats = stats.data_ptr()
         check(_lib.lib().ipoke_groupnorm_bwd(byref(d), ops._dt(dt), _lib.current_stream()))
+        if mod_n:
+            frames = N // mod_n
+            outs = []
+            for t_ in (dmg, dmb):
+                red = torch.empty_like(mg_t)
+                check(_lib.lib().ipoke_sum_frames(ptr(t_), ptr(red), frames, mg_t.numel(), ops._dt(dt), _lib.current_stream()))
+                outs.append(red)
+            dmg, dmb = outs
         return dx, dgamma, dbeta, dmg, dmb, dres, None
 
 
 def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None):
     meta = dict(N=x.N, S=x.S, C=x.C, G=groups, dtype=dtype, act=act)
+    if mod is not None and mod[0].N != x.N:       # frames of a clip decoded as one batch ordered (frame, clip): shared SPADE maps
+        assert x.N % mod[0].N == 0 and mod[0].S == x.S and mod[0].t.shape[0] == mod[0].N * x.S
+        meta["mod_samples"] = mod[0].N
     y = _NormFn.apply(x.t, gamma, beta, None if mod is None else mod[0].t, None if mod is None else mod[1].t,
                       None if res is None else res.t, meta)
     return K.CL(y, x.N, x.dhw, x.C)
@@ -655,8 +740,8 @@ def encode(enc, x, eps):
     return z, mu, lv, h.dhw
 
 
-def conv_block(blk, x, dtype, res=None, out_f32=False, pit=False):
-    w = effective_weight(blk.conv, pit)
+def conv_block(blk, x, dtype, res=None, out_f32=False, pit=False, frames=None):
+    w = effective_weight(blk.conv, pit, frames)
     if blk.norm is None:
         act = FS.ACT[blk.activation] if res is None else _lib.ACT_NONE
         if out_f32:
@@ -666,21 +751,21 @@ def conv_block(blk, x, dtype, res=None, out_f32=False, pit=False):
     return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=FS.ACT[blk.activation], res=res)
 
 
-def convT_block(blk, x, dtype, pit=False):
-    w = effective_weight(blk.conv, pit)
+def convT_block(blk, x, dtype, pit=False, frames=None):
+    w = effective_weight(blk.conv, pit, frames)
     if blk.norm is None:
         return conv(blk.conv, x, dtype, act=blk.act, w=w)
     return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=blk.act)
 
 
-def res_block(blk, x, dtype, pit=False):
+def res_block(blk, x, dtype, pit=False, frames=None):
     first = convT_block if isinstance(blk.conv1, FS.Conv2dTransposeBlock) else conv_block
     if blk.convolve_res:
         rfirst = convT_block if isinstance(blk.res_conv, FS.Conv2dTransposeBlock) else conv_block
-        res = rfirst(blk.res_conv, x, dtype, pit=pit)
+        res = rfirst(blk.res_conv, x, dtype, pit=pit, frames=frames)
     else:
         res = x
-    return conv_block(blk.conv2, first(blk.conv1, x, dtype, pit=pit), dtype, res=res, pit=pit)
+    return conv_block(blk.conv2, first(blk.conv1, x, dtype, pit=pit, frames=frames), dtype, res=res, pit=pit, frames=frames)
 
 
 def spade_modulation(sp, y_nchw, size, dtype):
@@ -703,12 +788,13 @@ def spade_modulations(gen, start_frame, dtype):
     return mods
 
 
-def decode_frame(gen, h, start_frame, dtype, pit, mods=None):
-    """SpadeCondConvDecoder.forward for one frame; returns the pre-tanh output [M, 3] fp32 (CL)."""
-    x = res_block(gen.in_block, h, dtype, pit=pit)
+def decode_frame(gen, h, start_frame, dtype, pit, mods=None, frames=None):
+    """SpadeCondConvDecoder.forward for one frame; returns the pre-tanh output [M, 3] fp32 (CL).  ``frames``: ``h`` holds the hidden states
+    of ALL ``frames`` decoder calls of the pass ordered (frame, clip) and ``mods`` the clips' SPADE maps (shared by a clip's frames)."""
+    x = res_block(gen.in_block, h, dtype, pit=pit, frames=frames)
     size = 8
     for i, (blk, sp) in enumerate(zip(gen.blocks, gen.spade_blocks)):
-        x = res_block(blk, x, dtype, pit=pit)
+        x = res_block(blk, x, dtype, pit=pit, frames=frames)
         size *= 2
         mod = mods[i] if mods is not None else spade_modulation(sp, start_frame, (size, size), dtype)
         x = group_norm(x, sp.groups, dtype, mod=mod)
@@ -741,7 +827,10 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
         clear_operand_cache()                      # scoped entries of passes whose backward never ran
     gate_w = [gru_gate_weights(cell) for cell in model.rnn.cells]
     mods = spade_modulations(model.gen, x0, dt) if _HOIST_SPADE else None
-    sn_pre = precompute_power_iterations(model.gen, T - 1) if (pit and _SN_AHEAD) else []
+    # all frames as one batch: needs the hoisted SPADE maps and 32-bit row offsets at the widest 128 x 128 layer
+    batched = _FRAME_BATCH and mods is not None and T > 2 and B * (T - 1) * X.shape[-1] * X.shape[-2] * 64 < (1 << 31)
+    sn_pre = precompute_power_iterations(model.gen, T - 1) if (pit and (_SN_AHEAD or batched)) else []
+    hs = []
     for t in range(T - 1):
         xin = in_rnn
         new_hidden = []
@@ -749,10 +838,20 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
             xin = gru_cell(cell, xin, h, dt, gw)
             new_hidden.append(xin)
         hidden = new_hidden
+        if batched:
+            hs.append(hidden[-1])
+            continue
         pre = decode_frame(model.gen, hidden[-1], x0, dt, pit, mods)
         lt, frame = _L1TanhFn.apply(pre.t, X[:, t + 1], 1.0 / n_out)
         l1 = l1 + lt
         frames.append(frame.view(B, pre.dhw[1], pre.dhw[2], 3).permute(0, 3, 1, 2))
+    if batched:
+        # the ConvGRU is sequential in time, the decoder is not: ONE pass over the (frame, clip)-ordered batch of all T - 1 frames
+        h_all = K.CL(torch.cat([h.t for h in hs], 0), B * (T - 1), hs[0].dhw, hs[0].C)
+        pre = decode_frame(model.gen, h_all, x0, dt, pit, mods, frames=T - 1)
+        tgt = X[:, 1:].transpose(0, 1).reshape(B * (T - 1), *X.shape[2:])           # targets in the same (frame, clip) order (one copy)
+        l1, frame = _L1TanhFn.apply(pre.t, tgt, 1.0 / n_out)
+        x_hat = frame.view(T - 1, B, pre.dhw[1], pre.dhw[2], 3).permute(1, 0, 4, 2, 3)
     for m_sn in sn_pre:                               # every decoder convolution consumed exactly its T - 1 iterations
         left = m_sn.__dict__.pop("_sn_pre", [])
         if left:
@@ -761,7 +860,7 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
     lv4 = lv.view(B, dhw[1], dhw[2], Z).permute(0, 3, 1, 2)
     kl = _KLFn.apply(mu, lv)                                                             # utils/losses.py:47-48
     loss = w_l1 * l1 + w_kl * kl
-    return loss, torch.stack(frames, dim=1), mu4, lv4
+    return loss, (x_hat if batched else torch.stack(frames, dim=1)), mu4, lv4
 
 
 class MultiTensorAdam:

@@ -67,11 +67,13 @@ def out_extent(i, k, s, p, transposed, out_pad=0):
 
 
 def conv(x, w_op, kc, cout, k, stride, pad, dtype, bias=None, act=_lib.ACT_NONE, transposed=False, out_pad=(0, 0, 0),
-         out_f32=False, src_f32=None, out=None, odhw=None, scatter=None):
+         out_f32=False, src_f32=None, out=None, odhw=None, scatter=None, row_scale=None):
     """Implicit-GEMM convolution.  ``x`` is a CL, or ``src_f32`` = (tensor, N, C, dhw, strides(n,c,d,h,w)) for an
     fp32 source read in place (input images).  ``odhw``: output extent when it is not the symmetric-padding formula's (windows
     that overhang the input read zeros).  ``scatter`` = (c_sn, c_sh, c_sw, c_row0): rows of ``out`` the positions are written to
-    (ipoke_conv_desc.c_scatter); the returned CL then describes this launch's positions only."""
+    (ipoke_conv_desc.c_scatter); the returned CL then describes this launch's positions only.  ``row_scale`` = (fp32 tensor, rs_images,
+    rs_stride): the accumulators of image n are multiplied by tensor[(n // rs_images) * rs_stride] before the bias
+    (ipoke_conv_desc.row_scale: 1 / sigma_t of the frame an image belongs to)."""
     if src_f32 is not None:
         src, N, cin, dhw, st = src_f32
     else:
@@ -102,6 +104,8 @@ def conv(x, w_op, kc, cout, k, stride, pad, dtype, bias=None, act=_lib.ACT_NONE,
     if scatter is not None:
         assert out is not None
         d.c_scatter = 1; d.c_sn, d.c_sh, d.c_sw, d.c_row0 = scatter
+    if row_scale is not None:
+        d.row_scale = row_scale[0].data_ptr(); d.rs_images = int(row_scale[1]); d.rs_stride = int(row_scale[2])
     ops.conv_forward(d, dtype)
     return CL(y, N, odhw, cout)
 

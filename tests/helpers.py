@@ -80,3 +80,22 @@ def synthetic_batch(B, T, size, seed=1, device="cpu"):
     poke = [torch.randn(B, 2, size, size, generator=g) * mask, torch.zeros(B, 5, 2, dtype=torch.int64)]
     batch = {"images": images, "flow": flow, "poke": poke, "sample_ids": torch.zeros(B, T, dtype=torch.int64)}
     return {k: ([p.to(device) for p in v] if isinstance(v, list) else v.to(device)) for k, v in batch.items()}
+
+
+_FILL_CACHE = {}
+
+
+@torch.no_grad()
+def cached_fill_(module, prefix):
+    """``deterministic_fill_`` of a LARGE module (the 1.05 / 1.24 B-parameter flows: ~20 s of CPU random numbers per fill) with the filled
+    state dict kept on the device for the rest of the session: the same (class, prefix, shapes) is filled once, later models copy it."""
+    from ipoke_amd.utils.detfill import deterministic_fill_
+    sd = module.state_dict()
+    key = (type(module).__name__, prefix, tuple((k, tuple(v.shape)) for k, v in sd.items()))
+    hit = _FILL_CACHE.get(key)
+    if hit is None:
+        deterministic_fill_(module, prefix=prefix)
+        _FILL_CACHE[key] = {k: v.detach().clone() for k, v in module.state_dict().items()}
+        return
+    for k, v in sd.items():
+        v.copy_(hit[k])

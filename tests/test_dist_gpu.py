@@ -56,7 +56,18 @@ def _worker(rank, world, port, overlap, out, env=None):
     dist.destroy_process_group()
 
 
+_RUNS = {}
+
+
 def _run(overlap, env=None):
+    """Memoised per (overlap, env): the plain / default-overlapped runs are the baselines of several tests below."""
+    key = (overlap, tuple(sorted((env or {}).items())))
+    if key not in _RUNS:
+        _RUNS[key] = _run_once(overlap, env)
+    return _RUNS[key]
+
+
+def _run_once(overlap, env=None):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), overlap, out, env), nprocs=2, join=True)

@@ -117,14 +117,17 @@ def check_step(m, g, dtype, tag, loss, X_hat, mu, slots=1):
     assert e_u <= tol["u"]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", ["default", "no_sn_ahead", "no_spade_hoist"])
+@pytest.mark.parametrize("variant,dtype", [("default", "f32"), ("default", "bf16"), ("per_frame", "f32"), ("per_frame", "bf16"),
+                                           ("no_sn_ahead", "f32"), ("no_spade_hoist", "f32")])
 def test_first_stage_train_mode_step(golden, monkeypatch, variant, dtype):
-    """One clip through the c4 code path (train mode) with the default switches, with the power iterations at the call sites
-    (IPOKE_NO_SN_AHEAD=1: the reference's literal order of work) and with per-frame SPADE maps (IPOKE_NO_SPADE_HOIST=1):
-    all three must reproduce the reference's X_hat, loss, gradients and u / v buffers."""
+    """One clip through the c4 code path (train mode): with the default switches (round 4: ALL frames decoded as one (frame, clip)-ordered
+    batch, one operand of W_orig, 1 / sigma_t in the GEMM epilogues, one weight gradient per convolution + the rank-1 sigma terms);
+    frame by frame (IPOKE_C4_PER_FRAME=1: the default of rounds 2-3); frame by frame with the power iterations at the call sites
+    (IPOKE_NO_SN_AHEAD=1: the reference's literal order of work); and with per-frame SPADE maps (IPOKE_NO_SPADE_HOIST=1).  All must
+    reproduce the reference's X_hat, loss, gradients and u / v buffers."""
     from ipoke_amd import first_stage_train as FT
     g = golden("g13_first_stage_train_mode_128")
+    monkeypatch.setattr(FT, "_FRAME_BATCH", variant == "default")
     monkeypatch.setattr(FT, "_SN_AHEAD", variant != "no_sn_ahead")
     monkeypatch.setattr(FT, "_HOIST_SPADE", variant != "no_spade_hoist")
     m = train_model(dtype)
@@ -135,18 +138,20 @@ def test_first_stage_train_mode_step(golden, monkeypatch, variant, dtype):
     grad_report(m, g, dtype, f"c4-train-mode/{variant}")
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_first_stage_train_mode_batch_of_copies(golden, dtype):
-    """B = 4, T = 16 (split-M weight gradients over 4x the rows, batched GRU / decoder launches): clips are independent, so four
-    copies of the golden clip reproduce the golden reconstruction in every slot, and the mean-loss gradients equal the single
-    clip's (checked against the reference's checksums of every tensor)."""
+@pytest.mark.parametrize("dtype,copies", [("f32", 4), ("bf16", 4), ("bf16", 10)])
+def test_first_stage_train_mode_batch_of_copies(golden, dtype, copies):
+    """B = 4 / 10, T = 16: clips are independent, so copies of the golden clip reproduce the golden reconstruction in every slot, and the
+    mean-loss gradients equal the single clip's (checked against the reference's checksums of every tensor).  B = 10 is the size class
+    of ``bench.py --config c4``: the decoder sees 150 images per launch -- 9 600 patches of 16 x 16 pixels at the
+    128 x 128 layers, conv3x3_c64 by the default rule with ~38 patches per persistent workgroup (forward, data gradient, the four
+    scattered sub-pixel phases), conv3x3_halo16 on the 64 x 64 / 128-channel layers, ~512-workgroup split-M weight gradients."""
     g = golden("g13_first_stage_train_mode_128")
     m = train_model(dtype)
-    X, eps = clip(g, copies=4)
+    X, eps = clip(g, copies=copies)
     loss, X_hat, mu, lv = m.training_loss(X, eps)
     loss.backward()
-    check_step(m, g, dtype, "c4-train-mode/B=4", loss, X_hat, mu, slots=4)
-    grad_report(m, g, dtype, "c4-train-mode/B=4")
+    check_step(m, g, dtype, f"c4-train-mode/B={copies}", loss, X_hat, mu, slots=copies)
+    grad_report(m, g, dtype, f"c4-train-mode/B={copies}")
 
 
 def test_spectral_sigma_multi_matches_sequential_calls():
