@@ -113,8 +113,9 @@ def kernel_roofline(B, dtype, iters=50):
     traffic = None
     if M == 1280 and dtype == "bf16":
         traffic = pmc_traffic("igemm_nt_glds_kernel<bool _Accum, int, E, 4, 5, 2, 3, 1, true, 2>", str(256 * 512))
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch: 2 x FETCH_SIZE + WRITE_SIZE of this kernel's dispatches INSIDE the train step",
+    peak = MFMA_BF16_PEAK_TFLOPS if dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch: 2 x FETCH_SIZE + WRITE_SIZE of this kernel's dispatches INSIDE the train step",
             "traffic_source": f"profiles/{PMC_ROUND}_bench_pmc_*.json: separate rocprofv3 --pmc passes of this command (not this run; PMC collection and timing cannot share a run)",
             "algorithmic_bytes_per_launch": int(2 * (M * hid + hid * hid + M * hid)),
             "kernel": "igemm_nt (NICE conv2 1x1, M=%d N=K=2048, %s)" % (M, dtype), "avg_launch_us": round(avg_s * 1e6, 2),
@@ -150,6 +151,54 @@ def insitu_rooflines(run_step, B, z, dtype):
             entry(1, f"igemm_tn_glds (NICE conv2 weight gradient, 2048x2048 over M={M}, {dtype}; side stream)", gemm_gf, how),
             entry(2, "macow_unit_fwd (4 masked-conv flows + 2 ActNorms per launch; mean over channel widths 8..64)", unit_gf, how),
             entry(3, "macow_unit_bwd (data path of the same unit; FLOPs counted as the forward's)", unit_gf, how)]
+
+
+KERNEL_FAMILIES = {      # in-situ timing tags (include/ipoke_hip.h) -> what the family is
+    1: "igemm_nt_glds, 1x1 square GEMM (NICE conv2 forward / data gradient)",
+    2: "igemm_tn_glds, square weight gradient (NICE conv2)",
+    5: "macow_unit_inv (4 masked-conv flows + 2 ActNorms inverted per launch, two samples per workgroup)",
+    17: "igemm_nt / igemm_nt_glds implicit-GEMM convolutions (all shapes that no stationary-input kernel takes)",
+    18: "conv3x3_s8 (3x3 on the 8x8 latent, stationary input)",
+    19: "conv3x3_halo (3x3, halo-staged 8x16 patches)",
+    20: "conv3x3_halo16 (3x3 / 3x3x3 wide layers, halo-staged 16x16 patches x 128 channels)",
+    21: "conv3x3_c64 (<= 64 output channels, filter resident in LDS, persistent workgroups)",
+    32: "igemm_tn / igemm_tn_glds weight gradients (split-M slabs)",
+}
+
+
+def config_rooflines(run_step, dtype):
+    """Per-configuration rooflines: ONE extra, untimed step with HIP events around every convolution, weight
+    gradient and flow-unit launch on the stream it runs on (ipoke_timing_start_all); per kernel family the launches, the summed
+    durations and the summed ALGORITHMIC work (FLOPs; input + weights + output bytes, each once).  Each family is priced against the
+    roof that bounds it (the larger of flops / MFMA peak and bytes / 8 TB/s); the list is ordered by time -- its head is the
+    configuration's dominant kernel."""
+    from ctypes import c_double, c_int
+    L = _lib.lib()
+    ids = sorted(KERNEL_FAMILIES)
+    n = len(ids)
+    tags = (c_int * n)(*ids)
+    counts, us, fl, by = (c_int * n)(), (c_double * n)(), (c_double * n)(), (c_double * n)()
+    torch.cuda.synchronize()
+    _lib.check(L.ipoke_timing_start_all())
+    run_step()
+    _lib.check(L.ipoke_timing_stop_ex(tags, n, counts, us, fl, by))
+    peak_tf = MFMA_BF16_PEAK_TFLOPS if dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    out = []
+    for k, tag in enumerate(ids):
+        if not counts[k] or us[k] <= 0.0:
+            continue
+        t = us[k] * 1e-6
+        tf, gbs = fl[k] / t / 1e12, by[k] / t / 1e9
+        mfma_bound = fl[k] / (peak_tf * 1e12) >= by[k] / 8e12
+        e = {"bound": "mfma" if mfma_bound else "hbm", "achieved": round(tf if mfma_bound else gbs, 2), "peak": peak_tf if mfma_bound else 8000.0,
+             "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round((tf / peak_tf) if mfma_bound else (gbs / 8000.0), 4), "traffic": None,
+             "kernel": KERNEL_FAMILIES[tag], "launches_in_step": int(counts[k]), "total_us_in_step": round(us[k], 1),
+             "avg_launch_us": round(us[k] / counts[k], 2), "algorithmic_gflop_in_step": round(fl[k] / 1e9, 1),
+             "algorithmic_mbytes_in_step": round(by[k] / 1e6, 1), "achieved_tflops": round(tf, 2), "achieved_gbs": round(gbs, 1),
+             "measured": "HIP events around each launch on its own stream inside one full step of THIS configuration (in situ)"}
+        out.append(e)
+    out.sort(key=lambda e: -e["total_us_in_step"])
+    return out
 
 
 def usable_cores():
@@ -244,11 +293,13 @@ def cpu_baseline_subprocess(config, clips, timeout_s):
                 "sample": f"cpu leg exceeded {timeout_s}s for {clips} clip(s); lower bound {clips * 16 / timeout_s:.4f} frames/s not reached"}
 
 
-def secondary_subprocess(config, steps, warmup, timeout_s=600):
-    """Time a secondary workload (c4: first-stage train step, c5: sampling) with this same script in a child process -- same timing
-    contract, fresh HIP context -- and return the fields of its JSON line that matter beside the headline."""
+def secondary_subprocess(config, steps, warmup, timeout_s=600, extra=()):
+    """Time a secondary workload (c4: first-stage train step, c5: sampling, c2 in the reference's own fp32 arithmetic) with this same
+    script in a child process -- same timing contract, fresh HIP context -- and return the fields of its JSON line that matter beside
+    the headline (incl. the configuration's OWN roofline objects)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
+           "--no-secondary"] + list(extra)
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -258,7 +309,7 @@ def secondary_subprocess(config, steps, warmup, timeout_s=600):
             if ln.startswith("{"):
                 d = json.loads(ln)
                 keep = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "algorithmic_tflop_per_step_per_gpu",
-                                          "step_mfma_frac", "hipgraph", "loss") if k in d}
+                                          "step_mfma_frac", "step_hbm_frac_12P", "hipgraph", "loss", "roofline", "roofline_other_kernels") if k in d}
                 keep["workload"] = d["config"]["workload"]
                 return keep
         return {"error": (out.stderr.strip().splitlines() or ["no output"])[-1][:300]}
@@ -373,6 +424,8 @@ def secondary(args, cfg, rank, world, device):
                  "what": "same K steps; flow_graph: reverse flow replayed as a captured hipGraph, decoder eager; full_graph: conditioning "
                          "encoders + reverse flow + ConvGRU + frame-batched decode replayed as ONE captured hipGraph (PokeMotionModel.set_sample_graph); "
                          "the headline value of this line is the eager path"}
+    # one extra step on EVERY rank (the data-parallel hook of c4 holds a collective) with the per-family event timing on
+    fams = config_rooflines(lambda: step(args.warmup + args.steps), args.dtype) if args.config != "fvd" else []
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {"metric": metric, "value": round(frames / (elapsed / args.steps), 2), "unit": "video-frames/sec", "n_gpus": world,
@@ -380,7 +433,15 @@ def secondary(args, cfg, rank, world, device):
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": workload, "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
                            "weights": "random init of the named architecture (no checkpoints offline)"},
-                "roofline": kernel_roofline(B, args.dtype) if args.config != "fvd" else None}
+                "roofline": None}
+        if fams:                           # the dominant kernel family OF THIS configuration; the rest beside it
+            line["roofline"] = fams[0]
+            line["roofline_other_kernels"] = fams[1:5]
+            done = sum(f["algorithmic_gflop_in_step"] for f in fams) / 1e3
+            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            line["executed_tflop_per_step_per_gpu"] = round(done, 2)          # convolutions + weight gradients + flow units actually launched
+            line["step_mfma_frac_executed"] = round(done / (ms * 1e-3) / peak, 4)
+            line["kernel_time_share"] = {"timed_families_ms": round(sum(f["total_us_in_step"] for f in fams) / 1e3, 2), "step_ms": round(ms, 2)}
         if args.config in ("c4", "c4gan"):
             line["loss"] = round(float(out.item()), 4)
         if args.config == "fvd":
@@ -509,7 +570,7 @@ def main():
             "loss": round(loss_val, 3),
             "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(per_step[0], 3), "ms_per_step_max": round(per_step[-1], 3),
             "algorithmic_tflop_per_step_per_gpu": round(step_tflop, 2),
-            "step_mfma_frac": round(step_tflop / (ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4),
+            "step_mfma_frac": round(step_tflop / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS), 4),
             "step_hbm_frac_12P": round(12 * P_bytes / (ms * 1e-3) / 8e12, 4),
             "roofline": roof,
         }
@@ -520,6 +581,8 @@ def main():
             del model, trainer, batch
             torch.cuda.empty_cache()
             line["secondary"] = {c: secondary_subprocess(c, args.secondary_steps, 3) for c in ("c4", "c5")}
+            if args.dtype == "bf16":       # the same c2 step in the reference's own arithmetic (exact-f32 matrix cores: 157 TF peak, the parity-tight mode)
+                line["secondary"]["c2_f32"] = secondary_subprocess("c2", args.secondary_steps, 3, extra=("--dtype", "f32"))
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_clips, args.cpu_timeout)
         print(json.dumps(line), flush=True)

@@ -313,8 +313,17 @@ int ipoke_wn_bwd_multi_range(const float* params, float* grads, const float* inv
 #define IPOKE_TAG_TN_SQUARE 2
 #define IPOKE_TAG_UNIT_FWD 3
 #define IPOKE_TAG_UNIT_BWD 4
+#define IPOKE_TAG_UNIT_INV 5
+/* every other ipoke_conv_forward launch is tagged by the kernel family the dispatcher chose (IPOKE_TAG_CONV_BASE + IPOKE_KERNEL_*), every
+ * other weight gradient IPOKE_TAG_WGRAD; both carry their algorithmic work: FLOPs = 2 * rows * Nout * taps * channels (transposed
+ * strided forms: divided by the stride product -- the taps that meet an input pixel), bytes = input + weights + output, each once. */
+#define IPOKE_TAG_CONV_BASE 16
+#define IPOKE_TAG_WGRAD 32
 int ipoke_timing_start(void);
+int ipoke_timing_start_all(void);   /* also the IPOKE_TAG_CONV_* / IPOKE_TAG_WGRAD families */
 int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us);
+/* per tag: launches, SUM of durations (us), SUM of algorithmic FLOPs and bytes -- the per-configuration rooflines of bench.py */
+int ipoke_timing_stop_ex(const int* tags, int ntags, int* counts, double* total_us, double* flops, double* bytes);
 
 /* LU-parametrised invertible 1x1 convolution (macow2.py:596-649), used by the flow engine when use1x1 is set: prepare builds
  * [W | W^-1 | wl | wu] (C*C floats each) per job in the workspace; apply: out[:, :C] = in[:, :C] mat^T (or mat), rest copied,

@@ -225,7 +225,10 @@ SIGNATURES = {
     "ipoke_poke_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "ipoke_poke_simulate": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ipoke_timing_start": (c_int, []),
+    "ipoke_timing_start_all": (c_int, []),
     "ipoke_timing_stop": (c_int, [POINTER(c_int), c_int, POINTER(c_int), POINTER(ctypes.c_double)]),
+    "ipoke_timing_stop_ex": (c_int, [POINTER(c_int), c_int, POINTER(c_int), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                     POINTER(ctypes.c_double)]),
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),
     "ipoke_flow_destroy": (None, [_P]),
     "ipoke_flow_param_count": (c_int64, [_P]),

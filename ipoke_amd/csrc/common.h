@@ -32,13 +32,16 @@ int fail(int code, const std::string& msg);
 #define IPK_LAUNCH_CHECK() IPK_HIP(hipGetLastError())
 
 // ---- in-situ timing of tagged launches (common.cpp; bench.py's roofline objects) ---------------------------------
-bool timing_active();
+bool timing_active(int tag = 1);      // tags >= IPOKE_TAG_CONV_BASE are recorded only at level 2 (ipoke_timing_start_all)
 int timing_begin(int tag, hipStream_t s, int units = 1);
 void timing_end(int slot, hipStream_t s);
+void timing_annotate(int slot, int tag, double flops, double bytes);
 struct TimedScope {       // records an event pair around the launches issued while it is alive (no-op unless timing is on)
   int slot; hipStream_t s;
-  TimedScope(int tag, hipStream_t st, int units = 1) : slot(tag != 0 && timing_active() ? timing_begin(tag, st, units) : -1), s(st) {}
+  TimedScope(int tag, hipStream_t st, int units = 1) : slot(tag != 0 && timing_active(tag) ? timing_begin(tag, st, units) : -1), s(st) {}
   ~TimedScope() { timing_end(slot, s); }
+  // set once the dispatcher has chosen the kernel: the family tag and the launch's algorithmic work (ipoke_timing_stop_ex)
+  void annotate(int tag, double flops, double bytes) { if (slot >= 0) timing_annotate(slot, tag, flops, bytes); }
 };
 
 // ---- element traits --------------------------------------------------------

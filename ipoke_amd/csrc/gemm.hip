@@ -2619,8 +2619,19 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   p.stamps = g_gemm_stamps;
   if (g_gemm_stamps) g_gemm_stamps += 4 * 4096;                // one slab of 4096 workgroups per launch
 #endif
-  TimedScope ts(p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 && p.splitk == 1 ? IPOKE_TAG_NT_SQUARE : 0, s);
-  return dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
+  const bool square = p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 && p.splitk == 1;
+  TimedScope ts(square ? IPOKE_TAG_NT_SQUARE : IPOKE_TAG_CONV_BASE, s);
+  rc = dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
+  if (ts.slot >= 0) {          // algorithmic work of this launch (timing runs only)
+    const GeomDev& g = p.g;
+    const double stride = g.transposed ? (double)g.sd * g.sh * g.sw : 1.0;
+    const double flops = 2.0 * g.M * d->Nout * (double)g.taps * d->Kc_real / stride;
+    const double in_rows = (double)d->NB * g.Di * g.Hi * g.Wi;
+    const double bytes = in_rows * d->Kc_real * (d->a_f32 ? 4 : esz) + (double)d->Nout * g.taps * d->Kc_real * esz +
+                         (double)g.M * d->Nout * (d->c_f32 ? 4 : esz) * (p.splitk > 1 && !d->c_accumulate ? p.splitk : 1);
+    ts.annotate(square ? 0 : IPOKE_TAG_CONV_BASE + g_last_kernel, flops, bytes);
+  }
+  return rc;
 }
 
 static int fill_tn(TnParams& p, const ipoke_wgrad_desc* d, int dtype, bool batched) {
@@ -2659,7 +2670,14 @@ extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stre
   TnParams p;
   int rc = fill_tn(p, d, dtype, false); if (rc) return rc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  TimedScope ts(p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 ? IPOKE_TAG_TN_SQUARE : 0, s);
+  const bool square = p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024;
+  TimedScope ts(square ? IPOKE_TAG_TN_SQUARE : IPOKE_TAG_WGRAD, s);
+  if (ts.slot >= 0) {
+    const int esz = dtype == IPOKE_BF16 ? 2 : 4;
+    const double in_rows = (double)d->NB * d->Di * d->Hi * d->Wi;
+    ts.annotate(0, 2.0 * p.g.M * d->Nout * (double)p.g.taps * d->Kc_real,
+                (double)p.g.M * d->Nout * esz + in_rows * d->Kc_real * (d->a_f32 ? 4 : esz) + (double)d->Nout * p.g.taps * d->Kc_real * 4 * p.splitm);
+  }
   return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s) : launch_tn<float>(p, s);
 }
 

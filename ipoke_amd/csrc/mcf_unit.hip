@@ -1013,6 +1013,9 @@ extern "C" int ipoke_macow_unit_inv(const ipoke_mcf_desc* d4, int dtype, void* s
                      (size_t)16 * (2 * U.C + 4) * 4 + (size_t)2 * 64 * U.C * 4 + (size_t)(8 * U.C + 8 * U.C) * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int grid = (U.B + 1) / 2;
+  TimedScope ts(IPOKE_TAG_UNIT_INV, s);
+  // four masked-conv flows per sample: 64 positions x (6-tap shifted conv C -> 4C, 1x1 conv (4C + Cc) -> 2C); weights once, state in + out
+  ts.annotate(0, 4.0 * U.B * 64.0 * (64.0 * U.C * U.C + 4.0 * U.Cc * U.C), 4.0 * (32.0 * U.C * U.C + 2.0 * U.Cc * U.C) * 2.0 + 2.0 * U.B * 64.0 * U.C * 4.0);
   if (wide) {
     rc = ensure_lds<macow_unit_inv_kernel<bf16_t, true>>(lds); if (rc) return rc;
     hipLaunchKernelGGL((macow_unit_inv_kernel<bf16_t, true>), dim3(grid), dim3(kMcfThreads), lds, s, U);
