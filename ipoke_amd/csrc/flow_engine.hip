@@ -1434,6 +1434,12 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     return IPOKE_OK;
   };
   flush_nice_fn = flush_nice;
+  // Every flush costs the CHAIN an event record (the side stream must see the couplings' operands): a barrier packet with a completion
+  // signal between two chain kernels, ~10 us of queue time each (profiles/r03_bench_trace_gaps.txt: 112 gaps of 12.8 us per step in
+  // front of the fused units).  IPOKE_NICE_FLUSH_MIN couplings are collected before the chain pays for one (the end of a piece always
+  // flushes: finish_piece).
+  static const int flush_min = getenv("IPOKE_NICE_FLUSH_MIN") ? atoi(getenv("IPOKE_NICE_FLUSH_MIN")) : 2;
+  auto maybe_flush_nice = [&]() -> int { return (int)pend_nice.size() >= flush_min ? flush_nice() : (int)IPOKE_OK; };
   size_t pk = 0;
   int cur = 0;
   int pending_an = -1;              // ActNorm op whose backward is carried by the next (lower) coupling's launch
@@ -1442,7 +1448,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     const Op& op = f->ops[i];
     if (op.unit_of >= 0 && i == op.unit_of + 5) {     // whole MaCowUnit (ops h .. h+5) differentiated by one launch
       const int h = op.unit_of;
-      rc = flush_nice(); if (rc) return rc;
+      rc = maybe_flush_nice(); if (rc) return rc;
       static const int lidx[4] = {0, 1, 3, 4};
       for (const Ctx& l : lanes) {
         ipoke_mcf_desc d4[4];
@@ -1483,7 +1489,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     // An ActNorm right behind a coupling is differentiated by the coupling's launch (ipoke_actnorm_affine_bwd), unless it is the
     // lowest op of the current piece: its parameter-gradient partials must exist when the piece is finished right after this op.
     if (op.type == OP_ACTNORM && op.an_prev >= 0 && i != f->units[pieces[pk].first].op_lo) { pending_an = i; continue; }
-    if (op.type != OP_NICE) { rc = flush_nice(); if (rc) return rc; }
+    if (op.type != OP_NICE) { rc = maybe_flush_nice(); if (rc) return rc; }
     for (const Ctx& l : lanes) {
       const float* gin = l.rowsf(goff[cur], l.ld); float* gout = l.rowsf(goff[cur ^ 1], l.ld);
       const float* xin = l.state(i);                 // saved input of op i

@@ -12,6 +12,8 @@ the three sub-model configurations from ``config['first_stage']``, ``config['pok
 from functools import partial
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -147,20 +149,37 @@ class PokeMotionModel(nn.Module):
         res = self.load_state_dict(self._sd(ckpt), strict=strict)
         self.flow.sync_buffers()
         self.first_stage_model.enc_motion.conv1.invalidate()
+        self._drop_graphs()
         return res
+
+    def load_state_dict(self, *args, **kwargs):
+        res = super().load_state_dict(*args, **kwargs)
+        self._drop_graphs()
+        return res
+
+    def _drop_graphs(self):
+        """Captured graphs hold the ADDRESSES of the cached weight operands: a state-dict load drops those caches (``_Cached``), so the
+        graphs of ``set_sample_graph`` / ``set_encoder_graph`` are recaptured on their next use."""
+        if getattr(self, "_sample_graphs", None):
+            self._sample_graphs = {}
+        if getattr(self, "_enc_graphs", None):
+            self._enc_graphs = {}
 
     def load_first_stage(self, ckpt):
         self.first_stage_model.load_state_dict(self._sd(ckpt), strict=False)
         self.first_stage_model.enc_motion.conv1.invalidate()
+        self._drop_graphs()
 
     def load_poke_embedder(self, ckpt):
         sd = self._sd(ckpt)
         sd = {".".join(k.split(".")[1:]): v for k, v in sd.items() if "encoder" in k or "decoder" in k}
         self.poke_embedder.load_state_dict(sd, strict=False)
+        self._drop_graphs()
 
     def load_conditioner(self, ckpt):
         sd = {k: v for k, v in self._sd(ckpt).items() if "encoder" in k or "decoder" in k}
         self.conditioner.load_state_dict(sd, strict=False)
+        self._drop_graphs()
 
     # ---- LR rule (:238-253) ---------------------------------------------------------------------------
     def on_train_epoch_start(self, num_training_batches=None):
@@ -251,7 +270,10 @@ class PokeMotionModel(nn.Module):
         else:
             stream.wait_stream(cur)
         with torch.cuda.stream(stream):
-            flow_input, cond = self.make_flow_input(batch)
+            if getattr(self, "_graph_encoders", False) and not self.augment_input:
+                flow_input, cond = self._flow_input_graphed(batch)
+            else:
+                flow_input, cond = self.make_flow_input(batch)
             ev = torch.cuda.Event(); ev.record(stream)
         for v in batch.values():                       # tensors the side stream reads must not be recycled under it
             for t_ in (v if isinstance(v, (list, tuple)) else [v]):
@@ -262,6 +284,72 @@ class PokeMotionModel(nn.Module):
             self._prefetched = {}
         # keyed FIFO: the next batch may be prefetched before this one is consumed (and a loop may feed the same object twice)
         self._prefetched.setdefault(id(batch), []).append((batch, flow_input, cond, ev))
+
+    # ---- the frozen encoders as ONE captured hipGraph -----------------------------------------------------------------------
+    def set_encoder_graph(self, enable=True):
+        """Replay the device side of ``make_flow_input`` (2-D poke / image encoders + the 3-D motion encoder: ~200 launches that Python
+        needs ~4 ms to queue for 3.6 ms of kernels) from one captured hipGraph per input shape when it is PREFETCHED for the next step
+        (``prefetch_flow_input``).  The replay is one host call, and inside the graph the two small 2-D encoders run BESIDE the 3-D encoder
+        (a second captured stream: no allocator traffic at replay).  MEASURED AND NOT ADOPTED AS DEFAULT (round 4, c2): the hole behind the
+        backward pass shrinks from 5.5 to 4.7 ms, but the step is 60.2-61.2 ms against 59.2-59.4 eager -- the forward pass of the next step
+        picks up gaps it did not have (IPOKE_ENC_GRAPH=1 turns it on in SecondStageTrainer; bit-identical results either way).  The reparameterisation noise is still drawn on the CPU generator per call, at the same point of the host program as the
+        eager path (motion_encoder.py:220), and copied into the graph's input buffer."""
+        self._graph_encoders = bool(enable)
+        self._enc_graphs = {}
+
+    def _flow_input_device(self, X, poke, eps, side=None):
+        """Device side of ``make_flow_input`` (reverse = False) with the noise given; ``side``: a stream for the 2-D encoders."""
+        if self.embed_poke_and_image:
+            poke = torch.cat([poke, X[:, 0]], dim=1)
+        cur = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(cur)
+        with torch.cuda.stream(side if side is not None else cur):
+            poke_emb, *_ = self.poke_embedder.encoder(poke)
+            cond = None
+            if self.use_cond:
+                cond, *_ = self.conditioner.encoder(X[:, 0])
+                if self.adapt_cond_ssize:
+                    cond = self._adapt_cond(cond)
+        if self.full_seq:
+            X_in = X if self.first_stage_model.full_sequence or self.config["data"]["max_frames"] < 16 else X[:, :-1]
+        else:
+            X_in = X if self.first_stage_model.full_sequence else X[:, 1:]
+        flow_input, _, _ = self.first_stage_model.enc_motion(X_in.transpose(1, 2), eps=eps)
+        if side is not None:
+            cur.wait_stream(side)
+        cond = torch.cat([cond, poke_emb], dim=1) if self.use_cond else poke_emb
+        return flow_input, cond
+
+    def _flow_input_graphed(self, batch):
+        X = batch["images"]
+        poke = batch[self.poke_key]
+        poke = poke[0] if isinstance(poke, list) else poke
+        key = (tuple(X.shape), tuple(poke.shape), X.dtype, poke.dtype)
+        ent = self._enc_graphs.get(key)
+        if ent is None:                                  # first call of a shape: eager (builds every lazily cached operand)
+            flow_input, cond = self.make_flow_input(batch)
+            self._enc_graphs[key] = {"state": "warm", "eps_shape": tuple(flow_input.shape)}
+            return flow_input, cond
+        self.first_stage_model.eval(); self.poke_embedder.eval()
+        if self.use_cond:
+            self.conditioner.eval()
+        enc = self.first_stage_model.enc_motion
+        eps = None if enc.be_determinstic else torch.FloatTensor(*ent["eps_shape"]).normal_()      # CPU generator, motion_encoder.py:220
+        if ent["state"] == "warm":
+            sX, sP = X.clone(), poke.clone()
+            sE = None if eps is None else eps.to(X.device)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream() if os.environ.get("IPOKE_ENC_GRAPH_SIDE", "1") != "0" else None
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                out = self._flow_input_device(sX, sP, sE, side=side)
+            ent.update(state="ready", graph=g, X=sX, poke=sP, eps=sE, out=out, side=side)
+        ent["X"].copy_(X, non_blocking=True); ent["poke"].copy_(poke, non_blocking=True)
+        if eps is not None:
+            ent["eps"].copy_(eps, non_blocking=True)
+        ent["graph"].replay()
+        return ent["out"]
 
     def forward_density(self, batch):
         queue = (getattr(self, "_prefetched", None) or {}).get(id(batch))
@@ -324,6 +412,8 @@ class PokeMotionModel(nn.Module):
             with torch.cuda.graph(g):
                 out = self._sample_device(sX, sP, sZ)
             ent.update(state="ready", graph=g, X=sX, poke=sP, z=sZ, out=out)
+        if self.flow.engine.shadow_stale:            # a replay skips the eager path's refresh of the flow's weight operands (same addresses)
+            self.flow.engine.prepare_weights()
         ent["X"].copy_(X); ent["poke"].copy_(poke); ent["z"].copy_(z)
         ent["graph"].replay()
         return ent["out"]

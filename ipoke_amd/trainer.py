@@ -48,6 +48,11 @@ class SecondStageTrainer:
         self.prefetch_stream = None
         if os.environ.get("IPOKE_NO_PREFETCH", "0") != "1" and torch.cuda.is_available():
             self.prefetch_stream = torch.cuda.Stream()
+            # IPOKE_ENC_GRAPH=1 (developer A/B, measured slower: PokeMotionModel.set_encoder_graph): the prefetched encoders replayed from
+            # one captured hipGraph, gated on the GPU side at the END of the backward pass, instead of ~200 eager launches
+            if os.environ.get("IPOKE_ENC_GRAPH", "0") == "1":
+                model.set_encoder_graph(True)
+        self.enc_graph_at = os.environ.get("IPOKE_ENC_GRAPH_AT", "bwd")        # developer A/B: "fwd" = may start right behind the forward pass
         self.prefetch_at_start = os.environ.get("IPOKE_PREFETCH_AT", "after_bwd") == "start"
         # IPOKE_PREFETCH_AT=piece<k> (developer A/B, measured round 3, NOT adopted): the next batch's encoders are queued when the
         # backward pass has issued its k-th piece (of IPOKE_PIECES), ordered after that point of the chain, so that they overlap the rest
@@ -171,7 +176,13 @@ class SecondStageTrainer:
                 if native and not ok:
                     self.opt.disarm_native()
             if prefetch and not (native and self.prefetch_piece is not None and state["done"]):
-                m.prefetch_flow_input(next_batch, self.prefetch_stream, after=fwd_done)      # queued after the backward pass (host order = GPU start order)
+                after = fwd_done
+                if getattr(m, "_graph_encoders", False) and self.enc_graph_at == "bwd":
+                    # a graph replay is ONE host call: the host, several ms ahead of the GPU here, would start it in the middle of the
+                    # backward pass; the event holds it until the chain (and the ready stream's last slice) is done
+                    after = torch.cuda.Event()
+                    after.record()
+                m.prefetch_flow_input(next_batch, self.prefetch_stream, after=after)      # queued after the backward pass (host order = GPU start order)
             self._optimizer_step(self.opt.finish_native if native else self.opt.finish_step)
         else:
             loss.backward()

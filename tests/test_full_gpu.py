@@ -90,9 +90,12 @@ def test_forward_sample_with_injected_latent(golden, dtype):
     assert e_v.max().item() <= (5e-4 if dtype == "f32" else 0.2) and e_v.mean().item() <= (2e-5 if dtype == "f32" else 2e-2)
 
 
-def test_encoder_prefetch_does_not_change_training():
+@pytest.mark.parametrize("enc_graph", ["1", "0"])
+def test_encoder_prefetch_does_not_change_training(enc_graph, monkeypatch):
     """train_step(batch, next_batch=...) runs the next batch's frozen encoders on a side stream during the current backward:
-    same losses and parameters as the plain loop (the encoder's CPU-generator draws keep their order)."""
+    same losses and parameters as the plain loop (the encoder's CPU-generator draws keep their order).  enc_graph = 1 (default): the
+    prefetched encoders are replayed from one captured hipGraph (first prefetch eager, second captures, third and fourth replay)."""
+    monkeypatch.setenv("IPOKE_ENC_GRAPH", enc_graph)
     from ipoke_amd import configs
     from ipoke_amd.second_stage import PokeMotionModel
     from ipoke_amd.trainer import SecondStageTrainer
@@ -109,7 +112,7 @@ def test_encoder_prefetch_does_not_change_training():
             deterministic_fill_(part, prefix=pfx)
         model.flow.sync_buffers()
         batches = []
-        for k in range(3):
+        for k in range(5):
             g = torch.Generator().manual_seed(20 + k)
             batches.append({"images": (torch.rand(2, 16, 3, 64, 64, generator=g) * 2 - 1).cuda(),
                             "flow": torch.randn(2, 2, 64, 64, generator=g).cuda(),
@@ -118,9 +121,11 @@ def test_encoder_prefetch_does_not_change_training():
         if not prefetch:
             tr.prefetch_stream = None
         losses = []
-        for k in range(3):
-            nxt = batches[k + 1] if k + 1 < 3 else None
+        for k in range(5):
+            nxt = batches[k + 1] if k + 1 < 5 else None
             losses.append(tr.train_step(batches[k], k, next_batch=nxt).item())
+        if prefetch and enc_graph == "1":
+            assert any(e.get("state") == "ready" for e in model._enc_graphs.values())
         torch.cuda.synchronize()
         return losses, model.flow.flat_params.detach().cpu()[::499].clone()
 
