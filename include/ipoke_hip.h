@@ -95,6 +95,10 @@ typedef struct {
    * (rs_images = clips per batch, row_scale = the {sigma, 1/sigma} table of ipoke_spectral_sigma_multi + 1, rs_stride = 2). */
   const float* row_scale;
   int32_t rs_images, rs_stride;
+  /* 1: W is K-MAJOR -- the row-major [Ktot][ldw] matrix, element (k, n) at W[k * ldw + n] (bf16, 1 x 1 kernels over dense rows, Kc a
+   * multiple of 64).  The data gradient of a 1 x 1 convolution then reads the weight's own straight copy W[out][in] (it reduces over
+   * `out`, the row index), so that weight needs no transposed operand (the coupling nets' conv2, macow_utils.py:270-281). */
+  int32_t w_kmajor;
 } ipoke_conv_desc;
 
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
@@ -407,6 +411,11 @@ int ipoke_adam_seg_size(void);
 int ipoke_adam_amsgrad_shadow_tiles(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, const void* jobs_dev, int njobs,
                                     int tile_begin, int ntiles, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                     float grad_scale, int max_blocks, int dtype, void* stream);
+/* the tile kernel's counterpart for tensors with ONE operand, their own cast (a flow whose conv2 data gradient reads the straight copy
+ * K-major, ipoke_conv_desc.w_kmajor): a linear stream over the same job table, chunks of 4096 elements */
+int ipoke_adam_amsgrad_cast_tiles(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, const void* jobs_dev, int njobs,
+                                  int tile_begin, int ntiles, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                  float grad_scale, int max_blocks, int dtype, void* stream);
 int ipoke_adam_amsgrad_segments(float* p, const float* g, float* m, float* v, float* vmax, const void* segs_dev, int seg_begin, int nsegs,
                                 int64_t begin, int64_t end, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                 float grad_scale, int blocks_per_segment, void* stream);

@@ -28,7 +28,7 @@ class ConvDesc(Structure):
         ("C", c_void_p), ("c_f32", c_int32), ("c_accumulate", c_int32), ("ldc", c_int64),
         ("c_coff", c_int32), ("c_cstride", c_int32), ("splitk", c_int32),
         ("c_scatter", c_int32), ("c_sn", c_int64), ("c_sh", c_int64), ("c_sw", c_int64), ("c_row0", c_int64),
-        ("row_scale", c_void_p), ("rs_images", c_int32), ("rs_stride", c_int32)]
+        ("row_scale", c_void_p), ("rs_images", c_int32), ("rs_stride", c_int32), ("w_kmajor", c_int32)]
 
 
 class WgradDesc(Structure):
@@ -210,6 +210,8 @@ SIGNATURES = {
     "ipoke_adam_seg_size": (c_int, []),
     "ipoke_adam_amsgrad_shadow_tiles": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                                                 c_int, c_float, c_int, c_int, _P]),
+    "ipoke_adam_amsgrad_cast_tiles": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                                              c_int, c_float, c_int, c_int, _P]),
     "ipoke_adam_amsgrad_segments": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int64, c_float, c_float, c_float, c_float,
                                             c_float, c_int, c_float, c_int, _P]),
     "ipoke_wn_bwd_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

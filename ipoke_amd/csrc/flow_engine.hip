@@ -117,6 +117,10 @@ struct ipoke_flow {
   // every masked-conv layer is differentiated inside a fused MaCowUnit launch, which also writes the layer's input in the matrix
   // cores' dtype: the shifted-conv weight gradients then read that copy through the LDS-DMA GEMM instead of the fp32 state
   bool mcf_xop = false;
+  // conv2 of every coupling net (plain 1x1, 73 % of the parameters) keeps ONLY its straight bf16 copy: the data gradient reads it
+  // K-major (igemm_nn_glds, ipoke_conv_desc.w_kmajor), the optimizer writes it while it holds the updated values (adam_cast_kernel),
+  // relayout never touches those tensors (IPOKE_C2_STRAIGHT=0: transposed shadow + relayout as in rounds 1-3)
+  bool c2_straight = false;
   // Optimizer applied by the engine itself as soon as a piece of the backward pass is final (ipoke_flow_set_native_adam): the
   // Adam-amsgrad update and the shadow refresh of the piece's parameter ranges are queued on the ready stream by finish_piece
   // without a round trip through the host callback.
@@ -269,7 +273,7 @@ struct Builder {
     op.sh_c1 = add_shadow((int64_t)hid * 9 * op.Kc1);
     op.sh_c1t = add_shadow((int64_t)op.cin * 9 * hid);
     op.sh_c2 = add_shadow((int64_t)hid * hid);
-    op.sh_c2t = add_shadow((int64_t)hid * hid);
+    op.sh_c2t = f.c2_straight ? -1 : add_shadow((int64_t)hid * hid);
     op.sh_c3 = add_shadow((int64_t)N3 * 9 * hid);
     op.sh_c3t = add_shadow((int64_t)hid * 9 * op.Kc3);
     // conv1.weight [hid][cin][3][3]
@@ -662,6 +666,10 @@ extern "C" int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out)
   std::unique_ptr<ipoke_flow> f(new ipoke_flow());
   f->cfg = *cfg;
   f->esz = cfg->dtype == IPOKE_BF16 ? 2 : 4; f->e16 = 16 / f->esz; f->ks = 64 / f->esz;
+  {
+    const char* cs = getenv("IPOKE_C2_STRAIGHT");
+    f->c2_straight = cfg->dtype == IPOKE_BF16 && cfg->hidden % 64 == 0 && !(cs && cs[0] == '0');
+  }
   int rc = build(*f); if (rc) return rc;
   {   // gaps between the optimizer-fused tensors (both tables are in parameter order)
     int64_t pos = 0;
@@ -885,11 +893,19 @@ extern "C" int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* para
  *   2. everything between them by ipoke_adam_amsgrad_segments,
  *   3. weight-norm scales and the relayout of the remaining (3x3, masked, weight-normed) tensors.
  * [begin, end) must cover whole tensors (the ranges ipoke_flow_backward_pieces announces, or [0, param_count)). */
+static int adam_range(ipoke_flow* f, float* params, const float* grads, float* m, float* v, float* vmax, void* shadow, int64_t begin, int64_t end,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream);
+
 extern "C" int ipoke_flow_adam_range(ipoke_flow* f, float* params, const float* grads, float* m, float* v, float* vmax, void* shadow,
                                      int64_t begin, int64_t end, float lr, float beta1, float beta2, float eps, float weight_decay,
                                      int step, float grad_scale, int max_blocks, void* stream) {
   IPK_REQUIRE(f && params && grads && m && v && vmax && shadow && begin >= 0 && end >= begin && end <= f->n_params, "bad arguments");
   { int rc0 = ensure_device(f); if (rc0) return rc0; }
+  return adam_range(f, params, grads, m, v, vmax, shadow, begin, end, lr, beta1, beta2, eps, weight_decay, step, grad_scale, max_blocks, stream);
+}
+
+static int adam_range(ipoke_flow* f, float* params, const float* grads, float* m, float* v, float* vmax, void* shadow, int64_t begin, int64_t end,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream) {
   if (end == begin) return IPOKE_OK;
   int a0 = 0, a1 = 0;
   while (a0 < (int)f->ajobs.size() && f->ajobs[a0].src_off < begin) ++a0;
@@ -899,8 +915,12 @@ extern "C" int ipoke_flow_adam_range(ipoke_flow* f, float* params, const float* 
     IPK_REQUIRE(f->ajobs[a1 - 1].src_off + (int64_t)f->ajobs[a1 - 1].N * f->ajobs[a1 - 1].K <= end, "range must cover whole tensors");
     const int t0 = f->ajobs[a0].tile_start, t1 = a1 < (int)f->ajobs.size() ? f->ajobs[a1].tile_start : f->atiles;
     void* sh = reinterpret_cast<unsigned char*>(shadow) + 2 * align_up(f->wn_rows, 64) * 4;
-    int rc = ipoke_adam_amsgrad_shadow_tiles(params, grads, m, v, vmax, sh, f->d_ajobs, (int)f->ajobs.size(), t0, t1 - t0, lr, beta1, beta2,
-                                             eps, weight_decay, step, grad_scale, max_blocks, f->cfg.dtype, stream);
+    // c2_straight: the tensor's one operand is its own cast, written linearly; else the 64 x 64-tile kernel that also transposes
+    int rc = f->c2_straight
+        ? ipoke_adam_amsgrad_cast_tiles(params, grads, m, v, vmax, sh, f->d_ajobs, (int)f->ajobs.size(), t0, t1 - t0, lr, beta1, beta2,
+                                        eps, weight_decay, step, grad_scale, max_blocks, f->cfg.dtype, stream)
+        : ipoke_adam_amsgrad_shadow_tiles(params, grads, m, v, vmax, sh, f->d_ajobs, (int)f->ajobs.size(), t0, t1 - t0, lr, beta1, beta2,
+                                          eps, weight_decay, step, grad_scale, max_blocks, f->cfg.dtype, stream);
     if (rc) return rc;
   }
   int s0 = 0, s1 = 0;
@@ -1364,6 +1384,12 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       for (int kind = 0; kind < 3; ++kind) {
         if (p0[kind] < 0 || p1[kind] <= p0[kind]) continue;
         const int64_t b0 = p0[kind], n = p1[kind] - p0[kind];
+        if (f->c2_straight) {      // conv2 tensors: update + their one operand in the same linear pass; the rest: update, then relayout
+          r = adam_range(f, pm, grads, A.m, A.v, A.vmax, const_cast<void*>(shadow), b0, b0 + n, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
+                         A.grad_scale, A.max_blocks, rstream);
+          if (r) return r;
+          continue;
+        }
         r = ipoke_adam_amsgrad_step_grid(pm + b0, grads + b0, A.m + b0, A.v + b0, A.vmax + b0, n, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
                                          A.grad_scale, A.max_blocks, rstream);
         if (r) return r;
@@ -1543,7 +1569,9 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
         // conv2 data gradient, times ELU'(h1)
         set_conv8(d, l.B, 1, 0);
         set_a_dense(d, dp2, hid, hid);
-        d.W = l.sh(op.sh_c2t); d.ldw = hid; d.Nout = hid; d.dact = h1; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
+        if (f->c2_straight) { d.W = l.sh(op.sh_c2); d.w_kmajor = 1; }      // W2[out][in] read K-major: no transposed copy exists
+        else d.W = l.sh(op.sh_c2t);
+        d.ldw = hid; d.Nout = hid; d.dact = h1; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
         d.C = dp1; d.ldc = hid;
         rc = ipoke_conv_forward(&d, l.dtype, l.stream()); if (rc) return rc;
         // conv1 data gradient accumulated into the conditioning channels

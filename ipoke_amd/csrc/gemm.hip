@@ -40,6 +40,7 @@ struct NtParams {
   int tiles_m, tiles_n, xa, xb;
   int prio;            // != 0: raise the waves' issue priority (s_setprio)
   int c_scatter; long c_sn, c_sh, c_sw, c_row0;      // output row of position (n, oh, ow) when c_scatter (ipoke_conv_desc)
+  int w_kmajor;        // 1: W is [Ktot][ldw] -- element (k, n) at W[k * ldw + n] (1x1 kernels: the straight copy of a weight used by its own data gradient)
   const float* row_scale; int rs_images, rs_stride;  // accumulators of image n are multiplied by row_scale[(n / rs_images) * rs_stride] before the bias
 #ifdef IPOKE_GEMM_STAMPS
   long long* stamps = nullptr;   // probe build only (scripts/probe_gemm_stamps.py): 4 wall-clock stamps per workgroup
@@ -2222,6 +2223,223 @@ template <typename F> __device__ __forceinline__ void tn_wait_frags(F (&f)[6]) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5])::"memory");
 }
 
+// =============================================================================================
+// igemm_nn: C[m][n] = sum_k A[m][k] * W[k][n] -- the weight given K-MAJOR, i.e. as the row-major [k][n] matrix (NtParams.w_kmajor).
+// This is the data gradient of a 1x1 convolution read from the weight's STRAIGHT copy W[out][in] (reduction over `out`, its row index):
+// with it the coupling nets' conv2 -- 73 % of the flow's parameters -- needs no transposed shadow, the optimizer writes the one bf16
+// copy itself and `relayout` never touches those tensors.
+// Same ring, tile shapes, K split and epilogue as igemm_nt_glds_kernel; the difference is the W operand: a K-block of 64 reduction rows x
+// BN = 128 columns goes global -> LDS untouched as 64 rows of 256 bytes (16-byte source chunks permuted by tn_swz against bank conflicts,
+// exactly the operand images of igemm_tn_glds_kernel) and the matrix-core fragments -- 8 consecutive k for one column per lane -- are
+// read with the transposing ds_read_b64_tr_b16 (two per fragment; inline assembly, see tn_ds_tr).
+template <int WM, int WN, int MREP, int NSTAGE, int WK>
+__global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nn_glds_kernel(const NtParams p) {
+  typedef bf16_t T;
+  constexpr int NREP = 2, NTHR = WM * WN * WK * 64, NWAVE = NTHR / 64;
+  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
+  static_assert(BN == 128, "the W image is 64 rows x 256 bytes");
+  constexpr int A_IT = (BM * 8 + NTHR - 1) / NTHR, B_IT = 1024 / NTHR, L = A_IT + B_IT;
+  constexpr int SUB = BM * 128 + 64 * 256;        // one K-block (64 k) of both operands
+  static_assert((NSTAGE - 2) * L <= 63 && 1024 % NTHR == 0, "vmcnt field / whole DMA instructions");
+  typedef typename ET<T>::frag frag_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* dummy = smem + NSTAGE * SUB;                           // 1 KB per wave: landing zone of padding DMAs
+  if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WM * WN), wr = wave % (WM * WN);
+  const int wm = wr / WN, wn = wr % WN;
+  const GeomDev& g = p.g;
+  int tm, tn;
+  {
+    const int bid = blockIdx.x;
+    if (p.xa > 0) {
+      const int xcd = bid & 7, q = bid >> 3;
+      const int sub_m = p.tiles_m / p.xa, sub_n = p.tiles_n / p.xb;
+      tm = (xcd % p.xa) * sub_m + q % sub_m;
+      tn = (xcd / p.xa) * sub_n + q / sub_m;
+    } else {
+      tm = bid % p.tiles_m; tn = bid / p.tiles_m;
+    }
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkb = (p.Ktot + 63) >> 6;
+  constexpr unsigned kInvalid = 0xffffffffu;
+  // A chunks: row r of the tile = GEMM row m0 + r (a 1x1 convolution on dense channels-last rows: row m starts at m * a_sw)
+  unsigned a_off[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int ch = tid + NTHR * i, row = ch >> 3, pos = ch & 7;
+    a_off[i] = (row < BM && m0 + row < g.M) ? (unsigned)((long)(m0 + row) * p.a_sw + p.a_coff + ((pos ^ ((row >> 1) & 7)) * 8)) : kInvalid;
+  }
+  // W chunks: DMA instruction i of this wave fills image rows 4 * (wave + NWAVE * i) + lane / 16, chunk lane % 16 <- source chunk ^ swz(row)
+  unsigned b_off[B_IT]; int b_row[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int row = 4 * (wave + NWAVE * i) + (lane >> 4), col = n0 + (((lane & 15) ^ tn_swz(row)) * 8);
+    b_row[i] = row;
+    b_off[i] = col < p.Nout ? (unsigned)((long)row * p.ldw + col) : kInvalid;
+  }
+  const T* Abase = reinterpret_cast<const T*>(p.A);
+  const T* Wbase = reinterpret_cast<const T*>(p.W);
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+  int kb_issue = 0;
+  auto issue_slot = [&](int slot) {
+    unsigned char* sa = smem + slot * SUB;
+    const bool real = kb_issue < nkb;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const T* src = (real && a_off[i] != kInvalid) ? Abase + a_off[i] : zero;
+      unsigned char* dst = (real && (wave * 64 + NTHR * i) < BM * 8) ? sa + (wave * 64 + NTHR * i) * 16 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+      if (a_off[i] != kInvalid) a_off[i] += 64;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const T* src = (real && b_off[i] != kInvalid && kb_issue * 64 + b_row[i] < p.Ktot) ? Wbase + b_off[i] : zero;
+      unsigned char* dst = real ? sa + BM * 128 + (wave + NWAVE * i) * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+      if (b_off[i] != kInvalid) b_off[i] += (unsigned)(64 * p.ldw);
+    }
+    ++kb_issue;
+  };
+
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets inside a K-block.  A: as igemm_nt_glds (16-byte units XOR-swizzled by (row >> 1) & 7); k-step s = 32 k
+  int a_rd[MREP][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int q = s2 * 4 + (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+      const int row = wm * MREP * 16 + i * 16 + (lane & 15);
+      a_rd[i][s2] = row * 128 + ((q ^ ((row >> 1) & 7)) * 16);
+    }
+  }
+  // W: lane (i16, grp) reads k rows 8 * grp + (i16 >> 2) (+ 4: second read) of k-step s, columns base + 4 * (i16 & 3) .. + 3
+  const int i16 = lane & 15, grp = lane >> 4;
+  const int rrow = 8 * grp + (i16 >> 2);
+  const int hsw = tn_swz(rrow);                  // the same for row + 4 and row + 32
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned b_rd[NREP];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int col = (wn * NREP + j) * 16 + 4 * (i16 & 3);
+    b_rd[j] = lds0 + (unsigned)(BM * 128 + rrow * 256 + (((col >> 3) ^ hsw) * 16) + ((col >> 2) & 1) * 8);
+  }
+  auto read_b = [&](frag_t (&fb)[NREP], unsigned sb, int kstep) {
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const unsigned a = b_rd[j] + sb + (unsigned)(kstep * 32 * 256);
+      const tn_tr4_t lo = tn_ds_tr<0>(a), hi = tn_ds_tr<4 * 256>(a);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { fb[j][e] = lo[e]; fb[j][4 + e] = hi[e]; }
+    }
+  };
+  auto wait_b = [&](frag_t (&fb)[NREP]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0]), "+v"(fb[1])::"memory"); };
+
+#pragma unroll
+  for (int s2 = 0; s2 < NSTAGE - 1; ++s2) issue_slot(s2);
+  int slot = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    wait_vmcnt<(NSTAGE - 2) * L>();               // this wave's share of the oldest slot has landed
+    __builtin_amdgcn_s_barrier();                 // ... and everybody else's; all reads of the slot refilled below are done
+    issue_slot((slot + NSTAGE - 1) % NSTAGE);
+    const unsigned char* base = smem + slot * SUB;
+    const unsigned sb = (unsigned)(slot * SUB);
+    slot = (slot + 1) % NSTAGE;
+    if constexpr (WK == 2) {                      // this wave group owns k-step `wk` of every K-block
+      frag_t fa[MREP], fb[NREP];
+      read_b(fb, sb, wk);
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) fa[i] = *reinterpret_cast<const frag_t*>(base + (wk ? a_rd[i][1] : a_rd[i][0]));
+      wait_b(fb);
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[i], fb[j], acc[i][j]);
+    } else {
+      frag_t fa[2][MREP], fb[2][NREP];
+      read_b(fb[0], sb, 0);
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) fa[0][i] = *reinterpret_cast<const frag_t*>(base + a_rd[i][0]);
+      wait_b(fb[0]);
+      read_b(fb[1], sb, 1);                       // the second k-step's fragments travel under the first one's MFMAs
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) fa[1][i] = *reinterpret_cast<const frag_t*>(base + a_rd[i][1]);
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[0][i], fb[0][j], acc[i][j]);
+      wait_b(fb[1]);
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[1][i], fb[1][j], acc[i][j]);
+    }
+  }
+  wait_vmcnt<0>();
+  if constexpr (WK > 1) {                  // the two K halves meet: group 1 hands its partial sums to group 0 through LDS
+    constexpr int EP = BN * 4 + 16;
+    unsigned char* st2 = smem + BM * EP + (wm * MREP * 16 + (lane & 15)) * EP + (wn * NREP * 16 + (lane >> 4) * 4) * 4;
+    __syncthreads();
+    if (wk == 1) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(st2 + i * 16 * EP + j * 64) = acc[i][j];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(st2 + i * 16 * EP + j * 64);
+    }
+  }
+  nt_epilogue<T, WM, WN, MREP, NREP, NTHR>(p, acc, smem, m0, n0, wm, wn, 0, wk == 0);
+}
+
+template <int WM, int WN, int MREP, int NSTAGE, int WK>
+static int launch_nn_glds(NtParams& p, hipStream_t s) {
+  constexpr int BM = WM * MREP * 16, BN = WN * 2 * 16;
+  p.tiles_m = ceil_div(p.g.M, BM);
+  p.tiles_n = ceil_div(p.Nout, BN);
+  p.splitk = 1; p.kb_per_split = ceil_div(p.Ktot, 64);
+  pick_xcd_map(p);
+  size_t lds = (size_t)NSTAGE * (BM * 128 + 64 * 256) + WM * WN * WK * 64 * 16;
+  if (lds < (size_t)WK * BM * (BN * 4 + 16)) lds = (size_t)WK * BM * (BN * 4 + 16);      // epilogue staging (+ the K halves' hand-over)
+  auto kern = igemm_nn_glds_kernel<WM, WN, MREP, NSTAGE, WK>;
+  IPK_SET_LDS_ONCE(kern, lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long)p.tiles_m * p.tiles_n)), dim3(WM * WN * WK * 64), lds, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+// K-major weights (w_kmajor): 1x1 kernels over dense bf16 rows
+static int dispatch_nn(NtParams& p, hipStream_t s) {
+  const GeomDev& g = p.g;
+  IPK_REQUIRE(g.taps == 1 && !g.transposed && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 0 && g.pw == 0 && !p.a_f32 &&
+              p.Kc == p.Kc_real && p.Kc % 64 == 0 && (p.a_coff & 7) == 0 && (p.a_sw & 7) == 0 && (p.ldw & 7) == 0 && p.ldw >= p.Nout &&
+              p.splitk == 1 && !p.c_scatter && p.a_sh == (long)g.Wi * p.a_sw && p.a_sn == (long)g.Hi * g.Wi * p.a_sw &&
+              (long)g.M * p.a_sw + p.Kc < (1L << 31) && (long)p.Ktot * p.ldw < (1L << 31),
+              "K-major weights: 1x1 kernel over dense bf16 channels-last rows, K a multiple of 64");
+  const int M = g.M;
+  const long tn128 = ceil_div(p.Nout, 128);
+  int best = 128; long best_cost = ((long)ceil_div(M, 128) * tn128 + 255) / 256 * 128;
+  if (M % 160 == 0) { const long c = ((long)(M / 160) * tn128 + 255) / 256 * 160; if (c <= best_cost) { best = 160; best_cost = c; } }
+  if (M % 80 == 0) { const long c = ((long)(M / 80) * tn128 + 255) / 256 * 80; if (c < best_cost) { best = 80; best_cost = c; } }
+  if (best == 80) return launch_nn_glds<1, 4, 5, 3, 2>(p, s);       // 80 x 128: two K halves x 4 waves of 80 x 32 (the c2 shape: 256 workgroups)
+  if (best == 160) return launch_nn_glds<2, 4, 5, 3, 1>(p, s);      // 160 x 128, 8 waves of 80 x 32
+  return launch_nn_glds<2, 4, 4, 3, 1>(p, s);                       // 128 x 128
+}
+
 // RM = reduction rows per ring slot (64).
 template <int NSTAGE, int RM>
 __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) {
@@ -2584,7 +2802,7 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
     IPK_REQUIRE(((uintptr_t)d->A & 15) == 0, "A must be 16-byte aligned");
   }
   IPK_REQUIRE(d->ldw % e16 == 0 && ((uintptr_t)d->W & 15) == 0, "weights need 16-byte aligned rows");
-  IPK_REQUIRE(d->ldw >= round_up(p.g.taps * d->Kc, e16) || d->ldw >= p.g.taps * d->Kc, "ldw too small");
+  IPK_REQUIRE(d->w_kmajor ? d->ldw >= d->Nout : (d->ldw >= round_up(p.g.taps * d->Kc, e16) || d->ldw >= p.g.taps * d->Kc), "ldw too small");
   p.A = d->A; p.a_f32 = d->a_f32; p.a_sn = d->a_sn; p.a_sd = d->a_sd; p.a_sh = d->a_sh; p.a_sw = d->a_sw; p.a_sc = d->a_sc;
   p.a_coff = d->a_coff; p.Kc_real = d->Kc_real; p.Kc = d->Kc;
   p.W = d->W; p.ldw = d->ldw; p.Nout = d->Nout; p.Ktot = p.g.taps * d->Kc;
@@ -2621,7 +2839,14 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
 #endif
   const bool square = p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 && p.splitk == 1;
   TimedScope ts(square ? IPOKE_TAG_NT_SQUARE : IPOKE_TAG_CONV_BASE, s);
-  rc = dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
+  p.w_kmajor = d->w_kmajor;
+  if (p.w_kmajor) {
+    IPK_REQUIRE(dtype == IPOKE_BF16, "K-major weights: bf16 only (the f32 mode keeps its transposed shadows)");
+    g_last_kernel = IPOKE_KERNEL_IGEMM;
+    rc = dispatch_nn(p, s);
+  } else {
+    rc = dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
+  }
   if (ts.slot >= 0) {          // algorithmic work of this launch (timing runs only)
     const GeomDev& g = p.g;
     const double stride = g.transposed ? (double)g.sd * g.sh * g.sw : 1.0;

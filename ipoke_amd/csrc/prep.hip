@@ -94,8 +94,8 @@ __device__ __forceinline__ void relayout_tile(const RelayoutJob& j, const float*
       *reinterpret_cast<pack_t*>(shadow + j.dstA + off) = o;
     }
   }
-  // B: rows k, columns (tap, n); four consecutive n per thread
-  for (int e = threadIdx.x; e < total / 4; e += 256) {
+  // B: rows k, columns (tap, n); four consecutive n per thread (dstB < 0: the tensor has no transposed operand)
+  for (int e = threadIdx.x; j.dstB >= 0 && e < total / 4; e += 256) {
     const int nl = (e % (TE / 4)) * 4, rest = e / (TE / 4);
     const int t = rest % TAPS, kl = rest / TAPS;
     const int n = n0 + nl, k = k0 + kl;
@@ -342,6 +342,45 @@ __global__ __launch_bounds__(256) void adam_shadow_tile_kernel(float* __restrict
   }
 }
 
+// The same tensors when their data gradient reads the straight copy K-major (flow engine: c2_straight): the ONE operand is the tensor's
+// own cast, so the update is a linear stream -- chunks of 4096 consecutive elements (= the 64 x 64 tiles of the job table, used here only
+// as a prefix sum over the jobs), 16 per thread in four 16-byte groups, all 20 loads issued before the arithmetic; p / m / v / v_max and
+// the bf16 operand leave the registers fully coalesced.  Same arithmetic as adam_amsgrad_kernel (adam_amsgrad_update).
+template <typename T>
+__global__ __launch_bounds__(256) void adam_cast_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ vmax, T* __restrict__ shadow,
+                                                        const AdamTileJob* __restrict__ jobs, int njobs, int chunk_begin, int nchunks, AdamHyper h) {
+  typedef typename RPack4<T>::type pack_t;
+  for (int c = chunk_begin + (int)blockIdx.x; c < chunk_begin + nchunks; c += (int)gridDim.x) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].tile_start <= c) lo = mid; else hi = mid - 1;
+    }
+    const AdamTileJob j = jobs[lo];
+    const long rel = (long)(c - j.tile_start) * 4096 + threadIdx.x * 4;
+    f32x4 pp[4], gg[4], mm[4], vv[4], vx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long i = j.src_off + rel + q * 1024;
+      pp[q] = *reinterpret_cast<const f32x4*>(p + i); gg[q] = *reinterpret_cast<const f32x4*>(g + i);
+      mm[q] = *reinterpret_cast<const f32x4*>(m + i); vv[q] = *reinterpret_cast<const f32x4*>(v + i);
+      vx[q] = *reinterpret_cast<const f32x4*>(vmax + i);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      adam_amsgrad_update4(pp[q], gg[q], mm[q], vv[q], vx[q], h);
+      const long i = j.src_off + rel + q * 1024;
+      *reinterpret_cast<f32x4*>(p + i) = pp[q]; *reinterpret_cast<f32x4*>(m + i) = mm[q];
+      *reinterpret_cast<f32x4*>(v + i) = vv[q]; *reinterpret_cast<f32x4*>(vmax + i) = vx[q];
+      pack_t o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = ET<T>::from_f32(pp[q][k]);
+      *reinterpret_cast<pack_t*>(shadow + j.dstA + rel + q * 1024) = o;
+    }
+  }
+}
+
 // the same update over the gaps between those tensors: segment s0 + blockIdx.y of a table, clipped to [begin, end)
 struct AdamSeg { long off, len; };
 __global__ void adam_amsgrad_seg_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -391,6 +430,28 @@ extern "C" int ipoke_adam_amsgrad_shadow_tiles(float* p, const float* g, float* 
   else
     hipLaunchKernelGGL(adam_shadow_tile_kernel<float>, dim3(grid), dim3(256), 0, s, p, g, m, v, vmax, (float*)shadow,
                        (const AdamTileJob*)jobs_dev, njobs, tile_begin, ntiles, h);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
+/* as ipoke_adam_amsgrad_shadow_tiles for tensors with ONE operand (their own cast in the tensor's order; AdamTileJob.dstB is ignored):
+ * the tile range [tile_begin, tile_begin + ntiles) of the job table is walked as chunks of 4096 consecutive elements */
+extern "C" int ipoke_adam_amsgrad_cast_tiles(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, const void* jobs_dev,
+                                             int njobs, int tile_begin, int ntiles, float lr, float beta1, float beta2, float eps,
+                                             float weight_decay, int step, float grad_scale, int max_blocks, int dtype, void* stream) {
+  IPK_REQUIRE(p && g && m && v && vmax && shadow && jobs_dev && njobs >= 1 && ntiles >= 0 && step >= 1, "bad arguments");
+  IPK_REQUIRE(dtype == IPOKE_BF16 || dtype == IPOKE_F32, "bad dtype");
+  if (ntiles == 0) return IPOKE_OK;
+  const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+  const int cap = max_blocks > 0 ? max_blocks : 4096;
+  const int grid = cap < ntiles ? cap : ntiles;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(adam_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, p, g, m, v, vmax, (bf16_t*)shadow, (const AdamTileJob*)jobs_dev, njobs,
+                       tile_begin, ntiles, h);
+  else
+    hipLaunchKernelGGL(adam_cast_kernel<float>, dim3(grid), dim3(256), 0, s, p, g, m, v, vmax, (float*)shadow, (const AdamTileJob*)jobs_dev, njobs,
+                       tile_begin, ntiles, h);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
