@@ -530,6 +530,20 @@ int ipoke_gru_gates_bwd(const void* ur_pre, const void* h, int ldh, const void* 
  * 1/sigma of spectral norm).  Replaces the reshape/permute/pad/cast chain of nn.Conv2d's weight on every call. */
 int ipoke_conv_weight_operand(const float* w, int cout, int cin, int taps, int transposed, const float* inv_scale, void* out, int kc,
                               int dtype, void* stream);
+/* ---- native unroll of the ConvGRU (csrc/gru.hip) ---------------------------------------------------------------------------------
+ * T steps x L stacked ConvGRU cells on the [B][H][W] latent (reference models/modules/motion_models/rnn.py:4-133 as
+ * SpadeCondMotionModel.forward drives it, models/first_stage_motion_model.py:503-514: every cell starts from the same hidden state, cell 0
+ * sees a constant input), forward and backward, issued back to back by host code of this library.  Replaces the Python loop over
+ * ConvGRUCell.forward and its autograd graph.  Activations are dtype rows [M = B*H*W][ld]; weights fp32 in PyTorch layout, 4 pointers per
+ * cell: w_ur [2Ch][Cx+Ch][3][3] (update gate's rows, then reset gate's), b_ur [2Ch], w_o [Ch][Cx+Ch][3][3], b_o [Ch]. */
+typedef struct { int32_t B, T, L, Cx, Ch, H, W; } ipoke_gru_desc;
+int64_t ipoke_gru_workspace_bytes(const ipoke_gru_desc* d, int dtype);
+/* out [T][M][ldo]: the last cell's hidden state after every step.  The workspace keeps every operand for ipoke_gru_unroll_backward. */
+int ipoke_gru_unroll_forward(const ipoke_gru_desc* d, const void* x0, int ldx, const void* h0, int ldh, const float* const* weights,
+                             void* workspace, void* out, int ldo, int dtype, void* stream);
+/* d_out [T][M][ldo] -> dweights (the layouts of `weights`, written), d_x0 [M][Cx] and d_h0 [M][Ch] (fp32; d_h0 summed over the cells) */
+int ipoke_gru_unroll_backward(const ipoke_gru_desc* d, const void* d_out, int ldo, void* workspace, float* const* dweights, float* d_x0,
+                              float* d_h0, int dtype, void* stream);
 /* ---- frames of a batch of clips decoded as ONE batch (first-stage training, ipoke_conv_desc.row_scale) ----------------------------
  * Backward pass over (dy, y) of a layer  y = act(conv(x, W) * scale[group] + bias)  whose rows are grouped by frame (group of row m =
  * m / rows_per_group; scale[group * scale_stride] = 1 / sigma_t of torch's spectral_norm, util.py:52, 252):

@@ -58,6 +58,10 @@ class NormBwdDesc(Structure):
                 ("mod_samples", c_int32)]
 
 
+class GruDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "T", "L", "Cx", "Ch", "H", "W")]
+
+
 class RowScaleBwdDesc(Structure):
     _fields_ = [("dy", c_void_p), ("lddy", c_int32), ("y", c_void_p), ("ldy", c_int32), ("M", c_int64), ("C", c_int32), ("Cpad", c_int32),
                 ("act", c_int32), ("bias", c_void_p), ("scale", c_void_p), ("scale_stride", c_int32), ("rows_per_group", c_int64),
@@ -108,6 +112,9 @@ SIGNATURES = {
     "ipoke_conv_forward_repeat": (c_int, [POINTER(ConvDesc), c_int, c_int, _P]),
     "ipoke_set_dispatch_override": (c_int, [c_char_p, c_int]),
     "ipoke_last_conv_kernel": (c_int, []),
+    "ipoke_gru_workspace_bytes": (c_int64, [POINTER(GruDesc), c_int]),
+    "ipoke_gru_unroll_forward": (c_int, [POINTER(GruDesc), _P, c_int, _P, c_int, POINTER(c_void_p), _P, _P, c_int, c_int, _P]),
+    "ipoke_gru_unroll_backward": (c_int, [POINTER(GruDesc), _P, c_int, _P, POINTER(c_void_p), _P, _P, c_int, _P]),
     "ipoke_rowscale_bwd_workspace_floats": (c_int64, [c_int64, c_int, c_int64]),
     "ipoke_rowscale_bwd": (c_int, [POINTER(RowScaleBwdDesc), c_int, _P]),
     "ipoke_spectral_bwd_frames": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int64, _P, c_int64, _P, c_int, _P]),

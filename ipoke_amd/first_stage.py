@@ -570,16 +570,33 @@ class SpadeCondMotionModel(nn.Module):
         # clip's start frame.  In evaluation mode (no power iteration between the reference's per-frame calls) the frames are
         # therefore decoded as ONE batch of length x B samples -- 15x fewer launches, and the 8x8 ... 32x32 stages become
         # GEMMs of a useful height (c5: 63.6 -> see DESIGN.md section 7).  Chunked so that row offsets stay below 2^31 elements.
-        hs = []
-        for _ in range(length):
-            hidden = self.rnn.run(in_rnn, hidden)
-            hs.append(hidden[-1])
+        from . import first_stage_train as FT
+        seq = None
+        if FT._GRU_NATIVE and FT.gru_native_ok(self.rnn, in_rnn, m, dt):
+            # the ConvGRU steps issued natively (csrc/gru.hip): one call instead of length x n_layers cells of Python launches
+            weights = []
+            for c in self.rnn.cells:
+                weights += [torch.cat([c.update_gate.weight, c.reset_gate.weight], 0), torch.cat([c.update_gate.bias, c.reset_gate.bias]),
+                            c.out_gate.weight, c.out_gate.bias]
+            geom = (B, length, self.n_layers, in_rnn.C, m.C, m.dhw[1], m.dhw[2])
+            seq, _ = FT.gru_unroll_forward(weights, in_rnn.t.contiguous(), m.t.contiguous(), geom, dt)
+            rows = B * m.S
+        else:
+            hs = []
+            for _ in range(length):
+                hidden = self.rnn.run(in_rnn, hidden)
+                hs.append(hidden[-1])
         size = self.config["data"]["spatial_size"][0]
         per = max(1, min(length, (1 << 30) // max(1, B * size * size * 64)))
         outs = []
         for t0 in range(0, length, per):
-            part = hs[t0:t0 + per]
-            h_all = K.CL(torch.cat([h.t for h in part], 0), B * len(part), part[0].dhw, part[0].C)
+            n = min(per, length - t0)
+            if seq is not None:
+                h_all = K.CL(seq[t0 * rows:(t0 + n) * rows], B * n, m.dhw, m.C)
+            else:
+                part = hs[t0:t0 + per]
+                h_all = K.CL(torch.cat([h.t for h in part], 0), B * len(part), part[0].dhw, part[0].C)
+            part = [None] * n
             y = self.gen.run(h_all, mods, frames=len(part))
             outs.append(y if len(part) > 1 else y.unsqueeze(1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)

@@ -642,6 +642,95 @@ def gru_cell(cell, x, h, dtype, gate_w=None):
     return K.CL(hn, x.N, x.dhw, Ch)
 
 
+_GRU_NATIVE = os.environ.get("IPOKE_GRU_PYTHON", "0") != "1"      # the ConvGRU unroll issued by the library (csrc/gru.hip); 0: cell by cell from Python
+
+
+def gru_native_ok(rnn, x, h, dtype):
+    """The native unroll covers the shipped ConvGRU: 3 x 3 gates, every cell as wide as its input, power-of-two maps."""
+    e = K.e16(dtype)
+    cells = list(rnn.cells)
+    H, W = x.dhw[1], x.dhw[2]
+    return (x.dhw[0] == 1 and H & (H - 1) == 0 and W & (W - 1) == 0 and x.C % e == 0 and h.C % e == 0 and len(cells) <= 16
+            and all(c.hidden == h.C and c.cin == (x.C if i == 0 else h.C) and c.update_gate.k == (1, 3, 3) and c.out_gate.k == (1, 3, 3)
+                    and c.update_gate.pad == (0, 1, 1) and c.update_gate.bias is not None and c.out_gate.bias is not None
+                    for i, c in enumerate(cells))
+            and (len(cells) == 1 or x.C == h.C))
+
+
+def _gru_desc(B, T, L, Cx, Ch, H, W):
+    d = _lib.GruDesc()
+    d.B, d.T, d.L, d.Cx, d.Ch, d.H, d.W = B, T, L, Cx, Ch, H, W
+    return d
+
+
+def gru_unroll_forward(weights, x0_t, h0_t, geom, dtype):
+    """ipoke_gru_unroll_forward: ``weights`` = per cell (w_ur, b_ur, w_o, b_o) fp32; returns (out [T * M, ld], workspace)."""
+    import ctypes
+    B, T, L, Cx, Ch, H, W = geom
+    d = _gru_desc(*geom)
+    lib = _lib.lib()
+    nbytes = int(lib.ipoke_gru_workspace_bytes(byref(d), ops._dt(dtype)))
+    if nbytes < 0:
+        raise RuntimeError("ConvGRU geometry not supported by the native unroll")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x0_t.device)
+    ldo = K.round_up(Ch, K.e16(dtype))
+    out = torch.zeros(T * B * H * W, ldo, dtype=_tdt(dtype), device=x0_t.device) if ldo > Ch else torch.empty(T * B * H * W, ldo, dtype=_tdt(dtype),
+                                                                                                             device=x0_t.device)
+    w32 = [w.detach().float().contiguous() for w in weights]
+    arr = (ctypes.c_void_p * len(w32))(*[w.data_ptr() for w in w32])
+    check(lib.ipoke_gru_unroll_forward(byref(d), ptr(x0_t), x0_t.shape[1], ptr(h0_t), h0_t.shape[1], arr, ptr(ws), ptr(out), ldo, ops._dt(dtype),
+                                       _lib.current_stream()))
+    return out, ws
+
+
+class _GruUnrollFn(torch.autograd.Function):
+    """All T steps of the stacked ConvGRU (rnn.py:59-133 as first_stage_motion_model.py:503-514 drives it) as ONE autograd node whose two
+    directions are issued natively (csrc/gru.hip): (x0 [M, ld], h0 [M, ld], per cell w_ur, b_ur, w_o, b_o) -> the last cell's hidden states of
+    all steps, [T * M, ld] ordered (step, clip) -- the batch the frame-batched decoder consumes."""
+
+    @staticmethod
+    def forward(ctx, x0_t, h0_t, geom, dtype, *weights):
+        out, ws = gru_unroll_forward(weights, x0_t.contiguous(), h0_t.contiguous(), geom, dtype)
+        ctx.geom, ctx.dtype = geom, dtype
+        ctx.shapes = (tuple(x0_t.shape), tuple(h0_t.shape))
+        ctx.save_for_backward(ws, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        import ctypes
+        ws, *weights = ctx.saved_tensors
+        B, T, L, Cx, Ch, H, W = ctx.geom
+        dt = ctx.dtype
+        M = B * H * W
+        ldo = K.round_up(Ch, K.e16(dt))
+        g = d_out.contiguous()
+        if g.dtype != _tdt(dt) or g.shape[1] != ldo:
+            g = _pad_cols(g[:, :min(g.shape[1], ldo)], ldo, dt)
+        dws = [torch.empty(w.shape, dtype=torch.float32, device=g.device) for w in weights]
+        d_x0 = torch.empty(M, Cx, dtype=torch.float32, device=g.device)
+        d_h0 = torch.empty(M, Ch, dtype=torch.float32, device=g.device)
+        arr = (ctypes.c_void_p * len(dws))(*[w.data_ptr() for w in dws])
+        d = _gru_desc(*ctx.geom)
+        check(_lib.lib().ipoke_gru_unroll_backward(byref(d), ptr(g), ldo, ptr(ws), arr, ptr(d_x0), ptr(d_h0), ops._dt(dt), _lib.current_stream()))
+        (sx, sh) = ctx.shapes
+        return _pad_cols(d_x0, sx[1], dt), _pad_cols(d_h0, sh[1], dt), None, None, *dws
+
+
+def gru_unroll(rnn, in_rnn, h0, steps, dtype, gate_w=None):
+    """ConvGRU.run over ``steps`` steps from the shared initial state ``h0`` with the constant input ``in_rnn`` (differentiable):
+    CL of steps * B images ordered (step, clip)."""
+    cells = list(rnn.cells)
+    if gate_w is None:
+        gate_w = [gru_gate_weights(c) for c in cells]
+    weights = []
+    for c, (w_ur, b_ur) in zip(cells, gate_w):
+        weights += [w_ur, b_ur, c.out_gate.weight, c.out_gate.bias]
+    geom = (in_rnn.N, steps, len(cells), in_rnn.C, h0.C, in_rnn.dhw[1], in_rnn.dhw[2])
+    out = _GruUnrollFn.apply(in_rnn.t, h0.t, geom, dtype, *weights)
+    return K.CL(out, steps * in_rnn.N, in_rnn.dhw, h0.C)
+
+
 # ------------------------------------------------------------------------------------------------ latent
 class _ReparamFn(torch.autograd.Function):
     @staticmethod
@@ -831,7 +920,8 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
     batched = _FRAME_BATCH and mods is not None and T > 2 and B * (T - 1) * X.shape[-1] * X.shape[-2] * 64 < (1 << 31)
     sn_pre = precompute_power_iterations(model.gen, T - 1) if (pit and (_SN_AHEAD or batched)) else []
     hs = []
-    for t in range(T - 1):
+    native_gru = batched and _GRU_NATIVE and gru_native_ok(model.rnn, in_rnn, m, dt)
+    for t in range(0 if native_gru else T - 1):
         xin = in_rnn
         new_hidden = []
         for cell, gw, h in zip(model.rnn.cells, gate_w, hidden):
@@ -847,7 +937,10 @@ def first_stage_forward_loss(model, X, eps, w_l1=10.0, w_kl=1e-7, power_iteratio
         frames.append(frame.view(B, pre.dhw[1], pre.dhw[2], 3).permute(0, 3, 1, 2))
     if batched:
         # the ConvGRU is sequential in time, the decoder is not: ONE pass over the (frame, clip)-ordered batch of all T - 1 frames
-        h_all = K.CL(torch.cat([h.t for h in hs], 0), B * (T - 1), hs[0].dhw, hs[0].C)
+        if native_gru:       # the T - 1 steps x n_layers cells issued by the library, one autograd node
+            h_all = gru_unroll(model.rnn, in_rnn, m, T - 1, dt, gate_w)
+        else:
+            h_all = K.CL(torch.cat([h.t for h in hs], 0), B * (T - 1), hs[0].dhw, hs[0].C)
         pre = decode_frame(model.gen, h_all, x0, dt, pit, mods, frames=T - 1)
         tgt = X[:, 1:].transpose(0, 1).reshape(B * (T - 1), *X.shape[2:])           # targets in the same (frame, clip) order (one copy)
         l1, frame = _L1TanhFn.apply(pre.t, tgt, 1.0 / n_out)

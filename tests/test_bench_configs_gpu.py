@@ -57,18 +57,50 @@ def full_flow(g, z, dtype, max_batch):
     return m.train()
 
 
+_GRAD_PLAN = {}
+
+
 def grad_errors(m, g, every=1):
-    """worst checksum error over the parameter tensors: |sum - ref| / abs-sum, sampled elements / (50 x mean |grad|)"""
+    """worst checksum error over the parameter tensors: |sum - ref| / abs-sum, sampled elements / (50 x mean |grad|).
+    The gradients are views of ONE flat buffer: the 2 940 sums / abs-sums come from two float64 prefix sums over it and the sampled
+    elements from one gather -- a single transfer per call instead of 2 940 (the per-tensor loop was most of the test's wall time)."""
     names, ref = g["grad_names"].tolist(), g["grad_checksums"]
     grads = dict(m.named_parameters())
+    flat = m.flat_grads
+    key = (int(m.engine.n_params), len(names), every)          # the offsets depend on the topology only
+    plan = _GRAD_PLAN.get(key)
+    if plan is None:
+        sel = list(range(0, len(names), every))
+        offs, nums, samp = [], [], []
+        for i in sel:
+            gr = grads[names[i]].grad
+            off = (gr.data_ptr() - flat.data_ptr()) // 4
+            assert gr.is_contiguous() and 0 <= off and off + gr.numel() <= flat.numel(), names[i]
+            idx = torch.randint(0, gr.numel(), (3,), generator=torch.Generator().manual_seed(zlib.crc32(names[i].encode())))
+            offs.append(off); nums.append(gr.numel()); samp.append(off + idx)
+        plan = _GRAD_PLAN[key] = (sel, torch.tensor(offs, device=flat.device), torch.tensor(nums, device=flat.device),
+                                  torch.stack(samp).to(flat.device), nums)
+        if len(_GRAD_PLAN) > 4:
+            _GRAD_PLAN.pop(next(iter(_GRAD_PLAN)))
+    sel, offs, nums, samp, nums_host = plan
+    f64 = flat.detach().double()
+    zero = torch.zeros(1, dtype=torch.float64, device=flat.device)
+    c1 = torch.cat([zero, f64.cumsum(0)])
+    sums = c1[offs + nums] - c1[offs]
+    del c1
+    c2 = torch.cat([zero, f64.abs().cumsum(0)])
+    asums = c2[offs + nums] - c2[offs]
+    del c2
+    vals = f64[samp.flatten()].view(-1, 3)
+    got = torch.cat([sums[:, None], asums[:, None], vals], 1).cpu().numpy()
     worst, worst_key = 0.0, None
-    for i in range(0, len(names), every):
-        k = names[i]
-        cs = checksum(grads[k].grad, k)
-        scale = max(ref[i][1] / grads[k].numel(), 1e-9)
+    for row, i in enumerate(sel):
+        cs = got[row]
+        scale = max(ref[i][1] / nums_host[row], 1e-9)
+        # (prefix-sum differences of float64: absolute rounding ~1e-16 x the buffer's running total -- far below the tolerances)
         err = max(abs(cs[0] - ref[i][0]) / max(ref[i][1], 1e-9), np.abs(cs[2:] - ref[i][2:]).max() / (scale * 50))
         if err > worst:
-            worst, worst_key = err, k
+            worst, worst_key = err, names[i]
     return worst, worst_key
 
 

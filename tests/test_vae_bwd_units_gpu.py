@@ -221,3 +221,46 @@ def test_wgrad_launch_modes_match_single_launch(mode):
     assert _rel(got, ref) <= 1e-5
     if mode == "slabs":
         assert torch.equal(run(splitm=8, slabs=True), got)       # deterministic
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,T,L,Z", [(2, 5, 3, 32), (3, 4, 4, 64), (1, 1, 1, 16)])
+def test_native_gru_unroll_vs_autograd(B, T, L, Z, dtype):
+    """ipoke_gru_unroll_forward / _backward (csrc/gru.hip: T steps x L stacked cells, the concatenations written in place by the producer
+    kernels, one weight-gradient GEMM per convolution over all steps) against the oracle's ConvGRU unrolled under torch autograd exactly
+    as SpadeCondMotionModel.forward drives it (first_stage_motion_model.py:503-514: every cell starts from the motion code, cell 0 sees a
+    constant input): the output sequence, d input, d initial state and every weight / bias gradient."""
+    from ipoke_amd.first_stage import ConvGRU
+    from oracle import vae_ref
+    gen = torch.Generator().manual_seed(B * 100 + T * 10 + L)
+    rnn = ConvGRU(Z, Z, 3, L, dtype=dtype).to(DEV)
+    with torch.no_grad():
+        for p in rnn.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * (0.3 if p.dim() == 1 else 1.5 / (9 * 2 * Z) ** 0.5))
+    ref = vae_ref.ConvGRU(Z, Z, L)
+    ref.load_state_dict({k: v.cpu() for k, v in rnn.state_dict().items()})
+    x = torch.randn(B, Z, 8, 8, generator=gen, requires_grad=True)
+    h0 = torch.randn(B, Z, 8, 8, generator=gen, requires_grad=True)
+    hidden = [h0] * L
+    outs = []
+    for _ in range(T):
+        hidden = ref(x, hidden)
+        outs.append(hidden[-1])
+    seq = torch.stack(outs, 0)                                        # [T, B, Z, 8, 8]
+    dseq = torch.randn(seq.shape, generator=gen)
+    seq.backward(dseq)
+    xc, hc = _cl(x.detach(), dtype), _cl(h0.detach(), dtype)
+    xc.t.requires_grad_(True); hc.t.requires_grad_(True)
+    assert FT.gru_native_ok(rnn, xc, hc, dtype)
+    out = FT.gru_unroll(rnn, xc, hc, T, dtype)
+    assert out.N == T * B and out.t.shape[0] == T * B * 64
+    tol = TOL[dtype] * (1 if dtype == "f32" else 1.5)
+    got = _nchw(out, dtype).view(T, B, Z, 8, 8)
+    assert _rel(got.detach(), seq.detach()) <= tol
+    dcl = _cl(dseq.view(T * B, Z, 8, 8), dtype)
+    out.t.backward(dcl.t)
+    assert _rel(_nchw(K.CL(xc.t.grad, B, (1, 8, 8), Z), dtype), x.grad) <= tol * 4
+    assert _rel(_nchw(K.CL(hc.t.grad, B, (1, 8, 8), Z), dtype), h0.grad) <= tol * 4
+    for (k, p), (k2, q) in zip(rnn.named_parameters(), ref.named_parameters()):
+        e = _rel(p.grad.cpu(), q.grad)
+        assert k == k2 and e <= tol * 6, (k, e)
