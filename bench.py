@@ -66,7 +66,7 @@ def randomise_couplings(model, seed=0):
     model.flow.mark_weights_updated()
 
 
-PMC_ROUND = "r03"          # the committed PMC passes roofline.traffic is read from (NOT measured by this run: see traffic_source)
+PMC_ROUND = "r04"          # the committed PMC passes roofline.traffic is read from (NOT measured by this run: see traffic_source)
 
 
 def pmc_traffic(kernel_substr, grid_size):

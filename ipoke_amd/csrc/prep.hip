@@ -389,16 +389,38 @@ __global__ void adam_amsgrad_seg_kernel(float* __restrict__ p, const float* __re
   const AdamSeg sg = segs[s0 + blockIdx.y];
   const long lo = sg.off > begin ? sg.off : begin, hi = sg.off + sg.len < end ? sg.off + sg.len : end;
   const long stride = (long)gridDim.x * blockDim.x * 4;
-  for (long i = lo + ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < hi; i += stride) {
-    if (i + 3 < hi) {
-      f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
-      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
-      f32x4 vx = *reinterpret_cast<f32x4*>(vmax + i);
-      adam_amsgrad_update4(pp, gg, mm, vv, vx, h);
-      *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm;
-      *reinterpret_cast<f32x4*>(v + i) = vv; *reinterpret_cast<f32x4*>(vmax + i) = vx;
-    } else {
-      for (long k = i; k < hi; ++k) adam_amsgrad_update(p[k], g[k], m[k], v[k], vmax[k], h);
+  // four 16-byte groups per thread and iteration, all 20 loads issued before the arithmetic: with one group in flight the few blocks a
+  // segment gets underneath the backward pass streamed at 1.8 TB/s (profiles/r04_bench_steady.txt: 310 us for the 27 % of a piece)
+  for (long i0 = lo + ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < hi; i0 += 4 * stride) {
+    if (i0 + 3 * stride + 3 < hi) {
+      f32x4 pp[4], gg[4], mm[4], vv[4], vx[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long i = i0 + q * stride;
+        pp[q] = *reinterpret_cast<f32x4*>(p + i); gg[q] = *reinterpret_cast<const f32x4*>(g + i);
+        mm[q] = *reinterpret_cast<f32x4*>(m + i); vv[q] = *reinterpret_cast<f32x4*>(v + i); vx[q] = *reinterpret_cast<f32x4*>(vmax + i);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long i = i0 + q * stride;
+        adam_amsgrad_update4(pp[q], gg[q], mm[q], vv[q], vx[q], h);
+        *reinterpret_cast<f32x4*>(p + i) = pp[q]; *reinterpret_cast<f32x4*>(m + i) = mm[q];
+        *reinterpret_cast<f32x4*>(v + i) = vv[q]; *reinterpret_cast<f32x4*>(vmax + i) = vx[q];
+      }
+      continue;
+    }
+    for (int q = 0; q < 4; ++q) {
+      const long i = i0 + q * stride;
+      if (i + 3 < hi) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+        f32x4 vx = *reinterpret_cast<f32x4*>(vmax + i);
+        adam_amsgrad_update4(pp, gg, mm, vv, vx, h);
+        *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm;
+        *reinterpret_cast<f32x4*>(v + i) = vv; *reinterpret_cast<f32x4*>(vmax + i) = vx;
+      } else {
+        for (long k = i; k < hi; ++k) adam_amsgrad_update(p[k], g[k], m[k], v[k], vmax[k], h);
+      }
     }
   }
 }

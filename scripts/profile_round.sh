@@ -1,7 +1,7 @@
 # Round profile: kernel traces (+ stats, queue gaps, chain / side-stream overlap), PMC passes (separate runs), bench lines.
 # Usage on the GPU box:  bash scripts/profile_round.sh r03
 set -x
-RN=${1:-r03}
+RN=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${RN}
@@ -11,10 +11,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c2 -- python $R/b
 cp $(find /tmp/p_c2 -name "*kernel_stats.csv" | head -1) $O/${RN}_bench_kernel_stats.csv
 python $R/scripts/trace_gaps.py $(find /tmp/p_c2 -name "*kernel_trace.csv" | head -1) > $O/${RN}_bench_trace_gaps.txt 2>&1
 python $R/scripts/trace_overlap.py $(find /tmp/p_c2 -name "*kernel_trace.csv" | head -1) > $O/${RN}_bench_overlap.txt 2>&1
+python $R/scripts/trace_steady.py $(find /tmp/p_c2 -name "*kernel_trace.csv" | head -1) flow_nll 6 > $O/${RN}_bench_steady.txt 2>&1
 # PMC passes (separate runs, counters only)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_$c.log 2>&1
-  python $R/scripts/pmc_summary.py $(find /tmp/p_$c -name "*counter_collection.csv" | head -1) $O/${RN}_bench_pmc_$c.json igemm_nt_glds igemm_tn_glds conv3x3_s8 macow_unit adam_amsgrad relayout
+  python $R/scripts/pmc_summary.py $(find /tmp/p_$c -name "*counter_collection.csv" | head -1) $O/${RN}_bench_pmc_$c.json igemm_nt_glds igemm_nn_glds igemm_tn_glds conv3x3_s8 macow_unit adam_amsgrad adam_cast relayout
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/p_sq -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_sq.log 2>&1
 python $R/scripts/pmc_summary.py $(find /tmp/p_sq -name "*counter_collection.csv" | head -1) $O/${RN}_bench_pmc_SQ.json igemm_nt_glds igemm_tn_glds conv3x3_s8 macow_unit adam_amsgrad
