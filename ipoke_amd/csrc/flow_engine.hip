@@ -397,7 +397,10 @@ int build(ipoke_flow& f) {
   static const bool noan = getenv("IPOKE_NO_AN_FUSION") != nullptr;     // developer A/B
   for (size_t i = 0; !noan && i + 1 < f.ops.size(); ++i) {
     Op& a = f.ops[i]; Op& b2 = f.ops[i + 1];
-    if (a.type == OP_NICE && b2.type == OP_ACTNORM && !b2.fused && b2.unit_of < 0 && b2.Cn <= 256) { a.an_next = (int)i + 1; b2.an_prev = (int)i; }
+    // (the pair kernels stage whole rows of a sample: ipoke_actnorm_affine_bwd needs P * ld <= 8192 floats of LDS)
+    if (a.type == OP_NICE && b2.type == OP_ACTNORM && !b2.fused && b2.unit_of < 0 && b2.Cn <= 256 && f.P * c.z_channels <= 8192) {
+      a.an_next = (int)i + 1; b2.an_prev = (int)i;
+    }
   }
   static const bool noxop = getenv("IPOKE_NO_MCF_XOP") != nullptr;      // developer A/B
   f.mcf_xop = c.dtype == IPOKE_BF16 && !noxop;
@@ -526,7 +529,9 @@ int nice_splitk(const Ctx& c) { return max_splitk(*c.f, c.B); }
 // (IPOKE_NO_UNIT_ZC=1: a launch of ipoke_extract_cols instead, as in rounds 1-2)
 bool unit_feeds(const ipoke_flow* f, size_t i) {
   static const int on = getenv("IPOKE_NO_UNIT_ZC") ? 0 : 1;
-  return on && i >= 6 && i < f->ops.size() && f->ops[i].type == OP_NICE && f->ops[i - 6].unit_head;
+  if (!(on && i >= 6 && i < f->ops.size() && f->ops[i].type == OP_NICE && f->ops[i - 6].unit_head)) return false;
+  const Op& nx = f->ops[i];          // the unit kernel gathers the conditioning columns from ITS state tile: they must lie inside its C channels
+  return nx.z_off + (nx.cin - 1) * nx.z_stride < f->ops[i - 6].C && nx.Kc1 % 2 == 0;
 }
 bool nice_feeds(const Op& a, const Op& b) {
   static const int on = getenv("IPOKE_NO_EXTRACT_FUSION") ? 0 : 1;

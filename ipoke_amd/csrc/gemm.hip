@@ -1027,6 +1027,20 @@ static int set_lds(KernelT k, size_t bytes) {
   IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return IPOKE_OK;
 }
+// Dynamic LDS a workgroup may ask for on this device (queried once): the stationary-input kernels are only dispatched when their buffers
+// fit, so that a smaller part falls back to the generic kernels instead of failing in hipFuncSetAttribute.
+static size_t device_max_lds() {
+  static std::once_flag once; static size_t bytes = 0;
+  std::call_once(once, []() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) bytes = (size_t)v;
+    else bytes = 64 * 1024;
+  });
+  return bytes;
+}
+constexpr size_t kLdsC64 = 9 * 64 * 128 + 2 * 41 * 1024 + 1024, kLdsHalo16 = 2 * 41 * 1024 + 4 * 128 * 128 + 8 * 1024,
+                 kLdsHalo = 2 * 24 * 1024 + 12 * 64 * 128 + 8 * 1024, kLdsS8 = 2 * 128 * 128 + 256 + 12 * 64 * 128 + 512 * 16;
+
 // The dynamic-LDS attribute of a kernel is set once per process, race-free (the header promises thread safety for launches on
 // distinct streams): one std::once_flag + result per expansion site, i.e. per kernel (template instantiation).
 #define IPK_SET_LDS_ONCE(kern, bytes) do {                                              \
@@ -1953,11 +1967,11 @@ static bool c64_applicable(const NtParams& p) {
                    (p.Kc == 64 || p.Kc == 128) && p.Kc_real == p.Kc && g.khw * nch <= 9 && (g.khw > 1 || p.c_scatter) && p.Nout <= 64 && (p.a_coff & 7) == 0 &&
                    p.ldw >= p.Ktot && (p.ldw & 7) == 0 && p.splitk == 1 && !p.c_acc && ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && p.n_pad <= 64 &&
                    (reinterpret_cast<uintptr_t>(p.W) & 15) == 0;
-  if (!can) return false;
+  if (!can || kLdsC64 > device_max_lds()) return false;
   return mode == 2 || g.M / 256 >= 512;
 }
 static int launch_conv3x3_c64(NtParams& p, hipStream_t s) {
-  const size_t lds = 9 * 64 * 128 + 2 * 41 * 1024 + 1024;
+  const size_t lds = kLdsC64;
   auto kern = conv3x3_c64_kernel;
   IPK_SET_LDS_ONCE(kern, lds);
   const int ntiles = p.g.M / 256;
@@ -1978,7 +1992,7 @@ static bool halo16_applicable(const NtParams& p) {
                    p.Kc % 64 == 0 && p.Kc_real == p.Kc && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot && p.splitk == 1 && !p.c_acc &&
                    ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 &&
                    (long)(g.M / g.S) * p.a_sn + (long)g.Di * p.a_sd + (long)g.Hi * p.a_sh + p.Kc < (1L << 31) && (long)p.Nout * p.ldw < (1L << 31);
-  if (!can) return false;
+  if (!can || kLdsHalo16 > device_max_lds()) return false;
   if (mode == 2) return true;
   // Measured (scripts/probe_halo16.py, B = 20, against the kernels used before): 128 -> 128 channels on 4 x 64 x 64: 304 vs 485 us;
   // 64 -> 128, depth stride 2, 8 x 64 x 64: 175 vs 302; 2-D 128 -> 128 on 64 x 64 at B = 32: 52 vs 73 -- but 256 -> 256 on
@@ -1991,7 +2005,7 @@ static bool halo16_applicable(const NtParams& p) {
   return (deep ? p.Kc >= 64 : p.Kc >= 128) && p.Nout >= 96 && wgs >= 256 && (wgs * 10 >= rounds * 256 * 8 || (shallow && wgs * 10 >= rounds * 256 * 6));
 }
 static int launch_conv3x3_halo16(NtParams& p, hipStream_t s) {
-  const size_t lds = 2 * 41 * 1024 + 4 * 128 * 128 + 8 * 1024;
+  const size_t lds = kLdsHalo16;
   auto kern = conv3x3_halo16_kernel;
   IPK_SET_LDS_ONCE(kern, lds);
   p.tiles_m = p.g.M / 256; p.tiles_n = ceil_div(p.Nout, 128); p.xa = p.xb = 0;
@@ -2007,7 +2021,7 @@ static bool halo_applicable(const NtParams& p) {
   static const int on3 = getenv("IPOKE_HALO3D") ? atoi(getenv("IPOKE_HALO3D")) : 1;    // the 3 x 3 x 3 form alone
   const bool flat = g.taps == 9 && g.Di == 1 && g.Do == 1 && g.pd == 0;
   const bool deep = on3 && g.taps == 27 && g.Di == g.Do && g.pd == 1 && (p.a_sd & 7) == 0;
-  if (!(flat || deep) || p.c_scatter) return false;
+  if (!(flat || deep) || p.c_scatter || kLdsHalo > device_max_lds()) return false;
   if (deep) {     // measured (scripts/probe_halo3d.py, B = 20): 64 channels 16x64x64: 670 vs 997 us, 12x32x32: 126 vs 185 us; but 128
                   // channels 8x32x32: 271 vs 230, 256 channels 4x16x16: 141 vs 101, 512 channels: 255 vs 177 -> 64 input channels only
     if (p.Kc > 64) return false;
@@ -2027,7 +2041,7 @@ static bool halo_applicable(const NtParams& p) {
          (p.Kc <= 64 || g.Ho * g.Wo <= 256);
 }
 static int launch_conv3x3_halo(NtParams& p, hipStream_t s) {
-  const size_t lds = 2 * 24 * 1024 + 12 * 64 * 128 + 8 * 1024;
+  const size_t lds = kLdsHalo;
   auto kern = conv3x3_halo_kernel;
   IPK_SET_LDS_ONCE(kern, lds);
   p.tiles_m = p.g.M / 128; p.tiles_n = ceil_div(p.Nout, 64); p.xa = p.xb = 0;
@@ -2101,7 +2115,7 @@ static int s8_samples_per_tile() {
 }
 static bool s8_applicable(const NtParams& p) {
   const GeomDev& g = p.g;
-  return s8_samples_per_tile() > 0 && !p.c_scatter && !p.a_f32 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Hi == 8 && g.Wi == 8 &&
+  return s8_samples_per_tile() > 0 && kLdsS8 <= device_max_lds() && !p.c_scatter && !p.a_f32 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Hi == 8 && g.Wi == 8 &&
          g.lDo == 0 && g.lHo == 3 && g.lWo == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 1 && g.pw == 1 &&
          p.Kc % 64 == 0 && p.Kc_real == p.Kc && p.Kc >= 256 && p.Nout <= 64 && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot &&
          ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && (long)(g.M >> 6) * p.a_sn + 7 * p.a_sh + 7 * p.a_sw + p.Kc < (1L << 31) &&

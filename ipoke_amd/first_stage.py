@@ -638,7 +638,13 @@ class SpadeCondMotionModel(nn.Module):
             self.logged["val/vgg_loss"] = self.vgg_loss(tgt.reshape(-1, *X.shape[2:]), X_hat.reshape(-1, *X_hat.shape[2:]))
         from . import metrics
         both = metrics.psnr_ssim(X_hat.reshape(-1, *X_hat.shape[2:]), tgt.reshape(-1, *X_hat.shape[2:]))
-        self.logged["ssim-val"], self.logged["psnr-val"] = both[1], both[0]
+        # logged with on_epoch=True in the reference: the epoch value is the mean over the validation batches (running sums on the device)
+        acc = self.__dict__.setdefault("_val_metric_acc", [0, None, None])
+        acc[0] += 1
+        acc[1] = both[1] if acc[1] is None else acc[1] + both[1]
+        acc[2] = both[0] if acc[2] is None else acc[2] + both[0]
+        self.logged["ssim-val"], self.logged["psnr-val"] = acc[1] / acc[0], acc[2] / acc[0]
+        self.logged["ssim-val_step"], self.logged["psnr-val_step"] = both[1], both[0]
         if getattr(self, "FVD", None) is not None and batch_id <= int(self.config["logging"]["n_samples_fvd"] / X_hat.size(0)):
             self.features_fvd_fake.append(X_hat)
             self.features_fvd_true.append(tgt)
@@ -654,6 +660,7 @@ class SpadeCondMotionModel(nn.Module):
         self.logged["FVD-val"], self.logged["FVD-val-x0"] = fvd, fvd_x0
         for lst in (self.features_fvd_fake, self.features_fvd_true, self.fvd_features_fake_x0, self.fvd_features_true_x0):
             lst.clear()
+        self.__dict__.pop("_val_metric_acc", None)          # the next epoch's ssim-val / psnr-val means start afresh
         return fvd, fvd_x0
 
     def training_loss(self, X, eps, w_l1=10.0, w_kl=1e-7, power_iteration=None):

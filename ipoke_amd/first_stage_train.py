@@ -65,6 +65,7 @@ def _pad_cols(t, ld, dtype):
 _OPCACHE = {}
 _SN_AHEAD = os.environ.get("IPOKE_NO_SN_AHEAD", "0") != "1"            # developer A/B: one power iteration per decoder call, at the call
 _HOIST_SPADE = os.environ.get("IPOKE_NO_SPADE_HOIST", "0") != "1"      # developer A/B: per-frame SPADE maps as the reference computes them
+_SPADE_DENSE_INPUT = os.environ.get("IPOKE_SPADE_F32_INPUT", "0") != "1"   # developer A/B: the SPADE branch reads the resized fp32 start frame in place
 _FRAME_BATCH = os.environ.get("IPOKE_C4_PER_FRAME", "0") != "1"         # all generated frames decoded as ONE batch (module docstring); 0: frame by frame
 
 
@@ -860,8 +861,15 @@ def res_block(blk, x, dtype, pit=False, frames=None):
 def spade_modulation(sp, y_nchw, size, dtype):
     N = y_nchw.shape[0]
     ycl = K.bilinear_cl(y_nchw, size)
-    st = (size[0] * size[1] * 3, 1, 0, size[1] * 3, 3)
-    h = conv(sp.conv, None, dtype, act=_lib.ACT_LRELU02, src=(ycl, N, 3, (1, size[0], size[1]), st))
+    if _SPADE_DENSE_INPUT:
+        # the resized start frame as dense channels-last pixels of the compute dtype, zero padded to one 16-byte chunk: the same rounding the
+        # in-place fp32 read applies on load, but the convolution and -- above all -- its weight gradient run on the LDS-DMA kernels instead
+        # of the register-staged fp32-source ones (4 x ~400 us per c4 step for 2.3 GFLOP each)
+        x = K.CL(_pad_cols(ycl, K.e16(dtype), dtype), N, (1, size[0], size[1]), 3)
+        h = conv(sp.conv, x, dtype, act=_lib.ACT_LRELU02)
+    else:
+        st = (size[0] * size[1] * 3, 1, 0, size[1] * 3, 3)
+        h = conv(sp.conv, None, dtype, act=_lib.ACT_LRELU02, src=(ycl, N, 3, (1, size[0], size[1]), st))
     return conv(sp.conv_gamma, h, dtype), conv(sp.conv_beta, h, dtype)
 
 

@@ -21,6 +21,7 @@ from ._lib import check, ptr
 # of the arithmetic; 20.0 ms without), and the train step 62.1-62.2 ms against 61.8 ms (scripts/probe_adam.py).  Off by default.
 _FUSE_DEFAULT = os.environ.get("IPOKE_ADAM_FUSION", "0") == "1"
 _FUSE_SHADOWS = _FUSE_DEFAULT
+_NATIVE_BLOCKS = int(os.environ.get("IPOKE_NATIVE_ADAM_BLOCKS", "128"))      # developer A/B: persistent grid of the engine-issued update underneath backward
 _TILE_BLOCKS = int(os.environ.get("IPOKE_ADAM_TILE_BLOCKS", "128"))     # developer A/B: persistent grid of the fused tile kernel underneath backward
 
 
@@ -157,7 +158,7 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         self._covered += n
 
     # ---- native piecewise step: the engine applies the update of every piece itself (single process) ------------------
-    def arm_native(self, grad_scale=1.0, max_blocks=128):
+    def arm_native(self, grad_scale=1.0, max_blocks=_NATIVE_BLOCKS):
         """Hand this step's update to the engine: ``ipoke_flow_backward_pieces`` then queues the Adam-amsgrad update and the shadow
         refresh of every piece on the ready stream as soon as the piece is final (ipoke_flow_set_native_adam) -- the launches of
         ``step_range`` without the host callback between the chain's kernels.  Call after ``begin_step``; ``finish_native`` after
@@ -179,6 +180,10 @@ class FusedAdamAmsgrad(torch.optim.Optimizer):
         if self._covered != self.flow.flat_params.numel():
             raise RuntimeError(f"piecewise optimizer step covered {self._covered} of {self.flow.flat_params.numel()} parameters")
         self.flow.engine.shadow_stale = False       # every slice refreshed its shadows right after its update
+        # a replicated checkpoint loaded into the sharded optimizer is only a source for the shards (_shard_state): after one full step
+        # every shard has been cut out of it -- release the 3 x P floats (they would undo ZeRO-1's 3P / world saving)
+        if getattr(self, "_full_state", None) is not None and getattr(self, "_shards", None) is not None:
+            self._full_state = None
 
     def _groups(self):
         return [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]

@@ -468,12 +468,15 @@ class PokeMotionModel(nn.Module):
             loss, loss_dict = self.loss_func(out, logdet)
         self.log_dict({"val/" + key: loss_dict[key] for key in loss_dict})
         X = batch["images"]
-        if getattr(self, "FVD", None) is not None and batch_id <= int(self.config["logging"]["n_fvd_samples"] / X.size(0)):
+        # second_stage_video.py:498-513: the sampled clips and ssim / psnr of every batch below the FVD sample budget, whether or not an
+        # I3D is attached; only the clip lists kept for the epoch's FVD need the FVD object
+        if batch_id <= int(self.config["logging"]["n_fvd_samples"] / X.size(0)):
             X_hat = self.forward_sample(batch, n_logged_vids=X.size(0))[0].to(X.device)
-            self._fvd_fake.append(X_hat)
-            self._fvd_true.append(X[:, 1:])
-            self._fvd_fake_x0.append(torch.cat([X[:, 0].unsqueeze(1), X_hat], dim=1))
-            self._fvd_true_x0.append(X)
+            if getattr(self, "FVD", None) is not None:
+                self._fvd_fake.append(X_hat)
+                self._fvd_true.append(X[:, 1:])
+                self._fvd_fake_x0.append(torch.cat([X[:, 0].unsqueeze(1), X_hat], dim=1))
+                self._fvd_true_x0.append(X)
             from . import metrics
             X_hat_log = X_hat.reshape(-1, *X_hat.shape[2:]).type_as(X)
             X_log = X[:, 1:].reshape(-1, *X_hat.shape[2:])

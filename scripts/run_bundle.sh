@@ -1,10 +1,5 @@
-set -x
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4m
-mkdir -p $O
-cd $R && timeout 900 python -m pytest tests/test_flow_gpu.py tests/test_full_gpu.py -q -x 2>&1 | tail -4 > $O/tests.txt; cat $O/tests.txt
-cd /tmp
-B="python $R/bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-secondary"
-for i in 1 2 3; do $B 2>$O/err.txt | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c2', d['ms_per_step'], d['ms_per_step_median'], d['loss'], d['roofline']['traffic'])" >> $O/ab.txt; done
-cat $O/ab.txt
+mkdir -p gpurun_out/fin
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -22 > gpurun_out/fin/tests.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > gpurun_out/fin/smoke.txt
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/fin/bench.err | tail -1 > gpurun_out/fin/bench_line.json
+cat gpurun_out/fin/tests.txt gpurun_out/fin/smoke.txt; tail -c 400 gpurun_out/fin/bench_line.json

@@ -190,7 +190,7 @@ def test_first_stage_validation_loop():
     model = SpadeCondMotionModel(conf, dirs={}, dtype="f32").to(DEV).eval()
     deterministic_fill_(model, prefix="first_stage.")
     model.attach_fvd(i3d=_model("f32"))
-    kept_hat, kept_x = [], []
+    kept_hat, kept_x, ssims, psnrs = [], [], [], []
     for i in range(2):
         X = (torch.rand(3, 16, 3, 64, 64, generator=torch.Generator().manual_seed(40 + i)) * 2 - 1).to(DEV)
         X_hat = model.validation_step({"images": X}, i)
@@ -198,8 +198,12 @@ def test_first_stage_validation_loop():
         assert abs(model.logged["val/rec_loss"].item() - want) <= 1e-5 * max(1.0, want)
         from oracle import metrics_ref
         fake, true = X_hat.cpu().reshape(-1, *X_hat.shape[2:]), X[:, 1:].cpu().reshape(-1, *X_hat.shape[2:])
-        assert abs(float(model.logged["ssim-val"]) - metrics_ref.ssim(fake, true).item()) <= 2e-5
-        assert abs(float(model.logged["psnr-val"]) - metrics_ref.psnr(fake, true).item()) <= 1e-3
+        ssims.append(metrics_ref.ssim(fake, true).item()); psnrs.append(metrics_ref.psnr(fake, true).item())
+        assert abs(float(model.logged["ssim-val_step"]) - ssims[-1]) <= 2e-5
+        assert abs(float(model.logged["psnr-val_step"]) - psnrs[-1]) <= 1e-3
+        # logged with on_epoch=True (first_stage_motion_model.py:323-324): the epoch value is the mean over the batches so far
+        assert abs(float(model.logged["ssim-val"]) - sum(ssims) / len(ssims)) <= 2e-5
+        assert abs(float(model.logged["psnr-val"]) - sum(psnrs) / len(psnrs)) <= 1e-3
         kept_hat.append(X_hat.cpu()); kept_x.append(X.cpu())
     fvd_val, fvd_x0 = model.validation_epoch_end()
     o = fvd_ref.I3D(400)
