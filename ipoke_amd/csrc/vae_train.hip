@@ -760,7 +760,9 @@ extern "C" int ipoke_spectral_bwd(const float* w, int cout, int cin, int taps, i
   return IPOKE_OK;
 }
 
-static const int kRowScaleRows = 2048;      // rows per block: 2 400 blocks at the 128 x 128 layers of c4; 512 left the final column sums a 600-trip chain (60 us)
+// rows per block (IPOKE_ROWSCALE_ROWS, developer A/B on c4: 512 / 1024 / 2048 -> 50.3 / 50.7 / 52.1 ms: the final column sums get shorter with larger
+// blocks, the pass itself slower by more)
+static const int kRowScaleRows = getenv("IPOKE_ROWSCALE_ROWS") ? atoi(getenv("IPOKE_ROWSCALE_ROWS")) : 512;
 extern "C" int64_t ipoke_rowscale_bwd_workspace_floats(int64_t M, int C, int64_t rows_per_group) {
   if (rows_per_group < 1 || M < 1) return 0;
   const int64_t ngroups = (M + rows_per_group - 1) / rows_per_group, nbx = (rows_per_group + kRowScaleRows - 1) / kRowScaleRows;

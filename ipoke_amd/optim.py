@@ -21,7 +21,9 @@ from ._lib import check, ptr
 # of the arithmetic; 20.0 ms without), and the train step 62.1-62.2 ms against 61.8 ms (scripts/probe_adam.py).  Off by default.
 _FUSE_DEFAULT = os.environ.get("IPOKE_ADAM_FUSION", "0") == "1"
 _FUSE_SHADOWS = _FUSE_DEFAULT
-_NATIVE_BLOCKS = int(os.environ.get("IPOKE_NATIVE_ADAM_BLOCKS", "128"))      # developer A/B: persistent grid of the engine-issued update underneath backward
+# persistent grid of the engine-issued update underneath backward (c2, round 4, with the linear conv2 kernel: 64 / 128 / 160 / 192 / 224 / 256
+# workgroups -> 65.0 / 57.8 / 57.4 / 57.35 / 57.4 / 59.2 ms)
+_NATIVE_BLOCKS = int(os.environ.get("IPOKE_NATIVE_ADAM_BLOCKS", "192"))
 _TILE_BLOCKS = int(os.environ.get("IPOKE_ADAM_TILE_BLOCKS", "128"))     # developer A/B: persistent grid of the fused tile kernel underneath backward
 
 

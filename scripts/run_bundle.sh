@@ -1,5 +1,8 @@
-mkdir -p gpurun_out/fin
-timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -22 > gpurun_out/fin/tests.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > gpurun_out/fin/smoke.txt
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/fin/bench.err | tail -1 > gpurun_out/fin/bench_line.json
-cat gpurun_out/fin/tests.txt gpurun_out/fin/smoke.txt; tail -c 400 gpurun_out/fin/bench_line.json
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r4o
+mkdir -p $O
+for v in 512 2048 1024 512 2048; do IPOKE_ROWSCALE_ROWS=$v python $R/bench.py --config c4 --steps 20 --warmup 5 --no-cpu-baseline 2>$O/err.txt | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c4 rows=$v', d['ms_per_step'], d['loss'])" >> $O/ab.txt; done
+B="python $R/bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-secondary"
+for v in 128 160 192 224 128 160 192; do IPOKE_NATIVE_ADAM_BLOCKS=$v $B 2>$O/err.txt | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c2 adam_blocks=$v', d['ms_per_step'], d['ms_per_step_median'])" >> $O/ab.txt; done
+cat $O/ab.txt
