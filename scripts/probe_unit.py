@@ -110,3 +110,34 @@ if os.path.exists(probe_path):
         b = 32 + 4 * q
         print(f"  L{k} (c) detail: sync->pass lo {t[b] - t[5 + 6 * q]}, pass hi {t[b + 1] - t[b]}, w1t issue {t[b + 2] - t[b + 1]}, "
               f"exchange+2 syncs {t[b + 3] - t[b + 2]}")
+
+
+def contended(kind, fn, n=120):
+    """Unit kernel timed while a second stream keeps the chip busy: 'hbm' = large device copies, 'mfma' = large bf16 GEMMs,
+    'tn' = the weight-gradient GEMM of the coupling nets' conv2 (what the side stream runs during the backward pass)."""
+    side = torch.cuda.Stream()
+    big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev); big_b = torch.empty_like(big_a)
+    ma = torch.randn(4096, 4096, device=dev, dtype=tdt); mb = torch.randn(4096, 4096, device=dev, dtype=tdt)
+    ta = torch.randn(1280, 2048, device=dev, dtype=tdt); tb = torch.randn(1280, 2048, device=dev, dtype=tdt)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(60 if kind != "tn" else 400):
+            if kind == "hbm":
+                big_b.copy_(big_a)
+            elif kind == "mfma":
+                torch.mm(ma, mb)
+            else:
+                torch.mm(ta.t(), tb)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        check(fn(D[i % NU], _lib.BF16, s))
+    e1.record(); e1.synchronize()
+    busy = not side.query()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3, busy
+
+
+for kind in ("hbm", "mfma", "tn"):
+    f, fb = contended(kind, lib.ipoke_macow_unit_fwd); b_, bb = contended(kind, lib.ipoke_macow_unit_bwd)
+    print(f"next to a '{kind}' stream: fwd {f:.1f} us (side still busy at the end: {fb})  bwd {b_:.1f} us ({bb})")
