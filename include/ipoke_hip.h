@@ -154,6 +154,10 @@ int ipoke_state_to_nchw(const float* state, float* x_nchw, int B, int C, int P, 
 int ipoke_extract_cols(const float* state, int ld, int off, int stride, int C, void* out, int ldo, int64_t M, int dtype,
                        void* stream);
 int ipoke_cond_prepare(const float* cond_nchw, void* out, int B, int Cc, int P, int act, int dtype, void* stream);
+/* dst[m][0:C] = src[m][0:C] for M rows of `dtype` elements with row pitches lds / ldd (elements); widths, pitches and bases multiples
+ * of 16 bytes.  condition_nice: torch.cat([conv2 out, h]) of NICEConvBlock.forward (macow_utils.py:328-332) is this copy of the
+ * activated conditioning map into the last h_channels columns of the hidden tile conv2 writes */
+int ipoke_copy_cols(const void* src, int lds, void* dst, int ldd, int C, int64_t M, int dtype, void* stream);
 
 /* ActNorm2dFlow (macow2.py:476-540) optionally fused with the Shuffle that follows it
  * (flow_blocks.py:314-326): out[:, c0+j] = in[:, c0+idx[j]] * exp(ls[idx[j]]) + bias[idx[j]].
@@ -353,6 +357,8 @@ typedef struct {
   int32_t dtype;            /* IPOKE_F32 / IPOKE_BF16                         */
   int32_t max_batch;
   int32_t use1x1;           /* LU-parametrised invertible 1x1 convs as the per-level shuffle layers (macow2.py:862) */
+  int32_t condition_nice;   /* every NICE coupling net (steps and priors) sees the conditioning map: conv3 takes hidden + cond_channels
+                             * inputs, the last cond_channels being ELU(h) (macow2.py:1024-1060, 553; macow_utils.py:275-283, 328-332) */
 } ipoke_flow_config;
 
 int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out);

@@ -98,7 +98,7 @@ class SnJob(Structure):
 class FlowConfig(Structure):
     _fields_ = [("z_channels", c_int32), ("hidden", c_int32), ("cond_channels", c_int32), ("factor", c_int32),
                 ("n_levels", c_int32), ("num_steps", c_int32 * 32), ("kernel_h", c_int32), ("kernel_w", c_int32),
-                ("dtype", c_int32), ("max_batch", c_int32), ("use1x1", c_int32)]
+                ("dtype", c_int32), ("max_batch", c_int32), ("use1x1", c_int32), ("condition_nice", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/ipoke_hip.h
@@ -128,6 +128,7 @@ SIGNATURES = {
     "ipoke_nchw_to_state": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_state_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_extract_cols": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int64, c_int, _P]),
+    "ipoke_copy_cols": (c_int, [_P, c_int, _P, c_int, c_int, c_int64, c_int, _P]),
     "ipoke_cond_prepare": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_actnorm_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "ipoke_actnorm_inv": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -57,6 +57,17 @@ __global__ void extract_cols_kernel(const float* __restrict__ s, int ld, int off
   }
 }
 
+// dst[m][0:C] = src[m][0:C], both in the matrix cores' dtype, 16 bytes per thread (condition_nice: the activated conditioning map
+// behind conv2's output in the coupling net's hidden tile, macow_utils.py:328-332)
+__global__ void copy_cols16_kernel(const u32x4* __restrict__ src, long lds16, u32x4* __restrict__ dst, long ldd16, int c16, long M) {
+  if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
+  const long total = M * c16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c16; const int j = (int)(i - m * c16);
+    dst[m * ldd16 + j] = src[m * lds16 + j];
+  }
+}
+
 // ------------------------------------------------------------------ ActNorm (+ Shuffle)
 // out[m][c0 + j] = in[m][c0 + idx[j]] * exp(ls[idx[j]]) + bias[idx[j]]   (idx == NULL: identity)
 // ls/bias == NULL: pure permutation.  Columns outside [c0, c0+C) are copied.
@@ -701,6 +712,16 @@ extern "C" int ipoke_extract_cols(const float* state, int ld, int off, int strid
   else
     hipLaunchKernelGGL(extract_cols_kernel<float>, dim3(grid_for(M * ldo, 256)), dim3(256), 0, STREAM(stream), state, ld, off, stride,
                        C, (float*)out, ldo, (long)M);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_copy_cols(const void* src, int lds, void* dst, int ldd, int C, int64_t M, int dtype, void* stream) {
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4, e16 = 16 / esz;
+  IPK_REQUIRE(src && dst && C >= 1 && lds >= C && ldd >= C, "bad arguments");
+  IPK_REQUIRE(C % e16 == 0 && lds % e16 == 0 && ldd % e16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+              (reinterpret_cast<uintptr_t>(dst) & 15) == 0, "copy_cols moves 16-byte units: widths, pitches and bases must be multiples of 16 bytes");
+  hipLaunchKernelGGL(copy_cols16_kernel, dim3(grid_for(M * (C / e16), 256)), dim3(256), 0, STREAM(stream), (const u32x4*)src,
+                     (long)(lds / e16), (u32x4*)dst, (long)(ldd / e16), C / e16, (long)M);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -48,6 +48,7 @@ struct Op {
   int slot = -1;                               // log-det slot index
   int mcf_idx = -1;                            // running index among the MCF ops (batched weight gradients)
   int nice_idx = -1;                           // running index among the NICE ops (batched weight gradients)
+  int hidK = 0;                                // NICE: input channels of conv3 = hidden (+ cond_channels with condition_nice)
   int level = 0;                               // multi-scale level the op belongs to
   int fuse_act = -1;                           // MCF: index of the ActNorm executed inside this layer's kernels
   bool fused = false;                          // ActNorm: executed by the preceding MCF layer (forward / backward)
@@ -260,28 +261,32 @@ struct Builder {
     }
     op.Kc1 = round_up(op.cin, f.e16);
     op.Kc3 = round_up(2 * op.cout, f.e16);
+    // condition_nice: torch.cat([conv2 out, h]) in front of the second activation (macow_utils.py:328-332) -- conv3 is built with
+    // hidden + h_channels inputs (:275-283); the hidden tile h2 gets that pitch and ELU(h) is copied behind conv2's columns
+    const int hidK = hid + (f.cfg.condition_nice ? f.cfg.cond_channels : 0);
+    op.hidK = hidK;
     op.p_c1 = add_param(pfx + ".net.conv1.weight", {hid, op.cin, 3, 3});
     op.p_c2 = add_param(pfx + ".net.conv2.weight", {hid, hid, 1, 1});
     add_flag(pfx + ".net.conv3.initialized");
     op.p_b = add_param(pfx + ".net.conv3.conv.bias", {2 * op.cout});
     op.p_g = add_param(pfx + ".net.conv3.conv.weight_g", {2 * op.cout, 1, 1, 1});
-    op.p_v = add_param(pfx + ".net.conv3.conv.weight_v", {2 * op.cout, hid, 3, 3});
+    op.p_v = add_param(pfx + ".net.conv3.conv.weight_v", {2 * op.cout, hidK, 3, 3});
     op.wn_off = f.wn_rows;
-    f.wjobs.push_back({(long)op.p_v, (long)op.p_g, (long)op.wn_off, 2 * op.cout, hid * 9, (int)f.wn_rows});
+    f.wjobs.push_back({(long)op.p_v, (long)op.p_g, (long)op.wn_off, 2 * op.cout, hidK * 9, (int)f.wn_rows});
     f.wn_rows += 2 * op.cout;
     const int N3 = 2 * op.cout;
     op.sh_c1 = add_shadow((int64_t)hid * 9 * op.Kc1);
     op.sh_c1t = add_shadow((int64_t)op.cin * 9 * hid);
     op.sh_c2 = add_shadow((int64_t)hid * hid);
     op.sh_c2t = f.c2_straight ? -1 : add_shadow((int64_t)hid * hid);
-    op.sh_c3 = add_shadow((int64_t)N3 * 9 * hid);
-    op.sh_c3t = add_shadow((int64_t)hid * 9 * op.Kc3);
+    op.sh_c3 = add_shadow((int64_t)N3 * 9 * hidK);
+    op.sh_c3t = add_shadow((int64_t)hidK * 9 * op.Kc3);      // (the data gradient only needs the first `hid` rows: h has no gradient)
     // conv1.weight [hid][cin][3][3]
     relayout_pair(op.p_c1, (long)op.cin * 9, 9, 9, hid, op.cin, -1, op.sh_c1, hid, op.Kc1, op.sh_c1t, op.cin, hid, op.cin);
     // conv2.weight [hid][hid]
     relayout_pair(op.p_c2, hid, 1, 1, hid, hid, -1, op.sh_c2, hid, hid, op.sh_c2t, hid, hid, hid);
     // conv3 weight_v [N3][hid][3][3] with weight-norm scale
-    relayout_pair(op.p_v, (long)hid * 9, 9, 9, N3, hid, op.wn_off, op.sh_c3, N3, hid, op.sh_c3t, hid, op.Kc3, hid);
+    relayout_pair(op.p_v, (long)hidK * 9, 9, 9, N3, hidK, op.wn_off, op.sh_c3, N3, hidK, op.sh_c3t, hidK, op.Kc3, hidK);
     op.slot = f.nslots++;
     f.ops.push_back(op);
   }
@@ -452,7 +457,7 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
   if (mode == 0) {
     p.state0 = take(cur, 2 * p.state_stride);
     p.tmp_h1 = take(cur, M * hid * f.esz);
-    p.tmp_h2 = take(cur, M * hid * f.esz);
+    p.tmp_h2 = take(cur, M * (hid + (f.cfg.condition_nice ? f.cfg.cond_channels : 0)) * f.esz);
     p.tmp_zc = take(cur, M * 64 * f.esz);
     p.bytes = cur;
     return p;
@@ -470,7 +475,7 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
       if (f.mcf_xop) op.ws_e = take(cur, M * op.Cp * f.esz);      // x in the compute dtype (written by the unit's backward kernel)
     } else if (op.type == OP_NICE) {
       op.ws_a = take(cur, M * hid * f.esz);           // h1
-      op.ws_b = take(cur, M * hid * f.esz);           // h2
+      op.ws_b = take(cur, M * op.hidK * f.esz);       // h2 (condition_nice: [h2 | ELU(cond)])
       op.ws_c = take(cur, M * op.cout * 4);           // scale
       op.ws_d = take(cur, M * op.Kc3 * f.esz);        // dparams
       op.ws_e = take(cur, M * hid * f.esz);           // dp2
@@ -553,11 +558,16 @@ int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2, vo
   int rc = ipoke_conv_forward(&d, c.dtype, c.stream()); if (rc) return rc;
   set_conv8(d, c.B, 1, 0);
   set_a_dense(d, h1, hid, hid);
-  d.W = c.sh(op.sh_c2); d.ldw = hid; d.Nout = hid; d.act = IPOKE_ACT_ELU; d.C = h2; d.ldc = hid;
+  d.W = c.sh(op.sh_c2); d.ldw = hid; d.Nout = hid; d.act = IPOKE_ACT_ELU; d.C = h2; d.ldc = op.hidK;
   rc = ipoke_conv_forward(&d, c.dtype, c.stream()); if (rc) return rc;
+  if (op.hidK > hid) {      // condition_nice: ELU(cat[conv2 out, h]) = [ELU(conv2 out) | ELU(h)], the second half is the shared activated map
+    rc = ipoke_copy_cols(c.cond(), c.f->cfg.cond_channels, static_cast<unsigned char*>(h2) + (size_t)hid * c.f->esz, op.hidK,
+                         c.f->cfg.cond_channels, c.M, c.dtype, c.stream());
+    if (rc) return rc;
+  }
   set_conv8(d, c.B, 3, 1);
-  set_a_dense(d, h2, hid, hid);
-  d.W = c.sh(op.sh_c3); d.ldw = 9 * hid; d.Nout = 2 * op.cout; d.C = c.partials(); d.c_f32 = 1; d.ldc = 64;
+  set_a_dense(d, h2, op.hidK, op.hidK);
+  d.W = c.sh(op.sh_c3); d.ldw = 9 * op.hidK; d.Nout = 2 * op.cout; d.C = c.partials(); d.c_f32 = 1; d.ldc = 64;
   d.splitk = nice_splitk(c);
   return ipoke_conv_forward(&d, c.dtype, c.stream());
 }
@@ -1112,7 +1122,7 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
       } else {
         const int64_t hb = (int64_t)f->cfg.hidden * f->esz;
         void* h1 = l.rows(save ? op.ws_a : l.plan.tmp_h1, hb);
-        void* h2 = l.rows(save ? op.ws_b : l.plan.tmp_h2, hb);
+        void* h2 = l.rows(save ? op.ws_b : l.plan.tmp_h2, (int64_t)op.hidK * f->esz);
         void* zc = save ? l.rows(op.ws_g, (int64_t)op.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
         const bool have_zc = (i > 0 && nice_feeds(f->ops[i - 1], op)) || (!init && unit_feeds(f, i));
         rc = nice_net(l, op, in, h1, h2, zc, have_zc); if (rc) return rc;
@@ -1232,7 +1242,8 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
       } else {
         // the conditioning channels are untouched by the coupling, so the net sees the same input as in forward
         const bool have_zc = i + 1 < (int)f->ops.size() && nice_feeds(f->ops[i + 1], op);     // the coupling inverted just before this one
-        rc = nice_net(l, op, in, l.rows(l.plan.tmp_h1, hb), l.rows(l.plan.tmp_h2, hb), l.rows(l.plan.tmp_zc, 64L * f->esz), have_zc);
+        rc = nice_net(l, op, in, l.rows(l.plan.tmp_h1, hb), l.rows(l.plan.tmp_h2, (int64_t)op.hidK * f->esz), l.rows(l.plan.tmp_zc, 64L * f->esz),
+                      have_zc);
         if (rc) return rc;
         ipoke_affine_desc a; nice_affine_desc(l, op, a);
         const bool feed = i > 0 && nice_feeds(op, f->ops[i - 1]);
@@ -1442,9 +1453,9 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       };
       // conv3 (effective weight; weight-norm backward runs at the end)
       base8(3, 1);
-      w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
+      w.a_sn = 64L * op.hidK; w.a_sh = 8L * op.hidK; w.a_sw = op.hidK; w.a_sc = 1; w.Kc_real = op.hidK; w.Kc = op.hidK;
       w.ldy = op.Kc3; w.Nout = 2 * op.cout;
-      w.w_sn = (int64_t)hid * 9; w.w_sc = 9; w.w_st = 1;
+      w.w_sn = (int64_t)op.hidK * 9; w.w_sc = 9; w.w_st = 1;
       rc = ipoke_conv_wgrad_batched(&w, entries(2), nb, c.ws, c.ws, grads, c.dtype, wstream); if (rc) return rc;
       // conv2
       base8(1, 0);
@@ -1551,7 +1562,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
         }
         rc = ipoke_mcf_bwd(&d, l.dtype, l.stream()); if (rc) return rc;
       } else {
-        const void* h1 = l.rows(op.ws_a, hb); const void* h2 = l.rows(op.ws_b, hb);
+        const void* h1 = l.rows(op.ws_a, hb); const void* h2 = l.rows(op.ws_b, (int64_t)op.hidK * f->esz);
         void* dprm = l.rows(op.ws_d, (int64_t)op.Kc3 * f->esz); void* dp2 = l.rows(op.ws_e, hb); void* dp1 = l.rows(op.ws_f, hb);
         if (pending_an == i + 1) {
           const Op& an = f->ops[i + 1];
@@ -1568,7 +1579,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
         // conv3 data gradient, times ELU'(h2)
         set_conv8(d, l.B, 3, 1); d.transposed = 1;
         set_a_dense(d, dprm, op.Kc3, op.Kc3);
-        d.W = l.sh(op.sh_c3t); d.ldw = 9 * op.Kc3; d.Nout = hid; d.dact = h2; d.ld_dact = hid; d.dact_act = IPOKE_ACT_ELU;
+        d.W = l.sh(op.sh_c3t); d.ldw = 9 * op.Kc3; d.Nout = hid; d.dact = h2; d.ld_dact = op.hidK; d.dact_act = IPOKE_ACT_ELU;
         d.C = dp2; d.ldc = hid;
         rc = ipoke_conv_forward(&d, l.dtype, l.stream()); if (rc) return rc;
         // conv2 data gradient, times ELU'(h1)

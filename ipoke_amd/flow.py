@@ -31,7 +31,7 @@ class FlowEngine:
     """Owner of the native handle and of the flat device buffers."""
 
     def __init__(self, arch, dtype="bf16", max_batch=64, device=None):
-        for key in ("attention", "condition_nice", "cond_conv", "multistack"):       # augmented_input only widens flow_in_channels (second_stage.py)
+        for key in ("attention", "cond_conv", "multistack"):       # augmented_input only widens flow_in_channels (second_stage.py)
             if arch.get(key, False):
                 raise NotImplementedError(f"architecture option {key}=True is outside the shipped iPOKE configs")
         if float(arch.get("p_dropout", 0.0)) > 0.0:
@@ -58,6 +58,7 @@ class FlowEngine:
         cfg.dtype = self.dtype
         cfg.max_batch = int(max_batch)
         cfg.use1x1 = int(bool(arch.get("use1x1", False)))
+        cfg.condition_nice = int(bool(arch.get("condition_nice", False)))      # macow2.py:1024-1060: the NICE nets see h as well
         self.cfg = cfg
         self.z, self.cond_channels, self.max_batch = cfg.z_channels, cfg.cond_channels, cfg.max_batch
         h = c_void_p()

@@ -288,17 +288,23 @@ class MaskedConvFlow(nn.Module):
 # NICE coupling
 # --------------------------------------------------------------------------
 class NICEConvBlock(nn.Module):
-    """conv3x3 -> ELU -> conv1x1 -> ELU -> weight-normed conv3x3.  Reference macow_utils.py:253-337
-    (no norm, no attention, dropout p=0, no conditioning: condition_nice is False)."""
+    """conv3x3 -> ELU -> conv1x1 -> [cat h] -> ELU -> weight-normed conv3x3.  Reference macow_utils.py:253-337
+    (no norm, no attention, dropout p=0).  ``h_channels`` > 0 is ``condition_nice`` (macow2.py:1024-1060, 553): the
+    conditioning map is concatenated behind conv2's output BEFORE the activation (macow_utils.py:328-332), so conv3 sees
+    ELU(h) in its last ``h_channels`` input channels; ``cond_conv`` (a GatedConv2d on h first, :330-331) is not restated."""
 
-    def __init__(self, cin, cout, hidden):
+    def __init__(self, cin, cout, hidden, h_channels=0):
         super().__init__()
+        self.cond = h_channels > 0
         self.conv1 = nn.Conv2d(cin, hidden, 3, padding=1, bias=False)
         self.conv2 = nn.Conv2d(hidden, hidden, 1, bias=False)
-        self.conv3 = Conv2dWeightNorm(hidden, cout, 3, padding=1)
+        self.conv3 = Conv2dWeightNorm(hidden + h_channels, cout, 3, padding=1)
 
-    def forward(self, x):
-        return self.conv3(F.elu(self.conv2(F.elu(self.conv1(x)))))
+    def forward(self, x, h=None):
+        out = self.conv2(F.elu(self.conv1(x)))
+        if h is not None and self.cond:
+            out = torch.cat([out, h], dim=1)
+        return self.conv3(F.elu(out))
 
 
 class NICE2d(nn.Module):
@@ -309,7 +315,7 @@ class NICE2d(nn.Module):
     'skip' with odd C falls back to 'continuous' (:304-307).
     """
 
-    def __init__(self, channels, hidden, split_type="continuous", order="up", factor=2):
+    def __init__(self, channels, hidden, split_type="continuous", order="up", factor=2, h_channels=0):
         super().__init__()
         if split_type == "skip" and channels % factor == 1:
             split_type = "continuous"
@@ -318,7 +324,7 @@ class NICE2d(nn.Module):
         cout = channels // factor
         cin = channels - cout
         self.z1_channels = cin if self.up else cout
-        self.net = NICEConvBlock(cin, 2 * cout, hidden)
+        self.net = NICEConvBlock(cin, 2 * cout, hidden, h_channels)
 
     def split(self, x):
         if self.split_type == "continuous":
@@ -335,7 +341,7 @@ class NICE2d(nn.Module):
     def forward(self, x, h=None, reverse=False):
         z1, z2 = self.split(x)
         z, zp = (z1, z2) if self.up else (z2, z1)
-        mu, scale = affine_params(self.net(z))
+        mu, scale = affine_params(self.net(z, h=h))
         if reverse:
             zp = affine_inv(zp, mu, scale)
             z1, z2 = (z, zp) if self.up else (zp, z)
@@ -377,17 +383,18 @@ class MaCowUnit(nn.Module):
 class MaCowStep(nn.Module):
     """Reference macow2.py:999-1117."""
 
-    def __init__(self, channels, kernel_size, hidden, h_channels):
+    def __init__(self, channels, kernel_size, hidden, h_channels, condition_nice=False):
         super().__init__()
+        hn = h_channels if condition_nice else 0                   # macow2.py:1024-1060
         self.actnorm1 = ActNorm2dFlow(channels)
         self.conv1x1 = Shuffle(channels)
         self.units1 = nn.ModuleList([MaCowUnit(channels, kernel_size, h_channels) for _ in range(2)])
-        self.coupling1_up = NICE2d(channels, hidden, "continuous", "up")
-        self.coupling1_dn = NICE2d(channels, hidden, "continuous", "down")
+        self.coupling1_up = NICE2d(channels, hidden, "continuous", "up", h_channels=hn)
+        self.coupling1_dn = NICE2d(channels, hidden, "continuous", "down", h_channels=hn)
         self.actnorm2 = ActNorm2dFlow(channels)
         self.units2 = nn.ModuleList([MaCowUnit(channels, kernel_size, h_channels) for _ in range(2)])
-        self.coupling2_up = NICE2d(channels, hidden, "skip", "up")
-        self.coupling2_dn = NICE2d(channels, hidden, "skip", "down")
+        self.coupling2_up = NICE2d(channels, hidden, "skip", "up", h_channels=hn)
+        self.coupling2_dn = NICE2d(channels, hidden, "skip", "down", h_channels=hn)
 
     def _sequence(self):
         return ([self.actnorm1, self.conv1x1] + list(self.units1) + [self.coupling1_up, self.coupling1_dn,
@@ -415,10 +422,10 @@ class MaCowStep(nn.Module):
 class MultiScalePrior(nn.Module):
     """Shuffle -> NICE(factor f, continuous, up) -> ActNorm on the last C/f channels.  Reference macow2.py:543-593."""
 
-    def __init__(self, channels, hidden, factor):
+    def __init__(self, channels, hidden, factor, h_channels=0):
         super().__init__()
         self.conv1x1 = Shuffle(channels)
-        self.coupling = NICE2d(channels, hidden, "continuous", "up", factor=factor)
+        self.coupling = NICE2d(channels, hidden, "continuous", "up", factor=factor, h_channels=h_channels)   # macow2.py:553
         self.z1_channels = self.coupling.z1_channels
         self.actnorm = ActNorm2dFlow(channels // factor)
 
@@ -426,10 +433,10 @@ class MultiScalePrior(nn.Module):
         k = self.z1_channels
         if reverse:
             x = torch.cat([x[:, :k], self.actnorm(x[:, k:], reverse=True)], dim=1)
-            x = self.coupling(x, reverse=True)
+            x = self.coupling(x, h=h, reverse=True)
             return self.conv1x1(x, reverse=True)
         x, _ = self.conv1x1(x)
-        x, ld = self.coupling(x)
+        x, ld = self.coupling(x, h=h)
         tail, ld2 = self.actnorm(x[:, k:])
         return torch.cat([x[:, :k], tail], dim=1), ld + ld2
 
@@ -437,7 +444,7 @@ class MultiScalePrior(nn.Module):
 class MultiScaleInternal(nn.Module):
     """Level loop with channel split-off.  Reference macow2.py:821-920."""
 
-    def __init__(self, num_steps, channels, hidden, h_channels, factor, kernel_size, use_1x1=False):
+    def __init__(self, num_steps, channels, hidden, h_channels, factor, kernel_size, use_1x1=False, condition_nice=False):
         super().__init__()
         self.reshape = "none"
         self.layers = nn.ModuleList()
@@ -445,8 +452,8 @@ class MultiScaleInternal(nn.Module):
         self.shuffle_layers = nn.ModuleList()
         step = channels // factor
         for n in num_steps:
-            self.layers.append(nn.ModuleList([MaCowStep(channels, kernel_size, hidden, h_channels) for _ in range(n)]))
-            self.priors.append(MultiScalePrior(channels, hidden, factor))
+            self.layers.append(nn.ModuleList([MaCowStep(channels, kernel_size, hidden, h_channels, condition_nice) for _ in range(n)]))
+            self.priors.append(MultiScalePrior(channels, hidden, factor, h_channels if condition_nice else 0))
             self.shuffle_layers.append(InvertibleConvLU1d(channels) if use_1x1 else Shuffle(channels))   # macow2.py:862
             channels -= step
             factor -= 1
@@ -487,14 +494,15 @@ class SupervisedMacowTransformer(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        for unsupported in ("attention", "condition_nice", "cond_conv"):
+        for unsupported in ("attention", "cond_conv"):
             if config.get(unsupported, False):
                 raise NotImplementedError(f"oracle covers shipped configs only ({unsupported}=True is not one)")
         assert config["transform"] == "affine" and config["prior_transform"] == "affine"
         assert config["activation"] == "elu" and config["coupling_type"] == "conv"
         self.flow = MultiScaleInternal(config["num_steps"], config["flow_in_channels"], config["flow_mid_channels"],
                                        config["h_channels"], config["factor"], tuple(config["kernel_size"]),
-                                       use_1x1=bool(config.get("use1x1", False)))
+                                       use_1x1=bool(config.get("use1x1", False)),
+                                       condition_nice=bool(config.get("condition_nice", False)))
 
     def forward(self, x, cond, reverse=False):
         if reverse:

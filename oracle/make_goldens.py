@@ -1081,13 +1081,52 @@ def g14_adapt_cond():
     npz("g14_adapt_cond_64", batch_seed=6, eps=eps, flow_input=flow_input, cond=cond, cond_latent_4x4=raw)
 
 
+def g16_condition_nice():
+    """G16: the reduced full-topology flow with ``condition_nice: True`` (macow2.py:1024-1060, 553; macow_utils.py:275-283, 328-332):
+    every NICE coupling net (steps and priors) sees the conditioning map behind conv2 -- activations, reverse pass, loss dict and every
+    parameter gradient of the reference, with a 32-channel conditioning map so that the widened conv3 (hidden + 32 inputs) keeps the
+    fixture small.  Parameters filled by name as in G2."""
+    INN = ref_import.ref("models.modules.INN.INN")
+    loss_m = ref_import.ref("models.modules.INN.loss")
+    arch = configs.reduced_flow_arch()
+    arch["condition_nice"] = True
+    arch["h_channels"] = 32
+    R = INN.SupervisedMacowTransformer(copy.deepcopy(arch))
+    O = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch))
+    assert list(R.state_dict()) == list(O.state_dict()), "state-dict keys/order differ from the reference"
+    assert [tuple(v.shape) for v in R.state_dict().values()] == [tuple(v.shape) for v in O.state_dict().values()]
+    w3 = R.state_dict()["flow.layers.0.0.coupling1_up.net.conv3.conv.weight_v"]
+    assert w3.shape[1] == 64 + 32, w3.shape
+    deterministic_fill_(R, prefix="flow."); deterministic_fill_(O, prefix="flow.")
+    x, cond = rn((3, 16, 8, 8), 61), rn((3, 32, 8, 8), 62)
+    out, logdet, loss, log = _loss_and_grads(R, loss_m.FlowLoss(), x, cond, 1234)
+    oo, ol, oloss, olog = _loss_and_grads(O, flow_ref.FlowLoss(), x, cond, 1234)
+    close(oo, out, 2e-5, "G16 out"); close(ol, logdet, 1e-3, "G16 logdet"); close(oloss, loss, 1e-3, "G16 loss")
+    rev = R(out.detach(), cond, reverse=True)
+    close(O(oo.detach(), cond, reverse=True), rev, 5e-5, "G16 reverse")
+    # the option must matter: the same parameters without the conditioning columns give another output
+    with torch.no_grad():
+        out0, _ = R(x, torch.zeros_like(cond))
+    assert (out0 - out).abs().max().item() > 1e-3
+    arrs = dict(x=x, cond=cond, out=out, logdet=logdet, loss=loss, reverse=rev, nll_loss=log["nll_loss"],
+                nlogdet_loss=log["nlogdet_loss"], roundtrip_err=(rev - x).abs().max())
+    worst = 0.0
+    for (k, p_), (k2, q) in zip(R.named_parameters(), O.named_parameters()):
+        assert k == k2
+        arrs["grad." + k] = p_.grad
+        worst = max(worst, (p_.grad - q.grad).abs().max().item() / (p_.grad.abs().max().item() + 1e-12))
+    assert worst < 1e-4, worst
+    print(f"  G16 oracle-vs-reference worst relative grad error {worst:.2e}")
+    npz("g16_condition_nice", **arrs)
+
+
 def main(which):
     torch.set_num_threads(os.cpu_count())
     torch.manual_seed(0)
     jobs = {"g1": g1_units, "g1_wide": lambda: g1_units((60, 64), "g1_flow_units_wide", with_lu=False),
             "g2": g2_reduced_flow, "g2_lu": g2_lu_flow, "g3": g3_full_flow, "g3_64": lambda: g3_full_flow(64), "g45": g4_g5_first_stage,
             "g4_128": g4_encoder_128, "g67": g6_g7_glue, "g128": g_128, "g8": g8_disc, "g9": g9_patch_disc, "g10": g10_fvd, "g11": g11_data, "g12": g12_vgg, "g13": g13_train_mode,
-            "g7_128": g7_sample_128, "g14": g14_adapt_cond}
+            "g7_128": g7_sample_128, "g14": g14_adapt_cond, "g16": g16_condition_nice}
     for name in (which or list(jobs)):
         print(f"[{name}]")
         t = time.time()

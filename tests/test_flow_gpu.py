@@ -101,6 +101,83 @@ def test_reduced_flow_with_lu_1x1_convs(golden, dtype):
     assert e_rev <= tol["rev"]
 
 
+def _condition_nice_arch(h_channels=32):
+    arch = configs.reduced_flow_arch()
+    arch["condition_nice"] = True
+    arch["h_channels"] = h_channels
+    return arch
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_condition_nice_flow(golden, dtype):
+    """condition_nice (macow2.py:1024-1060, 553; macow_utils.py:275-283, 328-332): conv3 of every NICE net takes hidden + h_channels
+    inputs, the last h_channels being ELU(h) -- forward, log-det, reverse and every parameter gradient against the reference (G16)."""
+    g = golden("g16_condition_nice")
+    m = build(_condition_nice_arch(), dtype).train()
+    assert tuple(m.state_dict()["flow.layers.0.0.coupling1_up.net.conv3.conv.weight_v"].shape) == (16, 96, 3, 3)
+    x, cond = t(g["x"], "cuda"), t(g["cond"], "cuda")
+    out, logdet = m(x, cond)
+    tol = dict(TOL[dtype])
+    if dtype == "bf16":       # the same relative bounds as TOL["bf16"] (0.5 % of the range; G2 reaches |out| 12.8, |logdet| 70 -- G16 16.2 and 110)
+        tol["out"] = tol["rev"] = 5e-3 * float(np.abs(g["out"]).max())
+        tol["logdet"] = 5e-3 * float(np.abs(g["logdet"]).max())
+    e_out = (out.detach().cpu() - t(g["out"])).abs().max().item()
+    e_ld = (logdet.detach().cpu() - t(g["logdet"])).abs().max().item()
+    print(f"[{dtype}] condition_nice: out err {e_out:.3e}, logdet err {e_ld:.3e}")
+    assert e_out <= tol["out"] and e_ld <= tol["logdet"]
+    loss = (0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()
+    loss.backward()
+    worst, worst_key = 0.0, None
+    for name, p in m.named_parameters():
+        ref = t(g["grad." + name])
+        err = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-6)
+        if err > worst:
+            worst, worst_key = err, name
+    print(f"[{dtype}] condition_nice: worst relative grad error {worst:.3e} at {worst_key}")
+    assert worst <= tol["grad"]
+    with torch.no_grad():
+        rev = m(t(g["out"], "cuda"), cond, reverse=True)
+        e_rev = (rev.cpu() - t(g["reverse"])).abs().max().item()
+        print(f"[{dtype}] condition_nice: reverse err {e_rev:.3e}")
+        assert e_rev <= tol["rev"]
+        out0, _ = m(x, torch.zeros_like(cond))
+        assert (out0 - out).abs().max().item() > 1e-3            # the conditioning columns are live
+
+
+def test_condition_nice_wide_vs_oracle():
+    """The same option at the shipped conditioning width (128 channels), hidden = 256 (conv3 on the stationary 3x3 kernel, K = 384
+    per tap), B = 5, f32 mode against the CPU oracle: forward, gradients of the conv3 weights (both column groups), reverse."""
+    from oracle import flow_ref
+    arch = configs.flow_arch(16, hidden=256, num_steps=[1, 1], factor=4)
+    arch["condition_nice"] = True
+    m = build(arch, "f32").train()
+    o = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch))
+    deterministic_fill_(o, prefix="flow.")
+    gen = torch.Generator().manual_seed(5)
+    x, cond = torch.randn(5, 16, 8, 8, generator=gen), torch.randn(5, 128, 8, 8, generator=gen)
+    out, logdet = m(x.cuda(), cond.cuda())
+    oo, ol = o(x, cond)
+    assert (out.detach().cpu() - oo).abs().max().item() <= TOL["f32"]["out"] * 4
+    assert (logdet.detach().cpu() - ol).abs().max().item() <= TOL["f32"]["logdet"] * 4
+    ((0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()).backward()
+    ((0.5 * (oo ** 2).sum(dim=[1, 2, 3])).mean() - ol.mean()).backward()
+    og = dict(o.named_parameters())
+    worst = 0.0
+    for name, p in m.named_parameters():
+        ref = og[name].grad
+        worst = max(worst, (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-6))
+        if name.endswith("coupling1_up.net.conv3.conv.weight_v"):
+            gc = p.grad.cpu()
+            for lo, hi in ((0, 256), (256, 384)):           # hidden columns, conditioning columns
+                e = (gc[:, lo:hi] - ref[:, lo:hi]).abs().max().item() / (ref[:, lo:hi].abs().max().item() + 1e-6)
+                assert e <= TOL["f32"]["grad"], (name, lo, e)
+    print(f"condition_nice wide: worst relative grad error {worst:.3e}")
+    assert worst <= TOL["f32"]["grad"]
+    with torch.no_grad():
+        rev = m(oo.detach().cuda(), cond.cuda(), reverse=True)
+        assert (rev.cpu() - x).abs().max().item() <= TOL["f32"]["rev"] * 4
+
+
 def test_reduced_flow_data_init(golden):
     """First forward with initialized == 0 (data-dependent ActNorm init, zero-init couplings)."""
     g = golden("g2_reduced_flow_init")

@@ -92,6 +92,35 @@ def test_reduced_flow_full_topology(golden):
         assert (p.grad - ref).abs().max() <= 1e-4 * (ref.abs().max() + 1e-6), k
 
 
+def _condition_nice_arch():
+    arch = configs.reduced_flow_arch()
+    arch["condition_nice"] = True
+    arch["h_channels"] = 32
+    return arch
+
+
+def test_condition_nice_flow(golden):
+    """condition_nice (macow2.py:1024-1060, 553; macow_utils.py:275-283, 328-332): every NICE net sees h behind conv2 -- the
+    reference's activations, reverse pass, loss and every parameter gradient (G16)."""
+    g = golden("g16_condition_nice")
+    o = flow_ref.SupervisedMacowTransformer(_condition_nice_arch())
+    assert o.state_dict()["flow.layers.0.0.coupling1_up.net.conv3.conv.weight_v"].shape[1] == 64 + 32
+    assert o.state_dict()["flow.priors.0.coupling.net.conv3.conv.weight_v"].shape[1] == 64 + 32
+    deterministic_fill_(o, prefix="flow.")
+    x, cond = t(g["x"]), t(g["cond"])
+    out, logdet = o(x, cond)
+    assert (out - t(g["out"])).abs().max() <= 2e-5 and (logdet - t(g["logdet"])).abs().max() <= 1e-3
+    assert (o(out.detach(), cond, reverse=True) - t(g["reverse"])).abs().max() <= 5e-5
+    loss = (0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-3
+    loss.backward()
+    for k, p in o.named_parameters():
+        ref = t(g["grad." + k])
+        assert (p.grad - ref).abs().max() <= 1e-4 * (ref.abs().max() + 1e-6), k
+    with torch.no_grad():                     # the conditioning columns matter
+        assert (o(x, torch.zeros_like(cond))[0] - out).abs().max() > 1e-3
+
+
 def test_lu_conv_unit_and_flow(golden):
     """InvertibleConvLU1d (macow2.py:596-649): the reference's unit golden, and the reduced flow with use1x1 (G2-LU)."""
     g = golden("g1_flow_units")

@@ -52,6 +52,46 @@ def test_augmented_input():
     assert vids[0].shape == (2, 15, 3, 64, 64) and torch.isfinite(vids[0]).all() and l0 == l0
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_condition_nice_second_stage(dtype):
+    """architecture.condition_nice (macow2.py:1024-1060): the whole second stage with conditioned NICE nets -- three optimizer steps (the
+    first has lr = 0, second_stage_video.py:238-253), the conditioning columns of conv3 move, the trained state dict loads into the
+    CPU oracle and gives the same flow output, sampling runs."""
+    arch = configs.flow_arch(32, hidden=64, num_steps=[2, 1, 1], factor=4)
+    arch["flow_mid_channels_factor"] = 2
+    arch["condition_nice"] = True
+    conf = configs.second_stage_config(64, 32, 16, batch_size=2, arch=arch)
+    model = PokeMotionModel(conf, dirs={}, dtype=dtype, device=DEV, max_batch=2)
+    for name in ("first_stage_model", "poke_embedder", "conditioner", "flow"):
+        deterministic_fill_(getattr(model, name), prefix=name + ".")
+    model.flow.sync_buffers()
+    key = "flow.layers.0.0.coupling1_up.net.conv3.conv.weight_v"
+    w0 = model.flow.state_dict()[key].clone()
+    assert tuple(w0.shape) == (32, 64 + 128, 3, 3)
+    batch = synthetic_batch(2, 16, 64, seed=4, device=DEV)
+    from ipoke_amd.trainer import SecondStageTrainer
+    tr = SecondStageTrainer(model)
+    losses = [tr.train_step(batch).item() for _ in range(3)]
+    assert all(l == l for l in losses)
+    w1 = model.flow.state_dict()[key]
+    moved = (w1 - w0).abs()
+    assert moved[:, :64].max().item() > 0 and moved[:, 64:].max().item() > 0, "both column groups of conv3 are trained"
+    model.eval()
+    torch.manual_seed(3)
+    flow_input, cond = model.make_flow_input(batch)
+    with torch.no_grad():
+        out, logdet = model.flow(flow_input, cond)
+    o = flow_ref.SupervisedMacowTransformer(copy.deepcopy(model.config["architecture"]))
+    o.load_state_dict({k: v.cpu() for k, v in model.flow.state_dict().items()})
+    with torch.no_grad():
+        oo, old = o(flow_input.cpu(), cond.cpu())
+    scale = oo.abs().max().item()
+    tol_o, tol_l = (2e-4, 2e-2) if dtype == "f32" else (5e-3 * scale, 5e-3 * old.abs().max().item())
+    assert (out.cpu() - oo).abs().max().item() <= tol_o and (logdet.cpu() - old).abs().max().item() <= tol_l
+    vids = model.forward_sample(batch, n_samples=1, n_logged_vids=2)
+    assert vids[0].shape == (2, 15, 3, 64, 64) and torch.isfinite(vids[0]).all()
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_gradient_accumulation_matches_the_large_batch_step(overlap):
     """training.min_acc_batch_size > data.batch_size (experiments/experiment.py:81-88 -> Lightning's accumulate_grad_batches = k):
