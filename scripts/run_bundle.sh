@@ -1,4 +1,3 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-python -m pytest tests/test_second_stage_options_gpu.py -x -q -s -k "condition_nice" 2>&1 | tail -25
-python -m pytest tests/test_flow_gpu.py tests/test_second_stage_options_gpu.py tests/test_trainer_gpu.py -x -q 2>&1 | tail -3
+python -m pytest tests/test_train_mode_gpu.py -x -q -s 2>&1 | grep "loss\|passed\|failed" | cut -c1-250 | tail -14

@@ -1,0 +1,39 @@
+"""The bf16 bounds of tests/test_train_mode_gpu.py against the yardstick they cite: how far the REFERENCE's own first-stage train
+step moves when its convolutions run in bf16 (``torch.autocast`` on the CPU, fp32 master weights -- scripts/ref_bf16_autocast.py, run
+in the build container where /root/reference exists; the measured deviations are the fixture tests/golden/g15_ref_bf16_autocast.npz).
+A bf16 run cannot be closer to the fp32 reference than bf16 arithmetic lets the reference be to itself: every bound must stay within
+1.5x the largest deviation the fixture holds for that metric."""
+import importlib
+import re
+
+import numpy as np
+import pytest
+
+# TOL key -> fixture key suffix
+METRICS = {"x_max": "x_max", "x_mean": "x_mean", "loss": "loss_rel", "sum": "sum", "smp_max": "smp_max", "smp_mean": "smp_mean"}
+
+
+def _yardstick(golden):
+    g = golden("g15_ref_bf16_autocast")
+    runs = sorted({re.match(r"(s\d+_T\d+)_", k).group(1) for k in g.keys()})
+    assert runs, "empty yardstick fixture"
+    return g, runs
+
+
+def test_fixture_is_complete(golden):
+    g, runs = _yardstick(golden)
+    for r in runs:
+        for suffix in list(METRICS.values()) + ["n_tensors"]:
+            assert f"{r}_{suffix}" in g, (r, suffix)
+        assert float(g[f"{r}_n_tensors"]) >= 100                 # every gradient tensor of the first stage was compared
+        assert 0.0 < float(g[f"{r}_x_mean"]) < float(g[f"{r}_x_max"]) < 1.0
+        assert 0.0 < float(g[f"{r}_smp_mean"]) < float(g[f"{r}_smp_max"])
+
+
+@pytest.mark.parametrize("key", sorted(METRICS))
+def test_bf16_bounds_within_1p5x_of_the_reference_deviation(golden, key):
+    g, runs = _yardstick(golden)
+    tol = importlib.import_module("tests.test_train_mode_gpu").TOL
+    ref = max(float(g[f"{r}_{METRICS[key]}"]) for r in runs)
+    assert tol["bf16"][key] <= 1.5 * ref * (1 + 1e-6), (key, tol["bf16"][key], ref, runs)
+    assert tol["f32"][key] < tol["bf16"][key]                   # f32 mode stays the tight check of the same code path

@@ -31,8 +31,12 @@ T = 16
 # all positions, where the sign flips of the L1 term do not average out), the same magnitudes (measured here, T = 16, 128x128:
 # 0.17 / 0.32 / 0.075).  A bf16 run cannot be closer to the fp32 reference than bf16 arithmetic lets the reference be to itself;
 # the bounds are 1.5x the reference's own deviation.  f32 mode is the tight check of the same code path.
-TOL = {"f32": dict(x_max=2e-4, x_mean=1e-5, loss=2e-4, mu=2e-4, sum=5e-3, smp_max=3e-2, smp_mean=5e-3, u=2e-5),
-       "bf16": dict(x_max=0.25, x_mean=1.5e-2, loss=5e-2, mu=6e-2, sum=0.25, smp_max=0.5, smp_mean=0.13, u=2e-5)}
+TOL = {"f32": dict(x_max=2e-4, x_mean=1e-5, loss=2e-5, mu=2e-4, sum=5e-3, smp_max=3e-2, smp_mean=5e-3, u=2e-5),
+       # bf16: every entry the yardstick fixture holds (tests/golden/g15_ref_bf16_autocast.npz, scripts/ref_bf16_autocast.py) is at most
+       # 1.5x the reference's own bf16-autocast deviation -- asserted on the CPU by tests/test_bf16_yardstick_cpu.py.  Measured on the
+       # MI355X (four variants, B = 1 / 4 / 10): x_max <= 0.204, x_mean 8.6e-3, loss 3.3e-5, sum <= 0.175, smp_max <= 0.339, smp_mean <= 0.081.
+       # `mu` (the encoder's posterior mean, not in the fixture) is measured 5.0e-2.
+       "bf16": dict(x_max=0.25, x_mean=1.4e-2, loss=1e-4, mu=6e-2, sum=0.22, smp_max=0.49, smp_mean=0.125, u=2e-5)}
 
 
 def train_model(dtype):
