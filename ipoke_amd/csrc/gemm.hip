@@ -2917,6 +2917,20 @@ extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stre
     ts.annotate(0, 2.0 * p.g.M * d->Nout * (double)p.g.taps * d->Kc_real,
                 (double)p.g.M * d->Nout * esz + in_rows * d->Kc_real * (d->a_f32 ? 4 : esz) + (double)d->Nout * p.g.taps * d->Kc_real * 4 * p.splitm);
   }
+  static const bool wlog = getenv("IPOKE_WGRAD_LOG") != nullptr;      // developer probe: every call timed on its own (serialises the stream)
+  if (wlog) {
+    hipEvent_t e0, e1;
+    IPK_HIP(hipEventCreate(&e0)); IPK_HIP(hipEventCreate(&e1));
+    IPK_HIP(hipEventRecord(e0, s));
+    rc = dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s) : launch_tn<float>(p, s);
+    IPK_HIP(hipEventRecord(e1, s)); IPK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f; IPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    fprintf(stderr, "WGRAD NB=%d in=%dx%dx%d out=%dx%dx%d k=%dx%dx%d s=%d,%d,%d Kc=%d Nout=%d a_f32=%d splitm=%d M=%ld GF=%.2f us=%.1f\n", d->NB, d->Di, d->Hi,
+            d->Wi, d->Do, d->Ho, d->Wo, d->kd, d->kh, d->kw, d->sd, d->sh, d->sw, d->Kc_real, d->Nout, d->a_f32, p.splitm, (long)p.g.M,
+            2e-9 * p.g.M * d->Nout * (double)p.g.taps * d->Kc_real, ms * 1e3);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+  }
   return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s) : launch_tn<float>(p, s);
 }
 

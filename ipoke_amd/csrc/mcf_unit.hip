@@ -37,7 +37,7 @@ struct UnitParams {
 #endif
 };
 #ifdef IPOKE_UNIT_STAMPS
-#define UNIT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && U.stamps) U.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define UNIT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && U.stamps && (i) < 64) U.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define UNIT_STAMP(i) do { } while (0)
 #endif
@@ -801,6 +801,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
     if (e < rows * G2) *reinterpret_cast<f32x2*>(yf + p * C + c) = yin[i];
   }
   __syncthreads();
+  UNIT_STAMP(0);
 #pragma unroll 1
   for (int k = 3; k >= 0; --k) {
     const UnitLayer& Lk = U.L[k];
@@ -823,6 +824,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
 #pragma unroll 1
     for (int step = 0; step < 8; ++step) {
       const int si = backwards ? 7 - step : step;
+      UNIT_STAMP(1 + 6 * step + 0 + (k == 3 ? 0 : 1000));
       // conditioning rows of the strip behind the hidden columns of the 16-row tile
       {
         const int cchunks = U.Cc / E16;
@@ -835,6 +837,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
           *reinterpret_cast<u32x4*>(a2 + row * a2_pitch + (H + ch * E16) * (int)sizeof(T)) = v;
         }
       }
+      UNIT_STAMP(1 + 6 * step + 1 + (k == 3 ? 0 : 1000));
       {   // hidden = ELU(shifted conv of the strips reconstructed so far)
         const int sidx = r >> 3, j = r & 7;
         const int pos = rows_first ? si * 8 + j : j * 8 + si;
@@ -865,8 +868,10 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      UNIT_STAMP(1 + 6 * step + 2 + (k == 3 ? 0 : 1000));
       if (step == 7 && k > 0) unit_load_w1<T, WIDE>(wr, U.L[k - 1].W1, U);
       __syncthreads();
+      UNIT_STAMP(1 + 6 * step + 3 + (k == 3 ? 0 : 1000));
       {   // raw (mu, s) of the 16 rows
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -878,8 +883,10 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
         if (n < N2) *reinterpret_cast<f32x4*>(prm + r * prm_ld + n) = acc;
       }
       __builtin_amdgcn_sched_barrier(0);
+      UNIT_STAMP(1 + 6 * step + 4 + (k == 3 ? 0 : 1000));
       if (step == 7 && k > 0) unit_load_w2<T, WIDE>(wr, U.L[k - 1].W2, U);
       __syncthreads();
+      UNIT_STAMP(1 + 6 * step + 5 + (k == 3 ? 0 : 1000));
       // x = (y - mu) / (scale + 1e-12)   (macow_utils.py:61-66); the strip joins the operand tile
       for (int e = tl; e < 16 * G2; e += kMcfThreads) {
         const int row = e / G2, c = (e - row * G2) * 2;
@@ -900,6 +907,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
       }
       __syncthreads();
     }
+    UNIT_STAMP(49 + (3 - k));
   }
   for (int e = tid; e < rows * G2; e += kMcfThreads) {
     const int p = e / G2, c = (e - p * G2) * 2;
@@ -1008,6 +1016,9 @@ extern "C" int ipoke_macow_unit_inv(const ipoke_mcf_desc* d4, int dtype, void* s
   UnitParams U;
   int rc = unit_params(U, d4, dtype, false); if (rc) return rc;
   IPK_REQUIRE(U.L[3].x && U.L[0].y && U.L[3].x != U.L[0].y, "null / aliased state");
+#ifdef IPOKE_UNIT_STAMPS
+  U.stamps = g_stamps;
+#endif
   const bool wide = U.Cp > 32;
   const size_t lds = (size_t)2 * 65 * (U.Cp * 2 + kTilePad) + (size_t)16 * ((wide ? 384 : 256) * 2 + kTilePad) + (size_t)2 * 64 * U.Cc * 2 +
                      (size_t)16 * (2 * U.C + 4) * 4 + (size_t)2 * 64 * U.C * 4 + (size_t)(8 * U.C + 8 * U.C) * 4;

@@ -110,6 +110,7 @@ def _build_weight_operand(w, dtype, transposed_conv, inv_scale=None):
     return out, kc
 
 
+_STEM_TRAIN_UNFOLDED = os.environ.get("IPOKE_STEM_TRAIN_UNFOLDED", "0") == "1"      # developer A/B: conv1 of the 3-D encoder read in place when training
 _WGRAD_WGS = int(os.environ.get("IPOKE_WGRAD_WGS", "512"))       # workgroups a split-M weight gradient aims for (c4: 256 / 512 / 1024 / 2048 -> 156.5 / 151.0 / 156.5 / 160.6 ms: more slabs = more fp32 partial traffic)
 
 
@@ -326,6 +327,87 @@ class _ConvFn(torch.autograd.Function):
             if d_x.shape[1] != x_t.shape[1]:
                 d_x = _pad_cols(d_x[:, :min(d_x.shape[1], x_t.shape[1])], x_t.shape[1], dt)
         return d_x, d_w, d_bias, None
+
+
+class _StemFn(torch.autograd.Function):
+    """conv1 of the 3-D motion encoder (Conv3d(3, 64, (3, 7, 7), 2, (1, 3, 3)), motion_encoder.py:106-107) on the fp32 clip, with
+    gradient w.r.t. the weight.  As in the inference path (first_stage.py::_stem) the clip is rewritten once as padded channels-last
+    pixels of four channels, so that a 7-tap run along x is ONE aligned 64-byte read: forward = 21 taps of 32 channels on the LDS-DMA
+    GEMM; the weight gradient is the same geometry through ``ipoke_conv_wgrad`` -- a dense bf16 operand for the LDS-DMA /
+    transposed-read kernel instead of 147 taps of 3 strided floats through the register-staged one (c4, B = 20: 1 623 -> see DESIGN §7
+    us for the weight gradient, 653 -> ~100 us forward) -- and the [64][21][32] result is unfolded into the parameter's layout."""
+
+    @staticmethod
+    def forward(ctx, x, w, dt):
+        B, C, T, H, W = x.shape
+        cout = w.shape[0]
+        lib = _lib.lib()
+        s = _lib.current_stream()
+        Wp = W + 6
+        clip = torch.empty(B * T * H * Wp, 4, dtype=_tdt(dt), device=x.device)
+        check(lib.ipoke_clip_to_cl4(ptr(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4), B, T, H, W, 3, 3,
+                                    ptr(clip), ops._dt(dt), s))
+        odhw = ((T + 2 - 3) // 2 + 1, (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1)
+        buf = torch.zeros(cout, 3, 7, 8, 4, dtype=torch.float32, device=w.device)
+        buf[:, :, :, :7, :3] = w.detach().float().permute(0, 2, 3, 4, 1)
+        wop = buf.reshape(cout, 21 * 32).to(_tdt(dt)).contiguous()
+        d = ops.conv_desc(B, (T, H, odhw[2]), odhw, (3, 7, 1), (2, 2, 1), (1, 3, 0))
+        d.A = clip.data_ptr(); d.a_f32 = 0
+        d.a_sn, d.a_sd, d.a_sh, d.a_sw, d.a_sc = T * H * Wp * 4, H * Wp * 4, Wp * 4, 8, 1
+        d.a_coff = 0; d.Kc_real = 32; d.Kc = 32
+        d.W = wop.data_ptr(); d.ldw = wop.shape[1]; d.Nout = cout
+        d.bias = 0; d.act = _lib.ACT_NONE
+        y = torch.empty(B * odhw[0] * odhw[1] * odhw[2], K.round_up(cout, K.e16(dt)), dtype=_tdt(dt), device=x.device)
+        d.C = y.data_ptr(); d.ldc = y.shape[1]
+        ops.conv_forward(d, dt)
+        ctx.save_for_backward(clip)
+        ctx.geom = (B, T, H, W, Wp, odhw, cout, dt, tuple(w.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (clip,) = ctx.saved_tensors
+        B, T, H, W, Wp, odhw, cout, dt, wshape = ctx.geom
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        lib = _lib.lib()
+        s = _lib.current_stream()
+        ldg = K.round_up(cout, K.e16(dt))
+        g = _pad_cols(dy, ldg, dt) if (dy.dtype != _tdt(dt) or dy.shape[1] != ldg) else dy.contiguous()
+        dwf = torch.empty(cout, 21 * 32, dtype=torch.float32, device=dy.device)
+        wd = WgradDesc()
+        wd.kd, wd.kh, wd.kw = 3, 7, 1
+        wd.sd, wd.sh, wd.sw = 2, 2, 1
+        wd.pd, wd.ph, wd.pw = 1, 3, 0
+        wd.NB = B
+        wd.Di, wd.Hi, wd.Wi = T, H, odhw[2]
+        wd.Do, wd.Ho, wd.Wo = odhw
+        wd.A = clip.data_ptr(); wd.a_f32 = 0
+        wd.a_sn, wd.a_sd, wd.a_sh, wd.a_sw, wd.a_sc = T * H * Wp * 4, H * Wp * 4, Wp * 4, 8, 1
+        wd.Kc_real = 32; wd.Kc = 32; wd.Kc_store = 32
+        wd.dY = g.data_ptr(); wd.ldy = ldg; wd.Nout = cout
+        wd.w_sn = 21 * 32; wd.w_st = 32; wd.w_sc = 1
+        tiles = -(-cout // 128) * -(-(21 * 32) // 128)
+        rows = g.shape[0]
+        splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), _WGRAD_WGS // tiles))
+        if splitm > 1:
+            slabs = torch.empty(splitm, dwf.numel(), dtype=torch.float32, device=dy.device)
+            wd.splitm = splitm; wd.split_stride = dwf.numel(); wd.dW = slabs.data_ptr()
+            check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+            check(lib.ipoke_reduce_rows(ptr(slabs), ptr(dwf), splitm, dwf.numel(), s))
+        else:
+            wd.dW = dwf.data_ptr()
+            check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+        d_w = dwf.view(cout, 3, 7, 8, 4)[:, :, :, :7, :3].permute(0, 4, 1, 2, 3).contiguous()
+        assert tuple(d_w.shape) == wshape
+        return None, d_w, None
+
+
+def stem_folds(mod, x):
+    """Whether conv1 on this clip can run folded (the reference's shipped geometry; otherwise the generic in-place path)."""
+    from .first_stage import _STEM_FOLD
+    return (_STEM_FOLD and not _STEM_TRAIN_UNFOLDED and x.shape[1] == 3 and tuple(mod.k) == (3, 7, 7) and tuple(mod.stride) == (2, 2, 2)
+            and tuple(mod.pad) == (1, 3, 3) and x.shape[4] % 2 == 0 and mod.bias is None and not mod.snorm and not mod.transposed)
 
 
 def conv(mod, x, dtype, act=_lib.ACT_NONE, out_f32=False, src=None, w=None):
@@ -812,7 +894,11 @@ def encode(enc, x, eps):
     dt = enc.dtype
     B, C, T, H, W = x.shape
     st = (x.stride(0), x.stride(1), x.stride(2), x.stride(3), x.stride(4))
-    h = conv(enc.conv1, None, dt, src=(x, B, C, (T, H, W), st))
+    if stem_folds(enc.conv1, x):
+        y = _StemFn.apply(x, enc.conv1.weight, dt)
+        h = K.CL(y, B, ((T + 2 - 3) // 2 + 1, (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1), enc.conv1.cout)
+    else:
+        h = conv(enc.conv1, None, dt, src=(x, B, C, (T, H, W), st))
     h = norm(enc.bn1, h, dt, act=_lib.ACT_RELU)
     layers = [enc.layer1, enc.layer2, enc.layer3] + ([enc.layer4] if enc.stride4 is not None else []) + ([enc.layer5] if enc.has5 else [])
     for layer in layers:

@@ -112,6 +112,44 @@ if os.path.exists(probe_path):
               f"exchange+2 syncs {t[b + 3] - t[b + 2]}")
 
 
+# ---- inverse (sampling): x = unit^-1(y), two samples per workgroup, 4 layers x 8 strips
+yinv = torch.randn(M, ld, device=dev, generator=g)
+xinv = [torch.empty(M, ld, device=dev) for _ in range(4)]
+
+
+def inv_descs(u):
+    d4 = (_lib.McfDesc * 4)()
+    for k in range(4):
+        d = d4[k]
+        d.ld, d.C, d.B, d.cond, d.Cc, d.order, d.rows_per_block = ld, C, B, cond.data_ptr(), 128, k, 16
+        w = W[u][k]
+        d.W1, d.W2, d.bias2 = w["W1"].data_ptr(), w["W2"].data_ptr(), bias2.data_ptr()
+        if k in (1, 3):
+            d.post_log_scale, d.post_bias = pls.data_ptr(), pb.data_ptr()
+    d4[3].x = yinv.data_ptr(); d4[0].y = xinv[0].data_ptr()
+    return d4
+
+
+DI = [inv_descs(u) for u in range(NU)]
+D, D_fb = DI, D
+print(f"C={C} B={B}: fused unit inverse {run(lib.ipoke_macow_unit_inv):.1f} us")
+if os.path.exists(probe_path):
+    P.ipoke_macow_unit_inv.argtypes = [ctypes.POINTER(_lib.McfDesc), ctypes.c_int, ctypes.c_void_p]
+    st.zero_()
+    for u in range(NU):
+        assert P.ipoke_macow_unit_inv(DI[u], _lib.BF16, s) == 0
+    torch.cuda.synchronize()
+    t = st.cpu().tolist()
+    print(f"inverse: prologue done at t = 0; layer ends at {[t[49 + q] - t[0] for q in range(4)]}")
+    names = ["top", "cond rows", "gemm1+ELU", "sync", "gemm2", "sync"]
+    for step in range(8):
+        row = [t[1 + 6 * step + q] for q in range(6)]
+        nxt = t[1 + 6 * (step + 1)] if step < 7 else t[49]
+        d = [row[q + 1] - row[q] for q in range(5)] + [nxt - row[5]]
+        print(f"  layer D strip {step}: cond rows {d[0]:5d}  gemm1+ELU {d[1]:5d}  sync {d[2]:5d}  gemm2 {d[3]:5d}  sync {d[4]:5d}  coupling+sync {d[5]:5d}   total {nxt - row[0]:6d}")
+D = D_fb
+
+
 def contended(kind, fn, n=120):
     """Unit kernel timed while a second stream keeps the chip busy: 'hbm' = large device copies, 'mfma' = large bf16 GEMMs,
     'tn' = the weight-gradient GEMM of the coupling nets' conv2 (what the side stream runs during the backward pass)."""
