@@ -110,6 +110,7 @@ def _build_weight_operand(w, dtype, transposed_conv, inv_scale=None):
     return out, kc
 
 
+_WGRAD_SWAP = os.environ.get("IPOKE_WGRAD_SWAP", "1") != "0"       # developer A/B: narrow-output convolutions' weight gradient with swapped roles
 _STEM_TRAIN_UNFOLDED = os.environ.get("IPOKE_STEM_TRAIN_UNFOLDED", "0") == "1"      # developer A/B: conv1 of the 3-D encoder read in place when training
 _WGRAD_WGS = int(os.environ.get("IPOKE_WGRAD_WGS", "512"))       # workgroups a split-M weight gradient aims for (c4: 256 / 512 / 1024 / 2048 -> 156.5 / 151.0 / 156.5 / 160.6 ms: more slabs = more fp32 partial traffic)
 
@@ -253,7 +254,25 @@ class _ConvFn(torch.autograd.Function):
             wd.pd, wd.ph, wd.pw = pd
             wd.NB = N
             src = m.get("src")
-            if not m["transposed"]:
+            # A convolution onto a handful of channels (the decoder's last one, 64 -> 3 at 128 x 128): as written the GEMM would stream
+            # the wide input once per tap against a 3-column operand (1.21 ms at B = 20, 14 TFLOP/s).  With the roles swapped -- the
+            # weight gradient of the mirrored convolution from dY (8 padded channels) to X, G[c][t'][n] = sum_i X[i][c] dY[i + t' - pad][n],
+            # valid for stride 1 and 'same' padding -- X is the dense 64-column operand read ONCE and the narrow dY is the one gathered
+            # per tap; dW[n][c][t] = G[c][k - 1 - t][n].
+            swapped = (_WGRAD_SWAP and not m["transposed"] and src is None and ldg <= 16 and x_t.shape[1] >= 4 * ldg and tuple(st) == (1, 1, 1)
+                       and all(kk % 2 == 1 and pp == kk // 2 for kk, pp in zip(k, pd)))
+            if swapped:
+                ld = x_t.shape[1]
+                wd.Di, wd.Hi, wd.Wi = odhw
+                wd.Do, wd.Ho, wd.Wo = idhw
+                wd.A = g.data_ptr(); wd.a_f32 = 0
+                wd.a_sn = odhw[0] * odhw[1] * odhw[2] * ldg; wd.a_sd = odhw[1] * odhw[2] * ldg; wd.a_sh = odhw[2] * ldg
+                wd.a_sw = ldg; wd.a_sc = 1
+                wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = ldg
+                wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
+                wd.w_sn = taps * ldg; wd.w_st = ldg; wd.w_sc = 1
+                d_w_sw = torch.empty(cin, k[0], k[1], k[2], ldg, dtype=torch.float32, device=dy.device)
+            elif not m["transposed"]:
                 wd.Di, wd.Hi, wd.Wi = idhw
                 wd.Do, wd.Ho, wd.Wo = odhw
                 if src is not None:
@@ -287,14 +306,17 @@ class _ConvFn(torch.autograd.Function):
             tiles = -(-wd.Nout // 128) * -(-(taps * wd.Kc) // 128)
             rows = N * wd.Do * wd.Ho * wd.Wo
             splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), _WGRAD_WGS // tiles))
+            d_w_out = d_w_sw if swapped else d_w
             if splitm > 1:
-                slabs = torch.empty(splitm, d_w.numel(), dtype=torch.float32, device=dy.device)
-                wd.splitm = splitm; wd.split_stride = d_w.numel(); wd.dW = slabs.data_ptr()
+                slabs = torch.empty(splitm, d_w_out.numel(), dtype=torch.float32, device=dy.device)
+                wd.splitm = splitm; wd.split_stride = d_w_out.numel(); wd.dW = slabs.data_ptr()
                 check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
-                check(lib.ipoke_reduce_rows(ptr(slabs), ptr(d_w), splitm, d_w.numel(), s))
+                check(lib.ipoke_reduce_rows(ptr(slabs), ptr(d_w_out), splitm, d_w_out.numel(), s))
             else:
-                wd.dW = d_w.data_ptr()
+                wd.dW = d_w_out.data_ptr()
                 check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+            if swapped:
+                d_w.copy_(d_w_sw[..., :cout].flip(1, 2, 3).permute(4, 0, 1, 2, 3).reshape(w.shape))
             if sn is not None:                        # d_w is the gradient w.r.t. weight_orig / sigma: fold sigma's own gradient in
                 sig, snap, bws = sn
                 t_w = 1

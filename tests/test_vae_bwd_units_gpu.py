@@ -19,6 +19,15 @@ def _cl(x_nchw, dtype):
     return K.from_nchw(x_nchw.to(DEV), dtype)
 
 
+def _cl5(x, dtype):
+    """[N, C, (D,) H, W] -> CL (a 5-D tensor goes through the 4-D converter with the depth folded into the rows)."""
+    if x.dim() == 4:
+        return _cl(x, dtype)
+    N, C, D, H, W = x.shape
+    c = K.from_nchw(x.reshape(N, C, D * H, W).to(DEV), dtype)
+    return K.CL(c.t, N, (D, H, W), C)
+
+
 def _nchw(cl, dtype):
     return K.to_nchw(cl, dtype).cpu()
 
@@ -126,6 +135,36 @@ def test_conv_block_backward_vs_autograd(dtype):
         assert _rel(mod.weight.grad.cpu(), w.grad) <= tol * 3, transposed
         assert _rel(mod.bias.grad.cpu(), b.grad) <= tol * 3
         assert _rel(_nchw(K.CL(xc.t.grad, 2, (1, H, H), cin), dtype), x.grad) <= tol * 3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(64, 3, 3, 1, 24), (32, 5, 3, 3, 8), (128, 12, 5, 1, 16), (64, 8, 1, 1, 16)])
+def test_narrow_output_conv_weight_gradient_swapped(case, dtype, monkeypatch):
+    """A convolution onto a handful of channels (the decoder's 64 -> 3 at the full resolution): its weight gradient runs with the roles
+    swapped (the mirrored convolution from dY to X, first_stage_train._ConvFn.backward) -- against torch autograd and against the
+    direct form, for 2-D and 3-D kernels, 3 / 5 / 8 / 12 output channels, kernel 1 / 3 / 5."""
+    from ipoke_amd.first_stage import _Conv
+    cin, cout, k, kd, H = case
+    gen = torch.Generator().manual_seed(11)
+    D = 4 if kd > 1 else 1
+    mod = _Conv(cin, cout, (kd, k, k) if kd > 1 else k, 1, (kd // 2, k // 2, k // 2) if kd > 1 else k // 2, dims=3 if kd > 1 else 2).to(DEV)
+    w = mod.weight.detach().cpu().clone().requires_grad_(True)
+    x = torch.randn(2, cin, *((D, H, H) if kd > 1 else (H, H)), generator=gen)
+    fwd = F.conv3d if kd > 1 else F.conv2d
+    y = fwd(x, w, mod.bias.detach().cpu(), stride=1, padding=(kd // 2, k // 2, k // 2) if kd > 1 else k // 2)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    grads = {}
+    for swap in (True, False):
+        monkeypatch.setattr(FT, "_WGRAD_SWAP", swap)
+        mod.weight.grad = None
+        xc, dyc = _cl5(x, dtype), _cl5(dy, dtype)
+        xc.t.requires_grad_(True)
+        out = FT.conv(mod, xc, dtype)
+        out.t.backward(dyc.t)
+        grads[swap] = mod.weight.grad.detach().cpu().clone()
+        assert _rel(grads[swap], w.grad) <= TOL[dtype] * 3, (case, swap)
+    assert _rel(grads[True], grads[False]) <= (1e-5 if dtype == "f32" else 2e-3), case      # same products, another summation order
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
