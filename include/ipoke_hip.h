@@ -99,6 +99,10 @@ typedef struct {
    * multiple of 64).  The data gradient of a 1 x 1 convolution then reads the weight's own straight copy W[out][in] (it reduces over
    * `out`, the row index), so that weight needs no transposed operand (the coupling nets' conv2, macow_utils.py:270-281). */
   int32_t w_kmajor;
+  /* depth stride of the output scatter (c_scatter with Do > 1: position (n, od, oh, ow) goes to row c_row0 + n*c_sn + od*c_sd + oh*c_sh +
+   * ow*c_sw): the data gradient of a stride-2 Conv3d (motion_encoder.py:33-36, 80-91 layer transitions) run as one stride-1 convolution
+   * per output parity class -- (1 or 2) taps per strided dimension instead of all 3 of which half fall between the gradient's samples */
+  int64_t c_sd;
 } ipoke_conv_desc;
 
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);

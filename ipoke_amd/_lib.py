@@ -28,7 +28,7 @@ class ConvDesc(Structure):
         ("C", c_void_p), ("c_f32", c_int32), ("c_accumulate", c_int32), ("ldc", c_int64),
         ("c_coff", c_int32), ("c_cstride", c_int32), ("splitk", c_int32),
         ("c_scatter", c_int32), ("c_sn", c_int64), ("c_sh", c_int64), ("c_sw", c_int64), ("c_row0", c_int64),
-        ("row_scale", c_void_p), ("rs_images", c_int32), ("rs_stride", c_int32), ("w_kmajor", c_int32)]
+        ("row_scale", c_void_p), ("rs_images", c_int32), ("rs_stride", c_int32), ("w_kmajor", c_int32), ("c_sd", c_int64)]
 
 
 class WgradDesc(Structure):

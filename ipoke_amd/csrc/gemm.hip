@@ -39,7 +39,7 @@ struct NtParams {
   int splitk, kb_per_split, n_pad;
   int tiles_m, tiles_n, xa, xb;
   int prio;            // != 0: raise the waves' issue priority (s_setprio)
-  int c_scatter; long c_sn, c_sh, c_sw, c_row0;      // output row of position (n, oh, ow) when c_scatter (ipoke_conv_desc)
+  int c_scatter; long c_sn, c_sd, c_sh, c_sw, c_row0;      // output row of position (n, od, oh, ow) when c_scatter (ipoke_conv_desc)
   int w_kmajor;        // 1: W is [Ktot][ldw] -- element (k, n) at W[k * ldw + n] (1x1 kernels: the straight copy of a weight used by its own data gradient)
   const float* row_scale; int rs_images, rs_stride;  // accumulators of image n are multiplied by row_scale[(n / rs_images) * rs_stride] before the bias
 #ifdef IPOKE_GEMM_STAMPS
@@ -187,18 +187,20 @@ __device__ __forceinline__ float fast_act(int act, float x) {
 __device__ __forceinline__ long out_row(const NtParams& p, int m) {
   if (!p.c_scatter) return m;
   const GeomDev& g = p.g;
-  int ow, oh, n;
+  int ow, oh, od, n;
   if (g.pow2) {
     ow = m & ((1 << g.lWo) - 1);
     const int t1 = m >> g.lWo;
     oh = t1 & ((1 << g.lHo) - 1);
-    n = t1 >> (g.lHo + g.lDo);
+    const int t2 = t1 >> g.lHo;
+    od = t2 & ((1 << g.lDo) - 1);
+    n = t2 >> g.lDo;
   } else {
     const int t1 = m / g.Wo; ow = m - t1 * g.Wo;
     const int t2 = t1 / g.Ho; oh = t1 - t2 * g.Ho;
-    n = t2 / g.Do;
+    n = t2 / g.Do; od = t2 - n * g.Do;
   }
-  return p.c_row0 + (long)n * p.c_sn + (long)oh * p.c_sh + (long)ow * p.c_sw;
+  return p.c_row0 + (long)n * p.c_sn + (long)od * p.c_sd + (long)oh * p.c_sh + (long)ow * p.c_sw;
 }
 
 // per-image-group scale of the accumulators (ipoke_conv_desc.row_scale): 1/sigma_t of the frame the image belongs to
@@ -2824,10 +2826,10 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   p.C = d->C; p.c_f32 = d->c_f32; p.c_acc = d->c_accumulate; p.ldc = d->ldc; p.c_coff = d->c_coff;
   p.c_cstride = d->c_cstride <= 0 ? 1 : d->c_cstride;
   p.splitk = d->splitk < 1 ? 1 : d->splitk;
-  p.c_scatter = d->c_scatter; p.c_sn = d->c_sn; p.c_sh = d->c_sh; p.c_sw = d->c_sw; p.c_row0 = d->c_row0;
+  p.c_scatter = d->c_scatter; p.c_sn = d->c_sn; p.c_sd = d->c_sd; p.c_sh = d->c_sh; p.c_sw = d->c_sw; p.c_row0 = d->c_row0;
   p.row_scale = d->row_scale; p.rs_images = d->rs_images; p.rs_stride = d->rs_stride < 1 ? 1 : d->rs_stride;
   if (d->row_scale) IPK_REQUIRE(p.splitk == 1 && !d->c_accumulate && d->rs_images >= 1, "row scale: plain stores, rs_images >= 1");
-  if (d->c_scatter) IPK_REQUIRE(p.splitk == 1 && !d->dact && !d->c_accumulate && p.g.Do == 1 && d->c_row0 >= 0, "output scatter: plain stores of a 2-D map");
+  if (d->c_scatter) IPK_REQUIRE(p.splitk == 1 && !d->dact && !d->c_accumulate && d->c_row0 >= 0 && (p.g.Do == 1 || d->c_sd > 0), "output scatter: plain stores; maps with depth need c_sd");
   p.n_pad = d->Nout;
   if (!d->c_f32 && p.splitk == 1) {
     const long lim = d->ldc - d->c_coff;
@@ -2854,12 +2856,25 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   const bool square = p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 && p.splitk == 1;
   TimedScope ts(square ? IPOKE_TAG_NT_SQUARE : IPOKE_TAG_CONV_BASE, s);
   p.w_kmajor = d->w_kmajor;
+  static const bool clog = getenv("IPOKE_CONV_LOG") != nullptr;      // developer probe: every call timed on its own (serialises the stream)
+  hipEvent_t le0 = nullptr, le1 = nullptr;
+  if (clog) { IPK_HIP(hipEventCreate(&le0)); IPK_HIP(hipEventCreate(&le1)); IPK_HIP(hipEventRecord(le0, s)); }
   if (p.w_kmajor) {
     IPK_REQUIRE(dtype == IPOKE_BF16, "K-major weights: bf16 only (the f32 mode keeps its transposed shadows)");
     g_last_kernel = IPOKE_KERNEL_IGEMM;
     rc = dispatch_nn(p, s);
   } else {
     rc = dtype == IPOKE_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
+  }
+  if (clog) {
+    IPK_HIP(hipEventRecord(le1, s)); IPK_HIP(hipEventSynchronize(le1));
+    float ms = 0.f; IPK_HIP(hipEventElapsedTime(&ms, le0, le1));
+    const double st2 = p.g.transposed ? (double)p.g.sd * p.g.sh * p.g.sw : 1.0;
+    fprintf(stderr, "CONV kern=%d tr=%d NB=%d in=%dx%dx%d out=%dx%dx%d k=%dx%dx%d s=%d,%d,%d Kc=%d Nout=%d a_f32=%d c_f32=%d splitk=%d scat=%d rs=%d M=%ld GF=%.2f us=%.1f\n",
+            g_last_kernel, d->transposed, d->NB, d->Di, d->Hi, d->Wi, d->Do, d->Ho, d->Wo, d->kd, d->kh, d->kw, d->sd, d->sh, d->sw, d->Kc_real, d->Nout,
+            d->a_f32, d->c_f32, p.splitk, d->c_scatter, d->row_scale != nullptr, (long)p.g.M,
+            2e-9 * p.g.M * d->Nout * (double)p.g.taps * d->Kc_real / st2, ms * 1e3);
+    (void)hipEventDestroy(le0); (void)hipEventDestroy(le1);
   }
   if (ts.slot >= 0) {          // algorithmic work of this launch (timing runs only)
     const GeomDev& g = p.g;

@@ -158,6 +158,58 @@ def _conv_transpose_phases(x, wop, kc, cout, dt, bias, act, out_f32, row_scale=N
     return K.CL(y, N, (1, Ho, Wo), cout)
 
 
+_DG_PHASES = os.environ.get("IPOKE_NO_DGRAD_PHASES", "0") != "1"     # developer A/B: strided 3 x 3 x 3 data gradients as one 27-tap launch
+_dg_index = {}
+
+
+def dgrad_phases_ok(k, st, pd, idhw, odhw):
+    return (_DG_PHASES and tuple(k) == (3, 3, 3) and tuple(pd) == (1, 1, 1) and all(s_ in (1, 2) for s_ in st) and max(st) == 2
+            and all(o == (i - 1) // s_ + 1 for i, o, s_ in zip(idhw, odhw, st)))
+
+
+def _dgrad_phases(gcl, w, cin, idhw, st, dt):
+    """Data gradient of a Conv3d(cin -> cout, 3, stride in {1, 2}^3, padding 1) (the 3-D encoder's layer transitions,
+    motion_encoder.py:80-91): dX[i] = sum over (o, t) with o * s + t - 1 = i of W[:, :, t]^T dY[o].  Along a strided dimension an even
+    position sees ONE tap (t = 1, o = i / 2) and an odd one TWO (t = 2 at o = (i - 1) / 2, t = 0 at o + 1); along an unstrided one all three
+    (flipped).  One stride-1 convolution over dY per parity class, its taps a contiguous slice of ONE permuted operand, its outputs
+    scattered to the class's positions (ipoke_conv_desc.c_scatter / c_sd) -- instead of 27 taps at every position of which 1 / 8 (or
+    1 / 2) fall on a sample of dY."""
+    N, odhw, cout = gcl.N, gcl.dhw, gcl.C
+    kc = gcl.t.shape[1]
+    sets = [([[2, 1, 0]] if s_ == 1 else [[1], [2, 0]]) for s_ in st]              # per dimension: taps of each parity class, in window order
+    key = (w.device, tuple(st))
+    plan = _dg_index.get(key)
+    if plan is None:
+        order, phases = [], []
+        for rd, td in enumerate(sets[0]):
+            for rh, th in enumerate(sets[1]):
+                for rw, tw in enumerate(sets[2]):
+                    phases.append(((rd, rh, rw), (len(td), len(th), len(tw)), len(order)))
+                    order += [(a * 3 + b) * 3 + c for a in td for b in th for c in tw]
+        plan = _dg_index[key] = (torch.tensor(order, device=w.device), phases)
+    idx, phases = plan
+    wt = w.detach().permute(1, 2, 3, 4, 0).reshape(cin, 27, cout)                      # [cin][tap][cout]
+    wop = torch.zeros(cin, 27, kc, dtype=_tdt(dt), device=w.device) if kc != cout else torch.empty(cin, 27, kc, dtype=_tdt(dt), device=w.device)
+    wop[:, :, :cout] = wt.index_select(1, idx)
+    wop = wop.view(cin, 27 * kc)
+    Di, Hi, Wi = idhw
+    ld = K.round_up(cin, K.e16(dt))
+    dx = torch.empty(N * Di * Hi * Wi, ld, dtype=_tdt(dt), device=w.device)
+    if ld != cin:
+        dx[:, cin:].zero_()
+    mul = tuple(s_ for s_ in st)
+    for (rd, rh, rw), (nd, nh, nw), first in phases:
+        r = (rd, rh, rw)
+        ext = tuple((i + 1) // 2 if (s_ == 2 and rr == 0) else (i // 2 if s_ == 2 else i) for i, s_, rr in zip(idhw, st, r))
+        if min(ext) == 0:
+            continue
+        pad = tuple(1 if s_ == 1 else 0 for s_ in st)
+        ntap = nd * nh * nw
+        K.conv(gcl, wop[:, first * kc:(first + ntap) * kc], kc, cin, (nd, nh, nw), (1, 1, 1), pad, dt, out=dx, odhw=ext,
+               scatter=(Di * Hi * Wi, mul[0] * Hi * Wi, mul[1] * Wi, mul[2], (rd * Hi + rh) * Wi + rw))
+    return K.CL(dx, N, tuple(idhw), cin)
+
+
 # ------------------------------------------------------------------------------------------------ convolution
 class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, w) + bias).  ``x`` is the CL tensor [M, ld] (or None with ``meta['src']`` an fp32 image)."""
@@ -336,7 +388,9 @@ class _ConvFn(torch.autograd.Function):
         if x_t is not None and ctx.needs_input_grad[0]:
             inv = None if sn is None else sn[0][1:]
             gcl = K.CL(g, N, odhw, cout)
-            if not m["transposed"]:
+            if not m["transposed"] and sn is None and snf is None and w.dim() == 5 and dgrad_phases_ok(k, st, pd, idhw, odhw):
+                dx = _dgrad_phases(gcl, w, cin, idhw, st, dt)
+            elif not m["transposed"]:
                 # conv weight [cout, cin, k] read as a ConvTranspose weight [in=cout, out=cin, k]
                 wop, kc = _weight_operand(w.detach(), dt, True, inv, cacheable=m.get("w_param", False), scope=m.get("w_scope"), owner=w)
                 opad = tuple(i - ((o - 1) * s_ - 2 * p + kk) for i, o, s_, p, kk in zip(idhw, odhw, st, pd, k))

@@ -103,7 +103,11 @@ def conv(x, w_op, kc, cout, k, stride, pad, dtype, bias=None, act=_lib.ACT_NONE,
     d.C = y.data_ptr(); d.ldc = y.shape[1]
     if scatter is not None:
         assert out is not None
-        d.c_scatter = 1; d.c_sn, d.c_sh, d.c_sw, d.c_row0 = scatter
+        d.c_scatter = 1
+        if len(scatter) == 5:                      # maps with depth: (c_sn, c_sd, c_sh, c_sw, c_row0)
+            d.c_sn, d.c_sd, d.c_sh, d.c_sw, d.c_row0 = scatter
+        else:
+            d.c_sn, d.c_sh, d.c_sw, d.c_row0 = scatter
     if row_scale is not None:
         d.row_scale = row_scale[0].data_ptr(); d.rs_images = int(row_scale[1]); d.rs_stride = int(row_scale[2])
     ops.conv_forward(d, dtype)

@@ -168,6 +168,37 @@ def test_narrow_output_conv_weight_gradient_swapped(case, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [((2, 2, 2), (4, 16, 16), 16, 24), ((2, 1, 1), (6, 8, 8), 24, 16), ((2, 2, 2), (5, 9, 10), 8, 12),
+                                  ((1, 2, 2), (3, 8, 12), 16, 16)])
+def test_strided_conv3d_data_gradient_by_parity_phases(case, dtype, monkeypatch):
+    """Data gradient of a 3 x 3 x 3 / padding 1 Conv3d with stride 2 along some dimensions (motion_encoder.py:80-91): one stride-1
+    convolution per output parity class scattered into dX (ipoke_conv_desc.c_sd) -- against torch autograd and against the single
+    27-tap launch, even and odd extents, strides (2,2,2) / (2,1,1) / (1,2,2)."""
+    from ipoke_amd.first_stage import _Conv
+    st, dhw, cin, cout = case
+    gen = torch.Generator().manual_seed(13)
+    mod = _Conv(cin, cout, (3, 3, 3), st, (1, 1, 1), bias=False, dims=3).to(DEV)
+    w = mod.weight.detach().cpu().clone().requires_grad_(True)
+    x = torch.randn(2, cin, *dhw, generator=gen, requires_grad=True)
+    y = F.conv3d(x, w, None, stride=st, padding=1)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    got = {}
+    for phases in (True, False):
+        monkeypatch.setattr(FT, "_DG_PHASES", phases)
+        mod.weight.grad = None
+        xc = _cl5(x.detach(), dtype); xc.t.requires_grad_(True)
+        out = FT.conv(mod, xc, dtype)
+        assert tuple(out.dhw) == tuple(y.shape[2:])
+        out.t.backward(_cl5(dy, dtype).t)
+        dx = K.CL(xc.t.grad, 2, dhw, cin)
+        got[phases] = _nchw(dx, dtype)
+        assert _rel(got[phases], x.grad) <= TOL[dtype] * 3, (case, phases)
+        assert _rel(mod.weight.grad.cpu(), w.grad) <= TOL[dtype] * 3
+    assert _rel(got[True], got[False]) <= (1e-5 if dtype == "f32" else 2e-3), case
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_gru_cell_backward_vs_autograd(dtype):
     from ipoke_amd.first_stage import ConvGRUCell
     from oracle import vae_ref
