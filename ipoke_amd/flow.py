@@ -18,6 +18,7 @@ There is no CPU path: forward/reverse raise if the HIP library or a GPU is missi
 import ctypes
 from ctypes import byref, c_char_p, c_int32, c_int64, c_void_p, create_string_buffer
 
+import os
 import torch
 import torch.nn as nn
 
@@ -126,6 +127,8 @@ class FlowEngine:
             for k in [k for k in self._ws if k[1] == key[1]]:
                 del self._ws[k]
             self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
+            if os.environ.get("IPOKE_POISON_WS", "0") == "1":       # developer probe: a read before the first write shows up as NaN
+                self._ws[key].view(torch.int16)[: n // 2].fill_(0x7FC0)
         return self._ws[key]
 
     def _staging(self, B):
