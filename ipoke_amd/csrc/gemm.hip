@@ -1781,6 +1781,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // per image.  Taps are the kh x kw window at offsets a - ph (ph - a for the data gradient), all within the one-pixel halo.
 // 8 waves = 4 pixel-row groups x 2 halves of 32 output channels; fragments beyond Nout are skipped (the image head computes 16 of
 // 64 columns); the epilogue runs from the accumulators.
+#ifndef IPOKE_C64_ABL
+// probe builds (scripts/probe_c64.py): 1 no MFMA, 2 no epilogue, 3 no image stream.  Round 4, 64 -> 64 at 128 x 128, 480 images: 937 us
+// full, 681 / 663 / 756 us ablated -- the three phases of a patch (wait for the image 1.5 us, MFMAs 2.2 us, epilogue 2.4 us) run one after
+// the other; deferring the epilogue by one image (its stores issued in front of the next patch's MFMAs) measured 964 us: not the stores'
+// acknowledgement at the loop's vmcnt(0).
+#define IPOKE_C64_ABL 0
+#endif
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(const NtParams p) {
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
@@ -1855,7 +1862,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ch = v % nch;
     wait_vmcnt<0>();                               // this image (and, the first time, the filter) has landed
     __builtin_amdgcn_s_barrier();                  // ... everybody's share of it; the other buffer is no longer read
+#if IPOKE_C64_ABL != 3
     issue_image(next_image(v), buf ^ 1);
+#endif
     if (ch == 0) {
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
@@ -1879,14 +1888,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(wb + (b_rd[j] ^ (hs * 64)));
+#if IPOKE_C64_ABL == 1
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) asm volatile("" :: "v"(fa[i]), "v"(fb[0]), "v"(fb[1]));
+#else
 #pragma unroll
         for (int i = 0; i < MREP; ++i) {
           GEMM_MMA(fa[i], fb[0], acc[i][0]);
           if (nfrag > 1) GEMM_MMA(fa[i], fb[1], acc[i][1]);
         }
+#endif
       }
     }
     if (ch + 1 < nch) continue;
+#if IPOKE_C64_ABL == 2
+    if (v >= 0) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1])); continue; }
+#endif
     // ---- epilogue straight from the accumulators: acc[i][j][e] = pixel (wm*4 + i, lane & 15), channel wn*32 + 16 j + 4 (lane >> 4) + e
     const int tile = v / nch;
     const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, img = t2 / tiles_y;
