@@ -5,6 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from ipoke_amd import _lib, ops
+from ipoke_amd._lib import check
 from ipoke_amd.utils.detfill import deterministic_fill_
 from oracle import flow_ref
 from tests.conftest import t
@@ -441,3 +442,47 @@ def test_kmajor_gemm(M, N, K, mask):
     err = (c.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
     print(f"kmajor gemm {M}x{N}x{K} mask={mask}: rel err {err:.3e}")
     assert err <= 1.2e-2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_copy_cols(dtype):
+    """ipoke_copy_cols: dst[m][0:C] = src[m][0:C] with different row pitches and a column offset on the destination (the activated
+    conditioning map behind conv2's columns of a coupling net's hidden tile, condition_nice); everything else stays untouched."""
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    e16 = 4 if dtype == "f32" else 8
+    g = torch.Generator().manual_seed(5)
+    M, C, lds, ldd, off = 1280, 16 * e16, 20 * e16, 40 * e16, 8 * e16
+    src = torch.randn(M, lds, generator=g).to(td).to(DEV)
+    dst = torch.full((M, ldd), 3.0, dtype=td, device=DEV)
+    before = dst.clone()
+    esz = src.element_size()
+    check(_lib.lib().ipoke_copy_cols(src.data_ptr(), lds, dst.data_ptr() + off * esz, ldd, C, M, ops._dt(dtype), _lib.current_stream()))
+    assert torch.equal(dst[:, off:off + C], src[:, :C])
+    assert torch.equal(dst[:, :off], before[:, :off]) and torch.equal(dst[:, off + C:], before[:, off + C:])
+    # misaligned widths are refused, not rounded
+    assert _lib.lib().ipoke_copy_cols(src.data_ptr(), lds, dst.data_ptr(), ldd, C - 1, M, ops._dt(dtype), _lib.current_stream()) != 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_output_scatter_with_depth(dtype):
+    """ipoke_conv_desc.c_scatter with the depth stride c_sd: a stride-1 3-D convolution whose outputs go to every second position of a
+    larger map (one parity class of a strided convolution's data gradient) -- against the dense result placed by index; the other
+    positions keep their contents."""
+    from ipoke_amd import nn as K
+    g = torch.Generator().manual_seed(9)
+    N, cin, cout, (D, H, W) = 2, 16, 24, (3, 5, 6)
+    x = torch.randn(N * D * H * W, cin, generator=g)
+    w = torch.randn(cout, cin, 2, 2, 1, generator=g) / (cin * 4) ** 0.5
+    xc = K.CL(x.to(DEV).to(ops.torch_dtype(dtype)), N, (D, H, W), cin)
+    wop, kc = K.weight_operand(w.to(DEV), dtype)
+    dense = K.conv(xc, wop, kc, cout, (2, 2, 1), (1, 1, 1), (0, 0, 0), dtype, odhw=(D, H, W))      # windows overhanging the input read zeros
+    Do, Ho, Wo = 2 * D, 2 * H, 2 * W
+    out = torch.full((N * Do * Ho * Wo, dense.t.shape[1]), 5.0, dtype=dense.t.dtype, device=DEV)
+    rd, rh, rw = 1, 0, 1
+    K.conv(xc, wop, kc, cout, (2, 2, 1), (1, 1, 1), (0, 0, 0), dtype, out=out, odhw=(D, H, W),
+           scatter=(Do * Ho * Wo, 2 * Ho * Wo, 2 * Wo, 2, (rd * Ho + rh) * Wo + rw))
+    o5 = out.view(N, Do, Ho, Wo, -1)
+    assert torch.equal(o5[:, rd::2, rh::2, rw::2, :cout], dense.t.view(N, D, H, W, -1)[..., :cout])
+    mask = torch.ones(N, Do, Ho, Wo, dtype=torch.bool, device=DEV)
+    mask[:, rd::2, rh::2, rw::2] = False
+    assert (o5[mask] == 5.0).all()
