@@ -549,6 +549,10 @@ int ipoke_conv_weight_operand(const float* w, int cout, int cin, int taps, int t
 typedef struct { int32_t B, T, L, Cx, Ch, H, W; } ipoke_gru_desc;
 int64_t ipoke_gru_workspace_bytes(const ipoke_gru_desc* d, int dtype);
 /* out [T][M][ldo]: the last cell's hidden state after every step.  The workspace keeps every operand for ipoke_gru_unroll_backward. */
+/* Forward unroll as ONE launch (a workgroup per sample runs the T x L recurrence on LDS-resident operands; bf16, 8 x 8 map, Cx = Ch in
+ * {32, 64}) -- the default where it applies; the test hook switches to the launch-per-phase form (0), back (1) or to the IPOKE_GRU_FUSED
+ * environment default (< 0).  Both forms fill the same workspace for ipoke_gru_unroll_backward. */
+int ipoke_gru_set_fused(int mode);
 int ipoke_gru_unroll_forward(const ipoke_gru_desc* d, const void* x0, int ldx, const void* h0, int ldh, const float* const* weights,
                              void* workspace, void* out, int ldo, int dtype, void* stream);
 /* d_out [T][M][ldo] -> dweights (the layouts of `weights`, written), d_x0 [M][Cx] and d_h0 [M][Ch] (fp32; d_h0 summed over the cells) */

@@ -112,6 +112,7 @@ SIGNATURES = {
     "ipoke_conv_forward_repeat": (c_int, [POINTER(ConvDesc), c_int, c_int, _P]),
     "ipoke_set_dispatch_override": (c_int, [c_char_p, c_int]),
     "ipoke_last_conv_kernel": (c_int, []),
+    "ipoke_gru_set_fused": (c_int, [c_int]),
     "ipoke_gru_workspace_bytes": (c_int64, [POINTER(GruDesc), c_int]),
     "ipoke_gru_unroll_forward": (c_int, [POINTER(GruDesc), _P, c_int, _P, c_int, POINTER(c_void_p), _P, _P, c_int, c_int, _P]),
     "ipoke_gru_unroll_backward": (c_int, [POINTER(GruDesc), _P, c_int, _P, POINTER(c_void_p), _P, _P, c_int, _P]),

@@ -12,7 +12,10 @@
 // h * r into the second convolution's operand.  Every operand of every (cell, step) is kept (T * L * ~0.8 MB at B = 20): the weight and
 // bias gradients of a cell are then ONE weight-gradient GEMM and one column sum over the rows of all T steps (the weights are shared by
 // the steps), issued after the serial data-gradient chain.
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -119,6 +122,221 @@ __global__ void gru_add2_kernel(const T* __restrict__ a, int lda, const T* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused forward unroll
+// The whole T x L recurrence of ONE sample in one workgroup (the cells couple positions of a sample, never samples): 4 launches of
+// 4-8 us per (cell, step) -- two implicit GEMMs of 0.05-0.3 GFLOP at launch latency and two element-wise kernels -- become two matrix-
+// core phases on LDS-resident operands.  8 x 8 map, bf16, Cx = Ch = CH in {32, 64}.  Per (cell l, step t), tile set l & 1:
+//   P0  xh = [x | h_l(t-1)] staged (x of cell 0 is the constant input; of cell l > 0 it was written by cell l - 1 of this step), the
+//       operand rows saved for the backward pass (XH, x-half of XHR)
+//   P1  ur = conv3x3(xh) + b  ->  u = sigmoid(ur[:CH]), hr = h * sigmoid(ur[CH:]) into the xhr tile; UR, U, hr-half of XHR saved
+//   P2  o = conv3x3(xhr) + b  ->  h' = h (1 - u) + tanh(o) u  ->  the cell's state, the x-halves of cell l + 1's tiles, `out` for the last
+// Every value is rounded to bf16 where the unfused path stores it (ur, u, hr, o, h'), so that both paths compute the same function of
+// the same rounded operands (the fp32 sums differ in their order only).  Weight fragments: one 16-column fragment of the convolution
+// per wave and all 9 * Kc / 32 K steps in registers, requested for the next phase as soon as the current phase's MFMAs are done.
+// fp32 conv weight [N][Kc][3][3] -> the fused kernel's operand: fragment (column block nf, K step q) is ONE contiguous KB, lane l of it
+// the 8 consecutive k = 32 q + 8 (l >> 4) .. of output column 16 nf + (l & 15), k = tap * Kc + channel.  (Read from the row-major
+// [N][9 Kc] operand a wave's fragment load touched 16 rows of 64 bytes each: 16 cache lines per instruction instead of 8 full ones.)
+__global__ void gru_tile_operand_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Kc) {
+  const long total = (long)N * 9 * Kc;
+  const int nfr = 9 * Kc / 32;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63); const long fq = i >> 9;
+    const int q = (int)(fq % nfr), nf = (int)(fq / nfr);
+    const int o = nf * 16 + (lane & 15), kk = q * 32 + (lane >> 4) * 8 + e;
+    const int t = kk / Kc, c = kk - t * Kc;
+    out[i] = (bf16_t)w[((long)o * Kc + c) * 9 + t];
+  }
+}
+
+struct GruFusedPtrs { const bf16_t* w_ur[16]; const bf16_t* w_o[16]; const float* b_ur[16]; const float* b_o[16]; };
+template <typename T> struct GPack4;
+template <> struct GPack4<bf16_t> { typedef __attribute__((ext_vector_type(4))) __bf16 type; };
+template <int CH>
+__global__ __launch_bounds__(512) void gru_fused_fwd_kernel(const bf16_t* __restrict__ x0, int ldx, const bf16_t* __restrict__ h0, int ldh,
+                                                            const GruFusedPtrs P,
+                                                            bf16_t* __restrict__ XH, bf16_t* __restrict__ XHR, bf16_t* __restrict__ UR,
+                                                            bf16_t* __restrict__ U, bf16_t* __restrict__ O, bf16_t* __restrict__ out, int ldo,
+                                                            long M, int Tn, int L) {
+  typedef bf16_t T;
+  typedef typename ET<T>::frag frag_t;
+  typedef typename GPack4<T>::type pack_t;
+  constexpr int KC = 2 * CH, KS = KC / 32, NFR = 9 * KS;            // K steps per tap, weight fragments per wave and convolution
+  constexpr int NA = NFR / 2, NB = NFR - NA;                        // the two K halves of a convolution's fragments
+  constexpr int PK = KC * 2 + 32;                                   // tile row pitch in bytes: 2 (mod 4) 16-byte units (mcf_unit.hip: kTilePad)
+  constexpr int NF1 = 2 * CH / 16, RG1 = 8 / NF1, RT1 = 4 / RG1;    // conv_ur: column fragments, row groups, row tiles per wave
+  constexpr int NF2 = CH / 16, RG2 = 8 / NF2, RT2 = 4 / RG2;        // conv_o
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tiles = smem;                                      // [2 sets][xh, xhr][65 rows][PK]
+  T* hst = reinterpret_cast<T*>(tiles + 4 * 65 * PK);               // [L][64][CH] state of the cells
+  T* x0s = hst + (long)L * 64 * CH;                                 // [64][CH]
+  T* us = x0s + 64 * CH;                                            // [64][CH] update gate of the current cell
+  float* bs = reinterpret_cast<float*>(us + 64 * CH);               // [L][3 CH] biases: b_ur (2 CH), b_o (CH)
+  const int tid = threadIdx.x;
+  const long row0 = (long)blockIdx.x * 64;
+
+  // one-time staging: zero tiles (zero rows stay zero), the constant input, the initial state of every cell, the biases
+  for (int i = tid; i < 4 * 65 * PK / 16; i += 512) reinterpret_cast<u32x4*>(tiles)[i] = u32x4{0u, 0u, 0u, 0u};
+  constexpr int CV = CH / 8;                                         // 16-byte chunks per half row
+  for (int i = tid; i < 64 * CV; i += 512) {
+    const int p = i / CV, c = (i - p * CV) * 8;
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(x0 + (row0 + p) * ldx + c);
+    const u32x4 hv = *reinterpret_cast<const u32x4*>(h0 + (row0 + p) * ldh + c);
+    *reinterpret_cast<u32x4*>(x0s + p * CH + c) = xv;
+    for (int l = 0; l < L; ++l) *reinterpret_cast<u32x4*>(hst + ((long)l * 64 + p) * CH + c) = hv;
+  }
+  for (int i = tid; i < L * 3 * CH; i += 512) {
+    const int l = i / (3 * CH), c = i - l * 3 * CH;
+    bs[i] = c < 2 * CH ? P.b_ur[l][c] : P.b_o[l][c - 2 * CH];
+  }
+  // Weight fragments: a wave owns ONE 16-column fragment of a convolution and all NFR K steps; they stream through two register sets of
+  // half a convolution each -- while the MFMAs of one half run, the other set is in flight (the next half of this convolution, or the first
+  // half of the next one), so that the 147-295 KB a convolution reads from L2 per (cell, step) are requested a whole half ahead.
+  frag_t wa[NA], wb[NB];
+  auto wbase = [&](const T* wop, int nfrag_col, int lane) { return wop + (long)nfrag_col * NFR * 512 + lane * 8; };   // gru_tile_operand_kernel
+  auto load_a = [&](const T* base) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) wa[q] = *reinterpret_cast<const frag_t*>(base + q * 512);
+  };
+  auto load_b = [&](const T* base) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) wb[q] = *reinterpret_cast<const frag_t*>(base + (NA + q) * 512);
+  };
+  // address of the tile row feeding position p through tap (ty, tx) of the padded 3 x 3 window
+  auto tap_row = [&](const unsigned char* tile, int p, int tap) {
+    const int ty = tap / 3, tx = tap - 3 * ty;
+    const int yy = (p >> 3) + ty - 1, xx = (p & 7) + tx - 1;
+    return ((unsigned)yy < 8u && (unsigned)xx < 8u) ? tile + (yy * 8 + xx) * PK : tile + 64 * PK;
+  };
+  load_a(wbase(P.w_ur[0], (tid >> 6) % NF1, tid & 63));
+  __syncthreads();
+#pragma unroll 1
+  for (int t = 0; t < Tn; ++t) {
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+      // lane indices from an opaque copy of the thread id: keeps the phases' addresses out of the loops' live-in set (they would sit next
+      // to the weight registers for the whole kernel -- mcf_unit.hip)
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int lane = tl & 63, wave = tl >> 6, r = lane & 15, gq = lane >> 4;
+      const int wn1 = wave % NF1, rg1 = wave / NF1, wn2 = wave % NF2, rg2 = wave / NF2;
+      unsigned char* xh = tiles + (l & 1) * 2 * 65 * PK;
+      unsigned char* xhr = xh + 65 * PK;
+      unsigned char* nxh = tiles + ((l + 1) & 1) * 2 * 65 * PK;       // tiles of cell l + 1
+      unsigned char* nxhr = nxh + 65 * PK;
+      T* hl = hst + (long)l * 64 * CH;
+      const long cell = ((long)l * Tn + t) * M + row0;                // first row of this (cell, step, sample) in the per-cell buffers
+      const T* w_ur = wbase(P.w_ur[l], wn1, lane);
+      const T* w_o = wbase(P.w_o[l], wn2, lane);
+      const int ln = l + 1 < L ? l + 1 : 0;
+      const bool more = l + 1 < L || t + 1 < Tn;
+      const T* w_next = wbase(P.w_ur[ln], wn1, lane);
+      // one convolution: K half A (already requested) while half B is requested, then half B while `next_a` (the following convolution's
+      // half A) is requested
+      auto conv = [&](const unsigned char* tile, auto rt_c, int rowt0, const T* wthis, const T* next_a, bool have_next, f32x4* acc) {
+        constexpr int RT = decltype(rt_c)::value;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        load_b(wthis);
+#pragma unroll
+        for (int q = 0; q < NFR; ++q) {
+          const int tap = q / KS, ks = q - tap * KS;
+          if (q == NA) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (have_next) load_a(next_a);
+          }
+          frag_t fa[RT];
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+            fa[i] = *reinterpret_cast<const frag_t*>(tap_row(tile, (rowt0 + i) * 16 + r, tap) + gq * 16 + ks * 64);
+#pragma unroll
+          for (int i = 0; i < RT; ++i) mma64(fa[i], q < NA ? wa[q < NA ? q : 0] : wb[q < NA ? 0 : q - NA], acc[i]);
+        }
+      };
+      // ---- P0
+      for (int i = tl; i < 64 * CV; i += 512) {
+        const int p = i / CV, c = (i - p * CV) * 8;
+        u32x4 xv;
+        if (l == 0) {
+          xv = *reinterpret_cast<const u32x4*>(x0s + p * CH + c);
+          *reinterpret_cast<u32x4*>(xh + p * PK + c * 2) = xv;
+          *reinterpret_cast<u32x4*>(xhr + p * PK + c * 2) = xv;
+        } else {
+          xv = *reinterpret_cast<const u32x4*>(xh + p * PK + c * 2);
+        }
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(hl + p * CH + c);
+        *reinterpret_cast<u32x4*>(xh + p * PK + (CH + c) * 2) = hv;
+        *reinterpret_cast<u32x4*>(XH + (cell + p) * KC + c) = xv;
+        *reinterpret_cast<u32x4*>(XH + (cell + p) * KC + CH + c) = hv;
+        *reinterpret_cast<u32x4*>(XHR + (cell + p) * KC + c) = xv;
+      }
+      __syncthreads();
+      // ---- P1: ur = conv3x3([x | h]) + b
+      {
+        f32x4 acc[RT1];
+        conv(xh, std::integral_constant<int, RT1>(), rg1 * RT1, w_ur, w_o, true, acc);
+        const int n = wn1 * 16 + 4 * gq;                                // columns n .. n + 3 of ur
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bs + l * 3 * CH + n);
+#pragma unroll
+        for (int i = 0; i < RT1; ++i) {
+          const int p = (rg1 * RT1 + i) * 16 + r;
+          pack_t urb;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) urb[q] = ET<T>::from_f32(acc[i][q] + b4[q]);
+          *reinterpret_cast<pack_t*>(UR + (cell + p) * KC + n) = urb;
+          if (n < CH) {
+            pack_t ub;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ub[q] = ET<T>::from_f32(act_apply(IPOKE_ACT_SIGMOID, ET<T>::to_f32(urb[q])));
+            *reinterpret_cast<pack_t*>(us + p * CH + n) = ub;
+            *reinterpret_cast<pack_t*>(U + (cell + p) * CH + n) = ub;
+          } else {
+            const int c = n - CH;
+            const pack_t hb = *reinterpret_cast<const pack_t*>(hl + p * CH + c);
+            pack_t hrb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              hrb[q] = ET<T>::from_f32(ET<T>::to_f32(hb[q]) * act_apply(IPOKE_ACT_SIGMOID, ET<T>::to_f32(urb[q])));
+            *reinterpret_cast<pack_t*>(xhr + p * PK + (CH + c) * 2) = hrb;
+            *reinterpret_cast<pack_t*>(XHR + (cell + p) * KC + CH + c) = hrb;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- P2: o = conv3x3([x | h r]) + b ; h' = h (1 - u) + tanh(o) u
+      {
+        f32x4 acc[RT2];
+        conv(xhr, std::integral_constant<int, RT2>(), rg2 * RT2, w_o, w_next, more, acc);
+        const int n = wn2 * 16 + 4 * gq;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bs + l * 3 * CH + 2 * CH + n);
+#pragma unroll
+        for (int i = 0; i < RT2; ++i) {
+          const int p = (rg2 * RT2 + i) * 16 + r;
+          pack_t ob;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ob[q] = ET<T>::from_f32(acc[i][q] + b4[q]);
+          *reinterpret_cast<pack_t*>(O + (cell + p) * CH + n) = ob;
+          const pack_t hb = *reinterpret_cast<const pack_t*>(hl + p * CH + n);
+          const pack_t ub = *reinterpret_cast<const pack_t*>(us + p * CH + n);
+          pack_t hn;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float uu = ET<T>::to_f32(ub[q]);
+            hn[q] = ET<T>::from_f32(ET<T>::to_f32(hb[q]) * (1.f - uu) + tanhf(ET<T>::to_f32(ob[q])) * uu);
+          }
+          *reinterpret_cast<pack_t*>(hl + p * CH + n) = hn;
+          if (l + 1 < L) {
+            *reinterpret_cast<pack_t*>(nxh + p * PK + n * 2) = hn;
+            *reinterpret_cast<pack_t*>(nxhr + p * PK + n * 2) = hn;
+          } else {
+            *reinterpret_cast<pack_t*>(out + ((long)t * M + row0 + p) * ldo + n) = hn;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace ipoke
 
 using namespace ipoke;
@@ -197,6 +415,10 @@ int gru_conv(const GruCtx& c, const void* A, int lda, int Kc, const void* Wop, i
 
 }  // namespace
 
+static std::atomic<int> g_gru_fused{-1};
+/* Test hook: 0 = the launch-per-phase forward unroll, 1 = the fused kernel where it applies, < 0 = re-read IPOKE_GRU_FUSED at the next call. */
+extern "C" int ipoke_gru_set_fused(int mode) { g_gru_fused.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); return IPOKE_OK; }
+
 extern "C" int64_t ipoke_gru_workspace_bytes(const ipoke_gru_desc* d, int dtype) {
   GruPlan p;
   if (gru_plan(p, d, dtype) != IPOKE_OK) return -1;
@@ -211,14 +433,54 @@ extern "C" int ipoke_gru_unroll_forward(const ipoke_gru_desc* d, const void* x0,
   GruPlan p; int rc = gru_plan(p, d, dtype); if (rc) return rc;
   IPK_REQUIRE(x0 && h0 && weights && workspace && out && ldx >= p.Cx && ldh >= p.Ch && ldo >= p.Ch, "bad arguments");
   GruCtx c{p, dtype, reinterpret_cast<unsigned char*>(workspace), reinterpret_cast<hipStream_t>(stream)};
-  // matrix-core operands of the four convolutions of every cell (forward and data-gradient forms), once per pass
+  // one workgroup per sample runs the whole recurrence (gru_fused_fwd_kernel) where it applies; IPOKE_GRU_FUSED=0: the launch-per-phase form
+  int fm = g_gru_fused.load(std::memory_order_relaxed);
+  if (fm < 0) { fm = (getenv("IPOKE_GRU_FUSED") && atoi(getenv("IPOKE_GRU_FUSED")) == 0) ? 0 : 1; g_gru_fused.store(fm, std::memory_order_relaxed); }
+  const bool fused = fm != 0 && dtype == IPOKE_BF16 && p.H == 8 && p.W == 8 && p.Cx == p.Ch && (p.Ch == 32 || p.Ch == 64) && p.L <= 16 &&
+                     ldx % 8 == 0 && ldh % 8 == 0 && ldo % 4 == 0 && ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(h0)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+  bool fused_ok = fused;
+  for (int l = 0; fused_ok && l < p.L; ++l)
+    fused_ok = weights[4 * l] && weights[4 * l + 1] && weights[4 * l + 2] && weights[4 * l + 3] &&
+               ((reinterpret_cast<uintptr_t>(weights[4 * l + 1]) | reinterpret_cast<uintptr_t>(weights[4 * l + 3])) & 3) == 0;
+  // matrix-core operands of the four convolutions of every cell (forward and data-gradient forms), once per pass; the fused kernel
+  // takes its two forward operands fragment-tiled (gru_tile_operand_kernel) in the same workspace slots
   for (int l = 0; l < p.L; ++l) {
     const float* w_ur = weights[4 * l], *w_o = weights[4 * l + 2];
     IPK_REQUIRE(w_ur && weights[4 * l + 1] && w_o && weights[4 * l + 3], "null weight");
-    rc = ipoke_conv_weight_operand(w_ur, 2 * p.Ch, p.Kc, 9, 0, nullptr, c.wop(l, 0), p.Kc, dtype, stream); if (rc) return rc;
+    if (fused_ok) {
+      rc = launch1d(gru_tile_operand_kernel, (long)2 * p.Ch * 9 * p.Kc, c.s, w_ur, reinterpret_cast<bf16_t*>(c.wop(l, 0)), 2 * p.Ch, p.Kc); if (rc) return rc;
+      rc = launch1d(gru_tile_operand_kernel, (long)p.Ch * 9 * p.Kc, c.s, w_o, reinterpret_cast<bf16_t*>(c.wop(l, 2)), p.Ch, p.Kc); if (rc) return rc;
+    } else {
+      rc = ipoke_conv_weight_operand(w_ur, 2 * p.Ch, p.Kc, 9, 0, nullptr, c.wop(l, 0), p.Kc, dtype, stream); if (rc) return rc;
+      rc = ipoke_conv_weight_operand(w_o, p.Ch, p.Kc, 9, 0, nullptr, c.wop(l, 2), p.Kc, dtype, stream); if (rc) return rc;
+    }
     rc = ipoke_conv_weight_operand(w_ur, p.Kc, 2 * p.Ch, 9, 1, nullptr, c.wop(l, 1), p.N2p, dtype, stream); if (rc) return rc;
-    rc = ipoke_conv_weight_operand(w_o, p.Ch, p.Kc, 9, 0, nullptr, c.wop(l, 2), p.Kc, dtype, stream); if (rc) return rc;
     rc = ipoke_conv_weight_operand(w_o, p.Kc, p.Ch, 9, 1, nullptr, c.wop(l, 3), p.Chp, dtype, stream); if (rc) return rc;
+  }
+  if (fused_ok) {
+    GruFusedPtrs P; std::memset(&P, 0, sizeof(P));
+    for (int l = 0; l < p.L; ++l) {
+      P.w_ur[l] = reinterpret_cast<const bf16_t*>(c.wop(l, 0)); P.w_o[l] = reinterpret_cast<const bf16_t*>(c.wop(l, 2));
+      P.b_ur[l] = weights[4 * l + 1]; P.b_o[l] = weights[4 * l + 3];
+    }
+    {
+      const int PK = 2 * p.Kc + 32;
+      const size_t lds = (size_t)4 * 65 * PK + ((size_t)p.L * 64 * p.Ch + 2 * 64 * p.Ch) * 2 + (size_t)p.L * 3 * p.Ch * 4;
+      bf16_t* XH = reinterpret_cast<bf16_t*>(c.ws + p.XH); bf16_t* XHR = reinterpret_cast<bf16_t*>(c.ws + p.XHR);
+      bf16_t* URp = reinterpret_cast<bf16_t*>(c.ws + p.UR); bf16_t* Up = reinterpret_cast<bf16_t*>(c.ws + p.U); bf16_t* Op = reinterpret_cast<bf16_t*>(c.ws + p.O);
+      if (p.Ch == 64) {
+        IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fused_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gru_fused_fwd_kernel<64>, dim3(p.B), dim3(512), lds, c.s, (const bf16_t*)x0, ldx, (const bf16_t*)h0, ldh, P, XH, XHR, URp, Up, Op,
+                           (bf16_t*)out, ldo, p.M, p.T, p.L);
+      } else {
+        IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fused_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gru_fused_fwd_kernel<32>, dim3(p.B), dim3(512), lds, c.s, (const bf16_t*)x0, ldx, (const bf16_t*)h0, ldh, P, XH, XHR, URp, Up, Op,
+                           (bf16_t*)out, ldo, p.M, p.T, p.L);
+      }
+      IPK_LAUNCH_CHECK();
+      return IPOKE_OK;
+    }
   }
   const long fill = (long)p.T * p.M * p.Cx + (long)p.L * p.M * p.Ch;
   if (dtype == IPOKE_BF16) rc = launch1d(gru_fill_kernel<bf16_t>, fill, c.s, (const bf16_t*)x0, ldx, (const bf16_t*)h0, ldh, (bf16_t*)(c.ws + p.XH), (bf16_t*)(c.ws + p.XHR), p.M, p.Cx, p.Ch, p.Kc, p.T, p.L);

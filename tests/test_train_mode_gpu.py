@@ -36,7 +36,9 @@ TOL = {"f32": dict(x_max=2e-4, x_mean=1e-5, loss=2e-5, mu=2e-4, sum=5e-3, smp_ma
        # 1.5x the reference's own bf16-autocast deviation -- asserted on the CPU by tests/test_bf16_yardstick_cpu.py.  Measured on the
        # MI355X (four variants, B = 1 / 4 / 10): x_max <= 0.204, x_mean 8.6e-3, loss 3.3e-5, sum <= 0.175, smp_max <= 0.339, smp_mean <= 0.081.
        # `mu` (the encoder's posterior mean, not in the fixture) is measured 5.0e-2.
-       "bf16": dict(x_max=0.25, x_mean=1.4e-2, loss=1e-4, mu=6e-2, sum=0.22, smp_max=0.49, smp_mean=0.125, u=2e-5)}
+       # `sum` and `smp_max` are MAXIMA over 152 tensors (extreme values of a noisy quantity: the run-to-run spread of the fp32 atomics alone
+       # moves them between 0.10 and 0.21 resp. 0.27 and 0.48 over 24 runs, i.e. up to 1.40x / 1.46x the reference's single run): 2x there.
+       "bf16": dict(x_max=0.25, x_mean=1.4e-2, loss=1e-4, mu=6e-2, sum=0.29, smp_max=0.65, smp_mean=0.125, u=2e-5)}
 
 
 def train_model(dtype):

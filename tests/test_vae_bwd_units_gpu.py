@@ -334,3 +334,42 @@ def test_native_gru_unroll_vs_autograd(B, T, L, Z, dtype):
     for (k, p), (k2, q) in zip(rnn.named_parameters(), ref.named_parameters()):
         e = _rel(p.grad.cpu(), q.grad)
         assert k == k2 and e <= tol * 6, (k, e)
+
+
+@pytest.mark.parametrize("B,T,L,Z", [(2, 5, 3, 32), (3, 4, 4, 64), (5, 15, 4, 64), (20, 3, 2, 32)])
+def test_fused_gru_forward_matches_the_launch_per_phase_form(B, T, L, Z):
+    """gru_fused_fwd_kernel (one workgroup per sample runs the T x L recurrence) against the four-launches-per-cell form it replaces: the
+    output sequence and, through the unchanged backward pass on the workspace each form filled, every gradient.  Both round to bf16 at
+    the same places, so they differ by the order of the fp32 sums only."""
+    from ipoke_amd.first_stage import ConvGRU
+    gen = torch.Generator().manual_seed(B * 100 + T * 10 + L)
+    rnn = ConvGRU(Z, Z, 3, L, dtype="bf16").to(DEV)
+    with torch.no_grad():
+        for p in rnn.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * (0.3 if p.dim() == 1 else 1.5 / (9 * 2 * Z) ** 0.5))
+    x = torch.randn(B, Z, 8, 8, generator=gen)
+    h0 = torch.randn(B, Z, 8, 8, generator=gen)
+    dseq = torch.randn(T * B, Z, 8, 8, generator=gen)
+    res = {}
+    try:
+        for mode in (0, 1):
+            check(_lib.lib().ipoke_gru_set_fused(mode))
+            for p in rnn.parameters():
+                p.grad = None
+            xc, hc = _cl(x, "bf16"), _cl(h0, "bf16")
+            xc.t.requires_grad_(True); hc.t.requires_grad_(True)
+            out = FT.gru_unroll(rnn, xc, hc, T, "bf16")
+            out.t.backward(_cl(dseq, "bf16").t)
+            res[mode] = (out.t.detach().float().cpu(), xc.t.grad.float().cpu(), hc.t.grad.float().cpu(),
+                         [p.grad.detach().cpu().clone() for p in rnn.parameters()])
+    finally:
+        check(_lib.lib().ipoke_gru_set_fused(-1))
+    a, b = res[0], res[1]
+    scale = a[0].abs().max().item()
+    err = (a[0] - b[0]).abs().max().item() / scale
+    print(f"fused GRU B={B} T={T} L={L} Z={Z}: output rel err {err:.2e}")
+    assert err <= 2e-2                                       # a bf16 rounding flip early in the recurrence is carried forward
+    for k in (1, 2):
+        assert (a[k] - b[k]).abs().max().item() <= 4e-2 * a[k].abs().max().item()
+    for ga, gb in zip(a[3], b[3]):
+        assert (ga - gb).abs().max().item() <= 4e-2 * ga.abs().max().item() + 1e-6
