@@ -14,6 +14,8 @@
 // the steps), issued after the serial data-gradient chain.
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -337,6 +339,226 @@ __global__ __launch_bounds__(512) void gru_fused_fwd_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused backward unroll
+// Operand of a DATA-GRADIENT convolution for the fused backward kernel, from the fp32 weight w [Nw][Kc][3][3]: column block nf / K step q
+// tiled as in gru_tile_operand_kernel, output column j = 16 nf + (l & 15) an INPUT channel of the convolution, k = tap * Nw + c with the
+// tap mirrored (the gradient of position p collects d[p + delta(tap)] through the weight of tap 8 - tap).
+__global__ void gru_tile_operand_t_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Nw, int Kc) {
+  const long total = (long)Kc * 9 * Nw;
+  const int nfr = 9 * Nw / 32;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63); const long fq = i >> 9;
+    const int q = (int)(fq % nfr), nf = (int)(fq / nfr);
+    const int j = nf * 16 + (lane & 15), kk = q * 32 + (lane >> 4) * 8 + e;
+    const int t = kk / Nw, c = kk - t * Nw;
+    out[i] = (bf16_t)w[((long)c * Kc + j) * 9 + (8 - t)];
+  }
+}
+
+// The reverse recurrence of ONE sample in one workgroup, on the workspace the forward pass filled (gru_fused_fwd_kernel or the
+// launch-per-phase form: the same buffers).  Per (cell l, step t), in reverse order -- the four launches of the unfused form as phases:
+//   A  g = sum of the gradients reaching h'(l, t) (same cell's next step: two terms; cell l + 1 of this step: two terms, or the loss
+//      gradient of the output sequence) ; d o = g u (1 - tanh(o)^2) ; d u = g (tanh(o) - h) ; d h1 = g (1 - u)
+//   B  [d x | d hr] = conv_o data gradient of d o
+//   C  d ur = [d u u (1 - u) | d hr h r (1 - r)] ; d h2 = d h1 + d hr r
+//   D  [d x | d h] = conv_ur data gradient of d ur
+// d o and d ur of every (cell, step) go to the workspace (operands of the weight-gradient GEMMs over all steps); the gradient of the
+// constant cell-0 input and of the common initial state are accumulated in fp32 in the order of the unfused form, and every
+// intermediate is rounded to bf16 where that form stores it.
+template <int CH>
+__global__ __launch_bounds__(512) void gru_fused_bwd_kernel(const bf16_t* __restrict__ d_out, int ldo, const GruFusedPtrs P,
+                                                            const bf16_t* __restrict__ XH, const bf16_t* __restrict__ UR,
+                                                            const bf16_t* __restrict__ U, const bf16_t* __restrict__ O,
+                                                            bf16_t* __restrict__ DO, bf16_t* __restrict__ DUR, float* __restrict__ d_x0,
+                                                            float* __restrict__ d_h0, long M, int Tn, int L) {
+  typedef bf16_t T;
+  typedef typename ET<T>::frag frag_t;
+  typedef typename GPack4<T>::type pack_t;
+  constexpr int KC = 2 * CH;
+  constexpr int KS_O = CH / 32, NFR_O = 9 * KS_O, KS_U = KC / 32, NFR_U = 9 * KS_U;
+  constexpr int NH = NFR_U / 2;                                     // register half-set (the larger convolution's half)
+  constexpr int PO = CH * 2 + 32, PU = KC * 2 + 32;                 // tile pitches in bytes (2 mod 4 16-byte units)
+  constexpr int NFc = KC / 16, RG = 8 / NFc, RT = 4 / RG;           // both data gradients produce KC columns
+  constexpr int CV = CH / 8;                                        // 16-byte chunks per CH-wide row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* do_t = smem;                                       // [65][PO]   d o     (A operand of phase B)
+  unsigned char* dur_t = do_t + 65 * PO;                            // [65][PU]   d ur    (A operand of phase D)
+  T* dxhr = reinterpret_cast<T*>(dur_t + 65 * PU);                  // [64][KC]   result of phase B: [d x | d hr]
+  T* dxhx = dxhr + 64 * KC;                                         // [64][CH]   x-half of phase D's result
+  T* dhn = dxhx + 64 * CH;                                          // [L][2][64][CH]  d h2 and the h-half of phase D's result, per cell
+  float* dx0 = reinterpret_cast<float*>(dhn + (long)L * 2 * 64 * CH);   // [64][CH] gradient of the constant input
+  const int tid = threadIdx.x;
+  const long row0 = (long)blockIdx.x * 64;
+  for (int i = tid; i < (65 * PO + 65 * PU) / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < 64 * CH; i += 512) dx0[i] = 0.f;
+
+  frag_t wa[NH], wb[NH];
+  auto load_set = [&](frag_t* w, const T* base, int first, int n) {
+#pragma unroll
+    for (int q = 0; q < NH; ++q)
+      if (q < n) w[q] = *reinterpret_cast<const frag_t*>(base + (long)(first + q) * 512);
+  };
+  auto tap_row = [&](const unsigned char* tile, int pitch, int p, int tap) {
+    const int ty = tap / 3, tx = tap - 3 * ty;
+    const int yy = (p >> 3) + ty - 1, xx = (p & 7) + tx - 1;
+    return ((unsigned)yy < 8u && (unsigned)xx < 8u) ? tile + (yy * 8 + xx) * pitch : tile + 64 * pitch;
+  };
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    load_set(wa, P.w_o[L - 1] + (long)(wave % NFc) * NFR_O * 512 + lane * 8, 0, NFR_O / 2);
+  }
+  __syncthreads();
+  bool pend_x0 = false;
+#pragma unroll 1
+  for (int t = Tn - 1; t >= 0; --t) {
+#pragma unroll 1
+    for (int l = L - 1; l >= 0; --l) {
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int lane = tl & 63, wave = tl >> 6, r = lane & 15, gq = lane >> 4;
+      const int wn = wave % NFc, rg = wave / NFc;
+      const long cell = ((long)l * Tn + t) * M + row0;
+      const T* w_o = P.w_o[l] + (long)wn * NFR_O * 512 + lane * 8;
+      const T* w_u = P.w_ur[l] + (long)wn * NFR_U * 512 + lane * 8;
+      const int ln = l > 0 ? l - 1 : L - 1;
+      const bool more = l > 0 || t > 0;
+      const T* w_next = P.w_o[ln] + (long)wn * NFR_O * 512 + lane * 8;
+      T* dh2 = dhn + ((long)l * 2 + 0) * 64 * CH;
+      T* dxhh = dhn + ((long)l * 2 + 1) * 64 * CH;
+      // one data-gradient convolution: K half A (requested earlier) under the request of half B, half B under the request of the next
+      // convolution's half A
+      auto conv = [&](const unsigned char* tile, auto pitch_c, auto ks_c, const T* wthis, const T* next_a, auto nnext_c, bool have_next, f32x4* acc) {
+        constexpr int PT = decltype(pitch_c)::value, KS = decltype(ks_c)::value, NFR = 9 * KS, NA = NFR / 2, NNA = decltype(nnext_c)::value;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        load_set(wb, wthis, NA, NFR - NA);
+#pragma unroll
+        for (int q = 0; q < NFR; ++q) {
+          const int tap = q / KS, ks = q - tap * KS;
+          if (q == NA) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (have_next) load_set(wa, next_a, 0, NNA);
+          }
+          frag_t fa[RT];
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+            fa[i] = *reinterpret_cast<const frag_t*>(tap_row(tile, PT, (rg * RT + i) * 16 + r, tap) + gq * 16 + ks * 64);
+#pragma unroll
+          for (int i = 0; i < RT; ++i) mma64(fa[i], q < NA ? wa[q < NA ? q : 0] : wb[q < NA ? 0 : q - NA], acc[i]);
+        }
+      };
+      // ---- A
+      const bool act = tl < 64 * CV;
+      const int pe = tl / CV, ce = (tl - pe * CV) * 8;                 // this thread's row and first channel in the element-wise phases
+      bf16x8 hv, du8, dh18;
+      if (act) {
+        if (pend_x0) {                                                // cell 0 of the step just left: its two x-path gradients
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(dxhx + pe * CH + ce), b = *reinterpret_cast<const bf16x8*>(dxhr + pe * KC + ce);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) dx0[pe * CH + ce + q] += ET<T>::to_f32(a[q]) + ET<T>::to_f32(b[q]);
+        }
+        float g[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[q] = 0.f;
+        if (t + 1 < Tn) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(dh2 + pe * CH + ce), b = *reinterpret_cast<const bf16x8*>(dxhh + pe * CH + ce);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { g[q] += ET<T>::to_f32(a[q]); g[q] += ET<T>::to_f32(b[q]); }
+        }
+        if (l + 1 < L) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(dxhx + pe * CH + ce), b = *reinterpret_cast<const bf16x8*>(dxhr + pe * KC + ce);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { g[q] += ET<T>::to_f32(a[q]); g[q] += ET<T>::to_f32(b[q]); }
+        } else {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(d_out + ((long)t * M + row0 + pe) * ldo + ce);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) g[q] += ET<T>::to_f32(a[q]);
+        }
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(O + (cell + pe) * CH + ce);
+        const bf16x8 uv = *reinterpret_cast<const bf16x8*>(U + (cell + pe) * CH + ce);
+        hv = *reinterpret_cast<const bf16x8*>(XH + (cell + pe) * KC + CH + ce);
+        bf16x8 do8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float uu = ET<T>::to_f32(uv[q]), th = tanhf(ET<T>::to_f32(ov[q])), hh = ET<T>::to_f32(hv[q]);
+          do8[q] = ET<T>::from_f32(g[q] * uu * (1.f - th * th));
+          du8[q] = ET<T>::from_f32(g[q] * (th - hh));
+          dh18[q] = ET<T>::from_f32(g[q] * (1.f - uu));
+        }
+        *reinterpret_cast<bf16x8*>(do_t + pe * PO + ce * 2) = do8;
+        *reinterpret_cast<bf16x8*>(DO + (cell + pe) * CH + ce) = do8;
+      }
+      pend_x0 = false;
+      __syncthreads();
+      // ---- B: [d x | d hr] = conv_o data gradient
+      {
+        f32x4 acc[RT];
+        conv(do_t, std::integral_constant<int, PO>(), std::integral_constant<int, KS_O>(), w_o, w_u, std::integral_constant<int, NFR_U / 2>(), true, acc);
+        const int n = wn * 16 + 4 * gq;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const int p = (rg * RT + i) * 16 + r;
+          pack_t v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ET<T>::from_f32(acc[i][q]);
+          *reinterpret_cast<pack_t*>(dxhr + p * KC + n) = v;
+        }
+      }
+      __syncthreads();
+      // ---- C
+      if (act) {
+        const bf16x8 uru = *reinterpret_cast<const bf16x8*>(UR + (cell + pe) * KC + ce);
+        const bf16x8 urr = *reinterpret_cast<const bf16x8*>(UR + (cell + pe) * KC + CH + ce);
+        const bf16x8 ghr8 = *reinterpret_cast<const bf16x8*>(dxhr + pe * KC + CH + ce);
+        bf16x8 a8, b8, h28;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float uu = act_apply(IPOKE_ACT_SIGMOID, ET<T>::to_f32(uru[q]));
+          a8[q] = ET<T>::from_f32(ET<T>::to_f32(du8[q]) * uu * (1.f - uu));
+          const float rr = act_apply(IPOKE_ACT_SIGMOID, ET<T>::to_f32(urr[q])), ghr = ET<T>::to_f32(ghr8[q]);
+          b8[q] = ET<T>::from_f32(ghr * ET<T>::to_f32(hv[q]) * rr * (1.f - rr));
+          h28[q] = ET<T>::from_f32(ET<T>::to_f32(dh18[q]) + ghr * rr);
+        }
+        *reinterpret_cast<bf16x8*>(dur_t + pe * PU + ce * 2) = a8;
+        *reinterpret_cast<bf16x8*>(dur_t + pe * PU + (CH + ce) * 2) = b8;
+        *reinterpret_cast<bf16x8*>(DUR + (cell + pe) * KC + ce) = a8;
+        *reinterpret_cast<bf16x8*>(DUR + (cell + pe) * KC + CH + ce) = b8;
+        *reinterpret_cast<bf16x8*>(dh2 + pe * CH + ce) = h28;
+      }
+      __syncthreads();
+      // ---- D: [d x | d h] = conv_ur data gradient
+      {
+        f32x4 acc[RT];
+        conv(dur_t, std::integral_constant<int, PU>(), std::integral_constant<int, KS_U>(), w_u, w_next, std::integral_constant<int, NFR_O / 2>(), more, acc);
+        const int n = wn * 16 + 4 * gq;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const int p = (rg * RT + i) * 16 + r;
+          pack_t v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ET<T>::from_f32(acc[i][q]);
+          if (n < CH) *reinterpret_cast<pack_t*>(dxhx + p * CH + n) = v;
+          else *reinterpret_cast<pack_t*>(dxhh + p * CH + n - CH) = v;
+        }
+      }
+      if (l == 0) pend_x0 = true;
+      __syncthreads();
+    }
+  }
+  // the last (cell 0, step 0) contribution to d x0, then both results
+  for (int i = tid; i < 64 * CH; i += 512) {
+    const int p = i / CH, c = i - p * CH;
+    const float v = dx0[i] + (ET<T>::to_f32(dxhx[i]) + ET<T>::to_f32(dxhr[p * KC + c]));
+    d_x0[(row0 + p) * CH + c] = v;
+    float h = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const float s2 = ET<T>::to_f32(dhn[((long)l * 2 + 0) * 64 * CH + i]) + ET<T>::to_f32(dhn[((long)l * 2 + 1) * 64 * CH + i]);
+      h = l > 0 ? h + s2 : s2;
+    }
+    d_h0[(row0 + p) * CH + c] = h;
+  }
+}
+
 }  // namespace ipoke
 
 using namespace ipoke;
@@ -416,6 +638,15 @@ int gru_conv(const GruCtx& c, const void* A, int lda, int Kc, const void* Wop, i
 }  // namespace
 
 static std::atomic<int> g_gru_fused{-1};
+// which operand layout the last forward pass left in a workspace (host-side: the backward pass must not read device memory to find out)
+static std::mutex g_gru_ws_mutex;
+static std::unordered_map<const void*, int> g_gru_ws_layout;       // workspace -> 1: fragment-tiled operands (fused kernels), 0: row-major
+static void gru_note_layout(const void* ws, int tiled) { std::lock_guard<std::mutex> g(g_gru_ws_mutex); g_gru_ws_layout[ws] = tiled; }
+static int gru_layout_of(const void* ws) {
+  std::lock_guard<std::mutex> g(g_gru_ws_mutex);
+  auto it = g_gru_ws_layout.find(ws);
+  return it == g_gru_ws_layout.end() ? 0 : it->second;
+}
 /* Test hook: 0 = the launch-per-phase forward unroll, 1 = the fused kernel where it applies, < 0 = re-read IPOKE_GRU_FUSED at the next call. */
 extern "C" int ipoke_gru_set_fused(int mode) { g_gru_fused.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); return IPOKE_OK; }
 
@@ -455,9 +686,15 @@ extern "C" int ipoke_gru_unroll_forward(const ipoke_gru_desc* d, const void* x0,
       rc = ipoke_conv_weight_operand(w_ur, 2 * p.Ch, p.Kc, 9, 0, nullptr, c.wop(l, 0), p.Kc, dtype, stream); if (rc) return rc;
       rc = ipoke_conv_weight_operand(w_o, p.Ch, p.Kc, 9, 0, nullptr, c.wop(l, 2), p.Kc, dtype, stream); if (rc) return rc;
     }
-    rc = ipoke_conv_weight_operand(w_ur, p.Kc, 2 * p.Ch, 9, 1, nullptr, c.wop(l, 1), p.N2p, dtype, stream); if (rc) return rc;
-    rc = ipoke_conv_weight_operand(w_o, p.Kc, p.Ch, 9, 1, nullptr, c.wop(l, 3), p.Chp, dtype, stream); if (rc) return rc;
+    if (fused_ok) {
+      rc = launch1d(gru_tile_operand_t_kernel, (long)p.Kc * 9 * 2 * p.Ch, c.s, w_ur, reinterpret_cast<bf16_t*>(c.wop(l, 1)), 2 * p.Ch, p.Kc); if (rc) return rc;
+      rc = launch1d(gru_tile_operand_t_kernel, (long)p.Kc * 9 * p.Ch, c.s, w_o, reinterpret_cast<bf16_t*>(c.wop(l, 3)), p.Ch, p.Kc); if (rc) return rc;
+    } else {
+      rc = ipoke_conv_weight_operand(w_ur, p.Kc, 2 * p.Ch, 9, 1, nullptr, c.wop(l, 1), p.N2p, dtype, stream); if (rc) return rc;
+      rc = ipoke_conv_weight_operand(w_o, p.Kc, p.Ch, 9, 1, nullptr, c.wop(l, 3), p.Chp, dtype, stream); if (rc) return rc;
+    }
   }
+  gru_note_layout(workspace, fused_ok ? 1 : 0);
   if (fused_ok) {
     GruFusedPtrs P; std::memset(&P, 0, sizeof(P));
     for (int l = 0; l < p.L; ++l) {
@@ -528,8 +765,27 @@ extern "C" int ipoke_gru_unroll_backward(const ipoke_gru_desc* d, const void* d_
   IPK_REQUIRE(d_out && workspace && dweights && d_x0 && d_h0 && ldo >= p.Ch, "bad arguments");
   GruCtx c{p, dtype, reinterpret_cast<unsigned char*>(workspace), reinterpret_cast<hipStream_t>(stream)};
   const long E = p.esz;
+  const bool fused_bwd = gru_layout_of(workspace) == 1 && dtype == IPOKE_BF16 && ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+  if (gru_layout_of(workspace) == 1) IPK_REQUIRE(fused_bwd, "the forward pass left fragment-tiled operands: d_out must be 16-byte aligned rows of a multiple of 8 elements");
+  if (fused_bwd) {
+    GruFusedPtrs P; std::memset(&P, 0, sizeof(P));
+    for (int l = 0; l < p.L; ++l) { P.w_ur[l] = reinterpret_cast<const bf16_t*>(c.wop(l, 1)); P.w_o[l] = reinterpret_cast<const bf16_t*>(c.wop(l, 3)); }
+    const int PO = 2 * p.Ch + 32, PU = 2 * p.Kc + 32;
+    const size_t lds = (size_t)65 * PO + (size_t)65 * PU + ((size_t)64 * p.Kc + 64 * p.Ch + (size_t)p.L * 2 * 64 * p.Ch) * 2 + (size_t)64 * p.Ch * 4;
+    const bf16_t* XH = reinterpret_cast<const bf16_t*>(c.ws + p.XH); const bf16_t* URp = reinterpret_cast<const bf16_t*>(c.ws + p.UR);
+    const bf16_t* Up = reinterpret_cast<const bf16_t*>(c.ws + p.U); const bf16_t* Op = reinterpret_cast<const bf16_t*>(c.ws + p.O);
+    bf16_t* DOp = reinterpret_cast<bf16_t*>(c.ws + p.DO); bf16_t* DURp = reinterpret_cast<bf16_t*>(c.ws + p.DUR);
+    if (p.Ch == 64) {
+      IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fused_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(gru_fused_bwd_kernel<64>, dim3(p.B), dim3(512), lds, c.s, (const bf16_t*)d_out, ldo, P, XH, URp, Up, Op, DOp, DURp, d_x0, d_h0, p.M, p.T, p.L);
+    } else {
+      IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fused_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(gru_fused_bwd_kernel<32>, dim3(p.B), dim3(512), lds, c.s, (const bf16_t*)d_out, ldo, P, XH, URp, Up, Op, DOp, DURp, d_x0, d_h0, p.M, p.T, p.L);
+    }
+    IPK_LAUNCH_CHECK();
+  }
   unsigned char* du = c.ws + p.DU; unsigned char* dh1 = c.ws + p.DH1;
-  for (int t = p.T - 1; t >= 0; --t) {
+  for (int t = fused_bwd ? -1 : p.T - 1; t >= 0; --t) {
     for (int l = p.L - 1; l >= 0; --l) {
       unsigned char* xh = c.cell(p.XH, l, t, p.Kc);
       unsigned char* ur = c.cell(p.UR, l, t, p.N2p); unsigned char* u = c.cell(p.U, l, t, p.Ch); unsigned char* o = c.cell(p.O, l, t, p.Chp);
@@ -568,7 +824,7 @@ extern "C" int ipoke_gru_unroll_backward(const ipoke_gru_desc* d, const void* d_
     }
   }
   // d h0 = sum over the cells of (d h2 + h-half of the first convolution's data gradient) after step 0
-  for (int l = 0; l < p.L; ++l) {
+  for (int l = 0; l < (fused_bwd ? 0 : p.L); ++l) {
     unsigned char* dxh = c.lay(p.DXH, l, p.Kc); unsigned char* dh2 = c.lay(p.DH2, l, p.Ch);
     if (dtype == IPOKE_BF16) rc = launch1d(gru_add2_kernel<bf16_t>, p.M * p.Ch, c.s, (const bf16_t*)dh2, p.Ch, (const bf16_t*)(dxh + (long)p.Cx * E), p.Kc, d_h0, p.Ch, p.M, p.Ch, l > 0 ? 1 : 0);
     else rc = launch1d(gru_add2_kernel<float>, p.M * p.Ch, c.s, (const float*)dh2, p.Ch, (const float*)(dxh + (long)p.Cx * E), p.Kc, d_h0, p.Ch, p.M, p.Ch, l > 0 ? 1 : 0);

@@ -369,7 +369,7 @@ def test_fused_gru_forward_matches_the_launch_per_phase_form(B, T, L, Z):
     err = (a[0] - b[0]).abs().max().item() / scale
     print(f"fused GRU B={B} T={T} L={L} Z={Z}: output rel err {err:.2e}")
     assert err <= 2e-2                                       # a bf16 rounding flip early in the recurrence is carried forward
-    for k in (1, 2):
-        assert (a[k] - b[k]).abs().max().item() <= 4e-2 * a[k].abs().max().item()
-    for ga, gb in zip(a[3], b[3]):
-        assert (ga - gb).abs().max().item() <= 4e-2 * ga.abs().max().item() + 1e-6
+    ge = [(a[k] - b[k]).abs().max().item() / a[k].abs().max().item() for k in (1, 2)]
+    we = max((ga - gb).abs().max().item() / (ga.abs().max().item() + 1e-12) for ga, gb in zip(a[3], b[3]))
+    print(f"   gradients: d x0 {ge[0]:.2e}, d h0 {ge[1]:.2e}, weights / biases {we:.2e} (relative to each tensor's maximum)")
+    assert max(ge) <= 4e-2 and we <= 4e-2
