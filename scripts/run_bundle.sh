@@ -1,7 +1,4 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp
-R=/root/repo; O=$R/gpurun_out; mkdir -p $O
-for c in c4 c5; do
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$c -- python $R/bench.py --config $c --steps 6 --warmup 3 --no-cpu-baseline > $O/${c}_stats_run.log 2>&1
-cp $(find /tmp/p_$c -name "*kernel_stats.csv" | head -1) $O/${c}_kernel_stats_now.csv
-done
+cd /root/repo; mkdir -p gpurun_out
+( time python -m pytest tests -m gpu -q 2>&1 | tail -5 ) 2>&1 | tail -9
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
