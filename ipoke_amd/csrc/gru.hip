@@ -14,6 +14,7 @@
 // the steps), issued after the serial data-gradient chain.
 #include <atomic>
 #include <cstdlib>
+#include <iterator>
 #include <mutex>
 #include <unordered_map>
 #include <cstring>
@@ -640,12 +641,28 @@ int gru_conv(const GruCtx& c, const void* A, int lda, int Kc, const void* Wop, i
 static std::atomic<int> g_gru_fused{-1};
 // which operand layout the last forward pass left in a workspace (host-side: the backward pass must not read device memory to find out)
 static std::mutex g_gru_ws_mutex;
-static std::unordered_map<const void*, int> g_gru_ws_layout;       // workspace -> 1: fragment-tiled operands (fused kernels), 0: row-major
-static void gru_note_layout(const void* ws, int tiled) { std::lock_guard<std::mutex> g(g_gru_ws_mutex); g_gru_ws_layout[ws] = tiled; }
+static std::unordered_map<const void*, std::pair<int, long>> g_gru_ws_layout;   // workspace -> (1: fragment-tiled operands / 0: row-major, sequence number)
+static long g_gru_ws_seq = 0;
+static void gru_note_layout(const void* ws, int tiled) {
+  std::lock_guard<std::mutex> g(g_gru_ws_mutex);
+  g_gru_ws_layout[ws] = {tiled, ++g_gru_ws_seq};
+  if (g_gru_ws_layout.size() > 4096) {         // workspaces come and go with the caller's allocator: forget the oldest half
+    for (auto it = g_gru_ws_layout.begin(); it != g_gru_ws_layout.end();)
+      it = it->second.second + 2048 < g_gru_ws_seq ? g_gru_ws_layout.erase(it) : std::next(it);
+  }
+}
 static int gru_layout_of(const void* ws) {
   std::lock_guard<std::mutex> g(g_gru_ws_mutex);
   auto it = g_gru_ws_layout.find(ws);
-  return it == g_gru_ws_layout.end() ? 0 : it->second;
+  return it == g_gru_ws_layout.end() ? 0 : it->second.first;
+}
+// dynamic-LDS limit of a kernel instantiation, raised once (grows monotonically)
+template <typename K> static int gru_ensure_lds(K kern, size_t bytes, size_t& granted) {
+  if (bytes > granted) {
+    IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    granted = bytes;
+  }
+  return IPOKE_OK;
 }
 /* Test hook: 0 = the launch-per-phase forward unroll, 1 = the fused kernel where it applies, < 0 = re-read IPOKE_GRU_FUSED at the next call. */
 extern "C" int ipoke_gru_set_fused(int mode) { g_gru_fused.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); return IPOKE_OK; }
@@ -707,11 +724,11 @@ extern "C" int ipoke_gru_unroll_forward(const ipoke_gru_desc* d, const void* x0,
       bf16_t* XH = reinterpret_cast<bf16_t*>(c.ws + p.XH); bf16_t* XHR = reinterpret_cast<bf16_t*>(c.ws + p.XHR);
       bf16_t* URp = reinterpret_cast<bf16_t*>(c.ws + p.UR); bf16_t* Up = reinterpret_cast<bf16_t*>(c.ws + p.U); bf16_t* Op = reinterpret_cast<bf16_t*>(c.ws + p.O);
       if (p.Ch == 64) {
-        IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fused_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static size_t granted64 = 0; rc = gru_ensure_lds(gru_fused_fwd_kernel<64>, lds, granted64); if (rc) return rc;
         hipLaunchKernelGGL(gru_fused_fwd_kernel<64>, dim3(p.B), dim3(512), lds, c.s, (const bf16_t*)x0, ldx, (const bf16_t*)h0, ldh, P, XH, XHR, URp, Up, Op,
                            (bf16_t*)out, ldo, p.M, p.T, p.L);
       } else {
-        IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fused_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static size_t granted32 = 0; rc = gru_ensure_lds(gru_fused_fwd_kernel<32>, lds, granted32); if (rc) return rc;
         hipLaunchKernelGGL(gru_fused_fwd_kernel<32>, dim3(p.B), dim3(512), lds, c.s, (const bf16_t*)x0, ldx, (const bf16_t*)h0, ldh, P, XH, XHR, URp, Up, Op,
                            (bf16_t*)out, ldo, p.M, p.T, p.L);
       }
@@ -776,10 +793,10 @@ extern "C" int ipoke_gru_unroll_backward(const ipoke_gru_desc* d, const void* d_
     const bf16_t* Up = reinterpret_cast<const bf16_t*>(c.ws + p.U); const bf16_t* Op = reinterpret_cast<const bf16_t*>(c.ws + p.O);
     bf16_t* DOp = reinterpret_cast<bf16_t*>(c.ws + p.DO); bf16_t* DURp = reinterpret_cast<bf16_t*>(c.ws + p.DUR);
     if (p.Ch == 64) {
-      IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fused_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      static size_t granted64 = 0; rc = gru_ensure_lds(gru_fused_bwd_kernel<64>, lds, granted64); if (rc) return rc;
       hipLaunchKernelGGL(gru_fused_bwd_kernel<64>, dim3(p.B), dim3(512), lds, c.s, (const bf16_t*)d_out, ldo, P, XH, URp, Up, Op, DOp, DURp, d_x0, d_h0, p.M, p.T, p.L);
     } else {
-      IPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fused_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      static size_t granted32 = 0; rc = gru_ensure_lds(gru_fused_bwd_kernel<32>, lds, granted32); if (rc) return rc;
       hipLaunchKernelGGL(gru_fused_bwd_kernel<32>, dim3(p.B), dim3(512), lds, c.s, (const bf16_t*)d_out, ldo, P, XH, URp, Up, Op, DOp, DURp, d_x0, d_h0, p.M, p.T, p.L);
     }
     IPK_LAUNCH_CHECK();
