@@ -1,7 +1,7 @@
 #!/bin/bash
-cd /root/repo; mkdir -p gpurun_out
-run() { timeout 300 python bench.py --steps 30 --warmup 8 --no-secondary --no-cpu-baseline 2>gpurun_out/err.log | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['ms_per_step'], d.get('loss'))" || tail -5 gpurun_out/err.log; }
-for i in 1 2; do
-echo "== default"; run
-echo "== gate"; IPOKE_PREFETCH_GATE=1 run
-done
+cd /tmp && export TMPDIR=/tmp
+R=/root/repo; O=$R/gpurun_out; mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_a -- python $R/bench.py --config c5 --steps 6 --warmup 3 --no-cpu-baseline > $O/a.log 2>&1
+cp $(find /tmp/p_a -name "*kernel_stats.csv" | head -1) $O/c5_stats_fused.csv
+IPOKE_NO_FUSED_RESIDUAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b -- python $R/bench.py --config c5 --steps 6 --warmup 3 --no-cpu-baseline > $O/b.log 2>&1
+cp $(find /tmp/p_b -name "*kernel_stats.csv" | head -1) $O/c5_stats_sep.csv
