@@ -178,6 +178,39 @@ def test_condition_nice_wide_vs_oracle():
         assert (rev.cpu() - x).abs().max().item() <= TOL["f32"]["rev"] * 4
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_condition_nice_with_lu_convs_vs_oracle(dtype):
+    """Both optional branches together (condition_nice + use1x1) at an odd batch size (B = 3: the reverse pass's 128-row tiles are ragged),
+    against the CPU oracle: forward, log-det, every gradient, reverse."""
+    from oracle import flow_ref
+    arch = _condition_nice_arch(64)
+    arch["use1x1"] = True
+    np.random.seed(12)
+    o = flow_ref.SupervisedMacowTransformer(copy.deepcopy(arch))
+    lu_state = {k: v.clone() for k, v in o.state_dict().items() if ".shuffle_layers." in k}   # the constructor's P, L, U draws (a name-keyed fill is not a permutation)
+    m = build(arch, dtype)
+    m.load_state_dict(lu_state, strict=False)
+    m.sync_buffers()
+    m.train()
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    gen = torch.Generator().manual_seed(21)
+    x, cond = torch.randn(3, 16, 8, 8, generator=gen), torch.randn(3, 64, 8, 8, generator=gen)
+    out, logdet = m(x.cuda(), cond.cuda())
+    oo, ol = o(x, cond)
+    scale, lscale = oo.abs().max().item(), ol.abs().max().item()
+    tol_o, tol_l, tol_g = (4e-4, 2e-2, 4e-3) if dtype == "f32" else (7.5e-3 * scale, 5e-3 * lscale, 6e-2)
+    assert (out.detach().cpu() - oo).abs().max().item() <= tol_o and (logdet.detach().cpu() - ol).abs().max().item() <= tol_l
+    ((0.5 * (out ** 2).sum(dim=[1, 2, 3])).mean() - logdet.mean()).backward()
+    ((0.5 * (oo ** 2).sum(dim=[1, 2, 3])).mean() - ol.mean()).backward()
+    og = dict(o.named_parameters())
+    worst = max((p.grad.cpu() - og[n].grad).abs().max().item() / (og[n].grad.abs().max().item() + 1e-6) for n, p in m.named_parameters())
+    print(f"[{dtype}] condition_nice + use1x1: worst relative grad error {worst:.3e}")
+    assert worst <= tol_g
+    with torch.no_grad():
+        rev = m(oo.detach().cuda(), cond.cuda(), reverse=True)
+    assert (rev.cpu() - x).abs().max().item() <= (1e-3 if dtype == "f32" else 7.5e-3 * scale)
+
+
 def test_reduced_flow_data_init(golden):
     """First forward with initialized == 0 (data-dependent ActNorm init, zero-init couplings)."""
     g = golden("g2_reduced_flow_init")
