@@ -628,6 +628,11 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
       if (!SIMPLE) b_k[i] += BK;
       if (b_off[i] != kInvalid) b_off[i] += BK;
     }
+#if defined(IPOKE_GEMM_STAMPS) && (IPOKE_GEMM_ABL == 5 || IPOKE_GEMM_ABL == 6)   // probe build: every K-block re-reads the first one (L2 hits only)
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) if (b_off[i] != kInvalid) b_off[i] -= BK;
+    return;
+#endif
     if (SIMPLE) {
       c_uni += BK;
       if (c_uni >= p.Kc) {                          // uniform: every chunk enters the next tap together
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
     const unsigned char* base = smem + slot * STAGE;
     slot = (slot + 1) % NSTAGE;
     const int nsub = min(KPB, kb_end - kb);
-#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 4      // probe build: operand stream only
+#if defined(IPOKE_GEMM_STAMPS) && (IPOKE_GEMM_ABL == 4 || IPOKE_GEMM_ABL == 5)      // probe build: operand stream only
     if (nsub < 0)
 #endif
     if constexpr (WK == 1) {
