@@ -375,6 +375,10 @@ class PokeMotionModel(nn.Module):
     def _sample_device(self, X, poke, z):
         """The device side of one sample of ``forward_sample``: conditioning encoders -> reverse flow -> ConvGRU + SPADE decode.  No host
         synchronisation, no host RNG: this is what ``set_sample_graph`` captures."""
+        return self.decode_first_stage(self._sample_motion(X, poke, z), X)
+
+    def _sample_motion(self, X, poke, z):
+        """First half of ``_sample_device``: conditioning encoders -> reverse flow (the motion latent of the first stage)."""
         if self.embed_poke_and_image:
             poke = torch.cat([poke, X[:, 0]], dim=1)
         poke_emb, *_ = self.poke_embedder.encoder(poke)
@@ -388,7 +392,58 @@ class PokeMotionModel(nn.Module):
         out_motion = self.flow(z, cond, reverse=True)
         if self.augment_input:
             out_motion = out_motion[:, :-self.config["architecture"]["augment_channels"]].contiguous()
-        return self.decode_first_stage(out_motion, X)
+        return out_motion
+
+    def sample_stream(self, batches, n_logged_vids=1, add_first_frame=False, use_keypoint_pokes=False):
+        """``forward_sample(batch)[0]`` for every batch of an iterable (the validation / test loops, `second_stage_video.py:490-584`,
+        call it batch after batch), two batches in flight: the reverse flow of batch k+1 runs on the caller's stream while the ConvGRU +
+        SPADE decode of batch k runs on a second stream.  The reverse flow is a serial chain of small launches (its inverse units occupy one
+        workgroup per sample), the decoder is wide convolutions -- they fill different parts of the chip.  Per batch the same kernels run
+        on the same data in the same order as in ``forward_sample`` (bit-identical results, tested); the latent is drawn from the CPU
+        generator per batch in the same order.  Yields one CPU tensor per batch, in order, one batch late."""
+        self.first_stage_model.eval(); self.poke_embedder.eval()
+        if self.use_cond:
+            self.conditioner.eval()
+        if getattr(self, "_decode_stream", None) is None:
+            from .utils.streams import overlapping_stream
+            self._decode_stream = overlapping_stream()      # not any new stream: see utils/streams.py
+        side, spatial = self._decode_stream, self.first_stage_config["architecture"]["min_spatial_size"]
+
+        @torch.no_grad()                     # per stage, not around the yields: a generator must not hold the caller's grad mode
+        def issue(batch):
+            X = batch["images"]
+            poke = self._poke_of(batch, use_keypoint_pokes)
+            # same CPU generator draw as forward_sample, but through pinned memory: a pageable copy would make the host wait for the
+            # stream to drain and give up its lead over the device
+            z = torch.randn((X.size(0), self.config["architecture"]["flow_in_channels"], spatial, spatial), pin_memory=True)
+            z = z.to(device=X.device, dtype=X.dtype, non_blocking=True)
+            motion = self._sample_motion(X, poke, z)
+            side.wait_stream(torch.cuda.current_stream())
+            for t_ in (motion, X):
+                t_.record_stream(side)
+            with torch.cuda.stream(side):
+                video = self.decode_first_stage(motion, X)
+                if add_first_frame:
+                    video = torch.cat([X[:, 0].unsqueeze(1), video], dim=1)
+                video = video[:n_logged_vids]
+                # the copy to the host is queued right behind this batch's decode (fetched one batch later it would wait behind the NEXT decode)
+                host = torch.empty(video.shape, dtype=video.dtype, pin_memory=True)
+                host.copy_(video, non_blocking=True)
+                done = torch.cuda.Event(); done.record(side)
+                return host, done
+
+        def fetch(item):
+            item[1].synchronize()
+            return item[0].clone()            # out of the pinned staging buffer, like ``.cpu()``
+
+        pending = None
+        for batch in batches:
+            video = issue(batch)
+            if pending is not None:
+                yield fetch(pending)
+            pending = video
+        if pending is not None:
+            yield fetch(pending)
 
     def set_sample_graph(self, enable=True):
         """BASELINE configs[4] ("flow inverse + VAE decode, hipGraph-captured"): replay the whole device side of ``forward_sample`` --

@@ -1,3 +1,10 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-timeout 120 scripts/exp/ldpath_probe 2>&1 | tee gpurun_out/ldpath.txt
+for i in 1 2 3; do
+timeout 600 python bench.py --config c5 --steps 20 --warmup 5 2>gpurun_out/c5_pipe.err | tail -1 > gpurun_out/c5_pipe.json
+python - <<'P'
+import json; d=json.load(open('gpurun_out/c5_pipe.json')); print(d['ms_per_step'])
+for k,v in d.items():
+    if isinstance(v,dict) and 'pipelined_ms_per_step' in v: print({a:b for a,b in v.items() if a.endswith('per_step')})
+P
+done

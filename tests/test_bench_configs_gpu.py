@@ -561,3 +561,25 @@ def test_sample_graph_replay_is_bit_identical(golden):
     m.set_sample_graph(False)
     assert torch.equal(got[0], eager[0]) and torch.equal(got[1], eager[1]) and torch.equal(got[2], eager[0])
     assert not torch.equal(eager[0], eager[1])
+
+
+def test_sample_stream_equals_forward_sample_batch_by_batch(golden):
+    """``sample_stream`` (reverse flow of batch k+1 on the caller's stream beside the decode of batch k on a second stream) yields,
+    batch after batch, the bytes of ``forward_sample`` -- distinct batches and latents, more batches than pipeline stages, the
+    first frame prepended; the caller's grad mode is untouched between yields."""
+    from tests.helpers import synthetic_batch
+    g7 = golden("g7_sample_128")
+    m = _c5_model(golden, "bf16", 2)
+    batches = [synthetic_batch(2, 16, 128, seed=int(g7["batch_seed"]) + i, device=DEV) for i in range(4)]
+    torch.manual_seed(123)
+    eager = [m.forward_sample(b, n_samples=1, n_logged_vids=2, add_first_frame=True)[0] for b in batches]
+    torch.manual_seed(123)
+    got = []
+    for v in m.sample_stream(batches, n_logged_vids=2, add_first_frame=True):
+        assert torch.is_grad_enabled()
+        got.append(v)
+    assert len(got) == len(eager) == 4
+    for a, b in zip(got, eager):
+        assert a.shape == b.shape == (2, 16, 3, 128, 128) and torch.equal(a, b)
+    assert not torch.equal(eager[0], eager[1])
+    assert list(m.sample_stream([])) == []
