@@ -172,6 +172,13 @@ int ipoke_actnorm_fwd(const float* in, float* out, int M, int ld, int c0, int C,
 /* inverse: undo the permutation with inv_idx (= backward_shuffle_idx), then (x - bias)/(exp(ls)+1e-8) */
 int ipoke_actnorm_inv(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
                       const float* bias, const int32_t* inv_idx, void* stream);
+/* The same with a second output for the sampling direction: the channels e_off + j*e_stride (j < e_C) of `out` once more as a dense,
+ * zero-padded [M][ext_ld] operand of `dtype` -- the conditioning input of the coupling that is inverted next (NICE2d.backward,
+ * macow2.py:449-470, reads its net's input from the state this ActNorm inverse produces), which then needs no ipoke_extract_cols
+ * launch.  ext == NULL: ipoke_actnorm_inv.  ext_ld - e_C <= ld. */
+int ipoke_actnorm_inv_ext(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
+                          const float* bias, const int32_t* inv_idx, void* ext, int ext_ld, int e_off, int e_stride, int e_C,
+                          int dtype, void* stream);
 /* per-sample partial sums part[b] = [d_log_scale(C) | d_bias(C)]; reduce over b with ipoke_reduce_rows */
 int ipoke_actnorm_bwd(const float* dy, const float* x, float* dx, int M, int ld, int c0, int C,
                       const float* log_scale, const int32_t* idx, const float* dld, int B, int P,

@@ -133,6 +133,7 @@ SIGNATURES = {
     "ipoke_cond_prepare": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_actnorm_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "ipoke_actnorm_inv": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "ipoke_actnorm_inv_ext": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ipoke_actnorm_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
     "ipoke_actnorm_init": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "ipoke_affine_fwd": (c_int, [POINTER(AffineDesc), _P, _P, _P, _P, c_int, c_int, _P]),

@@ -111,6 +111,33 @@ __global__ void actnorm_inv_kernel(const float* __restrict__ in, float* __restri
     out[i] = v;
   }
 }
+// The same with the conditioning operand of the coupling inverted NEXT as a second output (what extract_cols would read back out of
+// `out` in a launch of its own): ext[m][j] = T(out[m][e_off + j*e_stride]) for j < e_C, zero for e_C <= j < ext_ld (ext_ld - e_C <= ld)
+template <typename T>
+__global__ void actnorm_inv_ext_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int ld, int c0, int C,
+                                       const float* __restrict__ ls, const float* __restrict__ bias,
+                                       const int* __restrict__ inv_idx, T* __restrict__ ext, int ext_ld, int e_off, int e_stride,
+                                       int e_C) {
+  const long total = (long)M * ld;
+  const int pad = ext_ld - e_C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ld);
+    const long row = i / ld;
+    const int c = col - c0;
+    float v;
+    if (c >= 0 && c < C) {
+      const int src = inv_idx ? inv_idx[c] : c;
+      v = in[row * ld + c0 + src];
+      if (ls) v = (v - bias[c]) / (expf(ls[c]) + 1e-8f);
+    } else {
+      v = in[i];
+    }
+    out[i] = v;
+    const int rel = col - e_off;
+    if (rel >= 0 && rel % e_stride == 0 && rel / e_stride < e_C) ext[row * ext_ld + rel / e_stride] = ET<T>::from_f32(v);
+    if (col < pad) ext[row * ext_ld + e_C + col] = ET<T>::from_f32(0.f);
+  }
+}
 // backward.  x = saved input of the layer.  One block per sample; per-sample partial sums of the
 // parameter gradients go to part[b][2C] (reduced over b by ipoke_reduce_rows):
 //   dx[m][c0+idx[j]] = dy[m][c0+j] * exp(ls[idx[j]])
@@ -739,6 +766,24 @@ extern "C" int ipoke_actnorm_inv(const float* in, float* out, int M, int ld, int
   IPK_REQUIRE(in && out && c0 >= 0 && c0 + C <= ld, "bad arguments");
   hipLaunchKernelGGL(actnorm_inv_kernel, dim3(grid_for((long)M * ld, 256)), dim3(256), 0, STREAM(stream), in, out, M, ld,
                      c0, C, log_scale, bias, inv_idx);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_actnorm_inv_ext(const float* in, float* out, int M, int ld, int c0, int C, const float* log_scale,
+                                     const float* bias, const int32_t* inv_idx, void* ext, int ext_ld, int e_off, int e_stride,
+                                     int e_C, int dtype, void* stream) {
+  if (!ext) return ipoke_actnorm_inv(in, out, M, ld, c0, C, log_scale, bias, inv_idx, stream);
+  IPK_REQUIRE(in && out && c0 >= 0 && c0 + C <= ld, "bad arguments");
+  IPK_REQUIRE(e_C >= 1 && e_stride >= 1 && e_off >= 0 && e_off + (long)(e_C - 1) * e_stride < ld, "conditioning columns outside the state");
+  IPK_REQUIRE(ext_ld >= e_C && ext_ld - e_C <= ld, "ext_ld: at least e_C, padding no wider than the state");
+  IPK_REQUIRE(dtype == IPOKE_F32 || dtype == IPOKE_BF16, "dtype");
+  const dim3 grid(grid_for((long)M * ld, 256));
+  if (dtype == IPOKE_BF16)
+    hipLaunchKernelGGL(actnorm_inv_ext_kernel<bf16_t>, grid, dim3(256), 0, STREAM(stream), in, out, M, ld, c0, C, log_scale, bias, inv_idx,
+                       static_cast<bf16_t*>(ext), ext_ld, e_off, e_stride, e_C);
+  else
+    hipLaunchKernelGGL(actnorm_inv_ext_kernel<float>, grid, dim3(256), 0, STREAM(stream), in, out, M, ld, c0, C, log_scale, bias, inv_idx,
+                       static_cast<float*>(ext), ext_ld, e_off, e_stride, e_C);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -1206,6 +1206,13 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
   rc = make_lanes(c, f->n_lanes, lanes); if (rc) return rc;
   rc = fork_lanes(f, c.s, lanes); if (rc) return rc;
   const int64_t hb = (int64_t)f->cfg.hidden * f->esz;
+  static const bool no_an_ext = getenv("IPOKE_NO_AN_EXT") != nullptr;       // developer A/B
+  // a stand-alone ActNorm (+ Shuffle) whose inverse is directly followed by the inverse of a coupling (ops[k - 1] in this direction)
+  auto actnorm_feeds = [&](int k) {
+    if (no_an_ext || k < 1 || k >= (int)f->ops.size()) return false;
+    const Op& an = f->ops[k]; const Op& nx = f->ops[k - 1];
+    return an.type == OP_ACTNORM && an.unit_of < 0 && nx.type == OP_NICE && nx.Kc1 - nx.cin <= c.ld && nx.Kc1 <= 64;
+  };
   int cur = 0;
   for (int i = (int)f->ops.size() - 1; i >= 0; --i) {
     const Op& op = f->ops[i];
@@ -1232,16 +1239,19 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
       if (op.type == OP_LU) {
         rc = ipoke_lu_apply(in, out, (int64_t)l.B * l.f->P, l.ld, op.C, lu_mat(l, op, 1), 0, l.stream());
       } else if (op.type == OP_ACTNORM) {
-        rc = ipoke_actnorm_inv(in, out, (int)l.M, l.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
-                               op.p_bias >= 0 ? params + op.p_bias : nullptr, op.idx_bwd >= 0 ? perm + op.idx_bwd : nullptr,
-                               l.stream());
+        // followed (in this direction) by a coupling: its conditioning operand is written here instead of by an extract_cols launch
+        const Op* nx = actnorm_feeds(i) ? &f->ops[i - 1] : nullptr;
+        rc = ipoke_actnorm_inv_ext(in, out, (int)l.M, l.ld, op.c0, op.Cn, op.p_ls >= 0 ? params + op.p_ls : nullptr,
+                                   op.p_bias >= 0 ? params + op.p_bias : nullptr, op.idx_bwd >= 0 ? perm + op.idx_bwd : nullptr,
+                                   nx ? l.rows(l.plan.tmp_zc, 64L * f->esz) : nullptr, nx ? nx->Kc1 : 0, nx ? nx->z_off : 0,
+                                   nx ? nx->z_stride : 1, nx ? nx->cin : 0, l.dtype, l.stream());
       } else if (op.type == OP_MCF) {
         ipoke_mcf_desc d; mcf_desc(l, op, d);
         d.x = in; d.y = out;
         rc = ipoke_mcf_inv(&d, l.dtype, l.stream());
       } else {
         // the conditioning channels are untouched by the coupling, so the net sees the same input as in forward
-        const bool have_zc = i + 1 < (int)f->ops.size() && nice_feeds(f->ops[i + 1], op);     // the coupling inverted just before this one
+        const bool have_zc = i + 1 < (int)f->ops.size() && (nice_feeds(f->ops[i + 1], op) || actnorm_feeds(i + 1));     // written by the layer inverted just before this one
         rc = nice_net(l, op, in, l.rows(l.plan.tmp_h1, hb), l.rows(l.plan.tmp_h2, (int64_t)op.hidK * f->esz), l.rows(l.plan.tmp_zc, 64L * f->esz),
                       have_zc);
         if (rc) return rc;

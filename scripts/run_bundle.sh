@@ -1,10 +1,11 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-for i in 1 2 3; do
-timeout 600 python bench.py --config c5 --steps 20 --warmup 5 2>gpurun_out/c5_pipe.err | tail -1 > gpurun_out/c5_pipe.json
-python - <<'P'
-import json; d=json.load(open('gpurun_out/c5_pipe.json')); print(d['ms_per_step'])
-for k,v in d.items():
-    if isinstance(v,dict) and 'pipelined_ms_per_step' in v: print({a:b for a,b in v.items() if a.endswith('per_step')})
-P
+cd /tmp && export TMPDIR=/tmp
+for tag in on off; do
+  if [ $tag = off ]; then export IPOKE_NO_AN_EXT=1; fi
+  rm -rf /tmp/prof_$tag
+  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o c5 -- python /root/repo/bench.py --config c5 --steps 20 --warmup 5 > /dev/null 2>&1
+  f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
+  echo "== $tag $f"
+  grep -E "extract_cols|actnorm_inv|affine_inv|unit_inv" $f | cut -c1-160
 done

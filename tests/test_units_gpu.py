@@ -486,3 +486,36 @@ def test_conv_output_scatter_with_depth(dtype):
     mask = torch.ones(N, Do, Ho, Wo, dtype=torch.bool, device=DEV)
     mask[:, rd::2, rh::2, rw::2] = False
     assert (o5[mask] == 5.0).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("split", ["half", "skip"])
+def test_actnorm_inv_with_conditioning_operand(dtype, split):
+    """ipoke_actnorm_inv_ext: the ActNorm (+ Shuffle) inverse and, in the same launch, the conditioning operand of the coupling that is
+    inverted next -- bit-identical to ipoke_actnorm_inv followed by ipoke_extract_cols (continuous and even / odd channel splits, a
+    sub-range ActNorm as in the priors, padded operand columns zero, the columns beyond ext_ld untouched); ext == NULL is the plain
+    inverse; padding wider than the state is refused."""
+    g = torch.Generator().manual_seed(3)
+    M, ld, c0, C = 2 * 64, 32, 8, 24
+    s = torch.randn(M, ld, generator=g).to(DEV)
+    ls, b = (0.3 * torch.randn(C, generator=g)).to(DEV), torch.randn(C, generator=g).to(DEV)
+    inv_idx = torch.randperm(C, generator=g).to(torch.int32).to(DEV)
+    e_off, e_stride, e_C = (16, 1, 12) if split == "half" else (1, 2, 16)
+    ext_ld = 32
+    td = ops.torch_dtype(dtype)
+    want_state = ops.actnorm_inv(s, c0, C, ls, b, inv_idx)
+    want_ext = torch.empty(M, ext_ld, dtype=td, device=DEV)
+    check(_lib.lib().ipoke_extract_cols(want_state.data_ptr(), ld, e_off, e_stride, e_C, want_ext.data_ptr(), ext_ld, M, ops._dt(dtype),
+                                        _lib.current_stream()))
+    out = torch.empty_like(s)
+    ext = torch.full((M, ext_ld), 7.0, dtype=td, device=DEV)
+    check(_lib.lib().ipoke_actnorm_inv_ext(s.data_ptr(), out.data_ptr(), M, ld, c0, C, ls.data_ptr(), b.data_ptr(), inv_idx.data_ptr(),
+                                           ext.data_ptr(), ext_ld, e_off, e_stride, e_C, ops._dt(dtype), _lib.current_stream()))
+    assert torch.equal(out, want_state) and torch.equal(ext, want_ext)
+    assert float(ext[:, e_C:].abs().max()) == 0.0
+    out2 = torch.empty_like(s)
+    check(_lib.lib().ipoke_actnorm_inv_ext(s.data_ptr(), out2.data_ptr(), M, ld, c0, C, ls.data_ptr(), b.data_ptr(), inv_idx.data_ptr(),
+                                           None, 0, 0, 1, 0, ops._dt(dtype), _lib.current_stream()))
+    assert torch.equal(out2, want_state)
+    assert _lib.lib().ipoke_actnorm_inv_ext(s.data_ptr(), out.data_ptr(), M, ld, c0, C, ls.data_ptr(), b.data_ptr(), inv_idx.data_ptr(),
+                                            ext.data_ptr(), e_C + ld + 1, e_off, e_stride, e_C, ops._dt(dtype), _lib.current_stream()) != 0
