@@ -29,7 +29,7 @@ def overlapping_stream(candidates=8, spin_ms=0.5, report=None):
     cycles = 100_000
     _spin_pair_ms(main, None, cycles)                                   # warm: module load
     single = min(_spin_pair_ms(main, None, cycles) for _ in range(3))
-    cycles = max(int(cycles * spin_ms / max(single, 1e-3)), 1000)        # a spin of about spin_ms, whatever the counter's unit is
+    cycles = min(max(int(cycles * spin_ms / max(single, 1e-3)), 1000), 5_000_000)   # a spin of about spin_ms, whatever the counter's unit is (bounded)
     single = min(_spin_pair_ms(main, None, cycles) for _ in range(3))
     best, best_ratio = None, None
     for i in range(candidates):

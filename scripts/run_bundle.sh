@@ -1,11 +1,11 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-for tag in on off; do
-  if [ $tag = off ]; then export IPOKE_NO_AN_EXT=1; fi
-  rm -rf /tmp/prof_$tag
-  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o c5 -- python /root/repo/bench.py --config c5 --steps 20 --warmup 5 > /dev/null 2>&1
-  f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
-  echo "== $tag $f"
-  grep -E "extract_cols|actnorm_inv|affine_inv|unit_inv" $f | cut -c1-160
-done
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/final_tests.txt
+cat gpurun_out/final_tests.txt
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python bench.py 2>gpurun_out/final_bench.err | tail -1 > gpurun_out/final_bench.json
+python - <<'P'
+import json; d=json.load(open('gpurun_out/final_bench.json'))
+print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['cpu_baseline']['value'])
+for c,v in d.get('secondary',{}).items(): print(c, v.get('ms_per_step'), (v.get('hipgraph') or {}).get('pipelined_ms_per_step'))
+P
