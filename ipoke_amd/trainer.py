@@ -60,7 +60,30 @@ class SecondStageTrainer:
         # its side streams the full-chip encoder kernels cost more than the 4 ms hole they fill (the same verdict as =start)
         at = os.environ.get("IPOKE_PREFETCH_AT", "")
         self.prefetch_piece = int(at[5:]) if at.startswith("piece") else None
+        # IPOKE_PREFETCH_THREAD=1: the next batch's encoders are queued by a second host thread while this thread is inside the engine's
+        # backward call (a foreign call: the interpreter lock is free), ordered behind the forward pass on the GPU
+        self.prefetch_thread = os.environ.get("IPOKE_PREFETCH_THREAD", "0") == "1"
         model.flow.train()
+
+    def _prefetch_in_thread(self, next_batch, after):
+        """Start ``prefetch_flow_input(next_batch)`` on a second host thread; returns the function that joins it (and re-raises)."""
+        import threading
+        dev, box = torch.cuda.current_device(), {}
+
+        def run():
+            try:
+                torch.cuda.set_device(dev)              # the current device is per thread
+                self.model.prefetch_flow_input(next_batch, self.prefetch_stream, after=after)
+            except BaseException as e:                  # noqa: BLE001 -- handed to the joining thread
+                box["err"] = e
+        th = threading.Thread(target=run, name="ipoke-prefetch")
+        th.start()
+
+        def join():
+            th.join()
+            if "err" in box:
+                raise box["err"]
+        return join
 
     def _optimizer_step(self, fn):
         # (Issuing the update on its own stream so that the next step's frozen encoders run underneath it was measured:
@@ -167,6 +190,10 @@ class SecondStageTrainer:
                         m.prefetch_flow_input(next_batch, self.prefetch_stream, after=here)
                 hook_fn.wants_piece = True
             eng.grad_ready_hook = (self.n_grad_buckets, self.ready_stream, hook_fn)
+            worker = None
+            if prefetch and self.prefetch_thread and self.prefetch_piece is None:
+                worker = self._prefetch_in_thread(next_batch, fwd_done)
+                prefetch = False
             ok = False
             try:
                 loss.backward()               # exchanges and updates every slice from the engine's callbacks; on return the
@@ -175,6 +202,8 @@ class SecondStageTrainer:
                 eng.grad_ready_hook = None    # a backward outside train_step must not apply optimizer updates
                 if native and not ok:
                     self.opt.disarm_native()
+                if worker is not None:
+                    worker()
             if prefetch and not (native and self.prefetch_piece is not None and state["done"]):
                 after = fwd_done
                 if getattr(m, "_graph_encoders", False) and self.enc_graph_at == "bwd":
