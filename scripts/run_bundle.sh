@@ -1,8 +1,7 @@
 #!/bin/bash
-cd /root/repo; mkdir -p gpurun_out
-for e in "IPOKE_PREFETCH_THREAD=0" "IPOKE_PREFETCH_THREAD=1" "IPOKE_PREFETCH_THREAD=0" "IPOKE_PREFETCH_THREAD=1"; do
-env $e timeout 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-secondary 2>gpurun_out/thr.err | tail -1 > gpurun_out/thr.json
-python - <<P
-import json; d=json.load(open('gpurun_out/thr.json')); print("$e", d['ms_per_step'], d.get('ms_per_step_median'), d.get('loss'))
-P
-done
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04e; mkdir -p $O
+date
+timeout -s INT 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5p -- python -X faulthandler $R/bench.py --config c5 --steps 5 --warmup 3 --no-cpu-baseline > $O/c5_pipe_trace_run.log 2>&1
+echo "c5 pipelined trace rc=$?"; date
+grep -v "^E2026\|^W2026\|^I2026" $O/c5_pipe_trace_run.log | tail -30
