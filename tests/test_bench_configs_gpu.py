@@ -583,3 +583,18 @@ def test_sample_stream_equals_forward_sample_batch_by_batch(golden):
         assert a.shape == b.shape == (2, 16, 3, 128, 128) and torch.equal(a, b)
     assert not torch.equal(eager[0], eager[1])
     assert list(m.sample_stream([])) == []
+
+
+def test_overlapping_stream_runs_beside_the_current_one():
+    """utils/streams.py: the chosen second stream overlaps with the caller's (two spin kernels take about as long as one), also after a
+    dozen other streams of both priorities have been created and used."""
+    from ipoke_amd.utils.streams import overlapping_stream
+    others = [torch.cuda.Stream(priority=p) for p in (0, -1) * 6]
+    for s_ in others:
+        with torch.cuda.stream(s_):
+            torch.zeros(8, device=DEV)
+    torch.cuda.synchronize()
+    rep = []
+    s2 = overlapping_stream(report=rep)
+    assert isinstance(s2, torch.cuda.Stream) and s2 != torch.cuda.current_stream()
+    assert len(rep) >= 1 and rep[-1][1] < 1.5, rep
