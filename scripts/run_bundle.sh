@@ -1,3 +1,3 @@
 #!/bin/bash
+# scratch: the command bundle of the latest gpurun call
 cd /root/repo; mkdir -p gpurun_out
-python -m pytest tests/test_bench_configs_gpu.py -x -q -s -k "overlapping_stream" 2>&1 | tail -4
