@@ -90,12 +90,14 @@ def test_forward_sample_with_injected_latent(golden, dtype):
     assert e_v.max().item() <= (5e-4 if dtype == "f32" else 0.2) and e_v.mean().item() <= (2e-5 if dtype == "f32" else 2e-2)
 
 
-@pytest.mark.parametrize("enc_graph", ["1", "0"])
+@pytest.mark.parametrize("enc_graph", ["1", "0", "thread"])
 def test_encoder_prefetch_does_not_change_training(enc_graph, monkeypatch):
     """train_step(batch, next_batch=...) runs the next batch's frozen encoders on a side stream during the current backward:
     same losses and parameters as the plain loop (the encoder's CPU-generator draws keep their order).  enc_graph = 1 (default): the
     prefetched encoders are replayed from one captured hipGraph (first prefetch eager, second captures, third and fourth replay)."""
-    monkeypatch.setenv("IPOKE_ENC_GRAPH", enc_graph)
+    # enc_graph = "thread": eager encoders queued by a second host thread while the main thread is inside the backward call
+    monkeypatch.setenv("IPOKE_ENC_GRAPH", "0" if enc_graph == "thread" else enc_graph)
+    monkeypatch.setenv("IPOKE_PREFETCH_THREAD", "1" if enc_graph == "thread" else "0")
     from ipoke_amd import configs
     from ipoke_amd.second_stage import PokeMotionModel
     from ipoke_amd.trainer import SecondStageTrainer
@@ -118,6 +120,7 @@ def test_encoder_prefetch_does_not_change_training(enc_graph, monkeypatch):
                             "flow": torch.randn(2, 2, 64, 64, generator=g).cuda(),
                             "poke": [torch.zeros(2, 2, 64, 64).cuda(), torch.zeros(2, 5, 2, dtype=torch.int64).cuda()]})
         tr = SecondStageTrainer(model)
+        assert tr.prefetch_thread == (enc_graph == "thread")
         if not prefetch:
             tr.prefetch_stream = None
         losses = []
