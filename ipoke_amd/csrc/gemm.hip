@@ -561,6 +561,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
   const int nkb_total = (p.Ktot + BK - 1) / BK;
   const int kb_begin = z * p.kb_per_split;
   const int kb_end = min(nkb_total, kb_begin + p.kb_per_split);
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 8      // probe build: stamp 1 = kernel arguments have arrived (tile indices computed)
+  if (kb_end > m0 + n0 - 1000000) GEMM_STAMP(1);
+#endif
 
   fill_taptab(taptab, g);
 
@@ -688,6 +691,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
       ++kb_issue;
     }
   };
+#if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 7      // probe build: stamp 1 = set-up done, nothing requested yet
+  GEMM_STAMP(1);
+#endif
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue_slot(s);
 
@@ -712,7 +718,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
   for (int kb = kb_begin; kb < kb_end; kb += KPB) {
     wait_vmcnt<(NSTAGE - 2) * L * KPB>();      // this wave's share of the oldest slot has landed
     __builtin_amdgcn_s_barrier();                     // ... and everybody else's; all reads of the slot refilled below are done
+#if !(defined(IPOKE_GEMM_STAMPS) && (IPOKE_GEMM_ABL == 7 || IPOKE_GEMM_ABL == 8))
     if (kb == kb_begin) GEMM_STAMP(1);
+#endif
     issue_slot((slot + NSTAGE - 1) % NSTAGE);
     const unsigned char* base = smem + slot * STAGE;
     slot = (slot + 1) % NSTAGE;
