@@ -651,10 +651,11 @@ class _NormFn(torch.autograd.Function):
             d.dres = dres.data_ptr(); d.lddres = dres.shape[1]
         mod_n = int(m.get("mod_samples", 0)) if has_mod else 0
         if has_mod:
-            if mod_n:                  # per-frame modulation gradients [frames][clips * S][ld], summed over the frames below
-                dmg = torch.zeros(x_t.shape[0], mg_t.shape[1], dtype=mg_t.dtype, device=mg_t.device); dmb = torch.zeros_like(dmg)
-            else:
-                dmg = torch.zeros_like(mg_t); dmb = torch.zeros_like(mg_t)
+            # the kernel writes columns 0 .. C-1 of every row; only padding columns (ld > C) need the zero fill
+            alloc = torch.zeros if mg_t.shape[1] > C else torch.empty
+            rows_mod = x_t.shape[0] if mod_n else mg_t.shape[0]      # mod_n: per-frame modulation gradients [frames][clips * S][ld], summed over the frames below
+            dmg = alloc(rows_mod, mg_t.shape[1], dtype=mg_t.dtype, device=mg_t.device)
+            dmb = alloc(rows_mod, mg_t.shape[1], dtype=mg_t.dtype, device=mg_t.device)
             d.dmod_gamma = dmg.data_ptr(); d.dmod_beta = dmb.data_ptr(); d.ld_dmod = dmg.shape[1]
             d.mod_gamma = mg_t.data_ptr(); d.ld_mod = mg_t.shape[1]; d.mod_samples = mod_n
         if has_affine:
