@@ -32,6 +32,8 @@ from ctypes import byref
 import os
 import weakref
 
+import contextlib
+
 import torch
 
 from . import _lib, nn as K, ops
@@ -211,6 +213,37 @@ def _dgrad_phases(gcl, w, cin, idhw, st, dt):
 
 
 # ------------------------------------------------------------------------------------------------ convolution
+# Weight gradients beside the data-gradient chain (FirstStageTrainer.step only): inside ``wgrad_side_stream()`` the weight-gradient half
+# of _ConvFn.backward -- GEMM, slab reduction, spectral-norm terms -- is queued on a second stream behind the point of the chain where
+# its inputs exist, and the result is parked on the parameter (``_side_grad``) instead of going through autograd's accumulation, which
+# would read it on the caller's stream.  Leaving the context orders the caller's stream behind the second one and moves the parked
+# gradients to ``.grad``.  Only leaf parameters take this path; everything else (derived weights, other trainers) is untouched.
+_WGRAD_SIDE = {"stream": None, "params": []}
+_C4_WGRAD_SIDE = os.environ.get("IPOKE_C4_WGRAD_SIDE", "1") == "1"       # FirstStageTrainer.step: c4 42.9 -> 41.8 ms
+
+
+class wgrad_side_stream:
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        _WGRAD_SIDE["stream"] = self.stream
+        _WGRAD_SIDE["params"] = []
+        return self
+
+    def __exit__(self, *exc):
+        side, params = _WGRAD_SIDE["stream"], _WGRAD_SIDE["params"]
+        _WGRAD_SIDE["stream"] = None
+        _WGRAD_SIDE["params"] = []
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        for p_ in params:
+            g_ = p_.__dict__.pop("_side_grad", None)
+            if g_ is not None:
+                p_.grad = g_ if p_.grad is None else p_.grad + g_
+        return False
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, w) + bias).  ``x`` is the CL tensor [M, ld] (or None with ``meta['src']`` an fp32 image)."""
 
@@ -297,92 +330,112 @@ class _ConvFn(torch.autograd.Function):
         # ---- weight gradient, PyTorch layout
         d_w = None
         sn = m.get("sn")
-        if ctx.needs_input_grad[1]:                 # frozen weights (the VGG feature extractor) skip this half
-            taps = k[0] * k[1] * k[2]
-            d_w = torch.empty(w.shape, dtype=torch.float32, device=dy.device)
-            wd = WgradDesc()
-            wd.kd, wd.kh, wd.kw = k
-            wd.sd, wd.sh, wd.sw = st
-            wd.pd, wd.ph, wd.pw = pd
-            wd.NB = N
-            src = m.get("src")
-            # A convolution onto a handful of channels (the decoder's last one, 64 -> 3 at 128 x 128): as written the GEMM would stream
-            # the wide input once per tap against a 3-column operand (1.21 ms at B = 20, 14 TFLOP/s).  With the roles swapped -- the
-            # weight gradient of the mirrored convolution from dY (8 padded channels) to X, G[c][t'][n] = sum_i X[i][c] dY[i + t' - pad][n],
-            # valid for stride 1 and 'same' padding -- X is the dense 64-column operand read ONCE and the narrow dY is the one gathered
-            # per tap; dW[n][c][t] = G[c][k - 1 - t][n].
-            swapped = (_WGRAD_SWAP and not m["transposed"] and src is None and ldg <= 16 and x_t.shape[1] >= 4 * ldg and tuple(st) == (1, 1, 1)
-                       and all(kk % 2 == 1 and pp == kk // 2 for kk, pp in zip(k, pd)))
-            if swapped:
-                ld = x_t.shape[1]
-                wd.Di, wd.Hi, wd.Wi = odhw
-                wd.Do, wd.Ho, wd.Wo = idhw
-                wd.A = g.data_ptr(); wd.a_f32 = 0
-                wd.a_sn = odhw[0] * odhw[1] * odhw[2] * ldg; wd.a_sd = odhw[1] * odhw[2] * ldg; wd.a_sh = odhw[2] * ldg
-                wd.a_sw = ldg; wd.a_sc = 1
-                wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = ldg
-                wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
-                wd.w_sn = taps * ldg; wd.w_st = ldg; wd.w_sc = 1
-                d_w_sw = torch.empty(cin, k[0], k[1], k[2], ldg, dtype=torch.float32, device=dy.device)
-            elif not m["transposed"]:
-                wd.Di, wd.Hi, wd.Wi = idhw
-                wd.Do, wd.Ho, wd.Wo = odhw
-                if src is not None:
-                    t_src, _, _, _, sst = src
-                    wd.A = t_src.data_ptr(); wd.a_f32 = 1
-                    wd.a_sn, wd.a_sc, wd.a_sd, wd.a_sh, wd.a_sw = sst
-                    wd.Kc_real = cin; wd.Kc = K.round_up(cin, e16)
-                else:
-                    ld = x_t.shape[1]
-                    wd.A = x_t.data_ptr(); wd.a_f32 = 0
-                    wd.a_sn = idhw[0] * idhw[1] * idhw[2] * ld; wd.a_sd = idhw[1] * idhw[2] * ld; wd.a_sh = idhw[2] * ld
-                    wd.a_sw = ld; wd.a_sc = 1
-                    wd.Kc_real = K.round_up(cin, e16); wd.Kc = wd.Kc_real
-                wd.Kc_store = cin
-                wd.dY = g.data_ptr(); wd.ldy = ldg; wd.Nout = cout
-                wd.w_sn = cin * taps; wd.w_sc = taps; wd.w_st = 1
+        side = _WGRAD_SIDE["stream"] if (ctx.needs_input_grad[1] and w.is_leaf) else None
+        if side is not None:
+            here = torch.cuda.Event(); here.record()
+            side.wait_event(here)
+            for t_ in (g, x_t, dy) + tuple(snf or ()) + tuple(x for x in (sn or ()) if torch.is_tensor(x)) + ((dots,) if snf is not None else ()):
+                if torch.is_tensor(t_) and t_.is_cuda:
+                    t_.record_stream(side)
+            if m.get("src") is not None:
+                m["src"][0].record_stream(side)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+          if ctx.needs_input_grad[1]:                 # frozen weights (the VGG feature extractor) skip this half
+              s = _lib.current_stream()
+              taps = k[0] * k[1] * k[2]
+              d_w = torch.empty(w.shape, dtype=torch.float32, device=dy.device)
+              wd = WgradDesc()
+              wd.kd, wd.kh, wd.kw = k
+              wd.sd, wd.sh, wd.sw = st
+              wd.pd, wd.ph, wd.pw = pd
+              wd.NB = N
+              src = m.get("src")
+              # A convolution onto a handful of channels (the decoder's last one, 64 -> 3 at 128 x 128): as written the GEMM would stream
+              # the wide input once per tap against a 3-column operand (1.21 ms at B = 20, 14 TFLOP/s).  With the roles swapped -- the
+              # weight gradient of the mirrored convolution from dY (8 padded channels) to X, G[c][t'][n] = sum_i X[i][c] dY[i + t' - pad][n],
+              # valid for stride 1 and 'same' padding -- X is the dense 64-column operand read ONCE and the narrow dY is the one gathered
+              # per tap; dW[n][c][t] = G[c][k - 1 - t][n].
+              swapped = (_WGRAD_SWAP and not m["transposed"] and src is None and ldg <= 16 and x_t.shape[1] >= 4 * ldg and tuple(st) == (1, 1, 1)
+                         and all(kk % 2 == 1 and pp == kk // 2 for kk, pp in zip(k, pd)))
+              if swapped:
+                  ld = x_t.shape[1]
+                  wd.Di, wd.Hi, wd.Wi = odhw
+                  wd.Do, wd.Ho, wd.Wo = idhw
+                  wd.A = g.data_ptr(); wd.a_f32 = 0
+                  wd.a_sn = odhw[0] * odhw[1] * odhw[2] * ldg; wd.a_sd = odhw[1] * odhw[2] * ldg; wd.a_sh = odhw[2] * ldg
+                  wd.a_sw = ldg; wd.a_sc = 1
+                  wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = ldg
+                  wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
+                  wd.w_sn = taps * ldg; wd.w_st = ldg; wd.w_sc = 1
+                  d_w_sw = torch.empty(cin, k[0], k[1], k[2], ldg, dtype=torch.float32, device=dy.device)
+              elif not m["transposed"]:
+                  wd.Di, wd.Hi, wd.Wi = idhw
+                  wd.Do, wd.Ho, wd.Wo = odhw
+                  if src is not None:
+                      t_src, _, _, _, sst = src
+                      wd.A = t_src.data_ptr(); wd.a_f32 = 1
+                      wd.a_sn, wd.a_sc, wd.a_sd, wd.a_sh, wd.a_sw = sst
+                      wd.Kc_real = cin; wd.Kc = K.round_up(cin, e16)
+                  else:
+                      ld = x_t.shape[1]
+                      wd.A = x_t.data_ptr(); wd.a_f32 = 0
+                      wd.a_sn = idhw[0] * idhw[1] * idhw[2] * ld; wd.a_sd = idhw[1] * idhw[2] * ld; wd.a_sh = idhw[2] * ld
+                      wd.a_sw = ld; wd.a_sc = 1
+                      wd.Kc_real = K.round_up(cin, e16); wd.Kc = wd.Kc_real
+                  wd.Kc_store = cin
+                  wd.dY = g.data_ptr(); wd.ldy = ldg; wd.Nout = cout
+                  wd.w_sn = cin * taps; wd.w_sc = taps; wd.w_st = 1
+              else:
+                  # ConvTranspose y = C_W^T x: dW[in][out][tap] is the weight gradient of the direct conv with "input" dy, "output" x
+                  ld = x_t.shape[1]
+                  wd.Di, wd.Hi, wd.Wi = odhw
+                  wd.Do, wd.Ho, wd.Wo = idhw
+                  wd.A = g.data_ptr(); wd.a_f32 = 0
+                  wd.a_sn = odhw[0] * odhw[1] * odhw[2] * ldg; wd.a_sd = odhw[1] * odhw[2] * ldg; wd.a_sh = odhw[2] * ldg
+                  wd.a_sw = ldg; wd.a_sc = 1
+                  wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = cout
+                  wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
+                  wd.w_sn = cout * taps; wd.w_sc = taps; wd.w_st = 1
+              # the reduction runs over every output position (up to B*128*128 rows) while dW has only a handful of 128x128
+              # tiles: split the rows over enough workgroups to fill the chip; every split stores its own slab, summed below
+              # (deterministic, and ~10x cheaper than fp32 atomics into the few thousand addresses of dW)
+              tiles = -(-wd.Nout // 128) * -(-(taps * wd.Kc) // 128)
+              rows = N * wd.Do * wd.Ho * wd.Wo
+              splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), _WGRAD_WGS // tiles))
+              d_w_out = d_w_sw if swapped else d_w
+              if splitm > 1:
+                  slabs = torch.empty(splitm, d_w_out.numel(), dtype=torch.float32, device=dy.device)
+                  wd.splitm = splitm; wd.split_stride = d_w_out.numel(); wd.dW = slabs.data_ptr()
+                  check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+                  check(lib.ipoke_reduce_rows(ptr(slabs), ptr(d_w_out), splitm, d_w_out.numel(), s))
+              else:
+                  wd.dW = d_w_out.data_ptr()
+                  check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
+              if swapped:
+                  d_w.copy_(d_w_sw[..., :cout].flip(1, 2, 3).permute(4, 0, 1, 2, 3).reshape(w.shape))
+              if sn is not None:                        # d_w is the gradient w.r.t. weight_orig / sigma: fold sigma's own gradient in
+                  sig, snap, bws = sn
+                  t_w = 1
+                  for kk in w.shape[2:]:
+                      t_w *= int(kk)
+                  r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
+                  check(lib.ipoke_spectral_bwd(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snap), ptr(sig), ptr(bws), s))
+              if snf is not None:                       # d_w holds sum_t dW_eff_t / sigma_t; sigma_t's own gradients are rank-1 terms
+                  t_w = 1
+                  for kk in w.shape[2:]:
+                      t_w *= int(kk)
+                  r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
+                  check(lib.ipoke_spectral_bwd_frames(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snaps), snaps.stride(0),
+                                                      ptr(sig), sig.stride(0), ptr(dots), frames, s))
+        if side is not None and d_w is not None:
+            if hasattr(w, "_side_grad"):
+                with torch.cuda.stream(side):
+                    w._side_grad = w._side_grad + d_w
             else:
-                # ConvTranspose y = C_W^T x: dW[in][out][tap] is the weight gradient of the direct conv with "input" dy, "output" x
-                ld = x_t.shape[1]
-                wd.Di, wd.Hi, wd.Wi = odhw
-                wd.Do, wd.Ho, wd.Wo = idhw
-                wd.A = g.data_ptr(); wd.a_f32 = 0
-                wd.a_sn = odhw[0] * odhw[1] * odhw[2] * ldg; wd.a_sd = odhw[1] * odhw[2] * ldg; wd.a_sh = odhw[2] * ldg
-                wd.a_sw = ldg; wd.a_sc = 1
-                wd.Kc_real = ldg; wd.Kc = ldg; wd.Kc_store = cout
-                wd.dY = x_t.data_ptr(); wd.ldy = ld; wd.Nout = cin
-                wd.w_sn = cout * taps; wd.w_sc = taps; wd.w_st = 1
-            # the reduction runs over every output position (up to B*128*128 rows) while dW has only a handful of 128x128
-            # tiles: split the rows over enough workgroups to fill the chip; every split stores its own slab, summed below
-            # (deterministic, and ~10x cheaper than fp32 atomics into the few thousand addresses of dW)
-            tiles = -(-wd.Nout // 128) * -(-(taps * wd.Kc) // 128)
-            rows = N * wd.Do * wd.Ho * wd.Wo
-            splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), _WGRAD_WGS // tiles))
-            d_w_out = d_w_sw if swapped else d_w
-            if splitm > 1:
-                slabs = torch.empty(splitm, d_w_out.numel(), dtype=torch.float32, device=dy.device)
-                wd.splitm = splitm; wd.split_stride = d_w_out.numel(); wd.dW = slabs.data_ptr()
-                check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
-                check(lib.ipoke_reduce_rows(ptr(slabs), ptr(d_w_out), splitm, d_w_out.numel(), s))
-            else:
-                wd.dW = d_w_out.data_ptr()
-                check(lib.ipoke_conv_wgrad(byref(wd), ops._dt(dt), s))
-            if swapped:
-                d_w.copy_(d_w_sw[..., :cout].flip(1, 2, 3).permute(4, 0, 1, 2, 3).reshape(w.shape))
-            if sn is not None:                        # d_w is the gradient w.r.t. weight_orig / sigma: fold sigma's own gradient in
-                sig, snap, bws = sn
-                t_w = 1
-                for kk in w.shape[2:]:
-                    t_w *= int(kk)
-                r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
-                check(lib.ipoke_spectral_bwd(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snap), ptr(sig), ptr(bws), s))
-            if snf is not None:                       # d_w holds sum_t dW_eff_t / sigma_t; sigma_t's own gradients are rank-1 terms
-                t_w = 1
-                for kk in w.shape[2:]:
-                    t_w *= int(kk)
-                r_w, c_w = (w.shape[1], w.shape[0]) if m["transposed"] else (w.shape[0], w.shape[1])
-                check(lib.ipoke_spectral_bwd_frames(ptr(w), r_w, c_w, t_w, int(m["transposed"]), ptr(d_w), ptr(snaps), snaps.stride(0),
-                                                    ptr(sig), sig.stride(0), ptr(dots), frames, s))
+                w._side_grad = d_w
+                _WGRAD_SIDE["params"].append(w)
+            d_w = None
+        s = _lib.current_stream()
         # ---- data gradient: the adjoint convolution with the same weights
         d_x = None
         if x_t is not None and ctx.needs_input_grad[0]:
@@ -1261,7 +1314,14 @@ class FirstStageTrainer:
         loss, X_hat, mu, lv = first_stage_forward_loss(m, X, eps)
         if self.w_vgg != 0.0:
             loss = loss + self.w_vgg * self.vgg_loss(X[:, 1:].reshape(-1, *X.shape[2:]).float(), X_hat.reshape(-1, *X_hat.shape[2:]))
-        loss.backward()
+        if _C4_WGRAD_SIDE:
+            if getattr(self, "_wgrad_stream", None) is None:
+                from .utils.streams import overlapping_stream
+                self._wgrad_stream = overlapping_stream()
+            with wgrad_side_stream(self._wgrad_stream):
+                loss.backward()
+        else:
+            loss.backward()
         if self.grad_hook is not None:
             self.grad_hook()
         self.opt.step()

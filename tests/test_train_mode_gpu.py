@@ -223,3 +223,27 @@ def test_spectral_sigma_multi_matches_sequential_calls():
                         (snap_m[k, :r].double().cpu() - u).abs().max().item(), (snap_m[k, r:].double().cpu() - v).abs().max().item())
         print(f"sigma_multi weight {i} {shapes[i]}: vs sequential calls {e_seq:.2e}, vs float64 torch arithmetic {e_ref:.2e}")
         assert e_seq <= 1e-6 and e_ref <= 2e-5
+
+
+@pytest.mark.parametrize("dtype,copies", [("f32", 1), ("bf16", 4)])
+def test_weight_gradients_on_a_second_stream(golden, dtype, copies):
+    """``wgrad_side_stream`` (FirstStageTrainer.step under IPOKE_C4_WGRAD_SIDE=1): the weight-gradient half of every convolution's backward
+    queued on a second stream and parked on the parameter until the context ends.  Same kernels on the same data: the reference's
+    reconstruction, loss and gradient checksums hold as for the plain backward (three repetitions on a fresh model each -- a missing
+    ordering between the streams reads unfinished buffers), every parameter that has a gradient in the plain backward has one, and nothing
+    is left parked.  (Two plain backward passes are not bit-identical either -- fp32 atomics in the norm statistics -- so the bar is the
+    golden one.)"""
+    from ipoke_amd import first_stage_train as FT
+    g = golden("g13_first_stage_train_mode_128")
+    X, eps = clip(g, copies=copies)
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        m = train_model(dtype)
+        loss, X_hat, mu, lv = m.training_loss(X, eps)
+        with FT.wgrad_side_stream(side):
+            loss.backward()
+            parked = sum(hasattr(p, "_side_grad") for p in m.parameters())
+        assert parked > 20 and not any(hasattr(p, "_side_grad") for p in m.parameters())
+        assert FT._WGRAD_SIDE["stream"] is None and not FT._WGRAD_SIDE["params"]
+        check_step(m, g, dtype, f"c4-train-mode/wgrad-side/{rep}", loss, X_hat, mu, slots=copies)
+        grad_report(m, g, dtype, f"c4-train-mode/wgrad-side/{rep}")
