@@ -400,7 +400,7 @@ class PokeMotionModel(nn.Module):
         SPADE decode of batch k runs on a second stream.  The reverse flow is a serial chain of small launches (its inverse units occupy one
         workgroup per sample), the decoder is wide convolutions -- they fill different parts of the chip.  Per batch the same kernels run
         on the same data in the same order as in ``forward_sample`` (bit-identical results, tested); the latent is drawn from the CPU
-        generator per batch in the same order.  Yields one CPU tensor per batch, in order, one batch late."""
+        generator per batch in the same order.  Yields one CPU tensor per batch, in order, up to two batches late."""
         self.first_stage_model.eval(); self.poke_embedder.eval()
         if self.use_cond:
             self.conditioner.eval()
@@ -409,8 +409,12 @@ class PokeMotionModel(nn.Module):
             self._decode_stream = overlapping_stream()      # not any new stream: see utils/streams.py
         side, spatial = self._decode_stream, self.first_stage_config["architecture"]["min_spatial_size"]
 
+        # Schedule.  The decode stream never WAITS on the device for the flow: a stream parked in an event wait slows the other queue's
+        # dispatch (utils/streams.py: a chain of small launches runs 1.9x slower beside a waiting stream, 3-15x on an unlucky one).
+        # Instead the host queues the reverse flow of batch k+1 first and only then waits for the flow of batch k to finish -- it has
+        # been running while k+1 was queued -- before it queues the decode of k on the second stream.
         @torch.no_grad()                     # per stage, not around the yields: a generator must not hold the caller's grad mode
-        def issue(batch):
+        def issue_flow(batch):
             X = batch["images"]
             poke = self._poke_of(batch, use_keypoint_pokes)
             # same CPU generator draw as forward_sample, but through pinned memory: a pageable copy would make the host wait for the
@@ -418,7 +422,13 @@ class PokeMotionModel(nn.Module):
             z = torch.randn((X.size(0), self.config["architecture"]["flow_in_channels"], spatial, spatial), pin_memory=True)
             z = z.to(device=X.device, dtype=X.dtype, non_blocking=True)
             motion = self._sample_motion(X, poke, z)
-            side.wait_stream(torch.cuda.current_stream())
+            flow_done = torch.cuda.Event(); flow_done.record()
+            return X, motion, flow_done
+
+        @torch.no_grad()
+        def issue_decode(item):
+            X, motion, flow_done = item
+            flow_done.synchronize()                      # host-side: nothing waits on the device
             for t_ in (motion, X):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
@@ -426,7 +436,7 @@ class PokeMotionModel(nn.Module):
                 if add_first_frame:
                     video = torch.cat([X[:, 0].unsqueeze(1), video], dim=1)
                 video = video[:n_logged_vids]
-                # the copy to the host is queued right behind this batch's decode (fetched one batch later it would wait behind the NEXT decode)
+                # the copy to the host is queued right behind this batch's decode
                 host = torch.empty(video.shape, dtype=video.dtype, pin_memory=True)
                 host.copy_(video, non_blocking=True)
                 done = torch.cuda.Event(); done.record(side)
@@ -436,14 +446,22 @@ class PokeMotionModel(nn.Module):
             item[1].synchronize()
             return item[0].clone()            # out of the pinned staging buffer, like ``.cpu()``
 
-        pending = None
+        flowing, decoding = None, None       # batch whose reverse flow is queued / batch whose decode is queued
         for batch in batches:
-            video = issue(batch)
-            if pending is not None:
-                yield fetch(pending)
-            pending = video
-        if pending is not None:
-            yield fetch(pending)
+            nxt = issue_flow(batch)
+            if flowing is not None:
+                out = issue_decode(flowing)
+                if decoding is not None:
+                    yield fetch(decoding)
+                decoding = out
+            flowing = nxt
+        if flowing is not None:
+            out = issue_decode(flowing)
+            if decoding is not None:
+                yield fetch(decoding)
+            decoding = out
+        if decoding is not None:
+            yield fetch(decoding)
 
     def set_sample_graph(self, enable=True):
         """BASELINE configs[4] ("flow inverse + VAE decode, hipGraph-captured"): replay the whole device side of ``forward_sample`` --

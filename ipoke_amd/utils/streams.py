@@ -1,13 +1,22 @@
 """Picking a second stream that really runs beside the caller's.
 
 HIP streams are multiplexed onto a few hardware queues (four by default); which queue a new stream lands on depends on how many
-streams the process has created and used before (PyTorch's pools, the flow engine's side streams, RCCL).  Two streams that share a
-queue serialise -- and with cross-stream waits between them the host loses its lead as well: measured on `sample_stream`, 80 ms per
-batch on an unlucky stream against 41.5 ms on a lucky one (44.6 ms without any second stream).  `overlapping_stream` therefore tries
-a few candidates with a spin kernel on each side and keeps the first that overlaps."""
+streams the process has created before (PyTorch's pools hand them out in order, the flow engine creates five, RCCL its own).  Measured
+on an MI355X in a sampling process (`scripts/probe_pipe2.py`), for consecutive streams of PyTorch's pool, period four:
+
+* two of four run beside the caller's stream (two spin kernels take 1.1-1.2x the time of one);
+* one shares the caller's hardware queue (1.9-2.0x: no overlap at all, harmless otherwise);
+* one overlaps on an idle chip but is poison as soon as it WAITS for an event of the caller's stream: while its wait is pending, a
+  chain of small launches on the caller's stream runs 3-15x slower (1.9x beside a waiting stream of the first kind -- a pending
+  cross-stream wait is never free).  `sample_stream` with its decode stream parked in such a wait for the whole reverse flow ran at
+  80 ms per batch instead of 41.5; it now waits on the host instead, and this module keeps such streams out of the way.
+
+`overlapping_stream` tries a few candidates on an idle device and keeps the first that passes both checks."""
 import time
 
 import torch
+
+_SMALL = {}
 
 
 def _spin_pair_ms(main, other, cycles):
@@ -22,24 +31,59 @@ def _spin_pair_ms(main, other, cycles):
     return (time.perf_counter() - t0) * 1e3
 
 
+def _chain_ms_with_waiter(main, other, spin_cycles):
+    """Device time of a chain of 300 small launches on ``main`` while ``other`` (if given) sits in a wait for an event recorded behind
+    that chain."""
+    dev = torch.cuda.current_device()
+    if dev not in _SMALL:
+        _SMALL[dev] = torch.zeros(1024, dtype=torch.float32, device="cuda")
+    small = _SMALL[dev]
+    torch.cuda.synchronize()
+    c0, c1, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+    with torch.cuda.stream(main):
+        torch.cuda._sleep(spin_cycles)              # the host queues everything below while this runs
+        c0.record()
+        for _ in range(300):
+            small.add_(1.0)
+        c1.record()
+        done.record()
+    if other is not None:
+        other.wait_event(done)
+        with torch.cuda.stream(other):
+            small.add_(0.0)
+    torch.cuda.synchronize()
+    return c0.elapsed_time(c1)
+
+
+def _waiter_slowdown(main, other, spin_cycles):
+    _chain_ms_with_waiter(main, other, spin_cycles)
+    alone = min(_chain_ms_with_waiter(main, None, spin_cycles) for _ in range(2))
+    return min(_chain_ms_with_waiter(main, other, spin_cycles) for _ in range(2)) / alone
+
+
 def overlapping_stream(candidates=8, spin_ms=0.5, report=None):
-    """A torch.cuda.Stream whose work overlaps with the current stream's (checked with two spin kernels), or the best of
-    ``candidates`` if none does.  ``report`` (a list) receives (candidate index, pair time / single time) per candidate tried."""
+    """A torch.cuda.Stream whose work overlaps with the current stream's and whose pending waits do not stall it, or the best of
+    ``candidates`` if none passes.  ``report`` (a list) receives (candidate index, spin pair / single, chain slowdown beside the
+    waiting candidate) per candidate tried."""
     main = torch.cuda.current_stream()
     cycles = 100_000
     _spin_pair_ms(main, None, cycles)                                   # warm: module load
     single = min(_spin_pair_ms(main, None, cycles) for _ in range(3))
-    cycles = min(max(int(cycles * spin_ms / max(single, 1e-3)), 1000), 5_000_000)   # a spin of about spin_ms, whatever the counter's unit is (bounded)
+    per_ms = cycles / max(single, 1e-3)                                 # spin cycles per millisecond, whatever the counter's unit is
+    cycles = min(max(int(per_ms * spin_ms), 1000), 5_000_000)
+    hold = min(max(int(per_ms * 4.0), 1000), 40_000_000)                # ~4 ms: long enough to queue the chain behind it
     single = min(_spin_pair_ms(main, None, cycles) for _ in range(3))
-    best, best_ratio = None, None
+    best, best_score = None, None
     for i in range(candidates):
         cand = torch.cuda.Stream()
         _spin_pair_ms(main, cand, cycles)                               # first use of the stream binds its hardware queue
         ratio = min(_spin_pair_ms(main, cand, cycles) for _ in range(3)) / single
+        slow = _waiter_slowdown(main, cand, hold) if ratio < 1.3 else float("inf")
         if report is not None:
-            report.append((i, round(ratio, 3)))
-        if best_ratio is None or ratio < best_ratio:
-            best, best_ratio = cand, ratio
-        if ratio < 1.3:
+            report.append((i, round(ratio, 3), round(slow, 2) if slow != float("inf") else None))
+        score = ratio + (slow if slow != float("inf") else 100.0)
+        if best_score is None or score < best_score:
+            best, best_score = cand, score
+        if ratio < 1.3 and slow < 2.5:
             break
     return best

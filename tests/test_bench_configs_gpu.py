@@ -586,8 +586,8 @@ def test_sample_stream_equals_forward_sample_batch_by_batch(golden):
 
 
 def test_overlapping_stream_runs_beside_the_current_one():
-    """utils/streams.py: the chosen second stream overlaps with the caller's (two spin kernels take about as long as one), also after a
-    dozen other streams of both priorities have been created and used."""
+    """utils/streams.py: the chosen second stream overlaps with the caller's (two spin kernels take about as long as one) and a pending
+    wait on it does not stall the caller's launches, also after a dozen other streams of both priorities have been created and used."""
     from ipoke_amd.utils.streams import overlapping_stream
     others = [torch.cuda.Stream(priority=p) for p in (0, -1) * 6]
     for s_ in others:
@@ -597,4 +597,4 @@ def test_overlapping_stream_runs_beside_the_current_one():
     rep = []
     s2 = overlapping_stream(report=rep)
     assert isinstance(s2, torch.cuda.Stream) and s2 != torch.cuda.current_stream()
-    assert len(rep) >= 1 and rep[-1][1] < 1.5, rep
+    assert len(rep) >= 1 and rep[-1][1] < 1.5 and rep[-1][2] is not None and rep[-1][2] < 2.5, rep
