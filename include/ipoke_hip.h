@@ -269,6 +269,13 @@ typedef struct {
    * (NICE2d.forward, macow2.py:397-448: the net reads the channels zc_off + k * zc_stride, k < zc_cin, of the unit's output) as a
    * dtype [B*64][zc_ld] matrix, columns zc_cin .. zc_ld - 1 zero -- what ipoke_extract_cols would produce in a launch of its own */
   void* zc_out; int32_t zc_off, zc_stride, zc_cin, zc_ld;
+  /* ipoke_macow_unit_fwd / _bwd only, read from d4[0]: split = 2 or 4 runs a sample's 8x8 latent on that many workgroups (grid rows
+   * dealt in order; the workgroups exchange the 1-2 halo rows a masked convolution reads across the cut inside the launch).
+   * xchg = scratch of ipoke_macow_unit_xchg_bytes(B, split) bytes, zero-initialised ONCE by the caller and used by one launch at a
+   * time (launches on one stream); the kernels leave it all-zero.  Its first 32-bit word counts hand-off time-outs (0 = healthy).
+   * Outputs as with split = 0 / 1 (bit-identical states, saves and data gradients) except: logdet_slot[b * w + s] holds part s of
+   * the layer's log-det (w >= split), and dbias_part / post_part have split rows per sample (row b * split + s). */
+  int32_t split; void* xchg;
 } ipoke_mcf_desc;
 int ipoke_mcf_shadow_dims(int C, int Cc, int dtype, int32_t* dims8);
 int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream);
@@ -287,6 +294,7 @@ int ipoke_mcf_bwd(const ipoke_mcf_desc* d, int dtype, void* stream);
  *             per layer a2_save / scale_save (from forward), dparams_save / dc_save / dbias_part (outputs), and for the layers
  *             followed by an ActNorm y_post (its saved output) / post_part. */
 int ipoke_macow_unit_supported(int C, int Cc, int dtype);
+int64_t ipoke_macow_unit_xchg_bytes(int B, int split);
 int ipoke_macow_unit_fwd(const ipoke_mcf_desc* d4, int dtype, void* stream);
 int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* stream);
 /*   inverse : d4[3].x = the unit's OUTPUT state, d4[0].y = the reconstructed input (distinct buffers); W1 / W2 / bias2 /

@@ -78,7 +78,8 @@ class McfDesc(Structure):
                 ("dparams_save", c_void_p), ("dc_save", c_void_p), ("dbias_part", c_void_p),
                 ("post_log_scale", c_void_p), ("post_bias", c_void_p), ("y_post", c_void_p), ("post_part", c_void_p),
                 ("x_op_save", c_void_p),
-                ("zc_out", c_void_p), ("zc_off", c_int32), ("zc_stride", c_int32), ("zc_cin", c_int32), ("zc_ld", c_int32)]
+                ("zc_out", c_void_p), ("zc_off", c_int32), ("zc_stride", c_int32), ("zc_cin", c_int32), ("zc_ld", c_int32),
+                ("split", c_int32), ("xchg", c_void_p)]
 
 
 class NormDesc(Structure):
@@ -158,6 +159,7 @@ SIGNATURES = {
     "ipoke_mcf_inv": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_mcf_bwd": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_macow_unit_supported": (c_int, [c_int, c_int, c_int]),
+    "ipoke_macow_unit_xchg_bytes": (c_int64, [c_int, c_int]),
     "ipoke_macow_unit_fwd": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_macow_unit_bwd": (c_int, [POINTER(McfDesc), c_int, _P]),
     "ipoke_macow_unit_inv": (c_int, [POINTER(McfDesc), c_int, _P]),
