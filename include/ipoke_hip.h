@@ -219,7 +219,8 @@ int ipoke_actnorm_affine_bwd(int c0, int C, const float* log_scale, const int32_
 int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream);
 /* developer probe (IPOKE_SIDE_DELAY_US): one wave spinning for about `us` microseconds on `stream` */
 int ipoke_spin_delay(int us, void* stream);
-/* multi-tensor form: entries_dev[i] = {int64 src, int64 dst (float offsets), int32 ld, int32 ncols}; R rows each */
+/* multi-tensor form: entries_dev[i] = {int64 src, int64 dst (float offsets), int32 ld, int32 ncols, int32 rmul, int32 pad};
+ * entry i sums R * max(rmul, 1) rows */
 int ipoke_reduce_entry_size(void);
 int ipoke_reduce_rows_multi(const float* src, float* dst, const void* entries_dev, int nentries, int R, void* stream);
 
@@ -456,6 +457,9 @@ int ipoke_flow_backward(ipoke_flow* f, const float* params, const int32_t* perm,
  * on (a stream ordered after) `ready_stream` overlaps the remaining pieces.  On return `stream` is ordered after
  * `ready_stream`.  npieces = 1, ready_stream = stream, ready = NULL is ipoke_flow_backward. */
 typedef void (*ipoke_grad_ready_fn)(void* user, int piece, int64_t begin, int64_t end);
+/* host only: the (piece, begin, end) triples that ipoke_flow_backward_pieces(npieces) will announce, in callback order; returns their
+ * number (at most max_ranges triples are written into ranges[3 * max_ranges]) */
+int ipoke_flow_piece_ranges(const ipoke_flow* f, int npieces, int64_t* ranges, int max_ranges);
 /* Single-process training: let the engine apply torch.optim.Adam(amsgrad=True) (second_stage_video.py:648-650) itself.  While set
  * (m != NULL; m, v, vmax: optimizer state in the layout of params), ipoke_flow_backward_pieces queues -- on `ready_stream`, right
  * behind a piece's last gradient kernel -- ipoke_adam_amsgrad_step_grid over the piece's parameter ranges and the refresh of their
@@ -628,7 +632,8 @@ int ipoke_sn_jobs_upload(const ipoke_sn_job* jobs, int njobs, void* jobs_dev, vo
 /* `iterations` power iterations of every job, 3 launches per iteration; max_rows / max_cols: largest cout / cin*taps of the table */
 int ipoke_spectral_sigma_multi(const void* jobs_dev, int njobs, int max_rows, int max_cols, int iterations, float eps, void* stream);
 /* in place: gradient w.r.t. w_orig / sigma -> gradient w.r.t. w_orig:  (G - <G, W/sigma> u v^T) / sigma.
- * workspace: 2 floats, zeroed once by the caller. */
+ * workspace: ipoke_spectral_bwd_workspace_floats() floats (per-workgroup partial sums, summed in a fixed order; no initialisation). */
+long ipoke_spectral_bwd_workspace_floats(void);
 int ipoke_spectral_bwd(const float* w, int cout, int cin, int taps, int transposed, float* grad, const float* snapshot,
                        const float* sig, float* workspace, void* stream);
 /* torch.optim.Adam (amsgrad off, coupled weight decay; reference first_stage_motion_model.py:283-300) over `count` tensors;
@@ -671,9 +676,12 @@ int ipoke_l1_pair(const void* a, int lda, const void* b, int ldb, int64_t M, int
 int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, const float* dz, const float* dmu, const float* dlv, void* dmulv,
                       int ldo, int64_t M, int Z, int dtype, void* stream);
 /* *loss_accum += scale * sum |yhat - x|, grad = scale * sign(yhat - x); yhat channels-last fp32, x fp32 [N][C][S]
- * with sample stride x_sn (first_stage_motion_model.py:265: L1 between the generated and the true frames) */
+ * with sample stride x_sn (first_stage_motion_model.py:265: L1 between the generated and the true frames).
+ * partials: ipoke_l1_loss_partials() floats of scratch -> the value is summed in a fixed order (reproducible run to run);
+ * NULL: the workgroups add their sums with float atomics */
+long ipoke_l1_loss_partials(void);
 int ipoke_l1_loss(const float* yhat_cl, int ldy, const float* x_nchw, int N, int C, int S, int64_t x_sn, float scale,
-                  float* loss_accum, float* grad_cl, int ldg, void* stream);
+                  float* loss_accum, float* grad_cl, int ldg, float* partials, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * FVD evaluation (reference utils/metrics.py; host side in ipoke_amd/fvd.py).  The I3D convolutions are ipoke_conv_forward

@@ -193,6 +193,7 @@ SIGNATURES = {
     "ipoke_spectral_workspace_floats": (ctypes.c_long, [c_int, c_int, c_int]),
     "ipoke_spectral_sigma": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, ctypes.c_float, _P, _P, _P, _P]),
     "ipoke_spectral_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "ipoke_spectral_bwd_workspace_floats": (ctypes.c_long, []),
     "ipoke_sn_job_size": (c_int, []),
     "ipoke_sn_jobs_upload": (c_int, [_P, c_int, _P, _P]),
     "ipoke_spectral_sigma_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P]),
@@ -211,7 +212,8 @@ SIGNATURES = {
     "ipoke_l1_pair": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_float, _P, _P, c_int, c_int, _P]),
     "ipoke_kl_loss": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "ipoke_reparam_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
-    "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P]),
+    "ipoke_l1_loss": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, c_int, _P, _P]),
+    "ipoke_l1_loss_partials": (ctypes.c_long, []),
     "ipoke_relayout_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "ipoke_wn_scale_multi_range": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ipoke_flow_prepare_weights_range": (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
@@ -245,6 +247,7 @@ SIGNATURES = {
                                      POINTER(ctypes.c_double)]),
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),
     "ipoke_flow_destroy": (None, [_P]),
+    "ipoke_flow_piece_ranges": (c_int, [_P, c_int, POINTER(c_int64), c_int]),
     "ipoke_flow_param_count": (c_int64, [_P]),
     "ipoke_flow_index_count": (c_int64, [_P]),
     "ipoke_flow_tensor_count": (c_int32, [_P]),

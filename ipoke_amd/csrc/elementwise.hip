@@ -686,14 +686,15 @@ __global__ void adam_amsgrad_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
-// dst[e.dst + c] = sum_r src[e.src + r*e.ld + c], c < e.ncols -- one block per entry (multi-tensor reduction)
-struct ReduceEntry { long src, dst; int ld, ncols; };
+// dst[e.dst + c] = sum_{r < R * e.rmul} src[e.src + r*e.ld + c], c < e.ncols -- one block per entry (multi-tensor reduction)
+struct ReduceEntry { long src, dst; int ld, ncols, rmul, pad; };     // rmul rows per sample (>= 1)
 __global__ void reduce_rows_multi_kernel(const float* __restrict__ src, float* __restrict__ dst, const ReduceEntry* __restrict__ ent,
                                          int R) {
   const ReduceEntry e = ent[blockIdx.x];
   for (int c = threadIdx.x; c < e.ncols; c += blockDim.x) {
     float t = 0.f;
-    for (int r = 0; r < R; ++r) t += src[e.src + (long)r * e.ld + c];
+    const int rows = R * (e.rmul > 0 ? e.rmul : 1);
+    for (int r = 0; r < rows; ++r) t += src[e.src + (long)r * e.ld + c];
     dst[e.dst + c] = t;
   }
 }

@@ -115,6 +115,9 @@ struct ipoke_flow {
   std::vector<int> red_first;          // first reduction-table entry of op i (size nops + 1)
   int last_fwd_B = 0; bool have_saved = false;
   int P = 64;
+  // fused MaCowUnit launches on unit_split workgroups per sample (mcf_unit_split.hip; 1 = one workgroup per sample) and the
+  // zero-initialised exchange scratch of those launches (sized for max_batch; used by one launch at a time: the chain's stream)
+  int unit_split = 1; void* d_xchg = nullptr;
   // every masked-conv layer is differentiated inside a fused MaCowUnit launch, which also writes the layer's input in the matrix
   // cores' dtype: the shifted-conv weight gradients then read that copy through the LDS-DMA GEMM instead of the fp32 state
   bool mcf_xop = false;
@@ -423,6 +426,8 @@ struct Plan {
   int64_t lu = 0;                               // [W | W^-1 | wl | wu] of every LU 1x1 conv
 };
 constexpr int kMaxLanes = 4;
+constexpr int kMaxUnitSplit = 4;          // rows of dbias_part per sample
+constexpr int kDefaultUnitSplit = 4;
 int64_t take(int64_t& cur, int64_t bytes) { const int64_t o = cur; cur = align_up(cur + bytes, 256); return o; }
 
 int max_splitk(const ipoke_flow& f, int B) {
@@ -465,7 +470,7 @@ Plan make_plan(ipoke_flow& f, int B, int mode) {
   p.state0 = take(cur, (int64_t)(f.ops.size() + 1) * p.state_stride);
   p.g0 = take(cur, p.state_stride);
   p.g1 = take(cur, p.state_stride);
-  p.dbias_part = take(cur, (int64_t)f.ops.size() * (B + 1) * 128 * 4);
+  p.dbias_part = take(cur, (int64_t)f.ops.size() * (kMaxUnitSplit * B + 1) * 128 * 4);
   for (auto& op : f.ops) {
     if (op.type == OP_MCF) {
       op.ws_a = take(cur, M * op.K2p * f.esz);        // a2 (ELU(cat[c, h]))
@@ -510,7 +515,10 @@ struct Ctx {
   float* partials() const { return reinterpret_cast<float*>(ws + plan.partials + (int64_t)lane * plan.partials_lane); }
   void* cond() const { return rows(plan.cond_act, (int64_t)f->cfg.cond_channels * f->esz); }
   float* dld() const { return at<float>(plan.dld) + b0; }
-  float* dbp(int op_index, int ldp) const { return at<float>(plan.dbias_part) + (int64_t)op_index * (Bfull + 1) * 128 + (int64_t)b0 * ldp; }
+  // per-sample partial sums of op op_index: `parts` rows of ldp floats per sample (fused unit launches split over workgroups)
+  float* dbp(int op_index, int ldp, int parts = 1) const {
+    return at<float>(plan.dbias_part) + (int64_t)op_index * (kMaxUnitSplit * Bfull + 1) * 128 + (int64_t)b0 * parts * ldp;
+  }
 };
 
 void set_conv8(ipoke_conv_desc& d, int B, int k, int pad) {
@@ -601,7 +609,7 @@ int common_checks(ipoke_flow* f, int B) {
 }
 
 struct WgEntryH { long a_off, y_off, w_off; int kh, kw, ph, pw; };
-struct RedEntryH { long src, dst; int ld, ncols; };
+struct RedEntryH { long src, dst; int ld, ncols, rmul, pad; };   // rmul: rows per sample (ipoke_reduce_rows_multi sums R * rmul rows)
 
 void drop_graphs(ipoke_flow* f) {
   for (auto& g : f->graphs) {
@@ -625,21 +633,23 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
   for (size_t i = 0; i < f->ops.size(); ++i) {
     const Op& op = f->ops[i];
     f->red_first[i] = (int)red.size();
-    const long dbp = (long)(plan.dbias_part / 4) + (long)i * (B + 1) * 128;
+    const long dbp = (long)(plan.dbias_part / 4) + (long)i * (kMaxUnitSplit * B + 1) * 128;
+    // partial sums written by a fused unit launch (its four masked convs and two ActNorms) have unit_split rows per sample
+    const int rmul = op.unit_of >= 0 ? f->unit_split : 1;
     if (op.type == OP_MCF) {
       const McfGeom g = mcf_geom(op.order);
       w1[op.mcf_idx] = {f->mcf_xop ? (long)op.ws_e : (long)(plan.state0 + (int64_t)i * plan.state_stride), (long)op.ws_d, (long)op.p_w1, g.kh,
                         g.kw, -g.oy, -g.ox};
       w2[op.mcf_idx] = {(long)op.ws_a, (long)op.ws_c, (long)op.p_v, 1, 1, 0, 0};
-      red.push_back({dbp, (long)op.p_b, 2 * op.C, 2 * op.C});
+      red.push_back({dbp, (long)op.p_b, 2 * op.C, 2 * op.C, rmul, 0});
     } else if (op.type == OP_NICE) {
       nt[0][op.nice_idx] = {(long)op.ws_g, (long)op.ws_f, (long)op.p_c1, 3, 3, 1, 1};     // conv1: saved conditioning columns x d(pre-act 1)
       nt[1][op.nice_idx] = {(long)op.ws_a, (long)op.ws_e, (long)op.p_c2, 1, 1, 0, 0};     // conv2: h1 x d(pre-act 2)
       nt[2][op.nice_idx] = {(long)op.ws_b, (long)op.ws_d, (long)op.p_v, 3, 3, 1, 1};      // conv3: h2 x d(raw shift / scale)
-      red.push_back({dbp, (long)op.p_b, 2 * op.cout, 2 * op.cout});
+      red.push_back({dbp, (long)op.p_b, 2 * op.cout, 2 * op.cout, 1, 0});
     } else if (op.p_ls >= 0) {
-      red.push_back({dbp, (long)op.p_ls, 2 * op.Cn, op.Cn});
-      red.push_back({dbp + op.Cn, (long)op.p_bias, 2 * op.Cn, op.Cn});
+      red.push_back({dbp, (long)op.p_ls, 2 * op.Cn, op.Cn, rmul, 0});
+      red.push_back({dbp + op.Cn, (long)op.p_bias, 2 * op.Cn, op.Cn, rmul, 0});
     }
   }
   drop_graphs(f);    // captured launches hold the old table addresses
@@ -659,6 +669,36 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
   f->n_red = (int)red.size();
   f->tab_B = B;
   return IPOKE_OK;
+}
+
+// pieces of the piecewise backward: groups of consecutive units (steps / priors), last unit first, of roughly equal parameter counts
+std::vector<std::pair<int, int>> backward_pieces(const ipoke_flow* f, int npieces) {
+  std::vector<std::pair<int, int>> pieces;            // (lowest unit, highest unit)
+  const int U = (int)f->units.size();
+  int64_t total = 0;
+  for (const auto& u : f->units) total += u.p_hi - u.p_lo;
+  const int np = npieces < 1 ? 1 : (npieces > U ? U : npieces);
+  int hi = U - 1;
+  int64_t acc = 0, done = 0;
+  for (int u = U - 1; u >= 0; --u) {
+    acc += f->units[u].p_hi - f->units[u].p_lo;
+    const int left = np - (int)pieces.size();
+    if (u == 0 || (left > 1 && (acc >= (total - done + left - 1) / left || u == left - 1))) {
+      pieces.push_back({u, hi}); hi = u - 1; done += acc; acc = 0;
+    }
+  }
+  return pieces;
+}
+// flat-parameter ranges [begin, end) of a piece: layers.*, priors.* and (use1x1) shuffle_layers.* are separate regions
+void piece_param_ranges(const ipoke_flow* f, int lvl_lo, int lvl_hi, int64_t p0[3], int64_t p1[3]) {
+  for (int k = 0; k < 3; ++k) { p0[k] = -1; p1[k] = -1; }
+  for (int u = lvl_lo; u <= lvl_hi; ++u) {
+    const auto& un = f->units[u];
+    const int k = un.kind;
+    if (p0[k] < 0) p0[k] = un.p_lo;
+    p1[k] = un.p_hi;
+    if (un.p2_lo >= 0) { if (p0[2] < 0) p0[2] = un.p2_lo; p1[2] = un.p2_hi; }
+  }
 }
 
 hipEvent_t next_event(ipoke_flow* f) {
@@ -704,6 +744,12 @@ extern "C" int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out)
   f->n_lanes = ln ? atoi(ln) : 1;
   if (f->n_lanes < 1) f->n_lanes = 1;
   if (f->n_lanes > kMaxLanes) f->n_lanes = kMaxLanes;
+  {   // rows of a sample dealt to 2 / 4 workgroups in the fused unit launches (IPOKE_UNIT_SPLIT=1: one workgroup per sample)
+    const char* us = getenv("IPOKE_UNIT_SPLIT");
+    f->unit_split = us ? atoi(us) : kDefaultUnitSplit;
+    if (f->unit_split != 2 && f->unit_split != 4) f->unit_split = 1;
+    if (f->n_lanes > 1 || cfg->dtype != IPOKE_BF16) f->unit_split = 1;     // (lanes would share the scratch across streams)
+  }
   *out = f.release();
   return IPOKE_OK;
 }
@@ -712,6 +758,11 @@ extern "C" int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out)
 // (names, shapes, offsets) can be inspected on a host without a GPU.
 static int ensure_device(ipoke_flow* f) {
   if (f->d_rjobs) return IPOKE_OK;
+  if (f->unit_split > 1 && !f->d_xchg) {
+    const int64_t nb = ipoke_macow_unit_xchg_bytes(f->cfg.max_batch, f->unit_split);
+    IPK_HIP(hipMalloc(&f->d_xchg, nb));
+    IPK_HIP(hipMemset(f->d_xchg, 0, nb));
+  }
   IPK_REQUIRE((int)sizeof(RelayoutJobH) == ipoke_relayout_job_size() && (int)sizeof(WnJobH) == ipoke_wn_job_size(),
               "job table layout mismatch");
   IPK_HIP(hipMalloc(&f->d_rjobs, f->rjobs.size() * sizeof(RelayoutJobH)));
@@ -783,12 +834,32 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   for (int k = 0; k < 3; ++k) if (f->d_ntab[k]) (void)hipFree(f->d_ntab[k]);
   if (f->d_w2tab) (void)hipFree(f->d_w2tab);
   if (f->d_redtab) (void)hipFree(f->d_redtab);
+  if (f->d_xchg) (void)hipFree(f->d_xchg);
   for (auto e : f->events) (void)hipEventDestroy(e);
   drop_graphs(f);
   if (f->side) (void)hipStreamDestroy(f->side);
   if (f->cap) (void)hipStreamDestroy(f->cap);
   for (auto l : f->lanes) if (l) (void)hipStreamDestroy(l);
   delete f;
+}
+
+/* Host only (no device access): the flat-parameter ranges ipoke_flow_backward_pieces(npieces) announces through its `ready` callback, in
+ * callback order -- ranges[3 * i] = piece, ranges[3 * i + 1] = begin, ranges[3 * i + 2] = end (floats).  Returns the number of ranges
+ * (<= max_ranges entries are written), negative on error.  Lets a data-parallel host size its per-slice shards before the first step. */
+extern "C" int ipoke_flow_piece_ranges(const ipoke_flow* f, int npieces, int64_t* ranges, int max_ranges) {
+  IPK_REQUIRE(f != nullptr && (ranges != nullptr || max_ranges == 0), "bad arguments");
+  const std::vector<std::pair<int, int>> pieces = backward_pieces(f, npieces);
+  int n = 0;
+  for (size_t i = 0; i < pieces.size(); ++i) {
+    int64_t p0[3], p1[3];
+    piece_param_ranges(f, pieces[i].first, pieces[i].second, p0, p1);
+    for (int kind = 0; kind < 3; ++kind) {
+      if (p0[kind] < 0 || p1[kind] <= p0[kind]) continue;
+      if (n < max_ranges) { ranges[3 * n] = (int64_t)i; ranges[3 * n + 1] = p0[kind]; ranges[3 * n + 2] = p1[kind]; }
+      ++n;
+    }
+  }
+  return n;
 }
 
 extern "C" int64_t ipoke_flow_param_count(const ipoke_flow* f) { return f ? f->n_params : -1; }
@@ -1088,6 +1159,7 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
           d4[3].zc_out = save ? l.rows(nx.ws_g, (int64_t)nx.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
           d4[3].zc_off = nx.z_off; d4[3].zc_stride = nx.z_stride; d4[3].zc_cin = nx.cin; d4[3].zc_ld = nx.Kc1;
         }
+        if (f->unit_split > 1 && f->d_xchg) { d4[0].split = f->unit_split; d4[0].xchg = f->d_xchg; }
         rc = ipoke_macow_unit_fwd(d4, l.dtype, l.stream()); if (rc) return rc;
       }
       cur = nxt;
@@ -1352,22 +1424,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   }
   // pieces: groups of consecutive units (steps / priors), last unit first, of roughly equal parameter counts
   hipStream_t rs = ready_stream ? ready_stream : s;
-  std::vector<std::pair<int, int>> pieces;            // (lowest unit, highest unit)
-  {
-    const int U = (int)f->units.size();
-    int64_t total = 0;
-    for (const auto& u : f->units) total += u.p_hi - u.p_lo;
-    const int np = npieces < 1 ? 1 : (npieces > U ? U : npieces);
-    int hi = U - 1;
-    int64_t acc = 0, done = 0;
-    for (int u = U - 1; u >= 0; --u) {
-      acc += f->units[u].p_hi - f->units[u].p_lo;
-      const int left = np - (int)pieces.size();
-      if (u == 0 || (left > 1 && (acc >= (total - done + left - 1) / left || u == left - 1))) {
-        pieces.push_back({u, hi}); hi = u - 1; done += acc; acc = 0;
-      }
-    }
-  }
+  const std::vector<std::pair<int, int>> pieces = backward_pieces(f, npieces);            // (lowest unit, highest unit)
   std::function<int()> flush_nice_fn = []() { return (int)IPOKE_OK; };
   auto finish_piece = [&](int lvl_lo, int lvl_hi, int piece) -> int {
     int r = flush_nice_fn(); if (r) return r;
@@ -1512,15 +1569,17 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
           d4[k].a2_save = l.rows(mk.ws_a, (int64_t)mk.K2p * f->esz); d4[k].scale_save = l.rowsf(mk.ws_b, mk.C);
           d4[k].dparams_save = l.rows(mk.ws_c, (int64_t)mk.K3p * f->esz); d4[k].dc_save = l.rows(mk.ws_d, (int64_t)mk.Hq * f->esz);
           if (f->mcf_xop) d4[k].x_op_save = l.rows(mk.ws_e, (int64_t)mk.Cp * f->esz);
-          d4[k].dbias_part = l.dbp(j, 2 * mk.C);
+          d4[k].dbias_part = l.dbp(j, 2 * mk.C, f->unit_split);
           if (mk.fuse_act >= 0) {
             const Op& an = f->ops[mk.fuse_act];
             d4[k].post_log_scale = params + an.p_ls; d4[k].post_bias = params + an.p_bias;
             d4[k].y_post = l.state(j + 2);
-            d4[k].post_part = l.dbp(mk.fuse_act, 2 * an.Cn);
+            d4[k].post_part = l.dbp(mk.fuse_act, 2 * an.Cn, f->unit_split);
           }
         }
         d4[3].dy = l.rowsf(goff[cur], l.ld); d4[0].dx = l.rowsf(goff[cur ^ 1], l.ld); d4[0].dld = l.dld();
+        IPK_REQUIRE(f->unit_split == 1 || f->d_xchg, "row-split unit launches without exchange scratch (ensure_tables)");
+        if (f->unit_split > 1) { d4[0].split = f->unit_split; d4[0].xchg = f->d_xchg; }
         rc = ipoke_macow_unit_bwd(d4, l.dtype, l.stream()); if (rc) return rc;
       }
       for (int k = 3; k >= 0; --k) {                 // weight gradients: deferred, batched per run of same-width layers

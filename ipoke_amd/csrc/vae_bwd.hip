@@ -335,7 +335,7 @@ __global__ void reparam_bwd_kernel(const T* __restrict__ mulv, int ld, const flo
 // L1: loss += scale * sum |yhat - x| ; grad = scale * sign(yhat - x).  yhat channels-last fp32 [N*S][ldy], x fp32 [N][C][S]
 __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ yhat, int ldy, const float* __restrict__ x, int N, int C,
                                                       int S, long x_sn, float scale, float* __restrict__ loss, float* __restrict__ grad,
-                                                      int ldg) {
+                                                      int ldg, float* __restrict__ partials) {
   __shared__ float red[8];
   const long total = (long)N * S * C;
   float acc = 0.f;
@@ -347,7 +347,17 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
     if (grad) grad[m * ldg + c] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
   }
   const float tot = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(loss, tot * scale);
+  if (threadIdx.x == 0) {
+    if (partials) partials[blockIdx.x] = tot * scale;     // summed in a fixed order by l1_loss_final_kernel
+    else atomicAdd(loss, tot * scale);
+  }
+}
+__global__ __launch_bounds__(256) void l1_loss_final_kernel(const float* __restrict__ partials, int n, float* __restrict__ loss) {
+  __shared__ float red[8];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] += s;
 }
 
 }  // namespace ipoke
@@ -477,12 +487,19 @@ extern "C" int ipoke_reparam_bwd(const void* mulv, int ld, const float* eps, con
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
+static constexpr int kL1Blocks = 1024;
+extern "C" long ipoke_l1_loss_partials(void) { return kL1Blocks; }
 extern "C" int ipoke_l1_loss(const float* yhat_cl, int ldy, const float* x_nchw, int N, int C, int S, int64_t x_sn, float scale,
-                             float* loss_accum, float* grad_cl, int ldg, void* stream) {
+                             float* loss_accum, float* grad_cl, int ldg, float* partials, void* stream) {
   IPK_REQUIRE(yhat_cl && x_nchw && loss_accum && ldy >= C && (!grad_cl || ldg >= C), "bad arguments");
   const long total = (long)N * S * C;
-  hipLaunchKernelGGL(l1_loss_kernel, dim3(grid1d_b(total, 256, 1024)), dim3(256), 0, STREAM(stream), yhat_cl, ldy, x_nchw, N, C, S,
-                     (long)x_sn, scale, loss_accum, grad_cl, ldg);
+  const int g = grid1d_b(total, 256, kL1Blocks);
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(g), dim3(256), 0, STREAM(stream), yhat_cl, ldy, x_nchw, N, C, S, (long)x_sn, scale, loss_accum,
+                     grad_cl, ldg, partials);
   IPK_LAUNCH_CHECK();
+  if (partials) {
+    hipLaunchKernelGGL(l1_loss_final_kernel, dim3(1), dim3(256), 0, STREAM(stream), partials, g, loss_accum);
+    IPK_LAUNCH_CHECK();
+  }
   return IPOKE_OK;
 }

@@ -37,21 +37,37 @@ __device__ __forceinline__ float sn_at(const SnView& V, int r, int c) {
   const int c1 = c / V.n2, c2 = c - c1 * V.n2;
   return V.w[(long)r * V.s_r + (long)c1 * V.s_1 + c2];
 }
-// tv[c] += sum_{r in this block's row chunk} W[r][c] u[r]   (tv zeroed by the previous call's final kernel; fp32 atomics: the
-// row chunks give the launch (C / 256) x (R / 32) workgroups instead of C / 256 -- 18 for a 512 x 4608 matrix)
-constexpr int kSnRowChunk = 32;
-__global__ __launch_bounds__(256) void sn_cols_kernel(SnView V, const float* __restrict__ u, float* __restrict__ tv) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y * kSnRowChunk, r1 = min(V.R, r0 + kSnRowChunk);
-  if (c >= V.C) return;
-  const int c1 = c / V.n2, c2 = c - c1 * V.n2;
-  const float* col = V.w + (long)c1 * V.s_1 + c2;
+// tv[c] = sum_r W[r][c] u[r]: a workgroup owns kSnCols columns, its 256 threads are kSnCols columns x kSnRowGroups row groups (rows
+// r = group, group + kSnRowGroups, ...); the groups meet in LDS and are summed in a FIXED order -- no float atomics, so that the
+// power iteration (and with it sigma, the decoder's output and every gradient of a training step) is reproducible run to run.
+// (Rounds 2-4 split the rows over workgroups and added the chunks with atomicAdd: the order of those additions changed sigma in its
+//  last bits from run to run, which bf16 roundings downstream amplify into visibly different gradients.)
+constexpr int kSnCols = 32, kSnRowGroups = 8;
+__device__ __forceinline__ void sn_cols_body(const SnView& V, const float* __restrict__ u, float* __restrict__ tv, float (*part)[kSnCols]) {
+  const int cl = threadIdx.x % kSnCols, rg = threadIdx.x / kSnCols;
+  const int c = blockIdx.x * kSnCols + cl;
   float s = 0.f;
-  for (int r = r0; r < r1; ++r) s = fmaf(col[(long)r * V.s_r], u[r], s);
-  atomicAdd(tv + c, s);
+  if (c < V.C) {
+    const int c1 = c / V.n2, c2 = c - c1 * V.n2;
+    const float* col = V.w + (long)c1 * V.s_1 + c2;
+#pragma unroll 4
+    for (int r = rg; r < V.R; r += kSnRowGroups) s = fmaf(col[(long)r * V.s_r], u[r], s);
+  }
+  part[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < V.C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < kSnRowGroups; ++q) t += part[q][cl];
+    tv[c] = t;
+  }
 }
-// one wave per row: tu[r] = sum_c W[r][c] vhat[c], vhat = iterate ? tv / max(||tv||, eps) : v;  acc[1] += tu[r]^2
-// (iterate: every block derives ||tv|| itself; block 0 also stores vhat into v)
+__global__ __launch_bounds__(256) void sn_cols_kernel(SnView V, const float* __restrict__ u, float* __restrict__ tv) {
+  __shared__ float part[kSnRowGroups][kSnCols];
+  sn_cols_body(V, u, tv, part);
+}
+// one wave per row: tu[r] = sum_c W[r][c] vhat[c], vhat = iterate ? tv / max(||tv||, eps) : v
+// (iterate: every block derives ||tv|| itself; block 0 also stores vhat into v; ||tu|| is taken by the final kernel)
 __global__ __launch_bounds__(256) void sn_rows_kernel(SnView V, const float* __restrict__ tv, float* __restrict__ v, float* __restrict__ tu,
                                                       float* __restrict__ acc, int iterate, float eps) {
   __shared__ float red[4];
@@ -68,7 +84,7 @@ __global__ __launch_bounds__(256) void sn_rows_kernel(SnView V, const float* __r
     float s = 0.f;
     for (int c = lane; c < V.C; c += 64) s = fmaf(sn_at(V, r, c), src[c] * inv, s);
     s = wave_sum(s);
-    if (lane == 0) { tu[r] = s; atomicAdd(acc + 1, s * s); }
+    if (lane == 0) tu[r] = s;
   }
   if (iterate && blockIdx.x == 0)
     for (int c = threadIdx.x; c < V.C; c += 256) v[c] = tv[c] * inv;
@@ -78,7 +94,13 @@ __global__ __launch_bounds__(256) void sn_final_kernel(int R, int C, float* __re
                                                        float* __restrict__ acc, float* __restrict__ out, float* __restrict__ snap, int iterate,
                                                        float eps, float* __restrict__ tv) {
   __shared__ float red[4];
-  const float inv = iterate ? 1.f / fmaxf(sqrtf(acc[1]), eps) : 1.f;
+  float inv = 1.f;
+  if (iterate) {
+    float sq = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) sq = fmaf(tu[r], tu[r], sq);
+    inv = 1.f / fmaxf(sqrtf(block_sum(sq, red)), eps);
+    __syncthreads();                                      // `red` is reused below
+  }
   float s = 0.f;
   for (int r = threadIdx.x; r < R; r += 256) {
     const float ur = iterate ? tu[r] * inv : u[r];
@@ -87,9 +109,8 @@ __global__ __launch_bounds__(256) void sn_final_kernel(int R, int C, float* __re
     s = fmaf(ur, tu[r], s);
   }
   if (snap) for (int c = threadIdx.x; c < C; c += 256) snap[R + c] = v[c];
-  if (iterate) for (int c = threadIdx.x; c < C; c += 256) tv[c] = 0.f;          // clean accumulator for the next call
   s = block_sum(s, red);
-  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; acc[0] = 0.f; acc[1] = 0.f; }
+  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; }
 }
 // ---- the same three kernels over MANY weights per launch (blockIdx.z = job) and a given iteration index: a decoder weight is
 // normalised once per generated frame, i.e. T - 1 power iterations per training pass whose inputs are the weight and its own
@@ -98,15 +119,9 @@ struct SnJob { SnView V; float* u; float* v; float* out; float* snap; float* ws;
 __global__ __launch_bounds__(256) void sn_cols_multi_kernel(const SnJob* __restrict__ jobs) {
   const SnJob J = jobs[blockIdx.z];
   const SnView& V = J.V;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y * kSnRowChunk, r1 = min(V.R, r0 + kSnRowChunk);
-  if (c >= V.C || r0 >= V.R) return;
-  float* tv = J.ws + 4 + V.R;
-  const int c1 = c / V.n2, c2 = c - c1 * V.n2;
-  const float* col = V.w + (long)c1 * V.s_1 + c2;
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s = fmaf(col[(long)r * V.s_r], J.u[r], s);
-  atomicAdd(tv + c, s);
+  __shared__ float part[kSnRowGroups][kSnCols];
+  if ((int)blockIdx.x * kSnCols >= V.C) return;          // (uniform per workgroup)
+  sn_cols_body(V, J.u, J.ws + 4 + V.R, part);
 }
 __global__ __launch_bounds__(256) void sn_rows_multi_kernel(const SnJob* __restrict__ jobs, float eps) {
   __shared__ float red[4];
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(256) void sn_rows_multi_kernel(const SnJob* __restr
     float s = 0.f;
     for (int c = lane; c < V.C; c += 64) s = fmaf(sn_at(V, r, c), tv[c] * inv, s);
     s = wave_sum(s);
-    if (lane == 0) { tu[r] = s; atomicAdd(acc + 1, s * s); }
+    if (lane == 0) tu[r] = s;
   }
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < V.C; c += 256) J.v[c] = tv[c] * inv;
@@ -134,16 +149,19 @@ __global__ __launch_bounds__(256) void sn_final_multi_kernel(const SnJob* __rest
   const int R = J.V.R, C = J.V.C;
   float* acc = J.ws; float* tu = J.ws + 4; float* tv = tu + R;
   float* out = J.out + (long)it * J.out_stride; float* snap = J.snap + (long)it * J.snap_stride;
-  const float inv = 1.f / fmaxf(sqrtf(acc[1]), eps);
+  float sq = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) sq = fmaf(tu[r], tu[r], sq);
+  const float inv = 1.f / fmaxf(sqrtf(block_sum(sq, red)), eps);
+  __syncthreads();                                        // `red` is reused below
   float s = 0.f;
   for (int r = threadIdx.x; r < R; r += 256) {
     const float ur = tu[r] * inv;
     J.u[r] = ur; snap[r] = ur;
     s = fmaf(ur, tu[r], s);
   }
-  for (int c = threadIdx.x; c < C; c += 256) { snap[R + c] = J.v[c]; tv[c] = 0.f; }
+  for (int c = threadIdx.x; c < C; c += 256) snap[R + c] = J.v[c];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; acc[0] = 0.f; acc[1] = 0.f; }
+  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; }
 }
 
 // backward of w_eff = w / sigma with sigma = u^T W v (u, v constants):  dW = (G - <G, W_eff> u v^T) / sigma
@@ -158,23 +176,19 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(SnView V, const float* 
     s = fmaf(g[off], V.w[off], s);
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(acc, s);
+  if (threadIdx.x == 0) acc[blockIdx.x] = s;              // one partial per workgroup, summed in a fixed order by the apply kernel
 }
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(SnView V, float* __restrict__ g, const float* __restrict__ snap, const float* __restrict__ sig,
-                                                           float* __restrict__ acc, unsigned* __restrict__ done) {
+                                                           const float* __restrict__ acc) {
   const long total = (long)V.R * V.C;
-  const float inv = sig[1], dot = acc[0] * inv;          // <G, W/sigma>
+  float tot = 0.f;
+  for (int b = 0; b < (int)gridDim.x; ++b) tot += acc[b];
+  const float inv = sig[1], dot = tot * inv;             // <G, W/sigma>
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int r = (int)(i / V.C), c = (int)(i - (long)r * V.C);
     const int c1 = c / V.n2, c2 = c - c1 * V.n2;
     const long off = (long)r * V.s_r + (long)c1 * V.s_1 + c2;
     g[off] = (g[off] - dot * snap[r] * snap[V.R + c]) * inv;
-  }
-  // the last block to finish clears the accumulator for the next call
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(done, 1u) == gridDim.x - 1) { acc[0] = 0.f; *done = 0u; }
   }
 }
 
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ 
     dlv[i] = 0.5f * (e - 1.f) * inv_m;
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(loss, -0.5f * inv_m * s);
+  if (threadIdx.x == 0) atomicAdd(loss, -0.5f * inv_m * s);      // (ONE workgroup up to 2^20 elements: a deterministic value)
 }
 
 // ---------------------------------------------------------------------------------------------- pooling (discriminators)
@@ -711,7 +725,7 @@ extern "C" int ipoke_spectral_sigma(const float* w, int cout, int cin, int taps,
   const SnView V = sn_view(w, cout, cin, taps, transposed);
   float* acc = workspace; float* tu = workspace + 4; float* tv = tu + cout;
   if (iterate) {
-    hipLaunchKernelGGL(sn_cols_kernel, dim3((V.C + 255) / 256, (V.R + kSnRowChunk - 1) / kSnRowChunk), dim3(256), 0, STREAM(stream), V, u, tv);
+    hipLaunchKernelGGL(sn_cols_kernel, dim3((V.C + kSnCols - 1) / kSnCols), dim3(256), 0, STREAM(stream), V, u, tv);
     IPK_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(sn_rows_kernel, dim3((V.R + 3) / 4), dim3(256), 0, STREAM(stream), V, tv, v, tu, acc, iterate, eps);
@@ -747,7 +761,7 @@ extern "C" int ipoke_spectral_sigma_multi(const void* jobs_dev, int njobs, int m
   hipStream_t s = STREAM(stream);
   const SnJob* jd = reinterpret_cast<const SnJob*>(jobs_dev);
   for (int it = 0; it < iterations; ++it) {
-    hipLaunchKernelGGL(sn_cols_multi_kernel, dim3((max_cols + 255) / 256, (max_rows + kSnRowChunk - 1) / kSnRowChunk, njobs), dim3(256), 0, s, jd);
+    hipLaunchKernelGGL(sn_cols_multi_kernel, dim3((max_cols + kSnCols - 1) / kSnCols, 1, njobs), dim3(256), 0, s, jd);
     hipLaunchKernelGGL(sn_rows_multi_kernel, dim3((max_rows + 3) / 4, 1, njobs), dim3(256), 0, s, jd, eps);
     hipLaunchKernelGGL(sn_final_multi_kernel, dim3(1, 1, njobs), dim3(256), 0, s, jd, it, eps);
   }
@@ -756,17 +770,19 @@ extern "C" int ipoke_spectral_sigma_multi(const void* jobs_dev, int njobs, int m
 }
 
 /* In place: grad (gradient w.r.t. w_orig / sigma, PyTorch weight layout) -> gradient w.r.t. w_orig.  snapshot / sig: as written by
- * ipoke_spectral_sigma for the forward call; workspace: 2 zero-initialised floats (accumulator, block counter). */
+ * ipoke_spectral_sigma for the forward call; workspace: ipoke_spectral_bwd_workspace_floats() floats (per-workgroup partial sums of
+ * <G, W>, no initialisation needed). */
+static constexpr int kSnBwdBlocks = 256;
+extern "C" long ipoke_spectral_bwd_workspace_floats(void) { return kSnBwdBlocks; }
 extern "C" int ipoke_spectral_bwd(const float* w, int cout, int cin, int taps, int transposed, float* grad, const float* snapshot,
                                   const float* sig, float* workspace, void* stream) {
   IPK_REQUIRE(w && grad && snapshot && sig && workspace, "bad arguments");
   const SnView V = sn_view(w, cout, cin, taps, transposed);
   const long total = (long)V.R * V.C;
-  const int g = grid1(total, 512);
+  const int g = grid1(total, kSnBwdBlocks);
   hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(g), dim3(256), 0, STREAM(stream), V, grad, workspace);
   IPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(g), dim3(256), 0, STREAM(stream), V, grad, snapshot, sig, workspace,
-                     reinterpret_cast<unsigned*>(workspace + 1));
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(g), dim3(256), 0, STREAM(stream), V, grad, snapshot, sig, workspace);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
@@ -858,7 +874,9 @@ extern "C" int ipoke_adam_multi(float* const* p, const float* const* g, float* c
 extern "C" int ipoke_kl_loss(const float* mu, const float* lv, int64_t positions, int Z, float* loss, float* dmu, float* dlv, void* stream) {
   IPK_REQUIRE(mu && lv && loss && dmu && dlv && positions >= 1 && Z >= 1, "bad arguments");
   const long n = (long)positions * Z;
-  hipLaunchKernelGGL(kl_loss_kernel, dim3(grid1(n, 256)), dim3(256), 0, STREAM(stream), mu, lv, n, 1.f / (float)positions, loss, dmu, dlv);
+  // one workgroup for the usual latents (B * 64 positions x z channels): the value does not depend on the order of float atomics
+  hipLaunchKernelGGL(kl_loss_kernel, dim3(n <= (1L << 20) ? 1 : grid1(n, 256)), dim3(256), 0, STREAM(stream), mu, lv, n, 1.f / (float)positions, loss,
+                     dmu, dlv);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -549,7 +549,7 @@ def conv(mod, x, dtype, act=_lib.ACT_NONE, out_f32=False, src=None, w=None):
     if isinstance(w, _SnWeight):
         bws = getattr(w.mod, "_sn_bwd_ws", None)
         if bws is None or bws.device != w.w_orig.device:
-            bws = w.mod._sn_bwd_ws = torch.zeros(2, dtype=torch.float32, device=w.w_orig.device)
+            bws = w.mod._sn_bwd_ws = torch.zeros(int(_lib.lib().ipoke_spectral_bwd_workspace_floats()), dtype=torch.float32, device=w.w_orig.device)
         meta["sn"] = (w.sig, w.snap, bws)
         w = w.w_orig
     elif isinstance(w, _SnFrames):
@@ -997,9 +997,10 @@ class _L1TanhFn(torch.autograd.Function):
         frame = torch.tanh(pre_t)                                     # [M, C] fp32: the returned reconstruction
         loss = torch.zeros(1, device=pre_t.device)
         grad = torch.empty_like(pre_t)
+        part = torch.empty(int(_lib.lib().ipoke_l1_loss_partials()), device=pre_t.device)     # fixed-order sum: a reproducible value
         assert x_nchw.stride(1) == S and x_nchw.stride(2) == W and x_nchw.stride(3) == 1
         check(_lib.lib().ipoke_l1_loss(ptr(frame), frame.shape[1], ptr(x_nchw), N, C, S, x_nchw.stride(0), float(scale), ptr(loss),
-                                       ptr(grad), grad.shape[1], _lib.current_stream()))
+                                       ptr(grad), grad.shape[1], ptr(part), _lib.current_stream()))
         ctx.save_for_backward(grad, frame)
         return loss[0], frame
 

@@ -29,7 +29,7 @@ def _worker(rank, world, port, out):
     mx = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
     # fused-step semantics: the mean is applied as grad_scale = 1/world on the summed gradients
     g = torch.full((8,), 2.0 * (rank + 1)); D.allreduce_flat_(g, 2)
-    ok_mean = torch.allclose(g / world, torch.full((8,), 3.0))
+    ok_mean = torch.allclose(g / world, torch.full((8,), float(world + 1)))      # mean of 2 * (rank + 1) over the ranks
     # overlapped exchange: the flat buffer is reduced piece by piece (last levels first) with async handles, as
     # SecondStageTrainer does from the engine's gradient-ready callback
     flat2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
@@ -73,6 +73,85 @@ def test_gloo_world2_allreduce_broadcast():
     for rank in range(world):
         ok_sum, ok_bcast, mx, ok_mean = out[rank]
         assert ok_sum and ok_bcast and ok_mean and mx == 2.0
+
+
+def test_gloo_world8_allreduce_broadcast():
+    """the same worker at the world size of the MI355X node (8 ranks; arithmetic only, gloo on the CPU): bucketed
+    all-reduce of a length that divides into neither 8 buckets nor 8 shards, broadcast, max-over-ranks, the async pieces and the
+    ZeRO-1 exchange for slice lengths around the 4 * world granule (5, 32, 35, 64, 1003 floats)."""
+    world = 8
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for rank in range(world):
+        ok_sum, ok_bcast, mx, ok_rest = out[rank]
+        assert ok_sum and ok_bcast and ok_rest and mx == 8.0, rank
+
+
+def _piece_ranges(z, npieces):
+    from ctypes import byref, c_int64, c_void_p
+    from ipoke_amd import _lib, configs
+    lib = _lib.lib()
+    arch = configs.flow_arch(z)
+    cfg = _lib.FlowConfig()
+    cfg.z_channels, cfg.hidden, cfg.cond_channels, cfg.factor = z, arch["flow_mid_channels"], 128, 16
+    cfg.n_levels = len(arch["num_steps"])
+    for i, st in enumerate(arch["num_steps"]):
+        cfg.num_steps[i] = st
+    cfg.kernel_h, cfg.kernel_w, cfg.dtype, cfg.max_batch = 2, 3, _lib.BF16, 20
+    h = c_void_p()
+    _lib.check(lib.ipoke_flow_create(byref(cfg), byref(h)))
+    n = lib.ipoke_flow_piece_ranges(h, npieces, None, 0)
+    assert n >= npieces
+    buf = (c_int64 * (3 * n))()
+    assert lib.ipoke_flow_piece_ranges(h, npieces, buf, n) == n
+    total = lib.ipoke_flow_param_count(h)
+    lib.ipoke_flow_destroy(h)
+    return [(int(buf[3 * i]), int(buf[3 * i + 1]), int(buf[3 * i + 2])) for i in range(n)], int(total)
+
+
+def test_shard_layout_of_the_real_slices_at_world8():
+    """The slices the engine's piecewise backward announces for BOTH shipped flows (z = 64: 1 237 326 840 parameters, z = 32: 1 054 426 620;
+    16 pieces = the trainer's default), cut for 8 ranks as FusedAdamAmsgrad.step_range_sharded cuts them: every slice begins 16-byte
+    aligned, shards are multiples of 4 floats, the replicated tail is shorter than 4 * world floats, the ranks' shards and the tail tile
+    the slice exactly, and the slices tile the flat parameter buffer."""
+    from ipoke_amd import dist as D
+    world = 8
+    for z, expected in ((64, 1237326840), (32, 1054426620)):
+        ranges, total = _piece_ranges(z, 16)
+        assert expected <= total < expected + 4 * 6995          # the flat buffer pads every tensor to 16 bytes
+        assert len({p for p, _, _ in ranges}) == 16                 # 16 pieces, one or two regions (layers.*, priors.*) each
+        assert [p for p, _, _ in ranges] == sorted(p for p, _, _ in ranges)
+        covered = 0
+        spans = sorted((b, e) for _, b, e in ranges)
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        for (b0, e0), (b1, e1) in zip(spans, spans[1:]):
+            assert e0 == b1, "slices must tile the flat buffer without gaps or overlap"
+        tails = []
+        for _, b, e in ranges:
+            n = e - b
+            assert b % 4 == 0 and n > 0
+            sh, main = D.shard_layout(n, world)
+            assert sh % 4 == 0 and main == sh * world and 0 <= n - main < 4 * world
+            own = [(b + r * sh, b + (r + 1) * sh) for r in range(world)]
+            assert own[0][0] == b and own[-1][1] == b + main and all(lo % 4 == 0 for lo, _ in own)
+            covered += main + (n - main)
+            tails.append(n - main)
+        assert covered == total
+        # the exchange is dominated by the shards: the replicated tails are a few floats per slice
+        assert sum(tails) < 4 * world * len(ranges)
+        per_rank_state = sum(D.shard_layout(e - b, world)[0] for _, b, e in ranges) + sum(tails)
+        assert abs(per_rank_state - total / world) <= 4 * world * len(ranges)
+
+
+def test_bench_self_launch_command_for_8_gpus():
+    """`python bench.py --gpus 8` outside a torchrun environment re-executes itself as the launch line of the driver's contract."""
+    import bench
+    cmd = bench.self_launch_command(["--gpus", "8", "--steps", "5", "--warmup", "2"], 8, {}, script="/root/repo/bench.py", port=29511)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29511",
+                       "/root/repo/bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert bench.self_launch_command(["--gpus", "8"], 8, {"WORLD_SIZE": "8"}) is None          # already a rank
+    assert bench.self_launch_command([], 1, {}) is None
 
 
 def test_single_process_is_a_noop():

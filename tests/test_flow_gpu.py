@@ -373,3 +373,31 @@ def test_fused_adam_shadow_refresh_is_bit_identical(dtype, hidden):
         got = run(True, pieces)
         for name, a, b in zip(("params", "exp_avg", "exp_avg_sq", "max_exp_avg_sq", "shadow"), ref, got):
             assert torch.equal(a, b), (name, "whole" if pieces is None else "pieces", (a.float() - b.float()).abs().max().item())
+
+
+@pytest.mark.parametrize("split", [2, 4])
+def test_unit_row_split_engine_matches_one_workgroup_per_sample(golden, split, monkeypatch):
+    """IPOKE_UNIT_SPLIT: the engine's fused MaCowUnit launches on 2 / 4 workgroups per sample (csrc/mcf_unit_split.hip).  States and
+    data gradients are bit-identical by construction; log-dets and the bias / ActNorm gradients are sums over parts."""
+    g = golden("g2_reduced_flow")
+    arch = configs.reduced_flow_arch()
+    x, cond = t(g["x"]).cuda(), t(g["cond"]).cuda()
+
+    def run(s):
+        monkeypatch.setenv("IPOKE_UNIT_SPLIT", str(s))
+        m = build(arch, "bf16")
+        m.train()
+        m.flat_grads.zero_()
+        out, logdet = m(x, cond)
+        ((out ** 2).sum() * 0.5 - logdet.sum()).backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), logdet.detach().clone(), m.flat_grads.clone()
+
+    o1, l1, g1 = run(1)
+    o1b, l1b, g1b = run(1)
+    noise = (g1b - g1).abs().max().item()           # the split-K data gradients of the coupling nets accumulate with fp32 atomics
+    os_, ls_, gs_ = run(split)
+    assert torch.equal(os_, o1)
+    assert (ls_ - l1).abs().max().item() <= 1e-3
+    scale = g1.abs().max().item()
+    assert (gs_ - g1).abs().max().item() <= max(4 * noise, 2e-6 * scale), ((gs_ - g1).abs().max().item(), noise, scale)

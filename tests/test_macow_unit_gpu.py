@@ -197,3 +197,99 @@ def _pre_actnorm(y_post, an, C):
     x = y_post.clone()
     x[:, :C] = (y_post[:, :C] - b) / ls.exp()
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Row-split launches (csrc/mcf_unit_split.hip): a sample's 8x8 latent on 2 / 4 workgroups that hand the halo rows of every layer
+# to each other inside the launch.  The arithmetic per row is unchanged, so every state, save and data gradient must be
+# BIT-IDENTICAL to the one-workgroup launch; log-dets and parameter-gradient partials are summed per part.
+def _split_buffers(C, ld, B, S, dims):
+    M = B * 64
+    o = dict(ys=[torch.full((M, ld), float("nan"), device=DEV) for _ in range(4)],
+             a2=[torch.zeros(M, dims["K2p"], device=DEV, dtype=tdt(DT)) for _ in range(4)],
+             sc=[torch.zeros(M, C, device=DEV) for _ in range(4)],
+             dps=[torch.zeros(M, dims["K3p"], device=DEV, dtype=tdt(DT)) for _ in range(4)],
+             dcs=[torch.zeros(M, dims["Hq"], device=DEV, dtype=tdt(DT)) for _ in range(4)],
+             xop=[torch.zeros(M, dims["Cp"], device=DEV, dtype=tdt(DT)) for _ in range(4)],
+             dbp=[torch.zeros(B * S, 2 * C, device=DEV) for _ in range(4)],
+             pp=[torch.zeros(B * S, 2 * C, device=DEV) for _ in range(4)],
+             slot=torch.zeros(4, B, 4, device=DEV), dx=torch.full((M, ld), float("nan"), device=DEV))
+    nb = _lib.lib().ipoke_macow_unit_xchg_bytes(B, S)
+    o["xchg"] = torch.zeros(max(nb, 8) // 4, dtype=torch.int32, device=DEV)
+    return o
+
+
+def _split_descs(C, ld, B, S, xs, cond, shs, posts, keep, o, saved, dy, dld):
+    d4 = _descs(C, ld, B, cond, shs, posts, keep)
+    ins = [xs, saved["ys"][0], saved["ys"][1], saved["ys"][2]]
+    for k in range(4):
+        d = d4[k]
+        d.x = ins[k].data_ptr(); d.y = o["ys"][k].data_ptr()
+        d.a2_save = saved["a2"][k].data_ptr(); d.scale_save = saved["sc"][k].data_ptr(); d.logdet_slot = o["slot"][k].data_ptr()
+        d.dparams_save = o["dps"][k].data_ptr(); d.dc_save = o["dcs"][k].data_ptr(); d.dbias_part = o["dbp"][k].data_ptr()
+        d.x_op_save = o["xop"][k].data_ptr()
+        if posts[k] is not None:
+            d.y_post = saved["ys"][k].data_ptr(); d.post_part = o["pp"][k].data_ptr()
+    d4[3].dy = dy.data_ptr(); d4[0].dx = o["dx"].data_ptr(); d4[0].dld = dld.data_ptr()
+    if S > 1:
+        d4[0].split = S; d4[0].xchg = o["xchg"].data_ptr()
+    return d4
+
+
+@pytest.mark.parametrize("C,ld,B", [(64, 64, 5), (60, 64, 3), (32, 64, 4), (30, 32, 3), (8, 8, 2), (64, 64, 20)])
+def test_macow_unit_row_split_is_bit_identical(C, ld, B):
+    o_, x, h, shs, posts = _unit(C, ld, B, 300 + C)
+    dims = shs[0]["dims"]
+    xs = ops.to_state(x.to(DEV))
+    cond = ops.cond_prepare(h.to(DEV), DT)
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    dy = torch.randn(B * 64, ld, device=DEV, generator=gen)
+    dld = torch.randn(B, device=DEV, generator=gen)
+    keep = []
+    L = _lib.lib()
+    ref = _split_buffers(C, ld, B, 1, dims)
+    d = _split_descs(C, ld, B, 1, xs, cond, shs, posts, keep, ref, ref, dy, dld)
+    _lib.check(L.ipoke_macow_unit_fwd(d, _lib.DTYPES[DT], _lib.current_stream()))
+    _lib.check(L.ipoke_macow_unit_bwd(d, _lib.DTYPES[DT], _lib.current_stream()))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.empty(128 << 20, dtype=torch.uint8, device=DEV); big2 = torch.empty_like(big)
+    for S in (2, 4):
+        for rep in range(4):
+            o = _split_buffers(C, ld, B, S, dims)
+            if rep % 2:                                   # uneven load beside the hand-offs (a copy stream on the other CUs)
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        big2.copy_(big)
+            d = _split_descs(C, ld, B, S, xs, cond, shs, posts, keep, o, o, dy, dld)
+            _lib.check(L.ipoke_macow_unit_fwd(d, _lib.DTYPES[DT], _lib.current_stream()))
+            # the backward call reads the saves of the SPLIT forward (they are bit-identical, checked below)
+            _lib.check(L.ipoke_macow_unit_bwd(d, _lib.DTYPES[DT], _lib.current_stream()))
+            torch.cuda.synchronize()
+            for nme in ("ys", "a2", "sc", "dps", "dcs", "xop"):
+                for k in range(4):
+                    cols = C if nme == "ys" and k < 3 else None      # pass-through columns of intermediate states are not written
+                    assert torch.equal(o[nme][k][:, :cols], ref[nme][k][:, :cols]), (S, rep, nme, k)
+            assert torch.equal(o["dx"], ref["dx"]), (S, rep)
+            assert (o["slot"].sum(2) - ref["slot"].sum(2)).abs().max().item() <= 1e-3, (S, rep)
+            assert (o["slot"][:, :, S:] == 0).all()
+            for k in range(4):
+                for nme in ("dbp", "pp"):
+                    r = ref[nme][k].sum(0)
+                    assert ((o[nme][k].sum(0) - r).abs().max() / r.abs().max().clamp_min(1e-6)).item() <= 2e-6, (S, rep, nme, k)
+            assert int(o["xchg"][0].item()) == 0, "hand-off time-outs"
+            assert int((o["xchg"][64:] != 0).sum().item()) == 0, "the exchange scratch must be all-zero again after a launch"
+
+
+def test_macow_unit_row_split_rejects_bad_arguments():
+    C, ld, B = 8, 8, 2
+    o_, x, h, shs, posts = _unit(C, ld, B, 5)
+    xs = ops.to_state(x.to(DEV)); cond = ops.cond_prepare(h.to(DEV), DT)
+    keep = []
+    o = _split_buffers(C, ld, B, 2, shs[0]["dims"])
+    dy = torch.zeros(B * 64, ld, device=DEV); dld = torch.zeros(B, device=DEV)
+    d = _split_descs(C, ld, B, 2, xs, cond, shs, posts, keep, o, o, dy, dld)
+    d[0].xchg = None
+    assert _lib.lib().ipoke_macow_unit_fwd(d, _lib.DTYPES[DT], _lib.current_stream()) != 0        # no scratch
+    d[0].xchg = o["xchg"].data_ptr(); d[0].split = 3
+    assert _lib.lib().ipoke_macow_unit_fwd(d, _lib.DTYPES[DT], _lib.current_stream()) != 0        # 2 or 4 only

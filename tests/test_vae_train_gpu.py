@@ -69,7 +69,7 @@ def test_spectral_sigma_and_backward(cout, cin, k, transposed, iterate):
         assert abs(sig[0].item() - sigma.item()) <= 2e-5 * abs(sigma.item())
         assert abs(sig[1].item() * sig[0].item() - 1.0) <= 1e-6
         assert torch.equal(snap[:cout], uu) and torch.equal(snap[cout:], vv)
-    bws = torch.zeros(2, device=DEV)
+    bws = torch.zeros(int(lib.ipoke_spectral_bwd_workspace_floats()), device=DEV)
     for rep in range(2):
         d = G.clone()
         check(lib.ipoke_spectral_bwd(ptr(w), cout, cin, taps, int(transposed), ptr(d), ptr(snap), ptr(sig), ptr(bws), _lib.current_stream()))
