@@ -66,7 +66,12 @@ def randomise_couplings(model, seed=0):
     model.flow.mark_weights_updated()
 
 
-PMC_ROUND = "r04"          # the committed PMC passes roofline.traffic is read from (NOT measured by this run: see traffic_source)
+PMC_ROUND = "r05"          # the committed PMC passes roofline.traffic is read from (NOT measured by this run: see traffic_source)
+
+
+def gemm_source_hash():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "ipoke_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
 
 
 def pmc_traffic(kernel_substr, grid_size):
@@ -77,7 +82,7 @@ def pmc_traffic(kernel_substr, grid_size):
         for counter, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
             rows = json.load(open(os.path.join(ROOT, "profiles", f"{PMC_ROUND}_bench_pmc_{counter}.json")))
             hit = [r for r in rows if kernel_substr in r["kernel"] and r["grid_size"] == grid_size and r["counter"] == counter]
-            if not hit:
+            if not hit or hit[0].get("gemm_hip_sha16") != gemm_source_hash():      # counters of another build of the kernel: no figure
                 return None
             tot += mul * hit[0]["mean"] * 1024.0
         return round(tot)
@@ -401,7 +406,7 @@ def secondary(args, cfg, rank, world, device):
     torch.cuda.synchronize(); D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     graph = None
-    if args.config == "c5":
+    if args.config == "c5" and not args.quick:
         def timed_again():
             for i in range(3):
                 step(i)
@@ -469,8 +474,10 @@ def secondary(args, cfg, rank, world, device):
                                 "kernel": "whole I3D batch (58 implicit-GEMM launches + 13 pools + resize), wall clock of the step"}
         if graph:
             line["hipgraph"] = graph
+        if args.config == "c5":
             line["algorithmic_tflop_per_step_per_gpu"] = round(B * (FLOW_GFLOP[z] + 244.3) / 1e3, 2)     # un-hoisted
-            line["step_mfma_frac"] = round(line["algorithmic_tflop_per_step_per_gpu"] / (ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4)
+            line["step_mfma_frac"] = round(line["algorithmic_tflop_per_step_per_gpu"] / (ms * 1e-3) /
+                                           (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS), 4)
         print(json.dumps(line), flush=True)
     D.barrier()
 
@@ -506,6 +513,7 @@ def main():
     ap.add_argument("--cpu-timeout", type=int, default=600)
     ap.add_argument("--no-secondary", action="store_true", help="skip the c4 / c5 lines attached to the default c2 line")
     ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--quick", action="store_true", help="c5: the eager latency only (no hipGraph / two-batches-in-flight variants)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -597,8 +605,14 @@ def main():
             del model, trainer, batch
             torch.cuda.empty_cache()
             line["secondary"] = {c: secondary_subprocess(c, args.secondary_steps, 3) for c in ("c4", "c5")}
-            if args.dtype == "bf16":       # the same c2 step in the reference's own arithmetic (exact-f32 matrix cores: 157 TF peak, the parity-tight mode)
+            # BASELINE configs[2]: the per-GPU workload of the 8-GPU iper_128 job (z = 32, per-GPU batch 40) on this one GPU
+            line["secondary"]["c3"] = secondary_subprocess("c3", 5, 3)
+            if args.dtype == "bf16":
+                # every BASELINE configuration also in the reference's own arithmetic (exact-f32 matrix cores: 157 TFLOP/s peak -- the
+                # parity-tight mode; configs[3] / configs[4] name no dtype, the reference computes fp32)
                 line["secondary"]["c2_f32"] = secondary_subprocess("c2", args.secondary_steps, 3, extra=("--dtype", "f32"))
+                line["secondary"]["c4_f32"] = secondary_subprocess("c4", 5, 2, extra=("--dtype", "f32"))
+                line["secondary"]["c5_f32"] = secondary_subprocess("c5", 5, 2, extra=("--dtype", "f32", "--quick"))
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_clips, args.cpu_timeout)
         print(json.dumps(line), flush=True)

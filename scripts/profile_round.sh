@@ -1,7 +1,7 @@
 # Round profile: kernel traces (+ stats, queue gaps, chain / side-stream overlap), PMC passes (separate runs), bench lines.
 # Usage on the GPU box:  bash scripts/profile_round.sh r03
 set -x
-RN=${1:-r04}
+RN=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${RN}
@@ -32,3 +32,11 @@ python $R/bench.py --config c4 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RN
 python $R/bench.py --config c3 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $O/${RN}_c3_bench_line.json
 python $R/bench.py 2>/dev/null | tail -1 > $O/${RN}_bench_line.json
 ls -la $O
+# the counter files must describe the kernels of THIS tree (bench.py drops roofline.traffic otherwise)
+python - <<PY || { echo "STALE PMC FILES: re-run the PMC passes"; exit 1; }
+import hashlib, json, sys
+h = hashlib.sha256(open("$R/ipoke_amd/csrc/gemm.hip", "rb").read()).hexdigest()[:16]
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    rows = json.load(open("$O/${RN}_bench_pmc_%s.json" % c))
+    assert rows and all(r.get("gemm_hip_sha16") == h for r in rows), c
+PY

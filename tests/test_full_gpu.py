@@ -181,3 +181,73 @@ def test_lightning_checkpoint_loads_and_reproduces_the_oracle(tmp_path):
     e_ld = (logdet.detach().cpu() - o_ld).abs().max().item()
     print(f"ckpt round trip: out err {e_out:.3e} logdet err {e_ld:.3e}")
     assert e_out <= 2e-4 and e_ld <= 2e-2
+
+
+def test_full_size_adam_amsgrad_matches_torch_optim():
+    """the optimizer path the c2 / c3 benchmarks execute -- SecondStageTrainer.train_step with the engine-issued
+    (native) Adam-amsgrad over 16 backward pieces: adam_cast over the conv2 tensors, adam_amsgrad_seg over the rest, the shadow refresh
+    behind them -- on the FULL z = 32 flow (1.054 B parameters, 2048 hidden, f32 mode, B = 2) against torch.optim.Adam(amsgrad=True,
+    weight_decay) itself, stepped on the GPU over the same flat buffer with the gradients the engine produced.  (Those gradients are
+    pinned to the reference by the checksums of every tensor in test_bench_configs_gpu.py::test_full_size_flow.)  Two steps, so that
+    the second one starts from carried optimizer state; per-tensor comparison of the parameter UPDATES for every tensor."""
+    from ipoke_amd.second_stage import PokeMotionModel
+    from ipoke_amd.trainer import SecondStageTrainer
+    from tests.helpers import cached_fill_, synthetic_batch
+    conf = configs.second_stage_config(64, 32, 16, batch_size=2)           # plants_64 (BASELINE configs[0]): the full-size z = 32 flow
+    m = PokeMotionModel(conf, dirs={}, dtype="f32", device="cuda", max_batch=2)
+    assert m.flow.engine.n_params >= 1_054_000_000
+    deterministic_fill_(m.first_stage_model, prefix="first_stage.")
+    deterministic_fill_(m.poke_embedder, prefix="poke_embedder.")
+    deterministic_fill_(m.conditioner, prefix="conditioner.")
+    cached_fill_(m.flow, "flow.")
+    with torch.no_grad():
+        for k, p in m.flow.named_parameters():
+            if k.endswith("weight_g"):
+                p.mul_(0.05)                                               # couplings away from the identity, outputs bounded
+    m.flow.sync_buffers()
+    m.flow.mark_weights_updated()
+    tr = SecondStageTrainer(m, n_grad_buckets=16)
+    assert tr.native_opt and tr.overlap, "the benchmarked single-GPU path: native Adam, updates overlapped with the backward pass"
+    m.global_step = 2000                                                   # inside the LR warm-up ramp: a non-zero learning rate
+    batch = synthetic_batch(2, 16, 64, seed=3, device="cuda")
+    flat = m.flow.flat_params
+    g0 = tr.opt.param_groups[0]
+    ref_p = torch.nn.Parameter(flat.detach().clone())
+    ref = torch.optim.Adam([ref_p], lr=g0["lr"], betas=g0["betas"], eps=g0["eps"], weight_decay=g0["weight_decay"], amsgrad=True)
+    # tensor spans inside the flat buffer (views of it)
+    spans = []
+    for k, p in m.flow.named_parameters():
+        off = (p.data_ptr() - flat.data_ptr()) // 4
+        spans.append((k, off, p.numel()))
+    offs = torch.tensor([o for _, o, _ in spans], device="cuda"); nums = torch.tensor([n for _, _, n in spans], device="cuda")
+    zero = torch.zeros(1, dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for step in range(2):
+        before = flat.detach().clone()
+        loss = tr.train_step(batch, step)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        lr = tr.opt.param_groups[0]["lr"]
+        assert lr > 0
+        for pg in ref.param_groups:
+            pg["lr"] = lr
+        ref_p.grad = m.flow.flat_grads.detach().clone()                    # what the engine's update consumed (weight-norm backward included)
+        ref.step()
+        upd_e = (flat.detach() - before).double()
+        upd_r = (ref_p.detach() - before).double()
+        del before
+        # per tensor: sum |update difference| / sum |reference update| through prefix sums over the flat buffer
+        c = torch.cat([zero, (upd_e - upd_r).abs().cumsum(0)]); d_sum = c[offs + nums] - c[offs]; del c
+        c = torch.cat([zero, upd_r.abs().cumsum(0)]); r_sum = c[offs + nums] - c[offs]; del c
+        rel = (d_sum / r_sum.clamp_min(1e-30)).cpu().numpy()
+        moved = (r_sum > 0).cpu().numpy()
+        e_max = ((upd_e - upd_r).abs().max() / upd_r.abs().max()).item()
+        k_worst = int(np.argmax(np.where(moved, rel, 0.0)))
+        print(f"step {step + 1}: lr {lr:.3e}, loss {loss.item():.4f}, {int(moved.sum())} of {len(spans)} tensors moved; update error: "
+              f"max-norm {e_max:.3e}, worst tensor {rel[k_worst]:.3e} ({spans[k_worst][0]})")
+        assert moved.sum() >= 0.99 * len(spans)
+        assert e_max <= 2e-4 and rel[moved].max() <= 2e-4, (e_max, rel[moved].max(), spans[k_worst][0])
+        worst = max(worst, e_max)
+        # the next step starts from the engine's parameters on both sides (the comparison is of the update rule and its carried state)
+        with torch.no_grad():
+            ref_p.copy_(flat)
