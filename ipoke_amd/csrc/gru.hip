@@ -651,10 +651,10 @@ static void gru_note_layout(const void* ws, int tiled) {
       it = it->second.second + 2048 < g_gru_ws_seq ? g_gru_ws_layout.erase(it) : std::next(it);
   }
 }
-static int gru_layout_of(const void* ws) {
+static int gru_layout_of(const void* ws) {       // -1: no forward pass on record for this workspace
   std::lock_guard<std::mutex> g(g_gru_ws_mutex);
   auto it = g_gru_ws_layout.find(ws);
-  return it == g_gru_ws_layout.end() ? 0 : it->second.first;
+  return it == g_gru_ws_layout.end() ? -1 : it->second.first;
 }
 // dynamic-LDS limit of a kernel instantiation, raised once (grows monotonically)
 template <typename K> static int gru_ensure_lds(K kern, size_t bytes, size_t& granted) {
@@ -782,8 +782,13 @@ extern "C" int ipoke_gru_unroll_backward(const ipoke_gru_desc* d, const void* d_
   IPK_REQUIRE(d_out && workspace && dweights && d_x0 && d_h0 && ldo >= p.Ch, "bad arguments");
   GruCtx c{p, dtype, reinterpret_cast<unsigned char*>(workspace), reinterpret_cast<hipStream_t>(stream)};
   const long E = p.esz;
-  const bool fused_bwd = gru_layout_of(workspace) == 1 && dtype == IPOKE_BF16 && ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
-  if (gru_layout_of(workspace) == 1) IPK_REQUIRE(fused_bwd, "the forward pass left fragment-tiled operands: d_out must be 16-byte aligned rows of a multiple of 8 elements");
+  // a workspace the library has no forward pass on record for (never run, or evicted after > 2048 later forward passes) must not be
+  // read with a guessed operand layout: tiled operands read as row-major give wrong gradients without any error
+  const int ws_layout = gru_layout_of(workspace);
+  IPK_REQUIRE(ws_layout >= 0, "ipoke_gru_unroll_backward: no forward pass on record for this workspace (run ipoke_gru_unroll_forward on it first; "
+                              "the record of a workspace is kept for the 2048 most recent forward passes)");
+  const bool fused_bwd = ws_layout == 1 && dtype == IPOKE_BF16 && ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+  if (ws_layout == 1) IPK_REQUIRE(fused_bwd, "the forward pass left fragment-tiled operands: d_out must be 16-byte aligned rows of a multiple of 8 elements");
   if (fused_bwd) {
     GruFusedPtrs P; std::memset(&P, 0, sizeof(P));
     for (int l = 0; l < p.L; ++l) { P.w_ur[l] = reinterpret_cast<const bf16_t*>(c.wop(l, 1)); P.w_o[l] = reinterpret_cast<const bf16_t*>(c.wop(l, 3)); }

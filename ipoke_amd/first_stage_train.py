@@ -235,11 +235,16 @@ class wgrad_side_stream:
         side, params = _WGRAD_SIDE["stream"], _WGRAD_SIDE["params"]
         _WGRAD_SIDE["stream"] = None
         _WGRAD_SIDE["params"] = []
+        cur = torch.cuda.current_stream()
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            cur.wait_stream(side)
         for p_ in params:
             g_ = p_.__dict__.pop("_side_grad", None)
             if g_ is not None:
+                # allocated from the side stream's pool, used on the caller's stream from here on: tell the allocator, so that the block
+                # is not handed out again on the side stream while the optimizer still reads it
+                if side is not None:
+                    g_.record_stream(cur)
                 p_.grad = g_ if p_.grad is None else p_.grad + g_
         return False
 
@@ -1285,13 +1290,32 @@ class FirstStageTrainer:
         views = [self._dp_flat[o:o + k].view(p.shape) for o, k, p in zip(offs, sizes, self.params)]
         self.opt.grad_scale = 1.0 / world
 
+        # spectral-norm buffers: DDP broadcasts module buffers from rank 0 before every forward (broadcast_buffers=True in the reference's
+        # Lightning run); the power iteration sees rank-local batches only through the weights, which are equal on every rank, so one
+        # broadcast per step keeps sigma identical instead of letting round-off drift it apart
+        sn_bufs = [b for k, b in self.model.named_buffers() if k.endswith("weight_u") or k.endswith("weight_v")]
+
         def sync_grads():
-            have = [(v, p) for v, p in zip(views, self.params) if p.grad is not None]
-            torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
+            have, missing = [], []
+            for v, p in zip(views, self.params):
+                (have if p.grad is not None else missing).append((v, p))
+            # a parameter without a gradient on THIS rank still takes part in the sum (another rank may have one): its slot must hold
+            # zeros, not the reduced values of the previous step
+            for v, _ in missing:
+                v.zero_()
+            if hasattr(torch, "_foreach_copy_"):
+                torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
+            else:
+                for v, p in have:
+                    v.copy_(p.grad)
             D.allreduce_flat_(self._dp_flat, n_buckets)
             for v, p in have:
                 p.grad = v
+            for b in sn_bufs:
+                D.broadcast_(b, src=0)
         self.grad_hook = sync_grads
+
+
     def on_epoch_end(self):
         """Lightning steps the ExponentialLR scheduler once per epoch (first_stage_motion_model.py:383-388)."""
         self.opt.exponential_lr_step(self.gamma)

@@ -14,6 +14,8 @@ on an MI355X in a sampling process (`scripts/probe_pipe2.py`), for consecutive s
 `overlapping_stream` tries a few candidates on an idle device and keeps the first that passes both checks."""
 import time
 
+import os
+
 import torch
 
 _SMALL = {}
@@ -65,6 +67,10 @@ def overlapping_stream(candidates=8, spin_ms=0.5, report=None):
     """A torch.cuda.Stream whose work overlaps with the current stream's and whose pending waits do not stall it, or the best of
     ``candidates`` if none passes.  ``report`` (a list) receives (candidate index, spin pair / single, chain slowdown beside the
     waiting candidate) per candidate tried."""
+    # IPOKE_SIDE_STREAM=plain: no probing at all -- a fresh stream of PyTorch's pool (multi-rank jobs and shared GPUs: the probe below
+    # times spin kernels on what it assumes to be an idle device, and its device-wide synchronisations are not free there)
+    if os.environ.get("IPOKE_SIDE_STREAM", "") == "plain":
+        return torch.cuda.Stream()
     main = torch.cuda.current_stream()
     cycles = 100_000
     _spin_pair_ms(main, None, cycles)                                   # warm: module load
@@ -85,5 +91,9 @@ def overlapping_stream(candidates=8, spin_ms=0.5, report=None):
         if best_score is None or score < best_score:
             best, best_score = cand, score
         if ratio < 1.3 and slow < 2.5:
-            break
+            return cand
+    # no candidate passed both checks (a busy device makes the timings noise): say so instead of silently returning the least bad one
+    import warnings
+    warnings.warn(f"overlapping_stream: none of {candidates} streams passed the overlap / stalled-launch checks on this device "
+                  f"(best score {best_score:.2f}); using the best candidate -- set IPOKE_SIDE_STREAM=plain to skip the probe", RuntimeWarning)
     return best
