@@ -106,15 +106,6 @@ typedef struct {
 } ipoke_conv_desc;
 
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
-/* n back-to-back native launches of the same convolution (kernel timing without host round trips) */
-int ipoke_conv_forward_repeat(const ipoke_conv_desc* d, int dtype, int n, void* stream);
-/* Test hook: kernel-dispatch switch `name` ("c64": conv3x3_c64, "halo16": conv3x3_halo16) <- value (0 off, 1 the measured default
- * rule, 2 wherever the kernel can run; < 0: back to the environment default IPOKE_C64 / IPOKE_HALO16).  The switches are read from the
- * environment once per process -- no getenv on the launch path. */
-int ipoke_set_dispatch_override(const char* name, int value);
-/* Test hook: the kernel family the calling thread's last ipoke_conv_forward was dispatched to */
-enum { IPOKE_KERNEL_NONE = 0, IPOKE_KERNEL_IGEMM = 1, IPOKE_KERNEL_S8 = 2, IPOKE_KERNEL_HALO = 3, IPOKE_KERNEL_HALO16 = 4, IPOKE_KERNEL_C64 = 5 };
-int ipoke_last_conv_kernel(void);
 
 /* Split count the library wants for the skinny 3x3 convolutions of the coupling nets (conv3 forward: split-K partial
  * slabs; conv1 data gradient: atomic accumulation) at M = 64*B output rows and Kc input channels -- callers size their
@@ -217,8 +208,6 @@ int ipoke_actnorm_affine_bwd(int c0, int C, const float* log_scale, const int32_
                              int Cp, int t_off, int t_stride, int P, int ld, const float* x0, const float* scale, const float* dld, float* dx,
                              void* dparams, int ldp, float* dbias_part, int B, int dtype, void* stream);
 int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream);
-/* developer probe (IPOKE_SIDE_DELAY_US): one wave spinning for about `us` microseconds on `stream` */
-int ipoke_spin_delay(int us, void* stream);
 /* multi-tensor form: entries_dev[i] = {int64 src, int64 dst (float offsets), int32 ld, int32 ncols, int32 rmul, int32 pad};
  * entry i sums R * max(rmul, 1) rows */
 int ipoke_reduce_entry_size(void);
@@ -332,26 +321,6 @@ int ipoke_wn_bwd_multi_range(const float* params, float* grads, const float* inv
  *     shadow  bytes [shadow_bytes]         matrix-core weight operands, refreshed by prepare_weights
  *     workspace bytes [workspace_bytes(B, training)]
  * ------------------------------------------------------------------------------------------- */
-/* In-situ timing for the benchmark's roofline objects: between ipoke_timing_start() and ipoke_timing_stop() every launch of
- * a tagged kernel family is bracketed by HIP events on the stream it is launched on (the rest of the step runs as usual).
- * Tags: 1 = ipoke_conv_forward with a 1x1 kernel and Nout = K >= 1024 (the NICE conv2 GEMM and its data gradient),
- *       2 = ipoke_conv_wgrad / _batched of the same shape (a batched launch counts once per problem and its time is divided
- *       by the problem count), 3 = ipoke_macow_unit_fwd, 4 = ipoke_macow_unit_bwd. */
-#define IPOKE_TAG_NT_SQUARE 1
-#define IPOKE_TAG_TN_SQUARE 2
-#define IPOKE_TAG_UNIT_FWD 3
-#define IPOKE_TAG_UNIT_BWD 4
-#define IPOKE_TAG_UNIT_INV 5
-/* every other ipoke_conv_forward launch is tagged by the kernel family the dispatcher chose (IPOKE_TAG_CONV_BASE + IPOKE_KERNEL_*), every
- * other weight gradient IPOKE_TAG_WGRAD; both carry their algorithmic work: FLOPs = 2 * rows * Nout * taps * channels (transposed
- * strided forms: divided by the stride product -- the taps that meet an input pixel), bytes = input + weights + output, each once. */
-#define IPOKE_TAG_CONV_BASE 16
-#define IPOKE_TAG_WGRAD 32
-int ipoke_timing_start(void);
-int ipoke_timing_start_all(void);   /* also the IPOKE_TAG_CONV_* / IPOKE_TAG_WGRAD families */
-int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us);
-/* per tag: launches, SUM of durations (us), SUM of algorithmic FLOPs and bytes -- the per-configuration rooflines of bench.py */
-int ipoke_timing_stop_ex(const int* tags, int ntags, int* counts, double* total_us, double* flops, double* bytes);
 
 /* LU-parametrised invertible 1x1 convolution (macow2.py:596-649), used by the flow engine when use1x1 is set: prepare builds
  * [W | W^-1 | wl | wu] (C*C floats each) per job in the workspace; apply: out[:, :C] = in[:, :C] mat^T (or mat), rest copied,
@@ -568,10 +537,9 @@ int ipoke_conv_weight_operand(const float* w, int cout, int cin, int taps, int t
 typedef struct { int32_t B, T, L, Cx, Ch, H, W; } ipoke_gru_desc;
 int64_t ipoke_gru_workspace_bytes(const ipoke_gru_desc* d, int dtype);
 /* out [T][M][ldo]: the last cell's hidden state after every step.  The workspace keeps every operand for ipoke_gru_unroll_backward. */
-/* Forward unroll as ONE launch (a workgroup per sample runs the T x L recurrence on LDS-resident operands; bf16, 8 x 8 map, Cx = Ch in
- * {32, 64}) -- the default where it applies; the test hook switches to the launch-per-phase form (0), back (1) or to the IPOKE_GRU_FUSED
- * environment default (< 0).  Both forms fill the same workspace for ipoke_gru_unroll_backward. */
-int ipoke_gru_set_fused(int mode);
+/* The forward unroll runs as ONE launch where it applies (a workgroup per sample runs the T x L recurrence on LDS-resident operands;
+ * bf16, 8 x 8 map, Cx = Ch in {32, 64}), otherwise as four launches per cell and step; both forms fill the same workspace for
+ * ipoke_gru_unroll_backward (test hook to force either: ipoke_gru_set_fused, ipoke_hip_dev.h). */
 int ipoke_gru_unroll_forward(const ipoke_gru_desc* d, const void* x0, int ldx, const void* h0, int ldh, const float* const* weights,
                              void* workspace, void* out, int ldo, int dtype, void* stream);
 /* d_out [T][M][ldo] -> dweights (the layouts of `weights`, written), d_x0 [M][Cx] and d_h0 [M][Ch] (fp32; d_h0 summed over the cells) */

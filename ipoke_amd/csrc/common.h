@@ -5,6 +5,7 @@
 #include <string>
 
 #include "../../include/ipoke_hip.h"
+#include "../../include/ipoke_hip_dev.h"
 
 namespace ipoke {
 

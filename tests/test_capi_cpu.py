@@ -12,9 +12,22 @@ from ipoke_amd import _lib, configs
 from tests.conftest import ROOT
 
 
-def header_functions():
-    header = open(os.path.join(ROOT, "include", "ipoke_hip.h")).read()
-    return set(re.findall(r"^[a-z][a-z0-9_ ]*?\**\s*\b(ipoke_[a-z0-9_]+)\s*\(", header, flags=re.M))
+def header_functions(names=("ipoke_hip.h", "ipoke_hip_dev.h")):
+    """functions declared in the public header and in the developer / test-hook header"""
+    out = set()
+    for n in names:
+        header = open(os.path.join(ROOT, "include", n)).read()
+        out |= set(re.findall(r"^[a-z][a-z0-9_ ]*?\**\s*\b(ipoke_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    return out
+
+
+def test_test_hooks_live_in_the_developer_header():
+    """the drop-in boundary (ipoke_hip.h) declares no test hook / probe entry point."""
+    public = header_functions(("ipoke_hip.h",))
+    dev = header_functions(("ipoke_hip_dev.h",))
+    hooks = {"ipoke_spin_delay", "ipoke_timing_start", "ipoke_timing_start_all", "ipoke_timing_stop", "ipoke_timing_stop_ex",
+             "ipoke_set_dispatch_override", "ipoke_gru_set_fused", "ipoke_last_conv_kernel", "ipoke_conv_forward_repeat"}
+    assert hooks <= dev and not (hooks & public)
 
 
 def test_library_exports_every_declared_symbol():
