@@ -99,6 +99,32 @@ __device__ __forceinline__ float act_grad_from_out(int act, float y) {
   }
 }
 
+// ---- kernel-argument prefetch ------------------------------------------------
+#ifndef IPK_KERNARG_PREFETCH
+#define IPK_KERNARG_PREFETCH 1      // (0: developer A/B build)
+#endif
+// hipcc fetches kernel arguments lazily (an s_load next to each first use, each behind its own s_waitcnt).  The argument block of a launch
+// is cold -- the command processor has just written it -- so every first touch of a 64-byte line is a memory round trip (~0.3 us) and a
+// kernel with a few hundred bytes of arguments starts with a CHAIN of them.  One dword of every line of the first BYTES bytes requested
+// back to back at entry: one round trip; the compiler's own loads then hit the scalar cache.  Up to 8 lines (512 bytes); BYTES must not
+// exceed the size of the kernel's explicit arguments.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+  static_assert(BYTES >= 4, "at least one dword");
+  constexpr int last = ((BYTES - 4) / 64) * 64;
+  constexpr int o1 = 64 < last ? 64 : last, o2 = 128 < last ? 128 : last, o3 = 192 < last ? 192 : last, o4 = 256 < last ? 256 : last,
+                o5 = 320 < last ? 320 : last, o6 = 384 < last ? 384 : last, o7 = 448 < last ? 448 : last;
+  const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned d0, d1, d2, d3, d4, d5, d6, d7;
+  asm volatile(
+      "s_load_dword %0, %8, 0\n\ts_load_dword %1, %8, %9\n\ts_load_dword %2, %8, %10\n\ts_load_dword %3, %8, %11\n\t"
+      "s_load_dword %4, %8, %12\n\ts_load_dword %5, %8, %13\n\ts_load_dword %6, %8, %14\n\ts_load_dword %7, %8, %15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7)
+      : "s"(ka), "n"(o1), "n"(o2), "n"(o3), "n"(o4), "n"(o5), "n"(o6), "n"(o7)
+      : "memory");
+}
+
 // ---- reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

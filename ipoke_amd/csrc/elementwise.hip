@@ -293,6 +293,7 @@ __device__ __forceinline__ void affine_ext_pad(const AffineArgs& a, void* ext, i
 __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, float* __restrict__ out,
                                   float* __restrict__ scale_out, float* __restrict__ logdet_slot, int slot_stride, int Q,
                                   void* __restrict__ ext, int ext_ld, int ext_bf16) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(AffineArgs) + 64>();
   if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   extern __shared__ float raw_s[];
   __shared__ float red[8];
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(1024) void affine_bwd_kernel(int Cp, int t_off, int
                                                           const float* __restrict__ scale, const float* __restrict__ dld,
                                                           float* __restrict__ dx, T* __restrict__ dparams, int ldp,
                                                           float* __restrict__ dbias_part) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<84>();
   if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   // Thread (r0, i) owns transformed channel i of rows r0, r0 + rows_par, ...: it loads (dy, scale, x) once for BOTH outputs
   // (d mu, d s), keeps their column sums in registers and hands them to a deterministic LDS reduction.  (Rounds 1-2: every
@@ -426,6 +428,7 @@ struct ActNormArgs { int c0, C; const float* ls; const float* bias; const int* i
 __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const float* __restrict__ in, float* __restrict__ out,
                                           float* __restrict__ out2, float* __restrict__ scale_out, float* __restrict__ logdet_slot,
                                           int slot_stride, int Q) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)(sizeof(AffineArgs) + sizeof(ActNormArgs)) + 48>();
   if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   extern __shared__ float raw_s[];                 // [rows][2Cp] raw (mu, s), then [rows][ld] the coupling's output rows
   __shared__ float red[8];
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(1024) void actnorm_affine_bwd_kernel(ActNormArgs n,
                                                                   const float* __restrict__ dld, float* __restrict__ dx,
                                                                   T* __restrict__ dparams, int ldp, float* __restrict__ part,
                                                                   float* __restrict__ dbias_part) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(ActNormArgs) + 96>();
   if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   extern __shared__ float sm[];                    // [P][ld] gradient w.r.t. the coupling's output, then the partial-sum area
   const int tid = threadIdx.x, b = blockIdx.x;

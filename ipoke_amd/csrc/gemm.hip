@@ -370,6 +370,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP
 // =============================================================================================
 template <typename T, int WM, int WN, int MREP, int NREP>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr int E16 = ET<T>::E16;
   constexpr int BK = 128 / (int)sizeof(T);
@@ -521,6 +522,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // bound the math side of these small-M GEMMs (every wave re-reads the whole A tile).
 template <typename T, int WM, int WN, int MREP, int NREP, int NSTAGE, int KPB, bool SIMPLE, int WK = 1>
 __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
   constexpr int NTHR = WM * WN * WK * 64;          // 4 or 8 wave64 (8 waves = two per SIMD: one's LDS reads hide under the other's MFMAs)
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr int E16 = ET<T>::E16;
@@ -786,6 +788,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
 // weight gradient
 template <typename T, int NR>
 __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(TnParams)>();
   TnParams p = pin;
   if (pin.batch) {                       // batched launch: blockIdx.z selects operands and the 2-D tap geometry
     const TnBatchEntry e = pin.batch[blockIdx.z + pin.z0];
@@ -1098,6 +1101,7 @@ static void pick_xcd_map(NtParams& p) {
 // (two hand-over rounds) before the epilogue.
 // Split-K is over channel chunks (blockIdx.y); the epilogue is nt_epilogue (partials / atomics / dense outputs).
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s8_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
   typedef __attribute__((address_space(3))) void lds_void;
@@ -1306,6 +1310,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // minus the "outside the map" masks (the zero border is materialised by the staging DMA).  Output channels are tiled by 64
 // over blockIdx.y.  transposed (data gradient): the taps are mirrored, the caller supplies the transposed filter operand.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
   typedef typename Pack4<T>::type pack_t;
@@ -1532,6 +1537,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // through a three-slot ring.  Per output the DMA traffic is a third of the implicit GEMM's and the loop is bound by the matrix
 // cores: 8 waves = 4 pixel-row groups x 2 channel halves, 64 x 64 outputs each, 32 MFMAs per wave and barrier.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo16_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
   typedef typename Pack4<T>::type pack_t;
@@ -1802,6 +1808,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define IPOKE_C64_ABL 0
 #endif
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
   typedef typename Pack4<T>::type pack_t;
@@ -2280,6 +2287,7 @@ template <typename F> __device__ __forceinline__ void tn_wait_frags(F (&f)[6]) {
 // read with the transposing ds_read_b64_tr_b16 (two per fragment; inline assembly, see tn_ds_tr).
 template <int WM, int WN, int MREP, int NSTAGE, int WK>
 __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nn_glds_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
   typedef bf16_t T;
   constexpr int NREP = 2, NTHR = WM * WN * WK * 64, NWAVE = NTHR / 64;
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
@@ -2489,6 +2497,7 @@ static int dispatch_nn(NtParams& p, hipStream_t s) {
 // RM = reduction rows per ring slot (64).
 template <int NSTAGE, int RM>
 __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(TnParams)>();
   typedef bf16_t T;
   TnParams p = pin;
   if (pin.batch) {                       // batched launch: blockIdx.z selects operands and the 2-D tap geometry

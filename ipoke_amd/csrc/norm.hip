@@ -149,6 +149,7 @@ struct NormApply {
 // (rstd*gamma, beta - mean*rstd*gamma) are built once in LDS and the inner loop is one FMA per element, no divisions.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormApply)>();
   constexpr int E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
   __shared__ float sscale[4096], sshift[4096];
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
 // deviations) is taken from there.  grid (C / CS, N), dynamic LDS = S * CS * sizeof(T).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_fused_kernel(const NormApply a, int CS, float eps) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormApply)>();
   constexpr int E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];

@@ -120,6 +120,7 @@ __device__ __forceinline__ float norm_dw(const NormBwd& a, long m, int c) {
 // over rows rr, rr + rows_par, ... (16-byte loads, register partial sums, one fixed-order LDS reduction).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const NormBwd a) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormBwd)>();
   constexpr int E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
   __shared__ float sm[2][256 * E16];
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const NormBwd a) {
 }
 // pass 2a: per (n, g): S1 = sum_c gamma_c * sum du, S2 = sum_c gamma_c * sum du*xhat.  One block per sample, 16 threads per group.
 __global__ __launch_bounds__(256) void gn_bwd_groupsum_kernel(const NormBwd a) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormBwd)>();
   __shared__ float r1[256], r2[256];
   const int n = blockIdx.x, cpg = a.C / a.G;
   constexpr int PAR = 16;
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const NormBwd a, flo
 // per-channel constants of the sample live in LDS, the inner loop is 16-byte loads / stores without divisions.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormBwd)>();
   constexpr int E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
   extern __shared__ float lds[];            // [6][C]: mean, rstd, gamma, beta, S1/cnt, S2/cnt
