@@ -491,9 +491,7 @@ class PokeMotionModel(nn.Module):
             self.flow.engine.prepare_weights()
         ent["X"].copy_(X); ent["poke"].copy_(poke); ent["z"].copy_(z)
         ent["graph"].replay()
-        # the graph writes into ITS static output buffers: a second replay (a prefetched batch k + 1 while batch k is still queued or in its
-        # backward pass) would overwrite them -- hand out copies (two small tensors, ordered behind the replay on this stream)
-        return tuple(o.clone() for o in ent["out"])
+        return ent["out"]
 
     def forward_sample(self, batch, n_samples=1, n_logged_vids=1, show_progress=False, add_first_frame=False,
                        use_keypoint_pokes=False):
