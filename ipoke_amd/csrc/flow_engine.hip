@@ -1462,7 +1462,13 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     }
     if (f->nadam.on) {
       // single-GPU training: the update of the piece's ranges and the refresh of their shadows, natively, on the ready stream
-      const ipoke_flow::NativeAdam& A = f->nadam;
+      ipoke_flow::NativeAdam A = f->nadam;
+      {   // developer A/B (IPOKE_ADAM_EARLY_BLOCKS=n, IPOKE_ADAM_LATE_PIECES=k): the optimizer of all but the last k pieces on a smaller grid --
+          // a lower, steadier HBM rate beside the chain; the last pieces (whose parameters the next forward needs first) at full rate
+        static const int early = getenv("IPOKE_ADAM_EARLY_BLOCKS") ? atoi(getenv("IPOKE_ADAM_EARLY_BLOCKS")) : 0;
+        static const int late = getenv("IPOKE_ADAM_LATE_PIECES") ? atoi(getenv("IPOKE_ADAM_LATE_PIECES")) : 3;
+        if (early > 0 && piece < (int)pieces.size() - late) A.max_blocks = early;
+      }
       float* pm = const_cast<float*>(params);
       for (int kind = 0; kind < 3; ++kind) {
         if (p0[kind] < 0 || p1[kind] <= p0[kind]) continue;
