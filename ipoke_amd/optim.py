@@ -23,7 +23,8 @@ _FUSE_DEFAULT = os.environ.get("IPOKE_ADAM_FUSION", "0") == "1"
 _FUSE_SHADOWS = _FUSE_DEFAULT
 # persistent grid of the engine-issued update underneath backward (c2, round 4, with the linear conv2 kernel: 64 / 128 / 160 / 192 / 224 / 256
 # workgroups -> 65.0 / 57.8 / 57.4 / 57.35 / 57.4 / 59.2 ms)
-_NATIVE_BLOCKS = int(os.environ.get("IPOKE_NATIVE_ADAM_BLOCKS", "192"))
+# round 5 (unit kernels on 80 CUs): 160 workgroups with 24 backward pieces 54.6 / 54.8 ms against 55.6 / 55.5 at 192 / 16 (one call, two repeats)
+_NATIVE_BLOCKS = int(os.environ.get("IPOKE_NATIVE_ADAM_BLOCKS", "160"))
 _TILE_BLOCKS = int(os.environ.get("IPOKE_ADAM_TILE_BLOCKS", "128"))     # developer A/B: persistent grid of the fused tile kernel underneath backward
 
 

@@ -13,7 +13,7 @@ class SecondStageTrainer:
     the fused Adam-amsgrad update of that slice is applied, on a separate stream, while the remaining levels are still
     differentiating.  Without overlap the flat buffer is all-reduced in slices and updated after the backward pass."""
 
-    def __init__(self, model, n_grad_buckets=16, overlap=None):
+    def __init__(self, model, n_grad_buckets=24, overlap=None):
         self.model = model
         tr, bs = model.config["training"], model.config["data"]["batch_size"]
         # experiments/experiment.py:81-88: accumulate_grad_batches = ceil(min_acc_batch_size / batch_size) when that is larger than the
