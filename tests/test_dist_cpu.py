@@ -112,15 +112,15 @@ def _piece_ranges(z, npieces):
 
 def test_shard_layout_of_the_real_slices_at_world8():
     """The slices the engine's piecewise backward announces for BOTH shipped flows (z = 64: 1 237 326 840 parameters, z = 32: 1 054 426 620;
-    16 pieces = the trainer's default), cut for 8 ranks as FusedAdamAmsgrad.step_range_sharded cuts them: every slice begins 16-byte
+    24 pieces = the trainer's default, and 16), cut for 8 ranks as FusedAdamAmsgrad.step_range_sharded cuts them: every slice begins 16-byte
     aligned, shards are multiples of 4 floats, the replicated tail is shorter than 4 * world floats, the ranks' shards and the tail tile
     the slice exactly, and the slices tile the flat parameter buffer."""
     from ipoke_amd import dist as D
     world = 8
-    for z, expected in ((64, 1237326840), (32, 1054426620)):
-        ranges, total = _piece_ranges(z, 16)
+    for z, expected, npieces in ((64, 1237326840, 24), (32, 1054426620, 24), (64, 1237326840, 16)):      # 24: the trainer's default
+        ranges, total = _piece_ranges(z, npieces)
         assert expected <= total < expected + 4 * 6995          # the flat buffer pads every tensor to 16 bytes
-        assert len({p for p, _, _ in ranges}) == 16                 # 16 pieces, one or two regions (layers.*, priors.*) each
+        assert len({p for p, _, _ in ranges}) == npieces            # one or two regions (layers.*, priors.*) per piece
         assert [p for p, _, _ in ranges] == sorted(p for p, _, _ in ranges)
         covered = 0
         spans = sorted((b, e) for _, b, e in ranges)
