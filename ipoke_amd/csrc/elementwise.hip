@@ -634,12 +634,21 @@ __global__ void logdet_finalize_kernel(const float* __restrict__ slots, int nslo
 struct LsRef { long off; int C; };
 __global__ void actnorm_logdet_kernel(const float* __restrict__ params, const LsRef* __restrict__ refs, int n, int P,
                                       float* __restrict__ out_scalar) {
-  __shared__ float red[8];
+  __shared__ float red[16];
   float t = 0.f;
-  // C <= 64 per layer: 4 layers per pass of the 256 threads (fixed assignment -> deterministic sum)
-  const int sub = threadIdx.x >> 6, c = threadIdx.x & 63;
-  for (int l = sub; l < n; l += 4)
-    if (c < refs[l].C) t += params[refs[l].off + c];
+  // C <= 64 per layer: blockDim / 64 layers per pass (fixed assignment -> deterministic sum); eight passes' loads in flight at once --
+  // with 4 layers per pass and one dependent (descriptor, value) pair per iteration the 515 layers of the shipped flows took 170 us on
+  // the chain's queue, once per forward pass
+  const int sub = threadIdx.x >> 6, c = threadIdx.x & 63, per = blockDim.x >> 6;
+  for (int l0 = sub; l0 < n; l0 += 8 * per) {
+    LsRef r[8]; float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int l = l0 + u * per; r[u] = l < n ? refs[l] : LsRef{0, 0}; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = c < r[u].C ? params[r[u].off + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
   for (int l = 0; l < n; ++l)                       // layers wider than 64 channels (not in the shipped configs)
     for (int cc = 64 + threadIdx.x; cc < refs[l].C; cc += blockDim.x) t += params[refs[l].off + cc];
   const float tot = block_sum(t, red);
@@ -649,15 +658,48 @@ __global__ void actnorm_logdet_kernel(const float* __restrict__ params, const Ls
 // Writes scalars[0..2] = (loss, nll, nlogdet) and the gradients d_out = z/B (state layout), dld[b] = -w/B.
 __global__ void flow_nll_kernel(const float* __restrict__ z, const float* __restrict__ logdet, int B, int P, int C, int ld,
                                 float w, float* __restrict__ scalars, float* __restrict__ d_out, float* __restrict__ dld) {
-  __shared__ float red[8];
+  __shared__ float red[16];
   float t = 0.f;
   const long total = (long)B * P * ld;
   const float invB = 1.f / (float)B;
-  for (long i = threadIdx.x; i < total; i += blockDim.x) {
-    const int col = (int)(i % ld);
-    const float v = col < C ? z[i] : 0.f;
-    t += v * v;
-    if (d_out) d_out[i] = v * invB;
+  if ((ld & 3) == 0 && (((uintptr_t)z | (uintptr_t)d_out) & 15) == 0) {
+    // 16-byte groups, four per thread in flight (one workgroup: the value is a fixed-order sum; 72 us -> ~10 us at B = 20)
+    const long groups = total >> 2;
+    for (long g0 = threadIdx.x; g0 < groups; g0 += 4L * blockDim.x) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long g = g0 + (long)u * blockDim.x;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g < groups) {
+          v[u] = *reinterpret_cast<const f32x4*>(z + 4 * g);
+          const int col = (int)((4 * g) % ld);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (col + q >= C) v[u][q] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long g = g0 + (long)u * blockDim.x;
+        if (g < groups) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t += v[u][q] * v[u][q];
+          if (d_out) {
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = v[u][q] * invB;
+            *reinterpret_cast<f32x4*>(d_out + 4 * g) = o;
+          }
+        }
+      }
+    }
+  } else {
+    for (long i = threadIdx.x; i < total; i += blockDim.x) {
+      const int col = (int)(i % ld);
+      const float v = col < C ? z[i] : 0.f;
+      t += v * v;
+      if (d_out) d_out[i] = v * invB;
+    }
   }
   const float ss = block_sum(t, red);
   float l = 0.f;
@@ -933,7 +975,7 @@ extern "C" int ipoke_logdet_finalize(const float* slots, int nslots, int B, int 
 }
 extern "C" int ipoke_actnorm_logdet(const float* params, const void* refs_dev, int n, int P, float* out_scalar, void* stream) {
   IPK_REQUIRE(params && refs_dev && out_scalar, "null tensor");
-  hipLaunchKernelGGL(actnorm_logdet_kernel, dim3(1), dim3(256), 0, STREAM(stream), params, (const LsRef*)refs_dev, n, P,
+  hipLaunchKernelGGL(actnorm_logdet_kernel, dim3(1), dim3(1024), 0, STREAM(stream), params, (const LsRef*)refs_dev, n, P,
                      out_scalar);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
@@ -941,7 +983,7 @@ extern "C" int ipoke_actnorm_logdet(const float* params, const void* refs_dev, i
 extern "C" int ipoke_flow_nll(const float* z_state, const float* logdet, int B, int P, int C, int ld, float logdet_weight,
                               float* scalars3, float* d_out_state, float* dld, void* stream) {
   IPK_REQUIRE(z_state && logdet && scalars3, "null tensor");
-  hipLaunchKernelGGL(flow_nll_kernel, dim3(1), dim3(512), 0, STREAM(stream), z_state, logdet, B, P, C, ld, logdet_weight,
+  hipLaunchKernelGGL(flow_nll_kernel, dim3(1), dim3(1024), 0, STREAM(stream), z_state, logdet, B, P, C, ld, logdet_weight,
                      scalars3, d_out_state, dld);
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
