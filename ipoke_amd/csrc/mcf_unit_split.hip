@@ -694,7 +694,6 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_split_kernel(const
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (k > 0) { load_w2t(U.L[k - 1]); load_cact(U.L[k - 1]); }
       const int padc = U.Hq - H;
       for (int e = tid; e < R * padc; e += kMcfThreads) {
         const int p = e / padc, c = H + e - p * padc;
@@ -741,6 +740,8 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_split_kernel(const
       const bool wait = (nu + nd) > 0;
       Halo<4> hl;
       if (wait) halo_begin<S, 4>(hl, xg_region(U, b, k, S, s), s, nu, nd, H >> 1, 128, dc, dc_pitch, tl);
+      // the next layer's (b) operands are requested BEHIND the halo sweep: the CU's vector-memory pipeline is a FIFO, and in the train
+      // step (in-situ stamps, scripts/exp/insitu_unit_stamps.py) the sweep's loads queued behind these 72 KB
       if constexpr (MT == 2) {
         const int t_dep = s == 0 ? 1 : 0, t0 = wait ? 1 - t_dep : 0;
         if (t0 == 0) pass_c(0, acc_c[0]); else pass_c(1, acc_c[1]);
@@ -748,11 +749,13 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_split_kernel(const
         UNIT_STAMP_S(5 + 8 * (3 - k));
         if (wait) { halo_end<4>(U, hl); __syncthreads(); }
         UNIT_STAMP_S(6 + 8 * (3 - k));
+        if (k > 0) { load_w2t(U.L[k - 1]); load_cact(U.L[k - 1]); }
         if (t0 == 0) pass_c(1, acc_c[1]); else pass_c(0, acc_c[0]);
       } else {
         UNIT_STAMP_S(5 + 8 * (3 - k));
         if (wait) { halo_end<4>(U, hl); __syncthreads(); }
         UNIT_STAMP_S(6 + 8 * (3 - k));
+        if (k > 0) { load_w2t(U.L[k - 1]); load_cact(U.L[k - 1]); }
 #pragma unroll
         for (int t = 0; t < MT; ++t) pass_c(t, acc_c[t]);
       }
