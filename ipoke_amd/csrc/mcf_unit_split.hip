@@ -98,6 +98,27 @@ __device__ __forceinline__ void halo_end(const UnitParams& U, Halo<NI>& h) {
 // re-requested for the NEXT layer (buffer rs_next; soff_bias = kOob behind the last layer: zeros, no traffic) as soon as the tap's
 // matrix-core instructions have been issued -- the 36 KB per wave trickle out underneath the remaining taps instead of stalling
 // all eight waves in a burst behind the contraction.
+#ifndef IPOKE_UNIT_SPREAD
+#define IPOKE_UNIT_SPREAD 1      // 1: the next layer's weight requests in batches of 4-8 per wave between the phases of this layer (0: in
+#endif                           //    one burst inside the first contraction's last tile -- developer A/B)
+// re-request the fragments of taps [LO, HI) of the shifted-conv weights / of K steps [LO, HI) of the 1x1 weights from another layer's operand
+template <typename T, bool WIDE, int LO, int HI>
+__device__ __forceinline__ void reload_w1(McfW<T>& w, rsrc_t rs, int lane, int wave, int nks, int soff_bias) {
+  constexpr int J1 = UC<WIDE>::J1, CS = UC<WIDE>::CS;
+#pragma unroll
+  for (int tap = LO; tap < HI; ++tap)
+#pragma unroll
+    for (int st = 0; st < CS; ++st)
+#pragma unroll
+      for (int j = 0; j < J1; ++j)
+        w.w1[tap][st][j] = buf_frag<T>(rs, (wave + kMcfWaves * j) * nks * 1024 + lane * 16, (tap * CS + st) * 1024 + soff_bias);
+}
+template <typename T, bool WIDE, int LO, int HI>
+__device__ __forceinline__ void reload_w2(McfW<T>& w, rsrc_t rs, int lane, int wave, int n2, int soff_bias) {
+#pragma unroll
+  for (int st = LO; st < HI; ++st)
+    if (st < UC<WIDE>::N2S) w.w2[st][0] = buf_frag<T>(rs, wave * n2 * 1024 + lane * 16, (st < n2 ? st * 1024 : kOob) + soff_bias);
+}
 template <typename T, bool WIDE, bool RELOAD>
 __device__ __forceinline__ void split_gemm1_tile(const unsigned char* xs, int xs_pitch, const McfGeom& g, unsigned char* a2t, int a2_pitch, int H,
                                                  McfW<T>& w, int ptile, int lane, int wave, rsrc_t rs_next, int nks, int soff_bias, rsrc_t rs_w2,
@@ -106,7 +127,7 @@ __device__ __forceinline__ void split_gemm1_tile(const unsigned char* xs, int xs
   typedef typename ET<T>::frag frag_t;
   const int r = lane & 15, gq = lane >> 4;
   const unsigned char* zrow = xs + 64 * xs_pitch;
-  if (RELOAD) {
+  if (RELOAD && !IPOKE_UNIT_SPREAD) {
     // THIS layer's 1x1 weights (their registers are free since the previous layer's second contraction): requested here -- behind
     // the halo sweep, so that the sweep's loads and the previous coupling's hand-off stores do not queue behind them in the CU's
     // one vector-memory pipeline -- they land underneath this tile and the barrier behind it
@@ -129,11 +150,14 @@ __device__ __forceinline__ void split_gemm1_tile(const unsigned char* xs, int xs
 #pragma unroll
       for (int j = 0; j < J1; ++j) mma64(fa, w.w1[tap][st][j], acc[j]);
     }
-    if (RELOAD) {
+    if (RELOAD && (!IPOKE_UNIT_SPREAD || tap >= 4)) {        // spread: taps 0, 1 behind the last two taps; the rest between the later phases
 #pragma unroll
       for (int st = 0; st < CS; ++st)
 #pragma unroll
-        for (int j = 0; j < J1; ++j) w.w1[tap][st][j] = buf_frag<T>(rs_next, voff[j], (tap * CS + st) * 1024 + soff_bias);
+        for (int j = 0; j < J1; ++j) {
+          const int rt = IPOKE_UNIT_SPREAD ? tap - 4 : tap;
+          w.w1[rt][st][j] = buf_frag<T>(rs_next, voff[j], (rt * CS + st) * 1024 + soff_bias);
+        }
     }
   }
 #pragma unroll
@@ -231,7 +255,8 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
       post_e = U.L[q].post_ls[tid - q * C]; post_b = U.L[q].post_bias[tid - q * C]; post_on = true;
     }
   }
-  unit_load_w1<T, WIDE>(wr, U.L[0].W1, U);      // (the 1x1 weights of a layer are requested inside its first contraction)
+  unit_load_w1<T, WIDE>(wr, U.L[0].W1, U);
+  if (IPOKE_UNIT_SPREAD) unit_load_w2<T, WIDE>(wr, U.L[0].W2, U);
   for (int i = tid; i < (65 * xs_pitch + R * a2_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
   if (U.L[3].y && ld > C) {
     const int R2 = (ld - C) >> 1;
@@ -276,6 +301,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
     const int kn = k < 3 ? k + 1 : 3, soff_bias = k < 3 ? 0 : kOob;
     const rsrc_t rs1n = make_rsrc(U.L[kn].W1, ((U.H + 15) & ~15) * U.K1p * (int)sizeof(T));
     const rsrc_t rs2 = make_rsrc(Lk.W2, ((2 * C + 15) & ~15) * U.K2p * (int)sizeof(T));
+    const rsrc_t rs2n = make_rsrc(U.L[kn].W2, ((2 * C + 15) & ~15) * U.K2p * (int)sizeof(T));
     // halo rows of this layer's input that live in the neighbouring parts (layer 0: staged from global memory above)
     const int nu = (k > 0 && s > 0) ? rows_above(g) : 0, nd = (k > 0 && s < S - 1) ? rows_below(g) : 0;
     if constexpr (MT == 2) {
@@ -294,6 +320,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
       }
       __builtin_amdgcn_sched_barrier(0);
       UNIT_STAMP_S(3 + 8 * k);
+      if (IPOKE_UNIT_SPREAD && k > 0) reload_w2<T, WIDE, 8, 12>(wr, rs2, lane, wave, n2, 0);
       split_gemm1_tile<T, WIDE, true>(xs, xs_pitch, g, a2 + (1 - t0) * 16 * a2_pitch, a2_pitch, U.H, wr, p0 + (1 - t0) * 16, lane, wave, rs1n, nks,
                                       soff_bias, rs2, n2);
     } else if constexpr (MT == 1) {
@@ -305,6 +332,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
         __syncthreads();
       }
       UNIT_STAMP_S(3 + 8 * k);
+      if (IPOKE_UNIT_SPREAD && k > 0) reload_w2<T, WIDE, 8, 12>(wr, rs2, lane, wave, n2, 0);
       split_gemm1_tile<T, WIDE, true>(xs, xs_pitch, g, a2, a2_pitch, U.H, wr, p0, lane, wave, rs1n, nks, soff_bias, rs2, n2);
     } else {
 #pragma unroll
@@ -317,6 +345,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
     UNIT_STAMP_S(4 + 8 * k);
     __syncthreads();
     UNIT_STAMP_S(5 + 8 * k);
+    if (IPOKE_UNIT_SPREAD) reload_w1<T, WIDE, 2, 3>(wr, rs1n, lane, wave, nks, soff_bias);
     if (Lk.a2_save) {
       constexpr int E16 = ET<T>::E16;
       const int chunks = U.K2p / E16;
@@ -327,8 +356,10 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
       }
     }
     UNIT_STAMP_S(6 + 8 * k);
+    if (IPOKE_UNIT_SPREAD) reload_w1<T, WIDE, 3, 4>(wr, rs1n, lane, wave, nks, soff_bias);
     split_gemm2<T, WIDE, MT>(a2, a2_pitch, prm, N2, prm_ld, wr, lane, wave);
     __builtin_amdgcn_sched_barrier(0);
+    if (IPOKE_UNIT_SPREAD) reload_w1<T, WIDE, 4, 5>(wr, rs1n, lane, wave, nks, soff_bias);
     UNIT_STAMP_S(7 + 8 * k);
     __syncthreads();
     UNIT_STAMP_S(8 + 8 * k);
@@ -385,8 +416,13 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) ld_k[q] += q == k ? ld_acc : 0.f;
+    if (IPOKE_UNIT_SPREAD) {                      // (behind the coupling's stores and hand-off granules)
+      reload_w1<T, WIDE, 5, 6>(wr, rs1n, lane, wave, nks, soff_bias);
+      reload_w2<T, WIDE, 0, 4>(wr, rs2n, lane, wave, n2, soff_bias);
+    }
     __syncthreads();                              // the state update above is complete
     UNIT_STAMP_S(9 + 8 * k);
+    if (IPOKE_UNIT_SPREAD) reload_w2<T, WIDE, 4, 8>(wr, rs2n, lane, wave, n2, soff_bias);
     if (Lk.zc) {
       const int half = Lk.zc_ld >> 1;
       T* zb = reinterpret_cast<T*>(Lk.zc) + (row0 + p0) * Lk.zc_ld;
