@@ -236,7 +236,9 @@ def _split_descs(C, ld, B, S, xs, cond, shs, posts, keep, o, saved, dy, dld):
     return d4
 
 
-@pytest.mark.parametrize("C,ld,B", [(64, 64, 5), (60, 64, 3), (32, 64, 4), (30, 32, 3), (8, 8, 2), (64, 64, 20)])
+# (64, 64, 100): 400 workgroups at S = 4 on 256 CUs -- a grid that is not resident at once must not dead-lock (a workgroup only waits
+# for its neighbours, whose block ids are adjacent) nor time out
+@pytest.mark.parametrize("C,ld,B", [(64, 64, 5), (60, 64, 3), (32, 64, 4), (30, 32, 3), (8, 8, 2), (64, 64, 20), (64, 64, 100)])
 def test_macow_unit_row_split_is_bit_identical(C, ld, B):
     o_, x, h, shs, posts = _unit(C, ld, B, 300 + C)
     dims = shs[0]["dims"]
