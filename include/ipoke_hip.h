@@ -528,6 +528,9 @@ int ipoke_gru_gates_bwd(const void* ur_pre, const void* h, int ldh, const void* 
  * 1/sigma of spectral norm).  Replaces the reshape/permute/pad/cast chain of nn.Conv2d's weight on every call. */
 int ipoke_conv_weight_operand(const float* w, int cout, int cin, int taps, int transposed, const float* inv_scale, void* out, int kc,
                               int dtype, void* stream);
+/* the same for `count` weights in one launch (no inv_scale): w / out are HOST arrays of device pointers, dims5 a HOST array of
+ * {cout, cin, taps, transposed, kc} per weight -- the refresh of every cached operand behind an optimizer step */
+int ipoke_conv_weight_operand_multi(const float* const* w, void* const* out, const int32_t* dims5, int count, int dtype, void* stream);
 /* ---- native unroll of the ConvGRU (csrc/gru.hip) ---------------------------------------------------------------------------------
  * T steps x L stacked ConvGRU cells on the [B][H][W] latent (reference models/modules/motion_models/rnn.py:4-133 as
  * SpadeCondMotionModel.forward drives it, models/first_stage_motion_model.py:503-514: every cell starts from the same hidden state, cell 0

@@ -190,6 +190,7 @@ SIGNATURES = {
     "ipoke_gru_update_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_gru_gates_bwd": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "ipoke_conv_weight_operand": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
+    "ipoke_conv_weight_operand_multi": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int, c_int, _P]),
     "ipoke_spectral_workspace_floats": (ctypes.c_long, [c_int, c_int, c_int]),
     "ipoke_spectral_sigma": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, ctypes.c_float, _P, _P, _P, _P]),
     "ipoke_spectral_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

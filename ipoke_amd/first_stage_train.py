@@ -76,6 +76,45 @@ def clear_operand_cache():
     _OPCACHE.clear()
 
 
+_OPERAND_REFRESH = os.environ.get("IPOKE_C4_OPERAND_REFRESH", "1") != "0"      # developer A/B: 0 = operands rebuilt lazily, one launch per weight
+
+
+def take_operand_cache():
+    """Detach the cache's entries (ahead of an optimizer step that would drop them): ``refresh_operand_cache`` brings them back."""
+    snap = dict(_OPCACHE)
+    _OPCACHE.clear()
+    return snap
+
+
+def refresh_operand_cache(snap):
+    """Behind an optimizer step that wrote the parameters through raw pointers (no version bump): rebuild the cached operands of every
+    live PARAMETER in place -- same tensors, same cache keys -- with ONE multi-tensor launch, instead of dropping them and rebuilding
+    each lazily at its first use (c4: 101 launches of ~8 us on the chain per step).  Entries of derived weights (scoped: the per-pass
+    GRU gate concatenations), of other streams and of dead or re-versioned tensors are dropped as before."""
+    import ctypes as ct
+    cur = torch.cuda.current_stream().cuda_stream
+    by_dtype = {}
+    for key, (wref, (out, kc)) in snap.items():
+        p_, ver, shape, transposed, dtype, stream, scope = key
+        owner = wref()
+        if (owner is None or scope is not None or stream != cur or not isinstance(owner, torch.nn.Parameter) or owner.data_ptr() != p_
+                or owner._version != ver or tuple(owner.shape) != shape or not owner.is_contiguous() or owner.dtype != torch.float32):
+            continue
+        taps = 1
+        for k in shape[2:]:
+            taps *= int(k)
+        rows, cols = (shape[1], shape[0]) if transposed else (shape[0], shape[1])
+        by_dtype.setdefault(dtype, []).append((owner, out, (int(rows), int(cols), taps, int(bool(transposed)), int(kc)), key))
+    for dtype, jobs in by_dtype.items():
+        n = len(jobs)
+        wp = (ct.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+        op = (ct.c_void_p * n)(*[j[1].data_ptr() for j in jobs])
+        dims = (ct.c_int32 * (5 * n))(*[v for j in jobs for v in j[2]])
+        check(_lib.lib().ipoke_conv_weight_operand_multi(wp, op, dims, n, ops._dt(dtype), _lib.current_stream()))
+        for owner, out, d, key in jobs:
+            _OPCACHE[key] = snap[key]
+
+
 def _weight_operand(w, dtype, transposed_conv, inv_scale=None, cacheable=False, scope=None, owner=None):
     """fp32 conv weight in PyTorch layout -> ([rows][taps*kc] operand of the compute dtype, kc); ``transposed_conv`` reads
     ConvTranspose storage [in][out][k] as the conv weight [out][in][k]; ``inv_scale``: device scalar (1/sigma).
@@ -1349,6 +1388,9 @@ class FirstStageTrainer:
             loss.backward()
         if self.grad_hook is not None:
             self.grad_hook()
+        snap = take_operand_cache() if _OPERAND_REFRESH else None
         self.opt.step()
         m.invalidate_operands()
+        if snap is not None:
+            refresh_operand_cache(snap)
         return loss.detach(), X_hat.detach()

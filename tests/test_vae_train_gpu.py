@@ -114,3 +114,53 @@ def test_kl_value_and_gradient():
     assert abs(loss.item() - kl.item()) <= 1e-5 * max(1.0, abs(kl.item()))
     assert (dmu - mu4.grad.permute(0, 2, 3, 1).reshape(-1, Z)).abs().max() <= 1e-7
     assert (dlv - lv4.grad.permute(0, 2, 3, 1).reshape(-1, Z)).abs().max() <= 1e-7
+
+
+def test_weight_operand_multi_matches_single_calls_and_the_refreshed_cache():
+    """ipoke_conv_weight_operand_multi (every cached operand rebuilt in ONE launch behind the optimizer step) against one
+    ipoke_conv_weight_operand call per weight -- conv and ConvTranspose storage, 2-D / 3-D taps, channel padding, more weights than one
+    launch takes (64) -- and the trainer-side cache: after ``take_operand_cache`` / raw-pointer update / ``refresh_operand_cache`` the
+    cache hands out the SAME tensors holding the operands of the NEW values."""
+    import ctypes as ct
+    from ipoke_amd import first_stage_train as FT
+    lib = _lib.lib()
+    gen = torch.Generator().manual_seed(3)
+    shapes = [((64, 3, 3, 3), 0), ((128, 64, 3, 3), 0), ((64, 128, 3, 3), 1), ((32, 20, 1, 1), 0), ((16, 8, 3, 3, 3), 0)] * 14     # 70 weights
+    ws = [torch.randn(*sh, generator=gen).to(DEV) for sh, _ in shapes]
+    for dt in ("bf16", "f32"):
+        e16 = 8 if dt == "bf16" else 4
+        singles, outs, dims = [], [], []
+        for w, (sh, tr) in zip(ws, shapes):
+            taps = 1
+            for kk in sh[2:]:
+                taps *= kk
+            rows, cols = (sh[1], sh[0]) if tr else (sh[0], sh[1])
+            kc = -(-cols // e16) * e16
+            ref = torch.empty(rows, taps * kc, device=DEV, dtype=torch.bfloat16 if dt == "bf16" else torch.float32)
+            check(lib.ipoke_conv_weight_operand(ptr(w), rows, cols, taps, tr, None, ptr(ref), kc, _lib.DTYPES[dt], _lib.current_stream()))
+            singles.append(ref); outs.append(torch.full_like(ref, 7.0)); dims += [rows, cols, taps, tr, kc]
+        n = len(ws)
+        check(lib.ipoke_conv_weight_operand_multi((ct.c_void_p * n)(*[w.data_ptr() for w in ws]), (ct.c_void_p * n)(*[o.data_ptr() for o in outs]),
+                                                  (ct.c_int32 * (5 * n))(*dims), n, _lib.DTYPES[dt], _lib.current_stream()))
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(singles, outs)), dt
+    # the cache: operands of parameters are refreshed in place, derived (scoped) entries are dropped
+    FT.clear_operand_cache()
+    p1 = torch.nn.Parameter(ws[1].clone()); p2 = torch.nn.Parameter(ws[2].clone())
+    o1, kc1 = FT._weight_operand(p1.detach(), "bf16", False, cacheable=True, owner=p1)
+    o2, kc2 = FT._weight_operand(p2.detach(), "bf16", True, cacheable=True, owner=p2)
+    od, _ = FT._weight_operand(ws[0], "bf16", False, cacheable=True, scope=5, owner=ws[0])
+    snap = FT.take_operand_cache()
+    assert len(snap) == 3 and not FT._OPCACHE
+    v_before = p1._version
+    p1.data.mul_(2.0)                                               # as the fused optimizer does: through the storage, no version bump
+    assert p1._version == v_before
+    FT.refresh_operand_cache(snap)
+    torch.cuda.synchronize()
+    assert len(FT._OPCACHE) == 2                                    # the scoped (derived) entry is gone
+    fresh, _ = FT._build_weight_operand(p1.detach(), "bf16", False)
+    hit, _ = FT._weight_operand(p1.detach(), "bf16", False, cacheable=True, owner=p1)
+    assert hit is o1 and torch.equal(o1, fresh)                     # the SAME tensor, holding the operand of the new values
+    hit2, _ = FT._weight_operand(p2.detach(), "bf16", True, cacheable=True, owner=p2)
+    assert hit2 is o2
+    FT.clear_operand_cache()
