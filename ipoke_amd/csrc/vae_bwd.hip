@@ -175,10 +175,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const NormBwd a) {
   }
 }
 // pass 2a: per (n, g): S1 = sum_c gamma_c * sum du, S2 = sum_c gamma_c * sum du*xhat.  One block per sample, 16 threads per group.
-__global__ __launch_bounds__(256) void gn_bwd_groupsum_kernel(const NormBwd a) {
-  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormBwd)>();
-  __shared__ float r1[256], r2[256];
-  const int n = blockIdx.x, cpg = a.C / a.G;
+__device__ __forceinline__ void gn_bwd_groupsum_body(const NormBwd& a, int n, float* r1, float* r2) {
+  const int cpg = a.C / a.G;
   constexpr int PAR = 16;
   const int gl = threadIdx.x / PAR, pr = threadIdx.x % PAR;
   for (int g0 = 0; g0 < a.G; g0 += 256 / PAR) {
@@ -203,10 +201,10 @@ __global__ __launch_bounds__(256) void gn_bwd_groupsum_kernel(const NormBwd a) {
   }
 }
 // pass 2b: dgamma / dbeta per channel over all samples and chunks; 16 channels x 16 row lanes per block
-__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const NormBwd a, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float r1[256], r2[256];
+__device__ __forceinline__ void gn_bwd_affine_body(const NormBwd& a, int blk, float* __restrict__ dgamma, float* __restrict__ dbeta, float* r1,
+                                                   float* r2) {
   const int cl = threadIdx.x % 16, rl = threadIdx.x / 16;
-  const int c = blockIdx.x * 16 + cl;
+  const int c = blk * 16 + cl;
   float t1 = 0.f, t2 = 0.f;
   if (c < a.C) {
     for (int k = rl; k < a.N * a.nchunks; k += 16) {
@@ -221,6 +219,14 @@ __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const NormBwd a, flo
     for (int k = 0; k < 16; ++k) { u1 += r1[k * 16 + cl]; u2 += r2[k * 16 + cl]; }
     dbeta[c] = u1; dgamma[c] = u2;
   }
+}
+// passes 2a and 2b as ONE launch (round 5): workgroups [0, N) sum the groups of a sample, the rest the affine gradients of 16 channels --
+// two independent reductions over the same partials that used to cost two dependent launches per norm on the chain's queue
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const NormBwd a, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormBwd)>();
+  __shared__ float r1[256], r2[256];
+  if ((int)blockIdx.x < a.N) gn_bwd_groupsum_body(a, blockIdx.x, r1, r2);
+  else gn_bwd_affine_body(a, blockIdx.x - a.N, dgamma, dbeta, r1, r2);
 }
 // pass 3: dx = rstd * (dxhat - (S1 + xhat*S2)/cnt), plus the residual / modulation gradients.  Grid (chunks, N): the
 // per-channel constants of the sample live in LDS, the inner loop is 16-byte loads / stores without divisions.
@@ -446,12 +452,8 @@ extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(a.nchunks, d->N), dim3(256), 0, s, a),
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(a.nchunks, d->N), dim3(256), 0, s, a));
   IPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_groupsum_kernel, dim3(d->N), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(d->N + (d->dgamma ? (d->C + 15) / 16 : 0)), dim3(256), 0, s, a, d->dgamma, d->dbeta);
   IPK_LAUNCH_CHECK();
-  if (d->dgamma) {
-    hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((d->C + 15) / 16), dim3(256), 0, s, a, d->dgamma, d->dbeta);
-    IPK_LAUNCH_CHECK();
-  }
   const size_t lds = (size_t)6 * d->C * sizeof(float);
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(a.nchunks, d->N), dim3(256), lds, s, a),
