@@ -235,6 +235,7 @@ struct AffineArgs {
   int Cp, t_off, t_stride;
   int P, ld;
 };
+constexpr int kAffPre = 2;      // transformed elements per thread requested ahead (256 threads: 16 rows x <= 32 channels)
 // sum the split-K partials (+bias) of `rows` positions starting at row0 into LDS: raw_s[p][0:2Cp]
 __device__ __forceinline__ void affine_stage_raw(const AffineArgs& a, long row0, int rows, float* raw_s) {
   const int n2 = 2 * a.Cp;
@@ -300,15 +301,24 @@ __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, fl
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int rows = a.P / Q;
   const long row0 = (long)b * a.P + (long)q * rows;
+  // the transformed channels' inputs are requested BEFORE the split-K partials are staged (they used to be loaded behind the staging
+  // barrier: one more dependent memory round trip in a kernel that is nothing but such round trips)
+  float xin[kAffPre];
+#pragma unroll
+  for (int u = 0; u < kAffPre; ++u) {
+    const int e = threadIdx.x + u * blockDim.x;
+    xin[u] = 0.f;
+    if (e < rows * a.Cp) { const int p = e / a.Cp, i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
+  }
   affine_copy_rest(a, row0, rows, in, out);
   affine_stage_raw(a, row0, rows, raw_s);
   float ld_acc = 0.f;
-  for (int e = threadIdx.x; e < rows * a.Cp; e += blockDim.x) {
+  for (int e = threadIdx.x, u = 0; e < rows * a.Cp; e += blockDim.x, ++u) {
     const int p = e / a.Cp, i = e - p * a.Cp;
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
-    const float y = sc * in[off] + mu;
+    const float y = sc * (u < kAffPre ? xin[u < kAffPre ? u : 0] : in[off]) + mu;
     out[off] = y;
     if (ext) { if (ext_bf16) affine_ext_store<bf16_t>(ext, ext_ld, row0 + p, i, y); else affine_ext_store<float>(ext, ext_ld, row0 + p, i, y); }
     if (scale_out) scale_out[(row0 + p) * a.Cp + i] = sc;
@@ -324,14 +334,21 @@ __global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, fl
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int rows = a.P / Q;
   const long row0 = (long)b * a.P + (long)q * rows;
+  float xin[kAffPre];                      // (requested before the staging of the partials: see affine_fwd_kernel)
+#pragma unroll
+  for (int u = 0; u < kAffPre; ++u) {
+    const int e = threadIdx.x + u * blockDim.x;
+    xin[u] = 0.f;
+    if (e < rows * a.Cp) { const int p = e / a.Cp, i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
+  }
   affine_copy_rest(a, row0, rows, in, out);
   affine_stage_raw(a, row0, rows, raw_s);
-  for (int e = threadIdx.x; e < rows * a.Cp; e += blockDim.x) {
+  for (int e = threadIdx.x, u = 0; e < rows * a.Cp; e += blockDim.x, ++u) {
     const int p = e / a.Cp, i = e - p * a.Cp;
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
-    const float y = (in[off] - mu) / (sc + 1e-12f);      // macow_utils.py:64
+    const float y = ((u < kAffPre ? xin[u < kAffPre ? u : 0] : in[off]) - mu) / (sc + 1e-12f);      // macow_utils.py:64
     out[off] = y;
     if (ext) { if (ext_bf16) affine_ext_store<bf16_t>(ext, ext_ld, row0 + p, i, y); else affine_ext_store<float>(ext, ext_ld, row0 + p, i, y); }
   }
@@ -436,6 +453,25 @@ __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const flo
   const int rows = a.P / Q;
   const long row0 = (long)b * a.P + (long)q * rows;
   float* tile = raw_s + rows * 2 * a.Cp;
+  // requested ahead of everything that waits: the transformed channels' inputs and -- when a thread keeps its column over the rows it
+  // writes (blockDim a multiple of ld) -- the ActNorm parameters of that column (index, then scale / bias: two dependent loads that
+  // used to sit behind the last barrier)
+  float xin[kAffPre];
+#pragma unroll
+  for (int u = 0; u < kAffPre; ++u) {
+    const int e = threadIdx.x + u * blockDim.x;
+    xin[u] = 0.f;
+    if (e < rows * a.Cp) { const int p = e / a.Cp, i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
+  }
+  const bool col_fixed = blockDim.x % a.ld == 0;
+  int an_src = -1; float an_e = 1.f, an_b = 0.f;
+  if (col_fixed) {
+    const int j = (int)(threadIdx.x % a.ld) - n.c0;
+    if (j >= 0 && j < n.C) {
+      an_src = n.idx ? n.idx[j] : j;
+      if (n.ls) { an_e = expf(n.ls[an_src]); an_b = n.bias[an_src]; }
+    }
+  }
   {   // untouched channels -> tile (and `out`)
     const int total = rows * a.ld;
     for (int i0 = threadIdx.x; i0 < total; i0 += 4 * blockDim.x) {
@@ -456,13 +492,13 @@ __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const flo
   }
   affine_stage_raw(a, row0, rows, raw_s);
   float ld_acc = 0.f;
-  for (int e = threadIdx.x; e < rows * a.Cp; e += blockDim.x) {
+  for (int e = threadIdx.x, u = 0; e < rows * a.Cp; e += blockDim.x, ++u) {
     const int p = e / a.Cp, i = e - p * a.Cp;
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const int col = a.t_off + i * a.t_stride;
     const long off = (row0 + p) * a.ld + col;
-    const float y = sc * in[off] + mu;
+    const float y = sc * (u < kAffPre ? xin[u < kAffPre ? u : 0] : in[off]) + mu;
     tile[p * a.ld + col] = y;
     if (out) out[off] = y;
     if (scale_out) scale_out[(row0 + p) * a.Cp + i] = sc;
@@ -475,9 +511,14 @@ __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const flo
     const int j = col - n.c0;
     float v;
     if (j >= 0 && j < n.C) {
-      const int src = n.idx ? n.idx[j] : j;
-      v = tile[p * a.ld + n.c0 + src];
-      if (n.ls) v = v * expf(n.ls[src]) + n.bias[src];
+      if (col_fixed) {
+        v = tile[p * a.ld + n.c0 + an_src];
+        if (n.ls) v = v * an_e + an_b;
+      } else {
+        const int src = n.idx ? n.idx[j] : j;
+        v = tile[p * a.ld + n.c0 + src];
+        if (n.ls) v = v * expf(n.ls[src]) + n.bias[src];
+      }
     } else {
       v = tile[e];
     }
