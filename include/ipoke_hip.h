@@ -207,6 +207,31 @@ int ipoke_affine_actnorm_fwd(const ipoke_affine_desc* d, const float* in, float*
 int ipoke_actnorm_affine_bwd(int c0, int C, const float* log_scale, const int32_t* idx, const float* dy2, const float* x1, float* part,
                              int Cp, int t_off, int t_stride, int P, int ld, const float* x0, const float* scale, const float* dld, float* dx,
                              void* dparams, int ldp, float* dbias_part, int B, int dtype, void* stream);
+/* conv3 of a coupling net AND the coupling transform it feeds in one launch (NICEConvBlock's last convolution, macow_utils.py:270-281,
+ * followed by the affine transform, macow_utils.py:42-66, optionally with the ActNorm2dFlow (+ Shuffle) behind it): the K splits of a
+ * 128-row tile exchange their partial sums inside the launch (mode / results exactly those of ipoke_conv_forward with
+ * splitk = ipoke_conv3x3_coupling_splitk(...) followed by ipoke_affine_fwd_ext / ipoke_affine_actnorm_fwd / ipoke_affine_inv_ext:
+ * bit-identical states, scales and log-det slots; no partial-sum slabs are written).
+ *   conv: the 3x3 / pad 1 convolution on 8x8 maps as for ipoke_conv_forward (bf16, dense input, Nout = 2*Cp <= 64, no bias /
+ *         activation; C and splitk are ignored);  aff: bias, Cp, t_off, t_stride, P = 64, ld (raw / nsplit / strides ignored);
+ *   mode 0: out = coupling(in) (+ ext, scale_out, logdet_slot with slot_stride >= 4)   [ipoke_affine_fwd_ext]
+ *   mode 1: out (may be NULL) as mode 0, out2 = ActNorm(+ shuffle)(out)                 [ipoke_affine_actnorm_fwd]
+ *   mode 2: out = coupling^-1(in) (+ ext)                                               [ipoke_affine_inv_ext]
+ * xchg: ipoke_conv3x3_coupling_xchg_bytes() bytes of device scratch, initialised ONCE by ipoke_conv3x3_coupling_xchg_init and left in
+ * that state by every launch; one launch at a time per scratch.  Word 0 counts hand-offs that timed out (0 on a healthy device). */
+typedef struct {
+  int32_t mode;
+  const float* in; float* out; float* out2; float* scale_out; float* logdet_slot; int32_t slot_stride;
+  int32_t an_c0, an_C; const float* an_log_scale; const float* an_bias; const int32_t* an_idx;
+  void* ext; int32_t ext_ld;
+  void* xchg;
+} ipoke_coupling_epi;
+/* K splits of the fused launch at M = 64*B rows and Kc input channels: 4, 8, 16 or 32; 0 = the fused kernel does not apply */
+int ipoke_conv3x3_coupling_splitk(int M, int Kc, int dtype);
+int64_t ipoke_conv3x3_coupling_xchg_bytes(void);
+int ipoke_conv3x3_coupling_xchg_init(void* xchg, void* stream);
+int ipoke_conv3x3_coupling(const ipoke_conv_desc* conv, const ipoke_affine_desc* aff, const ipoke_coupling_epi* epi, int B, int dtype,
+                           void* stream);
 int ipoke_reduce_rows(const float* src, float* dst, int R, int ncols, void* stream);
 /* multi-tensor form: entries_dev[i] = {int64 src, int64 dst (float offsets), int32 ld, int32 ncols, int32 rmul, int32 pad};
  * entry i sums R * max(rmul, 1) rows */

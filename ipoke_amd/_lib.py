@@ -48,6 +48,14 @@ class AffineDesc(Structure):
                 ("P", c_int32), ("ld", c_int32)]
 
 
+class CouplingEpi(Structure):
+    """ipoke_coupling_epi (include/ipoke_hip.h): outputs of the fused conv3 + coupling launch"""
+    _fields_ = [("mode", c_int32), ("inp", c_void_p), ("out", c_void_p), ("out2", c_void_p), ("scale_out", c_void_p),
+                ("logdet_slot", c_void_p), ("slot_stride", c_int32), ("an_c0", c_int32), ("an_C", c_int32),
+                ("an_log_scale", c_void_p), ("an_bias", c_void_p), ("an_idx", c_void_p), ("ext", c_void_p), ("ext_ld", c_int32),
+                ("xchg", c_void_p)]
+
+
 class NormBwdDesc(Structure):
     _fields_ = [("x", c_void_p), ("ldx", c_int32), ("y", c_void_p), ("ldy", c_int32), ("dy", c_void_p), ("lddy", c_int32),
                 ("dx", c_void_p), ("lddx", c_int32), ("dres", c_void_p), ("lddres", c_int32),
@@ -122,6 +130,10 @@ SIGNATURES = {
     "ipoke_spectral_bwd_frames": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int64, _P, c_int64, _P, c_int, _P]),
     "ipoke_sum_frames": (c_int, [_P, _P, c_int, c_int64, c_int, _P]),
     "ipoke_conv3x3_skinny_splitk": (c_int, [c_int, c_int, c_int]),
+    "ipoke_conv3x3_coupling_splitk": (c_int, [c_int, c_int, c_int]),
+    "ipoke_conv3x3_coupling_xchg_bytes": (c_int64, []),
+    "ipoke_conv3x3_coupling_xchg_init": (c_int, [_P, _P]),
+    "ipoke_conv3x3_coupling": (c_int, [POINTER(ConvDesc), POINTER(AffineDesc), POINTER(CouplingEpi), c_int, c_int, _P]),
     "ipoke_conv_wgrad": (c_int, [POINTER(WgradDesc), c_int, _P]),
     "ipoke_wgrad_batch_entry_size": (c_int, []),
     "ipoke_conv_wgrad_batched": (c_int, [POINTER(WgradDesc), _P, c_int, _P, _P, _P, c_int, _P]),

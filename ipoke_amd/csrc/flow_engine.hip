@@ -118,6 +118,9 @@ struct ipoke_flow {
   // fused MaCowUnit launches on unit_split workgroups per sample (mcf_unit_split.hip; 1 = one workgroup per sample) and the
   // zero-initialised exchange scratch of those launches (sized for max_batch; used by one launch at a time: the chain's stream)
   int unit_split = 1; void* d_xchg = nullptr;
+  // conv3 of a coupling net and the coupling transform in one launch (ipoke_conv3x3_coupling; forward and reverse passes) and that
+  // launch's exchange scratch (initialised once, left in that state by every launch; the chain's stream only)
+  bool coupling_fuse = false; void* d_cxchg = nullptr;
   // every masked-conv layer is differentiated inside a fused MaCowUnit launch, which also writes the layer's input in the matrix
   // cores' dtype: the shifted-conv weight gradients then read that copy through the LDS-DMA GEMM instead of the fp32 state
   bool mcf_xop = false;
@@ -553,7 +556,17 @@ bool nice_feeds(const Op& a, const Op& b) {
 
 // coupling net forward: conv1 -> ELU -> conv2 -> ELU -> conv3 (split-K partials)
 // `zc_ready`: the conditioning operand was already written by the preceding coupling's transform (ipoke_affine_*_ext)
-int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2, void* zc, bool zc_ready = false) {
+void nice_conv3_desc(const Ctx& c, const Op& op, void* h2, ipoke_conv_desc& d) {
+  set_conv8(d, c.B, 3, 1);
+  set_a_dense(d, h2, op.hidK, op.hidK);
+  d.W = c.sh(op.sh_c3); d.ldw = 9 * op.hidK; d.Nout = 2 * op.cout; d.C = c.partials(); d.c_f32 = 1; d.ldc = 64;
+  d.splitk = nice_splitk(c);
+}
+// conv3 and the coupling transform of this net run as ONE launch (ipoke_conv3x3_coupling) at this batch size
+bool nice_fused(const Ctx& c, const Op& op) {
+  return c.f->coupling_fuse && c.f->d_cxchg && ipoke_conv3x3_coupling_splitk((int)c.M, op.hidK, c.dtype) > 0;
+}
+int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2, void* zc, bool zc_ready = false, bool with_conv3 = true) {
   const int hid = c.f->cfg.hidden;
   ipoke_conv_desc d;
   if (!zc_ready) {
@@ -573,10 +586,8 @@ int nice_net(const Ctx& c, const Op& op, const float* in, void* h1, void* h2, vo
                          c.f->cfg.cond_channels, c.M, c.dtype, c.stream());
     if (rc) return rc;
   }
-  set_conv8(d, c.B, 3, 1);
-  set_a_dense(d, h2, op.hidK, op.hidK);
-  d.W = c.sh(op.sh_c3); d.ldw = 9 * op.hidK; d.Nout = 2 * op.cout; d.C = c.partials(); d.c_f32 = 1; d.ldc = 64;
-  d.splitk = nice_splitk(c);
+  if (!with_conv3) return IPOKE_OK;
+  nice_conv3_desc(c, op, h2, d);
   return ipoke_conv_forward(&d, c.dtype, c.stream());
 }
 void nice_affine_desc(const Ctx& c, const Op& op, ipoke_affine_desc& a) {
@@ -750,6 +761,7 @@ extern "C" int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out)
     if (f->unit_split != 2 && f->unit_split != 4) f->unit_split = 1;
     if (f->n_lanes > 1 || cfg->dtype != IPOKE_BF16) f->unit_split = 1;     // (lanes would share the scratch across streams)
   }
+  f->coupling_fuse = f->n_lanes == 1 && cfg->dtype == IPOKE_BF16 && ipoke_conv3x3_coupling_splitk(64, cfg->hidden, cfg->dtype) > 0;
   *out = f.release();
   return IPOKE_OK;
 }
@@ -762,6 +774,11 @@ static int ensure_device(ipoke_flow* f) {
     const int64_t nb = ipoke_macow_unit_xchg_bytes(f->cfg.max_batch, f->unit_split);
     IPK_HIP(hipMalloc(&f->d_xchg, nb));
     IPK_HIP(hipMemset(f->d_xchg, 0, nb));
+  }
+  if (f->coupling_fuse && !f->d_cxchg) {
+    IPK_HIP(hipMalloc(&f->d_cxchg, (size_t)ipoke_conv3x3_coupling_xchg_bytes()));
+    int rc = ipoke_conv3x3_coupling_xchg_init(f->d_cxchg, nullptr); if (rc) return rc;
+    IPK_HIP(hipDeviceSynchronize());
   }
   IPK_REQUIRE((int)sizeof(RelayoutJobH) == ipoke_relayout_job_size() && (int)sizeof(WnJobH) == ipoke_wn_job_size(),
               "job table layout mismatch");
@@ -835,6 +852,7 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   if (f->d_w2tab) (void)hipFree(f->d_w2tab);
   if (f->d_redtab) (void)hipFree(f->d_redtab);
   if (f->d_xchg) (void)hipFree(f->d_xchg);
+  if (f->d_cxchg) (void)hipFree(f->d_cxchg);
   for (auto e : f->events) (void)hipEventDestroy(e);
   drop_graphs(f);
   if (f->side) (void)hipStreamDestroy(f->side);
@@ -1197,7 +1215,8 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
         void* h2 = l.rows(save ? op.ws_b : l.plan.tmp_h2, (int64_t)op.hidK * f->esz);
         void* zc = save ? l.rows(op.ws_g, (int64_t)op.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
         const bool have_zc = (i > 0 && nice_feeds(f->ops[i - 1], op)) || (!init && unit_feeds(f, i));
-        rc = nice_net(l, op, in, h1, h2, zc, have_zc); if (rc) return rc;
+        const bool one_launch = !init && nice_fused(l, op);
+        rc = nice_net(l, op, in, h1, h2, zc, have_zc, !one_launch); if (rc) return rc;
         ipoke_affine_desc a; nice_affine_desc(l, op, a);
         void* ext = nullptr; int ext_ld = 0;
         if (i + 1 < f->ops.size() && nice_feeds(op, f->ops[i + 1])) {
@@ -1205,7 +1224,21 @@ static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, 
           ext = save ? l.rows(nx.ws_g, (int64_t)nx.Kc1 * f->esz) : l.rows(l.plan.tmp_zc, 64L * f->esz);
           ext_ld = nx.Kc1;
         }
-        if (with_an) {
+        if (one_launch) {
+          ipoke_conv_desc d3; nice_conv3_desc(l, op, h2, d3);
+          ipoke_coupling_epi e; std::memset(&e, 0, sizeof(e));
+          e.mode = with_an ? 1 : 0; e.in = in; e.scale_out = save ? l.rowsf(op.ws_c, op.cout) : nullptr;
+          e.logdet_slot = l.slot(op.slot); e.slot_stride = 4; e.xchg = f->d_cxchg;
+          if (with_an) {
+            const Op& an = f->ops[op.an_next];
+            e.out = save ? l.state((int)i + 1) : nullptr; e.out2 = out;
+            e.an_c0 = an.c0; e.an_C = an.Cn; e.an_log_scale = an.p_ls >= 0 ? params + an.p_ls : nullptr;
+            e.an_bias = an.p_bias >= 0 ? params + an.p_bias : nullptr; e.an_idx = an.idx_fwd >= 0 ? perm + an.idx_fwd : nullptr;
+          } else {
+            e.out = out; e.ext = ext; e.ext_ld = ext_ld;
+          }
+          rc = ipoke_conv3x3_coupling(&d3, &a, &e, l.B, l.dtype, l.stream());
+        } else if (with_an) {
           const Op& an = f->ops[op.an_next];
           rc = ipoke_affine_actnorm_fwd(&a, in, save ? l.state((int)i + 1) : nullptr, out, save ? l.rowsf(op.ws_c, op.cout) : nullptr,
                                         l.slot(op.slot), 4, l.B, an.c0, an.Cn, an.p_ls >= 0 ? params + an.p_ls : nullptr,
@@ -1324,13 +1357,22 @@ static int run_reverse(ipoke_flow* f, const float* params, const int32_t* perm, 
       } else {
         // the conditioning channels are untouched by the coupling, so the net sees the same input as in forward
         const bool have_zc = i + 1 < (int)f->ops.size() && (nice_feeds(f->ops[i + 1], op) || actnorm_feeds(i + 1));     // written by the layer inverted just before this one
-        rc = nice_net(l, op, in, l.rows(l.plan.tmp_h1, hb), l.rows(l.plan.tmp_h2, (int64_t)op.hidK * f->esz), l.rows(l.plan.tmp_zc, 64L * f->esz),
-                      have_zc);
+        const bool one_launch = nice_fused(l, op);
+        void* h2 = l.rows(l.plan.tmp_h2, (int64_t)op.hidK * f->esz);
+        rc = nice_net(l, op, in, l.rows(l.plan.tmp_h1, hb), h2, l.rows(l.plan.tmp_zc, 64L * f->esz), have_zc, !one_launch);
         if (rc) return rc;
         ipoke_affine_desc a; nice_affine_desc(l, op, a);
         const bool feed = i > 0 && nice_feeds(op, f->ops[i - 1]);
-        rc = ipoke_affine_inv_ext(&a, in, out, l.B, feed ? l.rows(l.plan.tmp_zc, 64L * f->esz) : nullptr, feed ? f->ops[i - 1].Kc1 : 0, l.dtype,
-                                  l.stream());
+        void* ext = feed ? l.rows(l.plan.tmp_zc, 64L * f->esz) : nullptr;
+        const int ext_ld = feed ? f->ops[i - 1].Kc1 : 0;
+        if (one_launch) {
+          ipoke_conv_desc d3; nice_conv3_desc(l, op, h2, d3);
+          ipoke_coupling_epi e; std::memset(&e, 0, sizeof(e));
+          e.mode = 2; e.in = in; e.out = out; e.ext = ext; e.ext_ld = ext_ld; e.xchg = f->d_cxchg;
+          rc = ipoke_conv3x3_coupling(&d3, &a, &e, l.B, l.dtype, l.stream());
+        } else {
+          rc = ipoke_affine_inv_ext(&a, in, out, l.B, ext, ext_ld, l.dtype, l.stream());
+        }
       }
       if (rc) return rc;
     }

@@ -1100,8 +1100,27 @@ static void pick_xcd_map(NtParams& p) {
 // every fourth K-block (tap), four K-blocks are consumed per barrier, and the four groups' accumulators meet in LDS
 // (two hand-over rounds) before the epilogue.
 // Split-K is over channel chunks (blockIdx.y); the epilogue is nt_epilogue (partials / atomics / dense outputs).
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s8_kernel(const NtParams p) {
-  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
+//
+// NSPLIT > 0 (conv3x3_s8_coupling_kernel): the K splits of a row tile meet INSIDE the launch and the coupling transform the
+// convolution feeds (affine_fwd / affine_actnorm_fwd / affine_inv of elementwise.hip) runs in the same launch -- see the tail
+// of the body.
+struct CouplingEpi {
+  const float* bias; const float* in; float* out; float* out2; float* scale_out; float* logdet_slot;
+  const float* an_ls; const float* an_bias; const int* an_idx; void* ext; void* xchg;
+  int xchg_bytes, slot_stride, Cp, t_off, t_stride, ld, mode, an_c0, an_C, ext_ld, ext_bf16;
+  int ld_sh, cp_sh, ts_sh;      // log2 of ld / Cp / t_stride when a power of two, else -1
+};
+static constexpr int kCplHeader = 256;                 // bytes: word 0 counts spin time-outs
+static constexpr unsigned kCplEmpty = 0xffffffffu;     // a dword of the exchange scratch nobody has written yet (a NaN no sum produces)
+static constexpr unsigned kCplSpinMax = 1u << 21;
+
+#ifdef IPOKE_GEMM_STAMPS      // probe build: 4 (plain) / 8 (fused) wall-clock stamps per workgroup
+#define S8_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(blockIdx.x + blockIdx.y * gridDim.x) * (NSPLIT ? 16 : 4) + (i)] = wall_clock64(); } while (0)
+#else
+#define S8_STAMP(i) do {} while (0)
+#endif
+template <int NSPLIT>
+__device__ __forceinline__ void conv3x3_s8_body(const NtParams& p, const CouplingEpi& e, const int tile, const int z) {
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
   typedef __attribute__((address_space(3))) void lds_void;
@@ -1117,13 +1136,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned char* zrow = smem + 2 * ABUF;                   // 256 bytes of zeros: the "outside the map" row
   unsigned char* ring = zrow + 256;                        // R filter K-blocks
   unsigned char* dummy = ring + R * WSLOT;                 // landing zone of padding DMAs, 1 KB per wave
-  GEMM_STAMP(0);
+  S8_STAMP(0);
   if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mh = wave & 1, kq = wave >> 1;
   const GeomDev& g = p.g;
-  const int m0 = blockIdx.x * BM, z = blockIdx.y;
+  const int m0 = tile * BM;
   const int nchunks = p.Kc >> 6;
   const int c_begin = z * p.kb_per_split, c_end = min(nchunks, c_begin + p.kb_per_split);
   const int nch = max(0, c_end - c_begin), nkb = nch * 9, nrounds = (nkb + 3) >> 2;
@@ -1189,6 +1208,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     ++a_next;
   };
+  // fused launch: what the coupling at the end needs besides the convolution's sums is requested NOW, ahead of the K loop -- the
+  // slice's state rows, the bias and the ActNorm parameters of this thread's column (otherwise three dependent round trips behind
+  // the hand-off).  Index arithmetic: shifts when ld / Cp / t_stride are powers of two (the integer-division sequences of the
+  // general path cost the affine kernels ~1 us per launch).
+  constexpr int NOWN = NSPLIT == 0 ? 1 : (NSPLIT < 8 ? NSPLIT : 8), RPO = BM / NOWN;   // owners per tile, rows per owner (16 or 32)
+  constexpr int SLOT = RPO * 256;                                                      // one sender's rows for one owner, bytes
+  constexpr int NSL = RPO / 16;                                                        // 16-row slices per owner (1 or 2)
+  // one slice per owner (NSPLIT >= 8): both halves of the workgroup share its elements (element u of thread t256 of the 256-thread
+  // affine kernels goes to half u); two slices (NSPLIT = 4): a half per slice, two elements per thread
+  constexpr int NU = NSL == 1 ? 1 : 2;                 // transformed elements per thread (Cp <= 32)
+  constexpr int NC = NSL == 1 ? 2 : 4;                 // copied (untouched) elements per thread (ld <= 64)
+  const bool owner = NSPLIT > 0 && z < NOWN;
+  const int hf = tid >> 8, t256 = tid & 255;
+  const int u0 = NSL == 1 ? hf : 0;                    // first element index (of the 256-thread numbering) this thread handles
+  const long row0 = (long)m0 + z * RPO + (NSL == 1 ? 0 : hf * 16);                     // first state row of this thread's slice
+  const bool valid = owner && row0 < g.M;
+  const bool with_an = e.mode == 1;
+  const int ld = e.ld, Cp = e.Cp;
+  auto div_ld = [&](int i, int& q, int& r) { if (e.ld_sh >= 0) { q = i >> e.ld_sh; r = i & (ld - 1); } else { q = i / ld; r = i - q * ld; } };
+  auto div_cp = [&](int i, int& q, int& r) { if (e.cp_sh >= 0) { q = i >> e.cp_sh; r = i & (Cp - 1); } else { q = i / Cp; r = i - q * Cp; } };
+  auto is_transformed = [&](int col) {
+    const int rel = col - e.t_off;
+    if (e.ts_sh >= 0) return rel >= 0 && (rel & (e.t_stride - 1)) == 0 && (rel >> e.ts_sh) < Cp;
+    return rel >= 0 && rel % e.t_stride == 0 && rel / e.t_stride < Cp;
+  };
+  float pre_c[NC], pre_t[NU];
+  f32x4 pre_bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool col_fixed = false; int an_src = 0; float an_e = 1.f, an_b = 0.f;
+  if constexpr (NSPLIT > 0) {
+#pragma unroll
+    for (int u = 0; u < NC; ++u) pre_c[u] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) pre_t[u] = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < NC; ++u) {
+        const int i = t256 + (NC * u0 + u) * 256;
+        int pp, col; div_ld(i, pp, col);
+        if (i < 16 * ld && !is_transformed(col)) pre_c[u] = e.in[row0 * ld + i];
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int el = t256 + (u0 + u) * 256;
+        int pp, i; div_cp(el, pp, i);
+        if (el < 16 * Cp) pre_t[u] = e.in[(row0 + pp) * ld + e.t_off + (long)i * e.t_stride];
+      }
+      col_fixed = with_an && e.ld_sh >= 0 && ld <= 256;           // 256 % ld == 0: a thread keeps its column over the rows it writes
+      if (col_fixed) {
+        const int j = (t256 & (ld - 1)) - e.an_c0;
+        if (j >= 0 && j < e.an_C) {
+          an_src = e.an_idx ? e.an_idx[j] : j;
+          if (e.an_ls) { an_e = expf(e.an_ls[an_src]); an_b = e.an_bias[an_src]; }
+        }
+      }
+    }
+    if (owner && e.bias && tid < RPO * 16) {
+      const int j = (tid & 15) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (j + q < 2 * Cp) pre_bias[q] = e.bias[j + q];
+    }
+  }
   issue_a();                 // chunk 0
   issue_w(); issue_w();      // rounds 0 and 1
 
@@ -1223,7 +1303,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int r = 0; r < nrounds; ++r) {
     wait_vmcnt<4>();                 // everything but this wave's share of round r + 1 has landed (input chunks included)
     __builtin_amdgcn_s_barrier();
-    if (r == 0) GEMM_STAMP(1);
+    if (r == 0) S8_STAMP(1);
     // the first K-block of this round lies in chunk (4r)/9: request the chunk after it once (its buffer held chunk - 1,
     // whose last K-block was consumed before this barrier)
     if (a_next <= (4 * r) / 9 + 1) issue_a();          // (issued before the filter blocks: the wait above counts those only)
@@ -1269,7 +1349,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (t >= 9) { t -= 9; ++ci; }
   }
   wait_vmcnt<0>();
-  GEMM_STAMP(2);
+  S8_STAMP(2);
+  if constexpr (NSPLIT > 0) {
+    // the values requested ahead of the K loop have landed: pin that here, so that no use further down waits on the vector-memory
+    // counter (which by then also counts the hand-off's write-through stores)
+#pragma unroll
+    for (int u = 0; u < NC; ++u) asm volatile("" : "+v"(pre_c[u]));
+#pragma unroll
+    for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(pre_t[u]));
+    asm volatile("" : "+v"(pre_bias));
+    asm volatile("" : "+v"(an_src), "+v"(an_e), "+v"(an_b));
+  }
+  if constexpr (NSPLIT == 0) {
   // the four K groups meet: groups 2, 3 hand over to groups 0, 1, then group 1 to group 0 (nt_epilogue's staging layout)
   {
     unsigned char* st = smem + (mh * MREP * 16 + (lane & 15)) * EP + (lane >> 4) * 16;
@@ -1296,7 +1387,240 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   nt_epilogue<T, 2, 1, MREP, NREP, NTHR>(p, acc, smem, m0, 0, mh, 0, z, kq == 0);
-  GEMM_STAMP(3);
+  } else {
+    // ---- the K splits of this row tile meet inside the launch (reduce-scatter), then the rows' owners apply the coupling ----
+    // Before: 16 partial tiles -> 5 MB of fp32 slabs -> kernel boundary -> affine_* re-reads and sums them (14 us + boundary +
+    // 9 us per coupling, 215 couplings per pass).  Here the 128 rows of a tile are dealt in 16-row slices (= one block of the
+    // affine kernels: a quarter of a sample, log-det slot q) to NOWN = min(NSPLIT, 8) of the tile's NSPLIT workgroups; every
+    // workgroup sums its four K groups in LDS and sends each 16-byte chunk of a foreign row straight to that row's owner:
+    // relaxed agent-scope (sc1, write-through) stores into the owner's slot [sender][row][64 floats], no fence, no flag.  The
+    // data is the flag (form R2 of cdna_hip_programming.md Guideline 16, as in mcf_unit_split.hip): every DWORD of the scratch
+    // holds kCplEmpty until its value arrives; the owner sweeps its slots with sc1 loads until no dword is empty, puts
+    // kCplEmpty back (the scratch is in its initial state again when the launch ends: no memset node, replays from a hipGraph)
+    // and sums the NSPLIT partial rows in exactly the order of affine_stage_raw (a pairwise tree over the split index).
+    // Partners are adjacent in dispatch order (z is the fast index of the 1-D grid), groups complete in order: a partly
+    // resident grid finishes group by group.  Spins are bounded; a time-out is counted in word 0 of the scratch.
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(e.xchg, 0, e.xchg_bytes, 0x00020000);
+    // Barriers of this tail order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for the
+    // write-through stores of the hand-off to be acknowledged by the memory side (~1 us each time).
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    lds_barrier();                   // the ring and the input buffers are dead
+    {
+      unsigned char* st = smem + kq * BM * EP + (mh * MREP * 16 + (lane & 15)) * EP + (lane >> 4) * 16;
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(st + i * 16 * EP + j * 64) = acc[i][j];
+    }
+    lds_barrier();
+    f32x4 mine = f32x4{0.f, 0.f, 0.f, 0.f}; int mine_off = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = tid + NTHR * k, row = c >> 4, cq = c & 15;
+      const unsigned char* s0 = smem + row * EP + cq * 16;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(s0), v1 = *reinterpret_cast<const f32x4*>(s0 + BM * EP),
+                  v2 = *reinterpret_cast<const f32x4*>(s0 + 2 * BM * EP), v3 = *reinterpret_cast<const f32x4*>(s0 + 3 * BM * EP);
+      const f32x4 v = (v0 + v2) + (v1 + v3);              // the order of the hand-over rounds of the unfused kernel
+      const int o = row / RPO, r = row - o * RPO;
+      if (o == z) { mine = v; mine_off = r * 256 + cq * 16; }
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x,
+                                                  kCplHeader + (((tile * NOWN + o) * NSPLIT + z) * RPO + r) * 256 + cq * 16, 0, 16);
+    }
+    S8_STAMP(4);
+    if (!owner) return;              // (uniform) this workgroup owns no rows
+    // LDS from here on: own [RPO][64] | bsum [4][RPO][64] | raw_s [RPO][64] | an_tile [NSL][16][ld] | red [8]
+    float* own = reinterpret_cast<float*>(smem);
+    float* bsum = own + RPO * 64;
+    float* raw_s = bsum + 4 * RPO * 64;
+    float* an_tile = raw_s + RPO * 64;
+    float* red = an_tile + NSL * 16 * e.ld;
+    constexpr int NCH = RPO * 16 / 128, NP = NSPLIT / 4;
+    const int gq = tid >> 7, tl = tid & 127;
+    u32x4 rv[NCH][NP]; int ro[NCH][NP];
+    {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+          const int snd = gq + 4 * m;
+          ro[ch][m] = snd == z ? -1 : kCplHeader + ((tile * NOWN + z) * NSPLIT + snd) * SLOT + (tl + 128 * ch) * 16;
+          // (no branch around the load: every request goes out back to back; this workgroup's own slot reads the header)
+          rv[ch][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ro[ch][m] >= 0 ? ro[ch][m] : 0, 0, 16);
+        }
+      lds_barrier();                 // every read of the parked tiles is done
+      if (mine_off >= 0) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(own) + mine_off) = mine;
+      S8_STAMP(7);
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+          for (int m = 0; m < NP; ++m)
+            ok = ok && (ro[ch][m] < 0 || (rv[ch][m][0] != kCplEmpty && rv[ch][m][1] != kCplEmpty && rv[ch][m][2] != kCplEmpty && rv[ch][m][3] != kCplEmpty));
+        if (ok) break;
+        if (++spins >= kCplSpinMax) { atomicAdd(reinterpret_cast<unsigned*>(e.xchg), 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+          for (int m = 0; m < NP; ++m)
+            if (ro[ch][m] >= 0 && (rv[ch][m][0] == kCplEmpty || rv[ch][m][1] == kCplEmpty || rv[ch][m][2] == kCplEmpty || rv[ch][m][3] == kCplEmpty))
+              rv[ch][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ro[ch][m], 0, 16);
+      }
+      S8_STAMP(5);
+      lds_barrier();                 // own rows are in LDS
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        // affine_stage_raw's tree over 32 split slots (absent splits are zeros): v[u] += v[u + w] for w = 16, 8, 4, 2, 1
+        f32x4 v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          v[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (m < NP) v[m] = (gq + 4 * m) == z ? *reinterpret_cast<const f32x4*>(own + (tl + 128 * ch) * 4) : __builtin_bit_cast(f32x4, rv[ch][m < NP ? m : 0]);
+        }
+        const f32x4 a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
+        const f32x4 b = (a0 + a2) + (a1 + a3);
+        *reinterpret_cast<f32x4*>(bsum + gq * RPO * 64 + (tl + 128 * ch) * 4) = b;
+      }
+      lds_barrier();
+      S8_STAMP(8);
+      if (tid < RPO * 16) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsum + tid * 4), b1 = *reinterpret_cast<const f32x4*>(bsum + RPO * 64 + tid * 4),
+                    b2 = *reinterpret_cast<const f32x4*>(bsum + 2 * RPO * 64 + tid * 4), b3 = *reinterpret_cast<const f32x4*>(bsum + 3 * RPO * 64 + tid * 4);
+        f32x4 t = (b0 + b2) + (b1 + b3);
+        if (e.bias) {
+          const int j = (tid & 15) * 4;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (j + q < 2 * e.Cp) t[q] += pre_bias[q];
+        }
+        *reinterpret_cast<f32x4*>(raw_s + tid * 4) = t;
+      }
+      lds_barrier();
+    }
+    S8_STAMP(6);
+    // the scratch goes back to its initial state (nothing waits for these stores; they drain under the coupling's arithmetic)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int m = 0; m < NP; ++m)
+        if (ro[ch][m] >= 0)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{kCplEmpty, kCplEmpty, kCplEmpty, kCplEmpty}, rs_x, ro[ch][m], 0, 16);
+    // the coupling on this owner's slices: the bodies of affine_fwd_kernel / affine_actnorm_fwd_kernel / affine_inv_kernel
+    // (elementwise.hip) -- same element -> (row, channel) map and the same order of every sum as their 256-thread blocks:
+    // bit-identical outputs.  The inputs (pre_c / pre_t) and the ActNorm parameters of this thread's column were requested
+    // before the K loop.
+    {
+      const int sl = NSL == 1 ? 0 : hf;                        // this thread's slice
+      const float* rs = raw_s + sl * 16 * 64;
+      float* tl_an = an_tile + sl * 16 * ld;
+      float* lx = red + 8;                                     // [256]: the second element's log-scale (one slice per owner)
+      if (valid) {      // untouched channels
+        const int total = 16 * ld;
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+          const int i = t256 + (NC * u0 + u) * 256;
+          int pp, col; div_ld(i, pp, col);
+          if (i < total && !is_transformed(col)) {
+            if (with_an) tl_an[i] = pre_c[u];
+            if (e.out) e.out[row0 * ld + i] = pre_c[u];
+          }
+        }
+        for (int i = t256 + 4 * 256 + u0 * 256; i < total; i += 256 * (NSL == 1 ? 2 : 1)) {          // (states wider than 64 columns)
+          int pp, col; div_ld(i, pp, col);
+          if (!is_transformed(col)) {
+            const float v = e.in[row0 * ld + i];
+            if (with_an) tl_an[i] = v;
+            if (e.out) e.out[row0 * ld + i] = v;
+          }
+        }
+      }
+      S8_STAMP(9);
+      float ld_acc = 0.f;
+      if (valid) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int el = t256 + (u0 + u) * 256;
+          if (el < 16 * Cp) {
+            int pp, i; div_cp(el, pp, i);
+            const float mu = rs[pp * 64 + i];
+            const float sc = tanhf(0.5f * rs[pp * 64 + Cp + i]) + 1.f;
+            const int col = e.t_off + i * e.t_stride;
+            const long off = (row0 + pp) * ld + col;
+            float y;
+            if (e.mode == 2) y = (pre_t[u] - mu) / (sc + 1e-12f);      // macow_utils.py:64
+            else y = sc * pre_t[u] + mu;
+            if (with_an) tl_an[pp * ld + col] = y;
+            if (e.out) e.out[off] = y;
+            if (e.ext) {
+              if (e.ext_bf16) reinterpret_cast<bf16_t*>(e.ext)[(row0 + pp) * e.ext_ld + i] = ET<bf16_t>::from_f32(y);
+              else reinterpret_cast<float*>(e.ext)[(row0 + pp) * e.ext_ld + i] = y;
+            }
+            if (e.scale_out) e.scale_out[(row0 + pp) * Cp + i] = sc;
+            ld_acc += logf(sc);
+          }
+        }
+        if (e.ext && e.ext_ld > Cp) {
+          const int pad = e.ext_ld - Cp;
+          for (int el = NSL == 1 ? tid : t256; el < 16 * pad; el += NSL == 1 ? 512 : 256) {
+            const int pp = el / pad, i = Cp + (el - pp * pad);
+            if (e.ext_bf16) reinterpret_cast<bf16_t*>(e.ext)[(row0 + pp) * e.ext_ld + i] = ET<bf16_t>::from_f32(0.f);
+            else reinterpret_cast<float*>(e.ext)[(row0 + pp) * e.ext_ld + i] = 0.f;
+          }
+        }
+      }
+      S8_STAMP(10);
+      if (e.mode != 2) {             // per-slice log-det: block_sum of a 256-thread block
+        if constexpr (NSL == 1) {    // thread t256 of the block summed its first, then its second element
+          if (hf == 1) lx[t256] = ld_acc;
+          lds_barrier();
+          if (hf == 0) ld_acc += lx[t256];
+        }
+        const float ws = wave_sum(ld_acc);
+        lds_barrier();
+        if (lane == 0) red[wave] = ws;
+        lds_barrier();
+        float tot = 0.f;
+        for (int i = 0; i < 4; ++i) tot += red[sl * 4 + i];
+        if (valid && t256 == 0 && (NSL > 1 || hf == 0) && e.logdet_slot)
+          e.logdet_slot[(long)(row0 >> 6) * e.slot_stride + ((int)(row0 >> 4) & 3)] = tot;
+      }
+      S8_STAMP(11);
+      if (with_an && valid) {        // ActNorm (+ shuffle) of the slice's rows: out2
+        for (int el = NSL == 1 ? tid : t256; el < 16 * ld; el += NSL == 1 ? 512 : 256) {
+          int pp, col; div_ld(el, pp, col);
+          const int j = col - e.an_c0;
+          float v;
+          if (j >= 0 && j < e.an_C) {
+            if (col_fixed) {
+              v = tl_an[pp * ld + e.an_c0 + an_src];
+              if (e.an_ls) v = v * an_e + an_b;
+            } else {
+              const int src = e.an_idx ? e.an_idx[j] : j;
+              v = tl_an[pp * ld + e.an_c0 + src];
+              if (e.an_ls) v = v * expf(e.an_ls[src]) + e.an_bias[src];
+            }
+          } else {
+            v = tl_an[el];
+          }
+          e.out2[(row0 + pp) * ld + col] = v;
+        }
+      }
+    }
+  }
+  S8_STAMP(3);
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s8_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
+  CouplingEpi none{};
+  conv3x3_s8_body<0>(p, none, blockIdx.x, blockIdx.y);
+}
+template <int NSPLIT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s8_coupling_kernel(const NtParams p, const CouplingEpi e) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)(sizeof(NtParams) + sizeof(CouplingEpi))>();
+  conv3x3_s8_body<NSPLIT>(p, e, blockIdx.x / NSPLIT, blockIdx.x % NSPLIT);
 }
 
 // =============================================================================================
@@ -2181,9 +2505,93 @@ extern "C" int ipoke_conv3x3_skinny_splitk(int M, int Kc, int dtype) {
   return conv3x3_s8_splits(M, Kc, ts);
 }
 
+static thread_local int g_last_kernel = IPOKE_KERNEL_NONE;     // (see ipoke_last_conv_kernel)
+static long long* g_gemm_stamps = nullptr;                          // probe builds (ipoke_gemm_set_stamps)
+static int conv_params(NtParams& p, const ipoke_conv_desc* d, int dtype);
+
+// K splits of the fused conv3 + coupling launch: the largest power of two (4 .. 32) that keeps tiles x splits within one round of
+// the 256 CUs (the owners of a tile's rows wait for their partners: a group must be resident as a whole)
+static int coupling_splits(int M, int Kc) {
+  const int tiles = ceil_div(M, 128), nchunks = Kc / 64;
+  int want = 256 / tiles; if (want > nchunks) want = nchunks; if (want > 32) want = 32;
+  int ns = 0;
+  for (int c = 4; c <= want; c *= 2) ns = c;
+  return ns;
+}
+extern "C" int ipoke_conv3x3_coupling_splitk(int M, int Kc, int dtype) {
+  static const int on = getenv("IPOKE_COUPLING_FUSE") ? atoi(getenv("IPOKE_COUPLING_FUSE")) : 1;
+  if (!on || dtype != IPOKE_BF16 || s8_samples_per_tile() <= 0 || Kc % 64 != 0 || Kc < 256 || M % 64 != 0 || M < 64) return 0;
+  return coupling_splits(M, Kc);
+}
+extern "C" int64_t ipoke_conv3x3_coupling_xchg_bytes(void) { return kCplHeader + 256L * 128 * 256; }     // tiles x splits <= 256 slots of 128 rows x 64 floats
+extern "C" int ipoke_conv3x3_coupling_xchg_init(void* xchg, void* stream) {
+  IPK_REQUIRE(xchg != nullptr, "null scratch");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  IPK_HIP(hipMemsetAsync(xchg, 0xff, (size_t)ipoke_conv3x3_coupling_xchg_bytes(), s));
+  IPK_HIP(hipMemsetAsync(xchg, 0, kCplHeader, s));
+  return IPOKE_OK;
+}
+template <int NSPLIT>
+static int launch_conv3x3_s8_coupling(NtParams& p, const CouplingEpi& e, hipStream_t s) {
+  const size_t lds = kLdsS8;
+  auto kern = conv3x3_s8_coupling_kernel<NSPLIT>;
+  IPK_SET_LDS_ONCE(kern, lds);
+  p.tiles_m = ceil_div(p.g.M, 128); p.tiles_n = 1; p.xa = p.xb = 0; p.splitk = NSPLIT;
+  p.kb_per_split = ceil_div(p.Kc / 64, NSPLIT);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * NSPLIT)), dim3(512), lds, s, p, e);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+extern "C" int ipoke_conv3x3_coupling(const ipoke_conv_desc* conv, const ipoke_affine_desc* a, const ipoke_coupling_epi* ep, int B,
+                                      int dtype, void* stream) {
+  IPK_REQUIRE(conv && a && ep, "null descriptor");
+  IPK_REQUIRE(dtype == IPOKE_BF16, "the fused conv3 + coupling launch is bf16 only");
+  IPK_REQUIRE(ep->xchg != nullptr && ((uintptr_t)ep->xchg & 15) == 0, "exchange scratch missing (ipoke_conv3x3_coupling_xchg_bytes / _init)");
+  ipoke_conv_desc d = *conv;
+  d.C = ep->xchg; d.c_f32 = 1; d.ldc = 64; d.splitk = 1; d.c_accumulate = 0;       // (no partial-sum slabs: validation only)
+  NtParams p;
+  int rc = conv_params(p, &d, dtype); if (rc) return rc;
+  IPK_REQUIRE(!d.bias && d.act == IPOKE_ACT_NONE && !d.dact && !d.row_scale && !d.w_kmajor, "conv3 of a coupling: raw sums only (the bias is the coupling's)");
+  IPK_REQUIRE(s8_applicable(p) && p.g.M == 64 * B && !p.g.transposed, "not the skinny 3x3 convolution of a coupling net on 8x8 maps");
+  IPK_REQUIRE(a->Cp >= 1 && 2 * a->Cp == d.Nout && a->t_stride >= 1 && a->P == 64 && a->ld >= 1 && a->ld <= 256 &&
+              a->t_off >= 0 && a->t_off + (a->Cp - 1) * a->t_stride < a->ld, "bad coupling geometry");
+  IPK_REQUIRE(ep->mode >= 0 && ep->mode <= 2 && ep->in, "bad mode / null input state");
+  IPK_REQUIRE(ep->mode == 1 ? (ep->out2 && ep->out2 != ep->in && ep->an_C >= 1 && ep->an_c0 >= 0 && ep->an_c0 + ep->an_C <= a->ld &&
+                               (ep->an_log_scale == nullptr) == (ep->an_bias == nullptr) && !ep->ext)
+                            : (ep->out != nullptr), "bad outputs");
+  IPK_REQUIRE(!ep->logdet_slot || ep->slot_stride >= 4, "log-det slots are 4 wide (one per 16-row slice of a sample)");
+  IPK_REQUIRE(!ep->ext || ep->ext_ld >= a->Cp, "bad extra operand output");
+  const int ns = coupling_splits(p.g.M, p.Kc);
+  IPK_REQUIRE(ns >= 4, "too many row tiles for an in-launch exchange (ipoke_conv3x3_coupling_splitk == 0)");
+  CouplingEpi e{};
+  e.bias = a->bias; e.in = ep->in; e.out = ep->out; e.out2 = ep->mode == 1 ? ep->out2 : nullptr;
+  e.scale_out = ep->mode == 2 ? nullptr : ep->scale_out; e.logdet_slot = ep->mode == 2 ? nullptr : ep->logdet_slot;
+  e.an_ls = ep->an_log_scale; e.an_bias = ep->an_bias; e.an_idx = ep->an_idx; e.ext = ep->ext; e.xchg = ep->xchg;
+  e.xchg_bytes = (int)ipoke_conv3x3_coupling_xchg_bytes(); e.slot_stride = ep->slot_stride < 1 ? 1 : ep->slot_stride;
+  e.Cp = a->Cp; e.t_off = a->t_off; e.t_stride = a->t_stride; e.ld = a->ld; e.mode = ep->mode; e.an_c0 = ep->an_c0; e.an_C = ep->an_C;
+  e.ext_ld = ep->ext_ld; e.ext_bf16 = 1;
+  auto log2_or = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
+  e.ld_sh = log2_or(a->ld); e.cp_sh = log2_or(a->Cp); e.ts_sh = log2_or(a->t_stride);
+  {
+    static const int prio = getenv("IPOKE_NT_PRIO") ? atoi(getenv("IPOKE_NT_PRIO")) : 2;
+    p.prio = prio;
+  }
+#ifdef IPOKE_GEMM_STAMPS
+  p.stamps = g_gemm_stamps;
+  if (g_gemm_stamps) g_gemm_stamps += 16 * 4096;               // one slab of 4096 workgroups x 16 stamps per fused launch
+#endif
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  g_last_kernel = IPOKE_KERNEL_S8;
+  switch (ns) {
+    case 4: return launch_conv3x3_s8_coupling<4>(p, e, s);
+    case 8: return launch_conv3x3_s8_coupling<8>(p, e, s);
+    case 16: return launch_conv3x3_s8_coupling<16>(p, e, s);
+    default: return launch_conv3x3_s8_coupling<32>(p, e, s);
+  }
+}
+
 // kernel family the calling thread's last ipoke_conv_forward was dispatched to (ipoke_last_conv_kernel: the parity tests assert that
 // the benchmarked sizes reach the kernel they mean to check under the DEFAULT dispatch rule)
-static thread_local int g_last_kernel = IPOKE_KERNEL_NONE;
 
 template <typename T>
 static int dispatch_nt(NtParams& p, hipStream_t s) {
@@ -2823,7 +3231,6 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
 using namespace ipoke;
 
 #ifdef IPOKE_GEMM_STAMPS
-static long long* g_gemm_stamps = nullptr;
 extern "C" void ipoke_gemm_set_stamps(long long* base) { g_gemm_stamps = base; }
 #endif
 
@@ -2839,11 +3246,12 @@ extern "C" int ipoke_set_dispatch_override(const char* name, int value) {
 
 extern "C" int ipoke_last_conv_kernel(void) { return g_last_kernel; }
 
-extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream) {
+namespace ipoke {
+// descriptor -> kernel parameters (validation shared by ipoke_conv_forward and ipoke_conv3x3_coupling)
+static int conv_params(NtParams& p, const ipoke_conv_desc* d, int dtype) {
   IPK_REQUIRE(d != nullptr, "null descriptor");
   IPK_REQUIRE(dtype == IPOKE_F32 || dtype == IPOKE_BF16, "bad dtype");
   const int esz = dtype == IPOKE_BF16 ? 2 : 4, e16 = 16 / esz;
-  NtParams p;
   int rc = make_geom(p.g, d->NB, d->Di, d->Hi, d->Wi, d->Do, d->Ho, d->Wo, d->kd, d->kh, d->kw, d->sd, d->sh, d->sw,
                      d->pd, d->ph, d->pw, d->transposed);
   if (rc) return rc;
@@ -2881,6 +3289,14 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   } else if (!d->c_f32) {
     IPK_REQUIRE(p.c_cstride == 1 && !d->c_accumulate, "dtype outputs are dense, non-accumulating");
   }
+  return IPOKE_OK;
+}
+}  // namespace ipoke
+
+extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream) {
+  NtParams p;
+  int rc = conv_params(p, d, dtype); if (rc) return rc;
+  const int esz = dtype == IPOKE_BF16 ? 2 : 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   {
     // s_setprio(2) in the chain's GEMMs: their waves win the issue arbitration against the co-resident weight-gradient /
