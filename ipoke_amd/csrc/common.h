@@ -125,6 +125,24 @@ __device__ __forceinline__ void kernarg_prefetch() {
       : "memory");
 }
 
+// ---- division by a kernel argument --------------------------------------------------------------------------------------------
+// x / d and x % d for a launch-uniform divisor: a shift / mask when d is a power of two (the state widths, channel counts and strides
+// of the shipped flows are), the compiler's ~25-instruction division sequence otherwise.  The test on `sh` is scalar; the element-wise
+// kernels of the chain spent 1-3 us per launch on index arithmetic before this.  Dividends are non-negative.
+#ifndef IPK_FDIV
+#define IPK_FDIV 1      // 0: always divide (developer A/B)
+#endif
+struct FDiv {
+  int d, sh;
+  __device__ __forceinline__ explicit FDiv(int d_) : d(d_), sh(IPK_FDIV && d_ > 0 && (d_ & (d_ - 1)) == 0 ? __builtin_ctz((unsigned)d_) : -1) {}
+  __device__ __forceinline__ int div(int x) const { return sh >= 0 ? x >> sh : x / d; }
+  __device__ __forceinline__ int mod(int x) const { return sh >= 0 ? x & (d - 1) : x % d; }
+  __device__ __forceinline__ long div(long x) const { return sh >= 0 ? x >> sh : x / d; }
+  __device__ __forceinline__ int mod(long x) const { return sh >= 0 ? (int)(x & (long)(d - 1)) : (int)(x % d); }
+  // rel >= 0, a multiple of d, and rel / d < n  (the "is column rel one of the n strided channels" test)
+  __device__ __forceinline__ bool strided_hit(int rel, int n) const { return rel >= 0 && mod(rel) == 0 && div(rel) < n; }
+};
+
 // ---- reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -17,8 +17,9 @@ __global__ void nchw_to_state_kernel(const float* __restrict__ x, float* __restr
   const int b = blockIdx.x;
   const float* xb = x + (long)b * C * P;
   float* sb = s + (long)b * P * ld;
+  const FDiv fP(P);
   for (int i = threadIdx.x; i < C * P; i += blockDim.x) {
-    const int c = i / P, p = i - c * P;        // read coalesced along p
+    const int c = fP.div(i), p = i - c * P;        // read coalesced along p
     sb[(long)p * ld + c] = xb[i];
   }
 }
@@ -26,8 +27,9 @@ __global__ void state_to_nchw_kernel(const float* __restrict__ s, float* __restr
   const int b = blockIdx.x;
   float* xb = x + (long)b * C * P;
   const float* sb = s + (long)b * P * ld;
+  const FDiv fP(P);
   for (int i = threadIdx.x; i < C * P; i += blockDim.x) {
-    const int c = i / P, p = i - c * P;
+    const int c = fP.div(i), p = i - c * P;
     xb[i] = sb[(long)p * ld + c];
   }
 }
@@ -38,8 +40,9 @@ __global__ void cond_prepare_kernel(const float* __restrict__ h, T* __restrict__
   const int b = blockIdx.x;
   const float* hb = h + (long)b * Cc * P;
   T* ob = out + (long)b * P * Cc;
+  const FDiv fP(P);
   for (int i = threadIdx.x; i < Cc * P; i += blockDim.x) {
-    const int c = i / P, p = i - c * P;
+    const int c = fP.div(i), p = i - c * P;
     ob[(long)p * Cc + c] = ET<T>::from_f32(act_apply(act, hb[i]));
   }
 }
@@ -51,8 +54,9 @@ __global__ void extract_cols_kernel(const float* __restrict__ s, int ld, int off
                                     long M) {
   if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   const long total = M * ldo;
+  const FDiv fldo(ldo);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / ldo; const int j = (int)(i - m * ldo);
+    const long m = fldo.div(i); const int j = (int)(i - m * ldo);
     out[i] = ET<T>::from_f32(j < C ? s[m * ld + off + (long)j * stride] : 0.f);
   }
 }
@@ -62,8 +66,9 @@ __global__ void extract_cols_kernel(const float* __restrict__ s, int ld, int off
 __global__ void copy_cols16_kernel(const u32x4* __restrict__ src, long lds16, u32x4* __restrict__ dst, long ldd16, int c16, long M) {
   if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   const long total = M * c16;
+  const FDiv fc16(c16);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / c16; const int j = (int)(i - m * c16);
+    const long m = fc16.div(i); const int j = (int)(i - m * c16);
     dst[m * ldd16 + j] = src[m * lds16 + j];
   }
 }
@@ -76,9 +81,10 @@ __global__ void actnorm_fwd_kernel(const float* __restrict__ in, float* __restri
                                    const int* __restrict__ idx) {
   if (IPK_CHAIN_PRIO) __builtin_amdgcn_s_setprio(2);
   const long total = (long)M * ld;
+  const FDiv fld(ld);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int col = (int)(i % ld);
-    const long row = i / ld;
+    const int col = fld.mod(i);
+    const long row = fld.div(i);
     const int j = col - c0;
     float v;
     if (j >= 0 && j < C) {
@@ -96,9 +102,10 @@ __global__ void actnorm_inv_kernel(const float* __restrict__ in, float* __restri
                                    const float* __restrict__ ls, const float* __restrict__ bias,
                                    const int* __restrict__ inv_idx) {
   const long total = (long)M * ld;
+  const FDiv fld(ld);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int col = (int)(i % ld);
-    const long row = i / ld;
+    const int col = fld.mod(i);
+    const long row = fld.div(i);
     const int c = col - c0;
     float v;
     if (c >= 0 && c < C) {
@@ -120,9 +127,10 @@ __global__ void actnorm_inv_ext_kernel(const float* __restrict__ in, float* __re
                                        int e_C) {
   const long total = (long)M * ld;
   const int pad = ext_ld - e_C;
+  const FDiv fld(ld), fes(e_stride);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int col = (int)(i % ld);
-    const long row = i / ld;
+    const int col = fld.mod(i);
+    const long row = fld.div(i);
     const int c = col - c0;
     float v;
     if (c >= 0 && c < C) {
@@ -134,7 +142,7 @@ __global__ void actnorm_inv_ext_kernel(const float* __restrict__ in, float* __re
     }
     out[i] = v;
     const int rel = col - e_off;
-    if (rel >= 0 && rel % e_stride == 0 && rel / e_stride < e_C) ext[row * ext_ld + rel / e_stride] = ET<T>::from_f32(v);
+    if (fes.strided_hit(rel, e_C)) ext[row * ext_ld + fes.div(rel)] = ET<T>::from_f32(v);
     if (col < pad) ext[row * ext_ld + e_C + col] = ET<T>::from_f32(0.f);
   }
 }
@@ -150,15 +158,16 @@ __global__ __launch_bounds__(1024) void actnorm_bwd_kernel(const float* __restri
   extern __shared__ float sm[];   // [2][rows_par][C]
   const int tid = threadIdx.x, b = blockIdx.x;
   const long row0 = (long)b * P;
-  const int rows_par = blockDim.x / C;      // host guarantees >= 1
-  const int j = tid % C, r0 = tid / C;
+  const FDiv fC(C), fld(ld);
+  const int rows_par = fC.div((int)blockDim.x);      // host guarantees >= 1
+  const int j = fC.mod(tid), r0 = fC.div(tid);
   // pass-through columns first (independent of everything else), four elements per thread in flight
   for (int i0 = tid; i0 < P * ld; i0 += 4 * blockDim.x) {
     float v[4]; bool w[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * blockDim.x;
-      const int col = i % ld;
+      const int col = fld.mod(i);
       w[u] = i < P * ld && (col < c0 || col >= c0 + C);
       if (w[u]) v[u] = dy[row0 * ld + i];
     }
@@ -239,8 +248,9 @@ constexpr int kAffPre = 2;      // transformed elements per thread requested ahe
 // sum the split-K partials (+bias) of `rows` positions starting at row0 into LDS: raw_s[p][0:2Cp]
 __device__ __forceinline__ void affine_stage_raw(const AffineArgs& a, long row0, int rows, float* raw_s) {
   const int n2 = 2 * a.Cp;
+  const FDiv fn2(n2);
   for (int e = threadIdx.x; e < rows * n2; e += blockDim.x) {
-    const int p = e / n2, j = e - p * n2;
+    const int p = fn2.div(e), j = e - p * n2;
     const float* r = a.raw + (row0 + p) * a.ldraw + j;
     // every split's partial is requested at once (nsplit <= 32): one memory latency instead of nsplit / 8
     float v[32];
@@ -261,14 +271,14 @@ __device__ __forceinline__ void affine_stage_raw(const AffineArgs& a, long row0,
 __device__ __forceinline__ void affine_copy_rest(const AffineArgs& a, long row0, int rows, const float* __restrict__ in,
                                                  float* __restrict__ out) {
   const int total = rows * a.ld;
+  const FDiv fld(a.ld), fts(a.t_stride);
   for (int i0 = threadIdx.x; i0 < total; i0 += 4 * blockDim.x) {
     float v[4]; bool w[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * blockDim.x;
-      const int col = i % a.ld;
-      const int rel = col - a.t_off;
-      const bool transformed = rel >= 0 && rel % a.t_stride == 0 && rel / a.t_stride < a.Cp;
+      const int col = fld.mod(i);
+      const bool transformed = fts.strided_hit(col - a.t_off, a.Cp);
       w[u] = i < total && !transformed;
       if (w[u]) v[u] = in[row0 * a.ld + i];
     }
@@ -301,6 +311,7 @@ __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, fl
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int rows = a.P / Q;
   const long row0 = (long)b * a.P + (long)q * rows;
+  const FDiv fCp(a.Cp);
   // the transformed channels' inputs are requested BEFORE the split-K partials are staged (they used to be loaded behind the staging
   // barrier: one more dependent memory round trip in a kernel that is nothing but such round trips)
   float xin[kAffPre];
@@ -308,13 +319,13 @@ __global__ void affine_fwd_kernel(AffineArgs a, const float* __restrict__ in, fl
   for (int u = 0; u < kAffPre; ++u) {
     const int e = threadIdx.x + u * blockDim.x;
     xin[u] = 0.f;
-    if (e < rows * a.Cp) { const int p = e / a.Cp, i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
+    if (e < rows * a.Cp) { const int p = fCp.div(e), i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
   }
   affine_copy_rest(a, row0, rows, in, out);
   affine_stage_raw(a, row0, rows, raw_s);
   float ld_acc = 0.f;
   for (int e = threadIdx.x, u = 0; e < rows * a.Cp; e += blockDim.x, ++u) {
-    const int p = e / a.Cp, i = e - p * a.Cp;
+    const int p = fCp.div(e), i = e - p * a.Cp;
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
@@ -334,17 +345,18 @@ __global__ void affine_inv_kernel(AffineArgs a, const float* __restrict__ in, fl
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int rows = a.P / Q;
   const long row0 = (long)b * a.P + (long)q * rows;
+  const FDiv fCp(a.Cp);
   float xin[kAffPre];                      // (requested before the staging of the partials: see affine_fwd_kernel)
 #pragma unroll
   for (int u = 0; u < kAffPre; ++u) {
     const int e = threadIdx.x + u * blockDim.x;
     xin[u] = 0.f;
-    if (e < rows * a.Cp) { const int p = e / a.Cp, i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
+    if (e < rows * a.Cp) { const int p = fCp.div(e), i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
   }
   affine_copy_rest(a, row0, rows, in, out);
   affine_stage_raw(a, row0, rows, raw_s);
   for (int e = threadIdx.x, u = 0; e < rows * a.Cp; e += blockDim.x, ++u) {
-    const int p = e / a.Cp, i = e - p * a.Cp;
+    const int p = fCp.div(e), i = e - p * a.Cp;
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const long off = (row0 + p) * a.ld + a.t_off + (long)i * a.t_stride;
@@ -372,8 +384,9 @@ __global__ __launch_bounds__(1024) void affine_bwd_kernel(int Cp, int t_off, int
   extern __shared__ float sm[];      // [rows_par][2*Cp] partial column sums
   const int b = blockIdx.x, tid = threadIdx.x;
   const long row0 = (long)b * P;
-  const int rows_par = blockDim.x / Cp;                 // host guarantees Cp <= blockDim.x
-  const int i = tid % Cp, r0 = tid / Cp;
+  const FDiv fCp(Cp), fld(ld), fts(t_stride);
+  const int rows_par = fCp.div((int)blockDim.x);        // host guarantees Cp <= blockDim.x
+  const int i = fCp.mod(tid), r0 = fCp.div(tid);
   const float g_ld = dld[b];
   // this thread's elements first (their loads head the queue), then the untouched channels
   float g[4], sc[4], xv[4];
@@ -411,9 +424,8 @@ __global__ __launch_bounds__(1024) void affine_bwd_kernel(int Cp, int t_off, int
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int e = i0 + u * blockDim.x;
-        const int col = e % ld;
-        const int rel = col - t_off;
-        const bool transformed = rel >= 0 && rel % t_stride == 0 && rel / t_stride < Cp;
+        const int col = fld.mod(e);
+        const bool transformed = fts.strided_hit(col - t_off, Cp);
         w[u] = e < total && !transformed;
         if (w[u]) v[u] = dy[row0 * ld + e];
       }
@@ -423,8 +435,9 @@ __global__ __launch_bounds__(1024) void affine_bwd_kernel(int Cp, int t_off, int
   }
   {   // K padding of dparams (read by the conv3 data-gradient and weight-gradient GEMMs)
     const int pad = ldp - 2 * Cp;
+    const FDiv fpad(pad);
     for (int e = tid; e < P * pad; e += blockDim.x) {
-      const int p = e / pad, j = 2 * Cp + (e - p * pad);
+      const int p = fpad.div(e), j = 2 * Cp + (e - p * pad);
       dparams[(row0 + p) * ldp + j] = ET<T>::from_f32(0.f);
     }
   }
@@ -452,6 +465,7 @@ __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const flo
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int rows = a.P / Q;
   const long row0 = (long)b * a.P + (long)q * rows;
+  const FDiv fCp(a.Cp);
   float* tile = raw_s + rows * 2 * a.Cp;
   // requested ahead of everything that waits: the transformed channels' inputs and -- when a thread keeps its column over the rows it
   // writes (blockDim a multiple of ld) -- the ActNorm parameters of that column (index, then scale / bias: two dependent loads that
@@ -461,12 +475,13 @@ __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const flo
   for (int u = 0; u < kAffPre; ++u) {
     const int e = threadIdx.x + u * blockDim.x;
     xin[u] = 0.f;
-    if (e < rows * a.Cp) { const int p = e / a.Cp, i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
+    if (e < rows * a.Cp) { const int p = fCp.div(e), i = e - p * a.Cp; xin[u] = in[(row0 + p) * a.ld + a.t_off + (long)i * a.t_stride]; }
   }
-  const bool col_fixed = blockDim.x % a.ld == 0;
+  const FDiv fld(a.ld), fts(a.t_stride);
+  const bool col_fixed = fld.mod((int)blockDim.x) == 0;
   int an_src = -1; float an_e = 1.f, an_b = 0.f;
   if (col_fixed) {
-    const int j = (int)(threadIdx.x % a.ld) - n.c0;
+    const int j = fld.mod((int)threadIdx.x) - n.c0;
     if (j >= 0 && j < n.C) {
       an_src = n.idx ? n.idx[j] : j;
       if (n.ls) { an_e = expf(n.ls[an_src]); an_b = n.bias[an_src]; }
@@ -479,9 +494,8 @@ __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const flo
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * blockDim.x;
-        const int col = i % a.ld;
-        const int rel = col - a.t_off;
-        const bool transformed = rel >= 0 && rel % a.t_stride == 0 && rel / a.t_stride < a.Cp;
+        const int col = fld.mod(i);
+        const bool transformed = fts.strided_hit(col - a.t_off, a.Cp);
         w[u] = i < total && !transformed;
         if (w[u]) v[u] = in[row0 * a.ld + i];
       }
@@ -493,7 +507,7 @@ __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const flo
   affine_stage_raw(a, row0, rows, raw_s);
   float ld_acc = 0.f;
   for (int e = threadIdx.x, u = 0; e < rows * a.Cp; e += blockDim.x, ++u) {
-    const int p = e / a.Cp, i = e - p * a.Cp;
+    const int p = fCp.div(e), i = e - p * a.Cp;
     const float mu = raw_s[p * 2 * a.Cp + i];
     const float sc = tanhf(0.5f * raw_s[p * 2 * a.Cp + a.Cp + i]) + 1.f;
     const int col = a.t_off + i * a.t_stride;
@@ -507,7 +521,7 @@ __global__ void affine_actnorm_fwd_kernel(AffineArgs a, ActNormArgs n, const flo
   const float tot = block_sum(ld_acc, red);          // (its barriers also publish the tile)
   if (threadIdx.x == 0 && logdet_slot) logdet_slot[(long)b * slot_stride + q] = tot;
   for (int e = threadIdx.x; e < rows * a.ld; e += blockDim.x) {
-    const int p = e / a.ld, col = e - p * a.ld;
+    const int p = fld.div(e), col = e - p * a.ld;
     const int j = col - n.c0;
     float v;
     if (j >= 0 && j < n.C) {
@@ -547,8 +561,9 @@ __global__ __launch_bounds__(1024) void actnorm_affine_bwd_kernel(ActNormArgs n,
   // ---- phase A: ActNorm (+ shuffle) backward into the LDS tile
   {
     const int C = n.C, c0 = n.c0;
-    const int rows_par = blockDim.x / C;
-    const int j = tid % C, r0 = tid / C;
+    const FDiv fC(C);
+    const int rows_par = fC.div((int)blockDim.x);
+    const int j = fC.mod(tid), r0 = fC.div(tid);
     float a_ls = 0.f, a_b = 0.f;
     if (r0 < rows_par) {
       const int src = n.idx ? n.idx[j] : j;
@@ -577,8 +592,9 @@ __global__ __launch_bounds__(1024) void actnorm_affine_bwd_kernel(ActNormArgs n,
     }
     if (C < ld) {        // columns outside the ActNorm window pass through
       const int rest = ld - C;
+      const FDiv frest(rest);
       for (int e = tid; e < P * rest; e += blockDim.x) {
-        const int m = e / rest, k = e - m * rest;
+        const int m = frest.div(e), k = e - m * rest;
         const int col = k < c0 ? k : k + C;
         g1[m * ld + col] = dy2[(row0 + m) * ld + col];
       }
@@ -595,8 +611,9 @@ __global__ __launch_bounds__(1024) void actnorm_affine_bwd_kernel(ActNormArgs n,
     __syncthreads();                                // ps is reused below
   }
   // ---- phase B: the coupling's backward, its incoming gradient read from the tile
-  const int rows_par = blockDim.x / Cp;
-  const int i = tid % Cp, r0 = tid / Cp;
+  const FDiv fCp(Cp), fld(ld), fts(t_stride);
+  const int rows_par = fCp.div((int)blockDim.x);
+  const int i = fCp.mod(tid), r0 = fCp.div(tid);
   float a_mu = 0.f, a_s = 0.f;
   const bool act = r0 < rows_par;
   for (int m0 = r0; act && m0 < P; m0 += 4 * rows_par) {
@@ -626,15 +643,14 @@ __global__ __launch_bounds__(1024) void actnorm_affine_bwd_kernel(ActNormArgs n,
   }
   if (act) { ps[r0 * 2 * Cp + i] = a_mu; ps[r0 * 2 * Cp + Cp + i] = a_s; }
   for (int e = tid; e < P * ld; e += blockDim.x) {      // untouched channels
-    const int col = e % ld;
-    const int rel = col - t_off;
-    const bool transformed = rel >= 0 && rel % t_stride == 0 && rel / t_stride < Cp;
+    const bool transformed = fts.strided_hit(fld.mod(e) - t_off, Cp);
     if (!transformed) dx[row0 * ld + e] = g1[e];
   }
   {
     const int pad = ldp - 2 * Cp;
+    const FDiv fpad(pad);
     for (int e = tid; e < P * pad; e += blockDim.x) {
-      const int p = e / pad, j = 2 * Cp + (e - p * pad);
+      const int p = fpad.div(e), j = 2 * Cp + (e - p * pad);
       dparams[(row0 + p) * ldp + j] = ET<T>::from_f32(0.f);
     }
   }
