@@ -153,8 +153,9 @@ __device__ __forceinline__ u32x4 load_a_chunk(const void* A, int a_f32, long off
 
 __device__ __forceinline__ void fill_taptab(int* tab, const GeomDev& g) {
   for (int t = threadIdx.x; t < g.taps; t += blockDim.x) {
-    const int td = t / g.khw, rem = t - td * g.khw;
-    const int th = rem / g.kw, tw = rem - th * g.kw;
+    const FDiv fkhw(g.khw), fkw(g.kw);
+    const int td = fkhw.div(t), rem = t - td * g.khw;
+    const int th = fkw.div(rem), tw = rem - th * g.kw;
     tab[t] = td | (th << 8) | (tw << 16);
   }
 }
@@ -392,12 +393,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     const int bid = blockIdx.x;
     if (p.xa > 0) {
       const int xcd = bid & 7, q = bid >> 3;
-      const int sub_m = p.tiles_m / p.xa, sub_n = p.tiles_n / p.xb;
-      (void)sub_n;
-      tm = (xcd % p.xa) * sub_m + q % sub_m;
-      tn = (xcd / p.xa) * sub_n + q / sub_m;
+      const FDiv fxa(p.xa), fxb(p.xb);
+      const int sub_m = fxa.div(p.tiles_m), sub_n = fxb.div(p.tiles_n);
+      const FDiv fsm(sub_m);
+      tm = fxa.mod(xcd) * sub_m + fsm.mod(q);
+      tn = fxa.div(xcd) * sub_n + fsm.div(q);
     } else {
-      tm = bid % p.tiles_m; tn = bid / p.tiles_m;
+      const FDiv ftm(p.tiles_m);
+      tm = ftm.mod(bid); tn = ftm.div(bid);
     }
   }
   const int m0 = tm * BM, n0 = tn * BN;
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     arow[i] = decode_row(g, m0 + row, p.a_sn);
     arow[i].ok = arow[i].ok && in_tile;
     const int kglob = kb_begin * BK + kc * E16;
-    a_tap[i] = kglob / p.Kc;
+    a_tap[i] = FDiv(p.Kc).div(kglob);
     a_c[i] = kglob - a_tap[i] * p.Kc;
     a_lds[i] = in_tile ? row * kPitch + kc * 16 : -1;
   }
@@ -551,11 +554,14 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
     const int bid = blockIdx.x;
     if (p.xa > 0) {
       const int xcd = bid & 7, q = bid >> 3;
-      const int sub_m = p.tiles_m / p.xa, sub_n = p.tiles_n / p.xb;
-      tm = (xcd % p.xa) * sub_m + q % sub_m;
-      tn = (xcd / p.xa) * sub_n + q / sub_m;
+      const FDiv fxa(p.xa), fxb(p.xb);                   // (powers of two: pick_xcd_map)
+      const int sub_m = fxa.div(p.tiles_m), sub_n = fxb.div(p.tiles_n);
+      const FDiv fsm(sub_m);
+      tm = fxa.mod(xcd) * sub_m + fsm.mod(q);
+      tn = fxa.div(xcd) * sub_n + fsm.div(q);
     } else {
-      tm = bid % p.tiles_m; tn = bid / p.tiles_m;
+      const FDiv ftm(p.tiles_m);
+      tm = ftm.mod(bid); tn = ftm.div(bid);
     }
   }
   const int m0 = tm * BM, n0 = tn * BN;
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
     arow[i] = decode_row(g, m0 + row, p.a_sn);
     arow[i].ok = arow[i].ok && a_in[i];
     const int kglob = kb_begin * BK + (pos ^ ((row >> 1) & 7)) * E16;
-    a_tap[i] = kglob / p.Kc;
+    a_tap[i] = FDiv(p.Kc).div(kglob);
     a_c[i] = kglob - a_tap[i] * p.Kc;
   }
   unsigned b_off[B_IT]; int b_k[B_IT]; bool b_in[B_IT];
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
   const T* Abase = reinterpret_cast<const T*>(p.A);
   const T* Wbase = reinterpret_cast<const T*>(p.W);
   const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
-  int c_uni = (kb_begin * BK) % p.Kc;             // SIMPLE: channel offset of the K-block inside its tap (uniform)
+  int c_uni = FDiv(p.Kc).mod(kb_begin * BK);             // SIMPLE: channel offset of the K-block inside its tap (uniform)
   auto issue = [&](int slot_bytes, bool real) {
     unsigned char* sa = smem + slot_bytes;
     if (!real) {                                   // keep the vmcnt bookkeeping uniform past the last K-block
@@ -812,10 +818,10 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
   const int wm = wave >> 1, wn = wave & 1;
   const GeomDev& g = p.g;
   const int tile = (int)blockIdx.x + p.tile0;
-  const int tn = tile % p.tiles_n, tk = tile / p.tiles_n;
+  const int tn = FDiv(p.tiles_n).mod(tile), tk = FDiv(p.tiles_n).div(tile);
   const int n0 = tn * TN_, k0 = tk * TK_;
   const int z = blockIdx.y;
-  const int nmb_total = (g.M + RM - 1) / RM;
+  const int nmb_total = (g.M + RM - 1) / RM;      // (RM: compile-time)
   const int mb_begin = z * p.mb_per_split, mb_end = min(nmb_total, mb_begin + p.mb_per_split);
 
   fill_taptab(taptab, g);
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
 
   // A-operand column bookkeeping (fixed for the whole reduction)
   const int kcol = k0 + cb * E16;
-  const int x_tap = kcol / p.Kc, x_c = kcol - x_tap * p.Kc;
+  const int x_tap = FDiv(p.Kc).div(kcol), x_c = kcol - x_tap * p.Kc;
   const bool x_col_ok = do_x && kcol < p.Ktot;
   const int ncol = n0 + cb * E16;
   const bool y_col_ok = do_y && ncol < ((p.Nout + E16 - 1) / E16) * E16;
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams pin) {
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + wn * 64 + j * 16 + (lane >> 4) * 4;
       if (k >= p.Ktot) continue;
-      const int tap = k / p.Kc, c = k - tap * p.Kc;     // 4 consecutive k share the tap (Kc % 4 == 0)
+      const int tap = FDiv(p.Kc).div(k), c = k - tap * p.Kc;     // 4 consecutive k share the tap (Kc % 4 == 0)
       float* base = p.dW + (long)n * p.w_sn + (long)tap * p.w_st + (p.split_stride > 0 ? (long)z * p.split_stride : 0L);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -2719,11 +2725,14 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nn_glds_kernel(const 
     const int bid = blockIdx.x;
     if (p.xa > 0) {
       const int xcd = bid & 7, q = bid >> 3;
-      const int sub_m = p.tiles_m / p.xa, sub_n = p.tiles_n / p.xb;
-      tm = (xcd % p.xa) * sub_m + q % sub_m;
-      tn = (xcd / p.xa) * sub_n + q / sub_m;
+      const FDiv fxa(p.xa), fxb(p.xb);                   // (powers of two: pick_xcd_map)
+      const int sub_m = fxa.div(p.tiles_m), sub_n = fxb.div(p.tiles_n);
+      const FDiv fsm(sub_m);
+      tm = fxa.mod(xcd) * sub_m + fsm.mod(q);
+      tn = fxa.div(xcd) * sub_n + fsm.div(q);
     } else {
-      tm = bid % p.tiles_m; tn = bid / p.tiles_m;
+      const FDiv ftm(p.tiles_m);
+      tm = ftm.mod(bid); tn = ftm.div(bid);
     }
   }
   const int m0 = tm * BM, n0 = tn * BN;
@@ -2934,16 +2943,19 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     // (tiles_n / xa) x (tiles_k / xb) sub-grid, so that its L2 fetches 1/xa of dY and 1/xb of A instead of (with the plain
     // row-major order and tiles_n = 16) 1/8 of dY and ALL of A -- conv2 shape: 47 -> 31 MB of fabric reads per problem
     const int bid = (int)blockIdx.x, xcd = bid & 7, q = bid >> 3;
-    const int sub_n = p.tiles_n / p.xa, sub_k = p.tiles_k / p.xb;
-    tn = (xcd % p.xa) * sub_n + q % sub_n;
-    tk = (xcd / p.xa) * sub_k + q / sub_n;
+    const FDiv fxa(p.xa), fxb(p.xb);
+    const int sub_n = fxa.div(p.tiles_n), sub_k = fxb.div(p.tiles_k);
+    const FDiv fsn(sub_n);
+    tn = fxa.mod(xcd) * sub_n + fsn.mod(q);
+    tk = fxa.div(xcd) * sub_k + fsn.div(q);
   } else {
     const int tile = (int)blockIdx.x + p.tile0;
-    tn = tile % p.tiles_n; tk = tile / p.tiles_n;
+    const FDiv ftn(p.tiles_n);
+    tn = ftn.mod(tile); tk = ftn.div(tile);
   }
   const int n0 = tn * 128, k0 = tk * 128;
   const int z = blockIdx.y;
-  const int nmb_total = (g.M + RM - 1) / RM;
+  const int nmb_total = (g.M + RM - 1) / RM;      // (RM: compile-time)
   const int mb_begin = z * p.mb_per_split, mb_end = min(nmb_total, mb_begin + p.mb_per_split);
   const int nst = mb_end - mb_begin;
 
@@ -2961,7 +2973,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   const int ncol = n0 + schunk * 8;             // dY column of this lane's chunk
   const bool y_ok = ncol < p.ldy - p.y_coff && ncol < ((p.Nout + 7) & ~7);
   const int kcol = k0 + schunk * 8;             // A (im2col) column of this lane's chunk
-  const int x_tap = kcol / p.Kc, x_c = kcol - x_tap * p.Kc;
+  const int x_tap = FDiv(p.Kc).div(kcol), x_c = kcol - x_tap * p.Kc;
   const bool x_ok = kcol < p.Ktot && x_c < p.Kc_real;
   const int x_tapcode = x_ok ? taptab[x_tap] : 0;
   const int S = g.S;
@@ -3137,7 +3149,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     for (int j = 0; j < 2; ++j) {
       const int k = k0 + wk * 32 + j * 16 + (lane >> 4) * 4;
       if (k >= p.Ktot) continue;
-      const int tap = k / p.Kc, c = k - tap * p.Kc;     // 4 consecutive k share the tap (Kc % 4 == 0)
+      const int tap = FDiv(p.Kc).div(k), c = k - tap * p.Kc;     // 4 consecutive k share the tap (Kc % 4 == 0)
       float* base = p.dW + (long)n * p.w_sn + (long)tap * p.w_st + (p.split_stride > 0 ? (long)z * p.split_stride : 0L);
       if (vec4 && c + 3 < p.Kc_store) {                 // dense rows (1x1 convs): one 16-byte store instead of four
         *reinterpret_cast<f32x4*>(base + c) = acc[i][j];
