@@ -650,6 +650,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
   const long row0 = (long)b0 * 64;
   const int G2 = C >> 1;
   const int rows = nb * 64;
+  const float inv_g2 = 1.f / (float)G2, inv_cch = 1.f / (float)(U.Cc / E16);     // (index arithmetic of the strip loop: no integer-division sequences)
 
   // prologue: small loads first (results return in issue order), then the weights of layer D
   f32x2 yin[8];
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
       {
         const int cchunks = U.Cc / E16;
         for (int e = tl; e < 16 * cchunks; e += kMcfThreads) {
-          const int row = e / cchunks, ch = e - row * cchunks;
+          const int row = (int)(((float)e + 0.5f) * inv_cch), ch = e - row * cchunks;      // e / cchunks, exact for e < 2048, cchunks <= 16
           const int sidx = row >> 3, j = row & 7;
           const int pos = rows_first ? si * 8 + j : j * 8 + si;
           u32x4 v = {0u, 0u, 0u, 0u};
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
       UNIT_STAMP(1 + 6 * step + 5 + (k == 3 ? 0 : 1000));
       // x = (y - mu) / (scale + 1e-12)   (macow_utils.py:61-66); the strip joins the operand tile
       for (int e = tl; e < 16 * G2; e += kMcfThreads) {
-        const int row = e / G2, c = (e - row * G2) * 2;
+        const int row = (int)(((float)e + 0.5f) * inv_g2), c = (e - row * G2) * 2;          // e / G2, exact for e < 2048, G2 <= 32
         const int sidx = row >> 3, j = row & 7;
         if (sidx < nb) {
           const int pos = rows_first ? si * 8 + j : j * 8 + si;
