@@ -1584,8 +1584,7 @@ __device__ __forceinline__ void conv3x3_s8_body(const NtParams& p, const Couplin
           if (hf == 0) ld_acc += lx[t256];
         }
         const float ws = wave_sum(ld_acc);
-        lds_barrier();
-        if (lane == 0) red[wave] = ws;
+        if (lane == 0) red[wave] = ws;           // (red is written here only)
         lds_barrier();
         float tot = 0.f;
         for (int i = 0; i < 4; ++i) tot += red[sl * 4 + i];
