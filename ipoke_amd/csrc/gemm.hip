@@ -1125,16 +1125,20 @@ static constexpr unsigned kCplSpinMax = 1u << 21;
 #else
 #define S8_STAMP(i) do {} while (0)
 #endif
-template <int NSPLIT>
+// NREP = 2: 32 output columns (the conv1 data gradient of a coupling that conditions on <= 32 channels): half the filter ring --
+// 88 KB of LDS instead of 137, which fits beside ONE resident weight-gradient workgroup instead of waiting for a whole CU -- and
+// half the matrix-core work.
+template <int NSPLIT, int NREP = 4>
 __device__ __forceinline__ void conv3x3_s8_body(const NtParams& p, const CouplingEpi& e, const int tile, const int z) {
   typedef bf16_t T;
   typedef typename ET<T>::frag frag_t;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
-  constexpr int BM = 128, BN = 64, NTHR = 512, R = 12;     // ring: three rounds of four filter K-blocks
+  constexpr int BM = 128, BN = 16 * NREP, NTHR = 512, R = 12;     // ring: three rounds of four filter K-blocks
   constexpr int ABUF = BM * 128, WSLOT = BN * 128;
   constexpr int A_IT = BM * 8 / NTHR;                      // DMA instructions per thread and input chunk (2)
-  constexpr int MREP = 4, NREP = 4;
+  constexpr int MREP = 4;
+  constexpr int WJ = BN / 16;                              // filter DMA instructions per wave and round (8 rows each)
   constexpr int EP = BN * 4 + 16;                          // nt_epilogue's staging pitch
   constexpr unsigned kInvalid = 0xffffffffu;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1170,17 +1174,17 @@ __device__ __forceinline__ void conv3x3_s8_body(const NtParams& p, const Couplin
     }
   }
   // filter DMA of a round: wave w brings rows 32*(w >> 2) .. +31 (4 instructions of 8 rows) of K-block 4r + (w & 3)
-  unsigned w_src[4];
+  unsigned w_src[WJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = 32 * (wave >> 2) + 8 * j + (lane >> 3), pos = lane & 7;
+  for (int j = 0; j < WJ; ++j) {
+    const int n = 8 * WJ * (wave >> 2) + 8 * j + (lane >> 3), pos = lane & 7;
     w_src[j] = n < p.Nout ? (unsigned)((long)n * p.ldw + c_begin * 64 + ((pos ^ ((n >> 1) & 7)) * 8)) : kInvalid;
   }
   int wi_g = wave & 3, wi_c = 0, wi_t = wave & 3;          // K-block index / (chunk, tap) of this wave's next filter request
   auto issue_w = [&]() {
     const bool in = wi_g < nkb;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WJ; ++j) {
 #if defined(IPOKE_GEMM_STAMPS) && IPOKE_GEMM_ABL == 3
       continue;
 #endif
@@ -1190,7 +1194,7 @@ __device__ __forceinline__ void conv3x3_s8_body(const NtParams& p, const Couplin
       const bool real = in && w_src[j] != kInvalid;
 #endif
       const T* src = real ? Wbase + w_src[j] + (long)wi_t * p.Kc + wi_c * 64 : zero;
-      unsigned char* dst = in ? ring + (wi_g % R) * WSLOT + (4 * (wave >> 2) + j) * 1024 : dummy + wave * 1024;
+      unsigned char* dst = in ? ring + (wi_g % R) * WSLOT + (WJ * (wave >> 2) + j) * 1024 : dummy + wave * 1024;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
     }
     wi_g += 4; wi_t += 4;
@@ -1307,7 +1311,7 @@ __device__ __forceinline__ void conv3x3_s8_body(const NtParams& p, const Couplin
 
   int gk = kq, ci = 0, t = kq;                             // this wave's K-block of the round: index, chunk, tap
   for (int r = 0; r < nrounds; ++r) {
-    wait_vmcnt<4>();                 // everything but this wave's share of round r + 1 has landed (input chunks included)
+    wait_vmcnt<WJ>();                // everything but this wave's share of round r + 1 has landed (input chunks included)
     __builtin_amdgcn_s_barrier();
     if (r == 0) S8_STAMP(1);
     // the first K-block of this round lies in chunk (4r)/9: request the chunk after it once (its buffer held chunk - 1,
@@ -1343,13 +1347,14 @@ __device__ __forceinline__ void conv3x3_s8_body(const NtParams& p, const Couplin
           for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[hs][i], fb[hs][j], acc[i][j]);
       // issue order: the eight fragments of the first half-step, then the second half-step's reads one per two MFMAs of the first.
       // (hipcc's own schedule reads just in time, four MFMAs per s_waitcnt lgkmcnt(0): eight exposed LDS latencies per K-block.)
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      constexpr int NF = MREP + NREP, NM = MREP * NREP, PER = NM / NF;        // fragment reads / MFMAs per half-step
+      __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      for (int q = 0; q < NF; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - NF * PER, 0);
     }
     gk += 4; t += 4;
     if (t >= 9) { t -= 9; ++ci; }
@@ -1621,6 +1626,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
   CouplingEpi none{};
   conv3x3_s8_body<0>(p, none, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s8n32_kernel(const NtParams p) {      // <= 32 output columns
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
+  CouplingEpi none{};
+  conv3x3_s8_body<0, 2>(p, none, blockIdx.x, blockIdx.y);
 }
 template <int NSPLIT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s8_coupling_kernel(const NtParams p, const CouplingEpi e) {
@@ -2483,6 +2493,8 @@ static int s8_samples_per_tile() {
 }
 static bool s8_applicable(const NtParams& p) {
   const GeomDev& g = p.g;
+  static const int dgrad_on = getenv("IPOKE_S8_DGRAD") ? atoi(getenv("IPOKE_S8_DGRAD")) : 1;      // developer A/B: 0 sends the conv1 data gradient to the implicit GEMM
+  if (!dgrad_on && g.transposed) return false;
   return s8_samples_per_tile() > 0 && kLdsS8 <= device_max_lds() && !p.c_scatter && !p.a_f32 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Hi == 8 && g.Wi == 8 &&
          g.lDo == 0 && g.lHo == 3 && g.lWo == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 1 && g.pw == 1 &&
          p.Kc % 64 == 0 && p.Kc_real == p.Kc && p.Kc >= 256 && p.Nout <= 64 && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot &&
@@ -2491,13 +2503,21 @@ static bool s8_applicable(const NtParams& p) {
 }
 static int launch_conv3x3_s8(NtParams& p, hipStream_t s) {
   constexpr int BM = 128;
-  const size_t lds = 2 * BM * 128 + 256 + 12 * 64 * 128 + 512 * 16;
-  auto kern = conv3x3_s8_kernel;
-  IPK_SET_LDS_ONCE(kern, lds);
   p.tiles_m = ceil_div(p.g.M, BM); p.tiles_n = 1; p.xa = p.xb = 0;
   p.kb_per_split = ceil_div(p.Kc / 64, p.splitk);
   dim3 grid((unsigned)p.tiles_m, (unsigned)p.splitk);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  static const int n32 = getenv("IPOKE_S8_N32") ? atoi(getenv("IPOKE_S8_N32")) : 1;      // developer A/B: 0 keeps the 64-column kernel for narrow outputs
+  if (n32 && p.Nout <= 32) {
+    const size_t lds = 2 * BM * 128 + 256 + 12 * 32 * 128 + 512 * 16;
+    auto kern = conv3x3_s8n32_kernel;
+    IPK_SET_LDS_ONCE(kern, lds);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  } else {
+    const size_t lds = 2 * BM * 128 + 256 + 12 * 64 * 128 + 512 * 16;
+    auto kern = conv3x3_s8_kernel;
+    IPK_SET_LDS_ONCE(kern, lds);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }
