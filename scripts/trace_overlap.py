@@ -6,7 +6,8 @@ import collections
 import csv
 import sys
 
-CHAIN = {"igemm_nt_glds_kernel<bool _Accum, int, E, 4, 5, 2, 3, 1, true, 2>": "conv2 GEMM", "conv3x3_s8": "s8", "macow_unit_fwd": "unit fwd",
+CHAIN = {"igemm_nt_glds_kernel<bool _Accum, int, E, 4, 5, 2, 3, 1, true, 2>": "conv2 GEMM", "igemm_nn_glds": "conv2 data gradient (K-major)",
+         "conv3x3_s8_coupling": "conv3 + coupling (one launch)", "conv3x3_s8n32": "s8 (32 columns: conv1 data gradient)", "conv3x3_s8": "s8", "macow_unit_fwd": "unit fwd",
          "macow_unit_bwd": "unit bwd", "igemm_nt_glds_kernel<bool _Accum, int, E, 4, 5, 2, 3, 1, false, 2>": "conv1-type GEMM",
          "affine_bwd": "affine bwd", "affine_fwd": "affine fwd"}
 SIDE = {"igemm_tn_glds": "tn", "igemm_tn_kernel": "tn-reg", "adam_amsgrad": "adam", "relayout": "relayout", "wn_bwd": "wn", "wn_scale": "wn",
