@@ -350,8 +350,9 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
       constexpr int E16 = ET<T>::E16;
       const int chunks = U.K2p / E16;
       T* dst = reinterpret_cast<T*>(Lk.a2_save) + (row0 + p0) * U.K2p;
+      const float inv_ch = 1.f / (float)chunks;                        // i / chunks: exact for i < 2048, chunks <= 48
       for (int i = tid; i < R * chunks; i += kMcfThreads) {
-        const int row = i / chunks, ch = i - row * chunks;
+        const int row = (int)(((float)i + 0.5f) * inv_ch), ch = i - row * chunks;
         *reinterpret_cast<u32x4*>(dst + (long)row * U.K2p + ch * E16) = *reinterpret_cast<const u32x4*>(a2 + row * a2_pitch + ch * 16);
       }
     }
@@ -427,8 +428,9 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_fwd_split_kernel(const
       const int half = Lk.zc_ld >> 1;
       T* zb = reinterpret_cast<T*>(Lk.zc) + (row0 + p0) * Lk.zc_ld;
       const T z0 = ET<T>::from_f32(0.f);
+      const float inv_half = 1.f / (float)half;
       for (int i = tid; i < R * half; i += kMcfThreads) {
-        const int r = i / half, k2 = (i - r * half) * 2;
+        const int r = (int)(((float)i + 0.5f) * inv_half), k2 = (i - r * half) * 2;
         const unsigned char* xr = xs + (p0 + r) * xs_pitch;
         bf16x2 v;
         v[0] = k2 < Lk.zc_cin ? *reinterpret_cast<const T*>(xr + (Lk.zc_off + k2 * Lk.zc_stride) * (int)sizeof(T)) : z0;
