@@ -291,7 +291,22 @@ typedef struct {
    * Outputs as with split = 0 / 1 (bit-identical states, saves and data gradients) except: logdet_slot[b * w + s] holds part s of
    * the layer's log-det (w >= split), and dbias_part / post_part have split rows per sample (row b * split + s). */
   int32_t split; void* xchg;
+  /* ipoke_macow_unit_bwd with split >= 2 only, read from d4[0], optional: the ActNorm2dFlow (+ Shuffle) and the NICE coupling IN FRONT of
+   * the unit (forward order coupling -> ActNorm -> unit: MaCowStep, macow2.py:1066-1117) differentiated by the same launch -- see
+   * ipoke_unit_pair_desc below.  The launch then writes pair->dx instead of d4[0].dx. */
+  const struct ipoke_unit_pair_desc* pair;
 } ipoke_mcf_desc;
+/* The work of ipoke_actnorm_affine_bwd on the gradient a unit's backward launch produces, done by that launch row slice by row slice
+ * (both layers are row-wise maps): an ActNorm on the unit's channels [0, C) (log_scale NULL: pure shuffle; an_x = its saved input, the
+ * coupling's output; an_part [B * split][2C] partial sums, row b * split + s) and the affine coupling in front of it (x0 = its saved
+ * input, scale = its saved scales [M][Cp]; outputs dx [M][ld], dparams dtype [M][ldp] = [d mu | d s | 0 pad], dbias_part
+ * [B * split][2 Cp]; dx must be d4[0].dx: columns >= C pass through).  Results equal ipoke_actnorm_affine_bwd's (dx, dparams bit
+ * for bit; the partial sums in `split` parts). */
+typedef struct ipoke_unit_pair_desc {
+  const float* an_log_scale; const int32_t* an_idx; const float* an_x; float* an_part;
+  int32_t Cp, t_off, t_stride; const float* x0; const float* scale; void* dparams; int32_t ldp; float* dbias_part;
+  float* dx;
+} ipoke_unit_pair_desc;
 int ipoke_mcf_shadow_dims(int C, int Cc, int dtype, int32_t* dims8);
 int ipoke_mcf_fwd(const ipoke_mcf_desc* d, int dtype, void* stream);
 int ipoke_mcf_inv(const ipoke_mcf_desc* d, int dtype, void* stream);

@@ -87,7 +87,14 @@ class McfDesc(Structure):
                 ("post_log_scale", c_void_p), ("post_bias", c_void_p), ("y_post", c_void_p), ("post_part", c_void_p),
                 ("x_op_save", c_void_p),
                 ("zc_out", c_void_p), ("zc_off", c_int32), ("zc_stride", c_int32), ("zc_cin", c_int32), ("zc_ld", c_int32),
-                ("split", c_int32), ("xchg", c_void_p)]
+                ("split", c_int32), ("xchg", c_void_p), ("pair", c_void_p)]
+
+
+class UnitPairDesc(Structure):
+    """ipoke_unit_pair_desc (include/ipoke_hip.h)"""
+    _fields_ = [("an_log_scale", c_void_p), ("an_idx", c_void_p), ("an_x", c_void_p), ("an_part", c_void_p),
+                ("Cp", c_int32), ("t_off", c_int32), ("t_stride", c_int32), ("x0", c_void_p), ("scale", c_void_p),
+                ("dparams", c_void_p), ("ldp", c_int32), ("dbias_part", c_void_p), ("dx", c_void_p)]
 
 
 class NormDesc(Structure):

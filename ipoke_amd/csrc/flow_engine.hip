@@ -57,6 +57,8 @@ struct Op {
   int lu_idx = -1;                             // OP_LU: index into the LU job table
   int an_next = -1;                            // NICE: index of the stand-alone ActNorm (+ Shuffle) right behind it, run in the same launches
   int an_prev = -1;                            // ActNorm: index of the coupling whose launches execute it
+  int pair_unit = -1;                          // ActNorm / NICE: head of the fused unit whose row-split BACKWARD launch differentiates this
+                                               // (coupling, ActNorm) pair in front of it (ipoke_mcf_desc.pair); -1: launches of their own
 };
 
 struct RelayoutJobH {     // mirrors RelayoutJob of prep.hip
@@ -646,7 +648,7 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
     f->red_first[i] = (int)red.size();
     const long dbp = (long)(plan.dbias_part / 4) + (long)i * (kMaxUnitSplit * B + 1) * 128;
     // partial sums written by a fused unit launch (its four masked convs and two ActNorms) have unit_split rows per sample
-    const int rmul = op.unit_of >= 0 ? f->unit_split : 1;
+    const int rmul = op.unit_of >= 0 || op.pair_unit >= 0 ? f->unit_split : 1;
     if (op.type == OP_MCF) {
       const McfGeom g = mcf_geom(op.order);
       w1[op.mcf_idx] = {f->mcf_xop ? (long)op.ws_e : (long)(plan.state0 + (int64_t)i * plan.state_stride), (long)op.ws_d, (long)op.p_w1, g.kh,
@@ -657,7 +659,7 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
       nt[0][op.nice_idx] = {(long)op.ws_g, (long)op.ws_f, (long)op.p_c1, 3, 3, 1, 1};     // conv1: saved conditioning columns x d(pre-act 1)
       nt[1][op.nice_idx] = {(long)op.ws_a, (long)op.ws_e, (long)op.p_c2, 1, 1, 0, 0};     // conv2: h1 x d(pre-act 2)
       nt[2][op.nice_idx] = {(long)op.ws_b, (long)op.ws_d, (long)op.p_v, 3, 3, 1, 1};      // conv3: h2 x d(raw shift / scale)
-      red.push_back({dbp, (long)op.p_b, 2 * op.cout, 2 * op.cout, 1, 0});
+      red.push_back({dbp, (long)op.p_b, 2 * op.cout, 2 * op.cout, rmul, 0});
     } else if (op.p_ls >= 0) {
       red.push_back({dbp, (long)op.p_ls, 2 * op.Cn, op.Cn, rmul, 0});
       red.push_back({dbp + op.Cn, (long)op.p_bias, 2 * op.Cn, op.Cn, rmul, 0});
@@ -762,6 +764,17 @@ extern "C" int ipoke_flow_create(const ipoke_flow_config* cfg, ipoke_flow** out)
     if (f->n_lanes > 1 || cfg->dtype != IPOKE_BF16) f->unit_split = 1;     // (lanes would share the scratch across streams)
   }
   f->coupling_fuse = f->n_lanes == 1 && cfg->dtype == IPOKE_BF16 && ipoke_conv3x3_coupling_splitk(64, cfg->hidden, cfg->dtype) > 0;
+  {   // coupling -> ActNorm -> unit (MaCowStep): the pair's backward inside the unit's row-split backward launch (IPOKE_UNIT_PAIR=0: off)
+    const char* up = getenv("IPOKE_UNIT_PAIR");
+    const bool on = f->unit_split > 1 && f->n_lanes == 1 && (up ? atoi(up) != 0 : true);
+    for (size_t h = 2; on && h < f->ops.size(); ++h) {
+      const Op& u = f->ops[h]; Op& an = f->ops[h - 1]; Op& cp = f->ops[h - 2];
+      if (u.unit_head && an.type == OP_ACTNORM && an.an_prev == (int)h - 2 && cp.type == OP_NICE && an.c0 == 0 && an.Cn == u.C &&
+          cp.cout <= 32 && cp.t_off + (cp.cout - 1) * cp.t_stride < u.C) {
+        an.pair_unit = (int)h; cp.pair_unit = (int)h;
+      }
+    }
+  }
   *out = f.release();
   return IPOKE_OK;
 }
@@ -1628,6 +1641,17 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
         d4[3].dy = l.rowsf(goff[cur], l.ld); d4[0].dx = l.rowsf(goff[cur ^ 1], l.ld); d4[0].dld = l.dld();
         IPK_REQUIRE(f->unit_split == 1 || f->d_xchg, "row-split unit launches without exchange scratch (ensure_tables)");
         if (f->unit_split > 1) { d4[0].split = f->unit_split; d4[0].xchg = f->d_xchg; }
+        ipoke_unit_pair_desc pq;
+        if (h >= 2 && f->ops[h - 1].pair_unit == h) {     // the (coupling, ActNorm) pair in front of the unit rides along
+          const Op& an = f->ops[h - 1]; const Op& cp = f->ops[h - 2];
+          std::memset(&pq, 0, sizeof(pq));
+          pq.an_log_scale = an.p_ls >= 0 ? params + an.p_ls : nullptr; pq.an_idx = an.idx_fwd >= 0 ? perm + an.idx_fwd : nullptr;
+          pq.an_x = l.state(h - 1); pq.an_part = an.p_ls >= 0 ? l.dbp(h - 1, 2 * an.Cn, f->unit_split) : nullptr;
+          pq.Cp = cp.cout; pq.t_off = cp.t_off; pq.t_stride = cp.t_stride; pq.x0 = l.state(h - 2); pq.scale = l.rowsf(cp.ws_c, cp.cout);
+          pq.dparams = l.rows(cp.ws_d, (int64_t)cp.Kc3 * f->esz); pq.ldp = cp.Kc3; pq.dbias_part = l.dbp(h - 2, 2 * cp.cout, f->unit_split);
+          pq.dx = d4[0].dx;
+          d4[0].pair = &pq;
+        }
         rc = ipoke_macow_unit_bwd(d4, l.dtype, l.stream()); if (rc) return rc;
       }
       for (int k = 3; k >= 0; --k) {                 // weight gradients: deferred, batched per run of same-width layers
@@ -1647,10 +1671,15 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     }
     // An ActNorm right behind a coupling is differentiated by the coupling's launch (ipoke_actnorm_affine_bwd), unless it is the
     // lowest op of the current piece: its parameter-gradient partials must exist when the piece is finished right after this op.
+    if (op.type == OP_ACTNORM && op.pair_unit >= 0) {      // differentiated by the unit's launch above (so was its coupling: below)
+      if (i == f->units[pieces[pk].first].op_lo) { rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc; ++pk; }
+      continue;
+    }
     if (op.type == OP_ACTNORM && op.an_prev >= 0 && i != f->units[pieces[pk].first].op_lo) { pending_an = i; continue; }
     if (op.type != OP_NICE) { rc = maybe_flush_nice(); if (rc) return rc; }
     for (const Ctx& l : lanes) {
-      const float* gin = l.rowsf(goff[cur], l.ld); float* gout = l.rowsf(goff[cur ^ 1], l.ld);
+      const bool by_unit = op.type == OP_NICE && op.pair_unit >= 0;      // dx / dparams / partials of this coupling were written by a unit's launch
+      const float* gin = l.rowsf(goff[cur], l.ld); float* gout = l.rowsf(goff[by_unit ? cur : cur ^ 1], l.ld);
       const float* xin = l.state(i);                 // saved input of op i
       if (op.type == OP_LU) {
         // dx = dy W (W^T applied per position); parameter gradients straight into the flat buffer (the forward pass of
@@ -1681,7 +1710,9 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       } else {
         const void* h1 = l.rows(op.ws_a, hb); const void* h2 = l.rows(op.ws_b, (int64_t)op.hidK * f->esz);
         void* dprm = l.rows(op.ws_d, (int64_t)op.Kc3 * f->esz); void* dp2 = l.rows(op.ws_e, hb); void* dp1 = l.rows(op.ws_f, hb);
-        if (pending_an == i + 1) {
+        if (by_unit) {
+          rc = IPOKE_OK;
+        } else if (pending_an == i + 1) {
           const Op& an = f->ops[i + 1];
           rc = ipoke_actnorm_affine_bwd(an.c0, an.Cn, an.p_ls >= 0 ? params + an.p_ls : nullptr, an.idx_fwd >= 0 ? perm + an.idx_fwd : nullptr,
                                         gin, l.state(i + 1), an.p_ls >= 0 ? l.dbp(i + 1, 2 * an.Cn) : nullptr, op.cout, op.t_off, op.t_stride,
@@ -1724,7 +1755,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       pend_nice.push_back(i);      // weight gradients: launched when the chain leaves this group of couplings
       if (pending_an == i + 1) pending_an = -1;
     }
-    cur ^= 1;
+    if (!(op.type == OP_NICE && op.pair_unit >= 0)) cur ^= 1;
     if (i == f->units[pieces[pk].first].op_lo) {        // the lowest op of the current piece has been queued
       rc = finish_piece(pieces[pk].first, pieces[pk].second, pk); if (rc) return rc;
       ++pk;

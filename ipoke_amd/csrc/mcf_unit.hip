@@ -898,6 +898,19 @@ extern "C" int ipoke_macow_unit_bwd(const ipoke_mcf_desc* d4, int dtype, void* s
   UnitParams U;
   int rc = unit_params(U, d4, dtype, true); if (rc) return rc;
   IPK_REQUIRE(U.dy && U.dld && U.dx, "null gradient tensor");
+  std::memset(&U.pair, 0, sizeof(U.pair));
+  if (d4[0].pair) {
+    const ipoke_unit_pair_desc& q = *d4[0].pair;
+    IPK_REQUIRE(d4[0].split > 1, "the ActNorm + coupling pair runs in the row-split launches only");
+    IPK_REQUIRE(q.Cp >= 1 && q.Cp <= 32 && q.t_stride >= 1 && q.t_off >= 0 && q.t_off + (q.Cp - 1) * q.t_stride < U.C && q.ldp >= 2 * q.Cp,
+                "pair: the coupling must transform channels of the unit's window");
+    IPK_REQUIRE(q.x0 && q.scale && q.dparams && q.dx && q.dx != U.dy, "pair: null tensor");
+    IPK_REQUIRE(q.dx == U.dx, "pair: the pass-through columns (>= C) reach the pair's dx through the launch's own dx: pass the same buffer");
+    IPK_REQUIRE(!q.an_log_scale || (q.an_x && q.an_part), "pair: the ActNorm's saved input / partials are missing");
+    U.pair.an_ls = q.an_log_scale; U.pair.an_idx = q.an_idx; U.pair.an_x = q.an_x; U.pair.an_part = q.an_part;
+    U.pair.x0 = q.x0; U.pair.scale = q.scale; U.pair.dparams = q.dparams; U.pair.dbias_part = q.dbias_part; U.pair.dx = q.dx;
+    U.pair.Cp = q.Cp; U.pair.t_off = q.t_off; U.pair.t_stride = q.t_stride; U.pair.ldp = q.ldp; U.pair.on = 1;
+  }
 #ifdef IPOKE_UNIT_STAMPS
   U.stamps = g_stamps;
 #endif

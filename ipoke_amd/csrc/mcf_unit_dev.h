@@ -21,11 +21,20 @@ struct UnitLayer {
   void* zc; int zc_off, zc_stride, zc_cin, zc_ld;           // fwd: conditioning operand of the coupling behind the unit (NULL: none)
   int order;
 };
+// The ActNorm2dFlow (+ Shuffle) and the NICE coupling in FRONT of the unit (forward order: coupling -> ActNorm -> unit, MaCowStep /
+// macow2.py:1066-1117), differentiated by the unit's row-split backward launch on the rows each workgroup already holds
+// (ipoke_unit_pair_desc; the work of ipoke_actnorm_affine_bwd)
+struct UnitPair {
+  const float* an_ls; const int* an_idx; const float* an_x; float* an_part;
+  const float* x0; const float* scale; void* dparams; float* dbias_part; float* dx;
+  int Cp, t_off, t_stride, ldp, on;
+};
 struct UnitParams {
   UnitLayer L[4];
   const float* x; const void* cond; const float* dy; const float* dld; float* dx;
   int ld, C, B, Cc, H, Cp, K1p, K2p, K3p, Hq, slot_w;
   unsigned long long* xchg; int xchg_stride;       // row-split launches (mcf_unit_split.hip): granule scratch, granules per (sample, layer, part)
+  UnitPair pair;                                   // row-split backward only
 #ifdef IPOKE_UNIT_STAMPS
   unsigned long long* stamps;       // probe build only (scripts/exp): shader-clock stamps of block 0
 #endif

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_split_kernel(const
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = a0[q] + a2v[q] + a1[q];
           *reinterpret_cast<f32x4*>(gb + p * CP + n) = v;
-          if (k == 0) {
+          if (k == 0 && !U.pair.on) {
             if (vec_out) *reinterpret_cast<f32x4*>(U.dx + (rowp + p) * ld + n) = v;
             else {
 #pragma unroll
@@ -833,6 +833,86 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_bwd_split_kernel(const
           const int p = e / padc, j = N2 + e - p * padc;
           *reinterpret_cast<T*>(dp + p * dp_pitch + j * (int)sizeof(T)) = (T)0.f;
         }
+      }
+    }
+  }
+  // ---- the ActNorm (+ shuffle) and the coupling in front of the unit: both are row-wise maps, and this workgroup holds its R rows of
+  // the gradient they receive in `gb`.  One launch (ipoke_actnorm_affine_bwd: 13.7 us in the step, 100 times per step) and one pass of
+  // that gradient through memory less.  Phase A = actnorm_bwd_kernel, phase B = affine_bwd_kernel (elementwise.hip) on R rows; the
+  // parameter-gradient partials go to row b * S + s of their matrices like the unit's own.  The ActNorm's window is the unit's [0, C);
+  // columns >= C pass through all three layers and were copied by the prologue (U.dx == pair.dx, host-checked).
+  if (U.pair.on) {
+    const UnitPair& Q = U.pair;
+    float* g1 = psum;                              // [R][CP]: gradient w.r.t. the coupling's output
+    float* ps = psum + R * CP;                     // partial column sums
+    const int tl = tid;
+    {   // phase A
+      const int rows_par = kMcfThreads / C;        // >= 8
+      const int j = tl % C, r0 = tl / C;
+      float a_ls = 0.f, a_b = 0.f;
+      if (r0 < rows_par) {
+        const int src = Q.an_idx ? Q.an_idx[j] : j;
+        const float e = Q.an_ls ? expf(Q.an_ls[src]) : 1.f;
+        for (int m = r0; m < R; m += rows_par) {
+          const float g = gb[m * CP + j];
+          const float xv = Q.an_ls ? Q.an_x[(rowp + m) * ld + src] : 0.f;
+          g1[m * CP + src] = g * e;
+          a_ls += g * xv * e;
+          a_b += g;
+        }
+        if (Q.an_ls) { ps[r0 * C + j] = a_ls; ps[(rows_par + r0) * C + j] = a_b; }
+      }
+      __syncthreads();
+      if (Q.an_ls && tl < C) {
+        const int s_ = Q.an_idx ? Q.an_idx[tl] : tl;       // thread tl accumulated channel s_
+        const int used = rows_par < R ? rows_par : R;
+        float t_ls = 0.f, t_b = 0.f;
+        for (int rr = 0; rr < used; ++rr) { t_ls += ps[rr * C + tl]; t_b += ps[(rows_par + rr) * C + tl]; }
+        Q.an_part[((long)b * S + s) * 2 * C + s_] = t_ls + (float)R * g_ld;
+        Q.an_part[((long)b * S + s) * 2 * C + C + s_] = t_b;
+      }
+      __syncthreads();                              // ps is reused below
+    }
+    {   // phase B
+      const int Cq = Q.Cp, rows_par = kMcfThreads / Cq;
+      const int i = tl % Cq, r0 = tl / Cq;
+      T* dprm = reinterpret_cast<T*>(Q.dparams);
+      float a_mu = 0.f, a_s = 0.f;
+      const bool act = r0 < rows_par;
+      if (act) {
+        const int col = Q.t_off + i * Q.t_stride;
+        for (int m = r0; m < R; m += rows_par) {
+          const float g = g1[m * CP + col];
+          const float xv = Q.x0[(rowp + m) * ld + col];
+          const float sc = Q.scale[(rowp + m) * Cq + i];
+          const float t = sc - 1.f;                                           // tanh(s/2)
+          const float ds = (g * xv + g_ld / sc) * 0.5f * (1.f - t * t);
+          Q.dx[(rowp + m) * ld + col] = g * sc;
+          dprm[(rowp + m) * Q.ldp + i] = ET<T>::from_f32(g);                  // d mu
+          dprm[(rowp + m) * Q.ldp + Cq + i] = ET<T>::from_f32(ds);            // d s
+          a_mu += g; a_s += ds;
+        }
+        ps[r0 * 2 * Cq + i] = a_mu; ps[r0 * 2 * Cq + Cq + i] = a_s;
+      }
+      for (int e = tl; e < R * ld; e += kMcfThreads) {      // untouched channels
+        const int m = e / ld, col = e - m * ld;
+        const int rel = col - Q.t_off;
+        const bool transformed = rel >= 0 && rel % Q.t_stride == 0 && rel / Q.t_stride < Cq;
+        if (col < C && !transformed) Q.dx[(rowp + m) * ld + col] = g1[m * CP + col];
+      }
+      {
+        const int pad = Q.ldp - 2 * Cq;
+        for (int e = tl; e < R * pad; e += kMcfThreads) {
+          const int m = e / pad, j = 2 * Cq + (e - m * pad);
+          dprm[(rowp + m) * Q.ldp + j] = ET<T>::from_f32(0.f);
+        }
+      }
+      __syncthreads();
+      if (Q.dbias_part && tl < 2 * Cq) {
+        const int used = rows_par < R ? rows_par : R;
+        float t = 0.f;
+        for (int rr = 0; rr < used; ++rr) t += ps[rr * 2 * Cq + tl];
+        Q.dbias_part[((long)b * S + s) * 2 * Cq + tl] = t;
       }
     }
   }

@@ -295,3 +295,68 @@ def test_macow_unit_row_split_rejects_bad_arguments():
     assert _lib.lib().ipoke_macow_unit_fwd(d, _lib.DTYPES[DT], _lib.current_stream()) != 0        # no scratch
     d[0].xchg = o["xchg"].data_ptr(); d[0].split = 3
     assert _lib.lib().ipoke_macow_unit_fwd(d, _lib.DTYPES[DT], _lib.current_stream()) != 0        # 2 or 4 only
+
+
+@pytest.mark.parametrize("C,ld,B,Cp,t_off,t_stride,with_ls,with_idx", [(64, 64, 5, 32, 0, 2, True, True), (64, 64, 20, 32, 1, 2, True, False),
+                                                                        (64, 64, 3, 16, 32, 1, False, True), (64, 64, 4, 8, 3, 4, True, True),
+                                                                        (44, 64, 3, 22, 0, 2, True, True), (30, 32, 4, 15, 15, 1, True, True),
+                                                                        (8, 64, 2, 4, 1, 2, True, False)])
+def test_macow_unit_bwd_differentiates_the_pair_in_front(C, ld, B, Cp, t_off, t_stride, with_ls, with_idx):
+    """ipoke_mcf_desc.pair: the ActNorm (+ shuffle) and the coupling in front of the unit (forward order), differentiated by the unit's
+    row-split backward launch, against the unit's launch followed by ipoke_actnorm_affine_bwd (reference: MaCowStep's
+    coupling -> actnorm -> unit, macow2.py:1066-1117; ActNorm2dFlow.backward / Affine.backward through autograd)."""
+    from ctypes import byref, cast, c_void_p, pointer
+    from ipoke_amd._lib import UnitPairDesc
+    S = 4
+    o_, x, h, shs, posts = _unit(C, ld, B, 900 + Cp)
+    dims = shs[0]["dims"]
+    xs = ops.to_state(x.to(DEV)); cond = ops.cond_prepare(h.to(DEV), DT)
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    dy = torch.randn(B * 64, ld, device=DEV, generator=gen)
+    dld = torch.randn(B, device=DEV, generator=gen)
+    M = B * 64
+    an_ls = (torch.randn(C, device=DEV, generator=gen) * 0.2) if with_ls else None
+    an_idx = torch.randperm(C, device=DEV, generator=gen).to(torch.int32) if with_idx else None
+    x1 = torch.randn(M, ld, device=DEV, generator=gen)          # the ActNorm's saved input
+    x0 = torch.randn(M, ld, device=DEV, generator=gen)          # the coupling's saved input
+    scale = torch.rand(M, Cp, device=DEV, generator=gen) * 1.5 + 0.2
+    ldp = 2 * Cp + 8
+    keep = []
+    L = _lib.lib()
+    # --- two launches
+    o = _split_buffers(C, ld, B, S, dims)
+    d = _split_descs(C, ld, B, S, xs, cond, shs, posts, keep, o, o, dy, dld)
+    _lib.check(L.ipoke_macow_unit_fwd(d, _lib.DTYPES[DT], _lib.current_stream()))
+    _lib.check(L.ipoke_macow_unit_bwd(d, _lib.DTYPES[DT], _lib.current_stream()))
+    ref_dx = torch.full((M, ld), float("nan"), device=DEV)
+    ref_dp = torch.full((M, ldp), float("nan"), device=DEV).to(torch.bfloat16)
+    ref_part = torch.zeros(B, 2 * C, device=DEV); ref_db = torch.zeros(B, 2 * Cp, device=DEV)
+    _lib.check(L.ipoke_actnorm_affine_bwd(0, C, _lib.ptr(an_ls), _lib.ptr(an_idx), o["dx"].data_ptr(), x1.data_ptr(),
+                                          ref_part.data_ptr() if with_ls else None, Cp, t_off, t_stride, 64, ld, x0.data_ptr(),
+                                          scale.data_ptr(), dld.data_ptr(), ref_dx.data_ptr(), ref_dp.data_ptr(), ldp, ref_db.data_ptr(), B,
+                                          _lib.DTYPES[DT], _lib.current_stream()))
+    # --- one launch
+    o2 = _split_buffers(C, ld, B, S, dims)
+    d2 = _split_descs(C, ld, B, S, xs, cond, shs, posts, keep, o2, o, dy, dld)          # (saves of the first forward pass)
+    got_dx = torch.full((M, ld), float("nan"), device=DEV)
+    got_dp = torch.full((M, ldp), float("nan"), device=DEV).to(torch.bfloat16)
+    got_part = torch.zeros(B * S, 2 * C, device=DEV); got_db = torch.zeros(B * S, 2 * Cp, device=DEV)
+    q = UnitPairDesc()
+    q.an_log_scale = _lib.ptr(an_ls); q.an_idx = _lib.ptr(an_idx); q.an_x = x1.data_ptr(); q.an_part = got_part.data_ptr() if with_ls else None
+    q.Cp, q.t_off, q.t_stride = Cp, t_off, t_stride
+    q.x0 = x0.data_ptr(); q.scale = scale.data_ptr(); q.dparams = got_dp.data_ptr(); q.ldp = ldp; q.dbias_part = got_db.data_ptr()
+    q.dx = got_dx.data_ptr(); d2[0].dx = got_dx.data_ptr()          # one buffer: columns >= C pass through the launch's own dx
+    d2[0].pair = cast(pointer(q), c_void_p).value
+    _lib.check(L.ipoke_macow_unit_bwd(d2, _lib.DTYPES[DT], _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(got_dx, ref_dx)
+    assert torch.equal(got_dp.float(), ref_dp.float())
+    for got, ref in ((got_db, ref_db),) + (((got_part, ref_part),) if with_ls else ()):
+        g = got.view(B, S, -1).sum(1)
+        assert ((g - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item() <= 5e-6
+    for k in range(4):                                    # the unit's own outputs are untouched by the extra work
+        for nme in ("dps", "dcs", "dbp", "pp"):
+            assert torch.equal(o2[nme][k], o[nme][k]), (nme, k)
+    # rejected: without the row split, or on a unit that does not cover the whole state
+    d2[0].split = 1
+    assert L.ipoke_macow_unit_bwd(d2, _lib.DTYPES[DT], _lib.current_stream()) != 0
