@@ -1515,7 +1515,8 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
                                    rw1[kind] - rw0[kind], rstream);
       if (r) return r;
     }
-    if (f->nadam.on) {
+    static const bool probe_skip_adam = getenv("IPOKE_PROBE_SKIP_ADAM") != nullptr;      // developer probe: what the optimizer costs the step (parameters stay put)
+    if (f->nadam.on && !probe_skip_adam) {
       // single-GPU training: the update of the piece's ranges and the refresh of their shadows, natively, on the ready stream
       ipoke_flow::NativeAdam A = f->nadam;
       {   // developer A/B (IPOKE_ADAM_EARLY_BLOCKS=n, IPOKE_ADAM_LATE_PIECES=k): the optimizer of all but the last k pieces on a smaller grid --
