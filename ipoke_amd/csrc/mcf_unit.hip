@@ -639,12 +639,10 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
   constexpr int K2c = UC<WIDE>::N2S * 32;
   const int xs_pitch = U.Cp * (int)sizeof(T) + kTilePad;
   constexpr int a2_pitch = K2c * (int)sizeof(T) + kTilePad;
-  const int prm_ld = N2 + 4;
   unsigned char* xs = smem;                                        // T [2][64 + zero row][Cp]: reconstructed inputs (operand copy)
-  unsigned char* a2 = xs + 2 * 65 * xs_pitch;                      // T [16][K2c]
-  unsigned char* cs = a2 + 16 * a2_pitch;                          // T [2][64][Cc]: ELU(cond) of the two samples
-  float* prm = reinterpret_cast<float*>(cs + 2 * 64 * U.Cc * (int)sizeof(T));     // [16][2C (+4)]
-  float* yf = prm + 16 * prm_ld;                                   // [2][64][C] fp32 state: y on entry of a layer, x on exit
+  unsigned char* a2 = xs + 2 * 65 * xs_pitch;                      // T [2][16][K2c]: the strip's [hidden | cond] operand, double-buffered
+  unsigned char* cs = a2 + 2 * 16 * a2_pitch;                      // T [2][64][Cc]: ELU(cond) of the two samples
+  float* yf = reinterpret_cast<float*>(cs + 2 * 64 * U.Cc * (int)sizeof(T));      // [2][64][C] fp32 state: y on entry of a layer, x on exit
   float* bias_s = yf + 2 * 64 * C;                                 // [4][2C]
   float* post_s = bias_s + 4 * N2;                                 // [4][2][C]: exp(log_scale) + 1e-8, bias of the ActNorms
   const long row0 = (long)b0 * 64;
@@ -670,9 +668,26 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
     }
   }
   McfW<T> wr;
+  // The 1x1 conv's output columns are taken in the order (mu_c, s_c, mu_c+1, s_c+1, ...): wave w computes the raw shift AND scale of
+  // channels 8w .. 8w+7, so that a lane's four accumulator values are (mu, s) of two channels of its row and the inversion of the
+  // coupling runs straight from the registers -- no [16][2C] staging tile, no barrier between the contraction and the coupling
+  // (the strip loop is a chain of barrier-separated phases: 128 strips x 3 barriers per launch).  Rows of the fragment-tiled operand
+  // are picked per lane: fragment row n of wave w = operand row 8w + n/2 (+ C for odd n); rows of channels >= C read as zeros.
+  const int w2_n2 = U.K2p / KS;
+  int w2_voff;
+  {
+    const int lane_ = tid & 63, wave_ = tid >> 6, nloc = lane_ & 15, q = lane_ >> 4;
+    const int ch = 8 * wave_ + (nloc >> 1), R_ = (nloc & 1) ? C + ch : ch;
+    w2_voff = ch < C ? ((R_ >> 4) * w2_n2) * 1024 + (16 * q + (R_ & 15)) * 16 : kOob;
+  }
+  auto load_w2_pairs = [&](const void* W2) {
+    const rsrc_t rs = make_rsrc(W2, ((2 * C + 15) & ~15) * U.K2p * (int)sizeof(T));
+#pragma unroll
+    for (int st = 0; st < UC<WIDE>::N2S; ++st) wr.w2[st][0] = buf_frag<T>(rs, w2_voff, st < w2_n2 ? st * 1024 : kOob);
+  };
   unit_load_w1<T, WIDE>(wr, U.L[3].W1, U);
-  unit_load_w2<T, WIDE>(wr, U.L[3].W2, U);
-  for (int i = tid; i < (2 * 65 * xs_pitch + 16 * a2_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  load_w2_pairs(U.L[3].W2);
+  for (int i = tid; i < (2 * 65 * xs_pitch + 2 * 16 * a2_pitch) / 16; i += kMcfThreads) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
   {   // ELU(cond) rows of both samples
     const int cchunks = U.Cc / E16;
     const T* condp = reinterpret_cast<const T*>(U.cond) + row0 * U.Cc;
@@ -718,22 +733,27 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
     }
     const bool rows_first = Lk.order < 2, backwards = (Lk.order & 1);
     const float* bk = bias_s + k * N2;
+    // conditioning rows of strip `st` behind the hidden columns of operand buffer st & 1: for the first strip here, for every
+    // later one underneath the coupling phase of the strip before it (they used to head every strip: 550 of its ~5 400 cycles)
+    auto stage_cond = [&](int st) {
+      const int si_ = backwards ? 7 - st : st;
+      unsigned char* dst = a2 + (st & 1) * 16 * a2_pitch;
+      const int cchunks = U.Cc / E16;
+      for (int e = tl; e < 16 * cchunks; e += kMcfThreads) {
+        const int row = (int)(((float)e + 0.5f) * inv_cch), ch = e - row * cchunks;      // e / cchunks, exact for e < 2048, cchunks <= 16
+        const int sidx = row >> 3, j = row & 7;
+        const int pos = rows_first ? si_ * 8 + j : j * 8 + si_;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (sidx < nb) v = *reinterpret_cast<const u32x4*>(cs + ((sidx * 64 + pos) * cchunks + ch) * 16);
+        *reinterpret_cast<u32x4*>(dst + row * a2_pitch + (H + ch * E16) * (int)sizeof(T)) = v;
+      }
+    };
+    stage_cond(0);
 #pragma unroll 1
     for (int step = 0; step < 8; ++step) {
       const int si = backwards ? 7 - step : step;
+      unsigned char* a2b = a2 + (step & 1) * 16 * a2_pitch;
       UNIT_STAMP(1 + 6 * step + 0 + (k == 3 ? 0 : 1000));
-      // conditioning rows of the strip behind the hidden columns of the 16-row tile
-      {
-        const int cchunks = U.Cc / E16;
-        for (int e = tl; e < 16 * cchunks; e += kMcfThreads) {
-          const int row = (int)(((float)e + 0.5f) * inv_cch), ch = e - row * cchunks;      // e / cchunks, exact for e < 2048, cchunks <= 16
-          const int sidx = row >> 3, j = row & 7;
-          const int pos = rows_first ? si * 8 + j : j * 8 + si;
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (sidx < nb) v = *reinterpret_cast<const u32x4*>(cs + ((sidx * 64 + pos) * cchunks + ch) * 16);
-          *reinterpret_cast<u32x4*>(a2 + row * a2_pitch + (H + ch * E16) * (int)sizeof(T)) = v;
-        }
-      }
       UNIT_STAMP(1 + 6 * step + 1 + (k == 3 ? 0 : 1000));
       {   // hidden = ELU(shifted conv of the strips reconstructed so far)
         const int sidx = r >> 3, j = r & 7;
@@ -760,7 +780,7 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
             typename Pack4<T>::type tv;
 #pragma unroll
             for (int q = 0; q < 4; ++q) tv[q] = ET<T>::from_f32(fast_elu(acc[jj][q]));
-            *reinterpret_cast<typename Pack4<T>::type*>(a2 + r * a2_pitch + n * (int)sizeof(T)) = tv;
+            *reinterpret_cast<typename Pack4<T>::type*>(a2b + r * a2_pitch + n * (int)sizeof(T)) = tv;
           }
         }
       }
@@ -769,39 +789,37 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
       if (step == 7 && k > 0) unit_load_w1<T, WIDE>(wr, U.L[k - 1].W1, U);
       __syncthreads();
       UNIT_STAMP(1 + 6 * step + 3 + (k == 3 ? 0 : 1000));
-      {   // raw (mu, s) of the 16 rows
+      {   // raw (mu, s) of the 16 rows, two channels per lane, and x = (y - mu) / (scale + 1e-12) (macow_utils.py:61-66) straight from
+          // the accumulator; the strip joins the operand tile
+        const int c = 8 * wave + 2 * gq;                       // this lane: row r, channels c, c + 1
+        const int sidx = r >> 3, j = r & 7;
+        const int pos = rows_first ? si * 8 + j : j * 8 + si;
+        const bool live = c < C && sidx < nb;
+        f32x2 yv = {0.f, 0.f}, bm = {0.f, 0.f}, bs = {0.f, 0.f};
+        if (live) {                                            // (requested ahead of the contraction)
+          yv = *reinterpret_cast<const f32x2*>(yf + (sidx * 64 + pos) * C + c);
+          bm = *reinterpret_cast<const f32x2*>(bk + c); bs = *reinterpret_cast<const f32x2*>(bk + C + c);
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < UC<WIDE>::N2S; ++st) {
-          const frag_t fa = *reinterpret_cast<const frag_t*>(a2 + r * a2_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
+          const frag_t fa = *reinterpret_cast<const frag_t*>(a2b + r * a2_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
           mma64(fa, wr.w2[st][0], acc);
         }
-        const int n = wave * 16 + 4 * gq;
-        if (n < N2) *reinterpret_cast<f32x4*>(prm + r * prm_ld + n) = acc;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      UNIT_STAMP(1 + 6 * step + 4 + (k == 3 ? 0 : 1000));
-      if (step == 7 && k > 0) unit_load_w2<T, WIDE>(wr, U.L[k - 1].W2, U);
-      __syncthreads();
-      UNIT_STAMP(1 + 6 * step + 5 + (k == 3 ? 0 : 1000));
-      // x = (y - mu) / (scale + 1e-12)   (macow_utils.py:61-66); the strip joins the operand tile
-      for (int e = tl; e < 16 * G2; e += kMcfThreads) {
-        const int row = (int)(((float)e + 0.5f) * inv_g2), c = (e - row * G2) * 2;          // e / G2, exact for e < 2048, G2 <= 32
-        const int sidx = row >> 3, j = row & 7;
-        if (sidx < nb) {
-          const int pos = rows_first ? si * 8 + j : j * 8 + si;
-          const f32x2 mu = *reinterpret_cast<const f32x2*>(prm + row * prm_ld + c);
-          const f32x2 sv = *reinterpret_cast<const f32x2*>(prm + row * prm_ld + C + c);
-          const f32x2 yv = *reinterpret_cast<const f32x2*>(yf + (sidx * 64 + pos) * C + c);
+        __builtin_amdgcn_sched_barrier(0);
+        UNIT_STAMP(1 + 6 * step + 4 + (k == 3 ? 0 : 1000));
+        if (step == 7 && k > 0) load_w2_pairs(U.L[k - 1].W2);
+        UNIT_STAMP(1 + 6 * step + 5 + (k == 3 ? 0 : 1000));
+        if (live) {
           f32x2 xv;
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            xv[q] = __fdividef(yv[q] - (mu[q] + bk[c + q]), fast_scale(sv[q] + bk[C + c + q]) + 1e-12f);
+          xv[0] = __fdividef(yv[0] - (acc[0] + bm[0]), fast_scale(acc[1] + bs[0]) + 1e-12f);
+          xv[1] = __fdividef(yv[1] - (acc[2] + bm[1]), fast_scale(acc[3] + bs[1]) + 1e-12f);
           *reinterpret_cast<f32x2*>(yf + (sidx * 64 + pos) * C + c) = xv;
           bf16x2 tv; tv[0] = ET<T>::from_f32(xv[0]); tv[1] = ET<T>::from_f32(xv[1]);
           *reinterpret_cast<bf16x2*>(xs + (sidx * 65 + pos) * xs_pitch + c * (int)sizeof(T)) = tv;
         }
       }
+      if (step < 7) stage_cond(step + 1);        // (buffer (step + 1) & 1: last read two barriers ago)
       __syncthreads();
     }
     UNIT_STAMP(49 + (3 - k));
@@ -942,8 +960,8 @@ extern "C" int ipoke_macow_unit_inv(const ipoke_mcf_desc* d4, int dtype, void* s
   U.stamps = g_stamps;
 #endif
   const bool wide = U.Cp > 32;
-  const size_t lds = (size_t)2 * 65 * (U.Cp * 2 + kTilePad) + (size_t)16 * ((wide ? 384 : 256) * 2 + kTilePad) + (size_t)2 * 64 * U.Cc * 2 +
-                     (size_t)16 * (2 * U.C + 4) * 4 + (size_t)2 * 64 * U.C * 4 + (size_t)(8 * U.C + 8 * U.C) * 4;
+  const size_t lds = (size_t)2 * 65 * (U.Cp * 2 + kTilePad) + (size_t)2 * 16 * ((wide ? 384 : 256) * 2 + kTilePad) + (size_t)2 * 64 * U.Cc * 2 +
+                     (size_t)2 * 64 * U.C * 4 + (size_t)(8 * U.C + 8 * U.C) * 4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int grid = (U.B + 1) / 2;
   TimedScope ts(IPOKE_TAG_UNIT_INV, s);
