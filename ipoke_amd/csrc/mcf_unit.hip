@@ -8,6 +8,7 @@
 // outputs, coupling scales) is written on the way, exactly as the per-layer kernels write it.
 //
 // bf16 matrix-core inputs only (the register-resident weight path); f32 parity mode runs the per-layer kernels.
+#include <type_traits>
 #include "mcf_unit_dev.h"
 
 namespace ipoke {
@@ -749,8 +750,17 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
       }
     };
     stage_cond(0);
-#pragma unroll 1
-    for (int step = 0; step < 8; ++step) {
+    // One strip.  LAST (the layer's eighth strip, compile time): the next layer's weight fragments are re-requested piecewise -- a tap of the
+    // shifted conv as soon as its matrix-core instructions have been issued, a K step of the 1x1 conv likewise -- instead of in two bursts
+    // of 196 + 98 KB per workgroup behind the contractions, in whose ISSUE the eight waves sat for ~5 500 cycles per layer (the CU's
+    // vector-memory pipeline is a FIFO).
+    const bool reload = k > 0;
+    const UnitLayer& Ln = U.L[k > 0 ? k - 1 : 0];
+    const rsrc_t rs1n = make_rsrc(Ln.W1, ((U.H + 15) & ~15) * U.K1p * (int)sizeof(T));
+    const rsrc_t rs2n = make_rsrc(Ln.W2, ((2 * C + 15) & ~15) * U.K2p * (int)sizeof(T));
+    const int nks1 = U.K1p / KS;
+    auto strip = [&](const int step, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
       const int si = backwards ? 7 - step : step;
       unsigned char* a2b = a2 + (step & 1) * 16 * a2_pitch;
       UNIT_STAMP(1 + 6 * step + 0 + (k == 3 ? 0 : 1000));
@@ -772,6 +782,15 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
 #pragma unroll
             for (int jj = 0; jj < J1; ++jj) mma64(fa, wr.w1[tap][st][jj], acc[jj]);
           }
+          if constexpr (LAST) {
+            if (reload) {
+#pragma unroll
+              for (int st = 0; st < UC<WIDE>::CS; ++st)
+#pragma unroll
+                for (int jj = 0; jj < J1; ++jj)
+                  wr.w1[tap][st][jj] = buf_frag<T>(rs1n, (wave + kMcfWaves * jj) * nks1 * 1024 + lane * 16, (tap * UC<WIDE>::CS + st) * 1024);
+            }
+          }
         }
 #pragma unroll
         for (int jj = 0; jj < J1; ++jj) {
@@ -786,7 +805,6 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
       }
       __builtin_amdgcn_sched_barrier(0);
       UNIT_STAMP(1 + 6 * step + 2 + (k == 3 ? 0 : 1000));
-      if (step == 7 && k > 0) unit_load_w1<T, WIDE>(wr, U.L[k - 1].W1, U);
       __syncthreads();
       UNIT_STAMP(1 + 6 * step + 3 + (k == 3 ? 0 : 1000));
       {   // raw (mu, s) of the 16 rows, two channels per lane, and x = (y - mu) / (scale + 1e-12) (macow_utils.py:61-66) straight from
@@ -805,10 +823,12 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
         for (int st = 0; st < UC<WIDE>::N2S; ++st) {
           const frag_t fa = *reinterpret_cast<const frag_t*>(a2b + r * a2_pitch + (st * KS + E16 * gq) * (int)sizeof(T));
           mma64(fa, wr.w2[st][0], acc);
+          if constexpr (LAST) {
+            if (reload) wr.w2[st][0] = buf_frag<T>(rs2n, w2_voff, st < w2_n2 ? st * 1024 : kOob);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         UNIT_STAMP(1 + 6 * step + 4 + (k == 3 ? 0 : 1000));
-        if (step == 7 && k > 0) load_w2_pairs(U.L[k - 1].W2);
         UNIT_STAMP(1 + 6 * step + 5 + (k == 3 ? 0 : 1000));
         if (live) {
           f32x2 xv;
@@ -819,9 +839,12 @@ __global__ __launch_bounds__(kMcfThreads) void macow_unit_inv_kernel(const UnitP
           *reinterpret_cast<bf16x2*>(xs + (sidx * 65 + pos) * xs_pitch + c * (int)sizeof(T)) = tv;
         }
       }
-      if (step < 7) stage_cond(step + 1);        // (buffer (step + 1) & 1: last read two barriers ago)
+      if constexpr (!LAST) stage_cond(step + 1);  // (buffer (step + 1) & 1: last read two barriers ago)
       __syncthreads();
-    }
+    };
+#pragma unroll 1
+    for (int step = 0; step < 7; ++step) strip(step, std::false_type{});
+    strip(7, std::true_type{});
     UNIT_STAMP(49 + (3 - k));
   }
   for (int e = tid; e < rows * G2; e += kMcfThreads) {
