@@ -46,6 +46,10 @@ int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us);
 /* per tag: launches, SUM of durations (us), SUM of algorithmic FLOPs and bytes -- the per-configuration rooflines of bench.py */
 int ipoke_timing_stop_ex(const int* tags, int ntags, int* counts, double* total_us, double* flops, double* bytes);
 
+/* Test hook: sizeof of the descriptor structs of ipoke_hip.h in the order conv, wgrad, affine, coupling_epi, mcf, unit_pair, flow_config,
+ * norm, norm_bwd, rowscale_bwd, sn_job (out: at least 11 entries; returns the count) -- the binding's own structs must match. */
+int ipoke_desc_sizes(int32_t* out, int n);
+
 /* Test hook: forward unroll of the ConvGRU as one launch (1), as launches per phase (0), or the IPOKE_GRU_FUSED environment default (< 0) */
 int ipoke_gru_set_fused(int mode);
 

@@ -136,6 +136,7 @@ SIGNATURES = {
     "ipoke_rowscale_bwd": (c_int, [POINTER(RowScaleBwdDesc), c_int, _P]),
     "ipoke_spectral_bwd_frames": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int64, _P, c_int64, _P, c_int, _P]),
     "ipoke_sum_frames": (c_int, [_P, _P, c_int, c_int64, c_int, _P]),
+    "ipoke_desc_sizes": (c_int, [POINTER(c_int32), c_int]),
     "ipoke_conv3x3_skinny_splitk": (c_int, [c_int, c_int, c_int]),
     "ipoke_conv3x3_coupling_splitk": (c_int, [c_int, c_int, c_int]),
     "ipoke_conv3x3_coupling_xchg_bytes": (c_int64, []),

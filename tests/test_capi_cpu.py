@@ -165,3 +165,17 @@ def test_deterministic_fill_is_name_keyed():
     f = fill_value("s.forward_shuffle_idx", torch.empty(8, dtype=torch.int64))
     r = fill_value("s.backward_shuffle_idx", torch.empty(8, dtype=torch.int64))
     assert torch.equal(r, torch.argsort(f)) and sorted(f.tolist()) == list(range(8))
+
+
+def test_descriptor_structs_of_the_binding_match_the_header():
+    """ctypes mirrors of the descriptor structs (ipoke_amd/_lib.py) against sizeof in the library: a field added on one side only would
+    shift every field behind it without any error."""
+    import ctypes
+    from ipoke_amd import _lib
+    out = (ctypes.c_int32 * 16)()
+    n = _lib.lib().ipoke_desc_sizes(out, 16)
+    mirrors = [_lib.ConvDesc, _lib.WgradDesc, _lib.AffineDesc, _lib.CouplingEpi, _lib.McfDesc, _lib.UnitPairDesc, _lib.FlowConfig,
+               _lib.NormDesc, _lib.NormBwdDesc, _lib.RowScaleBwdDesc, _lib.SnJob]
+    assert n == len(mirrors)
+    for i, m in enumerate(mirrors):
+        assert ctypes.sizeof(m) == out[i], (m.__name__, ctypes.sizeof(m), out[i])
