@@ -2931,7 +2931,11 @@ static int dispatch_nn(NtParams& p, hipStream_t s) {
 }
 
 // RM = reduction rows per ring slot (64).
-template <int NSTAGE, int RM>
+// NARROW: outputs of <= 64 rows (conv3 of a coupling net, dW [2 Cp][9 * hidden]): a 64 (n) x 256 (k) tile instead of 128 x 128, whose second
+// 64 columns would be padding -- half of every workgroup's dY stream, fragment reads and matrix-core work on zeros, and the conv3 weight
+// gradients took as long as conv2's with 3.5x fewer FLOPs (7.1 ms of the weight-gradient queue per c2 step).  A stage is the dY image
+// (its upper 64 columns stay zero) and TWO A images (k0 .. k0 + 127, k0 + 128 .. k0 + 255); the eight waves own 64 x 32 each, side by side in k.
+template <int NSTAGE, int RM, bool NARROW = false>
 __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) {
   if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(TnParams)>();
   typedef bf16_t T;
@@ -2947,14 +2951,15 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   static_assert(RM == 64, "stage height: two 32-row reduction steps, read and multiplied in a two-phase software pipeline");
   constexpr int NI = RM / 32;                   // DMA instructions per thread, operand and stage
   constexpr int TILE = RM * 256;                // one operand image: 64 rows x 128 columns of bf16
-  constexpr int STAGE = 2 * TILE;
-  constexpr int L = 2 * NI;                     // DMA instructions per thread and stage
+  constexpr int NIMG = NARROW ? 3 : 2;          // operand images per stage
+  constexpr int STAGE = NIMG * TILE;
+  constexpr int L = NIMG * NI;                  // DMA instructions per thread and stage
   static_assert((NSTAGE - 2) * L <= 63, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* taptab = reinterpret_cast<int*>(smem + NSTAGE * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn2 = wave >> 2, wk = wave & 3;     // wave tile: 64 (n) x 32 (k)
+  const int wn2 = NARROW ? 0 : wave >> 2, wk = NARROW ? wave : wave & 3;     // wave tile: 64 (n) x 32 (k)
   const GeomDev& g = p.g;
   int tn, tk;
   if (p.xa > 0) {
@@ -2972,7 +2977,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     const FDiv ftn(p.tiles_n);
     tn = ftn.mod(tile); tk = ftn.div(tile);
   }
-  const int n0 = tn * 128, k0 = tk * 128;
+  const int n0 = tn * 128, k0 = tk * (NARROW ? 256 : 128);
   const int z = blockIdx.y;
   const int nmb_total = (g.M + RM - 1) / RM;      // (RM: compile-time)
   const int mb_begin = z * p.mb_per_split, mb_end = min(nmb_total, mb_begin + p.mb_per_split);
@@ -3007,6 +3012,21 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
         x_fix[i] = (unsigned)(r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw + p.a_coff + x_c);
     }
   }
+  // NARROW: the second A image (columns k0 + 128 ..)
+  const int kcol2 = kcol + 128;
+  const int x_tap2 = FDiv(p.Kc).div(kcol2), x_c2 = kcol2 - x_tap2 * p.Kc;
+  const bool x_ok2 = NARROW && kcol2 < p.Ktot && x_c2 < p.Kc_real;
+  const int x_tapcode2 = x_ok2 ? taptab[x_tap2] : 0;
+  unsigned x_fix2[2] = {kBad, kBad};
+  if (NARROW && p.rows_fixed && x_ok2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const RowPos r = decode_row(g, rl0 + 32 * i, p.a_sn);
+      int id, ih, iw;
+      if (tap_coords(g, r, x_tapcode2, id, ih, iw))
+        x_fix2[i] = (unsigned)(r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw + p.a_coff + x_c2);
+    }
+  }
   auto issue = [&](int slot, int mb, bool real) {
     unsigned char* sy = smem + slot * STAGE;
     unsigned char* sx = sy + TILE;
@@ -3037,6 +3057,26 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
       }
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sx + (wave + 8 * i) * 1024), 16, 0, 0);
     }
+    if constexpr (NARROW) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int m = mb * RM + rl0 + 32 * i;
+        const T* src = zero;
+        if (real && x_ok2 && m < g.M) {
+          if (p.rows_fixed) {
+            const int half = RM == 64 ? i : (mb & 1);
+            const long smp = RM == 64 ? (long)mb : (long)(mb >> 1);
+            if (x_fix2[half] != kBad) src = A + smp * p.a_sn + x_fix2[half];
+          } else {
+            const RowPos r = decode_row(g, m, p.a_sn);
+            int id, ih, iw;
+            if (tap_coords(g, r, x_tapcode2, id, ih, iw))
+              src = A + r.nb + (long)id * p.a_sd + (long)ih * p.a_sh + (long)iw * p.a_sw + p.a_coff + x_c2;
+          }
+        }
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sx + TILE + (wave + 8 * i) * 1024), 16, 0, 0);
+      }
+    }
   };
 
   // ---- fragment read offsets (bytes inside an operand image), loop invariant
@@ -3054,7 +3094,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
 #pragma unroll
   for (int i = 0; i < 4; ++i) y_rd[i] = lds0 + (unsigned)frag_off(wn2 * 64 + 16 * i);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) x_rd[j] = lds0 + (unsigned)(TILE + frag_off(wk * 32 + 16 * j));
+  for (int j = 0; j < 2; ++j) x_rd[j] = lds0 + (unsigned)(TILE * (1 + (NARROW ? wk >> 2 : 0)) + frag_off((NARROW ? wk & 3 : wk) * 32 + 16 * j));
   // the six operand fragments of reduction step KS (rows 32 KS .. 32 KS + 31) of the stage at byte offset sb: twelve reads in flight
   auto read_frags = [&](frag_t (&f)[6], unsigned sb, auto ks_tag) {
     constexpr int KS = decltype(ks_tag)::value;
@@ -3212,9 +3252,16 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     // flight, twice the barriers -- measured 35.5 against 29.7 us alone and 63.3 against 62.0 ms per step in round 3; removed.)
     static const int nst = getenv("IPOKE_TN_STAGES") ? atoi(getenv("IPOKE_TN_STAGES")) : 2;
     const int NST = nst == 3 ? 3 : 2;
-    const size_t lds2 = (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
-    auto kern = NST == 2 ? igemm_tn_glds_kernel<2, 64> : igemm_tn_glds_kernel<3, 64>;
-    if (NST == 2) { IPK_SET_LDS_ONCE(kern, lds2); } else { IPK_SET_LDS_ONCE(kern, lds2); }      // one flag per ring depth
+    // narrow outputs of the flow engine's batched launches (conv3 of the coupling nets): 64 x 256 tiles (see the kernel)
+    static const int narrow_on = getenv("IPOKE_TN_NARROW") ? atoi(getenv("IPOKE_TN_NARROW")) : 1;      // developer A/B
+    const bool narrow = narrow_on && NST == 2 && p.batch != nullptr && p.Nout <= 64 && p.Ktot >= 512 && p.max_wgs <= 0;
+    if (narrow) p.tiles_k = ceil_div(p.Ktot, 256);
+    const int nst_n = narrow_on == 3 ? 3 : 2;                  // (developer A/B: IPOKE_TN_NARROW=3 = three ring slots, 144 KB)
+    const size_t lds2 = narrow ? (size_t)nst_n * 3 * 64 * 256 + 256 * sizeof(int) : (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
+    auto kern = narrow ? (nst_n == 3 ? igemm_tn_glds_kernel<3, 64, true> : igemm_tn_glds_kernel<2, 64, true>)
+                       : NST == 2 ? igemm_tn_glds_kernel<2, 64> : igemm_tn_glds_kernel<3, 64>;
+    if (narrow && nst_n == 3) { IPK_SET_LDS_ONCE(kern, lds2); } else if (narrow) { IPK_SET_LDS_ONCE(kern, lds2); }
+    else if (NST == 2) { IPK_SET_LDS_ONCE(kern, lds2); } else { IPK_SET_LDS_ONCE(kern, lds2); }      // one flag per instantiation
     const int ntiles = p.tiles_n * p.tiles_k;
     const int cap = p.max_wgs > 0 ? p.max_wgs : ntiles;
     p.xa = p.xb = 0;
