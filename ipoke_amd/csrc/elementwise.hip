@@ -797,7 +797,18 @@ __global__ void reduce_rows_multi_kernel(const float* __restrict__ src, float* _
   for (int c = threadIdx.x; c < e.ncols; c += blockDim.x) {
     float t = 0.f;
     const int rows = R * (e.rmul > 0 ? e.rmul : 1);
-    for (int r = 0; r < rows; ++r) t += src[e.src + (long)r * e.ld + c];
+    const float* col = src + e.src + c;
+    // sixteen rows requested at once, added in row order (the same sum as one row at a time -- 20 .. 80 dependent memory round trips,
+    // 49 us per launch on the optimizer's queue, which the backward pass is bound by)
+    int r = 0;
+    for (; r + 16 <= rows; r += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = col[(long)(r + u) * e.ld];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += v[u];
+    }
+    for (; r < rows; ++r) t += col[(long)r * e.ld];
     dst[e.dst + c] = t;
   }
 }
