@@ -47,7 +47,10 @@ class SecondStageTrainer:
         # latency-bound backward chain (86.2 -> 83.2 ms at c2).  Every step still runs one encoder pass.
         self.prefetch_stream = None
         if os.environ.get("IPOKE_NO_PREFETCH", "0") != "1" and torch.cuda.is_available():
-            self.prefetch_stream = torch.cuda.Stream()
+            # IPOKE_PREFETCH_STREAM=chain (developer A/B): the next batch's encoders behind the backward chain on the caller's own stream
+            # instead of a fourth busy stream
+            self.prefetch_stream = (torch.cuda.current_stream() if os.environ.get("IPOKE_PREFETCH_STREAM", "own") == "chain"
+                                    else torch.cuda.Stream())
             # IPOKE_ENC_GRAPH=1 (developer A/B, measured slower: PokeMotionModel.set_encoder_graph): the prefetched encoders replayed from
             # one captured hipGraph, gated on the GPU side at the END of the backward pass, instead of ~200 eager launches
             if os.environ.get("IPOKE_ENC_GRAPH", "0") == "1":
