@@ -141,12 +141,12 @@ def insitu_rooflines(run_step, B, z, dtype):
     run on, while the rest of the step -- side-stream weight gradients, optimizer slices -- runs as usual."""
     from ctypes import c_double, c_int
     L = _lib.lib()
-    tags = (c_int * 4)(1, 2, 3, 4)
-    counts, mean = (c_int * 4)(), (c_double * 4)()
+    tags = (c_int * 5)(1, 2, 3, 4, 6)        # 6 = IPOKE_TAG_NN_SQUARE: the conv2 data gradient read from the K-major weight (igemm_nn_glds)
+    counts, mean = (c_int * 5)(), (c_double * 5)()
     torch.cuda.synchronize()
     _lib.check(L.ipoke_timing_start())
     run_step()
-    _lib.check(L.ipoke_timing_stop(tags, 4, counts, mean))
+    _lib.check(L.ipoke_timing_stop(tags, 5, counts, mean))
     hid, M = 2048, B * 64
     gemm_gf = 2.0 * M * hid * hid / 1e9
     unit_gf = B * MCF_GFLOP[z] / 200.0             # 200 MaCowUnits (4 flows each): mean over the 15 channel widths
@@ -158,7 +158,13 @@ def insitu_rooflines(run_step, B, z, dtype):
                 "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "kernel": kernel, "launches_in_step": int(counts[k]),
                 "avg_launch_us": round(us, 2), "algorithmic_gflop_per_launch": round(gflop, 3), "measured": what}
     how = "HIP events around each launch on its own stream inside one full train step (in situ, side streams active)"
-    return [entry(0, f"igemm_nt_glds (NICE conv2 1x1 forward + data gradient, M={M} N=K=2048, {dtype})", gemm_gf, how),
+    split = counts[4] > 0        # bf16: the data gradient runs in its own kernel (K-major weight) and is reported on its own
+    head = entry(0, f"igemm_nt_glds (NICE conv2 1x1 forward{'' if split else ' + data gradient'}, M={M} N=K=2048, {dtype})", gemm_gf, how)
+    if split:
+        both = (counts[0] * mean[0] + counts[4] * mean[4]) / (counts[0] + counts[4])
+        head["forward_and_data_gradient_avg_launch_us"] = round(both, 2)          # the blended figure rounds 1-5 reported as `roofline`
+        head["forward_and_data_gradient_frac"] = round(gemm_gf / both * 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
+    return [head] + ([entry(4, f"igemm_nn_glds (NICE conv2 data gradient, weight read K-major, M={M} N=K=2048, {dtype})", gemm_gf, how)] if split else []) + [
             entry(1, f"igemm_tn_glds (NICE conv2 weight gradient, 2048x2048 over M={M}, {dtype}; side stream)", gemm_gf, how),
             entry(2, "macow_unit_fwd (4 masked-conv flows + 2 ActNorms per launch; mean over channel widths 8..64)", unit_gf, how),
             entry(3, "macow_unit_bwd (data path of the same unit; FLOPs counted as the forward's)", unit_gf, how)]
@@ -168,6 +174,7 @@ KERNEL_FAMILIES = {      # in-situ timing tags (include/ipoke_hip.h) -> what the
     1: "igemm_nt_glds, 1x1 square GEMM (NICE conv2 forward / data gradient)",
     2: "igemm_tn_glds, square weight gradient (NICE conv2)",
     5: "macow_unit_inv (4 masked-conv flows + 2 ActNorms inverted per launch, two samples per workgroup)",
+    6: "igemm_nn_glds, 1x1 square GEMM with the weight read K-major (NICE conv2 data gradient)",
     17: "igemm_nt / igemm_nt_glds implicit-GEMM convolutions (all shapes that no stationary-input kernel takes)",
     18: "conv3x3_s8 (3x3 on the 8x8 latent, stationary input)",
     19: "conv3x3_halo (3x3, halo-staged 8x16 patches)",
@@ -320,7 +327,9 @@ def secondary_subprocess(config, steps, warmup, timeout_s=600, extra=()):
             if ln.startswith("{"):
                 d = json.loads(ln)
                 keep = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "algorithmic_tflop_per_step_per_gpu",
-                                          "step_mfma_frac", "step_hbm_frac_12P", "hipgraph", "loss", "roofline", "roofline_other_kernels") if k in d}
+                                          "step_mfma_frac", "step_hbm_frac_12P", "hipgraph", "loss", "roofline", "roofline_other_kernels",
+                                          "executed_tflop_per_step_per_gpu", "step_mfma_frac_executed", "kernel_time_share", "roofline_note",
+                                          "handoff_timeouts") if k in d}
                 keep["workload"] = d["config"]["workload"]
                 return keep
         return {"error": (out.stderr.strip().splitlines() or ["no output"])[-1][:300]}
@@ -411,6 +420,15 @@ def secondary(args, cfg, rank, world, device):
         out = step(args.warmup + i)
     torch.cuda.synchronize(); D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    handoff_timeouts = None
+    if args.config == "c5":
+        handoff_timeouts = list(model.flow.engine.handoff_timeouts())
+        if any(handoff_timeouts):
+            raise SystemExit(f"in-launch hand-off time-outs {handoff_timeouts}: the timed steps are invalid")
+    # one extra step on EVERY rank (the data-parallel hook of c4 holds a collective) with the per-family event timing on -- taken right
+    # behind the timed eager loop, BEFORE the hipGraph / two-batches-in-flight variants of c5 (round 5 took it after them and its
+    # single-stream families summed to more than the step: the variants leave other streams and graph state behind)
+    fams = config_rooflines(lambda: step(args.warmup + args.steps), args.dtype) if args.config != "fvd" else []
     graph = None
     if args.config == "c5" and not args.quick:
         def timed_again():
@@ -451,8 +469,6 @@ def secondary(args, cfg, rank, world, device):
                  "what": "same K steps; flow_graph: reverse flow replayed as a captured hipGraph, decoder eager; full_graph: conditioning "
                          "encoders + reverse flow + ConvGRU + frame-batched decode replayed as ONE captured hipGraph (PokeMotionModel.set_sample_graph); "
                          "the headline value of this line is the eager path"}
-    # one extra step on EVERY rank (the data-parallel hook of c4 holds a collective) with the per-family event timing on
-    fams = config_rooflines(lambda: step(args.warmup + args.steps), args.dtype) if args.config != "fvd" else []
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {"metric": metric, "value": round(frames / (elapsed / args.steps), 2), "unit": "video-frames/sec", "n_gpus": world,
@@ -461,6 +477,12 @@ def secondary(args, cfg, rank, world, device):
                 "config": {"workload": workload, "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
                            "weights": "random init of the named architecture (no checkpoints offline)"},
                 "roofline": None}
+        # a kernel family runs on ONE stream: launches that sum to more than the step were not timed inside a representative step
+        bad = [f["kernel"] for f in fams if f["total_us_in_step"] * 1e-3 > ms]
+        if bad:
+            line["roofline_note"] = ("in-situ family timing rejected: " + "; ".join(bad) + f" sum to more than the {ms:.2f} ms step "
+                                     "(single-stream families): perturbed timing step, no roofline reported for this configuration")
+            fams = []
         if fams:                           # the dominant kernel family OF THIS configuration; the rest beside it
             line["roofline"] = fams[0]
             line["roofline_other_kernels"] = fams[1:5]
@@ -480,6 +502,8 @@ def secondary(args, cfg, rank, world, device):
                                 "kernel": "whole I3D batch (58 implicit-GEMM launches + 13 pools + resize), wall clock of the step"}
         if graph:
             line["hipgraph"] = graph
+        if handoff_timeouts is not None:
+            line["handoff_timeouts"] = handoff_timeouts
         if args.config == "c5":
             line["algorithmic_tflop_per_step_per_gpu"] = round(B * (FLOW_GFLOP[z] + 244.3) / 1e3, 2)     # un-hoisted
             line["step_mfma_frac"] = round(line["algorithmic_tflop_per_step_per_gpu"] / (ms * 1e-3) /
@@ -571,6 +595,9 @@ def main():
     marks[args.steps].record()
     torch.cuda.synchronize(); D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    handoff_timeouts = list(model.flow.engine.handoff_timeouts())      # (row-split unit, fused conv3 + coupling) launches that gave up: must be 0, 0
+    if any(handoff_timeouts):
+        raise SystemExit(f"in-launch hand-off time-outs {handoff_timeouts}: the timed steps are invalid")
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     loss_val = float(loss.item())
@@ -597,7 +624,7 @@ def main():
                                    f"({model.flow.engine.n_params / 1e9:.3f} B params), per-GPU batch {B}",
                        "global_batch": world * B, "clip_frames": T, "parallelism": f"dp{world}",
                        "weights": "random init of the named architecture (no checkpoints offline)"},
-            "loss": round(loss_val, 3),
+            "loss": round(loss_val, 3), "handoff_timeouts": handoff_timeouts,
             "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(per_step[0], 3), "ms_per_step_max": round(per_step[-1], 3),
             "algorithmic_tflop_per_step_per_gpu": round(step_tflop, 2),
             "step_mfma_frac": round(step_tflop / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS), 4),
@@ -621,6 +648,12 @@ def main():
                 line["secondary"]["c5_f32"] = secondary_subprocess("c5", 5, 2, extra=("--dtype", "f32", "--quick"))
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_clips, args.cpu_timeout)
+        # LAST key: every configuration's ms per step in one short object (a 2 KB tail of the line still shows all of them)
+        summ = {args.config if args.dtype == "bf16" else args.config + "_f32": round(ms, 3)}
+        for name, sec in line.get("secondary", {}).items():
+            summ[name] = sec.get("ms_per_step") if isinstance(sec, dict) else None
+        line["summary"] = {"ms_per_step": summ, "roofline_frac": line["roofline"]["frac"] if line.get("roofline") else None,
+                           "cpu_frames_per_s": (line.get("cpu_baseline") or {}).get("value")}
         print(json.dumps(line), flush=True)
     D.barrier()
 

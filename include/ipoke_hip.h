@@ -80,7 +80,8 @@ typedef struct {
   int64_t ldc;             /* row stride of C in elements                                           */
   int32_t c_coff, c_cstride; /* column n is stored at c_coff + n*c_cstride                          */
   int32_t splitk;          /* >1: fp32 partials C[z][M][ldc], epilogue skipped (bias/act by consumer);
-                              with c_accumulate: the K slices are atomically added into C instead      */
+                              with c_accumulate: the K slices are added into C instead (deterministically
+                              through acc_scratch below, with atomics without it)                       */
   /* optional output scatter (c_scatter = 1; dtype or fp32 outputs, splitk = 1, no dact): output position (n, od = 0, oh, ow) is
    * stored at row c_row0 + n*c_sn + oh*c_sh + ow*c_sw of C instead of row m -- the four sub-pixel phases of a stride-2
    * ConvTranspose2d (util.py:52-55: 3 x 3, padding 1, output_padding 1) run as four stride-1 convolutions with 1 / 2 / 2 / 4 taps
@@ -103,12 +104,24 @@ typedef struct {
    * ow*c_sw): the data gradient of a stride-2 Conv3d (motion_encoder.py:33-36, 80-91 layer transitions) run as one stride-1 convolution
    * per output parity class -- (1 or 2) taps per strided dimension instead of all 3 of which half fall between the gradient's samples */
   int64_t c_sd;
+  /* optional scratch of the DETERMINISTIC split-K accumulation (c_accumulate with splitk > 1): ipoke_conv_acc_scratch_bytes(M, Nout,
+   * splitk) bytes, 16-byte aligned, prepared once with ipoke_conv_acc_scratch_init and left in that state by every launch; one
+   * launch at a time.  The K slices park their tiles in the scratch, the workgroup that arrives last at a tile sums them in a fixed
+   * order and adds the sum to C (no atomics: bit-reproducible).  NULL: the slices are added to C with fp32 atomics, whose rounding
+   * depends on their arrival order. */
+  void* acc_scratch;
+  int64_t acc_scratch_bytes;
 } ipoke_conv_desc;
 
 int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* stream);
+/* size / one-time preparation of ipoke_conv_desc.acc_scratch for accumulating launches of at most M output rows, Nout columns and
+ * splitk K slices (the conv1 data gradient of NICEConvBlock, macow_utils.py:270, added into the gradient of the conditioning
+ * channels; the reference runs with deterministic=True, experiments/experiment.py:33, 86) */
+int64_t ipoke_conv_acc_scratch_bytes(int M, int Nout, int splitk);
+int ipoke_conv_acc_scratch_init(void* scratch, void* stream);
 
 /* Split count the library wants for the skinny 3x3 convolutions of the coupling nets (conv3 forward: split-K partial
- * slabs; conv1 data gradient: atomic accumulation) at M = 64*B output rows and Kc input channels -- callers size their
+ * slabs; conv1 data gradient: accumulation into the gradient state, ipoke_conv_desc.acc_scratch) at M = 64*B output rows and Kc input channels -- callers size their
  * partial-sum slabs with it and pass it as ipoke_conv_desc.splitk.  0: no preference (the stationary-input kernel does
  * not apply).  Reference call sites: conv3 / conv1 of NICEConvBlock (models/modules/INN/macow_utils.py:270-281,
  * 3x3, padding 1, on the 8x8 latent). */
@@ -480,6 +493,15 @@ int ipoke_flow_backward_pieces(ipoke_flow* f, const float* params, const int32_t
                                const float* d_out_nchw, const float* d_logdet, int B, float* grads, float* dx_nchw,
                                void* workspace, int npieces, void* ready_stream, ipoke_grad_ready_fn ready, void* user,
                                void* stream);
+/* The row-split MaCowUnit launches and the fused conv3 + coupling launches hand partial results between workgroups through two
+ * exchange scratches the flow owns; their spins are bounded and a spin that gives up lets the launch finish on garbage.  The engine
+ * polls the two time-out counters at the end of every eager pass (a one-thread kernel into pinned host memory + an event) and the NEXT
+ * entry point of the same flow fails with IPOKE_ERR_STATE (scratches re-initialised) once it sees a non-zero count; a pass issued on
+ * another stream than the previous one is ordered behind it (the scratches serve one launch at a time).  This call is the
+ * synchronising form for trainers / tests / benchmarks: it waits for the device and writes out[0] = time-outs of the unit launches,
+ * out[1] = of the coupling launches since the scratches were last (re-)initialised.  (The reference has no counterpart: a single
+ * PyTorch stream orders macow2.py:925-995 / macow_utils.py:270-281 by construction.) */
+int ipoke_flow_handoff_timeouts(ipoke_flow* f, uint32_t* out);
 
 
 /* ---------------------------------------------------------------------------------------------

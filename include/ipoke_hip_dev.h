@@ -27,7 +27,8 @@ int ipoke_spin_delay(int us, void* stream);
 
 /* In-situ timing for the benchmark's roofline objects: between ipoke_timing_start() and ipoke_timing_stop() every launch of
  * a tagged kernel family is bracketed by HIP events on the stream it is launched on (the rest of the step runs as usual).
- * Tags: 1 = ipoke_conv_forward with a 1x1 kernel and Nout = K >= 1024 (the NICE conv2 GEMM and its data gradient),
+ * Tags: 1 = ipoke_conv_forward with a 1x1 kernel and Nout = K >= 1024 (the NICE conv2 GEMM; its data gradient too unless that is
+ *       read from the K-major weight: tag 6),
  *       2 = ipoke_conv_wgrad / _batched of the same shape (a batched launch counts once per problem and its time is divided
  *       by the problem count), 3 = ipoke_macow_unit_fwd, 4 = ipoke_macow_unit_bwd. */
 #define IPOKE_TAG_NT_SQUARE 1
@@ -35,6 +36,7 @@ int ipoke_spin_delay(int us, void* stream);
 #define IPOKE_TAG_UNIT_FWD 3
 #define IPOKE_TAG_UNIT_BWD 4
 #define IPOKE_TAG_UNIT_INV 5
+#define IPOKE_TAG_NN_SQUARE 6     /* the same square GEMM with the weight read K-major (ipoke_conv_desc.w_kmajor): the conv2 data gradient */
 /* every other ipoke_conv_forward launch is tagged by the kernel family the dispatcher chose (IPOKE_TAG_CONV_BASE + IPOKE_KERNEL_*), every
  * other weight gradient IPOKE_TAG_WGRAD; both carry their algorithmic work: FLOPs = 2 * rows * Nout * taps * channels (transposed
  * strided forms: divided by the stride product -- the taps that meet an input pixel), bytes = input + weights + output, each once. */

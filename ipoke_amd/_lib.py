@@ -6,7 +6,7 @@ fails, a ``RuntimeError`` is raised.  Build the library with
 """
 import ctypes
 import os
-from ctypes import CFUNCTYPE, POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import CFUNCTYPE, POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IPOKE_LIB_PATH") or os.path.join(_HERE, "libipoke_hip.so")     # IPOKE_LIB_PATH: developer A/B of two builds in one GPU call
@@ -28,7 +28,8 @@ class ConvDesc(Structure):
         ("C", c_void_p), ("c_f32", c_int32), ("c_accumulate", c_int32), ("ldc", c_int64),
         ("c_coff", c_int32), ("c_cstride", c_int32), ("splitk", c_int32),
         ("c_scatter", c_int32), ("c_sn", c_int64), ("c_sh", c_int64), ("c_sw", c_int64), ("c_row0", c_int64),
-        ("row_scale", c_void_p), ("rs_images", c_int32), ("rs_stride", c_int32), ("w_kmajor", c_int32), ("c_sd", c_int64)]
+        ("row_scale", c_void_p), ("rs_images", c_int32), ("rs_stride", c_int32), ("w_kmajor", c_int32), ("c_sd", c_int64),
+        ("acc_scratch", c_void_p), ("acc_scratch_bytes", c_int64)]
 
 
 class WgradDesc(Structure):
@@ -269,6 +270,9 @@ SIGNATURES = {
     "ipoke_flow_create": (c_int, [POINTER(FlowConfig), POINTER(c_void_p)]),
     "ipoke_flow_destroy": (None, [_P]),
     "ipoke_flow_piece_ranges": (c_int, [_P, c_int, POINTER(c_int64), c_int]),
+    "ipoke_flow_handoff_timeouts": (c_int, [_P, POINTER(c_uint32)]),
+    "ipoke_conv_acc_scratch_bytes": (c_int64, [c_int, c_int, c_int]),
+    "ipoke_conv_acc_scratch_init": (c_int, [_P, _P]),
     "ipoke_flow_param_count": (c_int64, [_P]),
     "ipoke_flow_index_count": (c_int64, [_P]),
     "ipoke_flow_tensor_count": (c_int32, [_P]),

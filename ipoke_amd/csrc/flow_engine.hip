@@ -123,6 +123,14 @@ struct ipoke_flow {
   // conv3 of a coupling net and the coupling transform in one launch (ipoke_conv3x3_coupling; forward and reverse passes) and that
   // launch's exchange scratch (initialised once, left in that state by every launch; the chain's stream only)
   bool coupling_fuse = false; void* d_cxchg = nullptr;
+  // Both scratches carry a count of hand-off time-outs in their word 0 (a spin that gave up: the launch finished on garbage).  Every
+  // eager pass ends with a one-thread kernel that copies the two words into pinned host memory and an event; the next entry point
+  // (a) orders itself behind that event when it runs on ANOTHER stream (the scratches serve one launch at a time) and (b) once the
+  // event has completed reads the words: non-zero -> the scratches are re-initialised and the call fails with IPOKE_ERR_STATE.
+  // scratch of the deterministic split-K accumulation of the conv1 data gradients (ipoke_conv_desc.acc_scratch; the chain's stream only)
+  void* d_acc = nullptr; int64_t acc_bytes = 0;
+  unsigned* h_tmo = nullptr; hipEvent_t pass_ev = nullptr; hipStream_t pass_stream = nullptr; bool pass_recorded = false, pass_unchecked = false;
+  int64_t xchg_bytes = 0;
   // every masked-conv layer is differentiated inside a fused MaCowUnit launch, which also writes the layer's input in the matrix
   // cores' dtype: the shifted-conv weight gradients then read that copy through the LDS-DMA GEMM instead of the fp32 state
   bool mcf_xop = false;
@@ -801,6 +809,21 @@ static int ensure_device(ipoke_flow* f) {
     const int64_t nb = ipoke_macow_unit_xchg_bytes(f->cfg.max_batch, f->unit_split);
     IPK_HIP(hipMalloc(&f->d_xchg, nb));
     IPK_HIP(hipMemset(f->d_xchg, 0, nb));
+    f->xchg_bytes = nb;
+  }
+  if (!f->d_acc) {
+    static const bool atomics = getenv("IPOKE_DGRAD_ATOMICS") != nullptr;      // developer A/B: the order-dependent atomic accumulation of rounds 1-5
+    if (!atomics) {
+      f->acc_bytes = ipoke_conv_acc_scratch_bytes(f->cfg.max_batch * f->P, 64, 32);
+      IPK_HIP(hipMalloc(&f->d_acc, (size_t)f->acc_bytes));
+      int rc = ipoke_conv_acc_scratch_init(f->d_acc, nullptr); if (rc) return rc;
+      IPK_HIP(hipDeviceSynchronize());
+    }
+  }
+  if (!f->h_tmo) {
+    IPK_HIP(hipHostMalloc(reinterpret_cast<void**>(&f->h_tmo), 64, hipHostMallocMapped));
+    std::memset(f->h_tmo, 0, 64);
+    IPK_HIP(hipEventCreateWithFlags(&f->pass_ev, hipEventDisableTiming));
   }
   if (f->coupling_fuse && !f->d_cxchg) {
     IPK_HIP(hipMalloc(&f->d_cxchg, (size_t)ipoke_conv3x3_coupling_xchg_bytes()));
@@ -880,6 +903,9 @@ extern "C" void ipoke_flow_destroy(ipoke_flow* f) {
   if (f->d_redtab) (void)hipFree(f->d_redtab);
   if (f->d_xchg) (void)hipFree(f->d_xchg);
   if (f->d_cxchg) (void)hipFree(f->d_cxchg);
+  if (f->d_acc) (void)hipFree(f->d_acc);
+  if (f->pass_ev) (void)hipEventDestroy(f->pass_ev);
+  if (f->h_tmo) (void)hipHostFree(f->h_tmo);
   for (auto e : f->events) (void)hipEventDestroy(e);
   drop_graphs(f);
   if (f->side) (void)hipStreamDestroy(f->side);
@@ -1154,6 +1180,66 @@ static int with_graph(ipoke_flow* f, std::vector<uintptr_t> key, hipStream_t cal
   return IPOKE_OK;
 }
 
+// ---- hand-off scratch guard (see ipoke_flow::h_tmo) -------------------------------------------------------------------------------
+__global__ void handoff_poll_kernel(const unsigned* unit_xchg, const unsigned* coupling_xchg, unsigned* host_words) {
+  if (threadIdx.x == 0) {
+    host_words[0] = unit_xchg ? unit_xchg[0] : 0u;
+    host_words[1] = coupling_xchg ? coupling_xchg[0] : 0u;
+  }
+}
+static int reinit_scratch(ipoke_flow* f, hipStream_t s) {
+  if (f->d_xchg) IPK_HIP(hipMemsetAsync(f->d_xchg, 0, (size_t)f->xchg_bytes, s));
+  if (f->d_cxchg) { int rc = ipoke_conv3x3_coupling_xchg_init(f->d_cxchg, reinterpret_cast<void*>(s)); if (rc) return rc; }
+  return IPOKE_OK;
+}
+static bool stream_is_capturing(hipStream_t s) {      // the caller may be capturing the whole pass into a graph of its own (set_sample_graph)
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+static int pass_begin(ipoke_flow* f, hipStream_t s) {
+  int rc = ensure_device(f); if (rc) return rc;
+  if (!f->pass_recorded || stream_is_capturing(s)) return IPOKE_OK;
+  if (s != f->pass_stream) IPK_HIP(hipStreamWaitEvent(s, f->pass_ev, 0));      // one launch at a time per scratch: order behind the last pass
+  if (f->pass_unchecked) {
+    const hipError_t q = hipEventQuery(f->pass_ev);
+    if (q == hipSuccess) {
+      f->pass_unchecked = false;
+      const unsigned tu = f->h_tmo[0], tc = f->h_tmo[1];
+      if (tu | tc) {
+        rc = reinit_scratch(f, s); if (rc) return rc;
+        f->h_tmo[0] = f->h_tmo[1] = 0;
+        return fail(IPOKE_ERR_STATE, "hand-off time-out in an earlier pass of this flow (row-split unit launches: " + std::to_string(tu) +
+                                     ", fused conv3 + coupling launches: " + std::to_string(tc) +
+                                     "): the states / gradients of that pass are invalid; the exchange scratches have been re-initialised");
+      }
+    } else {
+      (void)hipGetLastError();       // hipErrorNotReady: the host is ahead, look again at the next entry
+    }
+  }
+  return IPOKE_OK;
+}
+static int pass_end(ipoke_flow* f, hipStream_t s) {
+  if (!f->h_tmo || (!f->d_xchg && !f->d_cxchg) || stream_is_capturing(s)) return IPOKE_OK;
+  hipLaunchKernelGGL(handoff_poll_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned*>(f->d_xchg),
+                     reinterpret_cast<const unsigned*>(f->d_cxchg), f->h_tmo);
+  IPK_LAUNCH_CHECK();
+  IPK_HIP(hipEventRecord(f->pass_ev, s));
+  f->pass_stream = s; f->pass_recorded = true; f->pass_unchecked = true;
+  return IPOKE_OK;
+}
+/* Synchronising query: waits for the last pass of this flow and writes the hand-off time-out counts since the scratches were last
+ * (re-)initialised: out[0] row-split MaCowUnit launches, out[1] fused conv3 + coupling launches.  Returns IPOKE_OK; non-zero counts
+ * mean that a pass finished on garbage (the next entry point fails with IPOKE_ERR_STATE and re-initialises the scratches). */
+extern "C" int ipoke_flow_handoff_timeouts(ipoke_flow* f, uint32_t* out) {
+  IPK_REQUIRE(f && out, "null argument");
+  out[0] = out[1] = 0;
+  IPK_HIP(hipDeviceSynchronize());        // (also covers passes replayed from a caller's own graph, which carry no poll)
+  if (f->d_xchg) IPK_HIP(hipMemcpy(&out[0], f->d_xchg, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (f->d_cxchg) IPK_HIP(hipMemcpy(&out[1], f->d_cxchg, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return IPOKE_OK;
+}
+
 static int run_forward(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow, const float* x_nchw,
                        const float* cond_nchw, int B, float* out_nchw, float* logdet, void* workspace, int save, int init,
                        float* params_mut, hipStream_t stream_h) {
@@ -1298,10 +1384,11 @@ extern "C" int ipoke_flow_forward(ipoke_flow* f, const float* params, const int3
   IPK_REQUIRE(f != nullptr, "null flow handle");
   std::vector<uintptr_t> key = {1, (uintptr_t)params, (uintptr_t)perm, (uintptr_t)shadow, (uintptr_t)x_nchw, (uintptr_t)cond_nchw,
                                 (uintptr_t)B, (uintptr_t)out_nchw, (uintptr_t)logdet, (uintptr_t)workspace, (uintptr_t)save_for_backward};
-  int rc = with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
+  int rc = pass_begin(f, reinterpret_cast<hipStream_t>(stream)); if (rc) return rc;
+  rc = with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
     return run_forward(f, params, perm, shadow, x_nchw, cond_nchw, B, out_nchw, logdet, workspace, save_for_backward, 0, nullptr, s);
   });
-  if (rc == IPOKE_OK) { f->last_fwd_B = B; f->have_saved = save_for_backward != 0; }
+  if (rc == IPOKE_OK) { f->last_fwd_B = B; f->have_saved = save_for_backward != 0; rc = pass_end(f, reinterpret_cast<hipStream_t>(stream)); }
   return rc;
 }
 
@@ -1415,9 +1502,11 @@ extern "C" int ipoke_flow_reverse(ipoke_flow* f, const float* params, const int3
   IPK_REQUIRE(f != nullptr, "null flow handle");
   std::vector<uintptr_t> key = {2, (uintptr_t)params, (uintptr_t)perm, (uintptr_t)shadow, (uintptr_t)z_nchw, (uintptr_t)cond_nchw,
                                 (uintptr_t)B, (uintptr_t)x_nchw, (uintptr_t)workspace};
-  return with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
+  int rc = pass_begin(f, reinterpret_cast<hipStream_t>(stream)); if (rc) return rc;
+  rc = with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
     return run_reverse(f, params, perm, shadow, z_nchw, cond_nchw, B, x_nchw, workspace, s);
   });
+  return rc ? rc : pass_end(f, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1495,6 +1584,19 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   hipStream_t rs = ready_stream ? ready_stream : s;
   const std::vector<std::pair<int, int>> pieces = backward_pieces(f, npieces);            // (lowest unit, highest unit)
   std::function<int()> flush_nice_fn = []() { return (int)IPOKE_OK; };
+  std::vector<std::pair<int64_t, int64_t>> deferred_adam;      // parameter ranges whose native update waits for the end of the pass (IPOKE_ADAM_DEFER)
+  auto native_adam_range = [&](int64_t b0, int64_t b1, int max_blocks) -> int {
+    const ipoke_flow::NativeAdam& A = f->nadam;
+    float* pm = const_cast<float*>(params);
+    void* rstream = reinterpret_cast<void*>(rs);
+    if (f->c2_straight)      // conv2 tensors: update + their one operand in the same linear pass; the rest: update, then relayout
+      return adam_range(f, pm, grads, A.m, A.v, A.vmax, const_cast<void*>(shadow), b0, b1, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
+                        A.grad_scale, max_blocks, rstream);
+    int r = ipoke_adam_amsgrad_step_grid(pm + b0, grads + b0, A.m + b0, A.v + b0, A.vmax + b0, b1 - b0, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
+                                         A.grad_scale, max_blocks, rstream);
+    if (r) return r;
+    return prepare_range(f, params, const_cast<void*>(shadow), b0, b1, false, rstream);
+  };
   auto finish_piece = [&](int lvl_lo, int lvl_hi, int piece) -> int {
     int r = flush_nice_fn(); if (r) return r;
     r = flush_mcf(); if (r) return r;
@@ -1530,7 +1632,15 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       if (r) return r;
     }
     static const bool probe_skip_adam = getenv("IPOKE_PROBE_SKIP_ADAM") != nullptr;      // developer probe: what the optimizer costs the step (parameters stay put)
-    if (f->nadam.on && !probe_skip_adam) {
+    // IPOKE_ADAM_DEFER=k: the update + shadow refresh of the FIRST k pieces (the top levels: the next forward pass reaches them last) is
+    // queued behind the last piece's instead of beside the backward chain -- it then runs in the step-boundary hole, where the only other
+    // work is the next batch's frozen encoders (latency-bound launches that leave HBM idle), and the optimizer queue's backlog inside
+    // the backward pass (busy 24.7 of ~29 ms, profiles/r05_bench_steady.txt) shrinks by that share.
+    static const int adam_defer = getenv("IPOKE_ADAM_DEFER") ? atoi(getenv("IPOKE_ADAM_DEFER")) : 0;
+    if (f->nadam.on && !probe_skip_adam && piece < adam_defer && piece + 1 < (int)pieces.size()) {
+      for (int kind = 0; kind < 3; ++kind)
+        if (p0[kind] >= 0 && p1[kind] > p0[kind]) deferred_adam.push_back({p0[kind], p1[kind]});
+    } else if (f->nadam.on && !probe_skip_adam) {
       // single-GPU training: the update of the piece's ranges and the refresh of their shadows, natively, on the ready stream
       ipoke_flow::NativeAdam A = f->nadam;
       {   // developer A/B (IPOKE_ADAM_EARLY_BLOCKS=n, IPOKE_ADAM_LATE_PIECES=k): the optimizer of all but the last k pieces on a smaller grid --
@@ -1539,20 +1649,16 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
         static const int late = getenv("IPOKE_ADAM_LATE_PIECES") ? atoi(getenv("IPOKE_ADAM_LATE_PIECES")) : 3;
         if (early > 0 && piece < (int)pieces.size() - late) A.max_blocks = early;
       }
-      float* pm = const_cast<float*>(params);
       for (int kind = 0; kind < 3; ++kind) {
         if (p0[kind] < 0 || p1[kind] <= p0[kind]) continue;
-        const int64_t b0 = p0[kind], n = p1[kind] - p0[kind];
-        if (f->c2_straight) {      // conv2 tensors: update + their one operand in the same linear pass; the rest: update, then relayout
-          r = adam_range(f, pm, grads, A.m, A.v, A.vmax, const_cast<void*>(shadow), b0, b0 + n, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
-                         A.grad_scale, A.max_blocks, rstream);
-          if (r) return r;
-          continue;
+        r = native_adam_range(p0[kind], p1[kind], A.max_blocks); if (r) return r;
+      }
+      if (piece + 1 == (int)pieces.size()) {      // the last piece: what was held back goes out now, top levels last
+        static const int defer_blocks = getenv("IPOKE_ADAM_DEFER_BLOCKS") ? atoi(getenv("IPOKE_ADAM_DEFER_BLOCKS")) : 0;
+        for (auto it = deferred_adam.rbegin(); it != deferred_adam.rend(); ++it) {
+          r = native_adam_range(it->first, it->second, defer_blocks > 0 ? defer_blocks : f->nadam.max_blocks); if (r) return r;
         }
-        r = ipoke_adam_amsgrad_step_grid(pm + b0, grads + b0, A.m + b0, A.v + b0, A.vmax + b0, n, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
-                                         A.grad_scale, A.max_blocks, rstream);
-        if (r) return r;
-        r = prepare_range(f, params, const_cast<void*>(shadow), b0, b0 + n, false, rstream); if (r) return r;
+        deferred_adam.clear();
       }
     }
     if (ready)
@@ -1758,6 +1864,9 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
         set_a_dense(d, dp1, hid, hid);
         d.W = l.sh(op.sh_c1t); d.ldw = 9 * hid; d.Nout = op.cin; d.C = gout; d.c_f32 = 1; d.c_accumulate = 1; d.ldc = l.ld;
         d.c_coff = op.z_off; d.c_cstride = op.z_stride; d.splitk = nice_splitk(l);
+        // the K slices meet in the engine's scratch and are summed in a fixed order (bit-reproducible steps); sub-batch lanes
+        // (developer switch) run several of these launches at once and keep the atomic form
+        if (lanes.size() == 1 && op.cin <= 64) { d.acc_scratch = f->d_acc; d.acc_scratch_bytes = f->acc_bytes; }
         rc = ipoke_conv_forward(&d, l.dtype, l.stream()); if (rc) return rc;
       }
     }
@@ -1792,9 +1901,11 @@ extern "C" int ipoke_flow_backward(ipoke_flow* f, const float* params, const int
     return fail(IPOKE_ERR_STATE, "ipoke_flow_backward needs a preceding ipoke_flow_forward(save_for_backward=1) with the same batch");
   std::vector<uintptr_t> key = {3, (uintptr_t)params, (uintptr_t)perm, (uintptr_t)shadow, (uintptr_t)d_out_nchw, (uintptr_t)d_logdet,
                                 (uintptr_t)B, (uintptr_t)grads, (uintptr_t)dx_nchw, (uintptr_t)workspace};
-  return with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
+  int rc = pass_begin(f, reinterpret_cast<hipStream_t>(stream)); if (rc) return rc;
+  rc = with_graph(f, std::move(key), reinterpret_cast<hipStream_t>(stream), [&](hipStream_t s) {
     return run_backward(f, params, perm, shadow, d_out_nchw, d_logdet, B, grads, dx_nchw, workspace, s);
   });
+  return rc ? rc : pass_end(f, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int ipoke_flow_backward_pieces(ipoke_flow* f, const float* params, const int32_t* perm, const void* shadow,
@@ -1805,6 +1916,8 @@ extern "C" int ipoke_flow_backward_pieces(ipoke_flow* f, const float* params, co
   if (!f->have_saved || f->last_fwd_B != B)
     return fail(IPOKE_ERR_STATE, "ipoke_flow_backward needs a preceding ipoke_flow_forward(save_for_backward=1) with the same batch");
   // host callbacks cannot be captured: always eager
-  return run_backward(f, params, perm, shadow, d_out_nchw, d_logdet, B, grads, dx_nchw, workspace,
-                      reinterpret_cast<hipStream_t>(stream), npieces, reinterpret_cast<hipStream_t>(ready_stream), ready, user);
+  int rc = pass_begin(f, reinterpret_cast<hipStream_t>(stream)); if (rc) return rc;
+  rc = run_backward(f, params, perm, shadow, d_out_nchw, d_logdet, B, grads, dx_nchw, workspace,
+                    reinterpret_cast<hipStream_t>(stream), npieces, reinterpret_cast<hipStream_t>(ready_stream), ready, user);
+  return rc ? rc : pass_end(f, reinterpret_cast<hipStream_t>(stream));
 }

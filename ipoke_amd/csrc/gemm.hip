@@ -42,6 +42,9 @@ struct NtParams {
   int c_scatter; long c_sn, c_sd, c_sh, c_sw, c_row0;      // output row of position (n, od, oh, ow) when c_scatter (ipoke_conv_desc)
   int w_kmajor;        // 1: W is [Ktot][ldw] -- element (k, n) at W[k * ldw + n] (1x1 kernels: the straight copy of a weight used by its own data gradient)
   const float* row_scale; int rs_images, rs_stride;  // accumulators of image n are multiplied by row_scale[(n / rs_images) * rs_stride] before the bias
+  // deterministic split-K accumulation (c_acc && splitk > 1, ipoke_conv_desc.acc_scratch): per-tile arrival counters (zero between
+  // launches) and the slab area [tile][split][BM][BN] fp32; null -> the K slices are added with atomics (order-dependent rounding)
+  unsigned* acc_cnt; float* acc_part; long acc_part_bytes;
 #ifdef IPOKE_GEMM_STAMPS
   long long* stamps = nullptr;   // probe build only (scripts/probe_gemm_stamps.py): 4 wall-clock stamps per workgroup
 #endif
@@ -212,7 +215,10 @@ __device__ __forceinline__ int image_of_row(const GeomDev& g, int m) {
   return g.pow2 ? m >> (g.lDo + g.lHo + g.lWo) : m / g.S;
 }
 
-template <typename T, int WM, int WN, int MREP, int NREP, int NTHR = WM * WN * 64>
+// DET: the instantiation carries the deterministic split-K accumulation (only the skinny tiles a <= 64-column accumulating launch can
+// reach: the extra live ranges cost the wide tiles registers, two of them spilled)
+template <int WM, int WN, int MREP, int NREP> struct NtDet { static constexpr bool value = WM == 4 && WN == 1 && MREP == 1 && NREP == 4; };
+template <typename T, int WM, int WN, int MREP, int NREP, int NTHR = WM * WN * 64, bool DET = false>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP][NREP], unsigned char* smem, int m0, int n0,
                                             int wm, int wn, int z, bool writer = true) {
   typedef typename Pack4<T>::type pack_t;
@@ -221,6 +227,65 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[MREP
   const GeomDev& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr int G4F = BN / 4;
+  if constexpr (DET) if (p.splitk > 1 && p.c_acc && p.acc_part != nullptr) {
+    // Deterministic accumulation of the K slices into an fp32 tensor that already holds a value (the conv1 data gradient of every
+    // coupling net adds into the gradient state, flow_engine.hip; the reference trains with deterministic=True,
+    // experiments/experiment.py:33, 86).  The counter form of cdna_hip_programming.md Guideline 16: every slice parks its tile in
+    // the slab [tile][z] with write-through (sc1) stores, drains them, and draws a ticket from the tile's counter; the workgroup
+    // that draws the last ticket -- whichever it is -- reads the splitk slabs back with sc1 loads, sums them in a FIXED order
+    // (groups of eight slices pairwise, the groups in order) and adds the sum to C with plain read-modify-writes: every element has
+    // exactly one writer and the rounding no longer depends on the order in which the slices finish.  No spin, nothing to time out;
+    // the counter is back at zero when the launch ends.
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    __syncthreads();
+    if (writer) {
+      unsigned char* base = smem + (wm * MREP * 16 + (lane & 15)) * EP + (wn * NREP * 16 + (lane >> 4) * 4) * 4;
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(base + i * 16 * EP + j * 64) = acc[i][j];
+    }
+    __syncthreads();
+    const int tile = (m0 / BM) * p.tiles_n + n0 / BN;
+    constexpr int SLAB = BM * BN * 4;                      // bytes
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.acc_part) + (long)tile * p.splitk * SLAB, 0,
+                                                        p.splitk * SLAB, 0x00020000);
+    for (int idx = tid; idx < BM * G4F; idx += NTHR) {
+      const int row = idx / G4F, c4 = idx - row * G4F;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * EP + c4 * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, z * SLAB + (row * BN + 4 * c4) * 4, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's slab stores have reached the memory side
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);    // (the staging tile is dead)
+    if (tid == 0) *flag = __hip_atomic_fetch_add(p.acc_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != (unsigned)(p.splitk - 1)) return;
+    if (tid == 0) __hip_atomic_store(p.acc_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int idx = tid; idx < BM * G4F; idx += NTHR) {
+      const int row = idx / G4F, c4 = idx - row * G4F;
+      const int m = m0 + row, n = n0 + 4 * c4;
+      if (m >= g.M || n >= p.Nout) continue;
+      const int off = (row * BN + 4 * c4) * 4;
+      f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < p.splitk; s0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                      // (always load, clamp the index: no branch around a load)
+          const int sl = s0 + k < p.splitk ? s0 + k : p.splitk - 1;
+          v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, sl * SLAB + off, 0, 16));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (s0 + k >= p.splitk) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+      }
+      float* Cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + p.c_coff;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.Nout) Cp[(long)(n + r) * p.c_cstride] += sum[r];
+    }
+    return;
+  }
   if constexpr ((BM * G4F) % NTHR == 0 && NTHR % G4F == 0) {
     constexpr int ITER = BM * G4F / NTHR, RSTEP = NTHR / G4F;
     const bool fast = p.splitk == 1 && !p.c_scatter && !p.row_scale && !p.c_f32 && (p.Nout & 3) == 0 && m0 + BM <= g.M && n0 + BN <= p.Nout &&
@@ -503,7 +568,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     }
   }
 
-  nt_epilogue<T, WM, WN, MREP, NREP>(p, acc, smem, m0, n0, wm, wn, z);
+  nt_epilogue<T, WM, WN, MREP, NREP, WM * WN * 64, NtDet<WM, WN, MREP, NREP>::value>(p, acc, smem, m0, n0, wm, wn, z);
 }
 
 // =============================================================================================
@@ -786,7 +851,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
         for (int j = 0; j < NREP; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(st2 + i * 16 * EP + j * 64);
     }
   }
-  nt_epilogue<T, WM, WN, MREP, NREP, NTHR>(p, acc, smem, m0, n0, wm, wn, z, wk == 0);
+  nt_epilogue<T, WM, WN, MREP, NREP, NTHR, WK == 1 && NtDet<WM, WN, MREP, NREP>::value>(p, acc, smem, m0, n0, wm, wn, z, wk == 0);
   GEMM_STAMP(3);
 }
 
@@ -1072,6 +1137,28 @@ constexpr size_t kLdsC64 = 9 * 64 * 128 + 2 * 41 * 1024 + 1024, kLdsHalo16 = 2 *
     std::call_once(ipk_once, [&]() { ipk_rc = set_lds(kern, bytes); });                 \
     if (ipk_rc) return ipk_rc;                                                          \
   } while (0)
+
+// Scratch of the deterministic split-K accumulation (ipoke_conv_desc.acc_scratch): 4096 tile counters, then the slabs.
+static constexpr long kAccCounterBytes = 4096 * 4;
+extern "C" int64_t ipoke_conv_acc_scratch_bytes(int M, int Nout, int splitk) {
+  if (M < 1 || Nout < 1 || splitk < 1) return -1;
+  // upper bound over every tile shape the dispatcher may choose: rows padded to a 160-row tile, columns to a 128-column one
+  return kAccCounterBytes + (int64_t)splitk * ((int64_t)M + 160) * round_up(Nout, 128) * 4;
+}
+extern "C" int ipoke_conv_acc_scratch_init(void* scratch, void* stream) {
+  IPK_REQUIRE(scratch != nullptr, "null scratch");
+  IPK_HIP(hipMemsetAsync(scratch, 0, (size_t)kAccCounterBytes, reinterpret_cast<hipStream_t>(stream)));
+  return IPOKE_OK;
+}
+// the launchers call this once the tile shape is known
+static int acc_scratch_fits(const NtParams& p, int BM, int BN, bool det_capable) {
+  if (!(p.splitk > 1 && p.c_acc && p.acc_part)) return IPOKE_OK;
+  IPK_REQUIRE(det_capable, "deterministic accumulation is built into the skinny tiles only (Nout <= 64, default dispatch)");
+  const long tiles = (long)p.tiles_m * p.tiles_n;
+  IPK_REQUIRE(tiles <= 4096 && tiles * p.splitk * BM * BN * 4 <= p.acc_part_bytes && (long)p.splitk * BM * BN * 4 < (1L << 31),
+              "accumulation scratch too small for this launch (ipoke_conv_acc_scratch_bytes)");
+  return IPOKE_OK;
+}
 
 // XCD-aware tile -> block mapping: XCD x (= blockIdx % 8) owns a (tiles_m/xa) x (tiles_n/xb) sub-grid so
 // that its private L2 holds one slab of A rows and one slab of W rows; (xa, xb) minimises L2 fill bytes.
@@ -1397,7 +1484,7 @@ __device__ __forceinline__ void conv3x3_s8_body(const NtParams& p, const Couplin
       if (round == 0) __syncthreads();
     }
   }
-  nt_epilogue<T, 2, 1, MREP, NREP, NTHR>(p, acc, smem, m0, 0, mh, 0, z, kq == 0);
+  nt_epilogue<T, 2, 1, MREP, NREP, NTHR, true>(p, acc, smem, m0, 0, mh, 0, z, kq == 0);
   } else {
     // ---- the K splits of this row tile meet inside the launch (reduce-scatter), then the rows' owners apply the coupling ----
     // Before: 16 partial tiles -> 5 MB of fp32 slabs -> kernel boundary -> affine_* re-reads and sums them (14 us + boundary +
@@ -2447,6 +2534,7 @@ static int launch_nt_glds_impl(NtParams& p, hipStream_t s) {
   if (p.splitk < 1) p.splitk = 1;
   p.kb_per_split = ceil_div(nkb, p.splitk);
   pick_xcd_map(p);
+  { int rc = acc_scratch_fits(p, BM, BN, WK == 1 && NtDet<WM, WN, MREP, NREP>::value); if (rc) return rc; }
   size_t lds = (size_t)NSTAGE * KPB * (BM + BN) * 128 + WM * WN * WK * 64 * 16 + 256 * sizeof(int);
   if (lds < (size_t)WK * BM * (BN * 4 + 16)) lds = (size_t)WK * BM * (BN * 4 + 16);      // epilogue staging (+ the K halves' hand-over)
   auto kern = igemm_nt_glds_kernel<T, WM, WN, MREP, NREP, NSTAGE, KPB, SIMPLE, WK>;
@@ -2475,6 +2563,7 @@ static int launch_nt(NtParams& p, hipStream_t s) {
   if (p.splitk < 1) p.splitk = 1;
   p.kb_per_split = ceil_div(nkb, p.splitk);
   pick_xcd_map(p);
+  { int rc = acc_scratch_fits(p, BM, BN, NtDet<WM, WN, MREP, NREP>::value); if (rc) return rc; }
   const long nt = (long)p.tiles_m * p.tiles_n;
   size_t lds = 2 * (BM + BN) * kPitch;
   if (lds < (size_t)BM * (BN * 4 + 16)) lds = (size_t)BM * (BN * 4 + 16);
@@ -2507,6 +2596,7 @@ static int launch_conv3x3_s8(NtParams& p, hipStream_t s) {
   p.kb_per_split = ceil_div(p.Kc / 64, p.splitk);
   dim3 grid((unsigned)p.tiles_m, (unsigned)p.splitk);
   static const int n32 = getenv("IPOKE_S8_N32") ? atoi(getenv("IPOKE_S8_N32")) : 1;      // developer A/B: 0 keeps the 64-column kernel for narrow outputs
+  { int rc = acc_scratch_fits(p, BM, n32 && p.Nout <= 32 ? 32 : 64, true); if (rc) return rc; }
   if (n32 && p.Nout <= 32) {
     const size_t lds = 2 * BM * 128 + 256 + 12 * 32 * 128 + 512 * 16;
     auto kern = conv3x3_s8n32_kernel;
@@ -3360,8 +3450,16 @@ static int conv_params(NtParams& p, const ipoke_conv_desc* d, int dtype) {
     const long lim = d->ldc - d->c_coff;
     p.n_pad = (int)(round_up(d->Nout, e16) < lim ? round_up(d->Nout, e16) : lim);
   }
+  p.acc_cnt = nullptr; p.acc_part = nullptr; p.acc_part_bytes = 0;
   if (p.splitk > 1 && d->c_accumulate) {
-    IPK_REQUIRE(d->c_f32 && !d->bias && d->act == IPOKE_ACT_NONE && !d->dact, "atomic split-K accumulates raw fp32 sums only");
+    IPK_REQUIRE(d->c_f32 && !d->bias && d->act == IPOKE_ACT_NONE && !d->dact, "split-K accumulates raw fp32 sums only");
+    if (d->acc_scratch) {
+      IPK_REQUIRE(((uintptr_t)d->acc_scratch & 15) == 0 && d->acc_scratch_bytes > kAccCounterBytes && d->Nout <= 64,
+                  "bad accumulation scratch (16-byte aligned, ipoke_conv_acc_scratch_bytes; Nout <= 64)");
+      p.acc_cnt = reinterpret_cast<unsigned*>(d->acc_scratch);
+      p.acc_part = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(d->acc_scratch) + kAccCounterBytes);
+      p.acc_part_bytes = d->acc_scratch_bytes - kAccCounterBytes;
+    }
   } else if (p.splitk > 1) {
     IPK_REQUIRE(d->ldc % 4 == 0 && d->ldc >= d->Nout, "split-K partials need ldc >= Nout, multiple of 4");
   } else if (!d->c_f32) {
@@ -3387,7 +3485,7 @@ extern "C" int ipoke_conv_forward(const ipoke_conv_desc* d, int dtype, void* str
   if (g_gemm_stamps) g_gemm_stamps += 4 * 4096;                // one slab of 4096 workgroups per launch
 #endif
   const bool square = p.g.taps == 1 && d->Nout == p.Ktot && d->Nout >= 1024 && p.splitk == 1;
-  TimedScope ts(square ? IPOKE_TAG_NT_SQUARE : IPOKE_TAG_CONV_BASE, s);
+  TimedScope ts(square ? (d->w_kmajor ? IPOKE_TAG_NN_SQUARE : IPOKE_TAG_NT_SQUARE) : IPOKE_TAG_CONV_BASE, s);
   p.w_kmajor = d->w_kmajor;
   static const bool clog = getenv("IPOKE_CONV_LOG") != nullptr;      // developer probe: every call timed on its own (serialises the stream)
   hipEvent_t le0 = nullptr, le1 = nullptr;

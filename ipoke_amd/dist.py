@@ -51,6 +51,13 @@ def allreduce_flat_(flat, n_buckets=8):
     return flat
 
 
+def allreduce_(t):
+    """In-place sum of ``t`` over all ranks (blocking on the stream's timeline; identity in single-process runs)."""
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def allreduce_async(t):
     """Start the sum of ``t`` over all ranks on the current stream's timeline; returns a handle whose ``wait()`` orders the
     then-current stream after the collective (a no-op handle in single-process runs)."""

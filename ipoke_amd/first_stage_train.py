@@ -1302,6 +1302,8 @@ class FirstStageTrainer:
         """``vgg_loss`` (ipoke_amd.vgg.VGGLoss) with ``w_vgg`` adds the perceptual term of first_stage_motion_model.py:263-271;
         ``gamma``: per-epoch learning-rate decay (first_stage.yaml:45), applied by ``on_epoch_end``."""
         self.model = model
+        from . import warn_if_queues_late
+        warn_if_queues_late("FirstStageTrainer")
         self.gamma = float(gamma)
         self.vgg_loss, self.w_vgg = vgg_loss, float(w_vgg)
         if self.w_vgg != 0.0 and vgg_loss is None:
@@ -1333,6 +1335,7 @@ class FirstStageTrainer:
         # Lightning run); the power iteration sees rank-local batches only through the weights, which are equal on every rank, so one
         # broadcast per step keeps sigma identical instead of letting round-off drift it apart
         sn_bufs = [b for k, b in self.model.named_buffers() if k.endswith("weight_u") or k.endswith("weight_v")]
+        checked = {"mask": None}
 
         def sync_grads():
             have, missing = [], []
@@ -1342,6 +1345,18 @@ class FirstStageTrainer:
             # zeros, not the reduced values of the previous step
             for v, _ in missing:
                 v.zero_()
+            # ... and the set of such parameters must be the SAME on every rank: the optimizer skips a parameter whose .grad is None, so a
+            # parameter that is missing here and present elsewhere would be updated there only and the replicas would diverge.  Verified
+            # with one small all-reduce whenever the local set changes (normally once).
+            mask = tuple(p.grad is None for p in self.params)
+            if mask != checked["mask"]:
+                cnt = torch.tensor([float(m_) for m_ in mask], dtype=torch.float32, device=self._dp_flat.device)
+                D.allreduce_(cnt)
+                bad = [i for i, c in enumerate(cnt.tolist()) if c not in (0.0, float(world))]
+                if bad:
+                    raise RuntimeError(f"data-parallel first stage: {len(bad)} parameter(s) (first index {bad[0]}) have a gradient on some ranks "
+                                       "only; every rank must differentiate the same set of parameters")
+                checked["mask"] = mask
             if hasattr(torch, "_foreach_copy_"):
                 torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
             else:
@@ -1350,8 +1365,18 @@ class FirstStageTrainer:
             D.allreduce_flat_(self._dp_flat, n_buckets)
             for v, p in have:
                 p.grad = v
-            for b in sn_bufs:
-                D.broadcast_(b, src=0)
+            if sn_bufs:          # ONE collective for all power-iteration vectors (two per spectral-norm layer before)
+                flat_uv = torch.cat([b.reshape(-1) for b in sn_bufs])
+                D.broadcast_(flat_uv, src=0)
+                o = 0
+                pieces = []
+                for b in sn_bufs:
+                    pieces.append(flat_uv[o:o + b.numel()].view_as(b)); o += b.numel()
+                if hasattr(torch, "_foreach_copy_"):
+                    torch._foreach_copy_(sn_bufs, pieces)
+                else:
+                    for b, q in zip(sn_bufs, pieces):
+                        b.copy_(q)
         self.grad_hook = sync_grads
 
 

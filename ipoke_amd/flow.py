@@ -225,6 +225,21 @@ class FlowEngine:
                                           ptr(st["cond"]), B, ptr(st["out"]), ptr(ws), _lib.current_stream()))
         return st["out"].clone()
 
+    def handoff_timeouts(self):
+        """(unit launches, fused conv3 + coupling launches) whose in-launch hand-off gave up since the exchange scratches were last
+        initialised (``ipoke_flow_handoff_timeouts``; synchronises the device).  Anything but (0, 0) means a pass finished on garbage;
+        the engine's next entry point raises by itself, this is the explicit check of trainers, tests and the benchmark."""
+        from ctypes import c_uint32
+        out = (c_uint32 * 2)()
+        check(self.lib.ipoke_flow_handoff_timeouts(self.handle, out))
+        return int(out[0]), int(out[1])
+
+    def assert_handoffs_clean(self):
+        tu, tc = self.handoff_timeouts()
+        if tu or tc:
+            raise RuntimeError(f"in-launch hand-off timed out ({tu} row-split unit launches, {tc} fused conv3 + coupling launches): "
+                               "the results of those passes are invalid")
+
     def backward(self, d_out, d_logdet, need_dx=False):
         self._need_gpu()
         B = d_out.shape[0]

@@ -15,6 +15,8 @@ class SecondStageTrainer:
 
     def __init__(self, model, n_grad_buckets=24, overlap=None):
         self.model = model
+        from . import warn_if_queues_late
+        warn_if_queues_late("SecondStageTrainer")
         tr, bs = model.config["training"], model.config["data"]["batch_size"]
         # experiments/experiment.py:81-88: accumulate_grad_batches = ceil(min_acc_batch_size / batch_size) when that is larger than the
         # batch (1 for every shipped config: 3 < 20).  Lightning 1.1.7 divides each micro-batch loss by the count and steps the
@@ -47,10 +49,13 @@ class SecondStageTrainer:
         # latency-bound backward chain (86.2 -> 83.2 ms at c2).  Every step still runs one encoder pass.
         self.prefetch_stream = None
         if os.environ.get("IPOKE_NO_PREFETCH", "0") != "1" and torch.cuda.is_available():
-            # IPOKE_PREFETCH_STREAM=chain (developer A/B): the next batch's encoders behind the backward chain on the caller's own stream
-            # instead of a fourth busy stream
-            self.prefetch_stream = (torch.cuda.current_stream() if os.environ.get("IPOKE_PREFETCH_STREAM", "own") == "chain"
-                                    else torch.cuda.Stream())
+            # Stream budget: the step is tuned for FOUR busy streams -- chain, weight gradients, ready / optimizer, encoder
+            # prefetch.  A fifth busy stream costs +18 ms per step whatever it carries (measured with a second weight-gradient and a
+            # second optimizer stream, any GPU_MAX_HW_QUEUES).  At world > 1 RCCL's own stream is busy during the backward pass, so the
+            # next batch's encoders go behind the backward chain on the caller's stream there (measured on one GPU: +1.5 ms against the
+            # prefetch stream, i.e. 52.3 vs 50.8 ms); one GPU keeps the prefetch stream.  IPOKE_PREFETCH_STREAM=own|chain overrides.
+            where = os.environ.get("IPOKE_PREFETCH_STREAM", "own" if self.world == 1 else "chain")
+            self.prefetch_stream = torch.cuda.current_stream() if where == "chain" else torch.cuda.Stream()
             # IPOKE_ENC_GRAPH=1 (developer A/B, measured slower: PokeMotionModel.set_encoder_graph): the prefetched encoders replayed from
             # one captured hipGraph, gated on the GPU side at the END of the backward pass, instead of ~200 eager launches
             if os.environ.get("IPOKE_ENC_GRAPH", "0") == "1":
@@ -140,6 +145,9 @@ class SecondStageTrainer:
             for i in range(n):
                 batch, nxt = nxt, (get_batch(epoch, i + 1) if i + 1 < n else None)
                 loss = self.train_step(batch, i, next_batch=nxt)
+            # once per epoch (it synchronises): no in-launch hand-off of the flow's kernels gave up (the engine also checks at every
+            # entry point as soon as the previous pass's poll has landed)
+            self.model.flow.engine.assert_handoffs_clean()
         return loss
 
     def train_step(self, batch, batch_idx=0, next_batch=None):

@@ -251,3 +251,65 @@ def test_full_size_adam_amsgrad_matches_torch_optim():
         # the next step starts from the engine's parameters on both sides (the comparison is of the update rule and its carried state)
         with torch.no_grad():
             ref_p.copy_(flat)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_second_stage_train_steps_are_reproducible(dtype):
+    """the c2 train step -- plants_128, the full z = 64 flow (1.237 B parameters), B = 20, native Adam-amsgrad over
+    24 backward pieces, encoder prefetch on -- is BIT-reproducible: two ``SecondStageTrainer.train_step``s from the same parameters and
+    optimizer state, three times; the flat gradient buffer, the parameters and the loss of every repetition are identical.  The
+    reference trains with ``deterministic=True`` / ``cudnn.deterministic = True`` (experiments/experiment.py:33, 86).  Rounds 1-5 added
+    the K slices of every conv1 data gradient (215 per backward pass) into the gradient state with fp32 atomics; they now meet in a
+    scratch and are summed in a fixed order (ipoke_conv_desc.acc_scratch)."""
+    from ipoke_amd.second_stage import PokeMotionModel
+    from ipoke_amd.trainer import SecondStageTrainer
+    from tests.helpers import cached_fill_, synthetic_batch
+    cfg = configs.BENCH_CONFIGS["c2"]
+    B = cfg["batch_size"]
+    conf = configs.second_stage_config(cfg["spatial_size"], cfg["z_dim"], cfg["n_frames"], B)
+    m = PokeMotionModel(conf, dirs={}, dtype=dtype, device="cuda", max_batch=B)
+    assert m.flow.engine.n_params >= 1_237_000_000
+    deterministic_fill_(m.first_stage_model, prefix="first_stage.")
+    deterministic_fill_(m.poke_embedder, prefix="poke_embedder.")
+    deterministic_fill_(m.conditioner, prefix="conditioner.")
+    cached_fill_(m.flow, "flow.")
+    with torch.no_grad():
+        for k, p in m.flow.named_parameters():
+            if k.endswith("weight_g"):
+                p.mul_(0.05)                                               # couplings away from the identity, outputs bounded
+    m.flow.sync_buffers()
+    m.flow.mark_weights_updated()
+    tr = SecondStageTrainer(m)
+    assert tr.native_opt and tr.overlap and tr.prefetch_stream is not None, "the benchmarked single-GPU path"
+    batch = synthetic_batch(B, cfg["n_frames"], cfg["spatial_size"], seed=3, device="cuda")
+    flat = m.flow.flat_params
+    snap = flat.detach().clone()
+    state = (tr.opt.exp_avg, tr.opt.exp_avg_sq, tr.opt.max_exp_avg_sq)
+
+    def two_steps():
+        with torch.no_grad():
+            flat.copy_(snap)
+            for s_ in state:
+                s_.zero_()
+        tr.opt.steps = 0
+        m.global_step = 20                                                 # early in the LR warm-up ramp: a small non-zero learning rate
+        m.flow.mark_weights_updated()
+        if isinstance(getattr(m, "_prefetched", None), dict):
+            m._prefetched.clear()
+        torch.manual_seed(11)                                              # the encoder's reparameterisation noise (CPU generator)
+        losses = []
+        for step in range(2):
+            losses.append(tr.train_step(batch, step, next_batch=batch if step == 0 else None))
+        torch.cuda.synchronize()
+        assert tr.opt.param_groups[0]["lr"] > 0
+        return m.flow.flat_grads.detach().clone(), flat.detach().clone(), torch.stack([l.detach() for l in losses]).cpu()
+
+    g0, p0, l0 = two_steps()
+    assert torch.isfinite(l0).all() and torch.isfinite(g0).all() and not torch.equal(p0, snap)
+    for rep in range(2):
+        g, p, l = two_steps()
+        n_g, n_p = int((g != g0).sum()), int((p != p0).sum())
+        print(f"{dtype} repetition {rep + 1}: losses {l.tolist()} vs {l0.tolist()}, differing gradient elements {n_g}, parameters {n_p}")
+        assert torch.equal(l, l0) and n_g == 0 and n_p == 0
+        del g, p
+    assert m.flow.engine.handoff_timeouts() == (0, 0)

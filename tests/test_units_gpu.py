@@ -188,6 +188,65 @@ def test_conv3x3_skinny_stationary_input(B, Cout):
     assert add[:, 0::2].abs().max() == 0 and (2 * d.Nout >= 64 or add[:, 2 * d.Nout + 1::2].abs().max() == 0)
 
 
+@pytest.mark.parametrize("dtype,B,Nout", [("bf16", 20, 32), ("bf16", 5, 30), ("bf16", 20, 64), ("bf16", 40, 16), ("f32", 4, 32), ("f32", 3, 60)])
+def test_split_k_accumulation_through_the_scratch_is_deterministic(dtype, B, Nout):
+    """ipoke_conv_desc.acc_scratch: the K slices of an accumulating launch (the conv1 data gradient of NICEConvBlock,
+    macow_utils.py:270, added into the gradient of the conditioning channels) meet in a scratch and are summed in a fixed order by
+    the workgroup that arrives last -- same value as the atomic form up to fp32 rounding, and BIT-identical from run to run while a
+    copy stream perturbs the arrival order (the reference trains with deterministic=True, experiments/experiment.py:33, 86).
+    bf16: conv3x3_s8n32 (<= 32 columns) / conv3x3_s8 (64); f32: the 64 x 64 skinny tile of the implicit GEMM; ragged last tiles."""
+    L = _lib.lib()
+    Cin = 512
+    gen = torch.Generator().manual_seed(7 * B + Nout)
+    x = torch.randn(B, Cin, 1, 8, 8, generator=gen)
+    wt = torch.randn(Cin, Nout, 1, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    M = B * 64
+    if dtype == "bf16":
+        sk = L.ipoke_conv3x3_skinny_splitk(M, Cin, _lib.BF16)
+        xr, wr = x.bfloat16().float(), wt.bfloat16().float()
+    else:
+        sk, xr, wr = 6, x, wt
+    assert sk > 1
+    want = F.conv_transpose3d(xr, wr, None, padding=(0, 1, 1))[:, :, 0].permute(0, 2, 3, 1).reshape(M, Nout)
+    d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1), True)
+    xa = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV).to(tdt(dtype))
+    d.A = xa.data_ptr(); d.a_sn = 64 * Cin; d.a_sd = 0; d.a_sh = 8 * Cin; d.a_sw = Cin; d.a_sc = 1; d.Kc_real = Cin; d.Kc = Cin
+    ws = shadow_nt(wt.transpose(0, 1).contiguous().to(DEV), Cin, dtype=dtype)
+    d.W = ws.data_ptr(); d.ldw = ws.shape[1]; d.Nout = Nout
+    nbytes = L.ipoke_conv_acc_scratch_bytes(M, Nout, sk)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(L.ipoke_conv_acc_scratch_init(scratch.data_ptr(), _lib.current_stream()))
+    base = torch.randn(M, 136, generator=gen).to(DEV)
+    noise_src = torch.randn(64 << 20, device=DEV)
+    side = torch.cuda.Stream()
+
+    def run(with_scratch, disturb):
+        state = base.clone()
+        d.C = state.data_ptr(); d.c_f32 = 1; d.c_accumulate = 1; d.ldc = 136; d.c_coff = 3; d.c_cstride = 2; d.splitk = sk
+        d.acc_scratch = scratch.data_ptr() if with_scratch else None
+        d.acc_scratch_bytes = nbytes if with_scratch else 0
+        if disturb:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(disturb):
+                    noise_src.clone()
+        ops.conv_forward(d, dtype)
+        torch.cuda.synchronize()
+        return state
+
+    first = run(True, 0)
+    add = (first - base).cpu()
+    tol = (2e-3 if dtype == "bf16" else 2e-5) * max(1.0, want.abs().max().item())
+    assert (add[:, 3:3 + 2 * Nout:2] - want).abs().max() <= tol
+    untouched = torch.ones(136, dtype=torch.bool); untouched[3:3 + 2 * Nout:2] = False
+    assert add[:, untouched].abs().max() == 0
+    for k in range(1, 5):                                    # replays: the counters are back at zero, the sums in the same order
+        assert torch.equal(run(True, k), first)
+    atomic = run(False, 0)
+    assert (atomic - first).abs().max().item() <= tol * 1e-2 + 1e-5
+    assert int(scratch[:16384].view(torch.int32).abs().max()) == 0           # every tile's arrival counter was reset
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES[:6] + CONV_CASES[-2:], ids=[c[0] for c in CONV_CASES[:6] + CONV_CASES[-2:]])
 def test_conv_wgrad_vs_torch(case, dtype):
