@@ -130,6 +130,21 @@ int ipoke_conv3x3_skinny_splitk(int M, int Kc, int dtype);
 /* Weight gradient: dW[n][tap*Kc + c] (+)= sum_m dY[m][n] * A[src(m,tap)][c].
  * dY is dtype [M][ldy]; A as in ipoke_conv_desc (fp32 or dtype).  Output fp32, written through a
  * (n, c, tap) stride triple so PyTorch's [out][in][k...] layout is produced directly. */
+/* Optional Adam-amsgrad in the epilogue of a BATCHED weight-gradient launch (ipoke_wgrad_desc.adam): the gradient tile is consumed
+ * in registers instead of being written to w_base -- parameters and moments of the tile are read, updated with exactly the arithmetic
+ * of ipoke_adam_amsgrad_step (torch.optim.Adam(amsgrad=True, weight_decay), second_stage_video.py:648-650) and written back, and the
+ * updated parameters' cast goes to `operand` (the bf16 matrix-core copy the next forward / data-gradient pass reads).  params, m, v,
+ * vmax: bases of buffers in the layout of w_base (problem z uses element offset entries[z].w_off in all four), operand: base of
+ * the operand copies (problem z at element offset entries[z].sh_off, same [out][in] order).  Dense 1 x 1 problems in whole
+ * 128 x 128 tiles (Nout, Kc multiples of 128; w_sn = Kc, w_sc = 1), bf16, one reduction split.  -8 of the 42 bytes per parameter
+ * that weight gradient + optimizer move (the gradient is neither written nor read back). */
+typedef struct {
+  float* params; float* m; float* v; float* vmax; void* operand;
+  float lr, beta1, beta2, eps, weight_decay, grad_scale;
+  int32_t step;                          /* 1-based optimizer step (bias corrections) */
+  int32_t keep_grad;                     /* 1: the gradient is written to w_base as well (costs the 4 bytes the fusion saves) */
+} ipoke_wgrad_adam;
+
 typedef struct {
   int32_t NB, Di, Hi, Wi, Do, Ho, Wo, kd, kh, kw, sd, sh, sw, pd, ph, pw, transposed;
   const void* A; int32_t a_f32; int64_t a_sn, a_sd, a_sh, a_sw, a_sc; int32_t a_coff, Kc_real, Kc;
@@ -142,11 +157,13 @@ typedef struct {
                                             (deterministic; the caller sums the splitm slabs, e.g. ipoke_reduce_rows), 0 -> atomics */
   int32_t max_workgroups;                /* > 0: issue the output tiles in launches of at most this many workgroups, so that a
                                             weight gradient running on a side stream never holds every CU of the chip */
+  const ipoke_wgrad_adam* adam;          /* batched launches only: see ipoke_wgrad_adam; NULL = plain weight gradient */
 } ipoke_wgrad_desc;
 
 int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream);
 /* nbatch same-shape problems in one launch; entries_dev[i] = {int64 a_off bytes, int64 y_off bytes, int64 w_off floats,
- * int32 kh, kw, ph, pw} relative to a_base / y_base / w_base (the descriptor's A, dY, dW and kh/kw/ph/pw are ignored) */
+ * int32 kh, kw, ph, pw, int64 sh_off elements (used with ipoke_wgrad_desc.adam only)} relative to a_base / y_base / w_base (the
+ * descriptor's A, dY, dW and kh/kw/ph/pw are ignored) */
 int ipoke_wgrad_batch_entry_size(void);
 int ipoke_conv_wgrad_batched(const ipoke_wgrad_desc* d, const void* entries_dev, int nbatch, const void* a_base,
                              const void* y_base, float* w_base, int dtype, void* stream);

@@ -40,7 +40,14 @@ class WgradDesc(Structure):
         ("a_coff", c_int32), ("Kc_real", c_int32), ("Kc", c_int32),
         ("dY", c_void_p), ("ldy", c_int32), ("y_coff", c_int32), ("Nout", c_int32),
         ("dW", c_void_p), ("w_sn", c_int64), ("w_sc", c_int64), ("w_st", c_int64),
-        ("accumulate", c_int32), ("splitm", c_int32), ("Kc_store", c_int32), ("split_stride", c_int64), ("max_workgroups", c_int32)]
+        ("accumulate", c_int32), ("splitm", c_int32), ("Kc_store", c_int32), ("split_stride", c_int64), ("max_workgroups", c_int32),
+        ("adam", c_void_p)]
+
+
+class WgradAdam(Structure):
+    _fields_ = [("params", c_void_p), ("m", c_void_p), ("v", c_void_p), ("vmax", c_void_p), ("operand", c_void_p),
+                ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float), ("grad_scale", c_float),
+                ("step", c_int32), ("keep_grad", c_int32)]
 
 
 class AffineDesc(Structure):

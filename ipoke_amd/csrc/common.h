@@ -163,6 +163,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // ---- Adam with amsgrad (torch.optim.Adam semantics), one element; shared by every kernel that applies the update
 struct AdamHyper { float lr_bc1, beta1, beta2, eps, wd, bc2_sqrt, grad_scale; };     // lr_bc1 = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t)
+static inline AdamHyper adam_make_hyper(float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale) {
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  return AdamHyper{lr / (float)bc1, beta1, beta2, eps, wd, (float)sqrt(bc2), grad_scale};
+}
 // Every product-sum is an explicit fmaf and contraction is off inside the function, so that each kernel that applies the update
 // (linear, per segment, tile-wise with the shadow writes) produces bit-identical parameters whatever the compiler would have fused.
 __device__ __forceinline__ void adam_amsgrad_update(float& p, float g, float& m, float& v, float& vx, const AdamHyper& h) {

@@ -629,7 +629,7 @@ int common_checks(ipoke_flow* f, int B) {
   return IPOKE_OK;
 }
 
-struct WgEntryH { long a_off, y_off, w_off; int kh, kw, ph, pw; };
+struct WgEntryH { long a_off, y_off, w_off; int kh, kw, ph, pw; long sh_off = 0; };      // mirrors TnBatchEntry of gemm.hip
 struct RedEntryH { long src, dst; int ld, ncols, rmul, pad; };   // rmul: rows per sample (ipoke_reduce_rows_multi sums R * rmul rows)
 
 void drop_graphs(ipoke_flow* f) {
@@ -665,7 +665,7 @@ int ensure_tables(ipoke_flow* f, int B, const Plan& plan) {
       red.push_back({dbp, (long)op.p_b, 2 * op.C, 2 * op.C, rmul, 0});
     } else if (op.type == OP_NICE) {
       nt[0][op.nice_idx] = {(long)op.ws_g, (long)op.ws_f, (long)op.p_c1, 3, 3, 1, 1};     // conv1: saved conditioning columns x d(pre-act 1)
-      nt[1][op.nice_idx] = {(long)op.ws_a, (long)op.ws_e, (long)op.p_c2, 1, 1, 0, 0};     // conv2: h1 x d(pre-act 2)
+      nt[1][op.nice_idx] = {(long)op.ws_a, (long)op.ws_e, (long)op.p_c2, 1, 1, 0, 0, (long)op.sh_c2};     // conv2: h1 x d(pre-act 2); its operand copy (fused Adam)
       nt[2][op.nice_idx] = {(long)op.ws_b, (long)op.ws_d, (long)op.p_v, 3, 3, 1, 1};      // conv3: h2 x d(raw shift / scale)
       red.push_back({dbp, (long)op.p_b, 2 * op.cout, 2 * op.cout, rmul, 0});
     } else if (op.p_ls >= 0) {
@@ -1051,7 +1051,8 @@ extern "C" int ipoke_flow_prepare_weights_range(ipoke_flow* f, const float* para
  *   3. weight-norm scales and the relayout of the remaining (3x3, masked, weight-normed) tensors.
  * [begin, end) must cover whole tensors (the ranges ipoke_flow_backward_pieces announces, or [0, param_count)). */
 static int adam_range(ipoke_flow* f, float* params, const float* grads, float* m, float* v, float* vmax, void* shadow, int64_t begin, int64_t end,
-                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream);
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream,
+                      bool skip_tiles = false);
 
 extern "C" int ipoke_flow_adam_range(ipoke_flow* f, float* params, const float* grads, float* m, float* v, float* vmax, void* shadow,
                                      int64_t begin, int64_t end, float lr, float beta1, float beta2, float eps, float weight_decay,
@@ -1061,14 +1062,16 @@ extern "C" int ipoke_flow_adam_range(ipoke_flow* f, float* params, const float* 
   return adam_range(f, params, grads, m, v, vmax, shadow, begin, end, lr, beta1, beta2, eps, weight_decay, step, grad_scale, max_blocks, stream);
 }
 
+// skip_tiles: the plain 1x1 tensors of the range were already updated in the epilogue of their weight-gradient launches (wgrad_adam)
 static int adam_range(ipoke_flow* f, float* params, const float* grads, float* m, float* v, float* vmax, void* shadow, int64_t begin, int64_t end,
-                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream) {
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream,
+                      bool skip_tiles) {
   if (end == begin) return IPOKE_OK;
   int a0 = 0, a1 = 0;
   while (a0 < (int)f->ajobs.size() && f->ajobs[a0].src_off < begin) ++a0;
   a1 = a0;
   while (a1 < (int)f->ajobs.size() && f->ajobs[a1].src_off < end) ++a1;
-  if (a1 > a0) {
+  if (a1 > a0 && !skip_tiles) {
     IPK_REQUIRE(f->ajobs[a1 - 1].src_off + (int64_t)f->ajobs[a1 - 1].N * f->ajobs[a1 - 1].K <= end, "range must cover whole tensors");
     const int t0 = f->ajobs[a0].tile_start, t1 = a1 < (int)f->ajobs.size() ? f->ajobs[a1].tile_start : f->atiles;
     void* sh = reinterpret_cast<unsigned char*>(shadow) + 2 * align_up(f->wn_rows, 64) * 4;
@@ -1583,6 +1586,17 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   // pieces: groups of consecutive units (steps / priors), last unit first, of roughly equal parameter counts
   hipStream_t rs = ready_stream ? ready_stream : s;
   const std::vector<std::pair<int, int>> pieces = backward_pieces(f, npieces);            // (lowest unit, highest unit)
+  // IPOKE_WGRAD_ADAM=1 (opt-in; =2: the gradient written as well): Adam-amsgrad of conv2 (plain 1x1, 73 % of the parameters) in the
+  // epilogue of its weight-gradient GEMM (ipoke_wgrad_desc.adam) instead of adam_cast over the written gradient -- single-process
+  // training with the engine-issued optimizer only (a data-parallel run must exchange the gradient first).  Bit-identical
+  // parameters and moments (tests/test_full_gpu.py), 8 of 42 bytes per parameter less -- and MEASURED SLOWER on c2 (round 6, one call):
+  // 53.2 / 53.2 ms against 49.9 / 49.8.  The launch takes 155 us instead of 53 (the same 2.8 TB/s the stand-alone kernel streams at
+  // beside the chain, but on 512 workgroups that hold every CU instead of a 160-workgroup grid), the weight-gradient queue grows from
+  // 11.0 to 15.0 ms per half step and the chain's kernels from 22.2 to 24.5 ms; the saved gradient round trip was served by the
+  // memory-side cache anyway.  Off by default.
+  const int wgrad_adam_mode = getenv("IPOKE_WGRAD_ADAM") ? atoi(getenv("IPOKE_WGRAD_ADAM")) : 0;
+  const bool wgrad_adam = wgrad_adam_mode != 0 && f->nadam.on && !getenv("IPOKE_PROBE_SKIP_ADAM") && !getenv("IPOKE_ADAM_DEFER") && f->c2_straight &&
+                          c.dtype == IPOKE_BF16 && f->use_side && lanes.size() == 1 && hid % 128 == 0 && (int)f->ajobs.size() == f->n_nice && !f->cfg.condition_nice;
   std::function<int()> flush_nice_fn = []() { return (int)IPOKE_OK; };
   std::vector<std::pair<int64_t, int64_t>> deferred_adam;      // parameter ranges whose native update waits for the end of the pass (IPOKE_ADAM_DEFER)
   auto native_adam_range = [&](int64_t b0, int64_t b1, int max_blocks) -> int {
@@ -1591,7 +1605,7 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
     void* rstream = reinterpret_cast<void*>(rs);
     if (f->c2_straight)      // conv2 tensors: update + their one operand in the same linear pass; the rest: update, then relayout
       return adam_range(f, pm, grads, A.m, A.v, A.vmax, const_cast<void*>(shadow), b0, b1, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
-                        A.grad_scale, max_blocks, rstream);
+                        A.grad_scale, max_blocks, rstream, wgrad_adam);
     int r = ipoke_adam_amsgrad_step_grid(pm + b0, grads + b0, A.m + b0, A.v + b0, A.vmax + b0, b1 - b0, A.lr, A.beta1, A.beta2, A.eps, A.wd, A.step,
                                          A.grad_scale, max_blocks, rstream);
     if (r) return r;
@@ -1711,6 +1725,15 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       w.a_sn = 64L * hid; w.a_sh = 8L * hid; w.a_sw = hid; w.a_sc = 1; w.Kc_real = hid; w.Kc = hid;
       w.ldy = hid; w.Nout = hid;
       w.w_sn = hid; w.w_sc = 1; w.w_st = 0;
+      ipoke_wgrad_adam wa;
+      if (wgrad_adam) {
+        const ipoke_flow::NativeAdam& A = f->nadam;
+        wa.params = const_cast<float*>(params); wa.m = A.m; wa.v = A.v; wa.vmax = A.vmax;
+        wa.operand = const_cast<unsigned char*>(c.shadow + c.shadow_base());
+        wa.lr = A.lr; wa.beta1 = A.beta1; wa.beta2 = A.beta2; wa.eps = A.eps; wa.weight_decay = A.wd; wa.grad_scale = A.grad_scale; wa.step = A.step;
+        wa.keep_grad = wgrad_adam_mode == 2;
+        w.adam = &wa;
+      }
       rc = ipoke_conv_wgrad_batched(&w, entries(1), nb, c.ws, c.ws, grads, c.dtype, wstream); if (rc) return rc;
       // conv1 (input = conditioning channels of the saved state)
       base8(3, 1);
@@ -1885,7 +1908,8 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       ++pk;
     }
   }
-  if (rs != s) {        // later work on the caller's stream (optimizer step) sees every gradient
+  static const bool probe_no_join = getenv("IPOKE_PROBE_NO_READY_JOIN") != nullptr;      // developer probe (WRONG results): the caller's stream does not wait for the ready stream
+  if (rs != s && !probe_no_join) {        // later work on the caller's stream (optimizer step) sees every gradient
     hipEvent_t e = next_event(f);
     IPK_HIP(hipEventRecord(e, rs)); IPK_HIP(hipStreamWaitEvent(s, e, 0));
   }

@@ -71,7 +71,7 @@ struct NtParams {
 #endif
 
 // one problem of a batched weight-gradient launch (blockIdx.z): byte/float offsets against the launch's bases
-struct TnBatchEntry { long a_off, y_off, w_off; int kh, kw, ph, pw; };
+struct TnBatchEntry { long a_off, y_off, w_off; int kh, kw, ph, pw; long sh_off; };      // sh_off: element offset of the problem's operand copy (fused Adam)
 
 struct TnParams {
   GeomDev g;
@@ -85,6 +85,12 @@ struct TnParams {
   long split_stride;   // > 0: split z stores its slab at dW + z*split_stride instead of atomics
   int tile0, max_wgs;  // first output tile of this launch / cap on workgroups per launch (0: none)
   int z0;              // first problem (batch entry) of this launch
+  // Adam-amsgrad in the epilogue (ipoke_wgrad_desc.adam; batched launches of dense 1x1 problems): the gradient tile never leaves
+  // the registers -- the tile's parameters and moments are read, updated (adam_amsgrad_update, common.h: the arithmetic every
+  // optimizer kernel shares) and written back together with the parameters' cast into the operand copy at ad_sh + sh_off.
+  // Pointers are the bases of buffers in the layout of dW (the flat parameter buffer): problem z uses offset batch[z].w_off in all.
+  float* ad_p; float* ad_m; float* ad_v; float* ad_vmax; bf16_t* ad_sh; AdamHyper ad_h;
+  int ad_keep_grad;    // 1: the gradient tile is ALSO written to dW (tests that compare the update against an optimizer of their own)
 };
 
 // decode output row m -> input base coordinates
@@ -3025,7 +3031,7 @@ static int dispatch_nn(NtParams& p, hipStream_t s) {
 // 64 columns would be padding -- half of every workgroup's dY stream, fragment reads and matrix-core work on zeros, and the conv3 weight
 // gradients took as long as conv2's with 3.5x fewer FLOPs (7.1 ms of the weight-gradient queue per c2 step).  A stage is the dY image
 // (its upper 64 columns stay zero) and TWO A images (k0 .. k0 + 127, k0 + 128 .. k0 + 255); the eight waves own 64 x 32 each, side by side in k.
-template <int NSTAGE, int RM, bool NARROW = false>
+template <int NSTAGE, int RM, bool NARROW = false, bool ADAM = false>
 __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) {
   if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(TnParams)>();
   typedef bf16_t T;
@@ -3034,6 +3040,7 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
     const TnBatchEntry e = pin.batch[blockIdx.z + pin.z0];
     p.A = pin.a_base + e.a_off; p.dY = pin.y_base + e.y_off; p.dW = pin.w_base + e.w_off;
     p.g.khw = e.kh * e.kw; p.g.kw = e.kw; p.g.taps = e.kh * e.kw; p.g.ph = e.ph; p.g.pw = e.pw;
+    if constexpr (ADAM) { p.ad_p += e.w_off; p.ad_m += e.w_off; p.ad_v += e.w_off; p.ad_vmax += e.w_off; p.ad_sh += e.sh_off; }
   }
   typedef typename ET<T>::frag frag_t;
   typedef __attribute__((address_space(3))) void lds_void;
@@ -3288,6 +3295,47 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
 #endif
 
   // epilogue: acc[i][j][r] = dW[n = n0 + wn2*64 + 16i + (lane&15)][k = k0 + wk*32 + 16j + 4*(lane>>4) + r]
+  if constexpr (ADAM) {
+    // dense 1x1 problem (one tap, w_sc = 1, whole tiles: checked by the launcher).  Two rounds of four 4-element groups: the 16
+    // sixteen-byte loads of a round are issued before its arithmetic (64 registers: the kernel stays within the 128 that let two
+    // workgroups -- or one and a chain GEMM workgroup -- share a CU).  Non-temporal like the stand-alone optimizer kernels.
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 pp[2][2], mm[2][2], vv[2][2], vx[2][2];
+      long off[2][2];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * half + ii;
+        const int n = n0 + wn2 * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k = k0 + wk * 32 + j * 16 + (lane >> 4) * 4;
+          off[ii][j] = (long)n * p.w_sn + k;
+          pp[ii][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.ad_p + off[ii][j]));
+          mm[ii][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.ad_m + off[ii][j]));
+          vv[ii][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.ad_v + off[ii][j]));
+          vx[ii][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.ad_vmax + off[ii][j]));
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (p.ad_keep_grad) *reinterpret_cast<f32x4*>(p.dW + off[ii][j]) = acc[2 * half + ii][j];
+          adam_amsgrad_update4(pp[ii][j], acc[2 * half + ii][j], mm[ii][j], vv[ii][j], vx[ii][j], p.ad_h);
+          __builtin_nontemporal_store(pp[ii][j], reinterpret_cast<f32x4*>(p.ad_p + off[ii][j]));
+          __builtin_nontemporal_store(mm[ii][j], reinterpret_cast<f32x4*>(p.ad_m + off[ii][j]));
+          __builtin_nontemporal_store(vv[ii][j], reinterpret_cast<f32x4*>(p.ad_v + off[ii][j]));
+          __builtin_nontemporal_store(vx[ii][j], reinterpret_cast<f32x4*>(p.ad_vmax + off[ii][j]));
+          typedef __attribute__((ext_vector_type(4))) __bf16 bf4_t;
+          bf4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = ET<T>::from_f32(pp[ii][j][r]);
+          *reinterpret_cast<bf4_t*>(p.ad_sh + off[ii][j]) = o;
+        }
+    }
+    return;
+  }
   const bool vec4 = p.w_sc == 1 && !p.accumulate && !(p.splitm > 1 && p.split_stride == 0) && ((p.w_sn | p.w_st | p.split_stride) & 3) == 0 &&
                     (reinterpret_cast<uintptr_t>(p.dW) & 15) == 0 && (p.Kc & 3) == 0;
 #pragma unroll
@@ -3348,9 +3396,15 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     if (narrow) p.tiles_k = ceil_div(p.Ktot, 256);
     const int nst_n = narrow_on == 3 ? 3 : 2;                  // (developer A/B: IPOKE_TN_NARROW=3 = three ring slots, 144 KB)
     const size_t lds2 = narrow ? (size_t)nst_n * 3 * 64 * 256 + 256 * sizeof(int) : (size_t)NST * 2 * 64 * 256 + 256 * sizeof(int);
-    auto kern = narrow ? (nst_n == 3 ? igemm_tn_glds_kernel<3, 64, true> : igemm_tn_glds_kernel<2, 64, true>)
+    const bool adam = p.ad_p != nullptr;
+    if (adam) IPK_REQUIRE(!narrow && p.batch && p.g.taps == 1 && p.w_sc == 1 && p.w_sn == p.Ktot && p.Nout % 128 == 0 && p.Ktot % 128 == 0 &&
+                          p.splitm == 1 && !p.accumulate && p.Kc == p.Kc_real && (p.Kc_store == 0 || p.Kc_store == p.Kc) && (p.w_sn & 3) == 0,
+                          "Adam in the weight-gradient epilogue: batched dense 1x1 problems in whole 128 x 128 tiles, one reduction split");
+    auto kern = adam ? (NST == 2 ? igemm_tn_glds_kernel<2, 64, false, true> : igemm_tn_glds_kernel<3, 64, false, true>)
+                : narrow ? (nst_n == 3 ? igemm_tn_glds_kernel<3, 64, true> : igemm_tn_glds_kernel<2, 64, true>)
                        : NST == 2 ? igemm_tn_glds_kernel<2, 64> : igemm_tn_glds_kernel<3, 64>;
-    if (narrow && nst_n == 3) { IPK_SET_LDS_ONCE(kern, lds2); } else if (narrow) { IPK_SET_LDS_ONCE(kern, lds2); }
+    if (adam && NST == 2) { IPK_SET_LDS_ONCE(kern, lds2); } else if (adam) { IPK_SET_LDS_ONCE(kern, lds2); }
+    else if (narrow && nst_n == 3) { IPK_SET_LDS_ONCE(kern, lds2); } else if (narrow) { IPK_SET_LDS_ONCE(kern, lds2); }
     else if (NST == 2) { IPK_SET_LDS_ONCE(kern, lds2); } else { IPK_SET_LDS_ONCE(kern, lds2); }      // one flag per instantiation
     const int ntiles = p.tiles_n * p.tiles_k;
     const int cap = p.max_wgs > 0 ? p.max_wgs : ntiles;
@@ -3379,6 +3433,7 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
     }
     return IPOKE_OK;
   }
+  IPK_REQUIRE(p.ad_p == nullptr, "Adam in the weight-gradient epilogue needs the LDS-DMA kernel (bf16, dense 16-byte aligned operands)");
   static const int nr = getenv("IPOKE_TN_NR") ? atoi(getenv("IPOKE_TN_NR")) : 2;   // measured: 2 stages in flight beat 4 (54 vs 61 us at the NICE conv2 shape)
   dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.splitm, (unsigned)nbatch);
   if (nr == 2) {
@@ -3545,6 +3600,17 @@ static int fill_tn(TnParams& p, const ipoke_wgrad_desc* d, int dtype, bool batch
   IPK_REQUIRE(p.split_stride >= 0 && !(p.split_stride > 0 && d->accumulate), "split slabs are stored, not accumulated");
   p.Kc_store = d->Kc_store > 0 ? d->Kc_store : d->Kc_real;
   IPK_REQUIRE(p.Kc_store <= d->Kc_real, "Kc_store exceeds Kc_real");
+  p.ad_p = p.ad_m = p.ad_v = p.ad_vmax = nullptr; p.ad_sh = nullptr; p.ad_h = AdamHyper{}; p.ad_keep_grad = 0;
+  if (d->adam) {
+    const ipoke_wgrad_adam& a = *d->adam;
+    IPK_REQUIRE(batched && dtype == IPOKE_BF16 && a.params && a.m && a.v && a.vmax && a.operand && a.step >= 1,
+                "Adam in the weight-gradient epilogue: batched bf16 launches, all five buffers, step >= 1");
+    IPK_REQUIRE(((reinterpret_cast<uintptr_t>(a.params) | reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v) |
+                  reinterpret_cast<uintptr_t>(a.vmax)) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.operand) & 7) == 0, "unaligned optimizer buffers");
+    p.ad_p = a.params; p.ad_m = a.m; p.ad_v = a.v; p.ad_vmax = a.vmax; p.ad_sh = reinterpret_cast<bf16_t*>(a.operand);
+    p.ad_h = adam_make_hyper(a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.step, a.grad_scale);
+    p.ad_keep_grad = a.keep_grad;
+  }
   return IPOKE_OK;
 }
 

@@ -477,8 +477,7 @@ extern "C" int ipoke_adam_tile_job_size(void) { return (int)sizeof(AdamTileJob);
 extern "C" int ipoke_adam_seg_size(void) { return (int)sizeof(AdamSeg); }
 
 static AdamHyper make_hyper(float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale) {
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  return AdamHyper{lr / (float)bc1, beta1, beta2, eps, wd, (float)sqrt(bc2), grad_scale};
+  return adam_make_hyper(lr, beta1, beta2, eps, wd, step, grad_scale);
 }
 
 extern "C" int ipoke_adam_amsgrad_shadow_tiles(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, const void* jobs_dev,

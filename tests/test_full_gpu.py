@@ -313,3 +313,45 @@ def test_second_stage_train_steps_are_reproducible(dtype):
         assert torch.equal(l, l0) and n_g == 0 and n_p == 0
         del g, p
     assert m.flow.engine.handoff_timeouts() == (0, 0)
+
+
+def test_adam_in_the_conv2_weight_gradient_epilogue_trains_bit_identically(monkeypatch):
+    """IPOKE_WGRAD_ADAM=1 (opt-in, measured slower on c2: DESIGN.md §7): the single-GPU train step applies Adam-amsgrad to conv2 of every
+    coupling net (plain 1 x 1, 73 % of the parameters at full size; macow_utils.py:270-281, second_stage_video.py:648-650) in the epilogue
+    of its weight-gradient GEMM (ipoke_wgrad_desc.adam) instead of writing the gradient and running adam_cast over it (default): three
+    train steps from the same state, bf16 -- parameters and optimizer state of the two forms bit-identical; mode 2 also leaves the same
+    gradient in the flat buffer."""
+    from ipoke_amd.second_stage import PokeMotionModel
+    from ipoke_amd.trainer import SecondStageTrainer
+    from tests.helpers import synthetic_batch
+    arch = configs.flow_arch(32, hidden=128, num_steps=[2, 1, 1], factor=4)
+    arch["flow_mid_channels_factor"] = 4           # PokeMotionModel derives flow_mid_channels = factor * z_dim = 128 (whole 128 x 128 tiles)
+    conf = configs.second_stage_config(64, 32, 16, batch_size=4, arch=arch)
+    batch = synthetic_batch(4, 16, 64, seed=5, device="cuda")
+
+    def run(mode):
+        monkeypatch.setenv("IPOKE_WGRAD_ADAM", mode)
+        m = PokeMotionModel(conf, dirs={}, dtype="bf16", device="cuda", max_batch=4)
+        assert m.flow.engine.cfg.hidden == 128
+        deterministic_fill_(m.first_stage_model, prefix="first_stage.")
+        deterministic_fill_(m.poke_embedder, prefix="poke_embedder.")
+        deterministic_fill_(m.conditioner, prefix="conditioner.")
+        deterministic_fill_(m.flow, prefix="flow.")
+        m.flow.sync_buffers()
+        m.flow.mark_weights_updated()
+        tr = SecondStageTrainer(m)
+        assert tr.native_opt and tr.overlap
+        m.global_step = 300
+        torch.manual_seed(4)
+        losses = [tr.train_step(batch, k).item() for k in range(3)]
+        torch.cuda.synchronize()
+        assert m.flow.engine.handoff_timeouts() == (0, 0)
+        return (losses, m.flow.flat_params.detach().clone(), tr.opt.exp_avg.clone(), tr.opt.exp_avg_sq.clone(), tr.opt.max_exp_avg_sq.clone(),
+                m.flow.flat_grads.detach().clone())
+
+    plain, fused, keep = run("0"), run("1"), run("2")
+    assert all(np.isfinite(plain[0])) and plain[0] == fused[0] == keep[0], (plain[0], fused[0], keep[0])
+    for name, a, b, c in zip(("params", "m", "v", "vmax"), plain[1:5], fused[1:5], keep[1:5]):
+        assert torch.equal(a, b) and torch.equal(a, c), (name, int((a != b).sum()), int((a != c).sum()))
+    assert torch.equal(plain[5], keep[5]), "mode 2 writes the gradient the epilogue consumed"
+    assert not torch.equal(plain[5], fused[5]), "the fused form must not have written conv2's gradient (is it active?)"

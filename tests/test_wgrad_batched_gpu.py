@@ -40,8 +40,8 @@ def test_batched_weight_gradient_matches_torch(B, Cin, Cout, k, nb):
     y_all = y_all.to(DEV)
     dw = torch.full((nb, Cout, Cin, k * k), float("nan"), device=DEV)
     es = lib.ipoke_wgrad_batch_entry_size()
-    assert es == struct.calcsize("qqqiiii")
-    raw = b"".join(struct.pack("qqqiiii", i * M * Cin * 2, i * M * ldy * 2, i * Cout * Cin * k * k, k, k, pad, pad) for i in range(nb))
+    assert es == struct.calcsize("qqqiiiiq")
+    raw = b"".join(struct.pack("qqqiiiiq", i * M * Cin * 2, i * M * ldy * 2, i * Cout * Cin * k * k, k, k, pad, pad, 0) for i in range(nb))
     entries = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(DEV)
     d = WgradDesc()
     d.NB, d.Di, d.Hi, d.Wi, d.Do, d.Ho, d.Wo = B, 1, 8, 8, 1, 8, 8
@@ -57,3 +57,72 @@ def test_batched_weight_gradient_matches_torch(B, Cin, Cout, k, nb):
     for i in range(nb):
         err = (got[i] - refs[i]).abs().max().item()
         assert err <= 2e-3 * max(1.0, refs[i].abs().max().item()), (i, err)
+
+
+@pytest.mark.parametrize("B,C,nb", [(20, 256, 2), (3, 128, 3), (5, 384, 1)])
+def test_adam_in_the_weight_gradient_epilogue_is_bit_identical(B, C, nb):
+    """ipoke_wgrad_desc.adam: Adam-amsgrad of dense 1 x 1 weights (conv2 of NICEConvBlock, macow_utils.py:270-281, under
+    torch.optim.Adam(amsgrad=True, weight_decay), second_stage_video.py:648-650) applied in the epilogue of the batched weight-gradient
+    launch -- against the two-pass form it replaces: the same launch writing the gradient, then ipoke_adam_amsgrad_step over it.
+    Parameters, both moments and the running maximum BIT-identical over two optimizer steps (carried state); the operand copy is the
+    bf16 cast of the new parameters; keep_grad = 1 also leaves the gradient in w_base."""
+    from ipoke_amd._lib import WgradAdam
+    lib = _lib.lib()
+    M = B * 64
+    gen = torch.Generator().manual_seed(31 * B + C)
+    n = C * C
+    pad_front = 64                                           # problems do not start at the buffers' bases
+    flat = pad_front + nb * n
+    p0 = (torch.randn(flat, generator=gen) * 0.05).to(DEV)
+    state = {k_: v_.to(DEV) for k_, v_ in (("m", torch.randn(flat, generator=gen) * 1e-3), ("v", torch.rand(flat, generator=gen) * 1e-5),
+                                           ("vmax", torch.rand(flat, generator=gen) * 1e-5))}
+    hyp = dict(lr=3e-4, b1=0.9, b2=0.999, eps=1e-8, wd=1e-5, gs=0.5)
+
+    def entries(sh):
+        raw = b"".join(struct.pack("qqqiiiiq", i * M * C * 2, i * M * C * 2, pad_front + i * n, 1, 1, 0, 0, (8 + i * n) if sh else 0) for i in range(nb))
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(DEV)
+
+    def desc():
+        d = WgradDesc()
+        d.NB, d.Di, d.Hi, d.Wi, d.Do, d.Ho, d.Wo = B, 1, 8, 8, 1, 8, 8
+        d.kd, d.kh, d.kw, d.sd, d.sh, d.sw, d.pd, d.ph, d.pw = 1, 1, 1, 1, 1, 1, 0, 0, 0
+        d.a_f32 = 0; d.a_sn = 64 * C; d.a_sh = 8 * C; d.a_sw = C; d.a_sc = 1; d.Kc_real = C; d.Kc = C
+        d.ldy = C; d.Nout = C; d.w_sn = C; d.w_sc = 1; d.w_st = 0
+        return d
+
+    two = {k_: [p0.clone()] + [state[q].clone() for q in ("m", "v", "vmax")] for k_ in ("plain", "fused", "keep")}
+    operand = {k_: torch.zeros(8 + nb * n, dtype=torch.bfloat16, device=DEV) for k_ in ("fused", "keep")}
+    for step in (1, 2):
+        a_all = (torch.randn(nb, M, C, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
+        y_all = (torch.randn(nb, M, C, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
+        # two passes: gradient, then the stand-alone optimizer kernel over the whole flat buffer
+        grad = torch.zeros(flat, device=DEV)
+        d = desc()
+        e_plain = entries(False)
+        check(lib.ipoke_conv_wgrad_batched(byref(d), e_plain.data_ptr(), nb, a_all.data_ptr(), y_all.data_ptr(), grad.data_ptr(), _lib.BF16, ops._s()))
+        P, Mm, V, X = two["plain"]
+        check(lib.ipoke_adam_amsgrad_step(P.data_ptr(), grad.data_ptr(), Mm.data_ptr(), V.data_ptr(), X.data_ptr(), flat, hyp["lr"], hyp["b1"],
+                                          hyp["b2"], hyp["eps"], hyp["wd"], step, hyp["gs"], ops._s()))
+        for mode in ("fused", "keep"):
+            P2, M2, V2, X2 = two[mode]
+            wa = WgradAdam()
+            wa.params, wa.m, wa.v, wa.vmax, wa.operand = P2.data_ptr(), M2.data_ptr(), V2.data_ptr(), X2.data_ptr(), operand[mode].data_ptr()
+            wa.lr, wa.beta1, wa.beta2, wa.eps, wa.weight_decay, wa.grad_scale, wa.step = hyp["lr"], hyp["b1"], hyp["b2"], hyp["eps"], hyp["wd"], hyp["gs"], step
+            wa.keep_grad = int(mode == "keep")
+            d2 = desc()
+            from ctypes import addressof
+            d2.adam = addressof(wa)
+            g2 = torch.full((flat,), float("nan"), device=DEV)
+            e_f = entries(True)
+            check(lib.ipoke_conv_wgrad_batched(byref(d2), e_f.data_ptr(), nb, a_all.data_ptr(), y_all.data_ptr(), g2.data_ptr(), _lib.BF16, ops._s()))
+            torch.cuda.synchronize()
+            sl = slice(pad_front, flat)
+            for name, a_, b_ in (("p", P, P2), ("m", Mm, M2), ("v", V, V2), ("vmax", X, X2)):
+                assert torch.equal(a_[sl], b_[sl]), (mode, step, name, (a_[sl] - b_[sl]).abs().max().item())
+                assert torch.equal(b_[:pad_front], (p0 if name == "p" else state[name])[:pad_front]), "wrote outside the problems"
+            assert torch.equal(operand[mode][8:], P2[sl].to(torch.bfloat16)) and float(operand[mode][:8].abs().max()) == 0
+            if mode == "keep":
+                assert torch.equal(g2[sl], grad[sl])
+            else:
+                assert torch.isnan(g2).all(), "the fused launch must not write the gradient"
+        assert not torch.equal(two["plain"][0], p0)
