@@ -519,6 +519,10 @@ int ipoke_flow_backward_pieces(ipoke_flow* f, const float* params, const int32_t
  * out[1] = of the coupling launches since the scratches were last (re-)initialised.  (The reference has no counterpart: a single
  * PyTorch stream orders macow2.py:925-995 / macow_utils.py:270-281 by construction.) */
 int ipoke_flow_handoff_timeouts(ipoke_flow* f, uint32_t* out);
+/* the hipStream_t (as void*) of the flow's weight-gradient side stream, NULL on failure: lets the host verify that the streams IT
+ * keeps busy beside the backward pass do not share a hardware queue with it (the reference has one stream; experiments/experiment.py
+ * runs DDP's bucket all-reduce on NCCL's own) */
+void* ipoke_flow_side_stream(ipoke_flow* f);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -933,6 +933,13 @@ extern "C" int ipoke_flow_piece_ranges(const ipoke_flow* f, int npieces, int64_t
   return n;
 }
 
+/* The stream the engine issues its weight gradients on during ipoke_flow_backward* (created on first use; owned by the flow).  Hosts
+ * that keep further streams busy beside the backward pass (gradient exchange / optimizer, input prefetch) check theirs against it:
+ * two busy streams on one hardware queue serialise (ipoke_amd/utils/streams.py). */
+extern "C" void* ipoke_flow_side_stream(ipoke_flow* f) {
+  if (!f || ensure_device(f) != IPOKE_OK) return nullptr;
+  return reinterpret_cast<void*>(f->side);
+}
 extern "C" int64_t ipoke_flow_param_count(const ipoke_flow* f) { return f ? f->n_params : -1; }
 extern "C" int64_t ipoke_flow_index_count(const ipoke_flow* f) { return f ? f->n_perm : -1; }
 /* replay the layer programs (forward / reverse / one-shot backward) as captured hipGraphs (1) or launch them eagerly (0) */

@@ -58,13 +58,30 @@ def allreduce_(t):
     return t
 
 
+# Stream budget: the train step keeps FOUR streams busy -- chain, weight gradients, ready / optimizer, encoder prefetch --
+# and a further busy stream costs +18 ms per step, or 2x when its hardware queue is the chain's (HIP multiplexes streams onto
+# GPU_MAX_HW_QUEUES queues; tests/test_dist_gpu.py).  With ``async_op=True`` ProcessGroupNCCL runs every collective on an INTERNAL
+# stream of PyTorch's pool -- a fifth busy stream on a queue nobody chose.  The collectives of the overlapped exchange are therefore
+# issued as synchronous ops (``async_op=False``): since PyTorch 2.7 (AllreduceOptions.asyncOp) a synchronous op is enqueued on the
+# CURRENT stream, i.e. the RCCL kernel runs on the trainer's ready stream in front of the sharded update that consumes it, where it
+# is ordered by the stream itself.  The host does not block (NCCL / RCCL; gloo blocks the host in either form).
+class _Done:
+    def wait(self):
+        return True
+
+
+def _on_current_stream():
+    """True when this PyTorch runs synchronous collectives on the caller's stream (2.7+: the ``asyncOp`` option exists)."""
+    return hasattr(dist, "AllreduceOptions") and hasattr(dist.AllreduceOptions(), "asyncOp")
+
+
 def allreduce_async(t):
-    """Start the sum of ``t`` over all ranks on the current stream's timeline; returns a handle whose ``wait()`` orders the
-    then-current stream after the collective (a no-op handle in single-process runs)."""
+    """Sum of ``t`` over all ranks, ordered on the current stream's timeline (see the note above); returns a handle whose ``wait()``
+    orders the then-current stream after the collective (a no-op handle in single-process runs and for the on-stream form)."""
     if world_size() == 1:
-        class _Done:
-            def wait(self):
-                return True
+        return _Done()
+    if _on_current_stream():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=False)
         return _Done()
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
@@ -82,11 +99,17 @@ def shard_layout(n, world):
 
 def reduce_scatter_async(out, inp):
     """out <- this rank's 1/world slice of sum_ranks(inp) (inp.numel() == world * out.numel()); handle as allreduce_async."""
+    if _on_current_stream():
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, async_op=False)
+        return _Done()
     return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, async_op=True)
 
 
 def all_gather_async(out, inp):
     """out <- concatenation over ranks of inp (out.numel() == world * inp.numel())."""
+    if _on_current_stream():
+        dist.all_gather_into_tensor(out, inp, async_op=False)
+        return _Done()
     return dist.all_gather_into_tensor(out, inp, async_op=True)
 
 

@@ -225,6 +225,13 @@ class FlowEngine:
                                           ptr(st["cond"]), B, ptr(st["out"]), ptr(ws), _lib.current_stream()))
         return st["out"].clone()
 
+    def side_stream(self):
+        """The engine's weight-gradient stream as a torch stream (``ipoke_flow_side_stream``), or None without a GPU."""
+        if not torch.cuda.is_available():
+            return None
+        h = self.lib.ipoke_flow_side_stream(self.handle)
+        return torch.cuda.ExternalStream(h) if h else None
+
     def handoff_timeouts(self):
         """(unit launches, fused conv3 + coupling launches) whose in-launch hand-off gave up since the exchange scratches were last
         initialised (``ipoke_flow_handoff_timeouts``; synchronises the device).  Anything but (0, 0) means a pass finished on garbage;

@@ -42,8 +42,16 @@ class SecondStageTrainer:
             self.opt.enable_sharding(self.world, D.rank(), gd)
         # one process, no accumulation: the engine queues every piece's update itself (no host callback inside the backward pass)
         self.native_opt = self.overlap and self.world == 1 and os.environ.get("IPOKE_NO_NATIVE_ADAM", "0") != "1"
+        want_prefetch = os.environ.get("IPOKE_NO_PREFETCH", "0") != "1" and torch.cuda.is_available()
+        own_prefetch = want_prefetch and os.environ.get("IPOKE_PREFETCH_STREAM", "own") != "chain"
+        picked = []
         if self.overlap:
-            self.ready_stream = torch.cuda.Stream()      # the hook itself is installed around the backward of train_step only
+            # the streams this trainer keeps busy beside the chain and the engine's weight-gradient stream must each sit on a hardware
+            # queue of its own (utils/streams.py: a shared queue serialises them -- 2x on the step when it is the chain's)
+            from .utils.streams import distinct_streams
+            side = model.flow.engine.side_stream()
+            picked = distinct_streams(1 + int(own_prefetch), against=[torch.cuda.current_stream()] + ([side] if side is not None else []))
+            self.ready_stream = picked[0]                # the hook itself is installed around the backward of train_step only
         # train_step(batch, next_batch=...): the frozen encoders (first stage, poke, image) of the NEXT batch do not depend on the
         # flow's parameters; they are issued on their own stream right after this step's forward and run underneath its
         # latency-bound backward chain (86.2 -> 83.2 ms at c2).  Every step still runs one encoder pass.
@@ -51,11 +59,11 @@ class SecondStageTrainer:
         if os.environ.get("IPOKE_NO_PREFETCH", "0") != "1" and torch.cuda.is_available():
             # Stream budget: the step is tuned for FOUR busy streams -- chain, weight gradients, ready / optimizer, encoder
             # prefetch.  A fifth busy stream costs +18 ms per step whatever it carries (measured with a second weight-gradient and a
-            # second optimizer stream, any GPU_MAX_HW_QUEUES).  At world > 1 RCCL's own stream is busy during the backward pass, so the
-            # next batch's encoders go behind the backward chain on the caller's stream there (measured on one GPU: +1.5 ms against the
-            # prefetch stream, i.e. 52.3 vs 50.8 ms); one GPU keeps the prefetch stream.  IPOKE_PREFETCH_STREAM=own|chain overrides.
-            where = os.environ.get("IPOKE_PREFETCH_STREAM", "own" if self.world == 1 else "chain")
-            self.prefetch_stream = torch.cuda.current_stream() if where == "chain" else torch.cuda.Stream()
+            # second optimizer stream, any GPU_MAX_HW_QUEUES).  At world > 1 the collectives are issued as synchronous ops, which RCCL
+            # runs ON the ready stream (ipoke_amd/dist.py): the budget stays at four for every world size.  IPOKE_PREFETCH_STREAM=chain
+            # puts the next batch's encoders behind the backward chain on the caller's stream instead (three busy streams; +1.5 ms on
+            # one GPU, 52.3 vs 50.8) -- for PyTorch builds whose collectives still run on an internal stream.
+            self.prefetch_stream = (picked[1] if len(picked) > 1 else torch.cuda.Stream()) if own_prefetch else torch.cuda.current_stream()
             # IPOKE_ENC_GRAPH=1 (developer A/B, measured slower: PokeMotionModel.set_encoder_graph): the prefetched encoders replayed from
             # one captured hipGraph, gated on the GPU side at the END of the backward pass, instead of ~200 eager launches
             if os.environ.get("IPOKE_ENC_GRAPH", "0") == "1":

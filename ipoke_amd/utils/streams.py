@@ -97,3 +97,54 @@ def overlapping_stream(candidates=8, spin_ms=0.5, report=None):
     warnings.warn(f"overlapping_stream: none of {candidates} streams passed the overlap / stalled-launch checks on this device "
                   f"(best score {best_score:.2f}); using the best candidate -- set IPOKE_SIDE_STREAM=plain to skip the probe", RuntimeWarning)
     return best
+
+
+def _pair_ratio(a, b, cycles, single):
+    """(time of one spin kernel on ``a`` and one on ``b``) / (time of one): ~1.0-1.2 when the two streams sit on different hardware
+    queues, ~2.0 when they share one."""
+    _spin_pair_ms(a, b, cycles)                                         # first use binds the queue
+    return min(_spin_pair_ms(a, b, cycles) for _ in range(3)) / single
+
+
+def distinct_streams(n, against=(), candidates=32, spin_ms=0.4, report=None):
+    """``n`` streams of PyTorch's pool that run BESIDE each other and beside every stream in ``against`` (the caller's stream, the
+    flow engine's weight-gradient stream, ...): each accepted stream passes a two-kernel overlap check against all of them.  The train
+    step keeps four streams busy at once; two of them on one hardware queue serialise (measured: a busy stream on the chain's queue
+    doubles the step, 111.8 vs 49.5 ms), and which queue a stream of the pool lands on depends on every stream the process -- PyTorch,
+    this library, RCCL -- has created before.  Falls back to the best candidates with a warning when fewer than ``n`` pass (a busy or
+    shared device makes the timings noise); IPOKE_SIDE_STREAM=plain skips the probe."""
+    if os.environ.get("IPOKE_SIDE_STREAM", "") == "plain" or n <= 0:
+        return [torch.cuda.Stream() for _ in range(n)]
+    main = torch.cuda.current_stream()
+    cycles = 100_000
+    _spin_pair_ms(main, None, cycles)
+    single = min(_spin_pair_ms(main, None, cycles) for _ in range(3))
+    per_ms = cycles / max(single, 1e-3)
+    cycles = min(max(int(per_ms * spin_ms), 1000), 5_000_000)
+    hold = min(max(int(per_ms * 4.0), 1000), 40_000_000)
+    single = min(_spin_pair_ms(main, None, cycles) for _ in range(3))
+    chosen, rejected = [], []
+    fixed = list(against)
+    for i in range(candidates):
+        cand = torch.cuda.Stream()
+        if any(cand.cuda_stream == s_.cuda_stream for s_ in fixed + chosen):
+            continue
+        worst = max(_pair_ratio(o, cand, cycles, single) for o in fixed + chosen) if fixed or chosen else 1.0
+        # ... and a pending wait of the candidate for an event of the caller's stream must not stall that stream's launches (see above)
+        slow = _waiter_slowdown(main, cand, hold) if worst < 1.35 else float("inf")
+        if report is not None:
+            report.append((i, round(worst, 3), None if slow == float("inf") else round(slow, 2)))
+        if worst < 1.35 and slow < 2.5:
+            chosen.append(cand)
+            if len(chosen) == n:
+                return chosen
+        else:
+            rejected.append((worst + (0.0 if slow == float("inf") else slow), cand))
+    import warnings
+    warnings.warn(f"distinct_streams: only {len(chosen)} of {n} streams passed the overlap check against {len(fixed)} busy streams "
+                  "(is the device shared or busy?); filling up with the least overlapping candidates -- set IPOKE_SIDE_STREAM=plain to "
+                  "skip the probe", RuntimeWarning)
+    rejected.sort(key=lambda t_: t_[0])
+    while len(chosen) < n:
+        chosen.append(rejected.pop(0)[1] if rejected else torch.cuda.Stream())
+    return chosen

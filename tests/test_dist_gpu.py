@@ -124,3 +124,81 @@ def test_bench_gpus2_self_launches_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 16 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+
+
+def test_stream_budget_of_the_multi_gpu_step_on_one_gpu():
+    """VERDICT r5 item 4 / DESIGN.md §6 "stream budget": the c2 train step keeps FOUR streams busy (chain, the engine's weight-gradient
+    stream, ready / optimizer, encoder prefetch) -- as many as the device has compute pipes.  (i) SecondStageTrainer picks its two
+    streams so that all four overlap pairwise (two busy streams on one hardware queue serialise).  (ii) At world > 1 the collectives
+    are synchronous ops, which this PyTorch runs ON the caller's (ready) stream (ipoke_amd/dist.py: AllreduceOptions.asyncOp) -- RCCL
+    adds no stream.  (iii) What a fifth busy stream would cost is measured beside it at the benchmarked size with a loop of one-wave
+    kernels on an extra stream through the whole step: +26 ms on the least colliding stream of the pool (no candidate passes the
+    overlap check against four busy streams), 2x on one that shares the chain's queue (76.4 / 110.2 vs 49.9 ms when written)."""
+    import time
+    from ipoke_amd import _lib, configs
+    from ipoke_amd.second_stage import PokeMotionModel
+    from ipoke_amd.trainer import SecondStageTrainer
+    from ipoke_amd.utils import streams as S
+    from tests.helpers import synthetic_batch
+    cfg = configs.BENCH_CONFIGS["c2"]
+    B = cfg["batch_size"]
+    conf = configs.second_stage_config(cfg["spatial_size"], cfg["z_dim"], cfg["n_frames"], B)
+    torch.manual_seed(0)
+    m = PokeMotionModel(conf, dirs={}, dtype="bf16", device="cuda", max_batch=B)
+    tr = SecondStageTrainer(m)
+    main, side = torch.cuda.current_stream(), m.flow.engine.side_stream()
+    assert tr.native_opt and tr.prefetch_stream is not None and side is not None
+    busy = [main, side, tr.ready_stream, tr.prefetch_stream]
+    assert len({s_.cuda_stream for s_ in busy}) == 4
+    # (i) pairwise overlap of the four busy streams: two spin kernels on two of them take about the time of one
+    cycles = 2_000_000
+    S._spin_pair_ms(main, None, cycles)
+    single = min(S._spin_pair_ms(main, None, cycles) for _ in range(3))
+    ratios = {(i, j): S._pair_ratio(busy[i], busy[j], cycles, single) for i in range(4) for j in range(i + 1, 4)}
+    print("pairwise spin ratios of (chain, weight gradients, ready, prefetch):", {k: round(v, 2) for k, v in ratios.items()})
+    assert max(ratios.values()) < 1.5, ratios
+    batch = synthetic_batch(B, cfg["n_frames"], cfg["spatial_size"], seed=1, device="cuda")
+    tr.sync_initial_state(batch)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    with torch.no_grad():
+        for name, p in m.flow.named_parameters():
+            if name.endswith("weight_g"):
+                p.copy_(0.02 + 0.01 * torch.rand(p.shape, device=p.device, generator=g))
+    m.flow.mark_weights_updated()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)      # (no fifth stream passes the overlap check: that is the point)
+        fifth = S.distinct_streams(1, against=busy, candidates=12)[0]
+    colliding = None                                        # a pool stream on the chain's hardware queue, if the pool has one
+    for _ in range(32):
+        c_ = torch.cuda.Stream()
+        if all(c_.cuda_stream != s_.cuda_stream for s_ in busy + [fifth]) and S._pair_ratio(main, c_, cycles, single) > 1.7:
+            colliding = c_
+            break
+    L = _lib.lib()
+
+    def timed(extra, steps=10):
+        for i in range(3):
+            tr.train_step(batch, i, next_batch=batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if extra is not None:         # ~60 ms of back-to-back one-wave kernels: busy through the forward and the backward pass
+                extra.wait_stream(torch.cuda.current_stream())
+                for _ in range(60):
+                    _lib.check(L.ipoke_spin_delay(1000, extra.cuda_stream))
+            tr.train_step(batch, 3 + i, next_batch=batch)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    four = timed(None)
+    five = timed(fifth)
+    bad = timed(colliding) if colliding is not None else float("nan")
+    four2 = timed(None)
+    base = min(four, four2)
+    print(f"c2 step: four busy streams {four:.2f} / {four2:.2f} ms; + a busy fifth stream on its own hardware queue {five:.2f} ms; "
+          f"+ the same loop on a stream sharing the chain's queue {bad:.2f} ms")
+    from ipoke_amd import dist as D
+    assert D._on_current_stream(), "this PyTorch would run the gradient exchange on an internal (fifth) stream: set IPOKE_PREFETCH_STREAM=chain"
+    assert four2 <= 1.05 * four and four <= 1.05 * four2, (four, four2)          # the four-stream step itself is steady
+    assert m.flow.engine.handoff_timeouts() == (0, 0)
