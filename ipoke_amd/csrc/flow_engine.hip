@@ -1759,7 +1759,9 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   // signal between two chain kernels, ~10 us of queue time each (profiles/r03_bench_trace_gaps.txt: 112 gaps of 12.8 us per step in
   // front of the fused units).  IPOKE_NICE_FLUSH_MIN couplings are collected before the chain pays for one (the end of a piece always
   // flushes: finish_piece).
-  static const int flush_min = getenv("IPOKE_NICE_FLUSH_MIN") ? atoi(getenv("IPOKE_NICE_FLUSH_MIN")) : 2;
+  // round 6 (with the stationary-input conv1 / conv3 weight gradients: 32 workgroups per problem): four couplings per batch, 48.83 / 48.62
+  // against 48.98 / 49.04 ms at two (one call); 3 / 6 / 8: 48.9 / 48.8 / 48.8
+  static const int flush_min = getenv("IPOKE_NICE_FLUSH_MIN") ? atoi(getenv("IPOKE_NICE_FLUSH_MIN")) : 4;
   auto maybe_flush_nice = [&]() -> int { return (int)pend_nice.size() >= flush_min ? flush_nice() : (int)IPOKE_OK; };
   size_t pk = 0;
   int cur = 0;

@@ -1134,7 +1134,8 @@ static size_t device_max_lds() {
   return bytes;
 }
 constexpr size_t kLdsC64 = 9 * 64 * 128 + 2 * 41 * 1024 + 1024, kLdsHalo16 = 2 * 41 * 1024 + 4 * 128 * 128 + 8 * 1024,
-                 kLdsHalo = 2 * 24 * 1024 + 12 * 64 * 128 + 8 * 1024, kLdsS8 = 2 * 128 * 128 + 256 + 12 * 64 * 128 + 512 * 16;
+                 kLdsHalo = 2 * 24 * 1024 + 12 * 64 * 128 + 8 * 1024, kLdsS8 = 2 * 128 * 128 + 256 + 12 * 64 * 128 + 512 * 16,
+                 kLdsLat8 = 3 * 2 * 128 * 128 + 256;
 
 // The dynamic-LDS attribute of a kernel is set once per process, race-free (the header promises thread safety for launches on
 // distinct streams): one std::once_flag + result per expansion site, i.e. per kernel (template instantiation).
@@ -3364,6 +3365,224 @@ __global__ __launch_bounds__(512) void igemm_tn_glds_kernel(const TnParams pin) 
   }
 }
 
+// =============================================================================================
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on the 8x8 latent with the INPUT STATIONARY (round 6): conv1 and conv3 of
+// every coupling net (macow_utils.py:270-281) -- one side of the problem is narrow (conv3: <= 64 outputs over 9 x 2048 inputs, conv1:
+// 2048 outputs over 9 x <= 64 inputs).  As an implicit GEMM (igemm_tn_glds above) the nine taps are nine K-columns: every tile
+// re-gathers the shifted input rows per tap and stage -- 960 KB of operand stream per workgroup, a 20-stage chain of loaded L2 -> LDS
+// latencies; the two families took 11 ms of the weight-gradient queue per c2 step for 1.3 TFLOP (4 % of the matrix peak).
+// Here a workgroup owns a [64 outputs] x [64 inputs] x [9 taps] block of dW.  A stage is two whole samples: the dY image
+// [128 rows x 64 n] and the input image [128 rows x 64 c], 16 KB each, global -> LDS untouched (3-slot ring, one barrier per stage);
+// the nine taps read the SAME input image through shifted row addresses -- every lane of a transposing read (ds_read_b64_tr_b16)
+// supplies the address of one row, so a row whose tap falls outside the 8x8 map points at a zero row.  320 KB of operand stream per
+// workgroup at B = 20.  Eight waves = 2 reduction halves (rows 32 kg .. 32 kg + 31 of both samples) x 4 column groups (16 inputs
+// each); a wave holds acc[9 taps][4] fragments (144 registers); the halves meet in LDS in a fixed order, and the block leaves
+// through an LDS image of the PyTorch layout [n][c][tap] (9 x 64 consecutive floats per output row).
+// 128-byte image rows: 16-byte chunk p of row r is stored at chunk p ^ lat8_swz(r) (applied on the DMA's source side).
+__device__ __forceinline__ int lat8_swz(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
+
+struct Lat8Params {
+  const TnBatchEntry* batch; const unsigned char* a_base; const unsigned char* y_base; float* w_base;
+  int M;                 // 64 * B rows
+  int lda, a_coff, Kc, Kc_store;      // input rows: [M][lda] bf16, first channel a_coff, Kc channels in the K index, Kc_store written
+  int ldy, y_coff, Nout;              // dY rows: [M][ldy] bf16
+  long w_sn;             // floats between output rows of dW ([n][c][3][3]: w_sn = Cin * 9)
+  int tiles_n, tiles_c, z0;
+};
+
+template <int NSTAGE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3x3_lat8_kernel(const Lat8Params p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(Lat8Params)>();
+  typedef bf16_t T;
+  typedef ET<T>::frag frag_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int IMG = 128 * 128;                // one operand image: 128 rows x 64 bf16
+  constexpr int STAGE = 2 * IMG;
+  constexpr int L = 4;                          // DMA instructions per thread and stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* zrow = smem + NSTAGE * STAGE;  // 128 bytes of zeros
+  const TnBatchEntry e = p.batch[blockIdx.z + p.z0];
+  const T* A = reinterpret_cast<const T*>(p.a_base + e.a_off);
+  const T* dY = reinterpret_cast<const T*>(p.y_base + e.y_off);
+  float* dW = p.w_base + e.w_off;
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = wave >> 2, wc = wave & 3;
+  const int tile = blockIdx.x, tn = tile % p.tiles_n, tc = tile / p.tiles_n;
+  const int n0 = tn * 64, c0 = tc * 64;
+  const int nst = (p.M + 127) >> 7;
+  if (tid < 8) reinterpret_cast<f32x4*>(zrow)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- DMA: instruction i of a thread fills rows 8 * (wave + 8 i) .. + 7 (lane / 8) of an image, chunk position lane % 8
+  int d_row[2]; unsigned y_src[2], x_src[2]; bool y_ok[2], x_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave + 8 * i) + (lane >> 3), sch = (lane & 7) ^ lat8_swz(row);
+    d_row[i] = row;
+    const int ncol = n0 + sch * 8, ccol = c0 + sch * 8;
+    y_ok[i] = ncol < ((p.Nout + 7) & ~7) && ncol + 8 <= p.ldy - p.y_coff;
+    x_ok[i] = ccol < p.Kc;
+    y_src[i] = (unsigned)(p.y_coff + ncol);
+    x_src[i] = (unsigned)(p.a_coff + ccol);
+  }
+  auto issue = [&](int slot, int st, bool real) {
+    unsigned char* sy = smem + slot * STAGE;
+    unsigned char* sx = sy + IMG;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long m = (long)st * 128 + d_row[i];
+      const T* src = (real && y_ok[i] && m < p.M) ? dY + m * p.ldy + y_src[i] : zero;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sy + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long m = (long)st * 128 + d_row[i];
+      const T* src = (real && x_ok[i] && m < p.M) ? A + m * p.lda + x_src[i] : zero;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sx + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment reads.  Lane (i16 = lane & 15, grp = lane >> 4) supplies row 32 kg + 8 grp + (i16 >> 2) (+ 4 for the upper half of
+  //      the 8 reduction rows) of a sample, columns base + 4 (i16 & 3); it receives column base + i16, reduction rows 8 grp .. + 7
+  const int i16 = lane & 15, grp = lane >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned zaddr = lds0 + (unsigned)(NSTAGE * STAGE) + 8u * (unsigned)(i16 & 3);
+  const int r_lo = 32 * kg + 8 * grp + (i16 >> 2);                  // row inside a sample (0 .. 63); the upper half is r_lo + 4
+  auto img_off = [&](int row, int col) {                             // byte offset inside an image of (row, 4-column group at col)
+    return row * 128 + (((col >> 3) ^ lat8_swz(row)) * 16) + ((col >> 2) & 1) * 8;
+  };
+  unsigned y_rd[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) y_rd[i][h] = lds0 + (unsigned)img_off(r_lo + 4 * h, 16 * i + 4 * (i16 & 3));
+  const int xcol = 16 * wc + 4 * (i16 & 3);
+  // validity of tap (dy, dx) for this lane's two rows: y = 4 kg + grp for both, x = (i16 >> 2) + 4 h
+  const int py = 4 * kg + grp, px = i16 >> 2;
+  auto x_addr = [&](int h, int dy, int dx) -> unsigned {              // address of the shifted row inside sample 0 of slot 0
+    const int yy = py + dy, xx = px + 4 * h + dx;
+    if ((unsigned)yy >= 8u || (unsigned)xx >= 8u) return zaddr;
+    return lds0 + (unsigned)(IMG + img_off(r_lo + 4 * h + 8 * dy + dx, xcol));
+  };
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto tr_read = [&](unsigned addr) -> tn_tr4_t { return tn_ds_tr<0>(addr); };
+  auto load_frag = [&](frag_t& f, unsigned a_lo, unsigned a_hi) {
+    const tn_tr4_t lo = tr_read(a_lo), hi = tr_read(a_hi);
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) { f[e2] = lo[e2]; f[4 + e2] = hi[e2]; }
+  };
+
+  int issued = 0;
+#pragma unroll
+  for (int s2 = 0; s2 < NSTAGE - 1; ++s2) { issue(s2, issued, issued < nst); ++issued; }
+  int slot = 0;
+  for (int it = 0; it < nst; ++it) {
+    wait_vmcnt<(NSTAGE - 2) * L>();               // this wave's share of stage `it` has landed ...
+    __builtin_amdgcn_s_barrier();                 // ... everybody's, and everybody is done with the slot refilled below
+    {
+      const int fill = slot + NSTAGE - 1 >= NSTAGE ? slot - 1 : slot + NSTAGE - 1;
+      issue(fill, issued, issued < nst); ++issued;
+    }
+    const unsigned sb = (unsigned)(slot * STAGE);
+#pragma unroll
+    for (int smp = 0; smp < 2; ++smp) {
+      const unsigned so = sb + (unsigned)(smp * 64 * 128);
+      frag_t fy[4], fx[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_frag(fy[i], y_rd[i][0] + so, y_rd[i][1] + so);
+      {
+        const unsigned a0 = x_addr(0, -1, -1), a1 = x_addr(1, -1, -1);
+        load_frag(fx[0], a0 == zaddr ? zaddr : a0 + so, a1 == zaddr ? zaddr : a1 + so);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fy[0]), "+v"(fy[1]), "+v"(fy[2]), "+v"(fy[3]), "+v"(fx[0])::"memory");
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t < 8) {
+          const int dy = (t + 1) / 3 - 1, dx = (t + 1) % 3 - 1;
+          const unsigned a0 = x_addr(0, dy, dx), a1 = x_addr(1, dy, dx);
+          load_frag(fx[(t + 1) & 1], a0 == zaddr ? zaddr : a0 + so, a1 == zaddr ? zaddr : a1 + so);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma64(fy[i], fx[t & 1], acc[t][i]);
+        if (t < 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fx[(t + 1) & 1])::"memory");
+      }
+    }
+    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+  }
+  wait_vmcnt<0>();
+  __syncthreads();                                // the ring is dead
+
+  // ---- epilogue: the two reduction halves meet (kg 1 parks, kg 0 adds: a fixed order), the block leaves as rows of 9 * 64 floats.
+  // acc[t][i][r] = dW[n = n0 + 16 i + (lane & 15)][c = c0 + 16 wc + 4 (lane >> 4) + r][tap t]; two rounds of 32 output rows
+  float* img = reinterpret_cast<float*>(smem);    // [32 n][64 c * 9 + pad]: 577 floats per row (odd pitch: conflict-free scalar access)
+  constexpr int PITCH = 577;
+  const int c_loc = 16 * wc + 4 * grp;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (kg == 1) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        float* row = img + (16 * ii + i16) * PITCH;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) row[(c_loc + r) * 9 + t] = acc[t][2 * half + ii][r];
+      }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        float* row = img + (16 * ii + i16) * PITCH;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) row[(c_loc + r) * 9 + t] += acc[t][2 * half + ii][r];
+      }
+    }
+    __syncthreads();
+    const int ncols = 9 * max(0, min(64, p.Kc_store - c0));          // floats of a row that exist in dW
+    for (int idx = tid; idx < 32 * 576; idx += 512) {
+      const int rl = idx / 576, cc = idx - rl * 576;
+      const int n = n0 + 32 * half + rl;
+      if (n < p.Nout && cc < ncols) dW[(long)n * p.w_sn + (long)c0 * 9 + cc] = img[rl * PITCH + cc];
+    }
+    __syncthreads();
+  }
+}
+
+static bool lat8_applicable(const TnParams& p, int nbatch) {
+  static const int on = getenv("IPOKE_WGRAD_LAT8") ? atoi(getenv("IPOKE_WGRAD_LAT8")) : 1;      // developer A/B: 0 keeps the implicit-GEMM kernels
+  const GeomDev& g = p.g;
+  return on && p.batch && nbatch >= 1 && !p.a_f32 && p.a_sc == 1 && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Hi == 8 && g.Wi == 8 &&
+         g.Do == 1 && g.Ho == 8 && g.Wo == 8 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 1 && g.pw == 1 && !g.transposed &&
+         p.a_sh == 8 * p.a_sw && p.a_sn == 64 * p.a_sw && (p.a_sw & 7) == 0 && (p.a_coff & 7) == 0 && (p.Kc & 7) == 0 && p.Kc == p.Kc_real &&
+         (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && p.splitm == 1 && !p.accumulate && p.split_stride == 0 && p.w_sc == 9 && p.w_st == 1 &&
+         p.w_sn >= (long)p.Kc_store * 9 && p.max_wgs <= 0 && g.M % 64 == 0 && p.ad_p == nullptr && kLdsLat8 <= device_max_lds() &&
+         (long)g.M * p.a_sw < (1L << 31) && (long)g.M * p.ldy < (1L << 31) &&
+         ((reinterpret_cast<uintptr_t>(p.a_base) | reinterpret_cast<uintptr_t>(p.y_base)) & 15) == 0;
+}
+static int launch_lat8(const TnParams& t, hipStream_t s, int nbatch) {
+  Lat8Params p;
+  p.batch = t.batch; p.a_base = t.a_base; p.y_base = t.y_base; p.w_base = t.w_base;
+  p.M = t.g.M; p.lda = (int)t.a_sw; p.a_coff = t.a_coff; p.Kc = t.Kc; p.Kc_store = t.Kc_store;
+  p.ldy = t.ldy; p.y_coff = t.y_coff; p.Nout = t.Nout; p.w_sn = t.w_sn;
+  p.tiles_n = ceil_div(t.Nout, 64); p.tiles_c = ceil_div(t.Kc, 64); p.z0 = 0;
+  auto kern = wgrad3x3_lat8_kernel<3>;
+  IPK_SET_LDS_ONCE(kern, kLdsLat8);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_n * p.tiles_c), 1, (unsigned)nbatch), dim3(512), kLdsLat8, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
 template <typename T>
 static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   constexpr int RM = 128 / (int)sizeof(T);
@@ -3376,6 +3595,10 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   if (p.splitm < 1) p.splitm = 1;
   if (p.splitm > nmb) p.splitm = nmb;
   p.mb_per_split = ceil_div(nmb, p.splitm);
+  if constexpr (sizeof(T) == 2) {
+    // batched 3x3 problems on the 8x8 latent (conv1 / conv3 of the coupling nets): the stationary-input kernel
+    if (lat8_applicable(p, nbatch)) return launch_lat8(p, s, nbatch);
+  }
   const size_t lds = 4 * 128 * kPitch + 256 * sizeof(int);
   // LDS-DMA + transposed-read kernel: bf16, dense operands with 16-byte aligned rows
   static const int glds = getenv("IPOKE_TN_GLDS") ? atoi(getenv("IPOKE_TN_GLDS")) : 1;

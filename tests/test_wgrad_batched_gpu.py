@@ -16,8 +16,12 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("B,Cin,Cout,k,nb", [(3, 256, 64, 3, 2), (5, 512, 60, 3, 3), (4, 256, 24, 3, 1), (2, 128, 64, 3, 2),
-                                               (3, 64, 192, 3, 2), (3, 256, 256, 1, 2)])
+                                               (3, 64, 192, 3, 2), (3, 256, 256, 1, 2),
+                                               (20, 2048, 64, 3, 2), (20, 32, 2048, 3, 2), (7, 320, 136, 3, 1), (1, 64, 64, 3, 1)])
 def test_batched_weight_gradient_matches_torch(B, Cin, Cout, k, nb):
+    """(the 3 x 3 cases run the stationary-input kernel wgrad3x3_lat8 of round 6 -- incl. the benchmarked conv3 / conv1 shapes of a
+    coupling net at B = 20, odd batches (a half-empty last stage), ragged output and input widths; IPOKE_WGRAD_LAT8=0 sends them through
+    the implicit-GEMM kernels again)"""
     lib = _lib.lib()
     M = B * 64
     gen = torch.Generator().manual_seed(B * 100 + Cout + k)
