@@ -72,7 +72,7 @@ def randomise_couplings(model, seed=0):
     model.flow.mark_weights_updated()
 
 
-PMC_ROUND = "r05"          # the committed PMC passes roofline.traffic is read from (NOT measured by this run: see traffic_source)
+PMC_ROUND = "r06"          # the committed PMC passes roofline.traffic is read from (NOT measured by this run: see traffic_source)
 
 
 def gemm_source_hash():

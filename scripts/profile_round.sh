@@ -1,7 +1,7 @@
 # Round profile: kernel traces (+ stats, queue gaps, chain / side-stream overlap), PMC passes (separate runs), bench lines.
 # Usage on the GPU box:  bash scripts/profile_round.sh r03
 set -x
-RN=${1:-r05}
+RN=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${RN}
