@@ -3022,6 +3022,9 @@ static int dispatch_nn(NtParams& p, hipStream_t s) {
   int best = 128; long best_cost = ((long)ceil_div(M, 128) * tn128 + 255) / 256 * 128;
   if (M % 160 == 0) { const long c = ((long)(M / 160) * tn128 + 255) / 256 * 160; if (c <= best_cost) { best = 160; best_cost = c; } }
   if (M % 80 == 0) { const long c = ((long)(M / 80) * tn128 + 255) / 256 * 80; if (c < best_cost) { best = 80; best_cost = c; } }
+  static const int nn_stages = getenv("IPOKE_NN_STAGES") ? atoi(getenv("IPOKE_NN_STAGES")) : 3;      // developer A/B: ring depth of the 80 x 128 tile
+  if (best == 80 && nn_stages == 4) return launch_nn_glds<1, 4, 5, 4, 2>(p, s);
+  if (best == 80 && nn_stages == 5) return launch_nn_glds<1, 4, 5, 5, 2>(p, s);
   if (best == 80) return launch_nn_glds<1, 4, 5, 3, 2>(p, s);       // 80 x 128: two K halves x 4 waves of 80 x 32 (the c2 shape: 256 workgroups)
   if (best == 160) return launch_nn_glds<2, 4, 5, 3, 1>(p, s);      // 160 x 128, 8 waves of 80 x 32
   return launch_nn_glds<2, 4, 4, 3, 1>(p, s);                       // 128 x 128
@@ -3576,9 +3579,18 @@ static int launch_lat8(const TnParams& t, hipStream_t s, int nbatch) {
   p.M = t.g.M; p.lda = (int)t.a_sw; p.a_coff = t.a_coff; p.Kc = t.Kc; p.Kc_store = t.Kc_store;
   p.ldy = t.ldy; p.y_coff = t.y_coff; p.Nout = t.Nout; p.w_sn = t.w_sn;
   p.tiles_n = ceil_div(t.Nout, 64); p.tiles_c = ceil_div(t.Kc, 64); p.z0 = 0;
-  auto kern = wgrad3x3_lat8_kernel<3>;
-  IPK_SET_LDS_ONCE(kern, kLdsLat8);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_n * p.tiles_c), 1, (unsigned)nbatch), dim3(512), kLdsLat8, s, p);
+  static const int nst = getenv("IPOKE_LAT8_STAGES") ? atoi(getenv("IPOKE_LAT8_STAGES")) : 3;      // developer A/B: ring slots (2 samples each)
+  const dim3 grid((unsigned)(p.tiles_n * p.tiles_c), 1, (unsigned)nbatch);
+  if (nst == 4) {
+    constexpr size_t lds4 = 4 * 2 * 128 * 128 + 256;
+    auto kern = wgrad3x3_lat8_kernel<4>;
+    IPK_SET_LDS_ONCE(kern, lds4);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds4, s, p);
+  } else {
+    auto kern = wgrad3x3_lat8_kernel<3>;
+    IPK_SET_LDS_ONCE(kern, kLdsLat8);
+    hipLaunchKernelGGL(kern, grid, dim3(512), kLdsLat8, s, p);
+  }
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

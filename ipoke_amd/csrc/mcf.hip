@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
           const float t = sc - 1.f;
           v = (gy * P.x[(row0 + p) * P.ld + c] + g_ld / sc) * 0.5f * (1.f - t * t);
         }
-        atomicAdd(&colsum[j], v);
+        psum[p * N2 + j] = v;            // (column sums below, rows in order: no LDS float atomics, run-to-run reproducible)
       }
       const T tv = ET<T>::from_f32(v);
       *reinterpret_cast<T*>(dp + p * dp_pitch + j * (int)sizeof(T)) = tv;
@@ -356,7 +356,11 @@ __global__ __launch_bounds__(kMcfThreads) void mcf_bwd_kernel(const McfParams P)
       P.post_part[(long)b * N2 + threadIdx.x] = threadIdx.x < P.C ? t + 64.f * g_ld : t;
     }
   } else if (P.dbias_part) {
-    for (int i = threadIdx.x; i < N2; i += blockDim.x) P.dbias_part[(long)b * N2 + i] = colsum[i];
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) {
+      float t = 0.f;
+      for (int p = 0; p < 64; ++p) t += psum[p * N2 + i];
+      P.dbias_part[(long)b * N2 + i] = t;
+    }
   }
 
   // (b) dA2[:, :H] = dparams x W2[:, :H]  , times ELU'(c) -> dc

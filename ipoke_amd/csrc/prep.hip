@@ -196,7 +196,9 @@ __global__ void wn_bwd_kernel(const float* __restrict__ params, float* __restric
   if (vec && (j.K >> 2) <= 192) {
     // short rows (3x3 kernels on <= 64 channels, the masked convolutions: most rows of a piece): the row of v and of dW_eff stays in
     // registers between the dot product and the update instead of being read twice (8 of this kernel's 20 bytes per parameter; it
-    // runs on the optimizer's queue, which bounds the backward pass).  Same products, same order of the sums.
+    // runs on the optimizer's queue, which bounds the backward pass).  Same products; the per-lane partial sums associate differently
+    // from the long-row loop's (one expression per 8 / 4 products here), so the two paths agree to fp32 round-off, not bit for bit --
+    // a given row always takes the same path, which is what run-to-run reproducibility needs.
     const f32x4* v4 = reinterpret_cast<const f32x4*>(v);
     f32x4* d4 = reinterpret_cast<f32x4*>(dw);
     const int n4 = j.K >> 2;

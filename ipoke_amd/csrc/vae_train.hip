@@ -200,8 +200,16 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(SnView V, const float* 
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(SnView V, float* __restrict__ g, const float* __restrict__ snap, const float* __restrict__ sig,
                                                            const float* __restrict__ acc) {
   const long total = (long)V.R * V.C;
-  float tot = 0.f;
-  for (int b = 0; b < (int)gridDim.x; ++b) tot += acc[b];
+  // the dot kernel's per-workgroup partials, summed ONCE per workgroup in their fixed order (every thread of every workgroup used to walk
+  // all of them: up to 256 dependent loads per thread)
+  __shared__ float tot_s;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int b = 0; b < (int)gridDim.x; ++b) t += acc[b];
+    tot_s = t;
+  }
+  __syncthreads();
+  const float tot = tot_s;
   const float inv = sig[1], dot = tot * inv;             // <G, W/sigma>
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int r = (int)(i / V.C), c = (int)(i - (long)r * V.C);

@@ -9,3 +9,5 @@ cp $(find /tmp/p_$TAG -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stat
 python $R/scripts/trace_gaps.py $T > $O/${TAG}_trace_gaps.txt 2>&1
 python $R/scripts/trace_overlap.py $T > $O/${TAG}_overlap.txt 2>&1
 python $R/scripts/trace_steady.py $T flow_nll 6 > $O/${TAG}_steady.txt 2>&1
+python $R/scripts/trace_by_grid.py $T tn_glds > $O/${TAG}_tn_by_grid.txt 2>&1
+python $R/scripts/trace_by_grid.py $T lat8 >> $O/${TAG}_tn_by_grid.txt 2>&1
