@@ -113,7 +113,8 @@ def distinct_streams(n, against=(), candidates=32, spin_ms=0.4, report=None):
     doubles the step, 111.8 vs 49.5 ms), and which queue a stream of the pool lands on depends on every stream the process -- PyTorch,
     this library, RCCL -- has created before.  Falls back to the best candidates with a warning when fewer than ``n`` pass (a busy or
     shared device makes the timings noise); IPOKE_SIDE_STREAM=plain skips the probe."""
-    if os.environ.get("IPOKE_SIDE_STREAM", "") == "plain" or n <= 0:
+    # (several ranks sharing one GPU -- the single-GPU test mode of the data-parallel path -- would time each other's kernels)
+    if os.environ.get("IPOKE_SIDE_STREAM", "") == "plain" or os.environ.get("IPOKE_DIST_SINGLE_GPU") == "1" or n <= 0:
         return [torch.cuda.Stream() for _ in range(n)]
     main = torch.cuda.current_stream()
     cycles = 100_000
