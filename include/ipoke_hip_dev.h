@@ -52,6 +52,10 @@ int ipoke_timing_stop_ex(const int* tags, int ntags, int* counts, double* total_
  * norm, norm_bwd, rowscale_bwd, sn_job (out: at least 11 entries; returns the count) -- the binding's own structs must match. */
 int ipoke_desc_sizes(int32_t* out, int n);
 
+/* Test hook: make the flow's next polled pass report a hand-off time-out (which = 0: the row-split unit scratch, 1: the fused
+ * conv3 + coupling scratch) -- exercises the engine's IPOKE_ERR_STATE + scratch re-initialisation path (ipoke_flow_handoff_timeouts) */
+int ipoke_flow_test_inject_timeout(ipoke_flow* f, int which, void* stream);
+
 /* Test hook: forward unroll of the ConvGRU as one launch (1), as launches per phase (0), or the IPOKE_GRU_FUSED environment default (< 0) */
 int ipoke_gru_set_fused(int mode);
 

@@ -1238,6 +1238,18 @@ static int pass_end(ipoke_flow* f, hipStream_t s) {
   f->pass_stream = s; f->pass_recorded = true; f->pass_unchecked = true;
   return IPOKE_OK;
 }
+/* Test hook (include/ipoke_hip_dev.h): bumps the time-out word of the unit (which = 0) or coupling (which = 1) scratch on `stream`, as a
+ * hand-off that gave up would -- the engine must report it at the entry point after the next polled pass. */
+__global__ void handoff_inject_kernel(unsigned* word) { if (threadIdx.x == 0) atomicAdd(word, 1u); }
+extern "C" int ipoke_flow_test_inject_timeout(ipoke_flow* f, int which, void* stream) {
+  IPK_REQUIRE(f && (which == 0 || which == 1), "bad arguments");
+  int rc = ensure_device(f); if (rc) return rc;
+  unsigned* w = reinterpret_cast<unsigned*>(which == 0 ? f->d_xchg : f->d_cxchg);
+  IPK_REQUIRE(w != nullptr, "this flow has no such scratch (unit_split = 1 / coupling fusion off)");
+  hipLaunchKernelGGL(handoff_inject_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), w);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
 /* Synchronising query: waits for the last pass of this flow and writes the hand-off time-out counts since the scratches were last
  * (re-)initialised: out[0] row-split MaCowUnit launches, out[1] fused conv3 + coupling launches.  Returns IPOKE_OK; non-zero counts
  * mean that a pass finished on garbage (the next entry point fails with IPOKE_ERR_STATE and re-initialises the scratches). */

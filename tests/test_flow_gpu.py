@@ -401,3 +401,40 @@ def test_unit_row_split_engine_matches_one_workgroup_per_sample(golden, split, m
     assert (ls_ - l1).abs().max().item() <= 1e-3
     scale = g1.abs().max().item()
     assert (gs_ - g1).abs().max().item() <= max(4 * noise, 2e-6 * scale), ((gs_ - g1).abs().max().item(), noise, scale)
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_handoff_timeout_is_reported_and_the_scratch_recovers(which):
+    """the row-split unit launches and the fused conv3 + coupling launches bound their spin-waits and count a
+    time-out in word 0 of their exchange scratch -- which nothing read.  Now every eager pass ends with a poll of both words and the
+    next entry point of the flow fails with IPOKE_ERR_STATE once it has seen a non-zero count (the pass that timed out finished on
+    garbage), re-initialises the scratches, and the passes after that are clean again.  The time-out is injected through the test
+    hook ipoke_flow_test_inject_timeout (a real one needs a wedged partner workgroup)."""
+    import time
+    from ipoke_amd import _lib, configs
+    from ipoke_amd.flow import SupervisedMacowTransformer
+    from ipoke_amd.utils.detfill import deterministic_fill_
+    arch = configs.flow_arch(32, hidden=256, num_steps=[2, 1, 1], factor=4)
+    m = SupervisedMacowTransformer(arch, dtype="bf16", device="cuda", init="none", max_batch=4)
+    deterministic_fill_(m, prefix="flow.")
+    m.sync_buffers()
+    eng = m.engine
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 32, 8, 8, generator=g).cuda()
+    cond = torch.randn(4, arch["h_channels"], 8, 8, generator=g).cuda()
+    with torch.no_grad():
+        ref, _ = m(x, cond)
+        torch.cuda.synchronize()
+        assert eng.handoff_timeouts() == (0, 0)
+        _lib.check(eng.lib.ipoke_flow_test_inject_timeout(eng.handle, which, _lib.current_stream()))
+        m(x, cond)                                   # this pass's poll carries the count ...
+        torch.cuda.synchronize()
+        counts = eng.handoff_timeouts()
+        assert counts[which] == 1 and counts[1 - which] == 0
+        with pytest.raises(RuntimeError, match="hand-off time-out"):
+            m(x, cond)                               # ... and the next entry point refuses (and re-initialises the scratches)
+        torch.cuda.synchronize()
+        out, _ = m(x, cond)
+        torch.cuda.synchronize()
+        assert eng.handoff_timeouts() == (0, 0)
+        assert torch.equal(out, ref), "the scratches must be in their initial state again"
