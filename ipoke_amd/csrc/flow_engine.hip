@@ -1614,10 +1614,9 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
   // 11.0 to 15.0 ms per half step and the chain's kernels from 22.2 to 24.5 ms; the saved gradient round trip was served by the
   // memory-side cache anyway.  Off by default.
   const int wgrad_adam_mode = getenv("IPOKE_WGRAD_ADAM") ? atoi(getenv("IPOKE_WGRAD_ADAM")) : 0;
-  const bool wgrad_adam = wgrad_adam_mode != 0 && f->nadam.on && !getenv("IPOKE_PROBE_SKIP_ADAM") && !getenv("IPOKE_ADAM_DEFER") && f->c2_straight &&
+  const bool wgrad_adam = wgrad_adam_mode != 0 && f->nadam.on && !getenv("IPOKE_PROBE_SKIP_ADAM") && f->c2_straight &&
                           c.dtype == IPOKE_BF16 && f->use_side && lanes.size() == 1 && hid % 128 == 0 && (int)f->ajobs.size() == f->n_nice && !f->cfg.condition_nice;
   std::function<int()> flush_nice_fn = []() { return (int)IPOKE_OK; };
-  std::vector<std::pair<int64_t, int64_t>> deferred_adam;      // parameter ranges whose native update waits for the end of the pass (IPOKE_ADAM_DEFER)
   auto native_adam_range = [&](int64_t b0, int64_t b1, int max_blocks) -> int {
     const ipoke_flow::NativeAdam& A = f->nadam;
     float* pm = const_cast<float*>(params);
@@ -1665,15 +1664,9 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       if (r) return r;
     }
     static const bool probe_skip_adam = getenv("IPOKE_PROBE_SKIP_ADAM") != nullptr;      // developer probe: what the optimizer costs the step (parameters stay put)
-    // IPOKE_ADAM_DEFER=k: the update + shadow refresh of the FIRST k pieces (the top levels: the next forward pass reaches them last) is
-    // queued behind the last piece's instead of beside the backward chain -- it then runs in the step-boundary hole, where the only other
-    // work is the next batch's frozen encoders (latency-bound launches that leave HBM idle), and the optimizer queue's backlog inside
-    // the backward pass (busy 24.7 of ~29 ms, profiles/r05_bench_steady.txt) shrinks by that share.
-    static const int adam_defer = getenv("IPOKE_ADAM_DEFER") ? atoi(getenv("IPOKE_ADAM_DEFER")) : 0;
-    if (f->nadam.on && !probe_skip_adam && piece < adam_defer && piece + 1 < (int)pieces.size()) {
-      for (int kind = 0; kind < 3; ++kind)
-        if (p0[kind] >= 0 && p1[kind] > p0[kind]) deferred_adam.push_back({p0[kind], p1[kind]});
-    } else if (f->nadam.on && !probe_skip_adam) {
+    // (Moving the first k pieces' update + refresh behind the last piece's, into the step-boundary hole, was measured in round 6 and
+    // removed: 50.9 / 52.3 / 54.1 ms at k = 4 / 8 / 12 against 49.5 -- profiles/r06_ab_lines.txt.)
+    if (f->nadam.on && !probe_skip_adam) {
       // single-GPU training: the update of the piece's ranges and the refresh of their shadows, natively, on the ready stream
       ipoke_flow::NativeAdam A = f->nadam;
       {   // developer A/B (IPOKE_ADAM_EARLY_BLOCKS=n, IPOKE_ADAM_LATE_PIECES=k): the optimizer of all but the last k pieces on a smaller grid --
@@ -1685,13 +1678,6 @@ static int run_backward(ipoke_flow* f, const float* params, const int32_t* perm,
       for (int kind = 0; kind < 3; ++kind) {
         if (p0[kind] < 0 || p1[kind] <= p0[kind]) continue;
         r = native_adam_range(p0[kind], p1[kind], A.max_blocks); if (r) return r;
-      }
-      if (piece + 1 == (int)pieces.size()) {      // the last piece: what was held back goes out now, top levels last
-        static const int defer_blocks = getenv("IPOKE_ADAM_DEFER_BLOCKS") ? atoi(getenv("IPOKE_ADAM_DEFER_BLOCKS")) : 0;
-        for (auto it = deferred_adam.rbegin(); it != deferred_adam.rend(); ++it) {
-          r = native_adam_range(it->first, it->second, defer_blocks > 0 ? defer_blocks : f->nadam.max_blocks); if (r) return r;
-        }
-        deferred_adam.clear();
       }
     }
     if (ready)
