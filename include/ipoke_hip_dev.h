@@ -49,7 +49,7 @@ int ipoke_timing_stop(const int* tags, int ntags, int* counts, double* mean_us);
 int ipoke_timing_stop_ex(const int* tags, int ntags, int* counts, double* total_us, double* flops, double* bytes);
 
 /* Test hook: sizeof of the descriptor structs of ipoke_hip.h in the order conv, wgrad, affine, coupling_epi, mcf, unit_pair, flow_config,
- * norm, norm_bwd, rowscale_bwd, sn_job (out: at least 11 entries; returns the count) -- the binding's own structs must match. */
+ * norm, norm_bwd, rowscale_bwd, sn_job, wgrad_adam (out: at least 12 entries; returns the count) -- the binding's own structs must match. */
 int ipoke_desc_sizes(int32_t* out, int n);
 
 /* Test hook: make the flow's next polled pass report a hand-off time-out (which = 0: the row-split unit scratch, 1: the fused

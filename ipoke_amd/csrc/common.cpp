@@ -81,7 +81,7 @@ extern "C" int ipoke_desc_sizes(int32_t* out, int n) {
   const int32_t sz[] = {(int32_t)sizeof(ipoke_conv_desc), (int32_t)sizeof(ipoke_wgrad_desc), (int32_t)sizeof(ipoke_affine_desc),
                         (int32_t)sizeof(ipoke_coupling_epi), (int32_t)sizeof(ipoke_mcf_desc), (int32_t)sizeof(ipoke_unit_pair_desc),
                         (int32_t)sizeof(ipoke_flow_config), (int32_t)sizeof(ipoke_norm_desc), (int32_t)sizeof(ipoke_norm_bwd_desc),
-                        (int32_t)sizeof(ipoke_rowscale_bwd_desc), (int32_t)sizeof(ipoke_sn_job)};
+                        (int32_t)sizeof(ipoke_rowscale_bwd_desc), (int32_t)sizeof(ipoke_sn_job), (int32_t)sizeof(ipoke_wgrad_adam)};
   const int cnt = (int)(sizeof(sz) / sizeof(sz[0]));
   for (int i = 0; i < cnt && i < n; ++i) out[i] = sz[i];
   return cnt;

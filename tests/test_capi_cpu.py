@@ -175,7 +175,7 @@ def test_descriptor_structs_of_the_binding_match_the_header():
     out = (ctypes.c_int32 * 16)()
     n = _lib.lib().ipoke_desc_sizes(out, 16)
     mirrors = [_lib.ConvDesc, _lib.WgradDesc, _lib.AffineDesc, _lib.CouplingEpi, _lib.McfDesc, _lib.UnitPairDesc, _lib.FlowConfig,
-               _lib.NormDesc, _lib.NormBwdDesc, _lib.RowScaleBwdDesc, _lib.SnJob]
+               _lib.NormDesc, _lib.NormBwdDesc, _lib.RowScaleBwdDesc, _lib.SnJob, _lib.WgradAdam]
     assert n == len(mirrors)
     for i, m in enumerate(mirrors):
         assert ctypes.sizeof(m) == out[i], (m.__name__, ctypes.sizeof(m), out[i])
