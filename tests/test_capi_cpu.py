@@ -179,3 +179,18 @@ def test_descriptor_structs_of_the_binding_match_the_header():
     assert n == len(mirrors)
     for i, m in enumerate(mirrors):
         assert ctypes.sizeof(m) == out[i], (m.__name__, ctypes.sizeof(m), out[i])
+
+
+def test_package_import_sets_the_hardware_queue_default():
+    """the step keeps four streams busy; ``import ipoke_amd`` sets GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises unless
+    the variable is given (bench.py used to be the only place that did)."""
+    import subprocess
+    import sys
+    code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import ipoke_amd; "
+            "print(os.environ['GPU_MAX_HW_QUEUES'], ipoke_amd.hw_queue_setting())")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "8 ('8', True)", out.stdout
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '4'; import ipoke_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == "4", (out.stdout, out.stderr)
