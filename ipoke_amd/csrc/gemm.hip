@@ -1135,7 +1135,7 @@ static size_t device_max_lds() {
 }
 constexpr size_t kLdsC64 = 9 * 64 * 128 + 2 * 41 * 1024 + 1024, kLdsHalo16 = 2 * 41 * 1024 + 4 * 128 * 128 + 8 * 1024,
                  kLdsHalo = 2 * 24 * 1024 + 12 * 64 * 128 + 8 * 1024, kLdsS8 = 2 * 128 * 128 + 256 + 12 * 64 * 128 + 512 * 16,
-                 kLdsLat8 = 3 * 2 * 128 * 128 + 256;
+                 kLdsLat8 = 3 * 2 * 128 * 128 + 256, kLdsK64 = 128 * 128 + 256 + 6 * 128 * 128;
 
 // The dynamic-LDS attribute of a kernel is set once per process, race-free (the header promises thread safety for launches on
 // distinct streams): one std::once_flag + result per expansion site, i.e. per kernel (template instantiation).
@@ -1730,6 +1730,146 @@ template <int NSPLIT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s8_coupling_kernel(const NtParams p, const CouplingEpi e) {
   if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)(sizeof(NtParams) + sizeof(CouplingEpi))>();
   conv3x3_s8_body<NSPLIT>(p, e, blockIdx.x / NSPLIT, blockIdx.x % NSPLIT);
+}
+
+// =============================================================================================
+// 3x3 convolution (stride 1, pad 1) on the 8x8 latent with a NARROW dense input (<= 64 channels) and a wide output (round 6): conv1 of
+// every coupling net (cin conditioning channels -> 2048 hidden, macow_utils.py:270) and, in the transposed form, the data gradient of
+// conv3 (2 cout -> 2048).  The mirror image of conv3x3_s8: there the input is wide and the filter streams per (chunk, tap); here the
+// WHOLE input of a tile of two samples is one [128 rows x 64 channels] image (16 KB, staged once: channels beyond Kc are zero chunks)
+// and the reduction is nothing but the nine taps, read from that image through shifted row addresses (a lane outside the map reads a
+// zero row) -- as an implicit GEMM every tap re-gathered its 80 input rows behind a fresh L2 -> LDS latency (nine K-blocks, 14 us per
+// launch for 3 GFLOP).  A workgroup owns 128 rows x 128 output channels; the filter of a tap is a [128 x 64] block (16 KB) of the
+// [Nout][9 * Kc] operand, the nine blocks stream through six slots in rounds of three; 8 waves = 2 row halves x 4 column groups of
+// 64 x 32 wave tiles; the epilogue is nt_epilogue (bias, ELU, ELU' mask of the data-gradient form, dtype output).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_k64_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
+  typedef bf16_t T;
+  typedef typename ET<T>::frag frag_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int BM = 128, BN = 128, NTHR = 512, R = 6, MREP = 4, NREP = 2;
+  constexpr int ABUF = BM * 128, WSLOT = BN * 128;
+  constexpr unsigned kInvalid = 0xffffffffu;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* abuf = smem;                              // the input image [128 rows][64 channels]
+  unsigned char* zrow = smem + ABUF;                       // 256 bytes of zeros: the "outside the map" row
+  unsigned char* ring = zrow + 256;                        // R filter blocks (one tap each)
+  if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mh = wave & 1, nq = wave >> 1;
+  const GeomDev& g = p.g;
+  const FDiv ftm(p.tiles_m);
+  const int tm = ftm.mod((int)blockIdx.x), tn = ftm.div((int)blockIdx.x);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int sgn = g.transposed ? -1 : 1;
+  const int kchunks = p.Kc >> 3;                           // 16-byte chunks of real channels per row (1 .. 8)
+  if (tid < 16) reinterpret_cast<f32x4*>(zrow)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const T* Abase = reinterpret_cast<const T*>(p.A);
+  const T* Wbase = reinterpret_cast<const T*>(p.W);
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+  // input image: instruction i of a thread fills rows 8 * (wave + 8 i) .. + 7 (lane / 8), chunk position lane % 8 <- source chunk ^ swz(row)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = (wave + 8 * i) * 64 + lane, row = ch >> 3, pos = ch & 7, m = m0 + row;
+    const int sc = pos ^ ((row >> 1) & 7);
+    const T* src = zero;
+    if (m < g.M && sc < kchunks)
+      src = Abase + (long)(m >> 6) * p.a_sn + (long)((m >> 3) & 7) * p.a_sh + (long)(m & 7) * p.a_sw + p.a_coff + sc * 8;
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(abuf + (wave + 8 * i) * 1024), 16, 0, 0);
+  }
+  // filter block of tap t: rows n0 .. n0 + 127 of W, 64 channels at column t * Kc; instruction j of a thread: rows 8 * (wave + 8 j) + lane / 8
+  unsigned w_src[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * (wave + 8 * j) + (lane >> 3), n = n0 + row, sc = (lane & 7) ^ ((row >> 1) & 7);
+    w_src[j] = (n < p.Nout && sc < kchunks) ? (unsigned)((long)n * p.ldw + sc * 8) : kInvalid;
+  }
+  auto issue_w = [&](int t, int slot) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const T* src = (t < 9 && w_src[j] != kInvalid) ? Wbase + w_src[j] + (long)t * p.Kc : zero;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(ring + slot * WSLOT + (wave + 8 * j) * 1024), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < R; ++t) issue_w(t, t);               // rounds 0 and 1 (taps 0 .. 5)
+
+  // fragment bookkeeping: row r of this wave's sample (mh) is position (y, x) = (r >> 3, r & 7)
+  unsigned vmask[MREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    const int r = i * 16 + (lane & 15);
+    const int y = (r >> 3) & 7, x = r & 7;
+    unsigned vm = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + sgn * (t / 3 - 1), xx = x + sgn * (t % 3 - 1);
+      if ((unsigned)yy < 8u && (unsigned)xx < 8u) vm |= 1u << t;
+    }
+    vmask[i] = vm;
+  }
+  const int qlo = lane >> 4;
+  int b_rd[NREP];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int n = nq * 32 + j * 16 + (lane & 15);
+    b_rd[j] = n * 128 + ((qlo ^ ((n >> 1) & 7)) * 16);
+  }
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool two_steps = p.Kc > 32;                        // channels 32 .. 63 exist
+
+  auto tap_mma = [&](int t, int slot) {
+    const unsigned char* ab = abuf + mh * 64 * 128;
+    const unsigned char* wb = ring + slot * WSLOT;
+    const int th = t / 3, tw = t - 3 * th;
+    const int shift = sgn * ((th - 1) * 8 + (tw - 1));
+    const unsigned char* arow[MREP]; int aswz[MREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+      const bool ok = (vmask[i] >> t) & 1u;
+      const int sr = i * 16 + (lane & 15) + shift;
+      arow[i] = ok ? ab + sr * 128 : zrow;
+      aswz[i] = ok ? (sr >> 1) & 7 : 0;
+    }
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+      if (hs == 1 && !two_steps) break;
+      frag_t fa[MREP], fb[NREP];
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) fa[i] = *reinterpret_cast<const frag_t*>(arow[i] + (((hs * 4 + qlo) ^ aswz[i]) * 16));
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) fb[j] = *reinterpret_cast<const frag_t*>(wb + (b_rd[j] ^ (hs * 64)));
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) GEMM_MMA(fa[i], fb[j], acc[i][j]);
+    }
+  };
+
+  // round 0 (taps 0-2, slots 0-2) | refill slots 0-2 with taps 6-8 | round 1 (taps 3-5, slots 3-5) | round 2 (taps 6-8, slots 0-2)
+  wait_vmcnt<6>();                    // the input image and this wave's share of taps 0-2 (2 + 6 of 14 instructions may still fly: taps 3-5)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t = 0; t < 3; ++t) tap_mma(t, t);
+  __builtin_amdgcn_s_barrier();       // everybody is done with slots 0-2
+#pragma unroll
+  for (int t = 6; t < 9; ++t) issue_w(t, t - 6);
+  wait_vmcnt<6>();                    // taps 3-5 have landed (the 6 instructions just issued may fly)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t = 3; t < 6; ++t) tap_mma(t, t);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t = 6; t < 9; ++t) tap_mma(t, t - 6);
+  nt_epilogue<T, 2, 4, MREP, NREP, NTHR>(p, acc, smem, m0, n0, mh, nq, 0);
 }
 
 // =============================================================================================
@@ -2583,6 +2723,28 @@ static int launch_nt(NtParams& p, hipStream_t s) {
   return IPOKE_OK;
 }
 
+static bool k64_applicable(const NtParams& p) {
+  static const int on = getenv("IPOKE_K64") ? atoi(getenv("IPOKE_K64")) : 1;      // developer A/B: 0 keeps the implicit GEMM
+  const GeomDev& g = p.g;
+  return on && kLdsK64 <= device_max_lds() && !p.c_scatter && !p.a_f32 && !p.row_scale && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Hi == 8 &&
+         g.Wi == 8 && g.lDo == 0 && g.lHo == 3 && g.lWo == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 1 && g.pw == 1 &&
+         p.Kc <= 64 && (p.Kc & 7) == 0 && p.Kc_real == p.Kc && p.Nout >= 256 && p.splitk == 1 && !p.c_acc && (p.a_coff & 7) == 0 &&
+         p.ldw >= p.Ktot && ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && (long)(g.M >> 6) * p.a_sn + 7 * p.a_sh + 7 * p.a_sw + p.Kc < (1L << 31) &&
+         (long)p.Nout * p.ldw < (1L << 31) && 128 * (128 * 4 + 16) <= (int)kLdsK64 &&
+         // one workgroup per CU (115 KB of LDS): a second round loses to the implicit GEMM (B = 40: 14.9 against 13.4 us; B = 20 / 32: 8.2 / 8.5
+         // against 9.9 / 11.0 isolated, scripts/r6/probe_k64.py)
+         (long)ceil_div(g.M, 128) * ceil_div(p.Nout, 128) <= 256;
+}
+static int launch_conv3x3_k64(NtParams& p, hipStream_t s) {
+  p.tiles_m = ceil_div(p.g.M, 128); p.tiles_n = ceil_div(p.Nout, 128); p.xa = p.xb = 0;
+  p.kb_per_split = 9;
+  auto kern = conv3x3_k64_kernel;
+  IPK_SET_LDS_ONCE(kern, kLdsK64);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kLdsK64, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
 static int s8_samples_per_tile() {
   static const int ts = getenv("IPOKE_S8") ? (atoi(getenv("IPOKE_S8")) ? 2 : 0) : 2;      // developer A/B: IPOKE_S8=0 turns the kernel off
   return ts;
@@ -2722,6 +2884,7 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
   g_last_kernel = IPOKE_KERNEL_IGEMM;
   if constexpr (sizeof(T) == 2) {
     if (s8_applicable(p)) { g_last_kernel = IPOKE_KERNEL_S8; return launch_conv3x3_s8(p, s); }
+    if (k64_applicable(p)) { g_last_kernel = IPOKE_KERNEL_S8; return launch_conv3x3_k64(p, s); }      // (same family tag: stationary input on the 8x8 latent)
     if (c64_applicable(p)) { g_last_kernel = IPOKE_KERNEL_C64; return launch_conv3x3_c64(p, s); }
     if (halo16_applicable(p)) { g_last_kernel = IPOKE_KERNEL_HALO16; return launch_conv3x3_halo16(p, s); }
     if (halo_applicable(p)) { g_last_kernel = IPOKE_KERNEL_HALO; return launch_conv3x3_halo(p, s); }

@@ -188,6 +188,62 @@ def test_conv3x3_skinny_stationary_input(B, Cout):
     assert add[:, 0::2].abs().max() == 0 and (2 * d.Nout >= 64 or add[:, 2 * d.Nout + 1::2].abs().max() == 0)
 
 
+@pytest.mark.parametrize("B,Cin,Cout", [(20, 32, 2048), (3, 8, 256), (5, 24, 384), (4, 64, 512), (7, 40, 2048), (1, 16, 256)])
+def test_conv3x3_narrow_input_stationary(B, Cin, Cout):
+    """conv3x3_k64 (round 6): 3x3 on the 8x8 latent with a narrow dense input (<= 64 channels) and a wide output -- conv1 of
+    NICEConvBlock (macow_utils.py:270: conditioning channels -> hidden, ELU) and, transposed with the ELU' mask of the saved activation,
+    the data gradient of its conv3 (:281).  One staged input image, nine taps as shifted reads; dtype outputs as the engine uses them;
+    odd batches (a half-empty last tile), channel counts that are no multiple of 32, outputs that do not fill the last column tile."""
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(11 * B + Cin + Cout)
+    M = B * 64
+    kc = -(-Cin // 8) * 8
+    x = torch.randn(B, Cin, 1, 8, 8, generator=gen)
+    w = torch.randn(Cout, Cin, 1, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=gen) * 0.1
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    # ---- forward: h = ELU(conv(x, W) + b), bf16 output
+    ref = F.elu(F.conv3d(xb, wb, bias, padding=(0, 1, 1)))[:, :, 0].permute(0, 2, 3, 1).reshape(M, Cout)
+    xa = torch.zeros(M, kc, dtype=torch.bfloat16, device=DEV)
+    xa[:, :Cin] = x[:, :, 0].permute(0, 2, 3, 1).reshape(M, Cin).to(DEV).bfloat16()
+    d = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    d.A = xa.data_ptr(); d.a_sn = 64 * kc; d.a_sd = 0; d.a_sh = 8 * kc; d.a_sw = kc; d.a_sc = 1; d.Kc_real = kc; d.Kc = kc
+    ws = shadow_nt(w.to(DEV), kc, dtype="bf16")
+    bd = bias.to(DEV)
+    out = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    d.W = ws.data_ptr(); d.ldw = ws.shape[1]; d.Nout = Cout; d.bias = bd.data_ptr(); d.act = _lib.ACT_ELU
+    d.C = out.data_ptr(); d.c_f32 = 0; d.ldc = Cout
+    ops.conv_forward(d, "bf16")
+    torch.cuda.synchronize()
+    assert L.ipoke_last_conv_kernel() == 2, "expected the stationary-input family (IPOKE_KERNEL_S8)"
+    err = (out.float().cpu() - ref).abs().max().item()
+    print(f"narrow-input 3x3 B={B} {Cin}->{Cout}: forward max err {err:.3e} (ref max {ref.abs().max():.2f})")
+    assert torch.isfinite(out.float()).all() and err <= 2e-2 * max(1.0, ref.abs().max().item())
+    # ---- transposed + ELU' mask: dX = conv_transpose(dY, Wt) * ELU'(saved h), the data gradient of a 3x3 convolution Cout <- Cin ... here
+    # the roles: gradient rows [M][kc] (narrow), result [M][Cout] (wide)
+    dy = torch.randn(B, Cin, 1, 8, 8, generator=gen)
+    wt = torch.randn(Cin, Cout, 1, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    hsaved = (torch.randn(M, Cout, generator=gen)).bfloat16()                      # saved ELU outputs (mask where <= 0: y + 1)
+    dref = F.conv_transpose3d(dy.bfloat16().float(), wt.bfloat16().float(), None, padding=(0, 1, 1))[:, :, 0].permute(0, 2, 3, 1).reshape(M, Cout)
+    hf = hsaved.float()
+    dref = dref * torch.where(hf > 0, torch.ones_like(hf), hf + 1.0)
+    ga = torch.zeros(M, kc, dtype=torch.bfloat16, device=DEV)
+    ga[:, :Cin] = dy[:, :, 0].permute(0, 2, 3, 1).reshape(M, Cin).to(DEV).bfloat16()
+    d2 = ops.conv_desc(B, (1, 8, 8), (1, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1), True)
+    d2.A = ga.data_ptr(); d2.a_sn = 64 * kc; d2.a_sd = 0; d2.a_sh = 8 * kc; d2.a_sw = kc; d2.a_sc = 1; d2.Kc_real = kc; d2.Kc = kc
+    wts = shadow_nt(wt.transpose(0, 1).contiguous().to(DEV), kc, dtype="bf16")
+    hd = hsaved.to(DEV)
+    out2 = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    d2.W = wts.data_ptr(); d2.ldw = wts.shape[1]; d2.Nout = Cout; d2.dact = hd.data_ptr(); d2.ld_dact = Cout; d2.dact_act = _lib.ACT_ELU
+    d2.C = out2.data_ptr(); d2.c_f32 = 0; d2.ldc = Cout
+    ops.conv_forward(d2, "bf16")
+    torch.cuda.synchronize()
+    assert L.ipoke_last_conv_kernel() == 2
+    err2 = (out2.float().cpu() - dref).abs().max().item()
+    print(f"narrow-input 3x3 B={B} {Cin}->{Cout}: masked data gradient max err {err2:.3e} (ref max {dref.abs().max():.2f})")
+    assert torch.isfinite(out2.float()).all() and err2 <= 2e-2 * max(1.0, dref.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype,B,Nout", [("bf16", 20, 32), ("bf16", 5, 30), ("bf16", 20, 64), ("bf16", 40, 16), ("f32", 4, 32), ("f32", 3, 60)])
 def test_split_k_accumulation_through_the_scratch_is_deterministic(dtype, B, Nout):
     """ipoke_conv_desc.acc_scratch: the K slices of an accumulating launch (the conv1 data gradient of NICEConvBlock,
