@@ -11,3 +11,5 @@ python $R/scripts/trace_overlap.py $T > $O/${TAG}_overlap.txt 2>&1
 python $R/scripts/trace_steady.py $T flow_nll 6 > $O/${TAG}_steady.txt 2>&1
 python $R/scripts/trace_by_grid.py $T tn_glds > $O/${TAG}_tn_by_grid.txt 2>&1
 python $R/scripts/trace_by_grid.py $T lat8 >> $O/${TAG}_tn_by_grid.txt 2>&1
+python $R/scripts/trace_prev.py $T conv3x3_k64 > $O/${TAG}_k64_prev.txt 2>&1
+python $R/scripts/trace_prev.py $T "igemm_nt_glds_kernel<bool _Accum, int, E, 4, 5, 2, 3, 1, true, 2>" > $O/${TAG}_conv2_prev.txt 2>&1
