@@ -161,6 +161,11 @@ typedef struct {
 } ipoke_wgrad_desc;
 
 int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stream);
+/* Reduction splits (slabs: splitm with split_stride) the kernel that ipoke_conv_wgrad dispatches THIS problem to prefers when the caller aims
+ * at target_workgroups workgroups; 0: no preference (keep the caller's rule).  > 0 for stride-1 3x3 / 3x3x3 "same" convolutions on maps
+ * whose height and width are multiples of 16 (BasicBlock of the 3-D encoder, motion_encoder.py:45-74; the SPADE decoder's 3x3 layers,
+ * autoencoders/util.py:106-192): they run in a halo-staged kernel that tiles dW by 64 x 64 x 9 taps per depth tap. */
+int ipoke_conv_wgrad_splitm(const ipoke_wgrad_desc* d, int dtype, int target_workgroups);
 /* nbatch same-shape problems in one launch; entries_dev[i] = {int64 a_off bytes, int64 y_off bytes, int64 w_off floats,
  * int32 kh, kw, ph, pw, int64 sh_off elements (used with ipoke_wgrad_desc.adam only)} relative to a_base / y_base / w_base (the
  * descriptor's A, dY, dW and kh/kw/ph/pw are ignored) */

@@ -280,6 +280,7 @@ SIGNATURES = {
     "ipoke_flow_handoff_timeouts": (c_int, [_P, POINTER(c_uint32)]),
     "ipoke_flow_side_stream": (c_void_p, [_P]),
     "ipoke_flow_test_inject_timeout": (c_int, [_P, c_int, _P]),
+    "ipoke_conv_wgrad_splitm": (c_int, [_P, c_int, c_int]),
     "ipoke_conv_acc_scratch_bytes": (c_int64, [c_int, c_int, c_int]),
     "ipoke_conv_acc_scratch_init": (c_int, [_P, _P]),
     "ipoke_flow_param_count": (c_int64, [_P]),

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (b_row[i] >= 0 && b_k[i] < p.ldw)
+      if (b_row[i] >= 0 && b_k[i] < p.Ktot)       // (K columns past the reduction multiply zero A chunks -- but 0 x NaN is NaN: W may be a column slice of a wider operand)
         v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.W) + (long)b_row[i] * p.ldw + b_k[i]);
       rb[i] = v;
       b_k[i] += BK;
@@ -704,7 +704,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void igemm_nt_glds_kernel(const 
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const T* src = (b_off[i] != kInvalid && (SIMPLE || b_k[i] < p.ldw)) ? Wbase + b_off[i] : zero;
+      // K columns past Ktot meet zero A chunks, but they must not be FETCHED: W may be a column slice of a wider operand (the parity-class
+      // data gradients of first_stage_train._dgrad_phases), whose last row ends at the end of the allocation, and 0 x NaN = NaN
+      const T* src = (b_off[i] != kInvalid && (SIMPLE || b_k[i] < p.Ktot)) ? Wbase + b_off[i] : zero;
       unsigned char* dst = (wave * 64 + NTHR * i) < BN * 8 ? sa + BM * 128 + (wave * 64 + NTHR * i) * 16 : dummy + wave * 1024;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
       if (!SIMPLE) b_k[i] += BK;
@@ -3725,6 +3727,249 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// =============================================================================================
+// Weight gradient of a 3x3 (kd = 1) or 3x3x3 (kd = 3) / stride 1 / "same" convolution on LARGE maps with the input stationary (round 6;
+// the first stage's training step: BasicBlock conv1 / conv2 of the 3-D encoder, motion_encoder.py:45-74, and the 3x3 convolutions of the
+// SPADE decoder, autoencoders/util.py:106-192).  The idea of wgrad3x3_lat8 one size up: a workgroup owns a [64 out] x [64 in] x [9 taps]
+// block of dW for ONE depth tap and reduces over 16 x 16-pixel patches; a stage is the patch's dY image [256 px x 64 n] (32 KB) and its
+// input image WITH HALO [18 x 18 px x 64 c] (41 KB, zero border materialised by the DMA), double-buffered; the nine in-plane taps are
+// shifted row addresses of the transposing LDS reads (no validity masks: the halo is there).  As an implicit GEMM (igemm_tn_glds) every
+// 64-row stage re-gathers the input rows per K-column of the tap it belongs to: 65 FLOP per byte of L2 -> LDS traffic; here 259.
+// blockIdx.x = (n-chunk, c-chunk, depth tap), blockIdx.y = reduction split: patches z, z + splitm, ... ; a split stores its block into
+// slab z (split_stride) like the implicit-GEMM kernels (the caller sums the slabs: deterministic), or straight into dW when splitm = 1.
+struct HaloWgParams {
+  const bf16_t* A; const bf16_t* dY; float* dW;
+  int NB, D, H, W, kd;
+  long a_sn, a_sd, a_sh, a_sw; int a_coff, Kc, Kc_store;
+  int ldy, y_coff, Nout;
+  long w_sn, w_sc, w_st, split_stride;
+  int splitm, tiles_n, tiles_c, ppx, ppy;       // patches per row / column of a depth slice
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3x3_halo_kernel(const HaloWgParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(HaloWgParams)>();
+  typedef bf16_t T;
+  typedef ET<T>::frag frag_t;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int YIMG = 256 * 128;               // dY image: 256 pixels x 64 n
+  constexpr int XROWS = 18 * 18, XIMG = 328 * 128;      // input image with halo: 324 rows (+ 4 rows of padding to whole DMA instructions)
+  constexpr int STAGE = YIMG + XIMG;            // 74 752 bytes
+  constexpr int LY = 4, LX = 6, L = LY + LX;    // DMA instructions per thread and stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+  unsigned char* dummy = smem + 2 * STAGE;      // 8 KB landing zone of the padding DMA instructions (one KB per wave)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = wave >> 2, wc = wave & 3;
+  int tile = blockIdx.x;
+  const int tn = tile % p.tiles_n; tile /= p.tiles_n;
+  const int tc = tile % p.tiles_c, kdi = tile / p.tiles_c;
+  const int n0 = tn * 64, c0 = tc * 64, dshift = kdi - (p.kd >> 1);
+  const int z = blockIdx.y;
+  const int per_slice = p.ppx * p.ppy;
+  const long npatch = (long)p.NB * p.D * per_slice;
+
+  // ---- DMA bookkeeping.  dY: instruction i fills pixels 8 (wave + 8 i) .. + 7 (lane / 8), chunk position lane % 8.
+  //      X: instruction i fills halo rows 8 (wave + 8 i) .. + 7; rows >= 324 land in the dummy zone.
+  int y_q[LY]; unsigned y_col[LY]; bool y_ok[LY];
+#pragma unroll
+  for (int i = 0; i < LY; ++i) {
+    const int q = 8 * (wave + 8 * i) + (lane >> 3), sch = (lane & 7) ^ lat8_swz(q);
+    const int ncol = n0 + sch * 8;
+    y_q[i] = q; y_col[i] = (unsigned)(p.y_coff + ncol);
+    y_ok[i] = ncol < ((p.Nout + 7) & ~7) && ncol + 8 <= p.ldy - p.y_coff;
+  }
+  int x_hy[LX], x_hx[LX]; unsigned x_col[LX]; bool x_ok[LX];
+#pragma unroll
+  for (int i = 0; i < LX; ++i) {
+    const int hr = 8 * (wave + 8 * i) + (lane >> 3), sch = (lane & 7) ^ lat8_swz(hr);
+    const int ccol = c0 + sch * 8;
+    x_hy[i] = hr / 18; x_hx[i] = hr - 18 * x_hy[i];
+    x_col[i] = (unsigned)(p.a_coff + ccol);
+    x_ok[i] = hr < XROWS && ccol < p.Kc;
+  }
+  // patch pt -> (image, output depth, patch row, patch column); returns false when the depth tap leaves the volume
+  auto decode = [&](long pt, int& img, int& d_out, int& py0, int& px0) {
+    const int within = (int)(pt % per_slice);
+    const long sl = pt / per_slice;
+    d_out = (int)(sl % p.D); img = (int)(sl / p.D);
+    py0 = (within / p.ppx) * 16; px0 = (within % p.ppx) * 16;
+    const int d_in = d_out + dshift;
+    return d_in >= 0 && d_in < p.D;
+  };
+  auto issue = [&](int buf, long pt) {
+    int img, d_out, py0, px0;
+    decode(pt, img, d_out, py0, px0);
+    unsigned char* sy = smem + buf * STAGE;
+    unsigned char* sx = sy + YIMG;
+    const long m_base = (((long)img * p.D + d_out) * p.H + py0) * p.W + px0;       // dY row of the patch's first pixel
+#pragma unroll
+    for (int i = 0; i < LY; ++i) {
+      const int qy = y_q[i] >> 4, qx = y_q[i] & 15;
+      const T* src = y_ok[i] ? p.dY + (m_base + (long)qy * p.W + qx) * p.ldy + y_col[i] : zero;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sy + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+    const long a_base = (long)img * p.a_sn + (long)(d_out + dshift) * p.a_sd;
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      const int yy = py0 + x_hy[i] - 1, xx = px0 + x_hx[i] - 1;
+      const bool in = x_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const T* src = in ? p.A + a_base + (long)yy * p.a_sh + (long)xx * p.a_sw + x_col[i] : zero;
+      unsigned char* dst = 8 * (wave + 8 * i) < 328 ? sx + (wave + 8 * i) * 1024 : dummy + wave * 1024;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+  };
+  // next patch of this split at or after pt whose depth tap stays inside the volume (npatch: none)
+  auto next_valid = [&](long pt) {
+    for (; pt < npatch; pt += p.splitm) {
+      int a, b, c, d;
+      if (decode(pt, a, b, c, d)) return pt;
+    }
+    return npatch;
+  };
+
+  // ---- fragment reads: lane (i16 = lane & 15, grp = lane >> 4) supplies pixel 32 ks + 8 grp + (i16 >> 2) (+ 4) of the patch
+  const int i16 = lane & 15, grp = lane >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto img_off = [&](int row, int col) { return row * 128 + (((col >> 3) ^ lat8_swz(row)) * 16) + ((col >> 2) & 1) * 8; };
+  const int q_lo = 8 * grp + (i16 >> 2);                    // pixel inside a 32-pixel reduction step (two patch rows)
+  unsigned y_rd[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) y_rd[i][h] = lds0 + (unsigned)img_off(q_lo + 4 * h, 16 * i + 4 * (i16 & 3));
+  const int xcol = 16 * wc + 4 * (i16 & 3);
+  const int pyl = grp >> 1, pxl = 8 * (grp & 1) + (i16 >> 2);       // this lane's pixel of step 0: patch row pyl, column pxl (+ 4 h)
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_frag = [&](frag_t& f, unsigned a_lo, unsigned a_hi) {
+    const tn_tr4_t lo = tn_ds_tr<0>(a_lo), hi = tn_ds_tr<0>(a_hi);
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) { f[e2] = lo[e2]; f[4 + e2] = hi[e2]; }
+  };
+  auto x_addr = [&](unsigned xb, int ks, int h, int dy, int dx) -> unsigned {
+    const int row = (2 * ks + pyl + 1 + dy) * 18 + pxl + 4 * h + 1 + dx;
+    return xb + (unsigned)img_off(row, xcol);
+  };
+
+  long cur = next_valid(z);
+  int buf = 0;
+  if (cur < npatch) issue(0, cur);
+  while (cur < npatch) {
+    const long nxt = next_valid(cur + p.splitm);
+    if (nxt < npatch) { issue(buf ^ 1, nxt); wait_vmcnt<L>(); } else { wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();                 // this stage has landed for everybody
+    const unsigned yb = (unsigned)(buf * STAGE), xb = lds0 + (unsigned)(buf * STAGE + YIMG);
+#pragma unroll 1
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ks = 2 * kk + kg;                 // the two reduction halves take alternate 32-pixel steps
+      const unsigned so = yb + (unsigned)(ks * 32 * 128);
+      frag_t fy[4], fx[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_frag(fy[i], y_rd[i][0] + so, y_rd[i][1] + so);
+      load_frag(fx[0], x_addr(xb, ks, 0, -1, -1), x_addr(xb, ks, 1, -1, -1));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fy[0]), "+v"(fy[1]), "+v"(fy[2]), "+v"(fy[3]), "+v"(fx[0])::"memory");
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t < 8) {
+          const int dy = (t + 1) / 3 - 1, dx = (t + 1) % 3 - 1;
+          load_frag(fx[(t + 1) & 1], x_addr(xb, ks, 0, dy, dx), x_addr(xb, ks, 1, dy, dx));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma64(fy[i], fx[t & 1], acc[t][i]);
+        if (t < 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fx[(t + 1) & 1])::"memory");
+      }
+    }
+    __builtin_amdgcn_s_barrier();                 // everybody is done with this buffer: the next iteration may refill it
+    cur = nxt; buf ^= 1;
+  }
+  __syncthreads();
+
+  // ---- epilogue (as wgrad3x3_lat8): the two reduction halves meet in LDS in a fixed order, the block leaves by output rows
+  float* img = reinterpret_cast<float*>(smem);
+  constexpr int PITCH = 577;
+  const int c_loc = 16 * wc + 4 * grp;
+  float* dst = p.dW + (p.split_stride > 0 ? (long)z * p.split_stride : 0L);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (kg == 1) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        float* row = img + (16 * ii + i16) * PITCH;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) row[(c_loc + r) * 9 + t] = acc[t][2 * half + ii][r];
+      }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        float* row = img + (16 * ii + i16) * PITCH;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) row[(c_loc + r) * 9 + t] += acc[t][2 * half + ii][r];
+      }
+    }
+    __syncthreads();
+    const int cmax = max(0, min(64, p.Kc_store - c0));
+    for (int idx = tid; idx < 32 * 576; idx += 512) {
+      const int rl = idx / 576, cc = idx - rl * 576, c = cc / 9, t = cc - 9 * c;
+      const int n = n0 + 32 * half + rl;
+      if (n < p.Nout && c < cmax) dst[(long)n * p.w_sn + (long)(c0 + c) * p.w_sc + (long)(kdi * 9 + t) * p.w_st] = img[rl * PITCH + cc];
+    }
+    __syncthreads();
+  }
+}
+
+static constexpr size_t kLdsHaloWg = 2 * (256 * 128 + 328 * 128) + 8 * 1024;
+static bool halo_wgrad_applicable(const TnParams& p) {
+  static const int on = getenv("IPOKE_WGRAD_HALO") ? atoi(getenv("IPOKE_WGRAD_HALO")) : 1;      // developer A/B: 0 keeps the implicit GEMM
+  const GeomDev& g = p.g;
+  const int kd = g.taps / 9;
+  return on && !p.batch && !p.a_f32 && p.a_sc == 1 && (g.taps == 9 || g.taps == 27) && g.khw == 9 && g.kw == 3 && !g.transposed &&
+         g.sd == 1 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.pd == kd / 2 && g.Di == g.Do && g.Hi == g.Ho && g.Wi == g.Wo &&
+         g.Ho % 16 == 0 && g.Wo % 16 == 0 && (g.taps == 27 || g.Di == 1) &&
+         (p.a_coff & 7) == 0 && (p.Kc & 7) == 0 && p.Kc == p.Kc_real && ((p.a_sn | p.a_sd | p.a_sh | p.a_sw) & 7) == 0 &&
+         (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && !p.accumulate && (p.splitm == 1 || p.split_stride > 0) && p.max_wgs <= 0 &&
+         p.ad_p == nullptr && kLdsHaloWg <= device_max_lds() &&
+         ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.dY)) & 15) == 0 &&
+         // worth it where the patches are many and the tile is not mostly padding
+         (long)g.M >= 16384 && p.Kc >= 32 && p.Nout >= 32;
+}
+static int launch_halo_wgrad(const TnParams& t, hipStream_t s) {
+  const GeomDev& g = t.g;
+  HaloWgParams p;
+  p.A = reinterpret_cast<const bf16_t*>(t.A); p.dY = reinterpret_cast<const bf16_t*>(t.dY); p.dW = t.dW;
+  p.NB = g.M / g.S; p.D = g.Do; p.H = g.Ho; p.W = g.Wo; p.kd = g.taps / 9;
+  p.a_sn = t.a_sn; p.a_sd = t.a_sd; p.a_sh = t.a_sh; p.a_sw = t.a_sw; p.a_coff = t.a_coff; p.Kc = t.Kc; p.Kc_store = t.Kc_store;
+  p.ldy = t.ldy; p.y_coff = t.y_coff; p.Nout = t.Nout;
+  p.w_sn = t.w_sn; p.w_sc = t.w_sc; p.w_st = t.w_st; p.split_stride = t.splitm > 1 ? t.split_stride : 0;
+  p.splitm = t.splitm; p.tiles_n = ceil_div(t.Nout, 64); p.tiles_c = ceil_div(t.Kc, 64); p.ppx = g.Wo / 16; p.ppy = g.Ho / 16;
+  auto kern = wgrad3x3_halo_kernel;
+  IPK_SET_LDS_ONCE(kern, kLdsHaloWg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_n * p.tiles_c * p.kd), (unsigned)p.splitm), dim3(512), kLdsHaloWg, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+// Reduction splits the weight-gradient kernel the dispatcher will take for this problem wants for `target_wgs` workgroups (callers
+// size their slabs with it); 0: no preference (the caller's own rule).
+static int halo_wgrad_splits(const TnParams& p, int target_wgs) {
+  const GeomDev& g = p.g;
+  const long tiles = (long)ceil_div(p.Nout, 64) * ceil_div(p.Kc, 64) * (g.taps / 9);
+  const long patches = (long)(g.M / g.S) * g.Do * (g.Ho / 16) * (g.Wo / 16);
+  long sp = target_wgs / tiles; if (sp < 1) sp = 1;
+  if (sp > patches / 4) sp = patches / 4 > 0 ? patches / 4 : 1;
+  return (int)sp;
+}
+
 static bool lat8_applicable(const TnParams& p, int nbatch) {
   static const int on = getenv("IPOKE_WGRAD_LAT8") ? atoi(getenv("IPOKE_WGRAD_LAT8")) : 1;      // developer A/B: 0 keeps the implicit-GEMM kernels
   const GeomDev& g = p.g;
@@ -3773,6 +4018,8 @@ static int launch_tn(TnParams& p, hipStream_t s, int nbatch = 1) {
   if constexpr (sizeof(T) == 2) {
     // batched 3x3 problems on the 8x8 latent (conv1 / conv3 of the coupling nets): the stationary-input kernel
     if (lat8_applicable(p, nbatch)) return launch_lat8(p, s, nbatch);
+    // 3x3 / 3x3x3 stride-1 problems on large maps (first-stage training): the halo-staged kernel
+    if (nbatch == 1 && halo_wgrad_applicable(p)) return launch_halo_wgrad(p, s);
   }
   const size_t lds = 4 * 128 * kPitch + 256 * sizeof(int);
   // LDS-DMA + transposed-read kernel: bf16, dense operands with 16-byte aligned rows
@@ -4044,6 +4291,19 @@ extern "C" int ipoke_conv_wgrad(const ipoke_wgrad_desc* d, int dtype, void* stre
   return dtype == IPOKE_BF16 ? launch_tn<bf16_t>(p, s) : launch_tn<float>(p, s);
 }
 
+/* Reduction splits (slabs) the kernel that ipoke_conv_wgrad will dispatch this problem to prefers when the caller aims at `target_workgroups`
+ * workgroups: > 0 for the halo-staged 3x3 / 3x3x3 kernel (its tiles are 64 x 64 x 9 taps per depth tap), 0 = no preference (the caller's own
+ * rule for the 128 x 128 tiles of the implicit GEMM).  d->splitm / split_stride / dW are ignored. */
+extern "C" int ipoke_conv_wgrad_splitm(const ipoke_wgrad_desc* d, int dtype, int target_workgroups) {
+  if (!d || dtype != IPOKE_BF16 || target_workgroups < 1) return 0;
+  ipoke_wgrad_desc t = *d;
+  t.splitm = 2; t.split_stride = 1; t.adam = nullptr;
+  if (!t.dW) t.dW = reinterpret_cast<float*>(16);
+  TnParams p;
+  if (fill_tn(p, &t, dtype, false) != IPOKE_OK) return 0;
+  if (!halo_wgrad_applicable(p)) return 0;
+  return halo_wgrad_splits(p, target_workgroups);
+}
 extern "C" int ipoke_wgrad_batch_entry_size(void) { return (int)sizeof(TnBatchEntry); }
 
 /* Batched weight gradients: `nbatch` problems of identical shape (all but the 2-D kernel extent / padding, which come

@@ -153,6 +153,7 @@ def _build_weight_operand(w, dtype, transposed_conv, inv_scale=None):
 
 _WGRAD_SWAP = os.environ.get("IPOKE_WGRAD_SWAP", "1") != "0"       # developer A/B: narrow-output convolutions' weight gradient with swapped roles
 _STEM_TRAIN_UNFOLDED = os.environ.get("IPOKE_STEM_TRAIN_UNFOLDED", "0") == "1"      # developer A/B: conv1 of the 3-D encoder read in place when training
+_WGRAD_HALO_WGS = int(os.environ.get("IPOKE_WGRAD_HALO_WGS", "256"))  # workgroups the halo-staged weight gradient aims for (one per CU: 158 KB of LDS)
 _WGRAD_WGS = int(os.environ.get("IPOKE_WGRAD_WGS", "512"))       # workgroups a split-M weight gradient aims for (c4: 256 / 512 / 1024 / 2048 -> 156.5 / 151.0 / 156.5 / 160.6 ms: more slabs = more fp32 partial traffic)
 
 
@@ -446,6 +447,10 @@ class _ConvFn(torch.autograd.Function):
               tiles = -(-wd.Nout // 128) * -(-(taps * wd.Kc) // 128)
               rows = N * wd.Do * wd.Ho * wd.Wo
               splitm = max(1, min(rows // (8 * 16 * K.e16(dt)), _WGRAD_WGS // tiles))
+              # the halo-staged 3x3 / 3x3x3 kernel (stride 1, large maps) tiles dW by 64 x 64 x 9 taps: it names its own split count
+              pref = lib.ipoke_conv_wgrad_splitm(byref(wd), ops._dt(dt), _WGRAD_HALO_WGS)
+              if pref > 0:
+                  splitm = pref
               d_w_out = d_w_sw if swapped else d_w
               if splitm > 1:
                   slabs = torch.empty(splitm, d_w_out.numel(), dtype=torch.float32, device=dy.device)

@@ -188,6 +188,46 @@ def test_conv3x3_skinny_stationary_input(B, Cout):
     assert add[:, 0::2].abs().max() == 0 and (2 * d.Nout >= 64 or add[:, 2 * d.Nout + 1::2].abs().max() == 0)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_conv_weight_operand_as_a_column_slice_is_not_over_read(dtype):
+    """Round 6 bug: the implicit-GEMM kernels masked the K columns of the weight operand by its row pitch (ldw) instead of the reduction
+    length (Ktot).  With W given as a COLUMN SLICE of a wider operand -- the parity-class data gradients of a strided Conv3d,
+    first_stage_train._dgrad_phases (motion_encoder.py:80-91): taps [first, first + ntap) of one permuted [cin][27 * kc] operand -- the
+    last K-block ran past the slice, for the last row past the end of the allocation; those columns meet zero A chunks, but 0 x NaN = NaN
+    whenever the memory behind held NaNs (test_strided_conv3d_data_gradient_by_parity_phases failed once in eight runs).  Here the operand
+    is the head of a NaN-filled slab, so any over-read poisons the last output channel deterministically."""
+    gen = torch.Generator().manual_seed(3)
+    N, Cin, Cout, D, H, W = 2, 16, 24, 3, 8, 8                 # Cout = the "cin" of the data gradient: rows of the operand
+    e16 = 8 if dtype == "bf16" else 4
+    kc = Cin
+    x = torch.randn(N, Cin, D, H, W, generator=gen)
+    wfull = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (Cin * 18) ** 0.5
+    first, ntap = 9, 18                                          # depth taps 1 .. 2 of the 27: a (2, 3, 3) kernel
+    wsl = wfull[:, :, 1:3]
+    td = tdt(dtype)
+    xr, wr = (x.to(td).float(), wsl.to(td).float())
+    # depth: kernel 2, padding 0, output extent D (the last output reads one slice past the input: zero) -- as the parity class of odd positions
+    xp = F.pad(xr, (0, 0, 0, 0, 0, 1))
+    ref = F.conv3d(xp, wr, None, padding=(0, 1, 1))
+    rows = N * D * H * W
+    xa = x.permute(0, 2, 3, 4, 1).reshape(rows, Cin).to(DEV).to(td).contiguous()
+    ld_full = 27 * kc
+    slab = torch.full((Cout * ld_full + 8192,), float("nan"), dtype=td, device=DEV)
+    op = slab[:Cout * ld_full].view(Cout, 27, kc)
+    op.copy_(wfull.permute(0, 2, 3, 4, 1).reshape(Cout, 27, Cin).to(DEV).to(td))      # [n][tap][c], taps in (d, h, w) order
+    wview = slab[first * kc:]                                    # the slice starts at column first * kc of row 0
+    out = torch.full((rows, Cout), float("nan"), device=DEV)
+    d = ops.conv_desc(N, (D, H, W), (D, H, W), (2, 3, 3), (1, 1, 1), (0, 1, 1))
+    d.A = xa.data_ptr(); d.a_sn = D * H * W * kc; d.a_sd = H * W * kc; d.a_sh = W * kc; d.a_sw = kc; d.a_sc = 1; d.Kc_real = kc; d.Kc = kc
+    d.W = wview.data_ptr(); d.ldw = ld_full; d.Nout = Cout
+    d.C = out.data_ptr(); d.c_f32 = 1; d.ldc = Cout
+    ops.conv_forward(d, dtype)
+    torch.cuda.synchronize()
+    got = out.view(N, D, H, W, Cout).permute(0, 4, 1, 2, 3).cpu()
+    assert torch.isfinite(got).all(), f"{int((~torch.isfinite(got)).sum())} non-finite outputs: the operand was read past its K range"
+    assert (got - ref).abs().max().item() <= TOLS[dtype] * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("B,Cin,Cout", [(20, 32, 2048), (3, 8, 256), (5, 24, 384), (4, 64, 512), (7, 40, 2048), (1, 16, 256)])
 def test_conv3x3_narrow_input_stationary(B, Cin, Cout):
     """conv3x3_k64 (round 6): 3x3 on the 8x8 latent with a narrow dense input (<= 64 channels) and a wide output -- conv1 of

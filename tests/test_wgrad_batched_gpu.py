@@ -130,3 +130,62 @@ def test_adam_in_the_weight_gradient_epilogue_is_bit_identical(B, C, nb):
             else:
                 assert torch.isnan(g2).all(), "the fused launch must not write the gradient"
         assert not torch.equal(two["plain"][0], p0)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,HW,kd", [(4, 64, 64, 1, 64, 1), (4, 128, 96, 1, 64, 1), (4, 64, 128, 4, 32, 3), (4, 40, 72, 2, 48, 3),
+                                                 (20, 64, 64, 1, 128, 1), (1, 256, 256, 1, 128, 1)])
+def test_halo_staged_weight_gradient_matches_torch(N, Cin, Cout, D, HW, kd):
+    """wgrad3x3_halo (round 6): weight gradient of stride-1 3x3 (kd = 1) / 3x3x3 (kd = 3) "same" convolutions on large maps with the input
+    patch + halo stationary in LDS -- BasicBlock of the 3-D encoder (motion_encoder.py:45-74) and the SPADE decoder's 3x3 layers
+    (autoencoders/util.py:106-192) in first-stage training.  Against torch's autograd on the same bf16 operands: split-M slabs with the
+    split count the library names (ipoke_conv_wgrad_splitm), summed by ipoke_reduce_rows as the trainer does; and one split (direct
+    store).  Ragged channel counts, maps that are not square multiples of the patch grid's power of two, depth taps that leave the volume."""
+    lib = _lib.lib()
+    gen = torch.Generator().manual_seed(N * 1000 + Cin + Cout + kd)
+    H = W = HW
+    x = (torch.randn(N, Cin, D, H, W, generator=gen) * 0.5).to(torch.bfloat16)
+    dy = (torch.randn(N, Cout, D, H, W, generator=gen) * 0.5).to(torch.bfloat16)
+    xg, dyg = x.to(DEV).float(), dy.to(DEV).float()
+    w = torch.zeros(Cout, Cin, kd, 3, 3, device=DEV, requires_grad=True)
+    y = F.conv3d(xg, w, padding=(kd // 2, 1, 1))
+    (y * dyg).sum().backward()
+    ref = w.grad.detach()
+    M = N * D * H * W
+    kc, ldy = -(-Cin // 8) * 8, -(-Cout // 8) * 8
+    xa = torch.zeros(M, kc, dtype=torch.bfloat16, device=DEV); xa[:, :Cin] = x.to(DEV).permute(0, 2, 3, 4, 1).reshape(M, Cin)
+    ya = torch.zeros(M, ldy, dtype=torch.bfloat16, device=DEV); ya[:, :Cout] = dy.to(DEV).permute(0, 2, 3, 4, 1).reshape(M, Cout)
+    taps = kd * 9
+
+    def desc():
+        d = WgradDesc()
+        d.NB, d.Di, d.Hi, d.Wi, d.Do, d.Ho, d.Wo = N, D, H, W, D, H, W
+        d.kd, d.kh, d.kw, d.sd, d.sh, d.sw, d.pd, d.ph, d.pw = kd, 3, 3, 1, 1, 1, kd // 2, 1, 1
+        d.A = xa.data_ptr(); d.a_f32 = 0; d.a_sn = D * H * W * kc; d.a_sd = H * W * kc; d.a_sh = W * kc; d.a_sw = kc; d.a_sc = 1
+        d.Kc_real = kc; d.Kc = kc; d.Kc_store = Cin
+        d.dY = ya.data_ptr(); d.ldy = ldy; d.Nout = Cout
+        d.w_sn = Cin * taps; d.w_sc = taps; d.w_st = 1
+        return d
+
+    d = desc()
+    sp = lib.ipoke_conv_wgrad_splitm(byref(d), _lib.BF16, 256)
+    assert sp >= 1, "the halo-staged kernel should claim this problem"
+    nel = Cout * Cin * taps
+    slabs = torch.full((sp, nel), float("nan"), device=DEV)
+    d.splitm = sp; d.split_stride = nel; d.dW = slabs.data_ptr()
+    check(lib.ipoke_conv_wgrad(byref(d), _lib.BF16, ops._s()))
+    got = torch.empty(nel, device=DEV)
+    if sp > 1:
+        check(lib.ipoke_reduce_rows(slabs.data_ptr(), got.data_ptr(), sp, nel, ops._s()))
+    else:
+        got = slabs[0]
+    torch.cuda.synchronize()
+    assert not torch.isnan(slabs).any(), "unwritten slab elements"
+    scale = max(1.0, ref.abs().max().item())
+    err = (got.view_as(ref) - ref).abs().max().item()
+    print(f"halo wgrad N={N} {Cin}->{Cout} D={D} {H}x{W} kd={kd}: {sp} splits, max err {err:.3e} (ref max {ref.abs().max().item():.1f})")
+    assert err <= 3e-3 * scale
+    one = torch.full((nel,), float("nan"), device=DEV)
+    d1 = desc(); d1.splitm = 1; d1.dW = one.data_ptr()
+    check(lib.ipoke_conv_wgrad(byref(d1), _lib.BF16, ops._s()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(one).any() and (one.view_as(ref) - ref).abs().max().item() <= 3e-3 * scale
