@@ -593,10 +593,22 @@ typedef struct {
                                             workspace, see ipoke_groupnorm_stats_offset); NULL: recomputed from x */
   int32_t mod_samples;                   /* as ipoke_norm_desc.mod_samples: sample n read the modulation of sample n % mod_samples;
                                             dmod_gamma / dmod_beta are still written per sample (sum the frames: ipoke_sum_frames) */
+  /* optional (rs_scale != NULL; no SPADE modulation): x is the output of a frame-batched spectral-norm convolution WITHOUT activation,
+   * y_conv = conv(.) / sigma_t + b, that only this norm reads.  The pass over (dy, x) that ipoke_rowscale_bwd would make on the norm's dx
+   * is folded into the norm's own last pass: `dx` receives gs = round(dx) / sigma_t (the rows of the convolution's two gradient GEMMs),
+   * rs_dots[t] = sum over the rows of frame t of round(dx) * (x - b), rs_dbias[c] = column sums of round(dx) -- the same values from the
+   * same rounded dx, summed over blocks of 512 positions in a fixed order.  The samples are ordered (frame, clip). */
+  const float* rs_scale; int32_t rs_scale_stride;   /* 1 / sigma_t of frame t at rs_scale[t * rs_scale_stride]                     */
+  int64_t rs_rows_per_group;             /* rows of one frame = clips * S; N * S must be a multiple                               */
+  const float* rs_bias;                  /* the convolution's bias [C] (fp32) or NULL                                              */
+  float* rs_dots;                        /* [N * S / rs_rows_per_group]                                                            */
+  float* rs_dbias;                       /* [C] or NULL                                                                            */
+  float* rs_workspace;                   /* ipoke_groupnorm_bwd_rs_workspace_floats(N, S, C) floats                                */
 } ipoke_norm_bwd_desc;
 /* float offset of the (mean, rstd) table inside the workspace ipoke_groupnorm / ipoke_groupnorm_stats just filled */
 int64_t ipoke_groupnorm_stats_offset(int N, int S, int G);
 int64_t ipoke_groupnorm_bwd_workspace_floats(int N, int S, int C, int G);
+int64_t ipoke_groupnorm_bwd_rs_workspace_floats(int N, int S, int C);
 int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void* stream);
 /* out[:, :C] = dy * act'(y), out[:, C:Cpad] = 0   (backward of an activation fused into a conv / add epilogue) */
 int ipoke_act_bwd(const void* dy, int lddy, const void* y, int ldy, void* out, int ldo, int64_t M, int C, int Cpad, int act,

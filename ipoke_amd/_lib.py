@@ -71,7 +71,9 @@ class NormBwdDesc(Structure):
                 ("N", c_int32), ("S", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
                 ("gamma", c_void_p), ("beta", c_void_p), ("mod_gamma", c_void_p), ("ld_mod", c_int32),
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("act", c_int32), ("workspace", c_void_p), ("stats", c_void_p),
-                ("mod_samples", c_int32)]
+                ("mod_samples", c_int32),
+                ("rs_scale", c_void_p), ("rs_scale_stride", c_int32), ("rs_rows_per_group", c_int64), ("rs_bias", c_void_p),
+                ("rs_dots", c_void_p), ("rs_dbias", c_void_p), ("rs_workspace", c_void_p)]
 
 
 class GruDesc(Structure):
@@ -212,6 +214,7 @@ SIGNATURES = {
     "ipoke_groupnorm_stats_offset": (c_int64, [c_int, c_int, c_int]),
     "ipoke_groupnorm_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "ipoke_groupnorm_bwd": (c_int, [POINTER(NormBwdDesc), c_int, _P]),
+    "ipoke_groupnorm_bwd_rs_workspace_floats": (c_int64, [c_int, c_int, c_int]),
     "ipoke_act_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, _P]),
     "ipoke_colsum_workspace_floats": (c_int64, [c_int64, c_int]),
     "ipoke_colsum": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, c_int, _P, c_int, _P]),

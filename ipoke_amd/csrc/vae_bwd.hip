@@ -108,7 +108,11 @@ struct NormBwd {
   float* part;                         // [N][nchunks][2][C]  (sum du, sum du*xhat)
   float* gsum;                         // [N][G][2]           (S1 = sum dxhat, S2 = sum dxhat*xhat)
   int nchunks, pos_per_block;
+  // folded ipoke_rowscale_bwd (ipoke_norm_bwd_desc.rs_*): frame of sample n = n / rs_clips
+  const float* rs_scale; int rs_scale_stride, rs_clips, rs_pos_per_block, rs_nchunks;
+  const float* rs_bias; float* rs_dot_part; float* rs_col_part;
 };
+int rowscale_finalize(float* dot_part, float* col_part, int ngroups, int nbx, int C, float* dots, float* dbias, hipStream_t s);   // vae_train.hip
 // du for one element: dw = dy*act'(y); du = dw*(1+mg)
 template <typename T>
 __device__ __forceinline__ float norm_dw(const NormBwd& a, long m, int c) {
@@ -230,12 +234,16 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const NormBwd a, float
 }
 // pass 3: dx = rstd * (dxhat - (S1 + xhat*S2)/cnt), plus the residual / modulation gradients.  Grid (chunks, N): the
 // per-channel constants of the sample live in LDS, the inner loop is 16-byte loads / stores without divisions.
-template <typename T>
+// RS (round 6): x is the un-activated output of a frame-batched spectral-norm convolution that only this norm reads -- the pass
+// ipoke_rowscale_bwd would make over (dx, x) right behind this kernel (5 of the 15 such passes of a first-stage step, the ones at a
+// block's output resolution) happens on the registers here: dx leaves as round(dx) / sigma_t, the frame's <dx, x - b> and the column sums
+// go to per-block partials (blocks of rs_pos_per_block positions; fixed-order sums in rowscale_final_kernel).
+template <typename T, bool RS>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
   if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormBwd)>();
   constexpr int E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
-  extern __shared__ float lds[];            // [6][C]: mean, rstd, gamma, beta, S1/cnt, S2/cnt
+  extern __shared__ float lds[];            // [6][C]: mean, rstd, gamma, beta, S1/cnt, S2/cnt  (RS: + [256 * E16] column sums + [4])
   const int n = blockIdx.y, cpg = a.C / a.G, C = a.C;
   const long mod_row0 = (long)(a.mod_N > 0 ? n % a.mod_N : n) * a.S;
   const float inv_cnt = 1.f / ((float)a.S * cpg);
@@ -247,12 +255,26 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
   }
   __syncthreads();
   const int cvec = C / E16;
-  const int p0 = blockIdx.x * a.pos_per_block, p1 = min(a.S, p0 + a.pos_per_block);
+  const int ppb = RS ? a.rs_pos_per_block : a.pos_per_block;
+  const int p0 = blockIdx.x * ppb, p1 = min(a.S, p0 + ppb);
+  float* sm = lds + 6 * C;
+  float rs_sc = 0.f, dot = 0.f;
+  float* cpart = nullptr;
+  if (RS) {
+    rs_sc = a.rs_scale[(long)(n / a.rs_clips) * a.rs_scale_stride];
+    if (a.rs_col_part) cpart = a.rs_col_part + ((long)n * a.rs_nchunks + blockIdx.x) * C;
+  }
   for (int g0 = 0; g0 < cvec; g0 += 256) {
     const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
     const int rp = 256 / groups;
     const int cg = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
-    if (rr >= rp) continue;
+    float cs[E16], bb[E16];
+    if (RS) {
+#pragma unroll
+      for (int e = 0; e < E16; ++e) { cs[e] = 0.f; bb[e] = a.rs_bias ? a.rs_bias[cg * E16 + e] : 0.f; }
+    }
+    if (!RS && rr >= rp) continue;
+    if (rr < rp)
     for (int p = p0 + rr; p < p1; p += rp) {
       const long m = (long)n * a.S + p;
       const frag_t gy = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.dy) + m * a.lddy + cg * E16);
@@ -273,7 +295,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
           odmg[e] = ET<T>::from_f32(dw * (xh * lds[2 * C + c] + lds[3 * C + c]));
         }
         odw[e] = ET<T>::from_f32(dw);
-        odx[e] = ET<T>::from_f32(lds[C + c] * (du * lds[2 * C + c] - (lds[4 * C + c] + xh * lds[5 * C + c])));
+        const float dxv = lds[C + c] * (du * lds[2 * C + c] - (lds[4 * C + c] + xh * lds[5 * C + c]));
+        if (RS) {
+          const float g = ET<T>::to_f32(ET<T>::from_f32(dxv));        // the value the un-fused pass reads back
+          if (g != 0.f) dot = fmaf(g, ET<T>::to_f32(xv[e]) - bb[e], dot);
+          cs[e] += g;
+          odx[e] = ET<T>::from_f32(g * rs_sc);
+        } else {
+          odx[e] = ET<T>::from_f32(dxv);
+        }
       }
       *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dx) + m * a.lddx + cg * E16) = odx;
       if (a.dres) *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dres) + m * a.lddres + cg * E16) = odw;
@@ -282,6 +312,22 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
         *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dmb) + m * a.ld_dmod + cg * E16) = odw;
       }
     }
+    if (RS && cpart) {
+#pragma unroll
+      for (int e = 0; e < E16; ++e) sm[threadIdx.x * E16 + e] = rr < rp ? cs[e] : 0.f;
+      __syncthreads();
+      for (int i = threadIdx.x; i < groups * E16; i += 256) {
+        const int cgi = i / E16, e = i - cgi * E16;
+        float t = 0.f;
+        for (int k = 0; k < rp; ++k) t += sm[(k * groups + cgi) * E16 + e];
+        cpart[(g0 + cgi) * E16 + e] = t;
+      }
+      __syncthreads();
+    }
+  }
+  if (RS) {
+    dot = block_sum(dot, sm + 256 * E16);
+    if (threadIdx.x == 0) a.rs_dot_part[(long)n * a.rs_nchunks + blockIdx.x] = dot;
   }
 }
 
@@ -409,6 +455,10 @@ extern "C" int ipoke_colsum(const void* src, int ld, int64_t M, int C, int src_f
 }
 
 static const int kNormBwdPos = 128;
+static const int kNormRsPos = 512;          // positions per block of the pass that folds ipoke_rowscale_bwd in (that kernel's own block size)
+extern "C" int64_t ipoke_groupnorm_bwd_rs_workspace_floats(int N, int S, int C) {
+  return (int64_t)N * ((S + kNormRsPos - 1) / kNormRsPos) * (C + 1);
+}
 extern "C" int64_t ipoke_groupnorm_bwd_workspace_floats(int N, int S, int C, int G) {
   const int nchunks = (S + kNormBwdPos - 1) / kNormBwdPos;
   return ipoke_groupnorm_workspace_floats(N, S, G) + (int64_t)N * nchunks * 2 * C + (int64_t)N * G * 2;
@@ -431,7 +481,7 @@ extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void
               (!d->dres || d->lddres % e16 == 0) && (!d->mod_gamma || (d->ld_mod % e16 == 0 && d->ld_dmod % e16 == 0)) && d->C <= 4096,
               "channels and pitches must be multiples of 16 bytes");
   const int ppb_f = 128, nch_f = (d->S + ppb_f - 1) / ppb_f;
-  NormBwd a;
+  NormBwd a{};
   if (d->stats) {
     a.stats = d->stats;                    // (mean, rstd) saved by the forward pass
   } else {                                 // recomputed from the saved input, exactly as in the forward pass
@@ -455,9 +505,23 @@ extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void
   hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(d->N + (d->dgamma ? (d->C + 15) / 16 : 0)), dim3(256), 0, s, a, d->dgamma, d->dbeta);
   IPK_LAUNCH_CHECK();
   const size_t lds = (size_t)6 * d->C * sizeof(float);
+  if (d->rs_scale) {
+    IPK_REQUIRE(!d->mod_gamma && d->rs_dots && d->rs_workspace && d->rs_rows_per_group >= d->S && d->rs_rows_per_group % d->S == 0 &&
+                ((int64_t)d->N * d->S) % d->rs_rows_per_group == 0 && d->C <= 2048, "folded row-scale pass: whole frames of un-modulated samples");
+    a.rs_scale = d->rs_scale; a.rs_scale_stride = d->rs_scale_stride < 1 ? 1 : d->rs_scale_stride;
+    a.rs_clips = (int)(d->rs_rows_per_group / d->S); a.rs_pos_per_block = kNormRsPos; a.rs_nchunks = (d->S + kNormRsPos - 1) / kNormRsPos;
+    a.rs_bias = d->rs_bias; a.rs_dot_part = d->rs_workspace;
+    a.rs_col_part = d->rs_dbias ? d->rs_workspace + (int64_t)d->N * a.rs_nchunks : nullptr;
+    const size_t lds_rs = lds + (size_t)(256 * e16 + 4) * sizeof(float);
+    DISPATCH_T(dtype,
+      hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, true>), dim3(a.rs_nchunks, d->N), dim3(256), lds_rs, s, a),
+      hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), dim3(a.rs_nchunks, d->N), dim3(256), lds_rs, s, a));
+    IPK_LAUNCH_CHECK();
+    return rowscale_finalize(a.rs_dot_part, a.rs_col_part, d->N / a.rs_clips, a.rs_clips * a.rs_nchunks, d->C, d->rs_dots, d->rs_dbias, s);
+  }
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(a.nchunks, d->N), dim3(256), lds, s, a),
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(a.nchunks, d->N), dim3(256), lds, s, a));
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false>), dim3(a.nchunks, d->N), dim3(256), lds, s, a),
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), dim3(a.nchunks, d->N), dim3(256), lds, s, a));
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

@@ -872,6 +872,18 @@ extern "C" int ipoke_rowscale_bwd(const ipoke_rowscale_bwd_desc* d, int dtype, v
   return IPOKE_OK;
 }
 
+// the fixed-order sums of rowscale_final_kernel for partials another kernel wrote (the norm backward that folds this pass in, vae_bwd.hip):
+// dot_part[group][nbx], col_part[group * nbx + k][C] (or null)
+namespace ipoke {
+int rowscale_finalize(float* dot_part, float* col_part, int ngroups, int nbx, int C, float* dots, float* dbias, hipStream_t s) {
+  RowScaleBwd a{};
+  a.C = C; a.ngroups = ngroups; a.nbx = nbx; a.dot_part = dot_part; a.col_part = col_part; a.dots = dots; a.dbias = dbias;
+  hipLaunchKernelGGL(rowscale_final_kernel, dim3(ngroups + (dbias ? (C + 15) / 16 : 0)), dim3(256), 0, s, a);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+}  // namespace ipoke
+
 /* In place: grad (PyTorch weight layout; holds sum_t dW_eff_t / sigma_t) -= sum_t dots[t] / sigma_t * u_t v_t^T.  snapshots[t] = u_t | v_t and
  * sig[t] = {sigma_t, 1 / sigma_t} as written by ipoke_spectral_sigma_multi (strides in floats); dots from ipoke_rowscale_bwd. */
 extern "C" int ipoke_spectral_bwd_frames(const float* w, int cout, int cin, int taps, int transposed, float* grad, const float* snapshots,

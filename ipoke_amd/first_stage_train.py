@@ -318,6 +318,8 @@ class _ConvFn(torch.autograd.Function):
         meta["odhw"] = y.dhw
         ctx.meta = meta
         ctx.bias32 = b if snf is not None else None
+        if snf is not None:
+            meta["_bias32"] = b                   # the norm behind this convolution may fold the row-scale pass of backward (_NormFn)
         ctx.save_for_backward(x_t, w, y.t if (meta["act"] != _lib.ACT_NONE or snf is not None) else None)
         ctx.has_bias = bias is not None
         return y.t
@@ -336,7 +338,17 @@ class _ConvFn(torch.autograd.Function):
         s = _lib.current_stream()
         snf = m.get("sn_frames")
         d_bias = None
-        if snf is not None:
+        pre = m.pop("_prescaled", None)
+        if pre is not None:
+            # the norm that reads this convolution's output alone already made that pass on its own registers (_NormFn.backward): dy IS
+            # g = d(conv output) / sigma_t, the frames' dots and the bias gradient came with it
+            sig, snaps = snf
+            frames = int(sig.shape[0])
+            if dy.data_ptr() != pre[0].data_ptr() or dy.shape[1] != ldg:
+                raise RuntimeError("the pre-scaled gradient of a spectral-norm convolution did not arrive unchanged from its norm")
+            g, dots = dy, pre[1]
+            d_bias = pre[2] if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        elif snf is not None:
             # one pass over (dy, y): g = dy * act'(y) / sigma_t (the rows of both gradient GEMMs), the frames' <dY_t, Y_t - b> for sigma_t's
             # own gradient, and the bias gradient
             sig, snaps = snf
@@ -605,7 +617,9 @@ def conv(mod, x, dtype, act=_lib.ACT_NONE, out_f32=False, src=None, w=None):
         meta["sn_frames"] = (w.sig, w.snaps)
         w = w.w_orig
     y = _ConvFn.apply(None if src is not None else x.t, w, mod.bias, meta)
-    return K.CL(y, N, meta["odhw"], mod.cout)
+    out = K.CL(y, N, meta["odhw"], mod.cout)
+    out.conv_meta = meta
+    return out
 
 
 def effective_weight(mod, power_iteration=False, frames=None):
@@ -766,6 +780,19 @@ class _NormFn(torch.autograd.Function):
         ws = _workspace(_lib.lib().ipoke_groupnorm_bwd_workspace_floats(N, S, C, G), dy.device, "normbwd")
         d.workspace = ws.data_ptr()
         d.stats = stats.data_ptr()
+        pm = m.get("producer")
+        if pm is not None:
+            # x is the un-activated output of a frame-batched spectral-norm convolution nobody else reads: dx leaves as dx / sigma_t with
+            # the frames' <dx, x - b> and the bias gradient (the convolution's own pass over (dx, x), ipoke_rowscale_bwd, folded in)
+            sig = pm["sn_frames"][0]
+            frames = int(sig.shape[0])
+            rs_dots = torch.empty(frames, dtype=torch.float32, device=dy.device)
+            rs_db = torch.empty(C, dtype=torch.float32, device=dy.device) if pm.get("_bias32") is not None else None
+            rs_ws = _workspace(_lib.lib().ipoke_groupnorm_bwd_rs_workspace_floats(N, S, C), dy.device, "normbwd_rs")
+            d.rs_scale = sig.view(-1)[1:].data_ptr(); d.rs_scale_stride = 2; d.rs_rows_per_group = (N // frames) * S
+            d.rs_bias = 0 if pm.get("_bias32") is None else pm["_bias32"].data_ptr()
+            d.rs_dots = rs_dots.data_ptr(); d.rs_dbias = 0 if rs_db is None else rs_db.data_ptr(); d.rs_workspace = rs_ws.data_ptr()
+            pm["_prescaled"] = (dx, rs_dots, rs_db)
         check(_lib.lib().ipoke_groupnorm_bwd(byref(d), ops._dt(dt), _lib.current_stream()))
         if mod_n:
             frames = N // mod_n
@@ -778,8 +805,25 @@ class _NormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dmg, dmb, dres, None
 
 
-def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None):
+_NORM_RS = os.environ.get("IPOKE_NORM_ROWSCALE", "1") != "0"      # developer A/B: the convolution's own ipoke_rowscale_bwd pass instead
+
+
+def _rowscale_producer(x, mod):
+    """The meta of the convolution that produced ``x`` when the norm's backward may fold its row-scale pass: a frame-batched
+    spectral-norm convolution without activation whose dtype output this norm alone reads."""
+    pm = getattr(x, "conv_meta", None)
+    if not _NORM_RS or pm is None or mod is not None or pm.get("sn_frames") is None or pm["act"] != _lib.ACT_NONE or pm.get("out_f32", False):
+        return None
+    frames = int(pm["sn_frames"][0].shape[0])
+    if x.N % frames or x.t.shape[1] != x.C or x.C > 2048:
+        return None
+    return pm
+
+
+def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None, sole_reader=False):
     meta = dict(N=x.N, S=x.S, C=x.C, G=groups, dtype=dtype, act=act)
+    if sole_reader:
+        meta["producer"] = _rowscale_producer(x, mod)
     if mod is not None and mod[0].N != x.N:       # frames of a clip decoded as one batch ordered (frame, clip): shared SPADE maps
         assert x.N % mod[0].N == 0 and mod[0].S == x.S and mod[0].t.shape[0] == mod[0].N * x.S
         meta["mod_samples"] = mod[0].N
@@ -788,10 +832,11 @@ def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=N
     return K.CL(y, x.N, x.dhw, x.C)
 
 
-def norm(mod, x, dtype, act=_lib.ACT_NONE, res=None):
+def norm(mod, x, dtype, act=_lib.ACT_NONE, res=None, sole_reader=False):
+    """``sole_reader``: ``x`` is a convolution's output that nothing but this norm reads (see _rowscale_producer)."""
     if mod.kind == "group":
-        return group_norm(x, mod.groups, dtype, mod.weight, mod.bias, act=act, res=res)
-    return group_norm(x, mod.groups, dtype, act=act, res=res)
+        return group_norm(x, mod.groups, dtype, mod.weight, mod.bias, act=act, res=res, sole_reader=sole_reader)
+    return group_norm(x, mod.groups, dtype, act=act, res=res, sole_reader=sole_reader)
 
 
 class _AddActFn(torch.autograd.Function):
@@ -1104,14 +1149,14 @@ def conv_block(blk, x, dtype, res=None, out_f32=False, pit=False, frames=None):
             act = _lib.ACT_NONE             # the loss kernel applies tanh
         y = conv(blk.conv, x, dtype, act=act, out_f32=out_f32, w=w)
         return y if res is None else add_act(y, res, dtype, FS.ACT[blk.activation])
-    return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=FS.ACT[blk.activation], res=res)
+    return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=FS.ACT[blk.activation], res=res, sole_reader=True)
 
 
 def convT_block(blk, x, dtype, pit=False, frames=None):
     w = effective_weight(blk.conv, pit, frames)
     if blk.norm is None:
         return conv(blk.conv, x, dtype, act=blk.act, w=w)
-    return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=blk.act)
+    return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=blk.act, sole_reader=True)
 
 
 def res_block(blk, x, dtype, pit=False, frames=None):

@@ -252,3 +252,89 @@ def test_spectral_bwd_frames_and_sum_frames(transposed):
         _lib.check(L.ipoke_sum_frames(_lib.ptr(src), _lib.ptr(dst), frames, src.shape[1], _lib.DTYPES[name], _lib.current_stream()))
         want = src.float().sum(0)
         assert (dst.float() - want).abs().max().item() <= (1e-6 if name == "f32" else 2e-2) * want.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [("inst", 6, 64, 40, 0, False, False), ("group_res", 6, 32, 16, 16, True, True), ("inst_wide", 4, 256, 8, 0, False, False)],
+                         ids=lambda c: c[0])
+def test_norm_backward_folds_the_row_scale_pass(case, dtype):
+    """ipoke_norm_bwd_desc.rs_*: the norm's last backward pass writes gs = round(dx) / sigma_t, the frames' <dx, x - b> and the bias
+    gradient itself -- against the two-launch sequence (ipoke_groupnorm_bwd, then ipoke_rowscale_bwd on its dx): gs BIT-identical (the
+    same rounded dx, the same product), dots / dbias equal up to the order of the partial sums; the residual gradient is untouched.
+    Samples ordered (frame, clip); several 512-position blocks per sample in the first case (S = 1600)."""
+    from ipoke_amd._lib import NormBwdDesc, NormDesc
+    name, N, C, H, G, affine, use_res = case
+    frames = 3 if N % 3 == 0 else 2
+    S = H * H
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    gen = torch.Generator().manual_seed(N + C)
+    x = (torch.randn(N * S, C, generator=gen) * 1.3 + 0.2).to(td).to(DEV)
+    dy = torch.randn(N * S, C, generator=gen).to(td).to(DEV)
+    res = torch.randn(N * S, C, generator=gen).to(td).to(DEV) if use_res else None
+    gamma = (1 + 0.3 * torch.randn(C, generator=gen)).to(DEV) if affine else None
+    beta = (0.2 * torch.randn(C, generator=gen)).to(DEV) if affine else None
+    bias = (0.3 * torch.randn(C, generator=gen)).to(DEV)
+    groups = C if G == 0 else G
+    sig = torch.tensor([[2.0, 0.5], [0.8, 1.25], [1.6, 0.625]], device=DEV)[:frames].contiguous()
+    L = _lib.lib()
+    s = _lib.current_stream()
+    # forward (for y and the statistics)
+    y = torch.empty_like(x)
+    fd = NormDesc()
+    fd.x = x.data_ptr(); fd.ldx = C; fd.y = y.data_ptr(); fd.ldy = C; fd.N, fd.S, fd.C, fd.G, fd.eps = N, S, C, groups, 1e-5
+    if affine:
+        fd.gamma = gamma.data_ptr(); fd.beta = beta.data_ptr()
+    if use_res:
+        fd.res = res.data_ptr(); fd.ld_res = C
+    fd.act = _lib.ACT_RELU
+    ws_f = torch.empty(int(L.ipoke_groupnorm_workspace_floats(N, S, groups)), device=DEV)
+    fd.workspace = ws_f.data_ptr()
+    _lib.check(L.ipoke_groupnorm(byref(fd), _lib.DTYPES[dtype], s))
+
+    def run(fold):
+        dx = torch.full_like(x, 3.0)
+        dres = torch.empty_like(x) if use_res else None
+        d = NormBwdDesc()
+        d.x = x.data_ptr(); d.ldx = C; d.y = y.data_ptr(); d.ldy = C; d.dy = dy.data_ptr(); d.lddy = C; d.dx = dx.data_ptr(); d.lddx = C
+        d.N, d.S, d.C, d.G, d.eps = N, S, C, groups, 1e-5
+        d.act = _lib.ACT_RELU
+        if use_res:
+            d.dres = dres.data_ptr(); d.lddres = C
+        dg = db = None
+        if affine:
+            dg = torch.empty(C, device=DEV); db = torch.empty(C, device=DEV)
+            d.gamma = gamma.data_ptr(); d.beta = beta.data_ptr(); d.dgamma = dg.data_ptr(); d.dbeta = db.data_ptr()
+        ws = torch.empty(int(L.ipoke_groupnorm_bwd_workspace_floats(N, S, C, groups)), device=DEV)
+        d.workspace = ws.data_ptr()
+        dots = torch.empty(frames, device=DEV); dbias = torch.empty(C, device=DEV)
+        if fold:
+            ws_rs = torch.empty(int(L.ipoke_groupnorm_bwd_rs_workspace_floats(N, S, C)), device=DEV)
+            d.rs_scale = sig.view(-1)[1:].data_ptr(); d.rs_scale_stride = 2; d.rs_rows_per_group = (N // frames) * S
+            d.rs_bias = bias.data_ptr(); d.rs_dots = dots.data_ptr(); d.rs_dbias = dbias.data_ptr(); d.rs_workspace = ws_rs.data_ptr()
+            _lib.check(L.ipoke_groupnorm_bwd(byref(d), _lib.DTYPES[dtype], s))
+            gs = dx
+        else:
+            _lib.check(L.ipoke_groupnorm_bwd(byref(d), _lib.DTYPES[dtype], s))
+            gs = torch.empty_like(x)
+            M, rpg = N * S, (N // frames) * S
+            ws_r = torch.empty(int(L.ipoke_rowscale_bwd_workspace_floats(M, C, rpg)), device=DEV)
+            r = _lib.RowScaleBwdDesc()
+            r.dy = dx.data_ptr(); r.lddy = C; r.y = x.data_ptr(); r.ldy = C; r.M = M; r.C = C; r.Cpad = C; r.act = _lib.ACT_NONE
+            r.bias = bias.data_ptr(); r.scale = sig.view(-1)[1:].data_ptr(); r.scale_stride = 2; r.rows_per_group = rpg
+            r.gs = gs.data_ptr(); r.ldgs = C; r.dots = dots.data_ptr(); r.dbias = dbias.data_ptr(); r.workspace = ws_r.data_ptr()
+            _lib.check(L.ipoke_rowscale_bwd(byref(r), _lib.DTYPES[dtype], s))
+        torch.cuda.synchronize()
+        return gs, dots, dbias, dres, dg, db
+
+    gs0, dots0, db0, dres0, dg0, dbt0 = run(False)
+    gs1, dots1, db1, dres1, dg1, dbt1 = run(True)
+    assert torch.equal(gs0, gs1)
+    if use_res:
+        assert torch.equal(dres0, dres1)
+    if affine:
+        assert torch.equal(dg0, dg1) and torch.equal(dbt0, dbt1)
+    yard_d = float((gs0.float().abs().sum() / frames) * x.float().abs().mean()) * 1e-5 + 1e-4       # the dots cancel: yardstick = sum |dx| * mean |x|
+    e_dot = (dots0 - dots1).abs().max().item()
+    e_db = (db0 - db1).abs().max().item()
+    print(f"norm bwd + row scale {name}[{dtype}]: dots {dots0.tolist()} diff {e_dot:.2e} (yard {yard_d:.2e}), dbias diff {e_db:.2e}")
+    assert e_dot <= yard_d and e_db <= 1e-3 * max(1.0, db0.abs().max().item())
