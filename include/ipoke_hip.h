@@ -604,6 +604,9 @@ typedef struct {
   float* rs_dots;                        /* [N * S / rs_rows_per_group]                                                            */
   float* rs_dbias;                       /* [C] or NULL                                                                            */
   float* rs_workspace;                   /* ipoke_groupnorm_bwd_rs_workspace_floats(N, S, C) floats                                */
+  int32_t dmod_summed;                   /* 1 (with 0 < mod_samples < N): dmod_gamma / dmod_beta hold mod_samples * S rows -- the SUM over the
+                                            frames that share a modulation row, accumulated in fp32 in frame order and rounded once (no
+                                            per-sample maps, no ipoke_sum_frames pass)                                              */
 } ipoke_norm_bwd_desc;
 /* float offset of the (mean, rstd) table inside the workspace ipoke_groupnorm / ipoke_groupnorm_stats just filled */
 int64_t ipoke_groupnorm_stats_offset(int N, int S, int G);

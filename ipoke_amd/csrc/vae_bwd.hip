@@ -331,6 +331,87 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
   }
 }
 
+// The same pass for SPADE norms whose modulation maps are shared by the frames of a clip (samples ordered (frame, clip), mod_N = clips;
+// ipoke_norm_bwd_desc.dmod_summed): a workgroup owns a block of positions of ONE clip and walks the frames, so that the gradients of the
+// shared maps accumulate in registers (fp32, frame order) and leave once.  The per-sample form wrote two maps per SAMPLE and
+// ipoke_sum_frames read them all back: at the 128 x 128 x 64 level of a first-stage step 2 x 629 MB written + read per step for 2 x 42 MB
+// of result.  Thread (rr, cg) owns E16 channels of ROWS positions (16 accumulated channels-positions x 2 maps per thread: more costs the
+// occupancy that hides the per-frame constant reload); a block is ROWS * (256 / (C / E16)) positions.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_frames_kernel(const NormBwd a) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormBwd)>();
+  constexpr int E16 = ET<T>::E16, ROWS = 16 / E16;
+  typedef typename ET<T>::frag frag_t;
+  extern __shared__ float lds[];            // [6][C]: mean, rstd, gamma, beta, S1/cnt, S2/cnt
+  const int clip = blockIdx.y, clips = a.mod_N, frames = a.N / clips, cpg = a.C / a.G, C = a.C;
+  const float inv_cnt = 1.f / ((float)a.S * cpg);
+  const int cvec = C / E16, rp = 256 / cvec;
+  const int cg = threadIdx.x % cvec, rr = threadIdx.x / cvec;
+  const int p0 = blockIdx.x * (ROWS * rp);
+  for (int c = threadIdx.x; c < C; c += 256) { lds[2 * C + c] = a.gamma ? a.gamma[c] : 1.f; lds[3 * C + c] = a.beta ? a.beta[c] : 0.f; }
+  float adg[ROWS][E16], adb[ROWS][E16];
+  frag_t mg[ROWS];
+  bool live[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int p = p0 + rr + i * rp;
+    live[i] = rr < rp && p < a.S;
+    if (live[i]) mg[i] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + ((long)clip * a.S + p) * a.ld_mod + cg * E16);
+#pragma unroll
+    for (int e = 0; e < E16; ++e) { adg[i][e] = 0.f; adb[i][e] = 0.f; }
+  }
+#pragma unroll 1
+  for (int t = 0; t < frames; ++t) {
+    const int n = t * clips + clip;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int g = c / cpg;
+      lds[c] = a.stats[((long)n * a.G + g) * 2]; lds[C + c] = a.stats[((long)n * a.G + g) * 2 + 1];
+      lds[4 * C + c] = a.gsum[((long)n * a.G + g) * 2] * inv_cnt; lds[5 * C + c] = a.gsum[((long)n * a.G + g) * 2 + 1] * inv_cnt;
+    }
+    __syncthreads();
+    frag_t gy[ROWS], xv[ROWS], yv[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      if (!live[i]) continue;
+      const long m = (long)n * a.S + p0 + rr + i * rp;
+      gy[i] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.dy) + m * a.lddy + cg * E16);
+      xv[i] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
+      if (a.act != IPOKE_ACT_NONE) yv[i] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      if (!live[i]) continue;
+      const long m = (long)n * a.S + p0 + rr + i * rp;
+      frag_t odx, odw;
+#pragma unroll
+      for (int e = 0; e < E16; ++e) {
+        const int c = cg * E16 + e;
+        float dw = ET<T>::to_f32(gy[i][e]);
+        if (a.act != IPOKE_ACT_NONE) dw *= act_grad_from_out(a.act, ET<T>::to_f32(yv[i][e]));
+        const float xh = (ET<T>::to_f32(xv[i][e]) - lds[c]) * lds[C + c];
+        const float du = dw * (1.f + ET<T>::to_f32(mg[i][e]));
+        adg[i][e] += dw * (xh * lds[2 * C + c] + lds[3 * C + c]);
+        adb[i][e] += dw;
+        odw[e] = ET<T>::from_f32(dw);
+        odx[e] = ET<T>::from_f32(lds[C + c] * (du * lds[2 * C + c] - (lds[4 * C + c] + xh * lds[5 * C + c])));
+      }
+      *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dx) + m * a.lddx + cg * E16) = odx;
+      if (a.dres) *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dres) + m * a.lddres + cg * E16) = odw;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    if (!live[i]) continue;
+    const long m = (long)clip * a.S + p0 + rr + i * rp;
+    frag_t og, ob;
+#pragma unroll
+    for (int e = 0; e < E16; ++e) { og[e] = ET<T>::from_f32(adg[i][e]); ob[e] = ET<T>::from_f32(adb[i][e]); }
+    *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dmg) + m * a.ld_dmod + cg * E16) = og;
+    *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.dmb) + m * a.ld_dmod + cg * E16) = ob;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- ConvGRU backward
 // update: h' = h*(1-u) + tanh(o_pre)*u
 template <typename T>
@@ -505,6 +586,15 @@ extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void
   hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(d->N + (d->dgamma ? (d->C + 15) / 16 : 0)), dim3(256), 0, s, a, d->dgamma, d->dbeta);
   IPK_LAUNCH_CHECK();
   const size_t lds = (size_t)6 * d->C * sizeof(float);
+  if (d->dmod_summed && a.mod_N > 0) {
+    IPK_REQUIRE(d->mod_gamma && !d->rs_scale && d->N % a.mod_N == 0 && d->C / e16 <= 256, "summed modulation gradients: whole frames of modulated samples");
+    const int ppb = (16 / e16) * (256 / (d->C / e16));
+    DISPATCH_T(dtype,
+      hipLaunchKernelGGL(gn_bwd_apply_frames_kernel<bf16_t>, dim3((d->S + ppb - 1) / ppb, a.mod_N), dim3(256), lds, s, a),
+      hipLaunchKernelGGL(gn_bwd_apply_frames_kernel<float>, dim3((d->S + ppb - 1) / ppb, a.mod_N), dim3(256), lds, s, a));
+    IPK_LAUNCH_CHECK();
+    return IPOKE_OK;
+  }
   if (d->rs_scale) {
     IPK_REQUIRE(!d->mod_gamma && d->rs_dots && d->rs_workspace && d->rs_rows_per_group >= d->S && d->rs_rows_per_group % d->S == 0 &&
                 ((int64_t)d->N * d->S) % d->rs_rows_per_group == 0 && d->C <= 2048, "folded row-scale pass: whole frames of un-modulated samples");

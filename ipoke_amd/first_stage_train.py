@@ -766,14 +766,19 @@ class _NormFn(torch.autograd.Function):
             dres = torch.zeros_like(x_t) if x_t.shape[1] > C else torch.empty_like(x_t)
             d.dres = dres.data_ptr(); d.lddres = dres.shape[1]
         mod_n = int(m.get("mod_samples", 0)) if has_mod else 0
+        summed = False
         if has_mod:
             # the kernel writes columns 0 .. C-1 of every row; only padding columns (ld > C) need the zero fill
             alloc = torch.zeros if mg_t.shape[1] > C else torch.empty
-            rows_mod = x_t.shape[0] if mod_n else mg_t.shape[0]      # mod_n: per-frame modulation gradients [frames][clips * S][ld], summed over the frames below
+            # mod_n: the frames of a clip share its maps -- the kernel walks the frames and writes the sum (_NORM_FRAMES_SUM), or writes
+            # per-frame gradients [frames][clips * S][ld] that ipoke_sum_frames adds below
+            summed = bool(mod_n) and _NORM_FRAMES_SUM and mod_n < N
+            rows_mod = x_t.shape[0] if (mod_n and not summed) else mg_t.shape[0]
             dmg = alloc(rows_mod, mg_t.shape[1], dtype=mg_t.dtype, device=mg_t.device)
             dmb = alloc(rows_mod, mg_t.shape[1], dtype=mg_t.dtype, device=mg_t.device)
             d.dmod_gamma = dmg.data_ptr(); d.dmod_beta = dmb.data_ptr(); d.ld_dmod = dmg.shape[1]
             d.mod_gamma = mg_t.data_ptr(); d.ld_mod = mg_t.shape[1]; d.mod_samples = mod_n
+            d.dmod_summed = int(summed)
         if has_affine:
             dgamma = torch.empty(C, dtype=torch.float32, device=dy.device); dbeta = torch.empty_like(dgamma)
             d.gamma = g32.data_ptr(); d.beta = b32.data_ptr(); d.dgamma = dgamma.data_ptr(); d.dbeta = dbeta.data_ptr()
@@ -794,7 +799,7 @@ class _NormFn(torch.autograd.Function):
             d.rs_dots = rs_dots.data_ptr(); d.rs_dbias = 0 if rs_db is None else rs_db.data_ptr(); d.rs_workspace = rs_ws.data_ptr()
             pm["_prescaled"] = (dx, rs_dots, rs_db)
         check(_lib.lib().ipoke_groupnorm_bwd(byref(d), ops._dt(dt), _lib.current_stream()))
-        if mod_n:
+        if mod_n and not summed:
             frames = N // mod_n
             outs = []
             for t_ in (dmg, dmb):
@@ -806,6 +811,7 @@ class _NormFn(torch.autograd.Function):
 
 
 _NORM_RS = os.environ.get("IPOKE_NORM_ROWSCALE", "1") != "0"      # developer A/B: the convolution's own ipoke_rowscale_bwd pass instead
+_NORM_FRAMES_SUM = os.environ.get("IPOKE_NORM_FRAMES_SUM", "1") != "0"      # developer A/B: per-frame modulation gradients + ipoke_sum_frames
 
 
 def _rowscale_producer(x, mod):

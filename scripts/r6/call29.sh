@@ -1,0 +1,8 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06; mkdir -p $O; cd /tmp
+export TMPDIR=/tmp
+for v in 1 0; do
+IPOKE_NORM_FRAMES_SUM=$v rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4_$v -- python $R/bench.py --config c4 --steps 8 --warmup 3 --no-cpu-baseline > $O/c29_trace_$v.log 2>&1
+T=$(find /tmp/p_c4_$v -name "*kernel_trace.csv" | head -1)
+python $R/scripts/trace_steady.py $T reparam_kernel 6 > $O/c29_c4_steady_$v.txt 2>&1
+python $R/scripts/trace_by_grid.py $T gn_bwd_apply > $O/c29_grid_$v.txt 2>&1
+done

@@ -338,3 +338,68 @@ def test_norm_backward_folds_the_row_scale_pass(case, dtype):
     e_db = (db0 - db1).abs().max().item()
     print(f"norm bwd + row scale {name}[{dtype}]: dots {dots0.tolist()} diff {e_dot:.2e} (yard {yard_d:.2e}), dbias diff {e_db:.2e}")
     assert e_dot <= yard_d and e_db <= 1e-3 * max(1.0, db0.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [("c64", 5, 3, 64, 24), ("c256", 4, 2, 256, 8), ("c96_ragged", 3, 2, 96, 9)], ids=lambda c: c[0])
+def test_norm_backward_sums_the_shared_modulation_gradients_over_the_frames(case, dtype):
+    """ipoke_norm_bwd_desc.dmod_summed: samples ordered (frame, clip) share the clip's SPADE maps; the backward pass walks the frames and
+    writes d(mod_gamma), d(mod_beta) once per clip.  dx is bit-identical to the per-sample form; the summed maps are compared with float64
+    arithmetic on the same inputs -- and must be at least as close as the per-sample form + ipoke_sum_frames (which rounds every frame's
+    term to the storage type before adding)."""
+    from ipoke_amd._lib import NormBwdDesc, NormDesc
+    name, frames, clips, C, H = case
+    N, S, G = frames * clips, H * H, 16 if C % 16 == 0 else 8
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    gen = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(N * S, C, generator=gen) * 1.3 + 0.2).to(td).to(DEV)
+    dy = torch.randn(N * S, C, generator=gen).to(td).to(DEV)
+    mg = (0.5 * torch.randn(clips * S, C, generator=gen)).to(td).to(DEV)
+    mb = (0.5 * torch.randn(clips * S, C, generator=gen)).to(td).to(DEV)
+    L = _lib.lib()
+    s = _lib.current_stream()
+    y = torch.empty_like(x)
+    fd = NormDesc()
+    fd.x = x.data_ptr(); fd.ldx = C; fd.y = y.data_ptr(); fd.ldy = C; fd.N, fd.S, fd.C, fd.G, fd.eps = N, S, C, G, 1e-5
+    fd.mod_gamma = mg.data_ptr(); fd.mod_beta = mb.data_ptr(); fd.ld_mod = C; fd.mod_samples = clips; fd.act = _lib.ACT_NONE
+    ws_f = torch.empty(int(L.ipoke_groupnorm_workspace_floats(N, S, G)), device=DEV)
+    fd.workspace = ws_f.data_ptr()
+    _lib.check(L.ipoke_groupnorm(byref(fd), _lib.DTYPES[dtype], s))
+
+    def run(summed):
+        dx = torch.full_like(x, 3.0)
+        rows = clips * S if summed else N * S
+        dmg = torch.empty(rows, C, dtype=td, device=DEV); dmb = torch.empty(rows, C, dtype=td, device=DEV)
+        d = NormBwdDesc()
+        d.x = x.data_ptr(); d.ldx = C; d.y = y.data_ptr(); d.ldy = C; d.dy = dy.data_ptr(); d.lddy = C; d.dx = dx.data_ptr(); d.lddx = C
+        d.N, d.S, d.C, d.G, d.eps = N, S, C, G, 1e-5
+        d.act = _lib.ACT_NONE
+        d.dmod_gamma = dmg.data_ptr(); d.dmod_beta = dmb.data_ptr(); d.ld_dmod = C
+        d.mod_gamma = mg.data_ptr(); d.ld_mod = C; d.mod_samples = clips; d.dmod_summed = int(summed)
+        ws = torch.empty(int(L.ipoke_groupnorm_bwd_workspace_floats(N, S, C, G)), device=DEV)
+        d.workspace = ws.data_ptr()
+        _lib.check(L.ipoke_groupnorm_bwd(byref(d), _lib.DTYPES[dtype], s))
+        if not summed:
+            outs = []
+            for t_ in (dmg, dmb):
+                red = torch.empty(clips * S, C, dtype=td, device=DEV)
+                _lib.check(L.ipoke_sum_frames(t_.data_ptr(), red.data_ptr(), frames, red.numel(), _lib.DTYPES[dtype], s))
+                outs.append(red)
+            dmg, dmb = outs
+        torch.cuda.synchronize()
+        return dx, dmg, dmb
+
+    dx0, dmg0, dmb0 = run(False)
+    dx1, dmg1, dmb1 = run(True)
+    assert torch.equal(dx0, dx1)
+    x64 = x.double().view(N, S, G, C // G)
+    mean = x64.mean(dim=(1, 3), keepdim=True)
+    var = x64.var(dim=(1, 3), unbiased=False, keepdim=True)
+    xh = ((x64 - mean) / torch.sqrt(var + 1e-5)).view(frames, clips * S, C)
+    dw = dy.double().view(frames, clips * S, C)
+    want_g, want_b = (dw * xh).sum(0), dw.sum(0)
+    e = lambda got, want: ((got.double() - want).abs().max() / want.abs().max()).item()
+    e1g, e1b, e0g, e0b = e(dmg1, want_g), e(dmb1, want_b), e(dmg0, want_g), e(dmb0, want_b)
+    print(f"summed modulation gradients {name}[{dtype}]: d gamma {e1g:.2e} (per-sample form {e0g:.2e}), d beta {e1b:.2e} ({e0b:.2e})")
+    tol = 2e-5 if dtype == "f32" else 4e-3
+    assert e1g <= tol and e1b <= tol and e1g <= e0g * 1.05 + 1e-7 and e1b <= e0b * 1.05 + 1e-7
