@@ -534,7 +534,7 @@ void* ipoke_flow_side_stream(ipoke_flow* f);
  * First-stage VAE helpers on channels-last activations [N][S][ld] of dtype.
  * ------------------------------------------------------------------------------------------- */
 /* GroupNorm (InstanceNorm: G = C, no affine) fused with affine / SPADE modulation / residual / activation:
- *   y = act( xhat * gamma + beta  [ * (1 + mod_gamma) + mod_beta ]  [ + res ] )
+ *   y = act( xhat * gamma + beta  [ * (1 + mod_gamma) + mod_beta ]  [ + res ] )      (res_post: act( ... ) + res)
  * Replaces nn.GroupNorm / nn.InstanceNorm2d call sites: motion_encoder.py:49-72, autoencoders/util.py:26-36,
  * 223-233 and Spade.forward util.py:494-500. */
 typedef struct {
@@ -548,6 +548,9 @@ typedef struct {
   int32_t mod_samples;                                   /* > 0: mod_gamma / mod_beta hold mod_samples samples and sample n reads those of
                                                             sample n % mod_samples (all generated frames of a clip share the SPADE maps of
                                                             its start frame: the frames are decoded as ONE batch ordered (frame, clip)) */
+  int32_t res_post;                                      /* 1: y = act( ... ) + res -- the residual joins BEHIND the activation: ResBlock's
+                                                            `conv2(conv1(x)) + res_conv(x)` (util.py:106-192) with the norm + activation of
+                                                            res_conv as this call and conv2's output as `res`, one pass instead of two */
 } ipoke_norm_desc;
 int64_t ipoke_groupnorm_workspace_floats(int N, int S, int G);
 int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream);

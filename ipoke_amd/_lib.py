@@ -112,7 +112,8 @@ class NormDesc(Structure):
                 ("N", c_int32), ("S", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
                 ("gamma", c_void_p), ("beta", c_void_p),
                 ("mod_gamma", c_void_p), ("mod_beta", c_void_p), ("ld_mod", c_int32),
-                ("res", c_void_p), ("ld_res", c_int32), ("act", c_int32), ("workspace", c_void_p), ("mod_samples", c_int32)]
+                ("res", c_void_p), ("ld_res", c_int32), ("act", c_int32), ("workspace", c_void_p), ("mod_samples", c_int32),
+                ("res_post", c_int32)]
 
 
 class SnJob(Structure):

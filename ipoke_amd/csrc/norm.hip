@@ -35,6 +35,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     for (int e = 0; e < E16; ++e) { s[e] = 0.f; q[e] = 0.f; }
     if (rr < rp) {
       int p = p0 + rr;
+      for (; p + 3 * rp < p1; p += 4 * rp) {        // four rows per trip (round 6; same sums in the same order as two trips of two)
+        const frag_t a = *reinterpret_cast<const frag_t*>(xb + (long)p * ldx + (g0 + cg) * E16);
+        const frag_t b = *reinterpret_cast<const frag_t*>(xb + (long)(p + rp) * ldx + (g0 + cg) * E16);
+        const frag_t c = *reinterpret_cast<const frag_t*>(xb + (long)(p + 2 * rp) * ldx + (g0 + cg) * E16);
+        const frag_t d = *reinterpret_cast<const frag_t*>(xb + (long)(p + 3 * rp) * ldx + (g0 + cg) * E16);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) {
+          const float fa = ET<T>::to_f32(a[e]), fb = ET<T>::to_f32(b[e]), fc = ET<T>::to_f32(c[e]), fd = ET<T>::to_f32(d[e]);
+          s[e] += fa + fb; q[e] += fa * fa + fb * fb;
+          s[e] += fc + fd; q[e] += fc * fc + fd * fd;
+        }
+      }
       for (; p + rp < p1; p += 2 * rp) {            // two rows per trip: both loads in flight
         const frag_t a = *reinterpret_cast<const frag_t*>(xb + (long)p * ldx + (g0 + cg) * E16);
         const frag_t b = *reinterpret_cast<const frag_t*>(xb + (long)(p + rp) * ldx + (g0 + cg) * E16);
@@ -140,8 +152,9 @@ struct NormApply {
   const float* gamma; const float* beta;      // [C] affine or NULL
   const void* mod_gamma; const void* mod_beta; int ld_mod;   // SPADE: T [N*S][ld_mod]; y = xhat*(1+mg)+mb
   int mod_N;                       // > 0: the modulation maps hold mod_N samples, sample n reads those of n % mod_N
-  const void* res; int ld_res;     // optional residual added before the activation
+  const void* res; int ld_res;     // optional residual added before the activation (res_post: behind it)
   int act;
+  int res_post = 0;
   int pos_per_block;
   float* stats_out = nullptr;      // gn_fused_kernel: [N][G][2] (mean, rstd), kept for the backward pass
 };
@@ -187,8 +200,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
       for (int e = 0; e < E16; ++e) {
         float f = ET<T>::to_f32(v[e]) * sc[e] + sh[e];
         if (a.mod_gamma) f = f * (1.f + ET<T>::to_f32(mg[e])) + ET<T>::to_f32(mb[e]);
-        if (a.res) f += ET<T>::to_f32(r[e]);
+        if (a.res && !a.res_post) f += ET<T>::to_f32(r[e]);
         o[e] = act_apply(a.act, f);
+        if (a.res && a.res_post) o[e] += ET<T>::to_f32(r[e]);
       }
       if (a.y_f32) {
         float* yp = reinterpret_cast<float*>(a.y) + m * a.ldy + cc * E16;
@@ -316,8 +330,10 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const NormApply a, int CS
 #pragma unroll
       for (int e = 0; e < E16; ++e) {
         float f = ET<T>::to_f32(v[e]) * sc[e] + sh[e];
-        if (a.res) f += ET<T>::to_f32(r[u][e]);
-        w[e] = ET<T>::from_f32(act_apply(a.act, f));
+        if (a.res && !a.res_post) f += ET<T>::to_f32(r[u][e]);
+        f = act_apply(a.act, f);
+        if (a.res && a.res_post) f += ET<T>::to_f32(r[u][e]);
+        w[e] = ET<T>::from_f32(f);
       }
       *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.y) + m * a.ldy + c0 + cc * E16) = w;
     }
@@ -528,7 +544,7 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
       NormApply a;
       a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.y_f32 = 0; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
       a.stats = nullptr; a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = nullptr; a.mod_beta = nullptr; a.ld_mod = 0; a.mod_N = 0;
-      a.res = d->res; a.ld_res = d->ld_res; a.act = d->act; a.pos_per_block = 0; a.stats_out = stats;
+      a.res = d->res; a.ld_res = d->ld_res; a.act = d->act; a.pos_per_block = 0; a.stats_out = stats; a.res_post = d->res_post;
       if (dtype == IPOKE_BF16) {
         static bool attr_bf = false;
         if (!attr_bf) { IPK_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_bf = true; }
@@ -551,7 +567,7 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
   NormApply a;
   a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.y_f32 = d->y_f32; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
   a.stats = stats; a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = d->mod_gamma; a.mod_beta = d->mod_beta; a.ld_mod = d->ld_mod;
-  a.res = d->res; a.ld_res = d->ld_res; a.act = d->act;
+  a.res = d->res; a.ld_res = d->ld_res; a.act = d->act; a.res_post = d->res_post;
   a.mod_N = d->mod_samples > 0 && d->mod_samples < d->N ? d->mod_samples : 0;
   a.pos_per_block = 256;
   const int achunks = (d->S + a.pos_per_block - 1) / a.pos_per_block;

@@ -152,12 +152,13 @@ class _Norm(nn.Module):
         else:                      # "in": InstanceNorm2d(affine=False)
             self.groups = ch
 
-    def run(self, x, dtype, act=_lib.ACT_NONE, res=None):
+    def run(self, x, dtype, act=_lib.ACT_NONE, res=None, res_post=False):
         if self.kind == "group":
-            return K.group_norm(x, self.groups, dtype, self.weight.detach(), self.bias.detach(), act=act, res=res)
-        return K.group_norm(x, self.groups, dtype, act=act, res=res)
+            return K.group_norm(x, self.groups, dtype, self.weight.detach(), self.bias.detach(), act=act, res=res, res_post=res_post)
+        return K.group_norm(x, self.groups, dtype, act=act, res=res, res_post=res_post)
 
 
+_RES_POST = os.environ.get("IPOKE_NO_RES_POST", "0") != "1"         # developer A/B: ResBlock's sum as its own element-wise pass
 _STEM_FOLD = os.environ.get("IPOKE_NO_STEM_FOLD", "0") != "1"      # developer A/B: conv1 of the 3-D encoder read in place
 _CT_PHASES = os.environ.get("IPOKE_NO_CT_PHASES", "0") != "1"       # developer A/B: stride-2 ConvTranspose2d as one 9-tap launch
 _DEPTH1_SLICE = os.environ.get("IPOKE_NO_DEPTH1_SLICE", "0") != "1"  # developer A/B: 3 x 3 x 3 filters on depth-1 inputs run all 27 taps
@@ -417,7 +418,14 @@ class ResBlock(nn.Module):
                 self.res_conv = Conv2dBlock(cin, cout, 3, stride, 1, norm="in", activation=activation, snorm=snorm)
 
     def run(self, x, dtype):
-        res = self.res_conv.run(x, dtype) if self.convolve_res else x
+        rc = self.res_conv if self.convolve_res else None
+        if (_RES_POST and rc is not None and rc.norm is not None and self.conv2.norm is None and self.conv2.activation == "none"):
+            # out = conv2(conv1(x)) + act(norm(res_conv(x))): the sum rides on the skip path's norm pass (the residual joins behind its
+            # activation) instead of being a pass of its own over three tensors of the block's output size
+            y2 = self.conv2.run(self.conv1.run(x, dtype), dtype)
+            act = rc.act if isinstance(rc, Conv2dTransposeBlock) else ACT[rc.activation]
+            return rc.norm.run(rc.conv.run(x, dtype), dtype, act=act, res=y2, res_post=True)
+        res = rc.run(x, dtype) if rc is not None else x
         return self.conv2.run(self.conv1.run(x, dtype), dtype, res=res)
 
 

@@ -127,8 +127,9 @@ def _workspace(N, S, G, device):
     return buf
 
 
-def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None, eps=1e-5):
-    """y = act(GN(x)*gamma+beta [*(1+mod_gamma)+mod_beta] [+res]); InstanceNorm = groups == C, no affine."""
+def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None, eps=1e-5, res_post=False):
+    """y = act(GN(x)*gamma+beta [*(1+mod_gamma)+mod_beta] [+res]); InstanceNorm = groups == C, no affine.  ``res_post``: the residual
+    joins behind the activation, y = act(...) + res."""
     y = torch.empty_like(x.t)
     d = NormDesc()
     d.x = x.t.data_ptr(); d.ldx = x.t.shape[1]; d.y = y.data_ptr(); d.ldy = y.shape[1]; d.y_f32 = 0
@@ -140,7 +141,7 @@ def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=N
             assert x.N % mod[0].N == 0 and mod[0].S == x.S
             d.mod_samples = mod[0].N
     if res is not None:
-        d.res = res.t.data_ptr(); d.ld_res = res.t.shape[1]
+        d.res = res.t.data_ptr(); d.ld_res = res.t.shape[1]; d.res_post = int(bool(res_post))
     d.act = act
     ws = _workspace(x.N, x.S, groups, x.t.device)
     d.workspace = ws.data_ptr()

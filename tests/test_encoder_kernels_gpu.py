@@ -49,6 +49,28 @@ def test_groupnorm_small_maps_vs_torch(case, dtype):
     assert err <= (2e-5 if dtype == "f32" else 4e-2) * max(1.0, y.abs().max().item()), err
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(3, 64, 16, 16, 0, "relu"), (2, 64, 96, 96, 0, "relu"), (2, 128, 64, 64, 16, "elu")],
+                         ids=["inst_small", "inst_large", "group_large"])
+def test_groupnorm_residual_behind_the_activation(case, dtype):
+    """ipoke_norm_desc.res_post: y = act(norm(x)) + res -- ResBlock's sum riding on the skip path's norm pass (util.py:106-192); the
+    one-launch kernel of small maps and the stats / apply pair of large ones."""
+    N, C, H, W, G, act = case
+    gen = torch.Generator().manual_seed(C + H)
+    x = 2.0 * torch.randn(N, C, H, W, generator=gen) + 0.7
+    res = torch.randn(N, C, H, W, generator=gen)
+    groups = C if G == 0 else G
+    xc, rc = K.from_nchw(x.to(DEV), dtype), K.from_nchw(res.to(DEV), dtype)
+    xr, rr = K.to_nchw(xc, dtype).cpu(), K.to_nchw(rc, dtype).cpu()
+    y = {"relu": torch.relu, "elu": F.elu}[act](F.group_norm(xr, groups, eps=1e-5)) + rr
+    actc = {"relu": _lib.ACT_RELU, "elu": _lib.ACT_ELU}[act]
+    got = K.to_nchw(K.group_norm(xc, groups, dtype, act=actc, res=rc, res_post=True), dtype).cpu()
+    err = (got - y).abs().max().item()
+    assert err <= (2e-5 if dtype == "f32" else 4e-2) * max(1.0, y.abs().max().item()), err
+    pre = K.to_nchw(K.group_norm(xc, groups, dtype, act=actc, res=rc), dtype).cpu()          # the other order is a different function
+    assert (pre - y).abs().max().item() > 0.1
+
+
 def test_clip_to_cl4():
     gen = torch.Generator().manual_seed(3)
     B, T, H, W = 2, 3, 6, 10
