@@ -551,6 +551,12 @@ typedef struct {
   int32_t res_post;                                      /* 1: y = act( ... ) + res -- the residual joins BEHIND the activation: ResBlock's
                                                             `conv2(conv1(x)) + res_conv(x)` (util.py:106-192) with the norm + activation of
                                                             res_conv as this call and conv2's output as `res`, one pass instead of two */
+  /* statistics handed from one norm to the next (the SPADE norm behind such a ResBlock): the producer call also writes the chunk
+   * statistics (count, mean, M2 per (sample, chunk of 256 positions, group of next_G groups)) of its OUTPUT to next_part --
+   * ipoke_groupnorm_workspace_floats(N, S, next_G) floats, which the consumer call then passes as ITS workspace with
+   * part_chunks = ceil(S / 256): its own statistics pass over the tensor is skipped */
+  float* next_part; int32_t next_G;
+  int32_t part_chunks;
 } ipoke_norm_desc;
 int64_t ipoke_groupnorm_workspace_floats(int N, int S, int G);
 int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream);

@@ -113,7 +113,7 @@ class NormDesc(Structure):
                 ("gamma", c_void_p), ("beta", c_void_p),
                 ("mod_gamma", c_void_p), ("mod_beta", c_void_p), ("ld_mod", c_int32),
                 ("res", c_void_p), ("ld_res", c_int32), ("act", c_int32), ("workspace", c_void_p), ("mod_samples", c_int32),
-                ("res_post", c_int32)]
+                ("res_post", c_int32), ("next_part", c_void_p), ("next_G", c_int32), ("part_chunks", c_int32)]
 
 
 class SnJob(Structure):

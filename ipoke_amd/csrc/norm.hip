@@ -155,17 +155,23 @@ struct NormApply {
   const void* res; int ld_res;     // optional residual added before the activation (res_post: behind it)
   int act;
   int res_post = 0;
+  float* next_part = nullptr; int next_G = 0;      // gn_apply_kernel<T, true>: chunk statistics (count, mean, M2) of the OUTPUT for a following norm
   int pos_per_block;
   float* stats_out = nullptr;      // gn_fused_kernel: [N][G][2] (mean, rstd), kept for the backward pass
 };
 // grid (chunks, N): a block normalises pos_per_block positions of ONE sample, so the per-channel scale / shift
 // (rstd*gamma, beta - mean*rstd*gamma) are built once in LDS and the inner loop is one FMA per element, no divisions.
-template <typename T>
+// NEXT (round 6): the pass also leaves the chunk statistics of its (rounded) output in gn_stats_kernel's layout -- the norm that reads
+// this output next (the SPADE norm behind a ResBlock whose sum this pass carries, res_post) starts at gn_finalize: one read of the
+// tensor less.  Chunk = this pass's block of positions; one pass of 256 threads over the channels (C <= 256 * E16).
+template <typename T, bool NEXT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
   if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormApply)>();
   constexpr int E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
-  __shared__ float sscale[4096], sshift[4096];
+  __shared__ float sscale[NEXT ? 2048 : 4096], sshift[NEXT ? 2048 : 4096];
+  __shared__ float nsm[NEXT ? 2 : 1][NEXT ? 256 * E16 : 1];
+  __shared__ float ntot[NEXT ? 2 : 1][NEXT ? 2048 : 1];
   const int n = blockIdx.y;
   const int cpg = a.C / a.G;
   for (int c = threadIdx.x; c < a.C; c += 256) {
@@ -181,10 +187,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
     const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
     const int rp = 256 / groups;
     const int cc = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
-    if (rr >= rp) continue;
-    float sc[E16], sh[E16];
+    if (!NEXT && rr >= rp) continue;
+    float sc[E16], sh[E16], ns[E16], nq[E16];
 #pragma unroll
-    for (int e = 0; e < E16; ++e) { sc[e] = sscale[cc * E16 + e]; sh[e] = sshift[cc * E16 + e]; }
+    for (int e = 0; e < E16; ++e) { sc[e] = sscale[cc * E16 + e]; sh[e] = sshift[cc * E16 + e]; ns[e] = 0.f; nq[e] = 0.f; }
+    if (rr < rp)
     for (int p = p0 + rr; p < p1; p += rp) {
       const long m = (long)n * a.S + p;
       const frag_t v = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cc * E16);
@@ -211,9 +218,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const NormApply a) {
       } else {
         frag_t w;
 #pragma unroll
-        for (int e = 0; e < E16; ++e) w[e] = ET<T>::from_f32(o[e]);
+        for (int e = 0; e < E16; ++e) {
+          w[e] = ET<T>::from_f32(o[e]);
+          if (NEXT) { const float fv = ET<T>::to_f32(w[e]); ns[e] += fv; nq[e] += fv * fv; }
+        }
         *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(a.y) + m * a.ldy + cc * E16) = w;
       }
+    }
+    if (NEXT) {
+#pragma unroll
+      for (int e = 0; e < E16; ++e) {
+        nsm[0][threadIdx.x * E16 + e] = rr < rp ? ns[e] : 0.f;
+        nsm[1][threadIdx.x * E16 + e] = rr < rp ? nq[e] : 0.f;
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < groups * E16; i += 256) {
+        const int cgi = i / E16, e = i - cgi * E16;
+        float ts = 0.f, tq = 0.f;
+        for (int k = 0; k < rp; ++k) { ts += nsm[0][(k * groups + cgi) * E16 + e]; tq += nsm[1][(k * groups + cgi) * E16 + e]; }
+        ntot[0][cgi * E16 + e] = ts; ntot[1][cgi * E16 + e] = tq;
+      }
+      __syncthreads();
+    }
+  }
+  if (NEXT) {
+    const int cpgn = a.C / a.next_G;
+    for (int g = threadIdx.x; g < a.next_G; g += 256) {
+      float s_ = 0.f, q_ = 0.f;
+      for (int c = 0; c < cpgn; ++c) { s_ += ntot[0][g * cpgn + c]; q_ += ntot[1][g * cpgn + c]; }
+      const float cnt = (float)(p1 - p0) * cpgn;
+      const float mean = cnt > 0 ? s_ / cnt : 0.f;
+      float m2 = q_ - s_ * mean;
+      if (m2 < 0.f) m2 = 0.f;
+      float* o = a.next_part + (((long)n * gridDim.x + blockIdx.x) * a.next_G + g) * 3;
+      o[0] = cnt; o[1] = mean; o[2] = m2;
     }
   }
 }
@@ -525,6 +563,9 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
   IPK_REQUIRE(d->C % e16 == 0 && d->C % d->G == 0 && d->C <= 4096, "channels must be a multiple of 16 bytes and of the group count");
   IPK_REQUIRE(d->ldx % e16 == 0 && d->ldy % (d->y_f32 ? 1 : e16) == 0, "pitches must keep 16-byte alignment");
   IPK_REQUIRE((d->gamma == nullptr) == (d->beta == nullptr) && (d->mod_gamma == nullptr) == (d->mod_beta == nullptr), "affine pairs");
+  IPK_REQUIRE(!d->next_part || (d->next_G >= 1 && d->C % d->next_G == 0 && !d->y_f32 && d->C <= 2048 && d->C / e16 <= 256),
+              "statistics for a following norm: a dtype output of at most 2048 channels, whole groups");
+  IPK_REQUIRE(d->part_chunks >= 0 && (d->part_chunks == 0 || d->part_chunks <= (d->S + 127) / 128), "chunk statistics must fit the workspace");
   const int ppb = 128;
   const int nchunks = (d->S + ppb - 1) / ppb;
   float* part = d->workspace;
@@ -555,14 +596,25 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
         hipLaunchKernelGGL(gn_fused_kernel<float>, dim3(d->C / CS, d->N), dim3(256), tile, s, a, CS, d->eps);
       }
       IPK_LAUNCH_CHECK();
+      if (d->next_part) {                 // the one-launch kernel owns channel slabs, not position chunks: the output's statistics as a pass
+        const int nppb = 256, nnch = (d->S + nppb - 1) / nppb;
+        DISPATCH_T(dtype,
+          hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nnch, d->N), dim3(256), 0, s, (const bf16_t*)d->y, d->S, d->ldy, d->C, d->next_G, nppb, d->next_part),
+          hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nnch, d->N), dim3(256), 0, s, (const float*)d->y, d->S, d->ldy, d->C, d->next_G, nppb, d->next_part));
+        IPK_LAUNCH_CHECK();
+      }
       return IPOKE_OK;
     }
   }
-  DISPATCH_T(dtype,
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, d->N), dim3(256), 0, s, (const bf16_t*)d->x, d->S, d->ldx, d->C, d->G, ppb, part),
-    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, d->N), dim3(256), 0, s, (const float*)d->x, d->S, d->ldx, d->C, d->G, ppb, part));
-  IPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->N, (d->G + 15) / 16), dim3(256), 0, s, part, nchunks, d->G, d->eps, stats);
+  if (d->part_chunks > 0) {               // the producer of x left its chunk statistics in the workspace (next_part of that call)
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->N, (d->G + 15) / 16), dim3(256), 0, s, part, d->part_chunks, d->G, d->eps, stats);
+  } else {
+    DISPATCH_T(dtype,
+      hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(nchunks, d->N), dim3(256), 0, s, (const bf16_t*)d->x, d->S, d->ldx, d->C, d->G, ppb, part),
+      hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, d->N), dim3(256), 0, s, (const float*)d->x, d->S, d->ldx, d->C, d->G, ppb, part));
+    IPK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->N, (d->G + 15) / 16), dim3(256), 0, s, part, nchunks, d->G, d->eps, stats);
+  }
   IPK_LAUNCH_CHECK();
   NormApply a;
   a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.y_f32 = d->y_f32; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
@@ -571,9 +623,17 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
   a.mod_N = d->mod_samples > 0 && d->mod_samples < d->N ? d->mod_samples : 0;
   a.pos_per_block = 256;
   const int achunks = (d->S + a.pos_per_block - 1) / a.pos_per_block;
+  if (d->next_part) {
+    a.next_part = d->next_part; a.next_G = d->next_G;
+    DISPATCH_T(dtype,
+      hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), dim3(achunks, d->N), dim3(256), 0, s, a),
+      hipLaunchKernelGGL((gn_apply_kernel<float, true>), dim3(achunks, d->N), dim3(256), 0, s, a));
+    IPK_LAUNCH_CHECK();
+    return IPOKE_OK;
+  }
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(achunks, d->N), dim3(256), 0, s, a),
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(achunks, d->N), dim3(256), 0, s, a));
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t, false>), dim3(achunks, d->N), dim3(256), 0, s, a),
+    hipLaunchKernelGGL((gn_apply_kernel<float, false>), dim3(achunks, d->N), dim3(256), 0, s, a));
   IPK_LAUNCH_CHECK();
   return IPOKE_OK;
 }

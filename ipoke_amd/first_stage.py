@@ -152,13 +152,15 @@ class _Norm(nn.Module):
         else:                      # "in": InstanceNorm2d(affine=False)
             self.groups = ch
 
-    def run(self, x, dtype, act=_lib.ACT_NONE, res=None, res_post=False):
+    def run(self, x, dtype, act=_lib.ACT_NONE, res=None, res_post=False, next_groups=None):
         if self.kind == "group":
-            return K.group_norm(x, self.groups, dtype, self.weight.detach(), self.bias.detach(), act=act, res=res, res_post=res_post)
-        return K.group_norm(x, self.groups, dtype, act=act, res=res, res_post=res_post)
+            return K.group_norm(x, self.groups, dtype, self.weight.detach(), self.bias.detach(), act=act, res=res, res_post=res_post,
+                                next_groups=next_groups)
+        return K.group_norm(x, self.groups, dtype, act=act, res=res, res_post=res_post, next_groups=next_groups)
 
 
 _RES_POST = os.environ.get("IPOKE_NO_RES_POST", "0") != "1"         # developer A/B: ResBlock's sum as its own element-wise pass
+_NEXT_STATS = os.environ.get("IPOKE_NO_NEXT_STATS", "0") != "1"     # developer A/B: the SPADE norm makes its own statistics pass
 _STEM_FOLD = os.environ.get("IPOKE_NO_STEM_FOLD", "0") != "1"      # developer A/B: conv1 of the 3-D encoder read in place
 _CT_PHASES = os.environ.get("IPOKE_NO_CT_PHASES", "0") != "1"       # developer A/B: stride-2 ConvTranspose2d as one 9-tap launch
 _DEPTH1_SLICE = os.environ.get("IPOKE_NO_DEPTH1_SLICE", "0") != "1"  # developer A/B: 3 x 3 x 3 filters on depth-1 inputs run all 27 taps
@@ -417,14 +419,16 @@ class ResBlock(nn.Module):
             else:
                 self.res_conv = Conv2dBlock(cin, cout, 3, stride, 1, norm="in", activation=activation, snorm=snorm)
 
-    def run(self, x, dtype):
+    def run(self, x, dtype, next_groups=None):
+        """``next_groups``: a norm of that many groups reads the block's output next (the decoder's SPADE norm): the pass that writes
+        the output leaves its chunk statistics for it."""
         rc = self.res_conv if self.convolve_res else None
         if (_RES_POST and rc is not None and rc.norm is not None and self.conv2.norm is None and self.conv2.activation == "none"):
             # out = conv2(conv1(x)) + act(norm(res_conv(x))): the sum rides on the skip path's norm pass (the residual joins behind its
             # activation) instead of being a pass of its own over three tensors of the block's output size
             y2 = self.conv2.run(self.conv1.run(x, dtype), dtype)
             act = rc.act if isinstance(rc, Conv2dTransposeBlock) else ACT[rc.activation]
-            return rc.norm.run(rc.conv.run(x, dtype), dtype, act=act, res=y2, res_post=True)
+            return rc.norm.run(rc.conv.run(x, dtype), dtype, act=act, res=y2, res_post=True, next_groups=next_groups if _NEXT_STATS else None)
         res = rc.run(x, dtype) if rc is not None else x
         return self.conv2.run(self.conv1.run(x, dtype), dtype, res=res)
 
@@ -483,7 +487,7 @@ class SpadeCondConvDecoder(nn.Module):
         (the SPADE maps in ``mods`` are per clip and shared by the frames); the result is [clips, frames, 3, H, W]."""
         x = self.in_block.run(h, self.dtype)
         for blk, sp, mod in zip(self.blocks, self.spade_blocks, mods):
-            x = sp.run(blk.run(x, self.dtype), mod, self.dtype)
+            x = sp.run(blk.run(x, self.dtype, next_groups=sp.groups), mod, self.dtype)
         y = self.out_conv.run(x, self.dtype, out_f32=True)                     # [M][3] fp32, tanh applied
         if frames > 1:
             return y.t.view(frames, y.N // frames, y.dhw[1], y.dhw[2], 3).permute(1, 0, 4, 2, 3).contiguous()

@@ -127,9 +127,10 @@ def _workspace(N, S, G, device):
     return buf
 
 
-def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None, eps=1e-5, res_post=False):
+def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None, eps=1e-5, res_post=False, next_groups=None):
     """y = act(GN(x)*gamma+beta [*(1+mod_gamma)+mod_beta] [+res]); InstanceNorm = groups == C, no affine.  ``res_post``: the residual
-    joins behind the activation, y = act(...) + res."""
+    joins behind the activation, y = act(...) + res.  ``next_groups``: the pass also leaves the chunk statistics of y for a following
+    norm of that many groups (returned CL carries ``stats_part``); a CL with ``stats_part`` for ``groups`` skips its statistics pass."""
     y = torch.empty_like(x.t)
     d = NormDesc()
     d.x = x.t.data_ptr(); d.ldx = x.t.shape[1]; d.y = y.data_ptr(); d.ldy = y.shape[1]; d.y_f32 = 0
@@ -143,10 +144,22 @@ def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=N
     if res is not None:
         d.res = res.t.data_ptr(); d.ld_res = res.t.shape[1]; d.res_post = int(bool(res_post))
     d.act = act
-    ws = _workspace(x.N, x.S, groups, x.t.device)
+    handed = getattr(x, "stats_part", None)
+    if handed is not None and handed[0] == groups:          # the producer of x left its chunk statistics (for this group count)
+        ws = handed[1]
+        d.part_chunks = -(-x.S // 256)
+    else:
+        ws = _workspace(x.N, x.S, groups, x.t.device)
     d.workspace = ws.data_ptr()
+    nxt = None
+    if next_groups is not None and x.C % next_groups == 0 and x.C <= 2048:
+        nxt = torch.empty(int(_lib.lib().ipoke_groupnorm_workspace_floats(x.N, x.S, next_groups)), dtype=torch.float32, device=x.t.device)
+        d.next_part = nxt.data_ptr(); d.next_G = next_groups
     check(_lib.lib().ipoke_groupnorm(byref(d), ops._dt(dtype), _lib.current_stream()))
-    return CL(y, x.N, x.dhw, x.C)
+    out = CL(y, x.N, x.dhw, x.C)
+    if nxt is not None:
+        out.stats_part = (next_groups, nxt)
+    return out
 
 
 def add_act(a, b, dtype, act=_lib.ACT_NONE):

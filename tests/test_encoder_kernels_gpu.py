@@ -71,6 +71,32 @@ def test_groupnorm_residual_behind_the_activation(case, dtype):
     assert (pre - y).abs().max().item() > 0.1
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(4, 64, 80, 80, 16), (3, 256, 16, 16, 16), (2, 128, 33, 31, 8)], ids=["large", "small_one_launch", "ragged"])
+def test_groupnorm_hands_the_statistics_of_its_output_to_the_next_norm(case, dtype):
+    """ipoke_norm_desc.next_part / part_chunks: an InstanceNorm pass (with the residual behind its activation) leaves the chunk statistics
+    of its output; the SPADE norm that reads the output next skips its own statistics pass.  Same result as the stand-alone sequence up to
+    the order of the partial sums."""
+    N, C, H, W, G = case
+    gen = torch.Generator().manual_seed(C + H)
+    x = 2.0 * torch.randn(N, C, H, W, generator=gen) + 0.7
+    res = torch.randn(N, C, H, W, generator=gen)
+    mg, mb = 0.3 * torch.randn(N, C, H, W, generator=gen), 0.3 * torch.randn(N, C, H, W, generator=gen)
+    xc, rc = K.from_nchw(x.to(DEV), dtype), K.from_nchw(res.to(DEV), dtype)
+    mod = (K.from_nchw(mg.to(DEV), dtype), K.from_nchw(mb.to(DEV), dtype))
+    mid0 = K.group_norm(xc, C, dtype, act=_lib.ACT_RELU, res=rc, res_post=True)
+    mid1 = K.group_norm(xc, C, dtype, act=_lib.ACT_RELU, res=rc, res_post=True, next_groups=G)
+    assert torch.equal(mid0.t, mid1.t) and mid1.stats_part[0] == G
+    out0 = K.to_nchw(K.group_norm(mid0, G, dtype, mod=mod), dtype)
+    out1 = K.to_nchw(K.group_norm(mid1, G, dtype, mod=mod), dtype)
+    torch.cuda.synchronize()
+    err = (out0 - out1).abs().max().item()
+    print(f"handed statistics {case}[{dtype}]: max difference {err:.2e} (|out| <= {out0.abs().max().item():.2f})")
+    assert err <= (2e-5 if dtype == "f32" else 1.6e-2) * max(1.0, out0.abs().max().item())
+    other = K.group_norm(mid1, G // 2, dtype)                 # a norm of another group count ignores the hand-over
+    assert torch.isfinite(other.t.float()).all()
+
+
 def test_clip_to_cl4():
     gen = torch.Generator().manual_seed(3)
     B, T, H, W = 2, 3, 6, 10
