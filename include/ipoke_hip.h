@@ -616,6 +616,9 @@ typedef struct {
   int32_t dmod_summed;                   /* 1 (with 0 < mod_samples < N): dmod_gamma / dmod_beta hold mod_samples * S rows -- the SUM over the
                                             frames that share a modulation row, accumulated in fp32 in frame order and rounded once (no
                                             per-sample maps, no ipoke_sum_frames pass)                                              */
+  int32_t act_from_pre;                  /* 1: the forward pass was y = act(pre) + res (ipoke_norm_desc.res_post): act' is evaluated from the
+                                            pre-activation value recomputed from x and the statistics (y is not read); the residual's
+                                            gradient is dy itself (dres must be NULL); no SPADE modulation                            */
 } ipoke_norm_bwd_desc;
 /* float offset of the (mean, rstd) table inside the workspace ipoke_groupnorm / ipoke_groupnorm_stats just filled */
 int64_t ipoke_groupnorm_stats_offset(int N, int S, int G);

@@ -73,7 +73,8 @@ class NormBwdDesc(Structure):
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("act", c_int32), ("workspace", c_void_p), ("stats", c_void_p),
                 ("mod_samples", c_int32),
                 ("rs_scale", c_void_p), ("rs_scale_stride", c_int32), ("rs_rows_per_group", c_int64), ("rs_bias", c_void_p),
-                ("rs_dots", c_void_p), ("rs_dbias", c_void_p), ("rs_workspace", c_void_p), ("dmod_summed", c_int32)]
+                ("rs_dots", c_void_p), ("rs_dbias", c_void_p), ("rs_workspace", c_void_p), ("dmod_summed", c_int32),
+                ("act_from_pre", c_int32)]
 
 
 class GruDesc(Structure):

@@ -98,6 +98,16 @@ __device__ __forceinline__ float act_grad_from_out(int act, float y) {
     default: return 1.f;
   }
 }
+// derivative expressed through the pre-activation value f (the same function: act_grad_from_out(act, act_apply(act, f)))
+__device__ __forceinline__ float act_grad_from_pre(int act, float f) {
+  switch (act) {
+    case IPOKE_ACT_ELU: return f > 0.f ? 1.f : expm1f(f) + 1.f;
+    case IPOKE_ACT_RELU: return f > 0.f ? 1.f : 0.f;
+    case IPOKE_ACT_LRELU02: return f > 0.f ? 1.f : 0.2f;
+    case IPOKE_ACT_NONE: return 1.f;
+    default: return act_grad_from_out(act, act_apply(act, f));
+  }
+}
 
 // ---- kernel-argument prefetch ------------------------------------------------
 #ifndef IPK_KERNARG_PREFETCH

@@ -105,6 +105,7 @@ struct NormBwd {
   const float* gamma; const float* beta;
   const void* mod_gamma; int ld_mod; int mod_N;     // mod_N > 0: sample n reads the modulation rows of sample n % mod_N
   int act;
+  int act_from_pre;                    // 1: act' from the recomputed pre-activation value (forward: y = act(pre) + res, ipoke_norm_desc.res_post)
   float* part;                         // [N][nchunks][2][C]  (sum du, sum du*xhat)
   float* gsum;                         // [N][G][2]           (S1 = sum dxhat, S2 = sum dxhat*xhat)
   int nchunks, pos_per_block;
@@ -137,25 +138,32 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const NormBwd a) {
     const int groups = cvec - g0 < 256 ? cvec - g0 : 256;
     const int rp = 256 / groups;
     const int cg = g0 + threadIdx.x % groups, rr = threadIdx.x / groups;
-    float s1[E16], s2[E16], mean[E16], rstd[E16];
+    float s1[E16], s2[E16], mean[E16], rstd[E16], fsc[E16], fsh[E16];
 #pragma unroll
     for (int e = 0; e < E16; ++e) {
       s1[e] = 0.f; s2[e] = 0.f;
       const int g = (cg * E16 + e) / cpg;
       mean[e] = a.stats[((long)n * a.G + g) * 2]; rstd[e] = a.stats[((long)n * a.G + g) * 2 + 1];
+      fsc[e] = 0.f; fsh[e] = 0.f;
+      if (a.act_from_pre) {                 // the forward pass's own scale / shift (norm.hip gn_apply_kernel): pre = x * fsc + fsh
+        const float gm = a.gamma ? a.gamma[cg * E16 + e] : 1.f, bt = a.beta ? a.beta[cg * E16 + e] : 0.f;
+        fsc[e] = rstd[e] * gm; fsh[e] = bt - mean[e] * rstd[e] * gm;
+      }
     }
+    const bool need_y = a.act != IPOKE_ACT_NONE && !a.act_from_pre;
     if (rr < rp) {
       for (int p = p0 + rr; p < p1; p += rp) {
         const long m = (long)n * a.S + p;
         const frag_t gy = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.dy) + m * a.lddy + cg * E16);
         const frag_t xv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
         frag_t yv, mg;
-        if (a.act != IPOKE_ACT_NONE) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
+        if (need_y) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
         if (a.mod_gamma) mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + (mod_row0 + p) * a.ld_mod + cg * E16);
 #pragma unroll
         for (int e = 0; e < E16; ++e) {
           float du = ET<T>::to_f32(gy[e]);
-          if (a.act != IPOKE_ACT_NONE) du *= act_grad_from_out(a.act, ET<T>::to_f32(yv[e]));
+          if (need_y) du *= act_grad_from_out(a.act, ET<T>::to_f32(yv[e]));
+          else if (a.act_from_pre) du *= act_grad_from_pre(a.act, ET<T>::to_f32(xv[e]) * fsc[e] + fsh[e]);
           if (a.mod_gamma) du *= 1.f + ET<T>::to_f32(mg[e]);
           const float xh = (ET<T>::to_f32(xv[e]) - mean[e]) * rstd[e];
           s1[e] += du; s2[e] += du * xh;
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
   if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NormBwd)>();
   constexpr int E16 = ET<T>::E16;
   typedef typename ET<T>::frag frag_t;
-  extern __shared__ float lds[];            // [6][C]: mean, rstd, gamma, beta, S1/cnt, S2/cnt  (RS: + [256 * E16] column sums + [4])
+  extern __shared__ float lds[];            // [8][C]: mean, rstd, gamma, beta, S1/cnt, S2/cnt, forward scale, shift  (RS: + [256 * E16] column sums + [4])
   const int n = blockIdx.y, cpg = a.C / a.G, C = a.C;
   const long mod_row0 = (long)(a.mod_N > 0 ? n % a.mod_N : n) * a.S;
   const float inv_cnt = 1.f / ((float)a.S * cpg);
@@ -252,12 +260,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
     lds[c] = a.stats[((long)n * a.G + g) * 2]; lds[C + c] = a.stats[((long)n * a.G + g) * 2 + 1];
     lds[2 * C + c] = a.gamma ? a.gamma[c] : 1.f; lds[3 * C + c] = a.beta ? a.beta[c] : 0.f;
     lds[4 * C + c] = a.gsum[((long)n * a.G + g) * 2] * inv_cnt; lds[5 * C + c] = a.gsum[((long)n * a.G + g) * 2 + 1] * inv_cnt;
+    if (a.act_from_pre) {                   // the forward pass's own scale / shift (norm.hip gn_apply_kernel): pre = x * fsc + fsh
+      lds[6 * C + c] = lds[C + c] * lds[2 * C + c]; lds[7 * C + c] = lds[3 * C + c] - lds[c] * lds[C + c] * lds[2 * C + c];
+    }
   }
   __syncthreads();
   const int cvec = C / E16;
   const int ppb = RS ? a.rs_pos_per_block : a.pos_per_block;
   const int p0 = blockIdx.x * ppb, p1 = min(a.S, p0 + ppb);
-  float* sm = lds + 6 * C;
+  float* sm = lds + (a.act_from_pre ? 8 : 6) * C;
   float rs_sc = 0.f, dot = 0.f;
   float* cpart = nullptr;
   if (RS) {
@@ -280,14 +291,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const NormBwd a) {
       const frag_t gy = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.dy) + m * a.lddy + cg * E16);
       const frag_t xv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.x) + m * a.ldx + cg * E16);
       frag_t yv, mg;
-      if (a.act != IPOKE_ACT_NONE) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
+      const bool need_y = a.act != IPOKE_ACT_NONE && !a.act_from_pre;
+      if (need_y) yv = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.y) + m * a.ldy + cg * E16);
       if (a.mod_gamma) mg = *reinterpret_cast<const frag_t*>(reinterpret_cast<const T*>(a.mod_gamma) + (mod_row0 + p) * a.ld_mod + cg * E16);
       frag_t odx, odw, odmg;
 #pragma unroll
       for (int e = 0; e < E16; ++e) {
         const int c = cg * E16 + e;
         float dw = ET<T>::to_f32(gy[e]);
-        if (a.act != IPOKE_ACT_NONE) dw *= act_grad_from_out(a.act, ET<T>::to_f32(yv[e]));
+        if (need_y) dw *= act_grad_from_out(a.act, ET<T>::to_f32(yv[e]));
+        else if (a.act_from_pre) dw *= act_grad_from_pre(a.act, ET<T>::to_f32(xv[e]) * lds[6 * C + c] + lds[7 * C + c]);
         const float xh = (ET<T>::to_f32(xv[e]) - lds[c]) * lds[C + c];
         float du = dw;
         if (a.mod_gamma) {
@@ -574,6 +587,8 @@ extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void
   a.dx = d->dx; a.lddx = d->lddx; a.dres = d->dres; a.lddres = d->lddres; a.dmg = d->dmod_gamma; a.dmb = d->dmod_beta;
   a.ld_dmod = d->ld_dmod; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
   a.gamma = d->gamma; a.beta = d->beta; a.mod_gamma = d->mod_gamma; a.ld_mod = d->ld_mod; a.act = d->act;
+  a.act_from_pre = d->act_from_pre ? 1 : 0;
+  IPK_REQUIRE(!d->act_from_pre || (!d->mod_gamma && !d->dres), "act' from the pre-activation: un-modulated norms whose residual joined behind the activation (its gradient is dy)");
   a.mod_N = d->mod_samples > 0 && d->mod_samples < d->N ? d->mod_samples : 0;
   a.nchunks = (d->S + kNormBwdPos - 1) / kNormBwdPos; a.pos_per_block = kNormBwdPos;
   a.part = d->workspace + ipoke_groupnorm_workspace_floats(d->N, d->S, d->G);
@@ -585,7 +600,7 @@ extern "C" int ipoke_groupnorm_bwd(const ipoke_norm_bwd_desc* d, int dtype, void
   IPK_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(d->N + (d->dgamma ? (d->C + 15) / 16 : 0)), dim3(256), 0, s, a, d->dgamma, d->dbeta);
   IPK_LAUNCH_CHECK();
-  const size_t lds = (size_t)6 * d->C * sizeof(float);
+  const size_t lds = (size_t)(d->act_from_pre ? 8 : 6) * d->C * sizeof(float);
   if (d->dmod_summed && a.mod_N > 0) {
     IPK_REQUIRE(d->mod_gamma && !d->rs_scale && d->N % a.mod_N == 0 && d->C / e16 <= 256, "summed modulation gradients: whole frames of modulated samples");
     const int ppb = (16 / e16) * (256 / (d->C / e16));

@@ -733,7 +733,7 @@ class _NormFn(torch.autograd.Function):
             d.mod_gamma = mg_t.data_ptr(); d.mod_beta = mb_t.data_ptr(); d.ld_mod = mg_t.shape[1]
             d.mod_samples = int(meta.get("mod_samples", 0))        # > 0: the frames of a clip share its SPADE maps (batch ordered (frame, clip))
         if res_t is not None:
-            d.res = res_t.data_ptr(); d.ld_res = res_t.shape[1]
+            d.res = res_t.data_ptr(); d.ld_res = res_t.shape[1]; d.res_post = int(bool(meta.get("res_post", False)))
         d.act = meta["act"]
         ws = _workspace(_lib.lib().ipoke_groupnorm_workspace_floats(N, S, G), x_t.device, "norm")
         d.workspace = ws.data_ptr()
@@ -762,7 +762,11 @@ class _NormFn(torch.autograd.Function):
         d.N, d.S, d.C, d.G, d.eps = N, S, C, G, 1e-5
         d.act = m["act"]
         dres = dmg = dmb = dgamma = dbeta = None
-        if has_res:
+        if has_res and m.get("res_post", False):
+            # y = act(pre) + res: the residual's gradient is dy itself, act' comes from the pre-activation value recomputed from x (y is not read)
+            dres = dy
+            d.act_from_pre = 1
+        elif has_res:
             dres = torch.zeros_like(x_t) if x_t.shape[1] > C else torch.empty_like(x_t)
             d.dres = dres.data_ptr(); d.lddres = dres.shape[1]
         mod_n = int(m.get("mod_samples", 0)) if has_mod else 0
@@ -826,8 +830,9 @@ def _rowscale_producer(x, mod):
     return pm
 
 
-def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None, sole_reader=False):
-    meta = dict(N=x.N, S=x.S, C=x.C, G=groups, dtype=dtype, act=act)
+def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=None, mod=None, sole_reader=False, res_post=False):
+    """``res_post``: the residual joins behind the activation, y = act(norm(x)) + res."""
+    meta = dict(N=x.N, S=x.S, C=x.C, G=groups, dtype=dtype, act=act, res_post=bool(res_post) and res is not None)
     if sole_reader:
         meta["producer"] = _rowscale_producer(x, mod)
     if mod is not None and mod[0].N != x.N:       # frames of a clip decoded as one batch ordered (frame, clip): shared SPADE maps
@@ -838,11 +843,11 @@ def group_norm(x, groups, dtype, gamma=None, beta=None, act=_lib.ACT_NONE, res=N
     return K.CL(y, x.N, x.dhw, x.C)
 
 
-def norm(mod, x, dtype, act=_lib.ACT_NONE, res=None, sole_reader=False):
+def norm(mod, x, dtype, act=_lib.ACT_NONE, res=None, sole_reader=False, res_post=False):
     """``sole_reader``: ``x`` is a convolution's output that nothing but this norm reads (see _rowscale_producer)."""
     if mod.kind == "group":
-        return group_norm(x, mod.groups, dtype, mod.weight, mod.bias, act=act, res=res, sole_reader=sole_reader)
-    return group_norm(x, mod.groups, dtype, act=act, res=res, sole_reader=sole_reader)
+        return group_norm(x, mod.groups, dtype, mod.weight, mod.bias, act=act, res=res, sole_reader=sole_reader, res_post=res_post)
+    return group_norm(x, mod.groups, dtype, act=act, res=res, sole_reader=sole_reader, res_post=res_post)
 
 
 class _AddActFn(torch.autograd.Function):
@@ -1165,8 +1170,19 @@ def convT_block(blk, x, dtype, pit=False, frames=None):
     return norm(blk.norm, conv(blk.conv, x, dtype, w=w), dtype, act=blk.act, sole_reader=True)
 
 
+_RES_POST = os.environ.get("IPOKE_NO_RES_POST", "0") != "1"         # developer A/B: ResBlock's sum as its own element-wise pass
+
+
 def res_block(blk, x, dtype, pit=False, frames=None):
     first = convT_block if isinstance(blk.conv1, FS.Conv2dTransposeBlock) else conv_block
+    rc = blk.res_conv if blk.convolve_res else None
+    if _RES_POST and rc is not None and rc.norm is not None and blk.conv2.norm is None and blk.conv2.activation == "none":
+        # out = conv2(conv1(x)) + act(norm(res_conv(x))): the sum rides on the skip path's norm pass, forward (the residual joins behind
+        # the activation) and backward (its gradient is dy; act' from the recomputed pre-activation value, the saved output is not read)
+        y2 = conv_block(blk.conv2, first(blk.conv1, x, dtype, pit=pit, frames=frames), dtype, pit=pit, frames=frames)
+        w = effective_weight(rc.conv, pit, frames)
+        act = rc.act if isinstance(rc, FS.Conv2dTransposeBlock) else FS.ACT[rc.activation]
+        return norm(rc.norm, conv(rc.conv, x, dtype, w=w), dtype, act=act, res=y2, sole_reader=True, res_post=True)
     if blk.convolve_res:
         rfirst = convT_block if isinstance(blk.res_conv, FS.Conv2dTransposeBlock) else conv_block
         res = rfirst(blk.res_conv, x, dtype, pit=pit, frames=frames)

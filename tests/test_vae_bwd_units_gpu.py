@@ -59,6 +59,9 @@ CASES = [
     ("gn_elu", 2, 64, 8, 16, True, "elu", False, False),
     ("instnorm", 2, 16, 16, 0, False, "none", False, False),
     ("spade", 2, 32, 16, 16, False, "none", False, True),
+    # the residual joins BEHIND the activation (ipoke_norm_desc.res_post; backward: act' from the recomputed pre-activation value)
+    ("post_inst_relu", 3, 64, 24, 0, False, "relu", True, False),
+    ("post_group_elu", 2, 32, 16, 16, True, "elu", True, False),
 ]
 
 
@@ -77,9 +80,12 @@ def test_groupnorm_backward_vs_autograd(case, dtype):
     y = F.group_norm(x, groups, gamma if affine else None, beta if affine else None, eps=1e-5)
     if spade:
         y = y * (1 + mg) + mb
-    if use_res:
+    post = name.startswith("post_")
+    if use_res and not post:
         y = y + res
     y = {"relu": torch.relu, "elu": F.elu, "none": lambda v: v}[act](y)
+    if use_res and post:
+        y = y + res
     dy = torch.randn(y.shape, generator=gen)
     y.backward(dy)
 
@@ -94,7 +100,7 @@ def test_groupnorm_backward_vs_autograd(case, dtype):
     if spade:
         mod = (_cl(mg.detach(), dtype), _cl(mb.detach(), dtype))
         mod[0].t.requires_grad_(True); mod[1].t.requires_grad_(True)
-    out = FT.group_norm(xc, groups, dtype, g_d, b_d, act=actc, res=rc, mod=mod)
+    out = FT.group_norm(xc, groups, dtype, g_d, b_d, act=actc, res=rc, mod=mod, res_post=post)
     tol = TOL[dtype]
     assert _rel(_nchw(out, dtype).detach(), y.detach()) <= tol
     out.t.backward(_cl(dy, dtype).t)
