@@ -548,7 +548,8 @@ extern "C" int ipoke_colsum(const void* src, int ld, int64_t M, int C, int src_f
   return IPOKE_OK;
 }
 
-static const int kNormBwdPos = 128;
+// positions per workgroup of the two passes (IPOKE_NORM_BWD_POS: developer A/B)
+static const int kNormBwdPos = getenv("IPOKE_NORM_BWD_POS") ? atoi(getenv("IPOKE_NORM_BWD_POS")) : 128;
 static const int kNormRsPos = 512;          // positions per block of the pass that folds ipoke_rowscale_bwd in (that kernel's own block size)
 extern "C" int64_t ipoke_groupnorm_bwd_rs_workspace_floats(int N, int S, int C) {
   return (int64_t)N * ((S + kNormRsPos - 1) / kNormRsPos) * (C + 1);
