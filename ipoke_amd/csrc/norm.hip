@@ -577,10 +577,17 @@ extern "C" int ipoke_groupnorm(const ipoke_norm_desc* d, int dtype, void* stream
     static const bool fused_on = !(getenv("IPOKE_GN_FUSED") && atoi(getenv("IPOKE_GN_FUSED")) == 0);
     const int cpg = d->C / d->G, esz = dtype == IPOKE_BF16 ? 2 : 4;
     int unit = cpg; while (unit % e16) unit += cpg;                    // lcm(cpg, e16)
-    int CS = unit; while (CS < 32 && d->C % (CS + unit) == 0 && CS + unit <= d->C) CS += unit;
+    // Round 6: a LARGE tensor (>= 32 MB: the decoder's InstanceNorms over all frames of a batch) only takes this path with whole 128-byte
+    // row segments and a tile small enough for four workgroups per CU.  The rule above gave the 64 x 64 x 128 InstanceNorm slabs of 16
+    // channels -- 32 of every 128 bytes fetched used, one 128 KB workgroup per CU: 662 us for 503 MB at N = 480, where the statistics and
+    // apply passes take 90 + 190 us (scripts/r6/probe_norm.py); 280 vs 45 + 100 us at 32 x 32 x 256.
+    const bool large = (int64_t)d->N * d->S * d->C * esz >= ((int64_t)32 << 20);
+    const int want_ch = large ? 128 / esz : 32;
+    int CS = unit; while (CS < want_ch && d->C % (CS + unit) == 0 && CS + unit <= d->C) CS += unit;
     while (d->C % CS) CS += unit;
     const size_t tile = (size_t)d->S * CS * esz;
-    if (fused_on && !d->y_f32 && !d->mod_gamma && CS <= 2048 && CS / e16 <= 256 && tile <= 128 * 1024 && d->ldy % e16 == 0 &&
+    const bool shape_ok = large ? (CS * esz >= 128 && tile <= 32 * 1024) : tile <= 128 * 1024;
+    if (fused_on && !d->y_f32 && !d->mod_gamma && CS <= 2048 && CS / e16 <= 256 && shape_ok && d->ldy % e16 == 0 &&
         (!d->res || d->ld_res % e16 == 0)) {
       NormApply a;
       a.x = d->x; a.ldx = d->ldx; a.y = d->y; a.ldy = d->ldy; a.y_f32 = 0; a.N = d->N; a.S = d->S; a.C = d->C; a.G = d->G;
