@@ -396,6 +396,10 @@ def test_norm_backward_sums_the_shared_modulation_gradients_over_the_frames(case
     mean = x64.mean(dim=(1, 3), keepdim=True)
     var = x64.var(dim=(1, 3), unbiased=False, keepdim=True)
     xh = ((x64 - mean) / torch.sqrt(var + 1e-5)).view(frames, clips * S, C)
+    # the forward pass over the shared maps (the frame-walking apply kernel): y = xhat * (1 + mod_gamma) + mod_beta
+    want_y = xh * (1 + mg.double().view(1, clips * S, C)) + mb.double().view(1, clips * S, C)
+    e_y = ((y.double().view(frames, clips * S, C) - want_y).abs().max() / want_y.abs().max()).item()
+    assert e_y <= (2e-5 if dtype == "f32" else 6e-3), e_y
     dw = dy.double().view(frames, clips * S, C)
     want_g, want_b = (dw * xh).sum(0), dw.sum(0)
     e = lambda got, want: ((got.double() - want).abs().max() / want.abs().max()).item()
