@@ -180,6 +180,7 @@ KERNEL_FAMILIES = {      # in-situ timing tags (include/ipoke_hip.h) -> what the
     19: "conv3x3_halo (3x3, halo-staged 8x16 patches)",
     20: "conv3x3_halo16 (3x3 / 3x3x3 wide layers, halo-staged 16x16 patches x 128 channels)",
     21: "conv3x3_c64 (<= 64 output channels, filter resident in LDS, persistent workgroups)",
+    22: "conv3x3_k8 (one 16-byte chunk of input channels: the data gradient of the decoder's last convolution; nothing staged)",
     32: "igemm_tn / igemm_tn_glds weight gradients (split-M slabs)",
 }
 

@@ -19,7 +19,7 @@ int ipoke_conv_forward_repeat(const ipoke_conv_desc* d, int dtype, int n, void* 
  * environment once per process -- no getenv on the launch path. */
 int ipoke_set_dispatch_override(const char* name, int value);
 /* Test hook: the kernel family the calling thread's last ipoke_conv_forward was dispatched to */
-enum { IPOKE_KERNEL_NONE = 0, IPOKE_KERNEL_IGEMM = 1, IPOKE_KERNEL_S8 = 2, IPOKE_KERNEL_HALO = 3, IPOKE_KERNEL_HALO16 = 4, IPOKE_KERNEL_C64 = 5 };
+enum { IPOKE_KERNEL_NONE = 0, IPOKE_KERNEL_IGEMM = 1, IPOKE_KERNEL_S8 = 2, IPOKE_KERNEL_HALO = 3, IPOKE_KERNEL_HALO16 = 4, IPOKE_KERNEL_C64 = 5, IPOKE_KERNEL_K8 = 6 };
 int ipoke_last_conv_kernel(void);
 
 /* developer probe (IPOKE_SIDE_DELAY_US): one wave spinning for about `us` microseconds on `stream` */

@@ -363,7 +363,7 @@ def require_gpu():
 import contextlib
 
 
-KERNEL_NONE, KERNEL_IGEMM, KERNEL_S8, KERNEL_HALO, KERNEL_HALO16, KERNEL_C64 = range(6)       # ipoke_last_conv_kernel
+KERNEL_NONE, KERNEL_IGEMM, KERNEL_S8, KERNEL_HALO, KERNEL_HALO16, KERNEL_C64, KERNEL_K8 = range(7)       # ipoke_last_conv_kernel
 
 
 @contextlib.contextmanager

@@ -2725,6 +2725,103 @@ static int launch_nt(NtParams& p, hipStream_t s) {
   return IPOKE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// conv3x3_k8 (round 6): 3x3 / stride 1 / 'same' convolution (direct or transposed) whose INPUT is one 16-byte chunk of channels per
+// pixel (Kc = 8, bf16) and whose output has <= 64 channels -- the data gradient of the decoder's last convolution (64 -> 3 channels at
+// 128 x 128, util.py Conv2dBlock `out_conv`): 4.9 M output rows x 64 channels from a gradient of 3 (padded to 8) channels.  As an implicit
+// GEMM it is K = 72 in two 64-wide K blocks per 64-row tile: 76 800 workgroups that each stage 18 KB through LDS for 9 MFLOP, 1.04 ms for
+// 629 MB written (45 TFLOP/s).  Here nothing is staged: a wave owns 16 consecutive pixels of an image row; the fragment of a matrix-core
+// K step is FOUR TAPS -- lane group g holds the 8 channels of tap 4 ks + g, i.e. ONE 16-byte load of the gradient at the shifted pixel
+// (zero outside the image and for the three taps beyond the ninth) -- the whole filter (9 taps x 8 channels x 64 outputs = 9 KB) lives in
+// 48 registers per lane, and with the operand roles of mma64 a lane ends up with four consecutive output channels of its pixel: 8-byte
+// stores.  Persistent waves, the next group's three loads in flight under the twelve matrix-core instructions of the current one.
+__global__ __launch_bounds__(256) void conv3x3_k8_kernel(const NtParams p) {
+  if (IPK_KERNARG_PREFETCH) kernarg_prefetch<(int)sizeof(NtParams)>();
+  const GeomDev& g = p.g;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m16 = lane & 15, kg = lane >> 4;
+  const int nt = p.Nout >> 4;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W);
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + p.a_coff;
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + p.c_coff;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 wf[3][4];
+  int dy[3], dx[3];
+  bool tv[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int tap = 4 * ks + kg;
+    tv[ks] = tap < 9;
+    const int a = tap / 3, b = tap - 3 * a;
+    dy[ks] = g.transposed ? g.ph - a : a - g.ph;
+    dx[ks] = g.transposed ? g.pw - b : b - g.pw;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      wf[ks][t] = (tv[ks] && t < nt) ? *reinterpret_cast<const bf16x8*>(W + (long)(16 * t + m16) * p.ldw + tap * 8) : zero;
+  }
+  const int ngroups = g.M >> 4;
+  const int stride = (int)gridDim.x * 4;
+  auto gather = [&](int grp, bf16x8 (&fa)[3]) {
+    const int m = grp * 16 + m16;
+    const int ox = m & (g.Wo - 1), oy = (m >> g.lWo) & (g.Ho - 1), n = m >> (g.lWo + g.lHo);
+    const bf16_t* img = A + (long)n * p.a_sn;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int iy = oy + dy[ks], ix = ox + dx[ks];
+      const bool ok = tv[ks] && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+      fa[ks] = ok ? *reinterpret_cast<const bf16x8*>(img + (long)iy * p.a_sh + (long)ix * p.a_sw) : zero;
+    }
+  };
+  int grp = (int)blockIdx.x * 4 + wave;
+  if (grp >= ngroups) return;
+  bf16x8 cur[3], nxt[3];
+  gather(grp, cur);
+  for (; grp < ngroups; grp += stride) {
+    const bool more = grp + stride < ngroups;
+    if (more) gather(grp + stride, nxt);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < nt) mma64(cur[ks], wf[ks][t], acc[t]);
+    bf16_t* row = C + (long)(grp * 16 + m16) * p.ldc + 4 * kg;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < nt) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+        bf16x4_t o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (bf16_t)acc[t][q];
+        *reinterpret_cast<bf16x4_t*>(row + 16 * t) = o;
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) cur[ks] = nxt[ks];
+    }
+  }
+}
+static bool k8_applicable(const NtParams& p) {
+  static const int on = getenv("IPOKE_K8") ? atoi(getenv("IPOKE_K8")) : 1;      // developer A/B: 0 keeps the implicit GEMM
+  const GeomDev& g = p.g;
+  return on && !p.a_f32 && !p.c_f32 && !p.c_acc && p.splitk == 1 && !p.dact && !p.bias && p.act == IPOKE_ACT_NONE && !p.row_scale && !p.c_scatter &&
+         !p.w_kmajor && g.taps == 9 && g.khw == 9 && g.kw == 3 && g.Di == 1 && g.Do == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 &&
+         g.ph == 1 && g.pw == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.pow2 && (g.Wo & 15) == 0 && p.Kc == 8 && p.a_sc == 1 && (p.Nout & 15) == 0 &&
+         p.Nout <= 64 && (p.a_coff & 7) == 0 && ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 && p.ldw >= 72 && (p.ldw & 7) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.W) & 15) == 0 && p.c_cstride == 1 && (p.c_coff & 3) == 0 && (p.ldc & 3) == 0 && (g.M & 15) == 0 &&
+         g.M >= 65536 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 7) == 0;
+}
+static int launch_conv3x3_k8(NtParams& p, hipStream_t s) {
+  const int groups = p.g.M >> 4;
+  const int blocks = std::min((groups + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(conv3x3_k8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  IPK_LAUNCH_CHECK();
+  return IPOKE_OK;
+}
+
 static bool k64_applicable(const NtParams& p) {
   static const int on = getenv("IPOKE_K64") ? atoi(getenv("IPOKE_K64")) : 1;      // developer A/B: 0 keeps the implicit GEMM
   const GeomDev& g = p.g;
@@ -2887,6 +2984,7 @@ static int dispatch_nt(NtParams& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (s8_applicable(p)) { g_last_kernel = IPOKE_KERNEL_S8; return launch_conv3x3_s8(p, s); }
     if (k64_applicable(p)) { g_last_kernel = IPOKE_KERNEL_S8; return launch_conv3x3_k64(p, s); }      // (same family tag: stationary input on the 8x8 latent)
+    if (k8_applicable(p)) { g_last_kernel = IPOKE_KERNEL_K8; return launch_conv3x3_k8(p, s); }
     if (c64_applicable(p)) { g_last_kernel = IPOKE_KERNEL_C64; return launch_conv3x3_c64(p, s); }
     if (halo16_applicable(p)) { g_last_kernel = IPOKE_KERNEL_HALO16; return launch_conv3x3_halo16(p, s); }
     if (halo_applicable(p)) { g_last_kernel = IPOKE_KERNEL_HALO; return launch_conv3x3_halo(p, s); }

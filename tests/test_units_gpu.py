@@ -228,6 +228,40 @@ def test_conv_weight_operand_as_a_column_slice_is_not_over_read(dtype):
     assert (got - ref).abs().max().item() <= TOLS[dtype] * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,transposed", [(6, 128, 128, 3, 64, True), (5, 128, 128, 8, 48, False), (9, 64, 128, 5, 16, True),
+                                                       (17, 64, 64, 3, 64, True)])
+def test_conv3x3_one_chunk_input(N, H, W, Cin, Cout, transposed):
+    """conv3x3_k8 (round 6): 3x3 / stride 1 / 'same' with ONE 16-byte chunk of input channels and <= 64 outputs, nothing staged -- the data
+    gradient of the decoder's last convolution (util.py Conv2dBlock out_conv: 64 -> 3 channels, its gradient 3 (padded to 8) -> 64) --
+    against torch, direct and transposed (channels beyond the real ones are zero padding, as the interface demands of dtype activations)."""
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(N + H + Cin + Cout)
+    M = N * H * W
+    x = torch.randn(N, Cin, H, W, generator=gen)
+    if transposed:
+        w = torch.randn(Cin, Cout, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+        ref = F.conv_transpose2d(x.bfloat16().float(), w.bfloat16().float(), None, padding=1)
+        wop = shadow_nt(w.transpose(0, 1).contiguous().unsqueeze(2).to(DEV), 8, dtype="bf16")
+    else:
+        w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+        ref = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), None, padding=1)
+        wop = shadow_nt(w.unsqueeze(2).to(DEV), 8, dtype="bf16")
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    xa = torch.zeros(M, 8, dtype=torch.bfloat16, device=DEV)
+    xa[:, :Cin] = x.permute(0, 2, 3, 1).reshape(M, Cin).to(DEV).bfloat16()
+    d = ops.conv_desc(N, (1, H, W), (1, H, W), (1, 3, 3), (1, 1, 1), (0, 1, 1), transposed)
+    d.A = xa.data_ptr(); d.a_sn = H * W * 8; d.a_sd = 0; d.a_sh = W * 8; d.a_sw = 8; d.a_sc = 1; d.Kc_real = 8; d.Kc = 8
+    out = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    d.W = wop.data_ptr(); d.ldw = wop.shape[1]; d.Nout = Cout
+    d.C = out.data_ptr(); d.c_f32 = 0; d.ldc = Cout
+    ops.conv_forward(d, "bf16")
+    torch.cuda.synchronize()
+    assert L.ipoke_last_conv_kernel() == _lib.KERNEL_K8
+    err = (out.float().cpu() - ref).abs().max().item()
+    print(f"one-chunk 3x3 N={N} {H}x{W} {Cin}->{Cout} transposed={transposed}: max err {err:.3e} (ref max {ref.abs().max():.2f})")
+    assert torch.isfinite(out.float()).all() and err <= 1e-2 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("B,Cin,Cout", [(20, 32, 2048), (3, 8, 256), (5, 24, 384), (4, 64, 512), (7, 40, 2048), (1, 16, 256)])
 def test_conv3x3_narrow_input_stationary(B, Cin, Cout):
     """conv3x3_k64 (round 6): 3x3 on the 8x8 latent with a narrow dense input (<= 64 channels) and a wide output -- conv1 of
