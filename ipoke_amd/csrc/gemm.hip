@@ -2149,7 +2149,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else { kd_lo = max(0, 1 - dz * g.sd); kd_hi = min(2, g.Di - dz * g.sd); }
   }
   const int kdn = kd_hi - kd_lo + 1;
-  const int nch = (p.Kc >> 6) * kdn, nkb = nch * 9;
+  // taps per (chunk, depth tap): the 3 x 3 window, or the 2 x 2 window without padding of the four-tap sub-pixel phase of a stride-2
+  // ConvTranspose2d (round 6: kh = kw = 2, ph = pw = 0, scattered output rows; offsets 0 / +1 lie inside the one-pixel halo)
+  const int ntap = g.khw, tlast = ntap - 1;
+  const int nch = (p.Kc >> 6) * kdn, nkb = nch * ntap;
   const int sgn = g.transposed ? -1 : 1;
 
   const T* Abase = reinterpret_cast<const T*>(p.A);
@@ -2172,7 +2175,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // filter K-block wi_g = (virtual chunk, tap): element offset w_off = (kd * 9 + tap) * Kc + chunk * 64, kept incrementally
   int wi_g = 0, wi_t = 0, wi_kd = 0, wi_ch = 0;
-  const long w_off0 = (long)kd_lo * 9 * p.Kc;
+  const long w_off0 = (long)kd_lo * ntap * p.Kc;
   long w_off = w_off0;
   auto issue_w = [&]() {
     const bool in = wi_g < nkb;
@@ -2184,7 +2187,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
     }
     ++wi_g;
-    const bool tap_wrap = wi_t == 8, kd_wrap = tap_wrap && wi_kd + 1 == kdn;
+    const bool tap_wrap = wi_t == tlast, kd_wrap = tap_wrap && wi_kd + 1 == kdn;
     wi_t = tap_wrap ? 0 : wi_t + 1;
     wi_kd = kd_wrap ? 0 : (tap_wrap ? wi_kd + 1 : wi_kd);
     wi_ch = kd_wrap ? wi_ch + 1 : wi_ch;
@@ -2223,9 +2226,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto read_frags = [&](frag_t (&fa)[2][MREP], frag_t (&fb)[2][NREP], int kb, int ci_, int t_) {
     const unsigned char* ab = abuf + (ci_ & 1) * ABUF;
     const unsigned char* wb = ring + (kb % R) * WSLOT;
-    const int th = t_ / 3, tw = t_ - 3 * th;
+    const int th = g.kw == 3 ? t_ / 3 : t_ >> 1, tw = t_ - g.kw * th;
     // halo row of output pixel (wm*4 + i, lane & 15) under this tap
-    const int sr0 = (wm * 4 + 1 + sgn * (th - 1)) * HW + (lane & 15) + 1 + sgn * (tw - 1);
+    const int sr0 = (wm * 4 + 1 + sgn * (th - g.ph)) * HW + (lane & 15) + 1 + sgn * (tw - g.pw);
 #pragma unroll
     for (int hs = 0; hs < 2; ++hs) {
 #pragma unroll
@@ -2259,7 +2262,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto round = [&](int r, frag_t (&fa_cur)[2][MREP], frag_t (&fb_cur)[2][NREP], frag_t (&fa_nxt)[2][MREP], frag_t (&fb_nxt)[2][NREP]) {
     if (t == 1 || t == 2) wait_vmcnt<A_IT + W_IT>(); else wait_vmcnt<W_IT>();
     __builtin_amdgcn_s_barrier();
-    const int tn = t == 8 ? 0 : t + 1, cn = t == 8 ? ci + 1 : ci;
+    const int tn = t == tlast ? 0 : t + 1, cn = t == tlast ? ci + 1 : ci;
 #if IPOKE_H16_ABL != 2
     read_frags(fa_nxt, fb_nxt, r + 1, cn, tn);      // (past the last K-block: stale LDS contents, never multiplied)
 #if IPOKE_H16_ABL == 1
@@ -2310,13 +2313,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < NREP; ++j) *reinterpret_cast<f32x4*>(st + i * 16 * EP + j * 64) = acc[i][j];
   }
   __syncthreads();
-  const long mbase = ((long)slice * g.Ho + y0) * g.Wo + x0;
+  const long mbase = p.c_scatter ? p.c_row0 + (long)img * p.c_sn + (long)y0 * p.c_sh + (long)x0 * p.c_sw : ((long)slice * g.Ho + y0) * g.Wo + x0;
+  const long m_sh = p.c_scatter ? p.c_sh : g.Wo, m_sw = p.c_scatter ? p.c_sw : 1;
   const bool vec_ok = (p.Nout & 3) == 0;
   const float img_scale = image_scale(p, img);
   constexpr int G4 = BN / 4;
   for (int idx = tid; idx < BM * G4; idx += NTHR) {
     const int row = idx / G4, c4 = idx - row * G4;
-    const long m = mbase + (long)(row >> 4) * g.Wo + (row & 15);
+    const long m = mbase + (long)(row >> 4) * m_sh + (long)(row & 15) * m_sw;
     const int n = n0 + 4 * c4;
     if (n >= p.n_pad) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * EP + c4 * 16);
@@ -2598,11 +2602,16 @@ static int launch_conv3x3_c64(NtParams& p, hipStream_t s) {
 static bool halo16_applicable(const NtParams& p) {
   const int mode = dispatch_mode(g_halo16_mode, "IPOKE_HALO16");
   const GeomDev& g = p.g;
-  if (!mode || p.a_f32 || p.c_scatter || !(g.taps == 9 || g.taps == 27) || g.khw != 9 || g.kw != 3) return false;
-  const bool flat = g.taps == 9 && g.Di == 1 && g.Do == 1 && g.pd == 0 && g.sd == 1;
-  const bool deep = g.taps == 27 && g.pd == 1 && (p.a_sd & 7) == 0 && (g.sd == 1 ? g.Di == g.Do : (!g.transposed && g.sd == 2));
+  // the four-tap sub-pixel phase of a stride-2 ConvTranspose2d (2 x 2 window, no padding, scattered output rows; IPOKE_HALO16_PHASE=0: developer A/B)
+  static const bool phase_on = !(getenv("IPOKE_HALO16_PHASE") && atoi(getenv("IPOKE_HALO16_PHASE")) == 0);
+  const bool phase4 = phase_on && g.taps == 4 && g.khw == 4 && g.kw == 2 && g.ph == 0 && g.pw == 0 && !g.transposed && g.Di == 1 && g.Do == 1 && g.pd == 0 &&
+                      g.sd == 1 && p.c_scatter && !p.dact;
+  if (!mode || p.a_f32) return false;
+  if (!phase4 && (p.c_scatter || !(g.taps == 9 || g.taps == 27) || g.khw != 9 || g.kw != 3)) return false;
+  const bool flat = phase4 || (g.taps == 9 && g.Di == 1 && g.Do == 1 && g.pd == 0 && g.sd == 1);
+  const bool deep = !phase4 && g.taps == 27 && g.pd == 1 && (p.a_sd & 7) == 0 && (g.sd == 1 ? g.Di == g.Do : (!g.transposed && g.sd == 2));
   if (!(flat || deep)) return false;
-  const bool can = g.Hi == g.Ho && g.Wi == g.Wo && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
+  const bool can = g.Hi == g.Ho && g.Wi == g.Wo && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.sh == 1 && g.sw == 1 && (phase4 || (g.ph == 1 && g.pw == 1)) &&
                    p.Kc % 64 == 0 && p.Kc_real == p.Kc && (p.a_coff & 7) == 0 && p.ldw >= p.Ktot && p.splitk == 1 && !p.c_acc &&
                    ((p.a_sn | p.a_sh | p.a_sw) & 7) == 0 &&
                    (long)(g.M / g.S) * p.a_sn + (long)g.Di * p.a_sd + (long)g.Hi * p.a_sh + p.Kc < (1L << 31) && (long)p.Nout * p.ldw < (1L << 31);

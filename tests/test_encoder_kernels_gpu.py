@@ -138,6 +138,33 @@ def test_folded_stem_matches_conv3d(dtype, monkeypatch):
     assert (a - b).abs().max().item() <= tol * scale
 
 
+@pytest.mark.parametrize("N,H,W,cin,cout,snorm", [(3, 32, 32, 256, 128, True), (2, 16, 48, 128, 256, False), (5, 16, 16, 64, 160, True)])
+def test_conv_transpose_four_tap_phase_on_the_halo_staged_kernel(N, H, W, cin, cout, snorm, request):
+    """The four-tap sub-pixel phase (output pixels (2i + 1, 2j + 1): a 2 x 2 window without padding, scattered rows) of a stride-2
+    ConvTranspose2d with a WIDE output runs on conv3x3_halo16 (round 6): the window's offsets 0 / +1 lie inside the staged patch's halo.
+    Forced onto that kernel (the dispatch rule wants >= 256 workgroups), against torch and against the one-launch 9-tap form; the other
+    three phases of the same call keep their kernels."""
+    dtype = "bf16"
+    _lib.check(_lib.lib().ipoke_set_dispatch_override(b"halo16", 2))
+    request.addfinalizer(lambda: _lib.lib().ipoke_set_dispatch_override(b"halo16", -1))
+    torch.manual_seed(H * W + cin)
+    mod = FS._Conv(cin, cout, 3, 2, 1, transposed=True, snorm=snorm).to(DEV)
+    with torch.no_grad():
+        mod.bias.copy_(0.1 * torch.randn(cout))
+    x = torch.randn(N, cin, H, W)
+    xc = K.from_nchw(x.to(DEV), dtype)
+    xr = K.to_nchw(xc, dtype).cpu()
+    w = (mod.weight_orig / K.spectral_sigma(mod.weight_orig, mod.weight_u, mod.weight_v, True) if snorm else mod.weight).detach().cpu()
+    w = w.bfloat16().float()
+    ref = F.elu(F.conv_transpose2d(xr, w, mod.bias.detach().cpu(), stride=2, padding=1, output_padding=1))
+    got = mod.run(xc, dtype, act=_lib.ACT_ELU)                 # the (1, 1) phase is the last launch of the call
+    assert _lib.lib().ipoke_last_conv_kernel() == _lib.KERNEL_HALO16
+    a = K.to_nchw(got, dtype).cpu()
+    tol = 2e-2 * max(1.0, ref.abs().max().item())
+    assert (a - ref).abs().max().item() <= tol
+    assert (a[:, :, 1::2, 1::2] - ref[:, :, 1::2, 1::2]).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("N,H,W,cin,cout,snorm", [(2, 8, 8, 32, 24, False), (3, 16, 32, 64, 64, True), (1, 5, 7, 16, 40, False),
                                                   (2, 16, 48, 128, 64, True), (1, 32, 16, 128, 20, False)])
