@@ -105,10 +105,17 @@ class _Conv(_Cached):
                 w = self.weight_orig / K.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, True) if self.snorm else self.weight
                 wr = w.detach().transpose(0, 1)                                  # [cout, cin, kh, kw]
                 ops_ = {}
+                # wide layers (>= 128 input channels, >= 96 outputs): the two-tap phases as 2 x 2 windows with a zero row / column, so
+                # that they run on the halo-staged kernel like the four-tap phase (twice the multiplications at 2.4x the rate)
+                pad2 = _PHASE_PAD and self.cin >= 128 and self.cout >= 96 and ops._dt(dtype) == _lib.BF16
                 for a in (0, 1):
                     for b in (0, 1):
                         wp = wr[:, :, list(self._PHASE_TAPS[a])][:, :, :, list(self._PHASE_TAPS[b])].contiguous()
-                        ops_[(a, b)] = K.weight_operand(wp.unsqueeze(2), dtype)
+                        if pad2 and a + b == 1:
+                            full = torch.zeros(wp.shape[0], wp.shape[1], 2, 2, dtype=wp.dtype, device=wp.device)
+                            full[:, :, :1 + a, :1 + b] = wp
+                            wp = full
+                        ops_[(a, b)] = K.weight_operand(wp.unsqueeze(2), dtype) + ((wp.shape[2], wp.shape[3]),)
                 c[key] = (ops_, None if self.bias is None else self.bias.detach().float().contiguous())
         return c[key]
 
@@ -118,8 +125,8 @@ class _Conv(_Cached):
         Ho, Wo = 2 * Hi, 2 * Wi
         ldc = self.cout if out_f32 else K.round_up(self.cout, K.e16(dtype))
         y = torch.empty(N * Ho * Wo, ldc, dtype=torch.float32 if out_f32 else ops.torch_dtype(dtype), device=x.t.device)
-        for (a, bb), (wop, kc) in ops_.items():
-            K.conv(x, wop, kc, self.cout, (1, 1 + a, 1 + bb), (1, 1, 1), (0, 0, 0), dtype, bias=b, act=act, out_f32=out_f32, out=y,
+        for (a, bb), (wop, kc, (kh, kw)) in ops_.items():
+            K.conv(x, wop, kc, self.cout, (1, kh, kw), (1, 1, 1), (0, 0, 0), dtype, bias=b, act=act, out_f32=out_f32, out=y,
                    odhw=(1, Hi, Wi), scatter=(Ho * Wo, 2 * Wo, 2, a * Wo + bb))
         return K.CL(y, N, (1, Ho, Wo), self.cout)
 
@@ -159,6 +166,7 @@ class _Norm(nn.Module):
         return K.group_norm(x, self.groups, dtype, act=act, res=res, res_post=res_post, next_groups=next_groups)
 
 
+_PHASE_PAD = os.environ.get("IPOKE_NO_PHASE_PAD", "0") != "1"        # developer A/B: two-tap phases of wide up-convolutions as they are
 _RES_POST = os.environ.get("IPOKE_NO_RES_POST", "0") != "1"         # developer A/B: ResBlock's sum as its own element-wise pass
 _NEXT_STATS = os.environ.get("IPOKE_NO_NEXT_STATS", "0") != "1"     # developer A/B: the SPADE norm makes its own statistics pass
 _STEM_FOLD = os.environ.get("IPOKE_NO_STEM_FOLD", "0") != "1"      # developer A/B: conv1 of the 3-D encoder read in place
